@@ -1,0 +1,79 @@
+"""ctypes binding of the C-ABI in include/dgp_hip.h.  No fallback: if the HIP library is
+missing (or was not built) importing the engine raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdgp_hip.so")
+
+
+class DgpNetDesc(C.Structure):
+    _fields_ = [("depth", C.c_int32), ("num_joints", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32),
+                ("max_batch", C.c_int32), ("with_locref", C.c_int32), ("mean_pixel", C.c_float * 3),
+                ("bn_eps", C.c_float)]
+
+
+class DgpTensorView(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("ndim", C.c_int32),
+                ("shape", C.c_int64 * 4)]
+
+
+class DgpConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "N", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "rate", "pad_t", "pad_l", "Ho", "Wo", "relu",
+        "res_stride", "res_H", "res_W")]
+
+
+# every symbol include/dgp_hip.h declares: name -> (restype, argtypes)
+_vp, _i32, _f32, _sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
+SYMBOLS = {
+    "dgp_version": (C.c_int, []),
+    "dgp_last_error": (C.c_char_p, []),
+    "dgp_net_create": (C.c_int, [C.POINTER(DgpNetDesc), C.POINTER(_vp)]),
+    "dgp_net_destroy": (None, [_vp]),
+    "dgp_net_load_weights": (C.c_int, [_vp, C.POINTER(DgpTensorView), _i32]),
+    "dgp_net_workspace_bytes": (C.c_int, [_vp, _i32, C.POINTER(_sz)]),
+    "dgp_net_output_dims": (C.c_int, [_vp] + [C.POINTER(_i32)] * 4),
+    "dgp_net_stats": (C.c_int, [_vp, _i32, C.POINTER(_i32), C.POINTER(C.c_double)]),
+    "dgp_forward": (C.c_int, [_vp, _vp, _i32, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "dgp_soft_argmax": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "dgp_hard_argmax": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "dgp_infer": (C.c_int, [_vp, _vp, _i32, _vp, _sz, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "dgp_packed_weight_floats": (_sz, [_i32, _i32, _i32, _i32]),
+    "dgp_pack_conv_weights": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp]),
+    "dgp_conv2d": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dgp_maxpool_3x3s2_same": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "dgp_preprocess_u8": (C.c_int, [_vp, C.c_int64, C.POINTER(_f32), _vp, _vp]),
+}
+
+_lib = None
+
+
+class DgpError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libdgp_hip.so (once).  Raises if it is absent -- there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DgpError(
+            "libdgp_hip.so not found at %s -- build it with `python -m deepgraphpose_amd.build` "
+            "(hipcc --offload-arch=gfx950); deepgraphpose_amd has no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)     # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().dgp_last_error()
+        raise DgpError("%s failed (%d): %s" % (what or "dgp call", rc, (msg or b"").decode()))

@@ -1,0 +1,108 @@
+"""ResNet-v1 (TF-slim flavour) layer plan used by DeepLabCut / DGP.
+
+This is the architecture description of the hot path: a flat list of
+convolution layers with the exact TF-1.15 slim geometry, shared by the HIP
+engine (which mirrors it in C++, csrc/dgp_net.cpp) and by the CPU oracle.
+
+Reference semantics restated (slim is third-party and not vendored):
+  * PET/nnet/pose_net.py:36-54  -> resnet_v1_{50,101}(global_pool=False,
+    output_stride=16, is_training=False)
+  * slim resnet_v1: root conv2d_same(64, 7, stride 2) + max_pool2d(3, 2, SAME);
+    blocks (64,3,s2) (128,4,s2) (256,6|23,s2) (512,3,s1), stride on the LAST
+    unit of each block; stack_blocks_dense switches to atrous rate 2 once the
+    output stride 16 is reached, so all block4 3x3 convs have rate 2.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Tuple
+
+BLOCKS = {
+    50: [(64, 3, 2), (128, 4, 2), (256, 6, 2), (512, 3, 1)],
+    101: [(64, 3, 2), (128, 4, 2), (256, 23, 2), (512, 3, 1)],
+    152: [(64, 3, 2), (128, 8, 2), (256, 36, 2), (512, 3, 1)],
+}
+
+MEAN_PIXEL = (123.68, 116.779, 103.939)  # PET/default_config.py:23
+BN_EPS = 1e-5                            # slim resnet_arg_scope default
+
+
+@dataclass
+class UnitPlan:
+    scope: str          # e.g. resnet_v1_50/block1/unit_1/bottleneck_v1
+    depth_in: int
+    depth: int
+    depth_bottleneck: int
+    stride: int         # stride actually applied (after output_stride logic)
+    rate: int           # atrous rate of conv2
+    has_shortcut_conv: bool
+
+
+def resnet_units(depth: int = 50, output_stride: int = 16) -> List[UnitPlan]:
+    """Unit list after slim's stack_blocks_dense(output_stride/4) logic."""
+    if depth not in BLOCKS:
+        raise ValueError("unsupported resnet depth %r" % (depth,))
+    name = "resnet_v1_%d" % depth
+    target = output_stride // 4       # root block already has stride 4
+    current_stride, rate = 1, 1
+    units: List[UnitPlan] = []
+    depth_in = 64
+    for bi, (base, n_units, block_stride) in enumerate(BLOCKS[depth], start=1):
+        for ui in range(1, n_units + 1):
+            s = block_stride if ui == n_units else 1
+            d_out = base * 4
+            if current_stride == target:
+                unit_stride, unit_rate = 1, rate
+                rate *= s
+            else:
+                unit_stride, unit_rate = s, 1
+                current_stride *= s
+            units.append(UnitPlan(
+                scope="%s/block%d/unit_%d/bottleneck_v1" % (name, bi, ui),
+                depth_in=depth_in, depth=d_out, depth_bottleneck=base,
+                stride=unit_stride, rate=unit_rate,
+                has_shortcut_conv=(depth_in != d_out)))
+            depth_in = d_out
+    return units
+
+
+def same_out(n: int, s: int) -> int:
+    return -(-n // s)
+
+
+def feature_hw(h: int, w: int, depth: int = 50) -> Tuple[int, int]:
+    """Spatial size of the backbone output (stride 16, ceil at every halving)."""
+    for _ in range(4):
+        h, w = same_out(h, 2), same_out(w, 2)
+    return h, w
+
+
+def scoremap_hw(h: int, w: int, deconv_stride: int = 2) -> Tuple[int, int]:
+    """DGP/dataset.py:348-371 closed form: H_out = 2*ceil(H/16)."""
+    fh, fw = feature_hw(h, w)
+    return fh * deconv_stride, fw * deconv_stride
+
+
+def conv_macs_per_frame(h: int, w: int, depth: int = 50, nj: int = 4,
+                        with_locref: bool = False) -> int:
+    """Algorithmic multiply-accumulates of the conv stack for one frame.
+
+    Counts the reference's convolutions only (no BN/ReLU/pool), with the
+    transposed-conv heads counted at their true tap count (9 taps per input
+    pixel) -- the figure BASELINE.md section 3 quotes (35.61 GMAC at 640x480).
+    """
+    h1, w1 = same_out(h, 2), same_out(w, 2)
+    macs = h1 * w1 * 7 * 7 * 3 * 64
+    hh, ww = same_out(h1, 2), same_out(w1, 2)
+    for u in resnet_units(depth):
+        ho, wo = same_out(hh, u.stride), same_out(ww, u.stride)
+        if u.has_shortcut_conv:
+            macs += ho * wo * u.depth_in * u.depth
+        macs += hh * ww * u.depth_in * u.depth_bottleneck
+        macs += ho * wo * 9 * u.depth_bottleneck * u.depth_bottleneck
+        macs += ho * wo * u.depth_bottleneck * u.depth
+        hh, ww = ho, wo
+    heads = nj * (3 if with_locref else 1)
+    macs += hh * ww * 9 * 2048 * heads
+    return macs

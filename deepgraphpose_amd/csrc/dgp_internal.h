@@ -1,0 +1,47 @@
+// Internal declarations shared by the kernel file and the engine.  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace dgp {
+
+constexpr int BK = 32;            // K floats per main-loop step (8 chunks of 4)
+
+// Arguments of the implicit-GEMM convolution kernel (see dgp_kernels.hip).
+struct ConvArgs {
+    const float* in;      // NHWC [N,H,W,Cin]
+    const float* wpk;     // packed weight panels [nk*8][CoutP][4]
+    const float* scale;   // [Cout] or nullptr (=1)
+    const float* bias;    // [Cout] or nullptr (=0)
+    const float* res;     // residual NHWC [N,res_H,res_W,Cout] or nullptr
+    float*       out;
+    int N, H, W, Cin, log2cin4;
+    int Ho, Wo, Cout, CoutP;
+    int KH, KW, stride, dil, pad_t, pad_l;
+    int ntaps, nk;        // real taps, number of BK steps
+    int M;                // N*Ho*Wo
+    int res_s, res_H, res_W;   // res_s == 0: none
+    int relu;
+    int out_mode;         // 0: NHWC [M][Cout]; 1: transposed-conv phase scatter
+    int dc_nj;            // channels per phase for out_mode 1
+    int mtiles, ntiles;
+};
+
+enum TileCfg { TILE_128x128 = 0, TILE_256x64 = 1, TILE_128x64 = 2, TILE_128x32 = 3, TILE_256x128 = 4 };
+
+hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s);
+int        pick_tile(int M, int CoutP, int K);
+hipError_t launch_maxpool(const float* x, int N, int H, int W, int C, float* y, hipStream_t s);
+hipError_t launch_preprocess(const uint8_t* f, long long npix, float m0, float m1, float m2,
+                             float* out, hipStream_t s);
+hipError_t launch_soft_argmax(const float* scmap, int B, int H, int W, int C, float gamma,
+                              int gauss_len, float* mu, float* conf, int* idx, float* pmap,
+                              hipStream_t s);
+hipError_t launch_hard_argmax(const float* scmap, const float* locref, int B, int H, int W, int C,
+                              int* idx, float* prob, float* offs, hipStream_t s);
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
+
+}  // namespace dgp

@@ -1,0 +1,542 @@
+// gfx950 (MI355X / CDNA4) kernels for the Deep Graph Pose hot path.
+//
+//   conv_igemm_f32     implicit-GEMM convolution on the fp32 matrix cores
+//                      (v_mfma_f32_32x32x2_f32: exact fp32 fma chains), NHWC activations,
+//                      k-chunked weight panels, LDS-staged double-buffered tiles, fused
+//                      BN-affine / bias / residual / ReLU epilogue, optional transposed-conv
+//                      phase scatter.  Covers K2,K4,K5,K6,K7,K8 of SURVEY.md 2.3.
+//   maxpool3x3s2_same  K3
+//   preprocess_u8      K1 (uint8 -> fp32, mean-pixel subtraction, pad C 3->4)
+//   soft_argmax        K9+K10 (DGP/models/fitdgp_util.py:342-402, DGP/models/eval.py:331-343)
+//   hard_argmax        K11 (PET/nnet/predict.py:62-77)
+//
+// Wavefront = 64 lanes everywhere.  No CUDA-compat shims; this file only targets gfx950.
+#include "dgp_internal.h"
+
+namespace dgp {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------
+// Implicit-GEMM convolution
+//
+// GEMM view: out[m][co] = sum_k A[m][k] * Wt[k][co]
+//   m  = (n, ho, wo) output pixel, k = (tap, ci) with ci fastest, taps row-major (kh, kw).
+// K is walked in steps of BK = 32 floats = 8 chunks of 4 consecutive input channels.
+// A chunk q = ks*8 + c maps to tap = q / (Cin/4), channel offset (q % (Cin/4)) * 4, so one
+// K-step is one tap when Cin >= 32 and spans 8 taps for the Cin = 4 stem.
+//
+// MFMA operand trick: v_mfma_f32_32x32x2_f32 takes A[i = lane&31][k = lane>>5]; the order of
+// k inside the reduction is free as long as A and B agree, so lanes 0-31 own chunk 2*kc and
+// lanes 32-63 chunk 2*kc+1 and fetch their 4 k-values with ONE ds_read_b128; register j of
+// both halves then feeds MFMA j.  LDS images are [chunk][row][4 floats]: a 32-lane half
+// reads 512 contiguous bytes -> conflict-free ds_read_b128.  The A image pads each chunk
+// plane by one 16-byte slot so that the 8 lanes that write one pixel's 8 chunks hit
+// different banks.
+// ------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
+    constexpr int WM = BM / WAVES_M;       // wave tile rows
+    constexpr int WN = BN / WAVES_N;       // wave tile cols
+    constexpr int TM = WM / 32;
+    constexpr int TN = WN / 32;
+    constexpr int AROWS = BM / 32;         // A rows staged per thread
+    constexpr int BSLOTS = 8 * BN / 256;   // B 16-byte slots staged per thread
+    constexpr int LDA = BM + 1;            // slots per chunk plane of A
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    static_assert(BSLOTS >= 1, "BN too small");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* sA = reinterpret_cast<float4*>(smem);     // [2][8][LDA]
+    float4* sB = sA + 2 * 8 * LDA;                    // [2][8][BN]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wave_m0 = (wave / WAVES_N) * WM;
+    const int wave_n0 = (wave % WAVES_N) * WN;
+
+    // XCD-aware tile mapping (blocks b and b+8 share an XCD / L2): give each XCD a
+    // contiguous range of tile ids; inside it the n-tiles of one m-tile are adjacent so the
+    // A tile is fetched into that L2 once.  Bijective for any grid size.
+    int tile;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, loc = b >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = tile / p.ntiles;
+    const int nt = tile - mt * p.ntiles;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
+
+    // ---- per-thread A row bookkeeping -------------------------------------------------
+    const int c = t & 7;        // chunk within the K-step
+    const int rg = t >> 3;      // 0..31
+    int hi0[AROWS], wi0[AROWS];
+    long long pix0[AROWS];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+        const int m = m0 + rg + 32 * i;
+        if (m < p.M) {
+            const int n = m / HoWo;
+            const int rem = m - n * HoWo;
+            const int ho = rem / p.Wo;
+            const int wo = rem - ho * p.Wo;
+            hi0[i] = ho * p.stride - p.pad_t;
+            wi0[i] = wo * p.stride - p.pad_l;
+            pix0[i] = ((long long)n * p.H + hi0[i]) * p.W + wi0[i];
+        } else {
+            hi0[i] = -(1 << 28);
+            wi0[i] = -(1 << 28);
+            pix0[i] = 0;
+        }
+    }
+    const int cin4m1 = (p.Cin >> 2) - 1;
+
+    float4 ra[AROWS];
+    float4 rb[BSLOTS];
+
+    auto gload = [&](int ks) {
+        const int q = ks * 8 + c;
+        const int tap = q >> p.log2cin4;
+        const int ch = (q & cin4m1) << 2;
+        const int kh = tap / p.KW;
+        const int kw = tap - kh * p.KW;
+        const int dh = kh * p.dil, dw = kw * p.dil;
+        const bool tapok = tap < p.ntaps;
+        const long long doff = (long long)dh * p.W + dw;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            // unconditional load from a clamped address + select: keeps all staging loads in
+            // flight together (a branch per load would serialise them behind vmcnt(0) waits)
+            const int hi = hi0[i] + dh, wi = wi0[i] + dw;
+            const bool ok = tapok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const long long off = ok ? ((pix0[i] + doff) * p.Cin + ch) : 0ll;
+            float4 v = *reinterpret_cast<const float4*>(p.in + off);
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BSLOTS; ++i) {
+            const int s = t + 256 * i;
+            const int chunk = s / BN;
+            const int col = s - chunk * BN;
+            const bool ok = n0 + col < p.CoutP;
+            const int colc = ok ? n0 + col : 0;
+            float4 v = *reinterpret_cast<const float4*>(
+                p.wpk + (((long long)(ks * 8 + chunk) * p.CoutP + colc) << 2));
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[i] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+        float4* a = sA + buf * 8 * LDA + c * LDA + rg;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) a[32 * i] = ra[i];
+        float4* b = sB + buf * 8 * BN + t;
+#pragma unroll
+        for (int i = 0; i < BSLOTS; ++i) b[256 * i] = rb[i];
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    for (int ks = 0; ks < p.nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < p.nk) gload(ks + 1);
+        const float4* a_base = sA + buf * 8 * LDA + wave_m0 + l31;
+        const float4* b_base = sB + buf * 8 * BN + wave_n0 + l31;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const int chunk = 2 * kc + half;
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = a_base[chunk * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = b_base[chunk * BN + 32 * j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (ks + 1 < p.nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -----
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int co = n0 + wave_n0 + 32 * j + l31;
+        const bool cok = co < p.Cout;
+        const float sc = (cok && p.scale) ? p.scale[co] : 1.f;
+        const float bi = (cok && p.bias) ? p.bias[co] : 0.f;
+        int ph_a = 0, ph_b = 0, cj = co;
+        if (p.out_mode == 1) {
+            const int ph = co / p.dc_nj;
+            cj = co - ph * p.dc_nj;
+            ph_a = ph >> 1;
+            ph_b = ph & 1;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int m = m0 + wave_m0 + 32 * i + row;
+                if (!cok || m >= p.M) continue;
+                float v = acc[i][j][r] * sc + bi;
+                long long oidx;
+                if (p.out_mode == 0 && p.res_s <= 1) {
+                    oidx = (long long)m * p.Cout + co;
+                    if (p.res_s == 1) v += p.res[oidx];
+                } else {
+                    const int n = m / HoWo;
+                    const int rem = m - n * HoWo;
+                    const int ho = rem / p.Wo;
+                    const int wo = rem - ho * p.Wo;
+                    if (p.out_mode == 0) {
+                        oidx = (long long)m * p.Cout + co;
+                        v += p.res[(((long long)n * p.res_H + ho * p.res_s) * p.res_W + wo * p.res_s) * p.Cout + co];
+                    } else {
+                        oidx = (((long long)n * (2 * p.Ho) + 2 * ho + ph_a) * (2 * p.Wo) + 2 * wo + ph_b) * p.dc_nj + cj;
+                    }
+                }
+                if (p.relu) v = fmaxf(v, 0.f);
+                p.out[oidx] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static hipError_t launch_conv_t(ConvArgs a, hipStream_t s) {
+    constexpr size_t smem = (size_t)(2 * 8 * (BM + 1) + 2 * 8 * BN) * 16;
+    a.mtiles = (a.M + BM - 1) / BM;
+    a.ntiles = (a.CoutP + BN - 1) / BN;
+    auto kern = conv_igemm_f32<BM, BN, WAVES_M, WAVES_N>;
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const long long nwg = (long long)a.mtiles * a.ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), smem, s, a);
+    return hipGetLastError();
+}
+
+int pick_tile(int M, int CoutP, int K) {
+    (void)M; (void)K;
+    if (CoutP <= 32) return TILE_128x32;
+    if (CoutP <= 64) return TILE_128x64;
+    return TILE_128x128;
+}
+
+hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s) {
+    switch (tile_cfg) {
+        case TILE_128x32: return launch_conv_t<128, 32, 4, 1>(a, s);
+        case TILE_128x64: return launch_conv_t<128, 64, 2, 2>(a, s);
+        default:          return launch_conv_t<128, 128, 2, 2>(a, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// 3x3 / stride 2 max-pool, TF 'SAME' padding (pad_before = pad_total/2, padded cells never
+// win).  NHWC fp32, 4 channels (16 B) per thread.  HBM-bound.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool3x3s2_same(const float* __restrict__ x, int N, int H, int W,
+                                                         int C4, int Ho, int Wo, int pt, int pl,
+                                                         float* __restrict__ y) {
+    const long long total = (long long)N * Ho * Wo * C4;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+         g += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(g % C4);
+        long long pix = g / C4;
+        const int wo = (int)(pix % Wo);
+        pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int n = (int)(pix / Ho);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int hi = ho * 2 - pt + a;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int wi = wo * 2 - pl + b;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(
+                    x + ((((long long)n * H + hi) * W + wi) * C4 + c4) * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y);
+                m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *reinterpret_cast<float4*>(y + g * 4) = m;
+    }
+}
+
+hipError_t launch_maxpool(const float* x, int N, int H, int W, int C, float* y, hipStream_t s) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int pth = ((Ho - 1) * 2 + 3 - H) > 0 ? ((Ho - 1) * 2 + 3 - H) : 0;
+    const int ptw = ((Wo - 1) * 2 + 3 - W) > 0 ? ((Wo - 1) * 2 + 3 - W) : 0;
+    const long long total = (long long)N * Ho * Wo * (C / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(maxpool3x3s2_same, dim3((unsigned)blocks), dim3(256), 0, s, x, N, H, W, C / 4, Ho, Wo,
+                       pth / 2, ptw / 2, y);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// uint8 RGB -> fp32 (x - mean_pixel), channel-padded 3 -> 4 (PET/nnet/pose_net.py:38-40).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_u8(const uint8_t* __restrict__ f, long long npix, float m0,
+                                                     float m1, float m2, float* __restrict__ out) {
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < npix;
+         g += (long long)gridDim.x * blockDim.x) {
+        const uint8_t* q = f + g * 3;
+        float4 v;
+        v.x = (float)q[0] - m0;
+        v.y = (float)q[1] - m1;
+        v.z = (float)q[2] - m2;
+        v.w = 0.f;
+        *reinterpret_cast<float4*>(out + g * 4) = v;
+    }
+}
+
+hipError_t launch_preprocess(const uint8_t* f, long long npix, float m0, float m1, float m2, float* out,
+                             hipStream_t s) {
+    long long blocks = (npix + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(preprocess_u8, dim3((unsigned)blocks), dim3(256), 0, s, f, npix, m0, m1, m2, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// Block-wide reductions (256 threads = 4 waves of 64).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------
+// DGP 2-D soft-argmax + likelihood window.  One workgroup per (frame, joint) map.
+//   p = softmax(gamma * s) over H*W; zero-pad by gauss_len; depthwise blur with
+//   outer(g, g), g = exp(-x^2 / (2 sigma^2)) / sum, x = -r..r, r = sigma = gauss_len;
+//   renormalise; mu = E[(h, w)].       (DGP/models/fitdgp_util.py:281-402)
+//   likelihood: window [floor(mu), ceil(mu)+1) per axis clipped to the map, first row-major
+//   arg-max of e^x/(e^x+1) on the RAW logits.        (DGP/models/eval.py:331-343)
+// The map lives in LDS (H*W floats); sums are carried in fp64.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restrict__ scmap, int H, int W, int C,
+                                                          float gamma, int glen, float* __restrict__ mu,
+                                                          float* __restrict__ conf, int* __restrict__ idx,
+                                                          float* __restrict__ pmap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sp = reinterpret_cast<float*>(smem);       // H*W
+    __shared__ double red[3][4];
+    __shared__ float redf[4];
+    __shared__ float gk[16];
+
+    const int b = blockIdx.x / C;
+    const int cj = blockIdx.x - b * C;
+    const int HW = H * W;
+    const float* src = scmap + (long long)b * HW * C + cj;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    // Gaussian taps, fp32 like the reference graph
+    const int r = glen;
+    if (t == 0) {
+        float s = 0.f;
+        for (int i = -r; i <= r; ++i) {
+            const float xs = (float)i / (float)glen;
+            gk[i + r] = expf(-0.5f * xs * xs);
+            s += gk[i + r];
+        }
+        for (int i = 0; i <= 2 * r; ++i) gk[i] = gk[i] / s;
+    }
+
+    float mx = -INFINITY;
+    for (int i = t; i < HW; i += 256) {
+        const float v = src[(long long)i * C] * gamma;
+        sp[i] = v;
+        mx = fmaxf(mx, v);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) redf[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+
+    double se = 0.0;
+    for (int i = t; i < HW; i += 256) {
+        const float e = expf(sp[i] - mx);
+        sp[i] = e;
+        se += (double)e;
+    }
+    se = wave_sum(se);
+    if (lane == 0) red[0][wave] = se;
+    __syncthreads();
+    const float denom = (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    __syncthreads();
+    for (int i = t; i < HW; i += 256) sp[i] = sp[i] / denom;    // tf.nn.softmax output
+    __syncthreads();
+
+    // blur (zero padded) + moments
+    double s0 = 0.0, sh = 0.0, sw = 0.0;
+    for (int i = t; i < HW; i += 256) {
+        const int h = i / W, w = i - h * W;
+        float acc = 0.f;
+        for (int a = -r; a <= r; ++a) {
+            const int hh = h + a;
+            if ((unsigned)hh >= (unsigned)H) continue;
+            const float ga = gk[a + r];
+            for (int bb = -r; bb <= r; ++bb) {
+                const int ww = w + bb;
+                if ((unsigned)ww >= (unsigned)W) continue;
+                acc += (ga * gk[bb + r]) * sp[hh * W + ww];
+            }
+        }
+        s0 += (double)acc;
+        sh += (double)acc * (double)h;
+        sw += (double)acc * (double)w;
+        if (pmap) pmap[((long long)b * HW + i) * C + cj] = acc;   // un-normalised; fixed below
+    }
+    s0 = wave_sum(s0); sh = wave_sum(sh); sw = wave_sum(sw);
+    if (lane == 0) { red[0][wave] = s0; red[1][wave] = sh; red[2][wave] = sw; }
+    __syncthreads();
+    const double t0 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const double th = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double tw = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    if (pmap) {
+        const float inv_src = (float)t0;
+        for (int i = t; i < HW; i += 256) {
+            const long long o = ((long long)b * HW + i) * C + cj;
+            pmap[o] = pmap[o] / inv_src;
+        }
+    }
+    if (t == 0) {
+        const float mh = (float)(th / t0);
+        const float mw = (float)(tw / t0);
+        const long long o = (long long)b * C + cj;
+        mu[o * 2 + 0] = mh;
+        mu[o * 2 + 1] = mw;
+        // likelihood window on raw logits
+        int h0 = (int)floorf(mh), h1 = (int)ceilf(mh) + 1;
+        int w0 = (int)floorf(mw), w1 = (int)ceilf(mw) + 1;
+        if (h1 > H) h1 = H;
+        if (w1 > W) w1 = W;
+        if (h0 < 0) h0 = 0;
+        if (w0 < 0) w0 = 0;
+        float best = -1.f;
+        int bh = h0, bw = w0;
+        for (int hh = h0; hh < h1; ++hh)
+            for (int ww = w0; ww < w1; ++ww) {
+                const float x = src[(long long)(hh * W + ww) * C];
+                const float e = expf(x);
+                const float sg = e / (e + 1.f);
+                if (sg > best) { best = sg; bh = hh; bw = ww; }
+            }
+        conf[o] = best;
+        idx[o * 2 + 0] = bh;
+        idx[o * 2 + 1] = bw;
+    }
+}
+
+hipError_t launch_soft_argmax(const float* scmap, int B, int H, int W, int C, float gamma, int gauss_len,
+                              float* mu, float* conf, int* idx, float* pmap, hipStream_t s) {
+    const size_t smem = (size_t)H * W * sizeof(float);
+    static size_t attr_set = 0;
+    if (smem > 64 * 1024 && smem > attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(soft_argmax_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_set = smem;
+    }
+    hipLaunchKernelGGL(soft_argmax_kernel, dim3((unsigned)(B * C)), dim3(256), smem, s, scmap, H, W, C, gamma,
+                       gauss_len, mu, conf, idx, pmap);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// DLC hard arg-max (PET/nnet/predict.py:62-77): first row-major maximum of
+// sigmoid(scmap[:, :, j]); returns index, probability and the raw locref pair there.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hard_argmax_kernel(const float* __restrict__ scmap,
+                                                          const float* __restrict__ locref, int H, int W, int C,
+                                                          int* __restrict__ idx, float* __restrict__ prob,
+                                                          float* __restrict__ offs) {
+    __shared__ float rv[4];
+    __shared__ int ri[4];
+    const int b = blockIdx.x / C;
+    const int cj = blockIdx.x - b * C;
+    const int HW = H * W;
+    const float* src = scmap + (long long)b * HW * C + cj;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float bv = -1.f;
+    int bi = 0x7fffffff;
+    for (int i = t; i < HW; i += 256) {
+        const float x = src[(long long)i * C];
+        const float sg = 1.f / (1.f + expf(-x));      // tf.sigmoid in fp32 (pose_net.py:86)
+        if (sg > bv) { bv = sg; bi = i; }              // i increases: keeps the first maximum
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { rv[wave] = bv; ri[wave] = bi; }
+    __syncthreads();
+    if (t == 0) {
+        for (int k = 1; k < 4; ++k)
+            if (rv[k] > bv || (rv[k] == bv && ri[k] < bi)) { bv = rv[k]; bi = ri[k]; }
+        const long long o = (long long)b * C + cj;
+        const int h = bi / W, w = bi - h * W;
+        idx[o * 2 + 0] = h;
+        idx[o * 2 + 1] = w;
+        prob[o] = bv;
+        float dx = 0.f, dy = 0.f;
+        if (locref) {
+            const float* l = locref + ((long long)b * HW + bi) * (2 * C) + 2 * cj;
+            dx = l[0];
+            dy = l[1];
+        }
+        offs[o * 2 + 0] = dx;
+        offs[o * 2 + 1] = dy;
+    }
+}
+
+hipError_t launch_hard_argmax(const float* scmap, const float* locref, int B, int H, int W, int C, int* idx,
+                              float* prob, float* offs, hipStream_t s) {
+    hipLaunchKernelGGL(hard_argmax_kernel, dim3((unsigned)(B * C)), dim3(256), 0, s, scmap, locref, H, W, C, idx,
+                       prob, offs);
+    return hipGetLastError();
+}
+
+}  // namespace dgp

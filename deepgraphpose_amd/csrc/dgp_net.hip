@@ -1,0 +1,504 @@
+// Host engine + C-ABI of libdgp_hip.so (see include/dgp_hip.h).
+//
+// The engine walks the TF-slim resnet_v1 plan (same table as deepgraphpose_amd/arch.py):
+//   preprocess -> conv1 7x7/2 (+BN+ReLU) -> maxpool 3x3/2 SAME -> bottleneck units
+//   (shortcut | conv1 | conv2 | conv3+residual+ReLU) -> transposed-conv heads,
+// every convolution through the one implicit-GEMM kernel.  It owns only the repacked
+// weights; activations live in the caller's workspace.
+#include "../../include/dgp_hip.h"
+#include "dgp_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace dgp;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail(DGP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+    } while (0)
+
+namespace {
+
+struct ConvLayer {
+    std::string scope;        // TF scope of the conv (".../conv1"), weights = scope + "/weights"
+    int Cin = 0, Cout = 0, CoutP = 0, KH = 1, KW = 1, stride = 1, rate = 1;
+    int nk = 0, ntaps = 1;
+    bool has_bn = true, relu = false;
+    float *d_w = nullptr, *d_scale = nullptr, *d_bias = nullptr;
+};
+
+struct Unit {
+    int sc = -1, c1 = -1, c2 = -1, c3 = -1;
+    int stride = 1, rate = 1;
+    int depth_in = 0, depth = 0, depth_bn = 0;
+};
+
+int coutp_for(int cout) {
+    if (cout <= 32) return 32;
+    if (cout <= 64) return 64;
+    return round_up(cout, 128);
+}
+int nk_for(int kh, int kw, int cin) { return (kh * kw * (cin / 4) + 7) / 8; }
+
+void pack_panels(const float* hwio, int KH, int KW, int Cin, int Cout, float* packed) {
+    const int cin4 = Cin / 4, CoutP = coutp_for(Cout), nk = nk_for(KH, KW, Cin);
+    const size_t total = (size_t)nk * 8 * CoutP * 4;
+    memset(packed, 0, total * sizeof(float));
+    const int nchunks = KH * KW * cin4;
+    for (int q = 0; q < nchunks; ++q) {
+        const int tap = q / cin4, ch = (q % cin4) * 4;
+        for (int e = 0; e < 4; ++e) {
+            const float* src = hwio + ((size_t)tap * Cin + ch + e) * Cout;
+            float* dst = packed + (size_t)q * CoutP * 4 + e;
+            for (int co = 0; co < Cout; ++co) dst[(size_t)co * 4] = src[co];
+        }
+    }
+}
+
+void tf_same(int n, int k, int s, int d, int* out, int* pad_before) {
+    const int keff = (k - 1) * d + 1;
+    *out = (n + s - 1) / s;
+    int total = (*out - 1) * s + keff - n;
+    if (total < 0) total = 0;
+    *pad_before = total / 2;
+}
+
+}  // namespace
+
+struct dgp_net {
+    dgp_net_desc desc{};
+    int device = 0;
+    std::vector<ConvLayer> layers;
+    int conv1 = -1, head_part = -1, head_locref = -1;
+    std::vector<Unit> units;
+    bool loaded = false;
+    // geometry
+    int h1 = 0, w1 = 0, hp = 0, wp = 0, fh = 0, fw = 0;
+    ~dgp_net() {
+        for (auto& l : layers) {
+            if (l.d_w) (void)hipFree(l.d_w);
+            if (l.d_scale) (void)hipFree(l.d_scale);
+            if (l.d_bias) (void)hipFree(l.d_bias);
+        }
+    }
+};
+
+static int add_layer(dgp_net* net, const std::string& scope, int cin, int cout, int k, int stride, int rate,
+                     bool bn, bool relu) {
+    ConvLayer l;
+    l.scope = scope; l.Cin = cin; l.Cout = cout; l.KH = l.KW = k; l.stride = stride; l.rate = rate;
+    l.CoutP = coutp_for(cout); l.nk = nk_for(k, k, cin); l.ntaps = k * k; l.has_bn = bn; l.relu = relu;
+    net->layers.push_back(l);
+    return (int)net->layers.size() - 1;
+}
+
+extern "C" {
+
+int dgp_version(void) { return DGP_ABI_VERSION; }
+const char* dgp_last_error(void) { return g_err.c_str(); }
+
+int dgp_net_create(const dgp_net_desc* d, dgp_net** out) {
+    if (!d || !out) return fail(DGP_ERR_INVALID, "dgp_net_create: null argument");
+    int nunits[4];
+    if (d->depth == 50) { int v[4] = {3, 4, 6, 3}; memcpy(nunits, v, sizeof v); }
+    else if (d->depth == 101) { int v[4] = {3, 4, 23, 3}; memcpy(nunits, v, sizeof v); }
+    else if (d->depth == 152) { int v[4] = {3, 8, 36, 3}; memcpy(nunits, v, sizeof v); }
+    else return fail(DGP_ERR_INVALID, "dgp_net_create: depth must be 50, 101 or 152");
+    if (d->num_joints < 1 || d->in_h < 32 || d->in_w < 32 || d->max_batch < 1)
+        return fail(DGP_ERR_INVALID, "dgp_net_create: bad num_joints / frame size / max_batch");
+    dgp_net* net = new dgp_net();
+    net->desc = *d;
+    if (net->desc.bn_eps <= 0.f) net->desc.bn_eps = 1e-5f;
+    HIP_TRY(hipGetDevice(&net->device));
+    const std::string name = "resnet_v1_" + std::to_string(d->depth);
+    // root block: conv2d_same(64, 7, stride 2) on the channel-padded (3->4) centred frame
+    net->conv1 = add_layer(net, name + "/conv1", 4, 64, 7, 2, 1, true, true);
+    // slim stack_blocks_dense with output_stride 16 (target 4 after the root block)
+    const int base[4] = {64, 128, 256, 512};
+    const int bstride[4] = {2, 2, 2, 1};
+    int cur = 1, rate = 1, depth_in = 64;
+    for (int b = 0; b < 4; ++b)
+        for (int u = 1; u <= nunits[b]; ++u) {
+            Unit un;
+            const int s = (u == nunits[b]) ? bstride[b] : 1;
+            if (cur == 4) { un.stride = 1; un.rate = rate; rate *= s; }
+            else { un.stride = s; un.rate = 1; cur *= s; }
+            un.depth_in = depth_in; un.depth = base[b] * 4; un.depth_bn = base[b];
+            const std::string sc = name + "/block" + std::to_string(b + 1) + "/unit_" + std::to_string(u) +
+                                   "/bottleneck_v1";
+            if (un.depth_in != un.depth)
+                un.sc = add_layer(net, sc + "/shortcut", un.depth_in, un.depth, 1, un.stride, 1, true, false);
+            un.c1 = add_layer(net, sc + "/conv1", un.depth_in, un.depth_bn, 1, 1, 1, true, true);
+            un.c2 = add_layer(net, sc + "/conv2", un.depth_bn, un.depth_bn, 3, un.stride, un.rate, true, true);
+            un.c3 = add_layer(net, sc + "/conv3", un.depth_bn, un.depth, 1, 1, 1, true, true /*after add*/);
+            net->units.push_back(un);
+            depth_in = un.depth;
+        }
+    // heads: 3x3/stride-2 SAME transposed conv == 2x2 conv over (i-1..i, j-1..j) producing the
+    // 4 output phases as 4*nj channels, scattered by the epilogue.
+    {
+        ConvLayer l;
+        l.scope = "pose/part_pred/block4"; l.Cin = 2048; l.Cout = 4 * d->num_joints; l.KH = l.KW = 2;
+        l.CoutP = coutp_for(l.Cout); l.nk = nk_for(2, 2, 2048); l.ntaps = 4; l.has_bn = false; l.relu = false;
+        net->layers.push_back(l);
+        net->head_part = (int)net->layers.size() - 1;
+        if (d->with_locref) {
+            l.scope = "pose/locref_pred/block4"; l.Cout = 8 * d->num_joints; l.CoutP = coutp_for(l.Cout);
+            net->layers.push_back(l);
+            net->head_locref = (int)net->layers.size() - 1;
+        }
+    }
+    int pb;
+    net->h1 = (d->in_h + 1) / 2; net->w1 = (d->in_w + 1) / 2;     // conv2d_same stride 2
+    tf_same(net->h1, 3, 2, 1, &net->hp, &pb); tf_same(net->w1, 3, 2, 1, &net->wp, &pb);
+    net->fh = (((net->hp + 1) / 2) + 1) / 2; net->fw = (((net->wp + 1) / 2) + 1) / 2;
+    *out = net;
+    return DGP_OK;
+}
+
+void dgp_net_destroy(dgp_net* net) { delete net; }
+
+static const dgp_tensor_view* find_t(const std::map<std::string, const dgp_tensor_view*>& m,
+                                     const std::string& k) {
+    auto it = m.find(k);
+    return it == m.end() ? nullptr : it->second;
+}
+
+int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n) {
+    if (!net || !tensors) return fail(DGP_ERR_INVALID, "dgp_net_load_weights: null argument");
+    std::map<std::string, const dgp_tensor_view*> m;
+    for (int i = 0; i < n; ++i)
+        if (tensors[i].name) m[tensors[i].name] = &tensors[i];
+    HIP_TRY(hipSetDevice(net->device));
+    const int nj = net->desc.num_joints;
+    for (size_t li = 0; li < net->layers.size(); ++li) {
+        ConvLayer& l = net->layers[li];
+        const bool is_head = ((int)li == net->head_part || (int)li == net->head_locref);
+        const dgp_tensor_view* w = find_t(m, l.scope + "/weights");
+        if (!w) return fail(DGP_ERR_MISSING, "missing tensor " + l.scope + "/weights");
+        std::vector<float> hwio;
+        std::vector<float> scale(l.Cout, 1.f), bias(l.Cout, 0.f);
+        if ((int)li == net->conv1) {
+            if (w->ndim != 4 || w->shape[0] != 7 || w->shape[1] != 7 || w->shape[2] != 3 || w->shape[3] != 64)
+                return fail(DGP_ERR_INVALID, "bad shape for " + l.scope + "/weights (want [7,7,3,64])");
+            hwio.assign((size_t)49 * 4 * 64, 0.f);
+            for (int tp = 0; tp < 49; ++tp)
+                for (int ci = 0; ci < 3; ++ci)
+                    memcpy(&hwio[((size_t)tp * 4 + ci) * 64], w->data + ((size_t)tp * 3 + ci) * 64, 64 * sizeof(float));
+        } else if (is_head) {
+            const int njt = l.Cout / 4;      // nj or 2*nj
+            if (w->ndim != 4 || w->shape[0] != 3 || w->shape[1] != 3 || w->shape[2] != njt || w->shape[3] != 2048)
+                return fail(DGP_ERR_INVALID, "bad shape for " + l.scope + "/weights (want [3,3,Cout,2048])");
+            // W'[kh'][kw'][ci][(a,b),c] = w[a+2-2kh'][b+2-2kw'][c][ci] when both tap ids <= 2
+            hwio.assign((size_t)4 * 2048 * l.Cout, 0.f);
+            for (int khp = 0; khp < 2; ++khp)
+                for (int kwp = 0; kwp < 2; ++kwp)
+                    for (int a = 0; a < 2; ++a)
+                        for (int b = 0; b < 2; ++b) {
+                            const int ka = a + 2 - 2 * khp, kb = b + 2 - 2 * kwp;
+                            if (ka > 2 || kb > 2) continue;
+                            for (int c = 0; c < njt; ++c) {
+                                const float* src = w->data + (((size_t)ka * 3 + kb) * njt + c) * 2048;
+                                const int co = (a * 2 + b) * njt + c;
+                                for (int ci = 0; ci < 2048; ++ci)
+                                    hwio[(((size_t)khp * 2 + kwp) * 2048 + ci) * l.Cout + co] = src[ci];
+                            }
+                        }
+            const dgp_tensor_view* bb = find_t(m, l.scope + "/biases");
+            if (!bb) return fail(DGP_ERR_MISSING, "missing tensor " + l.scope + "/biases");
+            for (int ph = 0; ph < 4; ++ph)
+                for (int c = 0; c < njt; ++c) bias[ph * njt + c] = bb->data[c];
+            (void)nj;
+        } else {
+            if (w->ndim != 4 || w->shape[0] != l.KH || w->shape[1] != l.KW || w->shape[2] != l.Cin ||
+                w->shape[3] != l.Cout)
+                return fail(DGP_ERR_INVALID, "bad shape for " + l.scope + "/weights");
+            hwio.assign(w->data, w->data + (size_t)l.KH * l.KW * l.Cin * l.Cout);
+        }
+        if (l.has_bn) {
+            const dgp_tensor_view* g = find_t(m, l.scope + "/BatchNorm/gamma");
+            const dgp_tensor_view* be = find_t(m, l.scope + "/BatchNorm/beta");
+            const dgp_tensor_view* mu = find_t(m, l.scope + "/BatchNorm/moving_mean");
+            const dgp_tensor_view* var = find_t(m, l.scope + "/BatchNorm/moving_variance");
+            if (!g || !be || !mu || !var) return fail(DGP_ERR_MISSING, "missing BatchNorm tensors under " + l.scope);
+            for (int c = 0; c < l.Cout; ++c) {
+                // slim.batch_norm(is_training=False): y = (x-mean)*gamma*rsqrt(var+eps)+beta
+                const float inv = g->data[c] / sqrtf(var->data[c] + net->desc.bn_eps);
+                scale[c] = inv;
+                bias[c] = be->data[c] - mu->data[c] * inv;
+            }
+        }
+        const size_t nfl = (size_t)l.nk * 8 * l.CoutP * 4;
+        std::vector<float> packed(nfl);
+        pack_panels(hwio.data(), l.KH, l.KW, l.Cin, l.Cout, packed.data());
+        if (!l.d_w) HIP_TRY(hipMalloc(&l.d_w, nfl * sizeof(float)));
+        if (!l.d_scale) HIP_TRY(hipMalloc(&l.d_scale, l.Cout * sizeof(float)));
+        if (!l.d_bias) HIP_TRY(hipMalloc(&l.d_bias, l.Cout * sizeof(float)));
+        HIP_TRY(hipMemcpy(l.d_w, packed.data(), nfl * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(l.d_scale, scale.data(), l.Cout * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(l.d_bias, bias.data(), l.Cout * sizeof(float), hipMemcpyHostToDevice));
+    }
+    net->loaded = true;
+    return DGP_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct Plan {
+    size_t off_p0, off_c1, off_x0, off_x1, off_sc, off_r1, off_r2, off_scmap, off_locref, total;
+};
+
+size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+Plan make_plan(const dgp_net* net, int B) {
+    const dgp_net_desc& d = net->desc;
+    size_t p0 = (size_t)B * d.in_h * d.in_w * 4;
+    size_t c1 = (size_t)B * net->h1 * net->w1 * 64;
+    size_t x = (size_t)B * net->hp * net->wp * 64, sc = 0, r1 = 0, r2 = 0;
+    int h = net->hp, w = net->wp;
+    for (const Unit& u : net->units) {
+        const int ho = (h + u.stride - 1) / u.stride, wo = (w + u.stride - 1) / u.stride;
+        r1 = std::max(r1, (size_t)B * h * w * u.depth_bn);
+        r2 = std::max(r2, (size_t)B * ho * wo * u.depth_bn);
+        x = std::max(x, (size_t)B * ho * wo * u.depth);
+        if (u.sc >= 0) sc = std::max(sc, (size_t)B * ho * wo * u.depth);
+        h = ho; w = wo;
+    }
+    Plan p{};
+    size_t o = 0;
+    auto take = [&](size_t nfloats) { size_t r = o; o += align256(nfloats * sizeof(float)); return r; };
+    p.off_p0 = take(p0); p.off_c1 = take(c1); p.off_x0 = take(x); p.off_x1 = take(x); p.off_sc = take(sc);
+    p.off_r1 = take(r1); p.off_r2 = take(r2);
+    p.off_scmap = take((size_t)B * 4 * net->fh * net->fw * d.num_joints);
+    p.off_locref = take((size_t)B * 4 * net->fh * net->fw * 2 * d.num_joints);
+    p.total = o;
+    return p;
+}
+
+int run_conv(const ConvLayer& l, const float* in, int N, int H, int W, int pad_t, int pad_l, int Ho, int Wo,
+             const float* res, int res_s, int res_H, int res_W, bool relu, int out_mode, int dc_nj, float* out,
+             hipStream_t s) {
+    ConvArgs a{};
+    a.in = in; a.wpk = l.d_w; a.scale = l.has_bn ? l.d_scale : nullptr; a.bias = l.d_bias; a.res = res; a.out = out;
+    a.N = N; a.H = H; a.W = W; a.Cin = l.Cin; a.log2cin4 = ilog2(l.Cin / 4);
+    a.Ho = Ho; a.Wo = Wo; a.Cout = l.Cout; a.CoutP = l.CoutP;
+    a.KH = l.KH; a.KW = l.KW; a.stride = l.stride; a.dil = l.rate; a.pad_t = pad_t; a.pad_l = pad_l;
+    a.ntaps = l.ntaps; a.nk = l.nk; a.M = N * Ho * Wo;
+    a.res_s = res ? res_s : 0; a.res_H = res_H; a.res_W = res_W;
+    a.relu = relu ? 1 : 0; a.out_mode = out_mode; a.dc_nj = dc_nj;
+    hipError_t e = launch_conv(a, pick_tile(a.M, a.CoutP, l.nk * BK), s);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("conv launch (") + l.scope + "): " + hipGetErrorString(e));
+    return DGP_OK;
+}
+
+// conv2d_same / SAME padding-before for a k x k conv with given stride / rate on extent n
+int pad_before_for(int n, int k, int stride, int rate, bool conv2d_same_explicit) {
+    const int keff = (k - 1) * rate + 1;
+    if (conv2d_same_explicit && stride > 1) return (keff - 1) / 2;     // slim conv2d_same
+    int out, pb;
+    tf_same(n, k, stride, rate, &out, &pb);
+    return pb;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dgp_net_workspace_bytes(const dgp_net* net, int32_t batch, size_t* out_bytes) {
+    if (!net || !out_bytes || batch < 1 || batch > net->desc.max_batch)
+        return fail(DGP_ERR_INVALID, "dgp_net_workspace_bytes: bad argument (batch > max_batch?)");
+    *out_bytes = make_plan(net, batch).total;
+    return DGP_OK;
+}
+
+int dgp_net_output_dims(const dgp_net* net, int32_t* out_h, int32_t* out_w, int32_t* feat_h, int32_t* feat_w) {
+    if (!net) return fail(DGP_ERR_INVALID, "dgp_net_output_dims: null net");
+    if (out_h) *out_h = 2 * net->fh;
+    if (out_w) *out_w = 2 * net->fw;
+    if (feat_h) *feat_h = net->fh;
+    if (feat_w) *feat_w = net->fw;
+    return DGP_OK;
+}
+
+int dgp_net_stats(const dgp_net* net, int32_t batch, int32_t* n_launches, double* conv_flops) {
+    if (!net) return fail(DGP_ERR_INVALID, "dgp_net_stats: null net");
+    double macs = (double)net->h1 * net->w1 * 49 * 3 * 64;
+    int launches = 3;   // preprocess, conv1, pool
+    int h = net->hp, w = net->wp;
+    for (const Unit& u : net->units) {
+        const int ho = (h + u.stride - 1) / u.stride, wo = (w + u.stride - 1) / u.stride;
+        if (u.sc >= 0) { macs += (double)ho * wo * u.depth_in * u.depth; ++launches; }
+        macs += (double)h * w * u.depth_in * u.depth_bn;
+        macs += (double)ho * wo * 9 * u.depth_bn * u.depth_bn;
+        macs += (double)ho * wo * u.depth_bn * u.depth;
+        launches += 3;
+        h = ho; w = wo;
+    }
+    const int heads = net->desc.num_joints * (net->desc.with_locref ? 3 : 1);
+    macs += (double)h * w * 9 * 2048 * heads;
+    launches += net->desc.with_locref ? 2 : 1;
+    if (n_launches) *n_launches = launches;
+    if (conv_flops) *conv_flops = 2.0 * macs * batch;
+    return DGP_OK;
+}
+
+int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* workspace, size_t workspace_bytes,
+                float* scmap, float* locref, float* features, void* stream) {
+    if (!net || !frames || !workspace) return fail(DGP_ERR_INVALID, "dgp_forward: null argument");
+    if (!net->loaded) return fail(DGP_ERR_STATE, "dgp_forward: weights not loaded");
+    if (batch < 1 || batch > net->desc.max_batch) return fail(DGP_ERR_INVALID, "dgp_forward: batch out of range");
+    const Plan pl = make_plan(net, batch);
+    if (workspace_bytes < pl.total) return fail(DGP_ERR_INVALID, "dgp_forward: workspace too small");
+    if (locref && net->head_locref < 0) return fail(DGP_ERR_INVALID, "dgp_forward: net built without locref head");
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    float* P0 = (float*)(ws + pl.off_p0);
+    float* C1 = (float*)(ws + pl.off_c1);
+    float* X[2] = {(float*)(ws + pl.off_x0), (float*)(ws + pl.off_x1)};
+    float* SC = (float*)(ws + pl.off_sc);
+    float* R1 = (float*)(ws + pl.off_r1);
+    float* R2 = (float*)(ws + pl.off_r2);
+    const dgp_net_desc& d = net->desc;
+    const int B = batch;
+    int rc;
+
+    hipError_t e = launch_preprocess(frames, (long long)B * d.in_h * d.in_w, d.mean_pixel[0], d.mean_pixel[1],
+                                     d.mean_pixel[2], P0, s);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("preprocess: ") + hipGetErrorString(e));
+    // conv1: conv2d_same(7, stride 2): explicit pad 3 before
+    rc = run_conv(net->layers[net->conv1], P0, B, d.in_h, d.in_w, 3, 3, net->h1, net->w1, nullptr, 0, 0, 0, true, 0,
+                  0, C1, s);
+    if (rc) return rc;
+    e = launch_maxpool(C1, B, net->h1, net->w1, 64, X[0], s);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("maxpool: ") + hipGetErrorString(e));
+
+    int cur = 0, h = net->hp, w = net->wp;
+    for (const Unit& u : net->units) {
+        const int ho = (h + u.stride - 1) / u.stride, wo = (w + u.stride - 1) / u.stride;
+        const float* xin = X[cur];
+        float* xout = X[cur ^ 1];
+        const float* res = xin;
+        int res_s = u.stride, res_H = h, res_W = w;
+        if (u.sc >= 0) {
+            // slim.conv2d(1x1, stride, SAME): pad 0, samples x[::s, ::s]
+            rc = run_conv(net->layers[u.sc], xin, B, h, w, 0, 0, ho, wo, nullptr, 0, 0, 0, false, 0, 0, SC, s);
+            if (rc) return rc;
+            res = SC; res_s = 1; res_H = ho; res_W = wo;
+        }
+        rc = run_conv(net->layers[u.c1], xin, B, h, w, 0, 0, h, w, nullptr, 0, 0, 0, true, 0, 0, R1, s);
+        if (rc) return rc;
+        const int pb_h = pad_before_for(h, 3, u.stride, u.rate, true);
+        const int pb_w = pad_before_for(w, 3, u.stride, u.rate, true);
+        rc = run_conv(net->layers[u.c2], R1, B, h, w, pb_h, pb_w, ho, wo, nullptr, 0, 0, 0, true, 0, 0, R2, s);
+        if (rc) return rc;
+        rc = run_conv(net->layers[u.c3], R2, B, ho, wo, 0, 0, ho, wo, res, res_s, res_H, res_W, true, 0, 0, xout, s);
+        if (rc) return rc;
+        cur ^= 1; h = ho; w = wo;
+    }
+    const float* feat = X[cur];
+    if (features)
+        HIP_TRY(hipMemcpyAsync(features, feat, (size_t)B * h * w * 2048 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    float* sm = scmap ? scmap : (float*)(ws + pl.off_scmap);
+    rc = run_conv(net->layers[net->head_part], feat, B, h, w, 1, 1, h, w, nullptr, 0, 0, 0, false, 1, d.num_joints,
+                  sm, s);
+    if (rc) return rc;
+    if (locref) {
+        rc = run_conv(net->layers[net->head_locref], feat, B, h, w, 1, 1, h, w, nullptr, 0, 0, 0, false, 1,
+                      2 * d.num_joints, locref, s);
+        if (rc) return rc;
+    }
+    return DGP_OK;
+}
+
+int dgp_soft_argmax(const float* scmap, int32_t B, int32_t H, int32_t W, int32_t C, float gamma, int32_t gauss_len,
+                    float* mu, float* conf, int32_t* idx, float* pmap, void* stream) {
+    if (!scmap || !mu || !conf || !idx) return fail(DGP_ERR_INVALID, "dgp_soft_argmax: null argument");
+    if (B < 0 || H < 1 || W < 1 || C < 1 || gauss_len < 0 || gauss_len > 7)
+        return fail(DGP_ERR_INVALID, "dgp_soft_argmax: bad shape / gauss_len (0..7)");
+    if ((size_t)H * W * sizeof(float) > 150 * 1024) return fail(DGP_ERR_INVALID, "dgp_soft_argmax: map exceeds LDS");
+    if (B == 0) return DGP_OK;
+    hipError_t e = launch_soft_argmax(scmap, B, H, W, C, gamma, gauss_len, mu, conf, idx, pmap, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("soft_argmax: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
+int dgp_hard_argmax(const float* scmap, const float* locref, int32_t B, int32_t H, int32_t W, int32_t C,
+                    int32_t* idx, float* prob, float* offs, void* stream) {
+    if (!scmap || !idx || !prob || !offs) return fail(DGP_ERR_INVALID, "dgp_hard_argmax: null argument");
+    if (B < 0 || H < 1 || W < 1 || C < 1) return fail(DGP_ERR_INVALID, "dgp_hard_argmax: bad shape");
+    if (B == 0) return DGP_OK;
+    hipError_t e = launch_hard_argmax(scmap, locref, B, H, W, C, idx, prob, offs, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("hard_argmax: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
+int dgp_infer(dgp_net* net, const uint8_t* frames, int32_t batch, void* workspace, size_t workspace_bytes, float gamma,
+              int32_t gauss_len, float* mu, float* conf, int32_t* idx, float* scmap_out, void* stream) {
+    if (!net) return fail(DGP_ERR_INVALID, "dgp_infer: null net");
+    int rc = dgp_forward(net, frames, batch, workspace, workspace_bytes, scmap_out, nullptr, nullptr, stream);
+    if (rc) return rc;
+    const float* sm = scmap_out ? scmap_out : (const float*)((char*)workspace + make_plan(net, batch).off_scmap);
+    return dgp_soft_argmax(sm, batch, 2 * net->fh, 2 * net->fw, net->desc.num_joints, gamma, gauss_len, mu, conf, idx,
+                           nullptr, stream);
+}
+
+size_t dgp_packed_weight_floats(int32_t KH, int32_t KW, int32_t Cin, int32_t Cout) {
+    if (KH < 1 || KW < 1 || Cin < 4 || (Cin & 3) || Cout < 1) return 0;
+    return (size_t)nk_for(KH, KW, Cin) * 8 * coutp_for(Cout) * 4;
+}
+
+int dgp_pack_conv_weights(const float* hwio, int32_t KH, int32_t KW, int32_t Cin, int32_t Cout, float* packed) {
+    if (!hwio || !packed || dgp_packed_weight_floats(KH, KW, Cin, Cout) == 0)
+        return fail(DGP_ERR_INVALID, "dgp_pack_conv_weights: bad argument (Cin must be a multiple of 4)");
+    if ((Cin / 4) & (Cin / 4 - 1)) return fail(DGP_ERR_INVALID, "dgp_pack_conv_weights: Cin/4 must be a power of two");
+    pack_panels(hwio, KH, KW, Cin, Cout, packed);
+    return DGP_OK;
+}
+
+int dgp_conv2d(const dgp_conv_desc* d, const float* x, const float* packed_w, const float* scale, const float* bias,
+               const float* residual, float* y, void* stream) {
+    if (!d || !x || !packed_w || !y) return fail(DGP_ERR_INVALID, "dgp_conv2d: null argument");
+    if (d->Cin < 4 || (d->Cin & 3) || ((d->Cin / 4) & (d->Cin / 4 - 1)))
+        return fail(DGP_ERR_INVALID, "dgp_conv2d: Cin must be 4 * 2^k");
+    if (d->res_stride > 0 && !residual) return fail(DGP_ERR_INVALID, "dgp_conv2d: residual missing");
+    ConvArgs a{};
+    a.in = x; a.wpk = packed_w; a.scale = scale; a.bias = bias; a.res = d->res_stride > 0 ? residual : nullptr;
+    a.out = y; a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.log2cin4 = ilog2(d->Cin / 4);
+    a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.CoutP = coutp_for(d->Cout);
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.dil = d->rate; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
+    a.ntaps = d->KH * d->KW; a.nk = nk_for(d->KH, d->KW, d->Cin); a.M = d->N * d->Ho * d->Wo;
+    a.res_s = d->res_stride; a.res_H = d->res_H; a.res_W = d->res_W; a.relu = d->relu; a.out_mode = 0; a.dc_nj = 0;
+    hipError_t e = launch_conv(a, pick_tile(a.M, a.CoutP, a.nk * BK), (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_conv2d: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
+int dgp_maxpool_3x3s2_same(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, float* y, void* stream) {
+    if (!x || !y || (C & 3)) return fail(DGP_ERR_INVALID, "dgp_maxpool_3x3s2_same: bad argument (C % 4)");
+    hipError_t e = launch_maxpool(x, N, H, W, C, y, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("maxpool: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
+int dgp_preprocess_u8(const uint8_t* frames, int64_t n_pixels, const float mean[3], float* out_nhwc4, void* stream) {
+    if (!frames || !mean || !out_nhwc4) return fail(DGP_ERR_INVALID, "dgp_preprocess_u8: null argument");
+    hipError_t e = launch_preprocess(frames, n_pixels, mean[0], mean[1], mean[2], out_nhwc4, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("preprocess: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
+}  // extern "C"

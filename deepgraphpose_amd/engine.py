@@ -1,0 +1,235 @@
+"""Torch-facing wrapper over the C-ABI (include/dgp_hip.h).
+
+torch is plumbing here: it owns device memory and streams; every computation on the hot
+path is a HIP kernel in libdgp_hip.so reached through ctypes.  Nothing in this module
+falls back to torch ops or to the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .arch import MEAN_PIXEL, BN_EPS
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _need_cuda(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise _lib.DgpError("%s must be a device (cuda/HIP) tensor" % name)
+    if t.dtype != dtype:
+        raise _lib.DgpError("%s must have dtype %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise _lib.DgpError("%s must be contiguous" % name)
+
+
+class DGPNet:
+    """ResNet-v1 backbone + DGP heads on one MI355X.
+
+    Replaces the TF graph built by setup_dgp_eval_graph (DGP/models/eval.py:147-214):
+    `forward` is sess.run(scmap), `infer` is the whole per-frame body of estimate_pose's loop
+    (eval.py:306-345) for a batch of frames.
+    """
+
+    def __init__(self, depth: int = 50, num_joints: int = 4, in_h: int = 480, in_w: int = 640,
+                 max_batch: int = 32, with_locref: bool = False, device: int = 0,
+                 mean_pixel=MEAN_PIXEL, bn_eps: float = BN_EPS):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.DgpError("no HIP device visible: DGPNet needs an MI355X (there is no CPU fallback)")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        d = _lib.DgpNetDesc(depth, num_joints, in_h, in_w, max_batch, int(with_locref),
+                            (C.c_float * 3)(*mean_pixel), bn_eps)
+        h = C.c_void_p()
+        _lib.check(self.lib.dgp_net_create(C.byref(d), C.byref(h)), "dgp_net_create")
+        self._h = h
+        self.depth, self.nj, self.in_h, self.in_w = depth, num_joints, in_h, in_w
+        self.max_batch, self.with_locref = max_batch, with_locref
+        oh, ow, fh, fw = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(self.lib.dgp_net_output_dims(h, C.byref(oh), C.byref(ow), C.byref(fh), C.byref(fw)))
+        self.out_h, self.out_w, self.feat_h, self.feat_w = oh.value, ow.value, fh.value, fw.value
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_batch = 0
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self.lib.dgp_net_destroy(h)
+            self._h = None
+
+    # -- weights ---------------------------------------------------------------------
+    def load_weights(self, weights: Dict[str, np.ndarray]):
+        """weights: TF variable name -> fp32 array in TF layout (see synthetic.make_weights)."""
+        keep = []
+        views = (_lib.DgpTensorView * len(weights))()
+        for i, (k, v) in enumerate(weights.items()):
+            a = np.ascontiguousarray(v, dtype=np.float32)
+            keep.append(a)
+            views[i].name = k.encode()
+            views[i].data = a.ctypes.data_as(C.POINTER(C.c_float))
+            views[i].ndim = a.ndim
+            for j in range(4):
+                views[i].shape[j] = a.shape[j] if j < a.ndim else 1
+        _lib.check(self.lib.dgp_net_load_weights(self._h, views, len(weights)), "dgp_net_load_weights")
+
+    # -- workspace -------------------------------------------------------------------
+    def workspace(self, batch: int) -> torch.Tensor:
+        if self._ws is None or batch > self._ws_batch:
+            n = C.c_size_t()
+            _lib.check(self.lib.dgp_net_workspace_bytes(self._h, batch, C.byref(n)), "dgp_net_workspace_bytes")
+            self._ws = torch.empty(n.value, dtype=torch.uint8, device=self.device)
+            self._ws_batch = batch
+        return self._ws
+
+    def stats(self, batch: int) -> Tuple[int, float]:
+        nl, fl = C.c_int32(), C.c_double()
+        _lib.check(self.lib.dgp_net_stats(self._h, batch, C.byref(nl), C.byref(fl)))
+        return nl.value, fl.value
+
+    # -- compute ---------------------------------------------------------------------
+    def forward(self, frames: torch.Tensor, want_locref: bool = False, want_features: bool = False):
+        """frames uint8 [B,H,W,3] on device -> scmap [B,out_h,out_w,nj] (and locref / features)."""
+        _need_cuda(frames, torch.uint8, "frames")
+        B = frames.shape[0]
+        if tuple(frames.shape[1:]) != (self.in_h, self.in_w, 3):
+            raise _lib.DgpError("frames must be [B,%d,%d,3], got %s" % (self.in_h, self.in_w, tuple(frames.shape)))
+        ws = self.workspace(B)
+        scmap = torch.empty((B, self.out_h, self.out_w, self.nj), dtype=torch.float32, device=self.device)
+        locref = torch.empty((B, self.out_h, self.out_w, 2 * self.nj), dtype=torch.float32,
+                             device=self.device) if want_locref else None
+        feats = torch.empty((B, self.feat_h, self.feat_w, 2048), dtype=torch.float32,
+                            device=self.device) if want_features else None
+        _lib.check(self.lib.dgp_forward(self._h, _ptr(frames), B, _ptr(ws), ws.numel(), _ptr(scmap), _ptr(locref),
+                                        _ptr(feats), _stream(self.device)), "dgp_forward")
+        out = [scmap]
+        if want_locref:
+            out.append(locref)
+        if want_features:
+            out.append(feats)
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def infer(self, frames: torch.Tensor, gamma: float = 1.0, gauss_len: int = 1, out=None,
+              scmap_out: Optional[torch.Tensor] = None):
+        """Fused frames -> (mu [B,nj,2] (row,col), conf [B,nj], idx [B,nj,2] int32)."""
+        _need_cuda(frames, torch.uint8, "frames")
+        B = frames.shape[0]
+        if tuple(frames.shape[1:]) != (self.in_h, self.in_w, 3):
+            raise _lib.DgpError("frames must be [B,%d,%d,3], got %s" % (self.in_h, self.in_w, tuple(frames.shape)))
+        ws = self.workspace(B)
+        if out is None:
+            mu = torch.empty((B, self.nj, 2), dtype=torch.float32, device=self.device)
+            conf = torch.empty((B, self.nj), dtype=torch.float32, device=self.device)
+            idx = torch.empty((B, self.nj, 2), dtype=torch.int32, device=self.device)
+        else:
+            mu, conf, idx = out
+        _lib.check(self.lib.dgp_infer(self._h, _ptr(frames), B, _ptr(ws), ws.numel(), float(gamma), int(gauss_len),
+                                      _ptr(mu), _ptr(conf), _ptr(idx), _ptr(scmap_out), _stream(self.device)),
+                   "dgp_infer")
+        return mu, conf, idx
+
+
+# ---------------------------------------------------------------------------------------
+# stand-alone operators
+# ---------------------------------------------------------------------------------------
+def soft_argmax(scmap: torch.Tensor, gamma: float = 1.0, gauss_len: int = 2, want_pmap: bool = False):
+    """HIP argmax_2d_from_cm (+ likelihood window).  scmap fp32 [B,H,W,C] on device."""
+    lib = _lib.load()
+    _need_cuda(scmap, torch.float32, "scmap")
+    if scmap.dim() != 4:
+        raise _lib.DgpError("scmap must be rank 4 [B,H,W,C]")      # fitdgp_util.py:357 assert rank == 4
+    B, H, W, Cn = scmap.shape
+    dev = scmap.device
+    mu = torch.empty((B, Cn, 2), dtype=torch.float32, device=dev)
+    conf = torch.empty((B, Cn), dtype=torch.float32, device=dev)
+    idx = torch.empty((B, Cn, 2), dtype=torch.int32, device=dev)
+    pmap = torch.empty_like(scmap) if want_pmap else None
+    _lib.check(lib.dgp_soft_argmax(_ptr(scmap), B, H, W, Cn, float(gamma), int(gauss_len), _ptr(mu), _ptr(conf),
+                                   _ptr(idx), _ptr(pmap), _stream(dev)), "dgp_soft_argmax")
+    return (mu, conf, idx, pmap) if want_pmap else (mu, conf, idx)
+
+
+def hard_argmax(scmap: torch.Tensor, locref: Optional[torch.Tensor] = None):
+    """HIP DLC arg-max: idx [B,C,2] (row,col), prob [B,C], offs [B,C,2] (dx,dy raw locref)."""
+    lib = _lib.load()
+    _need_cuda(scmap, torch.float32, "scmap")
+    B, H, W, Cn = scmap.shape
+    if locref is not None:
+        _need_cuda(locref, torch.float32, "locref")
+        if tuple(locref.shape) != (B, H, W, 2 * Cn):
+            raise _lib.DgpError("locref must be [B,H,W,2*C]")
+    dev = scmap.device
+    idx = torch.empty((B, Cn, 2), dtype=torch.int32, device=dev)
+    prob = torch.empty((B, Cn), dtype=torch.float32, device=dev)
+    offs = torch.empty((B, Cn, 2), dtype=torch.float32, device=dev)
+    _lib.check(lib.dgp_hard_argmax(_ptr(scmap), _ptr(locref), B, H, W, Cn, _ptr(idx), _ptr(prob), _ptr(offs),
+                                   _stream(dev)), "dgp_hard_argmax")
+    return idx, prob, offs
+
+
+def pack_conv_weights(w_hwio: np.ndarray) -> np.ndarray:
+    lib = _lib.load()
+    w = np.ascontiguousarray(w_hwio, dtype=np.float32)
+    kh, kw, cin, cout = w.shape
+    n = lib.dgp_packed_weight_floats(kh, kw, cin, cout)
+    if n == 0:
+        raise _lib.DgpError("unsupported conv weight shape %s (Cin must be 4*2^k)" % (w.shape,))
+    out = np.empty(n, dtype=np.float32)
+    _lib.check(lib.dgp_pack_conv_weights(w.ctypes.data_as(C.c_void_p), kh, kw, cin, cout,
+                                         out.ctypes.data_as(C.c_void_p)), "dgp_pack_conv_weights")
+    return out
+
+
+def conv2d(x: torch.Tensor, w_hwio: np.ndarray, stride: int = 1, rate: int = 1, pad_t: int = 0, pad_l: int = 0,
+           out_hw: Optional[Tuple[int, int]] = None, scale=None, bias=None, residual: Optional[torch.Tensor] = None,
+           res_stride: int = 0, relu: bool = False) -> torch.Tensor:
+    """Single conv layer through the implicit-GEMM kernel (NHWC fp32)."""
+    lib = _lib.load()
+    _need_cuda(x, torch.float32, "x")
+    N, H, W, Cin = x.shape
+    kh, kw, cin2, cout = w_hwio.shape
+    assert cin2 == Cin
+    dev = x.device
+    if out_hw is None:
+        keh, kew = (kh - 1) * rate + 1, (kw - 1) * rate + 1
+        out_hw = ((H + 2 * pad_t - keh) // stride + 1, (W + 2 * pad_l - kew) // stride + 1)
+    Ho, Wo = out_hw
+    wp = torch.from_numpy(pack_conv_weights(w_hwio)).to(dev)
+    sc = None if scale is None else torch.as_tensor(scale, dtype=torch.float32).contiguous().to(dev)
+    bi = None if bias is None else torch.as_tensor(bias, dtype=torch.float32).contiguous().to(dev)
+    y = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=dev)
+    rh, rw = (residual.shape[1], residual.shape[2]) if residual is not None else (0, 0)
+    d = _lib.DgpConvDesc(N, H, W, Cin, cout, kh, kw, stride, rate, pad_t, pad_l, Ho, Wo, int(relu),
+                         res_stride if residual is not None else 0, rh, rw)
+    _lib.check(lib.dgp_conv2d(C.byref(d), _ptr(x), _ptr(wp), _ptr(sc), _ptr(bi), _ptr(residual), _ptr(y),
+                              _stream(dev)), "dgp_conv2d")
+    return y
+
+
+def maxpool_3x3s2_same(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _need_cuda(x, torch.float32, "x")
+    N, H, W, Cn = x.shape
+    y = torch.empty((N, (H + 1) // 2, (W + 1) // 2, Cn), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dgp_maxpool_3x3s2_same(_ptr(x), N, H, W, Cn, _ptr(y), _stream(x.device)), "dgp_maxpool")
+    return y
+
+
+def preprocess_u8(frames: torch.Tensor, mean=MEAN_PIXEL) -> torch.Tensor:
+    lib = _lib.load()
+    _need_cuda(frames, torch.uint8, "frames")
+    out = torch.empty(tuple(frames.shape[:-1]) + (4,), dtype=torch.float32, device=frames.device)
+    m = (C.c_float * 3)(*mean)
+    _lib.check(lib.dgp_preprocess_u8(_ptr(frames), frames.numel() // 3, m, _ptr(out), _stream(frames.device)),
+               "dgp_preprocess_u8")
+    return out

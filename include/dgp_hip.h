@@ -1,0 +1,137 @@
+/*
+ * dgp_hip.h -- C-ABI of libdgp_hip.so, the MI355X (gfx950) engine for the Deep Graph
+ * Pose hot path.  Plain pointers and sizes only; every device pointer is memory the
+ * CALLER owns (e.g. torch tensors), `stream` is a hipStream_t passed as void*.
+ *
+ * The reference (paninski-lab/deepgraphpose) has no FFI: its boundary for this path is
+ * one TF-1.x session call.  Each entry point below names the reference interface it
+ * replaces (paths relative to the reference root; PET = src/DeepLabCut/deeplabcut/
+ * pose_estimation_tensorflow, DGP = src/deepgraphpose):
+ *
+ *   dgp_forward        sess.run(scmap[,locref], {inputs: frames})   DGP/models/eval.py:328
+ *                      graph: PET/nnet/pose_net.py:36-54 (extract_features) +
+ *                             DGP/models/fitdgp_util.py:18-74 (dgp_prediction_layer)
+ *   dgp_soft_argmax    argmax_2d_from_cm                            DGP/models/fitdgp_util.py:342-402
+ *                      + likelihood read-out                        DGP/models/eval.py:331-343
+ *   dgp_hard_argmax    argmax_pose_predict                          PET/nnet/predict.py:62-77
+ *   dgp_infer          sess.run([mu_n, scmap]) + read-out           DGP/models/eval.py:306-345
+ *   dgp_net_create /   setup_dgp_eval_graph (graph build + Saver.restore)
+ *   dgp_net_load_weights                                            DGP/models/eval.py:147-214
+ *
+ * All functions return 0 on success or a negative dgp_status; dgp_last_error() gives a
+ * thread-local message.  All launches are asynchronous on `stream`; no hidden syncs.
+ * A dgp_net handle is bound to the device current at creation and is not thread-safe.
+ */
+#ifndef DGP_HIP_H
+#define DGP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGP_ABI_VERSION 1
+
+typedef enum dgp_status {
+    DGP_OK = 0,
+    DGP_ERR_INVALID = -1,     /* bad argument / shape */
+    DGP_ERR_HIP = -2,         /* HIP runtime error (see dgp_last_error) */
+    DGP_ERR_MISSING = -3,     /* a required weight tensor was not supplied */
+    DGP_ERR_STATE = -4        /* e.g. forward before load_weights */
+} dgp_status;
+
+typedef struct dgp_net dgp_net;   /* opaque */
+
+typedef struct dgp_net_desc {
+    int32_t depth;        /* 50 | 101 | 152 (net_type resnet_50 / resnet_101, PET/nnet/pose_net.py:14-16) */
+    int32_t num_joints;   /* cfg.num_joints */
+    int32_t in_h, in_w;   /* frame size */
+    int32_t max_batch;
+    int32_t with_locref;  /* build pose/locref_pred head too (cfg.location_refinement) */
+    float   mean_pixel[3];/* cfg.mean_pixel, RGB (PET/default_config.py:23) */
+    float   bn_eps;       /* slim resnet_arg_scope epsilon, 1e-5 */
+} dgp_net_desc;
+
+/* One named weight tensor in the TF variable layout (HWIO convs, [kh,kw,Cout,Cin]
+ * transposed convs, [C] vectors), fp32, host memory. */
+typedef struct dgp_tensor_view {
+    const char*  name;    /* TF variable name, e.g. "resnet_v1_50/conv1/weights" */
+    const float* data;
+    int32_t      ndim;
+    int64_t      shape[4];
+} dgp_tensor_view;
+
+int          dgp_version(void);
+const char*  dgp_last_error(void);
+
+int  dgp_net_create(const dgp_net_desc* desc, dgp_net** out);
+void dgp_net_destroy(dgp_net* net);
+/* Copies + repacks (k-chunked weight panels, BN folded to scale/bias).  Synchronous. */
+int  dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n);
+int  dgp_net_workspace_bytes(const dgp_net* net, int32_t batch, size_t* out_bytes);
+/* Output geometry of the heads: scoremap is [batch, out_h, out_w, num_joints]. */
+int  dgp_net_output_dims(const dgp_net* net, int32_t* out_h, int32_t* out_w,
+                         int32_t* feat_h, int32_t* feat_w);
+/* Number of conv-stack kernel launches of one forward and their algorithmic FLOPs. */
+int  dgp_net_stats(const dgp_net* net, int32_t batch, int32_t* n_launches, double* conv_flops);
+
+/* frames: device uint8 [batch, in_h, in_w, 3] NHWC (RGB).
+ * scmap : device fp32 [batch, out_h, out_w, nj]      (raw logits, pose/part_pred)
+ * locref: device fp32 [batch, out_h, out_w, 2*nj] or NULL
+ * features: optional device fp32 [batch, feat_h, feat_w, 2048] copy-out, or NULL */
+int  dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* workspace,
+                 size_t workspace_bytes, float* scmap, float* locref, float* features,
+                 void* stream);
+
+/* DGP soft-argmax + likelihood window.
+ * scmap [B,H,W,C] fp32 -> mu [B,C,2] (row, col) fp32, conf [B,C] fp32 (sigmoid of the raw
+ * logit at the window arg-max), idx [B,C,2] int32 (row, col), pmap optional [B,H,W,C]. */
+int  dgp_soft_argmax(const float* scmap, int32_t B, int32_t H, int32_t W, int32_t C,
+                     float gamma, int32_t gauss_len, float* mu, float* conf, int32_t* idx,
+                     float* pmap, void* stream);
+
+/* DLC hard arg-max over sigmoid(scmap).  idx [B,C,2] (row, col), prob [B,C],
+ * offs [B,C,2] = locref[b,row,col,2c..2c+1] (dx, dy; NOT yet scaled by locref_stdev) or
+ * zeros when locref == NULL. */
+int  dgp_hard_argmax(const float* scmap, const float* locref, int32_t B, int32_t H, int32_t W,
+                     int32_t C, int32_t* idx, float* prob, float* offs, void* stream);
+
+/* Fused A1..A4: frames -> (mu, conf, idx); scoremap stays in the workspace unless
+ * scmap_out != NULL. */
+int  dgp_infer(dgp_net* net, const uint8_t* frames, int32_t batch, void* workspace,
+               size_t workspace_bytes, float gamma, int32_t gauss_len, float* mu, float* conf,
+               int32_t* idx, float* scmap_out, void* stream);
+
+/* ---- single-layer entry points (used by the parity tests and by fit_dgp later) ---- */
+
+/* slim.conv2d / conv2d_same semantics on NHWC fp32 with HWIO weights supplied packed by
+ * dgp_pack_conv_weights.  y = relu?( conv(x) * scale + bias (+ residual) ). */
+typedef struct dgp_conv_desc {
+    int32_t N, H, W, Cin;          /* input  (Cin % 4 == 0) */
+    int32_t Cout;                  /* real output channels */
+    int32_t KH, KW, stride, rate;
+    int32_t pad_t, pad_l;          /* zero padding before (TF SAME / conv2d_same) */
+    int32_t Ho, Wo;                /* output spatial size */
+    int32_t relu;                  /* 1: apply ReLU */
+    int32_t res_stride;            /* 0: no residual; s>=1: residual[n, ho*s, wo*s, :] */
+    int32_t res_H, res_W;          /* residual spatial size */
+} dgp_conv_desc;
+
+size_t dgp_packed_weight_floats(int32_t KH, int32_t KW, int32_t Cin, int32_t Cout);
+/* host -> host repack: HWIO [KH,KW,Cin,Cout] -> k-chunked panels [Kp/4][CoutP][4] */
+int  dgp_pack_conv_weights(const float* hwio, int32_t KH, int32_t KW, int32_t Cin,
+                           int32_t Cout, float* packed);
+int  dgp_conv2d(const dgp_conv_desc* d, const float* x, const float* packed_w,
+                const float* scale /*[Cout] or NULL*/, const float* bias /*[Cout] or NULL*/,
+                const float* residual, float* y, void* stream);
+int  dgp_maxpool_3x3s2_same(const float* x, int32_t N, int32_t H, int32_t W, int32_t C,
+                            float* y, void* stream);
+int  dgp_preprocess_u8(const uint8_t* frames, int64_t n_pixels, const float mean[3],
+                       float* out_nhwc4, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGP_HIP_H */

@@ -1,0 +1,220 @@
+"""GPU parity tests: HIP path (through the C-ABI) vs the CPU oracle on identical seeded inputs.
+
+Tolerances (north_star): integer indices bit-exact; soft-argmax coordinates within 1e-3 px
+(= 1.25e-4 scoremap cells at stride 8); layer outputs within fp32 accumulation-order noise.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+PX_TOL = 1e-3          # px, north_star
+STRIDE = 8.0
+
+
+@pytest.fixture(scope="module")
+def eng(lib_built):
+    from deepgraphpose_amd import engine
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return engine
+
+
+def _rel_err(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+# ---------------------------------------------------------------------------- layers
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, rate, same_explicit
+    (2, 17, 23, 64, 64, 1, 1, 1),
+    (2, 17, 23, 64, 256, 1, 1, 1),
+    (1, 30, 40, 256, 64, 1, 1, 1),
+    (2, 19, 21, 64, 64, 3, 1, 1),
+    (2, 19, 21, 64, 64, 3, 2, 1),
+    (1, 15, 20, 128, 128, 3, 1, 2),
+    (1, 9, 11, 512, 512, 3, 1, 2),
+    (2, 20, 24, 256, 512, 1, 2, 1),
+    (1, 33, 47, 4, 64, 7, 2, 1),
+    (1, 8, 8, 2048, 16, 2, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_layer_matches_oracle(eng, case):
+    from oracle import dgp_oracle as O
+    N, H, W, Cin, Cout, k, stride, rate = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    scale = (1 + 0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    xt = O._to_nchw(x)
+    if k == 2:      # the head's 2x2 conv: pad 1 before, 0 after
+        ref = O.conv2d(torch.nn.functional.pad(xt, (1, 0, 1, 0)), w, 1, 1, "VALID")
+        pad = 1
+    else:
+        ref = O.conv2d_same(xt, w, stride, rate)
+        keff = (k - 1) * rate + 1
+        pad = (keff - 1) // 2 if stride > 1 else O.tf_same_pads(H, k, stride, rate)[1]
+    ref = O._to_nhwc(ref) * scale + bias
+    ref = np.maximum(ref, 0)
+    y = eng.conv2d(torch.from_numpy(x).cuda(), w, stride=stride, rate=rate, pad_t=pad, pad_l=pad,
+                   out_hw=ref.shape[1:3], scale=scale, bias=bias, relu=True).cpu().numpy()
+    assert y.shape == ref.shape
+    assert _rel_err(y, ref) < 2e-5
+
+
+def test_conv_residual_and_subsample(eng):
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 10, 12, 64)).astype(np.float32)
+    w = (rng.standard_normal((1, 1, 64, 256)) / 8).astype(np.float32)
+    res_full = rng.standard_normal((2, 19, 24, 256)).astype(np.float32)      # subsampled by 2 -> 10 x 12
+    ref = O._to_nhwc(O.conv2d(O._to_nchw(x), w, 1)) + res_full[:, ::2, ::2, :]
+    ref = np.maximum(ref, 0)
+    y = eng.conv2d(torch.from_numpy(x).cuda(), w, residual=torch.from_numpy(res_full).cuda(), res_stride=2,
+                   relu=True).cpu().numpy()
+    assert _rel_err(y, ref) < 2e-5
+    res_same = rng.standard_normal((2, 10, 12, 256)).astype(np.float32)
+    ref = O._to_nhwc(O.conv2d(O._to_nchw(x), w, 1)) + res_same
+    y = eng.conv2d(torch.from_numpy(x).cuda(), w, residual=torch.from_numpy(res_same).cuda(), res_stride=1).cpu().numpy()
+    assert _rel_err(y, ref) < 2e-5
+
+
+@pytest.mark.parametrize("hw", [(240, 320), (187, 101), (6, 7)])
+def test_maxpool_bit_exact(eng, hw):
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2,) + hw + (64,)).astype(np.float32)
+    ref = O._to_nhwc(O.max_pool_same(O._to_nchw(x), 3, 2))
+    y = eng.maxpool_3x3s2_same(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert y.shape == ref.shape
+    assert np.array_equal(y, ref)
+
+
+def test_preprocess_bit_exact(eng):
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(2)
+    f = rng.integers(0, 256, size=(2, 33, 35, 3), dtype=np.uint8)
+    ref = f.astype(np.float32) - np.asarray(O.MEAN_PIXEL, dtype=np.float32)
+    y = eng.preprocess_u8(torch.from_numpy(f).cuda()).cpu().numpy()
+    assert np.array_equal(y[..., :3], ref)
+    assert np.all(y[..., 3] == 0)
+
+
+# ---------------------------------------------------------------------------- soft-argmax
+def _peaky_scmap(rng, B, H, W, C, amp=8.0):
+    s = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for b in range(B):
+        for c in range(C):
+            cy, cx = rng.uniform(0, H - 1), rng.uniform(0, W - 1)
+            s[b, :, :, c] += amp * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / 8.0)
+    return s
+
+
+@pytest.mark.parametrize("shape,gl,gamma", [((3, 60, 80, 4), 1, 1.0), ((2, 94, 104, 5), 1, 1.0),
+                                            ((1, 90, 160, 20), 2, 1.0), ((2, 60, 80, 4), 2, 0.5),
+                                            ((2, 7, 5, 3), 1, 2.0), ((1, 1, 1, 1), 1, 1.0)])
+def test_soft_argmax_matches_oracle(eng, shape, gl, gamma):
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(7)
+    s = _peaky_scmap(rng, *shape)
+    mu_ref, pm_ref = O.argmax_2d_from_cm(s, gamma, gl)
+    mu64, _ = O.argmax_2d_from_cm(s, gamma, gl, dtype=np.float64)
+    mu, conf, idx, pmap = eng.soft_argmax(torch.from_numpy(s).cuda(), gamma, gl, want_pmap=True)
+    mu, conf, idx, pmap = mu.cpu().numpy(), conf.cpu().numpy(), idx.cpu().numpy(), pmap.cpu().numpy()
+    assert np.abs(mu - mu_ref).max() * STRIDE < PX_TOL
+    assert np.abs(mu - mu64).max() * STRIDE < PX_TOL
+    assert np.abs(pmap - pm_ref).max() < 1e-6
+    for b in range(shape[0]):
+        iref, lref = O.likelihood_window(s[b], mu[b])
+        assert np.array_equal(idx[b], iref)
+        assert np.abs(conf[b] - lref).max() < 2e-6
+
+
+def test_soft_argmax_known_answers(eng):
+    """One-hot scoremaps: closed-form expectation incl. the zero-padded border cells."""
+    from oracle import dgp_oracle as O
+    H, W = 12, 9
+    g = O.gaussian_taps(1)
+    np.testing.assert_allclose(g, [0.27406862, 0.45186276, 0.27406862], rtol=1e-6)
+    for (r, c) in [(5, 4), (0, 0), (11, 8), (0, 4)]:
+        s = np.full((1, H, W, 1), -200.0, dtype=np.float32)
+        s[0, r, c, 0] = 0.0
+        mu, conf, idx = eng.soft_argmax(torch.from_numpy(s).cuda(), 1.0, 1)
+        def exp1(p, n):
+            ks = [(p + d, g[d + 1]) for d in (-1, 0, 1) if 0 <= p + d < n]
+            return sum(a * b for a, b in ks) / sum(b for _, b in ks)
+        assert abs(mu[0, 0, 0].item() - exp1(r, H)) < 1e-5
+        assert abs(mu[0, 0, 1].item() - exp1(c, W)) < 1e-5
+
+
+def test_likelihood_tie_takes_first(eng):
+    s = np.zeros((1, 6, 6, 1), dtype=np.float32)          # flat map: mu = centre 2.5, window 2x2, all tied
+    mu, conf, idx = eng.soft_argmax(torch.from_numpy(s).cuda(), 1.0, 1)
+    assert idx.cpu().numpy().tolist() == [[[2, 2]]]
+    assert abs(conf.item() - 0.5) < 1e-7
+
+
+@pytest.mark.parametrize("with_locref", [False, True])
+def test_hard_argmax_bit_exact(eng, with_locref):
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(11)
+    B, H, W, C = 3, 60, 80, 4
+    s = _peaky_scmap(rng, B, H, W, C)
+    s[0, 10, 10, 0] = s[0, 40, 70, 0] = 50.0          # exact tie -> first in row-major order
+    loc = rng.standard_normal((B, H, W, 2 * C)).astype(np.float32) if with_locref else None
+    idx, prob, offs = eng.hard_argmax(torch.from_numpy(s).cuda(), None if loc is None else torch.from_numpy(loc).cuda())
+    idx, prob, offs = idx.cpu().numpy(), prob.cpu().numpy(), offs.cpu().numpy()
+    from deepgraphpose_amd.models.predict import pose_from_argmax
+    for b in range(B):
+        sig = O.sigmoid_f32(s[b])
+        offmat = None if loc is None else loc[b].reshape(H, W, C, 2) * np.float32(7.2801)
+        pose_ref, loc_ref = O.argmax_pose_predict(sig, offmat, 8.0)
+        assert np.array_equal(idx[b], loc_ref)
+        pose = pose_from_argmax(idx[b], prob[b], offs[b] if with_locref else None, 8.0, 7.2801)
+        np.testing.assert_allclose(pose[:, :2], pose_ref[:, :2], atol=1e-4)
+        np.testing.assert_allclose(pose[:, 2], pose_ref[:, 2], atol=2e-6)
+    assert idx[0, 0].tolist() == [10, 10]
+
+
+# ---------------------------------------------------------------------------- whole net
+@pytest.mark.parametrize("hw,depth,nj,B", [((96, 128), 50, 4, 3), ((75, 83), 50, 5, 2)])
+def test_network_small_matches_oracle(eng, hw, depth, nj, B):
+    from oracle import dgp_oracle as O
+    from deepgraphpose_amd.synthetic import make_weights, make_frames
+    wts = make_weights(depth, nj, True, seed=3, head_std=0.05)
+    frames = make_frames(B, hw[0], hw[1], nj, seed=4)
+    net = eng.DGPNet(depth, nj, hw[0], hw[1], max_batch=B, with_locref=True)
+    net.load_weights(wts)
+    scmap, locref, feats = net.forward(torch.from_numpy(frames).cuda(), want_locref=True, want_features=True)
+    f_ref = O.resnet_features(frames, wts, depth)
+    s_ref, l_ref = O.pose_heads(f_ref, wts, True)
+    assert feats.shape == f_ref.shape and scmap.shape == s_ref.shape and locref.shape == l_ref.shape
+    assert _rel_err(feats.cpu().numpy(), f_ref) < 1e-4
+    assert _rel_err(scmap.cpu().numpy(), s_ref) < 1e-4
+    assert _rel_err(locref.cpu().numpy(), l_ref) < 1e-4
+
+
+def test_infer_640x480_r50_matches_oracle(eng):
+    """BASELINE config 2 shapes (ResNet-50, 640x480, 4 joints), batch 2 so the oracle takes seconds."""
+    from oracle import dgp_oracle as O
+    from deepgraphpose_amd.synthetic import make_weights, make_frames
+    nj, B = 4, 2
+    wts = make_weights(50, nj, False, seed=0, head_std=0.05)
+    frames = make_frames(B, 480, 640, nj, seed=0)
+    net = eng.DGPNet(50, nj, 480, 640, max_batch=B)
+    net.load_weights(wts)
+    scm = torch.empty((B, 60, 80, nj), dtype=torch.float32, device="cuda")
+    mu, conf, idx = net.infer(torch.from_numpy(frames).cuda(), gamma=1.0, gauss_len=1, scmap_out=scm)
+    ref = O.infer(frames, wts, 50, STRIDE, 1.0, 1)
+    mu = mu.cpu().numpy()
+    x = mu[:, :, 1].astype(np.float64) * STRIDE + 0.5 * STRIDE
+    y = mu[:, :, 0].astype(np.float64) * STRIDE + 0.5 * STRIDE
+    err_px = np.sqrt((x - ref["x"]) ** 2 + (y - ref["y"]) ** 2)
+    print("max px err", err_px.max(), "scmap rel err", _rel_err(scm.cpu().numpy(), ref["scmap"]))
+    assert err_px.max() < PX_TOL
+    assert np.array_equal(idx.cpu().numpy(), ref["idx"])
+    assert np.abs(conf.cpu().numpy() - ref["likelihoods"]).max() < 1e-4
