@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the DGP hot path on MI355X (BASELINE.json metric).
+
+Workload (config.workload): BASELINE configs[1] -- ResNet-50, 640x480x3 uint8 frames,
+4 keypoints, batch 32 per GPU, inference (backbone + part_pred head + DGP soft-argmax +
+likelihood), synthetic device-resident frames, seeded random-init weights.
+A "step" = one batch of 32 frames through dgp_infer on each GPU.  With N > 1 every rank
+processes its own contiguous frame shard and ONE RCCL all-gather (inside the timed region)
+reassembles the [T, nj] trajectory: weak scaling.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (conv kernel, MFMA-bound, fp32 matrix
+peak) from hipEvent pairs recorded around every launch inside the timed region, and
+"cpu_baseline" (the CPU oracle = fp32 torch-CPU restatement of the TF1 reference path, timed
+on this box's host cores on a bounded sample; TF1 itself cannot be installed here).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix
+H, W, NJ, BATCH = 480, 640, 4, 32
+STRIDE = 8.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames in the bounded CPU-baseline sample")
+    ap.add_argument("--layer-table", type=str, default="", help="write the per-launch table (tsv) here")
+    args = ap.parse_args()
+
+    from deepgraphpose_amd import dist as ddist
+    from deepgraphpose_amd import engine
+    from deepgraphpose_amd.arch import conv_macs_per_frame
+    from deepgraphpose_amd.synthetic import make_frames, make_weights
+    import torch.distributed as dist
+
+    rank, local_rank, world = ddist.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
+                         % (args.gpus, world))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    B, K, Wm = args.batch, args.steps, args.warmup
+    wts = make_weights(50, NJ, False, seed=0, head_std=0.05)
+    net = engine.DGPNet(50, NJ, H, W, max_batch=B, device=local_rank)
+    net.load_weights(wts)
+
+    # device-resident ring of 4 distinct batches per rank (distinct across ranks too)
+    RING = 4
+    base = make_frames(8, H, W, NJ, seed=100 + rank)
+    g = torch.Generator().manual_seed(1234 + rank)
+    ring = []
+    for r in range(RING):
+        sel = torch.randint(0, base.shape[0], (B,), generator=g).numpy()
+        noise = torch.randint(-3, 4, (B, H, W, 3), generator=g, dtype=torch.int16).numpy()
+        fr = np.clip(base[sel].astype(np.int16) + noise, 0, 255).astype(np.uint8)
+        ring.append(torch.from_numpy(fr).to(dev))
+    n_local = K * B
+    traj = torch.empty((n_local, NJ, 5), dtype=torch.float32, device=dev)
+    mu = torch.empty((B, NJ, 2), dtype=torch.float32, device=dev)
+    conf = torch.empty((B, NJ), dtype=torch.float32, device=dev)
+    idx = torch.empty((B, NJ, 2), dtype=torch.int32, device=dev)
+
+    def step(i, record=True):
+        net.infer(ring[i % RING], 1.0, 1, out=(mu, conf, idx))
+        if record:
+            traj[i * B:(i + 1) * B] = ddist.pack_keypoints(mu, conf, idx)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    for i in range(Wm):
+        step(i % max(K, 1))
+    if world > 1:   # warm the collective too
+        ddist.gather_trajectory(traj, world * n_local)
+    torch.cuda.synchronize(dev)
+
+    net.profile_begin(K)
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(i)
+    full = ddist.gather_trajectory(traj, world * n_local)
+    torch.cuda.synchronize(dev)
+    barrier()
+    t1 = time.perf_counter()
+    n_prof, launches = net.profile_end()
+
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    assert full.shape[0] == world * n_local
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    fps = world * n_local / elapsed
+    flop_frame = 2.0 * conv_macs_per_frame(H, W, 50, NJ, False)
+    conv = [(n, f, ms) for (n, f, ms) in launches if n.startswith("conv:")]
+    conv_ms = sum(ms for _, _, ms in conv)
+    conv_flops = sum(f for _, f, _ in conv)
+    other_ms = sum(ms for n, _, ms in launches if not n.startswith("conv:"))
+    achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    roofline = {
+        "bound": "mfma", "kernel": "conv_igemm_f32 (all %d conv launches of one step)" % len(conv),
+        "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        "algorithmic_gflop_per_frame": round(flop_frame / 1e9, 3),
+        "conv_ms_per_step": round(conv_ms, 3), "other_kernels_ms_per_step": round(other_ms, 3),
+        "steps_profiled": n_prof,
+        "whole_step_frac": round(flop_frame * B / (elapsed / K) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+    }
+    if args.layer_table:
+        os.makedirs(os.path.dirname(os.path.abspath(args.layer_table)), exist_ok=True)
+        with open(args.layer_table, "w") as f:
+            f.write("launch\tname\tgflop\tavg_ms\ttflops\n")
+            for i, (n, fl, ms) in enumerate(launches):
+                f.write("%d\t%s\t%.3f\t%.4f\t%.2f\n" % (i, n, fl / 1e9, ms, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0))
+
+    out = {
+        "metric": "frames_per_sec", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
+        "steps": K, "warmup": Wm, "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "ResNet-50 640x480x3 u8, 4 keypoints, batch %d/GPU, inference "
+                               "(scoremap + DGP soft-argmax + likelihood), BASELINE configs[1]" % B,
+                   "frames_per_step_per_gpu": B, "sharding": "contiguous frame shards, 1 RCCL all-gather per run"},
+        "roofline": roofline,
+    }
+
+    if not args.no_cpu_baseline:
+        from oracle import dgp_oracle as O      # checker / baseline only
+        nf = args.cpu_frames
+        fr = ring[0][:nf].cpu().numpy()
+        torch.set_num_threads(os.cpu_count() or 1)
+        O.infer(fr[:1], wts, 50, STRIDE, 1.0, 1)                       # warm-up
+        c0 = time.perf_counter()
+        ref = O.infer(fr, wts, 50, STRIDE, 1.0, 1)
+        c1 = time.perf_counter()
+        m, c, ix = net.infer(ring[0][:nf].contiguous(), 1.0, 1)
+        m = m.cpu().numpy().astype(np.float64)
+        ex = m[:, :, 1] * STRIDE + 0.5 * STRIDE - ref["x"]
+        ey = m[:, :, 0] * STRIDE + 0.5 * STRIDE - ref["y"]
+        err = np.sqrt(ex ** 2 + ey ** 2)
+        out["cpu_baseline"] = {
+            "value": round(nf / (c1 - c0), 3), "unit": "frames/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "%d frames of the same workload in one batch after a 1-frame warm-up; fp32 torch-CPU "
+                      "restatement of the TF1 reference path (TF1 unavailable)" % nf,
+        }
+        out["accuracy_vs_oracle"] = {
+            "px_rmse": float(np.sqrt((err ** 2).mean())), "px_max": float(err.max()), "frames": nf,
+            "idx_bit_exact": bool(np.array_equal(ix.cpu().numpy(), ref["idx"])),
+        }
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

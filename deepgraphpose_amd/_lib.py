@@ -41,6 +41,9 @@ SYMBOLS = {
     "dgp_soft_argmax": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "dgp_hard_argmax": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "dgp_infer": (C.c_int, [_vp, _vp, _i32, _vp, _sz, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "dgp_net_profile_begin": (C.c_int, [_vp, _i32]),
+    "dgp_net_profile_end": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "dgp_net_profile_launch": (C.c_int, [_vp, _i32, C.c_char_p, _i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dgp_packed_weight_floats": (_sz, [_i32, _i32, _i32, _i32]),
     "dgp_pack_conv_weights": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp]),
     "dgp_conv2d": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

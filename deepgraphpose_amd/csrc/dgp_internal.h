@@ -26,9 +26,10 @@ struct ConvArgs {
     int out_mode;         // 0: NHWC [M][Cout]; 1: transposed-conv phase scatter
     int dc_nj;            // channels per phase for out_mode 1
     int mtiles, ntiles;
+    unsigned in_bytes, w_bytes, res_bytes, out_bytes;   // buffer-descriptor extents (< 4 GiB each)
 };
 
-enum TileCfg { TILE_128x128 = 0, TILE_256x64 = 1, TILE_128x64 = 2, TILE_128x32 = 3, TILE_256x128 = 4 };
+enum TileCfg { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_128x32 = 3 };
 
 hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s);
 int        pick_tile(int M, int CoutP, int K);

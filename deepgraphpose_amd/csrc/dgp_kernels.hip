@@ -34,6 +34,16 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 // plane by one 16-byte slot so that the 8 lanes that write one pixel's 8 chunks hit
 // different banks.
 // ------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    // raw buffer load: an offset >= num_records returns zeros (hardware range check), which is
+    // how zero padding, ragged tile edges and padded taps are produced without data selects
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+
+constexpr unsigned OOB = 0xFFFFFFF0u;
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
     constexpr int WM = BM / WAVES_M;       // wave tile rows
@@ -43,8 +53,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
     constexpr int AROWS = BM / 32;         // A rows staged per thread
     constexpr int BSLOTS = 8 * BN / 256;   // B 16-byte slots staged per thread
     constexpr int LDA = BM + 1;            // slots per chunk plane of A
+    constexpr int LDC = WN + 4;            // floats per row of a wave's epilogue staging tile
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     static_assert(BSLOTS >= 1, "BN too small");
+    static_assert(4 * 32 * LDC * 4 <= (2 * 8 * LDA + 2 * 8 * BN) * 16, "epilogue staging must fit");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* sA = reinterpret_cast<float4*>(smem);     // [2][8][LDA]
@@ -70,11 +82,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
     const int m0 = mt * BM;
     const int n0 = nt * BN;
 
+    const __amdgpu_buffer_rsrc_t rs_in =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (int)p.w_bytes, 0x00020000);
+
     // ---- per-thread A row bookkeeping -------------------------------------------------
     const int c = t & 7;        // chunk within the K-step
     const int rg = t >> 3;      // 0..31
-    int hi0[AROWS], wi0[AROWS];
-    long long pix0[AROWS];
+    int hi0[AROWS], wi0[AROWS], pix0[AROWS];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
@@ -86,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
             const int wo = rem - ho * p.Wo;
             hi0[i] = ho * p.stride - p.pad_t;
             wi0[i] = wo * p.stride - p.pad_l;
-            pix0[i] = ((long long)n * p.H + hi0[i]) * p.W + wi0[i];
+            pix0[i] = (n * p.H + hi0[i]) * p.W + wi0[i];
         } else {
             hi0[i] = -(1 << 28);
             wi0[i] = -(1 << 28);
@@ -94,6 +110,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
         }
     }
     const int cin4m1 = (p.Cin >> 2) - 1;
+    const unsigned b_off0 = (unsigned)((n0 + (t & (BN - 1))) * 16);
+    const unsigned b_chunk0 = (unsigned)(t / BN);
+    const unsigned b_row_bytes = (unsigned)p.CoutP * 16u;
 
     float4 ra[AROWS];
     float4 rb[BSLOTS];
@@ -106,29 +125,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
         const int kw = tap - kh * p.KW;
         const int dh = kh * p.dil, dw = kw * p.dil;
         const bool tapok = tap < p.ntaps;
-        const long long doff = (long long)dh * p.W + dw;
+        const int doff = dh * p.W + dw;
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
-            // unconditional load from a clamped address + select: keeps all staging loads in
-            // flight together (a branch per load would serialise them behind vmcnt(0) waits)
             const int hi = hi0[i] + dh, wi = wi0[i] + dw;
             const bool ok = tapok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const long long off = ok ? ((pix0[i] + doff) * p.Cin + ch) : 0ll;
-            float4 v = *reinterpret_cast<const float4*>(p.in + off);
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            ra[i] = v;
+            const unsigned off = ok ? ((unsigned)((pix0[i] + doff) * p.Cin + ch) << 2) : OOB;
+            ra[i] = buf_load16(rs_in, off);
         }
 #pragma unroll
         for (int i = 0; i < BSLOTS; ++i) {
-            const int s = t + 256 * i;
-            const int chunk = s / BN;
-            const int col = s - chunk * BN;
-            const bool ok = n0 + col < p.CoutP;
-            const int colc = ok ? n0 + col : 0;
-            float4 v = *reinterpret_cast<const float4*>(
-                p.wpk + (((long long)(ks * 8 + chunk) * p.CoutP + colc) << 2));
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[i] = v;
+            const unsigned chunk = (unsigned)(ks * 8) + b_chunk0 + (unsigned)(i * (256 / BN));
+            rb[i] = buf_load16(rs_w, chunk * b_row_bytes + b_off0);
         }
     };
     auto lstore = [&](int buf) {
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
     const int l31 = lane & 31;
     for (int ks = 0; ks < p.nk; ++ks) {
         const int buf = ks & 1;
-        if (ks + 1 < p.nk) gload(ks + 1);
+        if (ks + 1 < p.nk) gload(ks + 1);           // in flight under the MFMAs below
         const float4* a_base = sA + buf * 8 * LDA + wave_m0 + l31;
         const float4* b_base = sB + buf * 8 * BN + wave_n0 + l31;
 #pragma unroll
@@ -181,47 +189,99 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -----
+    // ---- epilogue ----------------------------------------------------------------------
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    if (p.out_mode == 1) {
+        // transposed-conv phase scatter (heads only: tiny, per-element stores)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int co = n0 + wave_n0 + 32 * j + l31;
-        const bool cok = co < p.Cout;
-        const float sc = (cok && p.scale) ? p.scale[co] : 1.f;
-        const float bi = (cok && p.bias) ? p.bias[co] : 0.f;
-        int ph_a = 0, ph_b = 0, cj = co;
-        if (p.out_mode == 1) {
+        for (int j = 0; j < TN; ++j) {
+            const int co = n0 + wave_n0 + 32 * j + l31;
+            const bool cok = co < p.Cout;
+            const float bi = (cok && p.bias) ? p.bias[co] : 0.f;
             const int ph = co / p.dc_nj;
-            cj = co - ph * p.dc_nj;
-            ph_a = ph >> 1;
-            ph_b = ph & 1;
-        }
+            const int cj = co - ph * p.dc_nj;
+            const int ph_a = ph >> 1, ph_b = ph & 1;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int m = m0 + wave_m0 + 32 * i + row;
-                if (!cok || m >= p.M) continue;
-                float v = acc[i][j][r] * sc + bi;
-                long long oidx;
-                if (p.out_mode == 0 && p.res_s <= 1) {
-                    oidx = (long long)m * p.Cout + co;
-                    if (p.res_s == 1) v += p.res[oidx];
-                } else {
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int m = m0 + wave_m0 + 32 * i + row;
+                    if (!cok || m >= p.M) continue;
                     const int n = m / HoWo;
                     const int rem = m - n * HoWo;
                     const int ho = rem / p.Wo;
                     const int wo = rem - ho * p.Wo;
-                    if (p.out_mode == 0) {
-                        oidx = (long long)m * p.Cout + co;
-                        v += p.res[(((long long)n * p.res_H + ho * p.res_s) * p.res_W + wo * p.res_s) * p.Cout + co];
-                    } else {
-                        oidx = (((long long)n * (2 * p.Ho) + 2 * ho + ph_a) * (2 * p.Wo) + 2 * wo + ph_b) * p.dc_nj + cj;
-                    }
+                    const long long oidx =
+                        (((long long)n * (2 * p.Ho) + 2 * ho + ph_a) * (2 * p.Wo) + 2 * wo + ph_b) * p.dc_nj + cj;
+                    p.out[oidx] = acc[i][j][r] + bi;
                 }
-                if (p.relu) v = fmaxf(v, 0.f);
-                p.out[oidx] = v;
             }
+        }
+        return;
+    }
+
+    // NHWC output: stage each wave's 32 x WN sub-tile through (now free) LDS so that global
+    // traffic is 16 B per lane on full rows, with all residual loads of a pass in flight at once.
+    float* sC = reinterpret_cast<float*>(smem) + wave * (32 * LDC);
+    constexpr int C4 = WN / 4;                 // float4 per staged row
+    constexpr int NV = 32 * C4 / 64;           // float4 per lane per pass
+    const __amdgpu_buffer_rsrc_t rs_res =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.in), 0,
+                                          p.res ? (int)p.res_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+    const int my_c4 = lane % C4;
+    const int my_r0 = lane / C4;
+    const int co4 = n0 + wave_n0 + 4 * my_c4;
+    const bool cok = co4 < p.Cout;
+    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), bi4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cok && p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + co4);
+    if (cok && p.bias) bi4 = *reinterpret_cast<const float4*>(p.bias + co4);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        __syncthreads();      // previous pass (or the main loop) is done with this LDS
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                sC[row * LDC + 32 * j + l31] = acc[i][j][r];
+            }
+        __syncthreads();
+        unsigned ooff[NV];
+        float4 rres[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int row = my_r0 + v * (64 / C4);
+            const int m = m0 + wave_m0 + 32 * i + row;
+            const bool ok = cok && m < p.M;
+            ooff[v] = ok ? ((unsigned)(m * p.Cout + co4) << 2) : OOB;
+            unsigned roff = OOB;
+            if (p.res_s == 1) {
+                roff = ooff[v];
+            } else if (p.res_s > 1 && ok) {
+                const int n = m / HoWo;
+                const int rem = m - n * HoWo;
+                const int ho = rem / p.Wo;
+                const int wo = rem - ho * p.Wo;
+                roff = (unsigned)(((n * p.res_H + ho * p.res_s) * p.res_W + wo * p.res_s) * p.Cout + co4) << 2;
+            }
+            rres[v] = buf_load16(rs_res, roff);      // zeros when there is no residual
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int row = my_r0 + v * (64 / C4);
+            const float4 a = *reinterpret_cast<const float4*>(sC + row * LDC + 4 * my_c4);
+            float4 o;
+            o.x = a.x * sc4.x + bi4.x + rres[v].x;
+            o.y = a.y * sc4.y + bi4.y + rres[v].y;
+            o.z = a.z * sc4.z + bi4.z + rres[v].z;
+            o.w = a.w * sc4.w + bi4.w + rres[v].w;
+            if (p.relu) {
+                o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)ooff[v], 0, 0);
         }
     }
 }
@@ -231,6 +291,7 @@ static hipError_t launch_conv_t(ConvArgs a, hipStream_t s) {
     constexpr size_t smem = (size_t)(2 * 8 * (BM + 1) + 2 * 8 * BN) * 16;
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = (a.CoutP + BN - 1) / BN;
+    if (a.CoutP % BN != 0) return hipErrorInvalidValue;       // weight panels are padded to the tile
     auto kern = conv_igemm_f32<BM, BN, WAVES_M, WAVES_N>;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
@@ -244,10 +305,21 @@ static hipError_t launch_conv_t(ConvArgs a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Tile choice: the grid should fill 256 CUs evenly.  With T equal tiles the last "round"
+// leaves CUs idle, efficiency ~ (T/256)/ceil(T/256); smaller tiles trade a little reuse
+// (irrelevant at fp32-MFMA rates) for a finer tail.
 int pick_tile(int M, int CoutP, int K) {
-    (void)M; (void)K;
+    (void)K;
     if (CoutP <= 32) return TILE_128x32;
-    if (CoutP <= 64) return TILE_128x64;
+    auto eff = [&](int bm, int bn) {
+        const double t = (double)((M + bm - 1) / bm) * ((CoutP + bn - 1) / bn);
+        return (t / 256.0) / (double)((long long)((t + 255) / 256));
+    };
+    if (CoutP <= 64) return eff(128, 64) >= 0.9 ? TILE_128x64 : TILE_64x64;
+    const double e128 = eff(128, 128), e64n = eff(128, 64), e64 = eff(64, 64);
+    if (e128 >= 0.92) return TILE_128x128;
+    if (e64n >= e128 + 0.04 && e64n >= e64 - 0.03) return TILE_128x64;
+    if (e64 >= e128 + 0.04) return TILE_64x64;
     return TILE_128x128;
 }
 
@@ -255,6 +327,7 @@ hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s) {
     switch (tile_cfg) {
         case TILE_128x32: return launch_conv_t<128, 32, 4, 1>(a, s);
         case TILE_128x64: return launch_conv_t<128, 64, 2, 2>(a, s);
+        case TILE_64x64:  return launch_conv_t<64, 64, 2, 2>(a, s);
         default:          return launch_conv_t<128, 128, 2, 2>(a, s);
     }
 }

@@ -86,7 +86,18 @@ struct dgp_net {
     bool loaded = false;
     // geometry
     int h1 = 0, w1 = 0, hp = 0, wp = 0, fh = 0, fw = 0;
+    // optional per-launch timing (hipEvent pairs recorded on the caller's stream)
+    bool prof_on = false, prof_in_infer = false;
+    int prof_slots = 0, prof_used = 0, prof_launches = 0, prof_cursor = 0;
+    std::vector<hipEvent_t> prof_ev;          // [slot][launch][2]
+    std::vector<std::string> prof_names;      // per launch of the last profiled forward
+    std::vector<double> prof_flops;
+    void prof_free() {
+        for (auto e : prof_ev) (void)hipEventDestroy(e);
+        prof_ev.clear();
+    }
     ~dgp_net() {
+        prof_free();
         for (auto& l : layers) {
             if (l.d_w) (void)hipFree(l.d_w);
             if (l.d_scale) (void)hipFree(l.d_scale);
@@ -289,7 +300,28 @@ Plan make_plan(const dgp_net* net, int B) {
     return p;
 }
 
-int run_conv(const ConvLayer& l, const float* in, int N, int H, int W, int pad_t, int pad_l, int Ho, int Wo,
+struct ProfScope {
+    dgp_net* net; hipStream_t s; int li;
+    ProfScope(dgp_net* n, hipStream_t st, const std::string& name, double flops) : net(n), s(st), li(-1) {
+        if (!net->prof_on || net->prof_used >= net->prof_slots) return;
+        li = net->prof_cursor++;
+        if (li >= net->prof_launches) { li = -1; return; }
+        if (net->prof_used == 0) { net->prof_names[li] = name; net->prof_flops[li] = flops; }
+        (void)hipEventRecord(net->prof_ev[((size_t)net->prof_used * net->prof_launches + li) * 2], s);
+    }
+    ~ProfScope() {
+        if (li >= 0) (void)hipEventRecord(net->prof_ev[((size_t)net->prof_used * net->prof_launches + li) * 2 + 1], s);
+    }
+};
+
+double conv_flops_of(const ConvLayer& l, int M, bool is_head) {
+    // algorithmic: the transposed-conv heads count their true 9 taps per input pixel
+    if (is_head) return 2.0 * M * 9.0 * l.Cin * (l.Cout / 4);
+    const int cin = (l.KH == 7) ? 3 : l.Cin;
+    return 2.0 * M * (double)l.KH * l.KW * cin * l.Cout;
+}
+
+int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, int W, int pad_t, int pad_l, int Ho, int Wo,
              const float* res, int res_s, int res_H, int res_W, bool relu, int out_mode, int dc_nj, float* out,
              hipStream_t s) {
     ConvArgs a{};
@@ -300,6 +332,17 @@ int run_conv(const ConvLayer& l, const float* in, int N, int H, int W, int pad_t
     a.ntaps = l.ntaps; a.nk = l.nk; a.M = N * Ho * Wo;
     a.res_s = res ? res_s : 0; a.res_H = res_H; a.res_W = res_W;
     a.relu = relu ? 1 : 0; a.out_mode = out_mode; a.dc_nj = dc_nj;
+    {
+        const double lim = 4294967000.0;
+        const double inb = (double)N * H * W * l.Cin * 4, outb = (double)a.M * l.Cout * 4;
+        const double resb = res ? (double)N * res_H * res_W * l.Cout * 4 : 0.0;
+        if (inb > lim || outb > lim || resb > lim)
+            return fail(DGP_ERR_INVALID, "activation tensor exceeds the 4 GiB buffer-descriptor range; lower the batch");
+        if (out_mode == 0 && (l.Cout & 3)) return fail(DGP_ERR_INVALID, "conv: Cout must be a multiple of 4");
+        a.in_bytes = (unsigned)inb; a.out_bytes = (unsigned)outb; a.res_bytes = (unsigned)resb;
+        a.w_bytes = (unsigned)((size_t)l.nk * 8 * l.CoutP * 16);
+    }
+    ProfScope ps(net, s, "conv:" + l.scope, conv_flops_of(l, a.M, out_mode == 1));
     hipError_t e = launch_conv(a, pick_tile(a.M, a.CoutP, l.nk * BK), s);
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("conv launch (") + l.scope + "): " + hipGetErrorString(e));
     return DGP_OK;
@@ -376,14 +419,22 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     const int B = batch;
     int rc;
 
-    hipError_t e = launch_preprocess(frames, (long long)B * d.in_h * d.in_w, d.mean_pixel[0], d.mean_pixel[1],
-                                     d.mean_pixel[2], P0, s);
+    net->prof_cursor = 0;
+    hipError_t e;
+    {
+        ProfScope ps(net, s, "preprocess_u8", 0.0);
+        e = launch_preprocess(frames, (long long)B * d.in_h * d.in_w, d.mean_pixel[0], d.mean_pixel[1],
+                              d.mean_pixel[2], P0, s);
+    }
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("preprocess: ") + hipGetErrorString(e));
     // conv1: conv2d_same(7, stride 2): explicit pad 3 before
-    rc = run_conv(net->layers[net->conv1], P0, B, d.in_h, d.in_w, 3, 3, net->h1, net->w1, nullptr, 0, 0, 0, true, 0,
+    rc = run_conv(net, net->layers[net->conv1], P0, B, d.in_h, d.in_w, 3, 3, net->h1, net->w1, nullptr, 0, 0, 0, true, 0,
                   0, C1, s);
     if (rc) return rc;
-    e = launch_maxpool(C1, B, net->h1, net->w1, 64, X[0], s);
+    {
+        ProfScope ps(net, s, "maxpool3x3s2", 0.0);
+        e = launch_maxpool(C1, B, net->h1, net->w1, 64, X[0], s);
+    }
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("maxpool: ") + hipGetErrorString(e));
 
     int cur = 0, h = net->hp, w = net->wp;
@@ -395,17 +446,17 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
         int res_s = u.stride, res_H = h, res_W = w;
         if (u.sc >= 0) {
             // slim.conv2d(1x1, stride, SAME): pad 0, samples x[::s, ::s]
-            rc = run_conv(net->layers[u.sc], xin, B, h, w, 0, 0, ho, wo, nullptr, 0, 0, 0, false, 0, 0, SC, s);
+            rc = run_conv(net, net->layers[u.sc], xin, B, h, w, 0, 0, ho, wo, nullptr, 0, 0, 0, false, 0, 0, SC, s);
             if (rc) return rc;
             res = SC; res_s = 1; res_H = ho; res_W = wo;
         }
-        rc = run_conv(net->layers[u.c1], xin, B, h, w, 0, 0, h, w, nullptr, 0, 0, 0, true, 0, 0, R1, s);
+        rc = run_conv(net, net->layers[u.c1], xin, B, h, w, 0, 0, h, w, nullptr, 0, 0, 0, true, 0, 0, R1, s);
         if (rc) return rc;
         const int pb_h = pad_before_for(h, 3, u.stride, u.rate, true);
         const int pb_w = pad_before_for(w, 3, u.stride, u.rate, true);
-        rc = run_conv(net->layers[u.c2], R1, B, h, w, pb_h, pb_w, ho, wo, nullptr, 0, 0, 0, true, 0, 0, R2, s);
+        rc = run_conv(net, net->layers[u.c2], R1, B, h, w, pb_h, pb_w, ho, wo, nullptr, 0, 0, 0, true, 0, 0, R2, s);
         if (rc) return rc;
-        rc = run_conv(net->layers[u.c3], R2, B, ho, wo, 0, 0, ho, wo, res, res_s, res_H, res_W, true, 0, 0, xout, s);
+        rc = run_conv(net, net->layers[u.c3], R2, B, ho, wo, 0, 0, ho, wo, res, res_s, res_H, res_W, true, 0, 0, xout, s);
         if (rc) return rc;
         cur ^= 1; h = ho; w = wo;
     }
@@ -413,14 +464,15 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     if (features)
         HIP_TRY(hipMemcpyAsync(features, feat, (size_t)B * h * w * 2048 * sizeof(float), hipMemcpyDeviceToDevice, s));
     float* sm = scmap ? scmap : (float*)(ws + pl.off_scmap);
-    rc = run_conv(net->layers[net->head_part], feat, B, h, w, 1, 1, h, w, nullptr, 0, 0, 0, false, 1, d.num_joints,
+    rc = run_conv(net, net->layers[net->head_part], feat, B, h, w, 1, 1, h, w, nullptr, 0, 0, 0, false, 1, d.num_joints,
                   sm, s);
     if (rc) return rc;
     if (locref) {
-        rc = run_conv(net->layers[net->head_locref], feat, B, h, w, 1, 1, h, w, nullptr, 0, 0, 0, false, 1,
+        rc = run_conv(net, net->layers[net->head_locref], feat, B, h, w, 1, 1, h, w, nullptr, 0, 0, 0, false, 1,
                       2 * d.num_joints, locref, s);
         if (rc) return rc;
     }
+    if (net->prof_on && net->prof_used < net->prof_slots && !net->prof_in_infer) ++net->prof_used;
     return DGP_OK;
 }
 
@@ -449,11 +501,57 @@ int dgp_hard_argmax(const float* scmap, const float* locref, int32_t B, int32_t 
 int dgp_infer(dgp_net* net, const uint8_t* frames, int32_t batch, void* workspace, size_t workspace_bytes, float gamma,
               int32_t gauss_len, float* mu, float* conf, int32_t* idx, float* scmap_out, void* stream) {
     if (!net) return fail(DGP_ERR_INVALID, "dgp_infer: null net");
+    net->prof_in_infer = true;
     int rc = dgp_forward(net, frames, batch, workspace, workspace_bytes, scmap_out, nullptr, nullptr, stream);
+    net->prof_in_infer = false;
     if (rc) return rc;
     const float* sm = scmap_out ? scmap_out : (const float*)((char*)workspace + make_plan(net, batch).off_scmap);
-    return dgp_soft_argmax(sm, batch, 2 * net->fh, 2 * net->fw, net->desc.num_joints, gamma, gauss_len, mu, conf, idx,
-                           nullptr, stream);
+    {
+        ProfScope ps(net, (hipStream_t)stream, "soft_argmax", 0.0);
+        rc = dgp_soft_argmax(sm, batch, 2 * net->fh, 2 * net->fw, net->desc.num_joints, gamma, gauss_len, mu, conf,
+                             idx, nullptr, stream);
+    }
+    if (net->prof_on && net->prof_used < net->prof_slots) ++net->prof_used;
+    return rc;
+}
+
+int dgp_net_profile_begin(dgp_net* net, int32_t max_steps) {
+    if (!net || max_steps < 1) return fail(DGP_ERR_INVALID, "dgp_net_profile_begin: bad argument");
+    int nl = 0;
+    dgp_net_stats(net, 1, &nl, nullptr);
+    nl += 1;   // soft-argmax
+    net->prof_free();
+    net->prof_launches = nl; net->prof_slots = max_steps; net->prof_used = 0; net->prof_cursor = 0;
+    net->prof_names.assign(nl, ""); net->prof_flops.assign(nl, 0.0);
+    net->prof_ev.resize((size_t)max_steps * nl * 2);
+    for (auto& e : net->prof_ev) HIP_TRY(hipEventCreate(&e));
+    net->prof_on = true;
+    return DGP_OK;
+}
+
+int dgp_net_profile_end(dgp_net* net, int32_t* n_steps, int32_t* n_launches) {
+    if (!net) return fail(DGP_ERR_INVALID, "dgp_net_profile_end: null net");
+    net->prof_on = false;
+    if (n_steps) *n_steps = net->prof_used;
+    if (n_launches) *n_launches = net->prof_launches;
+    return DGP_OK;
+}
+
+int dgp_net_profile_launch(dgp_net* net, int32_t launch, char* name, int32_t name_cap, double* flops, double* avg_ms) {
+    if (!net || launch < 0 || launch >= net->prof_launches) return fail(DGP_ERR_INVALID, "dgp_net_profile_launch: bad index");
+    if (name && name_cap > 0) { strncpy(name, net->prof_names[launch].c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (flops) *flops = net->prof_flops[launch];
+    double tot = 0; int cnt = 0;
+    for (int st = 0; st < net->prof_used; ++st) {
+        hipEvent_t a = net->prof_ev[((size_t)st * net->prof_launches + launch) * 2];
+        hipEvent_t b = net->prof_ev[((size_t)st * net->prof_launches + launch) * 2 + 1];
+        float ms = 0.f;
+        if (hipEventSynchronize(b) != hipSuccess) continue;
+        if (hipEventElapsedTime(&ms, a, b) != hipSuccess) continue;
+        tot += ms; ++cnt;
+    }
+    if (avg_ms) *avg_ms = cnt ? tot / cnt : 0.0;
+    return DGP_OK;
 }
 
 size_t dgp_packed_weight_floats(int32_t KH, int32_t KW, int32_t Cin, int32_t Cout) {
@@ -482,6 +580,15 @@ int dgp_conv2d(const dgp_conv_desc* d, const float* x, const float* packed_w, co
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.dil = d->rate; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
     a.ntaps = d->KH * d->KW; a.nk = nk_for(d->KH, d->KW, d->Cin); a.M = d->N * d->Ho * d->Wo;
     a.res_s = d->res_stride; a.res_H = d->res_H; a.res_W = d->res_W; a.relu = d->relu; a.out_mode = 0; a.dc_nj = 0;
+    if (d->Cout & 3) return fail(DGP_ERR_INVALID, "dgp_conv2d: Cout must be a multiple of 4");
+    {
+        const double lim = 4294967000.0;
+        const double inb = (double)d->N * d->H * d->W * d->Cin * 4, outb = (double)a.M * d->Cout * 4;
+        const double resb = a.res ? (double)d->N * d->res_H * d->res_W * d->Cout * 4 : 0.0;
+        if (inb > lim || outb > lim || resb > lim) return fail(DGP_ERR_INVALID, "dgp_conv2d: tensor exceeds 4 GiB");
+        a.in_bytes = (unsigned)inb; a.out_bytes = (unsigned)outb; a.res_bytes = (unsigned)resb;
+        a.w_bytes = (unsigned)((size_t)a.nk * 8 * a.CoutP * 16);
+    }
     hipError_t e = launch_conv(a, pick_tile(a.M, a.CoutP, a.nk * BK), (hipStream_t)stream);
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_conv2d: ") + hipGetErrorString(e));
     return DGP_OK;

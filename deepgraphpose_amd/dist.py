@@ -1,0 +1,73 @@
+"""Frame-sharded multi-GPU inference: one process per GPU, RCCL all-gather over xGMI.
+
+Frames of a video are independent (estimate_pose has no cross-frame state,
+DGP/models/eval.py:306-345), so rank r takes the contiguous block
+[r*ceil(T/W), (r+1)*ceil(T/W)) and the only exchange is ONE all-gather per video (or per
+chunk of frames) of the per-frame keypoints -- 20 bytes per (frame, joint): (row, col, conf)
+fp32 + (iy, ix) int32 bit-cast into the same 4-byte lanes so a single collective moves both.
+The payload is tiny (latency-bound), which is why it is done once per chunk, never per batch.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block of frame indices owned by `rank` (last shards may be short or empty)."""
+    per = -(-n_frames // world) if n_frames > 0 else 0
+    lo = min(rank * per, n_frames)
+    hi = min(lo + per, n_frames)
+    return lo, hi
+
+
+def pack_keypoints(mu: torch.Tensor, conf: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """[T,nj,2] f32, [T,nj] f32, [T,nj,2] i32 -> [T,nj,5] f32 (idx bit-cast)."""
+    return torch.cat([mu, conf.unsqueeze(-1), idx.contiguous().view(torch.float32)], dim=-1).contiguous()
+
+
+def unpack_keypoints(buf: torch.Tensor):
+    mu = buf[..., 0:2].contiguous()
+    conf = buf[..., 2].contiguous()
+    idx = buf[..., 3:5].contiguous().view(torch.int32)
+    return mu, conf, idx
+
+
+def gather_trajectory(local: torch.Tensor, n_frames: int, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """All-gather per-rank packed keypoints [T_r, nj, 5] into the frame-ordered [T, nj, 5]
+    on every rank.  Shards are padded to ceil(T/W) so one fixed-size all-gather suffices."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local[:n_frames]
+    world = dist.get_world_size(group)
+    per = -(-n_frames // world)
+    nj, k = local.shape[1], local.shape[2]
+    send = local
+    if local.shape[0] != per:
+        send = torch.zeros((per, nj, k), dtype=local.dtype, device=local.device)
+        send[: local.shape[0]] = local
+    out = torch.empty((world * per, nj, k), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, send.contiguous(), group=group)
+    return out[:n_frames]
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, local_rank, world) from torchrun's env; initialises the process group when world > 1.
+    backend 'nccl' is RCCL on ROCm; 'gloo' is used by the CPU tests."""
+    import os
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, world

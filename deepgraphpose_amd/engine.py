@@ -97,6 +97,23 @@ class DGPNet:
         _lib.check(self.lib.dgp_net_stats(self._h, batch, C.byref(nl), C.byref(fl)))
         return nl.value, fl.value
 
+    # -- measurement -----------------------------------------------------------------
+    def profile_begin(self, max_steps: int):
+        _lib.check(self.lib.dgp_net_profile_begin(self._h, max_steps), "dgp_net_profile_begin")
+
+    def profile_end(self):
+        """-> list of (name, algorithmic flops, avg ms) per launch of one step."""
+        ns, nl = C.c_int32(), C.c_int32()
+        _lib.check(self.lib.dgp_net_profile_end(self._h, C.byref(ns), C.byref(nl)), "dgp_net_profile_end")
+        out = []
+        buf = C.create_string_buffer(256)
+        for i in range(nl.value):
+            fl, ms = C.c_double(), C.c_double()
+            _lib.check(self.lib.dgp_net_profile_launch(self._h, i, buf, 256, C.byref(fl), C.byref(ms)))
+            if buf.value:
+                out.append((buf.value.decode(), fl.value, ms.value))
+        return ns.value, out
+
     # -- compute ---------------------------------------------------------------------
     def forward(self, frames: torch.Tensor, want_locref: bool = False, want_features: bool = False):
         """frames uint8 [B,H,W,3] on device -> scmap [B,out_h,out_w,nj] (and locref / features)."""

@@ -104,6 +104,16 @@ int  dgp_infer(dgp_net* net, const uint8_t* frames, int32_t batch, void* workspa
                size_t workspace_bytes, float gamma, int32_t gauss_len, float* mu, float* conf,
                int32_t* idx, float* scmap_out, void* stream);
 
+/* ---- measurement: hipEvent pairs around every launch of dgp_forward / dgp_infer, recorded on
+ * the caller's stream (no syncs until dgp_net_profile_launch reads them).  Used by bench.py for
+ * the roofline object; the reference's only timing is time.time() around sess.run
+ * (DGP/models/fitdgp.py:817-828). */
+int  dgp_net_profile_begin(dgp_net* net, int32_t max_steps);
+int  dgp_net_profile_end(dgp_net* net, int32_t* n_steps, int32_t* n_launches);
+/* Average duration (ms, over the profiled steps), name and algorithmic FLOPs of launch i. */
+int  dgp_net_profile_launch(dgp_net* net, int32_t launch, char* name, int32_t name_cap,
+                            double* flops, double* avg_ms);
+
 /* ---- single-layer entry points (used by the parity tests and by fit_dgp later) ---- */
 
 /* slim.conv2d / conv2d_same semantics on NHWC fp32 with HWIO weights supplied packed by
