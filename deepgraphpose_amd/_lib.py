@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdgp_hip.so")
+# DGP_HIP_LIB lets scripts/ load a diagnostic build (-DDGP_DIAG) of the same sources
+LIB_PATH = os.environ.get("DGP_HIP_LIB") or os.path.join(_HERE, "libdgp_hip.so")
 
 
 class DgpNetDesc(C.Structure):

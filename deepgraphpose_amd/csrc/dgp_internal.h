@@ -26,6 +26,7 @@ struct ConvArgs {
     int out_mode;         // 0: NHWC [M][Cout]; 1: transposed-conv phase scatter
     int dc_nj;            // channels per phase for out_mode 1
     int mtiles, ntiles;
+    unsigned long long* dbg;
     unsigned in_bytes, w_bytes, res_bytes, out_bytes;   // buffer-descriptor extents (< 4 GiB each)
 };
 

@@ -12,8 +12,23 @@
 //
 // Wavefront = 64 lanes everywhere.  No CUDA-compat shims; this file only targets gfx950.
 #include "dgp_internal.h"
+#include <cstdlib>
+#include <cstdio>
+#include <vector>
 
 namespace dgp {
+
+#ifdef DGP_DIAG
+// diagnostic build only (scripts/diag.sh): s_memtime stamps fence the schedule; read SHARES, not totals
+#define DIAG_STAMP(x)                                                                   \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+    } while (0)
+#else
+#define DIAG_STAMP(x)
+#endif
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -44,7 +59,10 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned 
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+// WIDE = (Cin >= 32): all 8 chunks of a K-step lie in ONE tap, so tap / channel bookkeeping is
+// wave-uniform (SALU, advanced incrementally) and each A load costs ~7 VALU ops.  The generic
+// path (WIDE = false, used by the 4-channel stem) recomputes the tap per lane.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool WIDE>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
     constexpr int WM = BM / WAVES_M;       // wave tile rows
     constexpr int WN = BN / WAVES_N;       // wave tile cols
@@ -110,34 +128,55 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
         }
     }
     const int cin4m1 = (p.Cin >> 2) - 1;
-    const unsigned b_off0 = (unsigned)((n0 + (t & (BN - 1))) * 16);
-    const unsigned b_chunk0 = (unsigned)(t / BN);
+    const unsigned b_lane_off = (unsigned)(t / BN) * ((unsigned)p.CoutP * 16u) + (unsigned)((n0 + (t & (BN - 1))) * 16);
     const unsigned b_row_bytes = (unsigned)p.CoutP * 16u;
+    int rowoff[AROWS];          // WIDE: byte offset of (pixel row, lane's chunk) at tap (0,0), channel 0
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) rowoff[i] = (pix0[i] * p.Cin + 4 * c) * 4;
+    // wave-uniform tap walker (WIDE): K-step ks covers tap w_tap, channels [w_ch, w_ch + 32)
+    int w_kh = 0, w_kw = 0, w_ch = 0, w_tap = 0;
 
     float4 ra[AROWS];
     float4 rb[BSLOTS];
 
     auto gload = [&](int ks) {
-        const int q = ks * 8 + c;
-        const int tap = q >> p.log2cin4;
-        const int ch = (q & cin4m1) << 2;
-        const int kh = tap / p.KW;
-        const int kw = tap - kh * p.KW;
-        const int dh = kh * p.dil, dw = kw * p.dil;
-        const bool tapok = tap < p.ntaps;
-        const int doff = dh * p.W + dw;
+        if constexpr (WIDE) {
+            const int dh = w_kh * p.dil, dw = w_kw * p.dil;
+            const int doff = ((dh * p.W + dw) * p.Cin + w_ch) * 4;
+            const bool tapok = w_tap < p.ntaps;
 #pragma unroll
-        for (int i = 0; i < AROWS; ++i) {
-            const int hi = hi0[i] + dh, wi = wi0[i] + dw;
-            const bool ok = tapok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const unsigned off = ok ? ((unsigned)((pix0[i] + doff) * p.Cin + ch) << 2) : OOB;
-            ra[i] = buf_load16(rs_in, off);
-        }
+            for (int i = 0; i < AROWS; ++i) {
+                const int hi = hi0[i] + dh, wi = wi0[i] + dw;
+                const bool ok = tapok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                ra[i] = buf_load16(rs_in, ok ? (unsigned)(rowoff[i] + doff) : OOB);
+            }
+            w_ch += 32;
+            if (w_ch >= p.Cin) {
+                w_ch = 0; ++w_tap;
+                if (++w_kw == p.KW) { w_kw = 0; ++w_kh; }
+            }
+        } else {
+            const int q = ks * 8 + c;
+            const int tap = q >> p.log2cin4;
+            const int ch = (q & cin4m1) << 2;
+            const int kh = tap / p.KW;
+            const int kw = tap - kh * p.KW;
+            const int dh = kh * p.dil, dw = kw * p.dil;
+            const bool tapok = tap < p.ntaps;
+            const int doff = dh * p.W + dw;
 #pragma unroll
-        for (int i = 0; i < BSLOTS; ++i) {
-            const unsigned chunk = (unsigned)(ks * 8) + b_chunk0 + (unsigned)(i * (256 / BN));
-            rb[i] = buf_load16(rs_w, chunk * b_row_bytes + b_off0);
+            for (int i = 0; i < AROWS; ++i) {
+                const int hi = hi0[i] + dh, wi = wi0[i] + dw;
+                const bool ok = tapok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                const unsigned off = ok ? ((unsigned)((pix0[i] + doff) * p.Cin + ch) << 2) : OOB;
+                ra[i] = buf_load16(rs_in, off);
+            }
         }
+        const unsigned kbase = (unsigned)(ks * 8) * b_row_bytes;
+#pragma unroll
+        for (int i = 0; i < BSLOTS; ++i)
+            rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                        rs_w, (int)b_lane_off, (int)(kbase + (unsigned)(i * (256 / BN)) * b_row_bytes), 0));
     };
     auto lstore = [&](int buf) {
         float4* a = sA + buf * 8 * LDA + c * LDA + rg;
@@ -156,15 +195,28 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#ifdef DGP_DIAG
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+#endif
+#ifdef DGP_DIAG
+    if (p.dbg) st0 = __builtin_amdgcn_s_memtime();
+#endif
     gload(0);
     lstore(0);
     __syncthreads();
-
+#ifdef DGP_DIAG
+    if (p.dbg) st1 = __builtin_amdgcn_s_memtime();
+#endif
     const int half = lane >> 5;
     const int l31 = lane & 31;
+#ifdef DGP_DIAG
+    unsigned long long d0, d1, d2, d3, d4, d5, acc_gl = 0, acc_mf = 0, acc_vm = 0, acc_ls = 0, acc_ba = 0;
+#endif
     for (int ks = 0; ks < p.nk; ++ks) {
         const int buf = ks & 1;
+        DIAG_STAMP(d0);
         if (ks + 1 < p.nk) gload(ks + 1);           // in flight under the MFMAs below
+        DIAG_STAMP(d1);
         const float4* a_base = sA + buf * 8 * LDA + wave_m0 + l31;
         const float4* b_base = sB + buf * 8 * BN + wave_n0 + l31;
 #pragma unroll
@@ -185,10 +237,23 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                 }
         }
+        DIAG_STAMP(d2);
+#ifdef DGP_DIAG
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DIAG_STAMP(d3);
+#endif
         if (ks + 1 < p.nk) lstore(buf ^ 1);
+        DIAG_STAMP(d4);
         __syncthreads();
+        DIAG_STAMP(d5);
+#ifdef DGP_DIAG
+        acc_gl += d1 - d0; acc_mf += d2 - d1; acc_vm += d3 - d2; acc_ls += d4 - d3; acc_ba += d5 - d4;
+#endif
     }
 
+#ifdef DGP_DIAG
+    if (p.dbg) st2 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- epilogue ----------------------------------------------------------------------
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     if (p.out_mode == 1) {
@@ -284,51 +349,85 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)ooff[v], 0, 0);
         }
     }
+#ifdef DGP_DIAG
+    if (p.dbg && t == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+        unsigned long long* d = p.dbg + 10ull * blockIdx.x;
+        d[0] = st1 - st0; d[1] = st2 - st1; d[2] = st3 - st2;
+        d[3] = acc_gl; d[4] = acc_mf; d[5] = acc_vm; d[6] = acc_ls; d[7] = acc_ba;
+    }
+#endif
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool WIDE>
 static hipError_t launch_conv_t(ConvArgs a, hipStream_t s) {
-    constexpr size_t smem = (size_t)(2 * 8 * (BM + 1) + 2 * 8 * BN) * 16;
+    size_t smem = (size_t)(2 * 8 * (BM + 1) + 2 * 8 * BN) * 16;
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = (a.CoutP + BN - 1) / BN;
+#ifdef DGP_DIAG
+    static unsigned long long* dbg_buf = nullptr;
+    {
+        const long long nb = (long long)a.mtiles * a.ntiles;
+        if (!dbg_buf) (void)hipMalloc(&dbg_buf, 10 * 8 * 65536);
+        a.dbg = nb <= 65536 ? dbg_buf : nullptr;
+    }
+#endif
     if (a.CoutP % BN != 0) return hipErrorInvalidValue;       // weight panels are padded to the tile
-    auto kern = conv_igemm_f32<BM, BN, WAVES_M, WAVES_N>;
+    auto kern = conv_igemm_f32<BM, BN, WAVES_M, WAVES_N, WIDE>;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     const long long nwg = (long long)a.mtiles * a.ntiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), smem, s, a);
+#ifdef DGP_DIAG
+    if (a.dbg) {
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> h(10 * nwg);
+        (void)hipMemcpy(h.data(), a.dbg, 80 * nwg, hipMemcpyDeviceToHost);
+        double v[8] = {0};
+        for (long long b = 0; b < nwg; ++b) for (int k = 0; k < 8; ++k) v[k] += (double)h[10 * b + k];
+        for (int k = 0; k < 8; ++k) v[k] /= (double)nwg;
+        printf("[diag %dx%d] tiles %lld nk %d | cycles/tile: prologue %.0f loop %.0f epilogue %.0f | per K-step (wave 0): "
+               "gload-issue %.0f mfma+ldsread %.0f vmcnt-wait %.0f lds-store %.0f barrier %.0f\n", BM, BN, nwg, a.nk,
+               v[0], v[1], v[2], v[3] / a.nk, v[4] / a.nk, v[5] / a.nk, v[6] / a.nk, v[7] / a.nk);
+    }
+#endif
     return hipGetLastError();
 }
 
-// Tile choice: the grid should fill 256 CUs evenly.  With T equal tiles the last "round"
-// leaves CUs idle, efficiency ~ (T/256)/ceil(T/256); smaller tiles trade a little reuse
-// (irrelevant at fp32-MFMA rates) for a finer tail.
+// Tile choice, from scripts/conv_sweep.py on MI355X (ResNet-50 640x480 batch-32 shapes, TFLOP/s for
+// 128x128 / 128x64 / 64x64): the small 64x64 tile (4 workgroups per CU, finest tail) wins for the
+// K-heavy 3x3 convs and for 1x1 convs with a deep K and few output channels; 128x64 wins for the
+// shallow-K, wide-N 1x1 convs (fewer re-reads of the activation rows); 128x128 never won.
 int pick_tile(int M, int CoutP, int K) {
-    (void)K;
+    (void)M;
     if (CoutP <= 32) return TILE_128x32;
-    auto eff = [&](int bm, int bn) {
-        const double t = (double)((M + bm - 1) / bm) * ((CoutP + bn - 1) / bn);
-        return (t / 256.0) / (double)((long long)((t + 255) / 256));
-    };
-    if (CoutP <= 64) return eff(128, 64) >= 0.9 ? TILE_128x64 : TILE_64x64;
-    const double e128 = eff(128, 128), e64n = eff(128, 64), e64 = eff(64, 64);
-    if (e128 >= 0.92) return TILE_128x128;
-    if (e64n >= e128 + 0.04 && e64n >= e64 - 0.03) return TILE_128x64;
-    if (e64 >= e128 + 0.04) return TILE_64x64;
-    return TILE_128x128;
+    if (const char* f = getenv("DGP_FORCE_TILE")) {     // tuning experiments only
+        const int v = atoi(f);
+        if (v == TILE_128x128 && CoutP % 128 == 0) return v;
+        if ((v == TILE_128x64 || v == TILE_64x64) && CoutP % 64 == 0) return v;
+    }
+    if (K >= 1024 && CoutP <= 512) return TILE_64x64;      // 3x3 convs, deep-K 1x1 reductions
+    if (K >= 576 && CoutP <= 256) return TILE_64x64;       // 3x3 convs of block1/2
+    return TILE_128x64;
 }
 
 hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s) {
+    if (a.Cin < 32) {       // generic per-lane tap path (stem / small test shapes)
+        if (tile_cfg == TILE_128x32) return launch_conv_t<128, 32, 4, 1, false>(a, s);
+        if (a.CoutP % 128 == 0 && tile_cfg == TILE_128x128) return launch_conv_t<128, 128, 2, 2, false>(a, s);
+        return launch_conv_t<128, 64, 2, 2, false>(a, s);
+    }
     switch (tile_cfg) {
-        case TILE_128x32: return launch_conv_t<128, 32, 4, 1>(a, s);
-        case TILE_128x64: return launch_conv_t<128, 64, 2, 2>(a, s);
-        case TILE_64x64:  return launch_conv_t<64, 64, 2, 2>(a, s);
-        default:          return launch_conv_t<128, 128, 2, 2>(a, s);
+        case TILE_128x32: return launch_conv_t<128, 32, 4, 1, true>(a, s);
+        case TILE_128x64: return launch_conv_t<128, 64, 2, 2, true>(a, s);
+        case TILE_64x64:  return launch_conv_t<64, 64, 2, 2, true>(a, s);
+        default:          return launch_conv_t<128, 128, 2, 2, true>(a, s);
     }
 }
 

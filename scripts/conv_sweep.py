@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Time single conv layers of the ResNet-50 640x480 batch-32 plan under each tile config."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from deepgraphpose_amd import engine
+
+LAYERS = [  # name, N,H,W,Cin,Cout,k,stride,rate,pad
+    ("b1.conv1 256->64", 32, 120, 160, 256, 64, 1, 1, 1, 0),
+    ("b1.conv2 3x3 64", 32, 120, 160, 64, 64, 3, 1, 1, 1),
+    ("b1.conv3 64->256", 32, 120, 160, 64, 256, 1, 1, 1, 0),
+    ("b2.conv2 3x3 128", 32, 60, 80, 128, 128, 3, 1, 1, 1),
+    ("b2.conv3 128->512", 32, 60, 80, 128, 512, 1, 1, 1, 0),
+    ("b3.conv1 1024->256", 32, 30, 40, 1024, 256, 1, 1, 1, 0),
+    ("b3.conv2 3x3 256", 32, 30, 40, 256, 256, 3, 1, 1, 1),
+    ("b3.conv3 256->1024", 32, 30, 40, 256, 1024, 1, 1, 1, 0),
+    ("b4.conv1 2048->512", 32, 30, 40, 2048, 512, 1, 1, 1, 0),
+    ("b4.conv2 3x3d2 512", 32, 30, 40, 512, 512, 3, 1, 2, 2),
+    ("b4.conv3 512->2048", 32, 30, 40, 512, 2048, 1, 1, 1, 0),
+    ("b4.short 1024->2048", 32, 30, 40, 1024, 2048, 1, 1, 1, 0),
+]
+BIG = int(os.environ.get("SWEEP_BATCH_MULT", "1"))
+only = sys.argv[1:] 
+rng = np.random.default_rng(0)
+for name, N, H, W, Cin, Cout, k, s, r, pad in LAYERS:
+    if only and not any(o in name for o in only):
+        continue
+    N = N * BIG
+    x = torch.randn((N, H, W, Cin), device="cuda")
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    flops = 2.0 * N * H * W * k * k * Cin * Cout
+    res = []
+    for tile in (0, 1, 2):
+        if tile == 0 and Cout % 128: 
+            res.append("   -  "); continue
+        os.environ["DGP_FORCE_TILE"] = str(tile)
+        y = engine.conv2d(x, w, stride=s, rate=r, pad_t=pad, pad_l=pad, out_hw=(H, W), relu=True)
+        # time launches only: re-pack happens inside conv2d, so call the C-ABI directly in a loop
+        import ctypes as C
+        from deepgraphpose_amd import _lib
+        lib = _lib.load()
+        wp = torch.from_numpy(engine.pack_conv_weights(w)).cuda()
+        d = _lib.DgpConvDesc(N, H, W, Cin, Cout, k, k, s, r, pad, pad, H, W, 1, 0, 0, 0)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        def run():
+            _lib.check(lib.dgp_conv2d(C.byref(d), C.c_void_p(x.data_ptr()), C.c_void_p(wp.data_ptr()), None, None, None,
+                                      C.c_void_p(y.data_ptr()), st))
+        for _ in range(3): run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): run()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        res.append("%6.1f" % (flops / ms / 1e9))
+    print("%-22s GF %7.1f | TF 128x128 %s | 128x64 %s | 64x64 %s" % (name, flops / 1e9, res[0], res[1], res[2]), flush=True)

@@ -1,0 +1,19 @@
+#!/bin/bash
+# rocprofv3 passes for bench.py on the GPU box.  Usage: scripts/profile.sh <tag>
+# 1) --kernel-trace --stats   2..4) separate --pmc passes (never combined with sys/hip traces).
+set -u
+TAG=${1:-r1}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd "$ROOT"
+BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/bench_trace.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -- $BENCH > "$OUT/bench_pmc_mfma.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > "$OUT/bench_pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH > "$OUT/bench_pmc_write.log" 2>&1
+python3 scripts/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+tail -5 "$OUT"/bench_*.log | cut -c1-600
+find "$OUT" -name "*.csv" | head -20
+du -sh "$OUT"
