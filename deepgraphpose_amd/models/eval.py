@@ -1,0 +1,239 @@
+"""Drop-in counterparts of deepgraphpose/models/eval.py on the MI355X engine.
+
+Same entry points and signatures as the reference (DGP/models/eval.py):
+  setup_dgp_eval_graph(dlc_cfg, dgp_model_file, loc_ref=False, gauss_len=1, gamma=1)     :147
+  estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle=1, ...)    :217
+  export_pose_like_dlc / load_pose_from_dlc_to_dict                                      :621 / :648
+  plot_dgp(video_file, output_dir='', ...)                                               :816
+The TF session call `sess.run([mu_n, scmap], feed_dict={inputs: frame[None]})` (:328) is served by
+`EvalSession.run`, which batches frames through the fused HIP path (dgp_infer); the per-joint likelihood
+loop (:331-343) runs inside the soft-argmax kernel.  Video decode and movie rendering are untouched
+third-party territory (moviepy) and only used when installed.
+"""
+from __future__ import annotations
+
+import os
+from os.path import join
+from pathlib import Path
+from typing import Dict, Optional
+
+import numpy as np
+import yaml
+
+
+class _Fetch:
+    """Symbolic handle standing in for a TF tensor of the eval graph."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __repr__(self):
+        return "<dgp fetch %s>" % self.name
+
+
+class EvalSession:
+    """What `TF.Session` + the restored graph were in the reference: holds the weights and one DGPNet per
+    frame size (the TF placeholder was [1, None, None, 3]); `run` accepts the same fetch list."""
+
+    def __init__(self, weights: Dict[str, np.ndarray], depth: int, nj: int, loc_ref: bool, gauss_len, gamma,
+                 mean_pixel, max_batch: int = 32, device: int = 0):
+        self.weights, self.depth, self.nj, self.loc_ref = weights, depth, nj, loc_ref
+        self.gauss_len, self.gamma, self.mean_pixel = gauss_len, gamma, tuple(mean_pixel)
+        self.max_batch, self.device = max_batch, device
+        self._nets = {}
+        self.mu_n, self.softmax_tensor = _Fetch("mu_n"), _Fetch("softmax_tensor")
+        self.scmap, self.inputs = _Fetch("scmap"), _Fetch("inputs")
+        self.locref = _Fetch("locref") if loc_ref else None
+        self.likelihood, self.idx = _Fetch("likelihood"), _Fetch("mu_likelihoods")
+
+    def net_for(self, h: int, w: int):
+        from .. import engine
+        key = (h, w)
+        if key not in self._nets:
+            net = engine.DGPNet(self.depth, self.nj, h, w, max_batch=self.max_batch, with_locref=self.loc_ref,
+                                device=self.device, mean_pixel=self.mean_pixel)
+            net.load_weights(self.weights)
+            self._nets = {key: net}          # keep one resident geometry (activations are GBs)
+        return self._nets[key]
+
+    def run(self, fetches, feed_dict):
+        import torch
+        from .. import engine
+        single = not isinstance(fetches, (list, tuple))
+        fl = [fetches] if single else list(fetches)
+        frames = feed_dict[self.inputs]
+        if isinstance(frames, np.ndarray):
+            if frames.dtype != np.uint8:
+                # the reference feeds img_as_ubyte frames cast to fp32 (eval.py:326-328): integral 0..255
+                frames = np.clip(np.rint(frames), 0, 255).astype(np.uint8)
+            frames = torch.from_numpy(np.ascontiguousarray(frames)).cuda(self.device)
+        B, h, w, _ = frames.shape
+        net = self.net_for(h, w)
+        names = {f.name for f in fl}
+        out = {}
+        for s in range(0, B, self.max_batch):
+            fb = frames[s:s + self.max_batch].contiguous()
+            if self.loc_ref and "locref" in names:
+                scm, loc = net.forward(fb, want_locref=True)
+            else:
+                scm, loc = net.forward(fb), None
+            part = {"scmap": scm, "locref": loc}
+            if names & {"mu_n", "softmax_tensor", "likelihood", "mu_likelihoods"}:
+                mu, conf, idx, pmap = engine.soft_argmax(scm, self.gamma, self.gauss_len, want_pmap=True)
+                part.update(mu_n=mu, softmax_tensor=pmap, likelihood=conf, mu_likelihoods=idx)
+            for k, v in part.items():
+                if k in names:
+                    out.setdefault(k, []).append(v.cpu().numpy())
+        res = [np.concatenate(out[f.name], 0) for f in fl]
+        return res[0] if single else res
+
+    def close(self):
+        self._nets = {}
+
+
+def setup_dgp_eval_graph(dlc_cfg, dgp_model_file, loc_ref=False, gauss_len=1, gamma=1):
+    """-> (sess, mu_n, softmax_tensor, scmap, locref, inputs), as eval.py:147-214.
+
+    `dgp_model_file` is a snapshot written by this package (.npz / .safetensors with TF variable names);
+    a missing file raises FileNotFoundError, a net_type that does not match the snapshot raises
+    KeyError (the reference relies on exactly that failure to fall back from resnet_50 to resnet_101)."""
+    from .. import weights_io
+    weights = weights_io.load_weights(str(dgp_model_file))
+    depth = int(str(dlc_cfg.net_type).split("_")[-1])
+    if ("resnet_v1_%d/conv1/weights" % depth) not in weights:
+        raise KeyError("snapshot %s holds no resnet_v1_%d variables" % (dgp_model_file, depth))
+    sess = EvalSession(weights, depth, int(dlc_cfg.num_joints), bool(loc_ref), gauss_len, gamma,
+                       dlc_cfg.get("mean_pixel", [123.68, 116.779, 103.939]))
+    return sess, sess.mu_n, sess.softmax_tensor, sess.scmap, sess.locref, sess.inputs
+
+
+def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle=1, save_pose=True, save_str="",
+                  new_size=None, crop_size=None, batch_size: int = 32):
+    """Estimate pose on an arbitrary video (eval.py:217-372).  Returns {'x','y','likelihoods'} [T,nj] float64,
+    or the csv path if labels already exist (:247-249).  `batch_size` is new: frames go through the GPU in
+    batches instead of one sess.run per frame."""
+    from ..config import get_train_config
+    from ..frames import open_frame_source
+
+    f = os.path.basename(str(video_file)).rsplit(".", 1)
+    save_file = join(output_dir, f[0] + "_labeled%s" % save_str)
+    if os.path.exists(save_file + ".csv"):
+        print("labels already exist! video at %s will not be processed" % video_file)
+        return save_file + ".csv"
+
+    video_clip = open_frame_source(video_file)
+    n_frames = int(video_clip.n_frames)
+    with open(proj_cfg_file, "r") as stream:
+        proj_config = yaml.safe_load(stream)
+    proj_config["video_path"] = None
+    dlc_cfg = get_train_config(proj_config, shuffle=shuffle)
+
+    try:
+        dlc_cfg.net_type = "resnet_50"
+        sess, mu_n, _, scmap, _, inputs = setup_dgp_eval_graph(dlc_cfg, dgp_model_file)
+    except KeyError:
+        dlc_cfg.net_type = "resnet_101"
+        sess, mu_n, _, scmap, _, inputs = setup_dgp_eval_graph(dlc_cfg, dgp_model_file)
+    sess.max_batch = int(batch_size)
+
+    nj = dlc_cfg.num_joints
+    markers = np.zeros((n_frames, nj, 2))
+    likelihoods = np.zeros((n_frames, nj))
+    scale_x = scale_y = 1
+
+    def prep(frame):
+        nonlocal scale_x, scale_y
+        if new_size is None and crop_size is None:
+            return np.asarray(frame)
+        from PIL import Image
+        im = Image.fromarray(frame)
+        if new_size is not None:
+            scale_x = im.width / new_size[1]
+            scale_y = im.height / new_size[0]
+            im = im.resize(size=(new_size[1], new_size[0]))
+        if crop_size is not None:
+            im = im.crop(crop_size)
+        return np.asarray(im)
+
+    def flush(buf, start):
+        if not buf:
+            return
+        mu, lik = sess.run([mu_n, sess.likelihood], feed_dict={inputs: np.stack(buf)})
+        markers[start:start + len(buf)] = mu
+        likelihoods[start:start + len(buf)] = lik
+
+    buf, start, ii = [], 0, -1
+    for ii, frame in enumerate(video_clip.iter_frames()):
+        if ii >= n_frames:
+            break
+        buf.append(prep(frame))
+        if len(buf) == batch_size:
+            flush(buf, start)
+            start, buf = ii + 1, []
+    flush(buf, start)
+    sess.close()
+    video_clip.close()
+
+    xr = markers[:, :, 1] * dlc_cfg.stride + 0.5 * dlc_cfg.stride      # eval.py:352-353
+    yr = markers[:, :, 0] * dlc_cfg.stride + 0.5 * dlc_cfg.stride
+    xr *= scale_x
+    yr *= scale_y
+    labels = {"x": xr, "y": yr, "likelihoods": likelihoods}
+    if save_pose:
+        if not Path(save_file).parent.exists():
+            os.makedirs(os.path.dirname(save_file))
+        export_pose_like_dlc(labels, os.path.basename(str(dgp_model_file)), dlc_cfg.all_joints_names, save_file)
+    return labels
+
+
+def export_pose_like_dlc(labels, scorer, joints_names, save_file):
+    """DLC-format export (eval.py:621-645): columns MultiIndex (scorer, bodyparts, coords), index = frame
+    number; csv always, hdf5 (key df_with_missing, table format) when pytables is installed."""
+    import pandas as pd
+    n_frames, n_labels = labels["x"].shape
+    data = np.empty((n_frames, 3 * n_labels), dtype=labels["x"].dtype)
+    data[:, 0::3] = labels["x"]
+    data[:, 1::3] = labels["y"]
+    data[:, 2::3] = labels["likelihoods"]
+    cols = pd.MultiIndex.from_product([[scorer], list(joints_names), ["x", "y", "likelihood"]],
+                                      names=["scorer", "bodyparts", "coords"])
+    df = pd.DataFrame(data, columns=cols, index=np.arange(n_frames))
+    try:
+        df.to_hdf(save_file + ".h5", key="df_with_missing", format="table", mode="w")
+    except ImportError:
+        print("pytables not installed: skipping %s.h5 (csv is written)" % save_file)
+    df.to_csv(save_file + ".csv")
+
+
+def load_pose_from_dlc_to_dict(filename):
+    """eval.py:648-653."""
+    dlc = np.genfromtxt(filename, delimiter=",", dtype=None, encoding=None)
+    dlc = dlc[3:, 1:].astype("float")
+    return {"x": dlc[:, 0::3], "y": dlc[:, 1::3], "likelihoods": dlc[:, 2::3]}
+
+
+def plot_dgp(video_file, output_dir="", label_dir=None, proj_cfg_file=None, dgp_model_file=None, shuffle=1, dotsize=3,
+             colormap="jet", save_str="", mask_threshold=0.1, new_size=None):
+    """eval.py:816-874.  Exports the labels when missing, then hands (clip, x, y, mask) to the movie
+    renderer.  Drawing the annotated movie is moviepy / matplotlib work outside this package's scope: when
+    those are absent the labels are still produced and the csv path is returned."""
+    f = os.path.basename(str(video_file)).rsplit(".", 1)
+    save_file = join(output_dir, f[0] + "_labeled%s.mp4" % save_str)
+    if label_dir is None:
+        label_dir = output_dir
+    label_file = join(label_dir, f[0] + "_labeled%s.csv" % save_str)
+    if not os.path.exists(label_file):
+        estimate_pose(proj_cfg_file, dgp_model_file, video_file, label_dir, shuffle=shuffle, save_str=save_str,
+                      new_size=new_size)
+    labels = load_pose_from_dlc_to_dict(label_file)
+    mask_array = labels["likelihoods"].T > mask_threshold
+    try:
+        from moviepy.editor import VideoFileClip  # noqa: F401
+    except ImportError:
+        print("moviepy not installed: labels written to %s, annotated movie skipped (%d/%d markers above the "
+              "%.2f likelihood mask)" % (label_file, int(mask_array.sum()), mask_array.size, mask_threshold))
+        return label_file
+    from .render import create_annotated_movie           # thin moviepy wrapper, optional
+    create_annotated_movie(video_file, labels["x"].T, labels["y"].T, mask_array=mask_array, filename=save_file,
+                           dotsize=dotsize, colormap=colormap)
+    return save_file

@@ -1,0 +1,166 @@
+"""CPU tests of the oracle: golden vectors produced by the reference's own numpy code (A4, A6),
+known answers for the TF-semantics restatement (A1-A3), and an independent C cross-check."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dgp_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz"))
+
+
+# ------------------------------------------------------------------ golden: reference numpy code
+def test_argmax_pose_predict_matches_reference_vectors():
+    for i in range(int(GOLD["app_n"])):
+        scmap = GOLD["app%d_scmap" % i]
+        off = GOLD["app%d_off" % i] if ("app%d_off" % i) in GOLD.files else None
+        pose, loc = O.argmax_pose_predict(scmap, off, 8.0)
+        np.testing.assert_array_equal(pose, GOLD["app%d_pose" % i])
+        # the oracle's fp32 sigmoid reproduces the fixture's probabilities from the logits
+        np.testing.assert_allclose(O.sigmoid_f32(GOLD["app%d_logits" % i]), scmap, rtol=0, atol=1.2e-7)
+    assert GOLD["app0_pose"][0, :2].tolist() == [3 * 8 + 4 + float(GOLD["app0_off"][2, 3, 0, 0]),
+                                                2 * 8 + 4 + float(GOLD["app0_off"][2, 3, 0, 1])]
+
+
+def test_likelihood_window_matches_reference_vectors():
+    for i in range(int(GOLD["lik_n"])):
+        idx, lik = O.likelihood_window(GOLD["lik%d_scmap" % i], GOLD["lik%d_mu" % i])
+        np.testing.assert_array_equal(idx, GOLD["lik%d_idx" % i])
+        np.testing.assert_array_equal(lik, GOLD["lik%d_lik" % i])
+
+
+# ------------------------------------------------------------------ known answers (TF semantics)
+def test_tf_same_padding_arithmetic():
+    assert O.tf_same_pads(240, 3, 2) == (120, 0, 1)        # even: extra pixel AFTER
+    assert O.tf_same_pads(187, 3, 2) == (94, 1, 1)
+    assert O.tf_same_pads(30, 3, 1, 2) == (30, 2, 2)       # atrous rate 2
+    assert O.tf_same_pads(60, 1, 2) == (30, 0, 0)
+
+
+def test_feature_and_scoremap_dims():
+    from deepgraphpose_amd.arch import feature_hw, scoremap_hw
+    from deepgraphpose_amd.dataset import compute_pred_dims
+    assert feature_hw(480, 640) == (30, 40) and scoremap_hw(480, 640) == (60, 80)
+    assert feature_hw(747, 832) == (47, 52) and scoremap_hw(747, 832) == (94, 104)
+    assert feature_hw(720, 1280) == (45, 80) and compute_pred_dims(720, 1280) == (90, 160)
+
+
+def test_unit_plan_matches_slim_stack_blocks_dense():
+    from deepgraphpose_amd.arch import resnet_units, conv_macs_per_frame
+    u = resnet_units(50)
+    assert len(u) == 16
+    assert [x.stride for x in u] == [1, 1, 2, 1, 1, 1, 2] + [1] * 9        # stride on the LAST unit, block3 dense
+    assert [x.rate for x in u] == [1] * 13 + [2, 2, 2]                      # block4 atrous rate 2
+    assert len(resnet_units(101)) == 33
+    assert abs(conv_macs_per_frame(480, 640) / 1e9 - 35.61) < 0.01         # BASELINE.md work model
+    assert abs(conv_macs_per_frame(720, 1280, 101, 20, True) / 1e9 - 178.73) < 0.01
+
+
+def test_gaussian_taps_constants():
+    np.testing.assert_allclose(O.gaussian_taps(1), [0.27406862, 0.45186276, 0.27406862], rtol=1e-6)
+    g2 = O.gaussian_taps(2)
+    assert len(g2) == 5 and abs(g2.sum() - 1) < 1e-6 and g2[2] == g2.max()
+
+
+def test_deconv_unit_impulse_stamps_kernel():
+    """x = delta at (i, j) -> the 3x3 kernel appears at rows 2i..2i+2, cols 2j..2j+2 (no flip), cropped."""
+    w = np.arange(9, dtype=np.float32).reshape(3, 3, 1, 1) + 1
+    x = np.zeros((1, 4, 5, 1), np.float32)
+    x[0, 1, 2, 0] = 1
+    y = O.conv2d_transpose_same(x, w, None)[0, :, :, 0]
+    assert y.shape == (8, 10)
+    ref = np.zeros((8, 10), np.float32)
+    ref[2:5, 4:7] = w[:, :, 0, 0]
+    np.testing.assert_array_equal(y, ref)
+    x[:] = 0
+    x[0, 3, 4, 0] = 1                           # last cell: the stamp is cut by the 2H x 2W crop
+    y = O.conv2d_transpose_same(x, w, None)[0, :, :, 0]
+    np.testing.assert_array_equal(y[6:8, 8:10], w[:2, :2, 0, 0])
+
+
+def test_soft_argmax_one_hot_closed_form():
+    g = O.gaussian_taps(1).astype(np.float64)
+    H, W = 10, 7
+    for r, c in [(4, 3), (0, 0), (9, 6)]:
+        s = np.full((1, H, W, 1), -200.0, np.float32)
+        s[0, r, c, 0] = 0
+        mu, pm = O.argmax_2d_from_cm(s, 1.0, 1)
+        def ex(p, n):
+            ks = [(p + d, g[d + 1]) for d in (-1, 0, 1) if 0 <= p + d < n]
+            return sum(a * b for a, b in ks) / sum(b for _, b in ks)
+        assert abs(mu[0, 0, 0] - ex(r, H)) < 1e-5 and abs(mu[0, 0, 1] - ex(c, W)) < 1e-5
+        assert abs(pm.sum() - 1) < 1e-5
+
+
+def test_argmax_tie_is_first_row_major():
+    s = np.zeros((4, 5, 1), np.float32)
+    s[1, 3, 0] = s[2, 0, 0] = 0.9
+    _, loc = O.argmax_pose_predict(s, None, 8.0)
+    assert loc.tolist() == [[1, 3]]
+
+
+# ------------------------------------------------------------------ independent C restatement
+@pytest.fixture(scope="module")
+def naive():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_build", "libdgp_naive.so"))
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.mark.parametrize("k,stride,rate", [(1, 1, 1), (3, 1, 1), (3, 2, 1), (3, 1, 2), (7, 2, 1), (1, 2, 1)])
+def test_conv_restatement_vs_naive_c(naive, k, stride, rate):
+    rng = np.random.default_rng(k * 10 + stride + rate)
+    N, H, W, Ci, Co = 2, 11, 14, 5, 6
+    x = rng.standard_normal((N, H, W, Ci)).astype(np.float32)
+    w = rng.standard_normal((k, k, Ci, Co)).astype(np.float32)
+    ref = O._to_nhwc(O.conv2d_same(O._to_nchw(x), w, stride, rate))
+    keff = (k - 1) * rate + 1
+    pad = (keff - 1) // 2 if stride > 1 else O.tf_same_pads(H, k, 1, rate)[1]
+    Ho, Wo = ref.shape[1:3]
+    y = np.empty((N, Ho, Wo, Co), np.float32)
+    naive.naive_conv2d(_p(x), N, H, W, Ci, _p(w), k, k, Co, stride, rate, pad, pad, Ho, Wo, _p(y))
+    np.testing.assert_allclose(ref, y, rtol=1e-4, atol=1e-4)
+
+
+def test_deconv_maxpool_softargmax_vs_naive_c(naive):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 5, 6, 7)).astype(np.float32)
+    w = rng.standard_normal((3, 3, 4, 7)).astype(np.float32)
+    b = rng.standard_normal(4).astype(np.float32)
+    ref = O.conv2d_transpose_same(x, w, b)
+    y = np.empty_like(ref)
+    naive.naive_conv2d_transpose(_p(x), 2, 5, 6, 7, _p(w), 3, 3, 4, _p(b), 2, _p(y))
+    np.testing.assert_allclose(ref, y, rtol=1e-4, atol=1e-4)
+    for hw in [(12, 10), (11, 9)]:
+        xp = rng.standard_normal((1,) + hw + (3,)).astype(np.float32)
+        refp = O._to_nhwc(O.max_pool_same(O._to_nchw(xp), 3, 2))
+        yp = np.empty_like(refp)
+        naive.naive_maxpool_same(_p(xp), 1, hw[0], hw[1], 3, 3, 2, _p(yp))
+        np.testing.assert_array_equal(refp, yp)
+    s = (rng.standard_normal((2, 9, 8, 3)) * 3).astype(np.float32)
+    for gl in (1, 2):
+        mu32, _ = O.argmax_2d_from_cm(s, 1.5, gl)
+        mu = np.empty((2, 3, 2), np.float64)
+        naive.naive_soft_argmax(_p(s), 2, 9, 8, 3, C.c_double(1.5), gl, _p(mu))
+        np.testing.assert_allclose(mu32, mu, atol=2e-5)
+
+
+def test_batch_norm_and_backbone_shapes():
+    from deepgraphpose_amd.synthetic import make_weights, make_frames
+    w = make_weights(50, 3, True, seed=5)
+    fr = make_frames(1, 64, 80, 3, seed=1)
+    f, ends = O.resnet_features(fr, w, 50, return_endpoints=True)
+    assert f.shape == (1, 4, 5, 2048)
+    assert ends["conv1"].shape == (1, 32, 40, 64) and ends["pool1"].shape == (1, 16, 20, 64)
+    s, l = O.pose_heads(f, w, True)
+    assert s.shape == (1, 8, 10, 3) and l.shape == (1, 8, 10, 6)
+    assert np.isfinite(f).all() and f.min() >= 0
