@@ -43,7 +43,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=8, help="frames in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-frames", type=int, default=64, help="frames in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="torch CPU threads for the baseline (16 was the fastest of 8..128 on the GPU box)")
     ap.add_argument("--layer-table", type=str, default="", help="write the per-launch table (tsv) here")
     args = ap.parse_args()
 
@@ -135,6 +137,15 @@ def main():
         "steps_profiled": n_prof,
         "whole_step_frac": round(flop_frame * B / (elapsed / K) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
     }
+    # HBM traffic of the conv launches of one step, from the committed rocprofv3 PMC passes of this same
+    # command (scripts/profile.sh -> profiles/traffic_r1.json); null when no profile has been taken.
+    tj = os.path.join(ROOT, "profiles", "traffic_r1.json")
+    if os.path.exists(tj):
+        try:
+            roofline["traffic"] = float(json.load(open(tj))["conv_hbm_bytes_per_step"])
+            roofline["traffic_unit"] = "bytes per step (54 conv launches), PMC FETCH_SIZE x2 + WRITE_SIZE"
+        except Exception:
+            pass
     if args.layer_table:
         os.makedirs(os.path.dirname(os.path.abspath(args.layer_table)), exist_ok=True)
         with open(args.layer_table, "w") as f:
@@ -154,26 +165,31 @@ def main():
 
     if not args.no_cpu_baseline:
         from oracle import dgp_oracle as O      # checker / baseline only
-        nf = args.cpu_frames
-        fr = ring[0][:nf].cpu().numpy()
-        torch.set_num_threads(os.cpu_count() or 1)
+        nf = max(8, args.cpu_frames // 8 * 8)
+        ncmp = 8
+        fr = ring[0][:ncmp].cpu().numpy()
+        nthreads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+        torch.set_num_threads(nthreads)
         O.infer(fr[:1], wts, 50, STRIDE, 1.0, 1)                       # warm-up
         c0 = time.perf_counter()
         ref = O.infer(fr, wts, 50, STRIDE, 1.0, 1)
+        for b in range(1, nf // 8):                                     # same work, other batches of the ring
+            O.infer(ring[b % RING][:8].cpu().numpy(), wts, 50, STRIDE, 1.0, 1)
         c1 = time.perf_counter()
-        m, c, ix = net.infer(ring[0][:nf].contiguous(), 1.0, 1)
+        m, c, ix = net.infer(ring[0][:ncmp].contiguous(), 1.0, 1)
         m = m.cpu().numpy().astype(np.float64)
         ex = m[:, :, 1] * STRIDE + 0.5 * STRIDE - ref["x"]
         ey = m[:, :, 0] * STRIDE + 0.5 * STRIDE - ref["y"]
         err = np.sqrt(ex ** 2 + ey ** 2)
         out["cpu_baseline"] = {
-            "value": round(nf / (c1 - c0), 3), "unit": "frames/s", "cores": torch.get_num_threads(),
+            "value": round(nf / (c1 - c0), 3), "unit": "frames/s", "cores": nthreads,
             "kind": "port",
-            "sample": "%d frames of the same workload in one batch after a 1-frame warm-up; fp32 torch-CPU "
-                      "restatement of the TF1 reference path (TF1 unavailable)" % nf,
+            "sample": "%d frames of the same workload as %d batches of 8 after a 1-frame warm-up (%.1f s); fp32 "
+                      "torch-CPU restatement of the TF1 reference path (TF1 unavailable); %d host CPUs visible"
+                      % (nf, nf // 8, c1 - c0, os.cpu_count() or 0),
         }
         out["accuracy_vs_oracle"] = {
-            "px_rmse": float(np.sqrt((err ** 2).mean())), "px_max": float(err.max()), "frames": nf,
+            "px_rmse": float(np.sqrt((err ** 2).mean())), "px_max": float(err.max()), "frames": ncmp,
             "idx_bit_exact": bool(np.array_equal(ix.cpu().numpy(), ref["idx"])),
         }
     print(json.dumps(out), flush=True)

@@ -14,6 +14,6 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_C
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > "$OUT/bench_pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH > "$OUT/bench_pmc_write.log" 2>&1
 python3 scripts/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
-tail -5 "$OUT"/bench_*.log | cut -c1-600
+for f in "$OUT"/bench_*.log; do grep -h "^{" "$f" | cut -c1-400; done
 find "$OUT" -name "*.csv" | head -20
 du -sh "$OUT"
