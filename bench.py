@@ -88,13 +88,15 @@ def main():
         if record:
             traj[i * B:(i + 1) * B] = ddist.pack_keypoints(mu, conf, idx)
 
+    use_pg = dist.is_initialized()
+
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier(device_ids=[local_rank])
 
     for i in range(Wm):
         step(i % max(K, 1))
-    if world > 1:   # warm the collective too
+    if use_pg:      # warm the collective too
         ddist.gather_trajectory(traj, world * n_local)
     torch.cuda.synchronize(dev)
 
@@ -111,13 +113,13 @@ def main():
     n_prof, launches = net.profile_end()
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_pg:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     assert full.shape[0] == world * n_local
 
     if rank != 0:
-        if world > 1:
+        if use_pg:
             dist.destroy_process_group()
         return
 
@@ -193,7 +195,7 @@ def main():
             "idx_bit_exact": bool(np.array_equal(ix.cpu().numpy(), ref["idx"])),
         }
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

@@ -38,7 +38,7 @@ def unpack_keypoints(buf: torch.Tensor):
 def gather_trajectory(local: torch.Tensor, n_frames: int, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
     """All-gather per-rank packed keypoints [T_r, nj, 5] into the frame-ordered [T, nj, 5]
     on every rank.  Shards are padded to ceil(T/W) so one fixed-size all-gather suffices."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized():
         return local[:n_frames]
     world = dist.get_world_size(group)
     per = -(-n_frames // world)
@@ -59,7 +59,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ       # under torchrun, even with 1 rank
+    if (world > 1 or launched) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

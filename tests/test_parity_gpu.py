@@ -181,7 +181,7 @@ def test_hard_argmax_bit_exact(eng, with_locref):
 
 
 # ---------------------------------------------------------------------------- whole net
-@pytest.mark.parametrize("hw,depth,nj,B", [((96, 128), 50, 4, 3), ((75, 83), 50, 5, 2)])
+@pytest.mark.parametrize("hw,depth,nj,B", [((96, 128), 50, 4, 3), ((75, 83), 50, 5, 2), ((64, 96), 101, 20, 1)])
 def test_network_small_matches_oracle(eng, hw, depth, nj, B):
     from oracle import dgp_oracle as O
     from deepgraphpose_amd.synthetic import make_weights, make_frames
