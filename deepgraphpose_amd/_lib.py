@@ -21,6 +21,13 @@ class DgpTensorView(C.Structure):
                 ("shape", C.c_int64 * 4)]
 
 
+class DgpLossDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("nt", "H", "W", "nj", "nl", "n_visible", "n_hidden", "gm2", "gm3",
+                                          "gauss_len", "huber")] + \
+               [(n, C.c_float) for n in ("gamma", "lengthscale", "stride", "wn_visible", "wn_hidden",
+                                         "locref_loss_weight", "n_frames_total", "n_visible_frames_total")]
+
+
 class DgpConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "N", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "rate", "pad_t", "pad_l", "Ho", "Wo", "relu",
@@ -45,6 +52,8 @@ SYMBOLS = {
     "dgp_net_profile_begin": (C.c_int, [_vp, _i32]),
     "dgp_net_profile_end": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "dgp_net_profile_launch": (C.c_int, [_vp, _i32, C.c_char_p, _i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dgp_loss_scratch_bytes": (C.c_int, [C.POINTER(DgpLossDesc), C.POINTER(_sz)]),
+    "dgp_loss_fwd_bwd": (C.c_int, [C.POINTER(DgpLossDesc)] + [_vp] * 16 + [_sz, _vp]),
     "dgp_packed_weight_floats": (_sz, [_i32, _i32, _i32, _i32]),
     "dgp_pack_conv_weights": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp]),
     "dgp_conv2d": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -43,6 +43,25 @@ hipError_t launch_soft_argmax(const float* scmap, int B, int H, int W, int C, fl
 hipError_t launch_hard_argmax(const float* scmap, const float* locref, int B, int H, int W, int C,
                               int* idx, float* prob, float* offs, hipStream_t s);
 
+// Arguments of the DGP loss forward+backward kernels (dgp_loss.hip).
+struct LossArgs {
+    const float* pred;          // [nt,H,W,nj]
+    const float* locref_pred;   // [nt,H,W,2nj]
+    const float* mu;            // [nt*nj,2] soft-argmax of pred
+    const float* targets;       // [n_vis_frames*nj,2] labels (NaN -> 0), scoremap units (row, col)
+    const float* locref_map;    // [nt,H,W,2nj]
+    const float* locref_mask;   // [nt,H,W,2nj]
+    const int* visible_marker; const int* hidden_marker; const int* visible_in_targets;
+    const float* S0; const float* ws; const float* ws_max;     // [nl,nj], [nl], [nl]
+    float* dpred; float* dlocref;
+    float* losses;              // [8]: visible, hidden, locref, ws, total, total_visible
+    float* t_all; float* dLdt; int* kind; float* stats; float* norm;   // scratch
+    int nt, H, W, nj, nl, n_v, n_h;
+    int gm2, gm3, gauss_len, huber;
+    float gamma, lengthscale, stride, hidden_scale, clique_scale, locref_weight;
+};
+hipError_t launch_loss(const LossArgs& a, hipStream_t s);
+
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
 

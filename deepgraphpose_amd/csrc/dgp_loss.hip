@@ -1,0 +1,386 @@
+// DGP loss: forward + backward w.r.t. the two head outputs, as wavefront-reduction kernels (gfx950).
+//
+// Restates dgp_loss (DGP/models/fitdgp.py:946-1076) on [nt, H, W, nj] scoremaps:
+//   mu = soft-argmax(pred)                      fitdgp_util.py:342-402   (kernel in dgp_kernels.hip)
+//   t  = labels for visible markers, mu for hidden ones (no stop_gradient)      fitdgp.py:946-961
+//   G  = exp(-|alpha - t|^2 / 2l^2) / (max G + 1e-5)                           :964-976
+//   visible CE, hidden CE (gm2 in {0,1,2}, gm3 in {0,3})                       :979-1039
+//   locref Huber on visible markers                                            :1041-1055
+//   spatial clique ("skeleton graph smoothness")                               :1060-1076
+// and their gradient d total / d pred, d total / d locref_pred, including the path through the hidden
+// targets (Gaussian target + clique -> mu -> softmax).  Maps are tiny (<= 14 400 px), so every kernel is one
+// workgroup per marker map with LDS-resident probabilities and fp64 wave reductions.
+//
+// The temporal clique (fitdgp.py:1079-1124) is off by default in the reference (wt = 0) and not built yet.
+#include "dgp_internal.h"
+
+namespace dgp {
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wmaxf(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide helpers for 256 threads; `red` is 8 doubles of LDS
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wsum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max(float v, double* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wmaxf(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = (double)v;
+    __syncthreads();
+    return fmaxf(fmaxf((float)red[0], (float)red[1]), fmaxf((float)red[2], (float)red[3]));
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float ce_logits(float z, float x) {      // tf.nn.sigmoid_cross_entropy_with_logits
+    return fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: marker assembly + spatial clique (single workgroup).
+//   t_all[m] = label (visible) | mu (hidden); kind[m] = 0 visible / 1 hidden
+//   ws_loss and dL/dt (clique part) for every marker.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void loss_assemble_clique(LossArgs a) {
+    __shared__ double red[8];
+    const int nm = a.nt * a.nj;
+    for (int m = threadIdx.x; m < nm; m += 256) {
+        a.kind[m] = -1;
+        a.t_all[2 * m] = 0.f; a.t_all[2 * m + 1] = 0.f;
+        a.dLdt[2 * m] = 0.f; a.dLdt[2 * m + 1] = 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.n_h; i += 256) {
+        const int m = a.hidden_marker[i];
+        a.kind[m] = 1;
+        a.t_all[2 * m] = a.mu[2 * m]; a.t_all[2 * m + 1] = a.mu[2 * m + 1];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.n_v; i += 256) {
+        const int m = a.visible_marker[i], s = a.visible_in_targets[i];
+        a.kind[m] = 0;
+        a.t_all[2 * m] += a.targets[2 * s]; a.t_all[2 * m + 1] += a.targets[2 * s + 1];   // scatter_nd adds
+    }
+    __syncthreads();
+    double loss = 0.0;
+    if (a.nl > 0) {
+        const float C = a.clique_scale;      // 1/(H W) * n_vis_tot / n_vis_batch / (n_vis_tot + n_hid_tot) / wn_visible
+        for (int e = threadIdx.x; e < a.nl * a.nt; e += 256) {
+            const int l = e / a.nt, n = e - l * a.nt;
+            float d0 = 0.f, d1 = 0.f;
+            for (int j = 0; j < a.nj; ++j) {
+                const float s = a.S0[l * a.nj + j];
+                if (s != 0.f) {
+                    d0 += s * (a.t_all[2 * (n * a.nj + j)] * a.stride + 0.5f * a.stride);
+                    d1 += s * (a.t_all[2 * (n * a.nj + j) + 1] * a.stride + 0.5f * a.stride);
+                }
+            }
+            const float dist = sqrtf(d0 * d0 + d1 * d1);
+            const float wmax = a.ws_max[l], wsl = a.ws[l];
+            loss += (double)((fmaxf(dist - wmax, 0.f) + wmax) * wsl * C);
+            if (dist > wmax) {
+                const float g0 = C * wsl * d0 / dist * a.stride, g1 = C * wsl * d1 / dist * a.stride;
+                for (int j = 0; j < a.nj; ++j) {
+                    const float s = a.S0[l * a.nj + j];
+                    if (s != 0.f) {
+                        atomicAdd(&a.dLdt[2 * (n * a.nj + j)], s * g0);
+                        atomicAdd(&a.dLdt[2 * (n * a.nj + j) + 1], s * g1);
+                    }
+                }
+            }
+        }
+    }
+    loss = block_sum(loss, red);
+    if (threadIdx.x == 0) a.losses[3] = (float)loss;     // ws_loss
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: c = max sigmoid(x) per marker (needed across markers for the gm3 = 3 normaliser).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void loss_marker_stats(LossArgs a) {
+    __shared__ double red[8];
+    const int m = blockIdx.x, n = m / a.nj, cj = m - n * a.nj;
+    const int HW = a.H * a.W;
+    const float* x = a.pred + (long long)n * HW * a.nj + cj;
+    float qmax = -1.f;
+    for (int i = threadIdx.x; i < HW; i += 256) qmax = fmaxf(qmax, sigmoidf(x[(long long)i * a.nj]));
+    qmax = block_max(qmax, red);
+    if (threadIdx.x == 0) a.stats[m] = qmax;
+}
+
+// K3: normalisers that need all markers (single workgroup): present = H*W*#{hidden: 1 - c != 0}
+__global__ __launch_bounds__(256) void loss_normalisers(LossArgs a) {
+    __shared__ double red[8];
+    double cnt = 0;
+    for (int i = threadIdx.x; i < a.n_h; i += 256)
+        if (1.f - a.stats[a.hidden_marker[i]] != 0.f) cnt += 1;
+    cnt = block_sum(cnt, red);
+    if (threadIdx.x == 0) {
+        const double HW = (double)a.H * a.W;
+        a.norm[0] = a.n_v > 0 ? (float)(1.0 / (a.n_v * HW)) : 0.f;                        // visible mean
+        a.norm[1] = a.n_h > 0 ? (float)(a.hidden_scale / (a.n_h * HW)) : 0.f;             // hidden, gm3 = 0
+        a.norm[2] = cnt > 0 ? (float)(a.hidden_scale / (cnt * HW)) : 0.f;                 // hidden, gm3 = 3
+        a.losses[0] = 0.f; a.losses[1] = 0.f; a.losses[2] = 0.f;
+        a.norm[3] = 0.f;   // locref nonzero count (filled by loss_locref_count)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: per-marker CE loss + d/dpred (direct) + d/dt, then (hidden markers) back through the soft-argmax.
+// G and sigmoid(x) are computed ONCE into LDS so that the "is this the max element" tests of the
+// reduce_max gradients (ties share the gradient evenly, like tf.reduce_max) are exact.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void loss_ce_backward(LossArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sG = reinterpret_cast<float*>(smem);      // H*W Gaussian bump (later: softmax probabilities)
+    float* sq = sG + a.H * a.W;                      // H*W sigmoid(x)
+    __shared__ double red[8];
+    __shared__ float gk[16];
+    const int m = blockIdx.x, n = m / a.nj, cj = m - n * a.nj;
+    const int kind = a.kind[m];
+    const int HW = a.H * a.W;
+    const long long base = (long long)n * HW * a.nj + cj;
+    const float* x = a.pred + base;
+    float* dx = a.dpred + base;
+    if (kind < 0) {       // marker in neither list: no loss term
+        for (int i = threadIdx.x; i < HW; i += 256) dx[(long long)i * a.nj] = 0.f;
+        return;
+    }
+    const float t0 = a.t_all[2 * m], t1 = a.t_all[2 * m + 1];
+    const float l2 = a.lengthscale * a.lengthscale, inv2l2 = 1.f / (2.f * l2);
+    const bool hidden = kind == 1;
+    const bool use_c = hidden && a.gm2 != 0;           // confidence c enters the hidden term
+    const bool scale_target = hidden && a.gm2 == 1;
+    const bool scaled_logit = hidden && a.gm3 == 3;
+    const float e20 = 1e-20f;
+
+    float gmax = -1.f, c = -1.f;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const int h = i / a.W, w = i - h * a.W;
+        const float dh = (float)h - t0, dw = (float)w - t1;
+        const float G = expf(-(dh * dh + dw * dw) * inv2l2);
+        const float q = sigmoidf(x[(long long)i * a.nj]);
+        sG[i] = G; sq[i] = q;
+        gmax = fmaxf(gmax, G); c = fmaxf(c, q);
+    }
+    gmax = block_max(gmax, red);
+    c = block_max(c, red);
+    double ngd = 0, nqd = 0;
+    for (int i = threadIdx.x; i < HW; i += 256) { if (sG[i] == gmax) ngd += 1; if (sq[i] == c) nqd += 1; }
+    const float ng = (float)block_sum(ngd, red), nq = (float)block_sum(nqd, red);
+    const float gden = gmax + 1e-5f;
+    const float A = !hidden ? a.norm[0] : (scaled_logit ? a.norm[2] * (1.f - c) : a.norm[1]);
+    const float Araw = !hidden ? a.norm[0] : (scaled_logit ? a.norm[2] : a.norm[1]);
+
+    // pass 1: loss value, dL/dc, dL/dGmax accumulators
+    double ce_sum = 0, dLdc = 0, dLdgmax = 0;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const float G = sG[i], g = G / gden, q = sq[i];
+        const float xi = x[(long long)i * a.nj];
+        const float z = scale_target ? g * c : g;
+        float xe = xi, dxe_ds = 0.f;
+        if (scaled_logit) {
+            const float sv = q * c;
+            xe = -logf(1.f - sv + e20) + logf(sv + e20);
+            dxe_ds = 1.f / (sv + e20) + 1.f / (1.f - sv + e20);
+        }
+        ce_sum += (double)ce_logits(z, xe);
+        const float u = A * (sigmoidf(xe) - z);            // dL/dxe
+        const float dLdz = A * (-xe);
+        if (use_c) {
+            if (scaled_logit) dLdc += (double)(u * dxe_ds * q);
+            if (scale_target) dLdc += (double)(dLdz * g);
+        }
+        const float dLdg = scale_target ? dLdz * c : dLdz;
+        dLdgmax += (double)(-dLdg * G / (gden * gden));
+    }
+    ce_sum = block_sum(ce_sum, red);
+    dLdc = block_sum(dLdc, red);
+    dLdgmax = block_sum(dLdgmax, red);
+    if (scaled_logit) dLdc += -(double)Araw * ce_sum;      // d/dc of the (1 - c) weight
+    if (threadIdx.x == 0) atomicAdd(&a.losses[hidden ? 1 : 0], (float)((double)A * ce_sum));
+
+    // pass 2: dL/dx (direct) and dL/dt
+    double gt0 = 0, gt1 = 0;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const int h = i / a.W, w = i - h * a.W;
+        const float dh = (float)h - t0, dw = (float)w - t1;
+        const float G = sG[i], g = G / gden, q = sq[i];
+        const float xi = x[(long long)i * a.nj];
+        const float z = scale_target ? g * c : g;
+        float xe = xi, dxe_ds = 0.f;
+        if (scaled_logit) {
+            const float sv = q * c;
+            xe = -logf(1.f - sv + e20) + logf(sv + e20);
+            dxe_ds = 1.f / (sv + e20) + 1.f / (1.f - sv + e20);
+        }
+        const float u = A * (sigmoidf(xe) - z);
+        float gx;
+        if (scaled_logit) {
+            float dLdq = u * dxe_ds * c;
+            if (q == c) dLdq += (float)(dLdc / nq);
+            gx = dLdq * q * (1.f - q);
+        } else {
+            gx = u;
+            if (use_c && q == c) gx += (float)(dLdc / nq) * q * (1.f - q);
+        }
+        dx[(long long)i * a.nj] = gx;
+        if (hidden) {                 // targets of hidden markers are functions of mu
+            const float dLdz = A * (-xe);
+            const float dLdg = scale_target ? dLdz * c : dLdz;
+            float dLdG = dLdg / gden;
+            if (G == gmax) dLdG += (float)(dLdgmax / ng);
+            const float k = dLdG * G / l2;
+            gt0 += (double)(k * dh);
+            gt1 += (double)(k * dw);
+        }
+    }
+    if (!hidden) return;
+    gt0 = block_sum(gt0, red);
+    gt1 = block_sum(gt1, red);
+    const float g_h = (float)gt0 + a.dLdt[2 * m], g_w = (float)gt1 + a.dLdt[2 * m + 1];
+
+    // ---- back through mu = soft-argmax(x): p = softmax(gamma x), b = blur(p), mu = sum b (h,w) / sum b
+    float* sp = sG;
+    const int r = a.gauss_len;
+    if (threadIdx.x == 0) {
+        float sacc = 0.f;
+        for (int i = -r; i <= r; ++i) { const float xs = (float)i / (float)a.gauss_len; gk[i + r] = expf(-0.5f * xs * xs); sacc += gk[i + r]; }
+        for (int i = 0; i <= 2 * r; ++i) gk[i] /= sacc;
+    }
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < HW; i += 256) { const float v = x[(long long)i * a.nj] * a.gamma; sp[i] = v; mx = fmaxf(mx, v); }
+    mx = block_max(mx, red);
+    double se = 0;
+    for (int i = threadIdx.x; i < HW; i += 256) { const float e = expf(sp[i] - mx); sp[i] = e; se += (double)e; }
+    se = block_sum(se, red);
+    const float den = (float)se;
+    for (int i = threadIdx.x; i < HW; i += 256) sp[i] /= den;
+    __syncthreads();
+    double B = 0, Bh = 0, Bw = 0;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const int h = i / a.W, w = i - h * a.W;
+        float bsum = 0.f;
+        for (int aa = -r; aa <= r; ++aa) {
+            const int hh = h + aa;
+            if ((unsigned)hh >= (unsigned)a.H) continue;
+            for (int bb = -r; bb <= r; ++bb) {
+                const int ww = w + bb;
+                if ((unsigned)ww >= (unsigned)a.W) continue;
+                bsum += gk[aa + r] * gk[bb + r] * sp[hh * a.W + ww];
+            }
+        }
+        B += (double)bsum; Bh += (double)bsum * h; Bw += (double)bsum * w;
+    }
+    B = block_sum(B, red); Bh = block_sum(Bh, red); Bw = block_sum(Bw, red);
+    const float mu_h = (float)(Bh / B), mu_w = (float)(Bw / B), invB = (float)(1.0 / B);
+    // dL/db_i = r_i = (g_h (h - mu_h) + g_w (w - mu_w)) / B inside the map, 0 outside; dL/dp = blur(r)
+    auto dLdp = [&](int h, int w) {
+        float sacc = 0.f;
+        for (int aa = -r; aa <= r; ++aa) {
+            const int hh = h + aa;
+            if ((unsigned)hh >= (unsigned)a.H) continue;
+            for (int bb = -r; bb <= r; ++bb) {
+                const int ww = w + bb;
+                if ((unsigned)ww >= (unsigned)a.W) continue;
+                sacc += gk[aa + r] * gk[bb + r] * (g_h * ((float)hh - mu_h) + g_w * ((float)ww - mu_w)) * invB;
+            }
+        }
+        return sacc;
+    };
+    double inner = 0;
+    for (int i = threadIdx.x; i < HW; i += 256) { const int h = i / a.W, w = i - h * a.W; inner += (double)(sp[i] * dLdp(h, w)); }
+    inner = block_sum(inner, red);
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const int h = i / a.W, w = i - h * a.W;
+        dx[(long long)i * a.nj] += a.gamma * sp[i] * (dLdp(h, w) - (float)inner);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// locref Huber (k = 1) on visible markers: count of non-zero mask entries, then loss + gradient.
+// One workgroup per visible marker; channel pair (2j, 2j+1) of frame n.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void loss_locref_count(LossArgs a) {
+    __shared__ double red[8];
+    const int m = a.visible_marker[blockIdx.x], n = m / a.nj, cj = m - n * a.nj;
+    const int HW = a.H * a.W;
+    const float* mk = a.locref_mask + (long long)n * HW * 2 * a.nj + 2 * cj;
+    double cnt = 0;
+    for (int i = threadIdx.x; i < 2 * HW; i += 256) {
+        const int px = i >> 1, k = i & 1;
+        if (mk[(long long)px * 2 * a.nj + k] != 0.f) cnt += 1;
+    }
+    cnt = block_sum(cnt, red);
+    if (threadIdx.x == 0) atomicAdd(&a.norm[3], (float)cnt);
+}
+
+__global__ __launch_bounds__(256) void loss_locref_backward(LossArgs a) {
+    __shared__ double red[8];
+    const int m = a.visible_marker[blockIdx.x], n = m / a.nj, cj = m - n * a.nj;
+    const int HW = a.H * a.W;
+    const long long base = (long long)n * HW * 2 * a.nj + 2 * cj;
+    const float nz = a.norm[3];
+    const float wgt = nz > 0.f ? a.locref_weight / nz : 0.f;
+    double ls = 0;
+    for (int i = threadIdx.x; i < 2 * HW; i += 256) {
+        const int px = i >> 1, k = i & 1;
+        const long long o = base + (long long)px * 2 * a.nj + k;
+        const float d = a.locref_pred[o] - a.locref_map[o], mk = a.locref_mask[o];
+        const float ad = fabsf(d);
+        float el, de;
+        if (a.huber) { el = ad < 1.f ? 0.5f * d * d : ad - 0.5f; de = ad < 1.f ? d : (d > 0.f ? 1.f : -1.f); }
+        else { el = d * d; de = 2.f * d; }
+        ls += (double)(el * mk);
+        a.dlocref[o] = wgt * mk * de;
+    }
+    ls = block_sum(ls, red);
+    if (threadIdx.x == 0) atomicAdd(&a.losses[2], (float)(ls * wgt));
+}
+
+__global__ void loss_finalize(LossArgs a) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        a.losses[4] = a.losses[0] + a.losses[1] + a.losses[2] + (a.nl > 0 ? a.losses[3] : 0.f);   // total_loss
+        a.losses[5] = a.losses[0] + a.losses[2];                                                 // total_loss_visible
+    }
+}
+
+hipError_t launch_loss(const LossArgs& a, hipStream_t s) {
+    const int nm = a.nt * a.nj;
+    hipError_t e = hipMemsetAsync(a.dlocref, 0, (size_t)a.nt * a.H * a.W * 2 * a.nj * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(loss_assemble_clique, dim3(1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(loss_marker_stats, dim3(nm), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(loss_normalisers, dim3(1), dim3(256), 0, s, a);
+    const size_t smem = (size_t)2 * a.H * a.W * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(loss_ce_backward),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(loss_ce_backward, dim3(nm), dim3(256), smem, s, a);
+    if (a.n_v > 0) {
+        hipLaunchKernelGGL(loss_locref_count, dim3(a.n_v), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(loss_locref_backward, dim3(a.n_v), dim3(256), 0, s, a);
+    }
+    hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace dgp

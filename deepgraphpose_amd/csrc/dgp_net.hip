@@ -554,6 +554,67 @@ int dgp_net_profile_launch(dgp_net* net, int32_t launch, char* name, int32_t nam
     return DGP_OK;
 }
 
+static size_t loss_scratch_layout(const dgp_loss_desc* d, size_t off[8]) {
+    const size_t nm = (size_t)d->nt * d->nj;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
+    off[0] = take(nm * 4);        // conf
+    off[1] = take(nm * 2 * 4);    // idx
+    off[2] = take(nm * 2 * 4);    // t_all
+    off[3] = take(nm * 2 * 4);    // dLdt
+    off[4] = take(nm * 4);        // kind
+    off[5] = take(nm * 4);        // stats
+    off[6] = take(8 * 4);         // norm
+    return o;
+}
+
+int dgp_loss_scratch_bytes(const dgp_loss_desc* d, size_t* out_bytes) {
+    if (!d || !out_bytes || d->nt < 1 || d->nj < 1) return fail(DGP_ERR_INVALID, "dgp_loss_scratch_bytes: bad argument");
+    size_t off[8];
+    *out_bytes = loss_scratch_layout(d, off);
+    return DGP_OK;
+}
+
+int dgp_loss_fwd_bwd(const dgp_loss_desc* d, const float* pred, const float* locref_pred, const float* targets,
+                     const float* locref_map, const float* locref_mask, const int32_t* visible_marker,
+                     const int32_t* hidden_marker, const int32_t* visible_in_targets, const float* S0, const float* ws,
+                     const float* ws_max, float* dpred, float* dlocref, float* mu, float* losses, void* scratch,
+                     size_t scratch_bytes, void* stream) {
+    if (!d || !pred || !locref_pred || !dpred || !dlocref || !mu || !losses || !scratch)
+        return fail(DGP_ERR_INVALID, "dgp_loss_fwd_bwd: null argument");
+    if (d->nt < 1 || d->H < 1 || d->W < 1 || d->nj < 1 || d->nl < 0 || d->n_visible < 0 || d->n_hidden < 0)
+        return fail(DGP_ERR_INVALID, "dgp_loss_fwd_bwd: bad shape");
+    if (!(d->gm2 == 0 || d->gm2 == 1 || d->gm2 == 2) || !(d->gm3 == 0 || d->gm3 == 3) || (d->gm3 == 3 && d->gm2 == 0))
+        return fail(DGP_ERR_INVALID, "dgp_loss_fwd_bwd: Not implemented (gm2 in {0,1,2}, gm3 in {0,3}, gm3=3 needs gm2>0)");
+    if ((size_t)2 * d->H * d->W * sizeof(float) > 150 * 1024) return fail(DGP_ERR_INVALID, "dgp_loss_fwd_bwd: map exceeds LDS");
+    if ((d->n_visible > 0 && (!visible_marker || !visible_in_targets || !targets || !locref_map || !locref_mask)) ||
+        (d->n_hidden > 0 && !hidden_marker) || (d->nl > 0 && (!S0 || !ws || !ws_max)))
+        return fail(DGP_ERR_INVALID, "dgp_loss_fwd_bwd: missing marker / target / skeleton arrays");
+    size_t off[8];
+    if (scratch_bytes < loss_scratch_layout(d, off)) return fail(DGP_ERR_INVALID, "dgp_loss_fwd_bwd: scratch too small");
+    char* sc = (char*)scratch;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = launch_soft_argmax(pred, d->nt, d->H, d->W, d->nj, d->gamma, d->gauss_len, mu, (float*)(sc + off[0]),
+                                      (int*)(sc + off[1]), nullptr, s);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("loss soft_argmax: ") + hipGetErrorString(e));
+    LossArgs a{};
+    a.pred = pred; a.locref_pred = locref_pred; a.mu = mu; a.targets = targets; a.locref_map = locref_map;
+    a.locref_mask = locref_mask; a.visible_marker = visible_marker; a.hidden_marker = hidden_marker;
+    a.visible_in_targets = visible_in_targets; a.S0 = S0; a.ws = ws; a.ws_max = ws_max; a.dpred = dpred; a.dlocref = dlocref;
+    a.losses = losses; a.t_all = (float*)(sc + off[2]); a.dLdt = (float*)(sc + off[3]); a.kind = (int*)(sc + off[4]);
+    a.stats = (float*)(sc + off[5]); a.norm = (float*)(sc + off[6]);
+    a.nt = d->nt; a.H = d->H; a.W = d->W; a.nj = d->nj; a.nl = d->nl; a.n_v = d->n_visible; a.n_h = d->n_hidden;
+    a.gm2 = d->gm2; a.gm3 = d->gm3; a.gauss_len = d->gauss_len; a.huber = d->huber;
+    a.gamma = d->gamma; a.lengthscale = d->lengthscale; a.stride = d->stride; a.locref_weight = d->locref_loss_weight;
+    const double n_vis_tot = d->n_visible_frames_total, n_hid_tot = d->n_frames_total - d->n_visible_frames_total;
+    const double n_h = d->n_hidden, n_v_eff = d->n_visible > 0 ? d->n_visible : d->n_hidden;     // fitdgp.py:983-984
+    a.hidden_scale = (n_h > 0 && n_hid_tot > 0) ? (float)(n_vis_tot / n_hid_tot * n_h / n_v_eff * d->wn_hidden / d->wn_visible) : 0.f;
+    a.clique_scale = n_v_eff > 0 ? (float)(1.0 / ((double)d->H * d->W) * n_vis_tot / n_v_eff / (n_vis_tot + n_hid_tot) / d->wn_visible) : 0.f;
+    e = launch_loss(a, s);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("loss kernels: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
 size_t dgp_packed_weight_floats(int32_t KH, int32_t KW, int32_t Cin, int32_t Cout) {
     if (KH < 1 || KW < 1 || Cin < 4 || (Cin & 3) || Cout < 1) return 0;
     return (size_t)nk_for(KH, KW, Cin) * 8 * coutp_for(Cout) * 4;

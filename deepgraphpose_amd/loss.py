@@ -1,0 +1,82 @@
+"""Torch-facing wrapper of the DGP loss kernels (include/dgp_hip.h: dgp_loss_fwd_bwd).
+
+`dgp_loss_fwd_bwd` evaluates the loss terms of dgp_loss (DGP/models/fitdgp.py:946-1076) on the head outputs
+and returns d total_loss / d pred and d total_loss / d locref_pred; the backbone backward consumes those."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import _ptr, _stream, _need_cuda
+
+LOSS_NAMES = ("visible_loss_pred", "hidden_loss_pred", "visible_loss_locref", "ws_loss", "total_loss",
+              "total_loss_visible")
+
+
+@dataclass
+class DGPHyper:
+    """Hyper-parameters fit_dgp hard-codes on the config singleton (fitdgp.py:637-654), made explicit."""
+    ws: float = 1000.0
+    ws_max: float = 1.2
+    wt: float = 0.0
+    wt_max: float = 0.0
+    wn_visible: float = 5.0
+    wn_hidden: float = 3.0
+    gamma: float = 1.0
+    gauss_len: int = 1
+    lengthscale: float = 1.0
+    lr: float = 0.005
+    gm2: int = 0
+    gm3: int = 0
+    stride: float = 8.0
+    locref_loss_weight: float = 0.05
+    locref_huber_loss: bool = True
+    momentum: float = 0.9
+    clip_norm: float = 10.0
+
+
+def _dev_i32(a, dev):
+    return torch.as_tensor(np.asarray(a, dtype=np.int32), device=dev).contiguous()
+
+
+def _dev_f32(a, dev):
+    return torch.as_tensor(np.asarray(a, dtype=np.float32), device=dev).contiguous()
+
+
+def dgp_loss_fwd_bwd(pred: torch.Tensor, locref_pred: torch.Tensor, batch: dict, hyper: DGPHyper, S0, ws, ws_max,
+                     n_frames_total: float, n_visible_frames_total: float):
+    """pred [nt,H,W,nj], locref_pred [nt,H,W,2nj] device fp32.  batch: targets [nv,nj,2] (NaN = unlabeled),
+    locref_map / locref_mask [nt,H,W,2nj], visible_marker, hidden_marker, visible_marker_in_targets.
+    -> (losses dict of python floats, dpred, dlocref, mu [nt,nj,2])."""
+    lib = _lib.load()
+    _need_cuda(pred, torch.float32, "pred")
+    _need_cuda(locref_pred, torch.float32, "locref_pred")
+    dev = pred.device
+    nt, H, W, nj = pred.shape
+    vm, hm = _dev_i32(batch["visible_marker"], dev), _dev_i32(batch["hidden_marker"], dev)
+    vt = _dev_i32(batch["visible_marker_in_targets"], dev)
+    targets = _dev_f32(np.nan_to_num(np.asarray(batch["targets"], dtype=np.float64), nan=0.0).reshape(-1, 2), dev)
+    lmap, lmask = _dev_f32(batch["locref_map"], dev), _dev_f32(batch["locref_mask"], dev)
+    S0 = np.asarray(S0, dtype=np.float32).reshape(-1, nj)
+    nl = S0.shape[0]
+    S0d, wsd, wmd = _dev_f32(S0, dev), _dev_f32(ws, dev), _dev_f32(ws_max, dev)
+    d = _lib.DgpLossDesc(nt, H, W, nj, nl, vm.numel(), hm.numel(), hyper.gm2, hyper.gm3, hyper.gauss_len,
+                         int(hyper.locref_huber_loss), hyper.gamma, hyper.lengthscale, hyper.stride, hyper.wn_visible,
+                         hyper.wn_hidden, hyper.locref_loss_weight, float(n_frames_total), float(n_visible_frames_total))
+    nb = C.c_size_t()
+    _lib.check(lib.dgp_loss_scratch_bytes(C.byref(d), C.byref(nb)), "dgp_loss_scratch_bytes")
+    scratch = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+    dpred, dloc = torch.empty_like(pred), torch.empty_like(locref_pred)
+    mu = torch.empty((nt, nj, 2), dtype=torch.float32, device=dev)
+    losses = torch.zeros(8, dtype=torch.float32, device=dev)
+    _lib.check(lib.dgp_loss_fwd_bwd(C.byref(d), _ptr(pred), _ptr(locref_pred), _ptr(targets), _ptr(lmap), _ptr(lmask),
+                                    _ptr(vm), _ptr(hm), _ptr(vt), _ptr(S0d), _ptr(wsd), _ptr(wmd), _ptr(dpred),
+                                    _ptr(dloc), _ptr(mu), _ptr(losses), _ptr(scratch), scratch.numel(), _stream(dev)),
+               "dgp_loss_fwd_bwd")
+    lv = losses.cpu().numpy()
+    return {k: float(lv[i]) for i, k in enumerate(LOSS_NAMES)}, dpred, dloc, mu

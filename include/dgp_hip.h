@@ -114,6 +114,31 @@ int  dgp_net_profile_end(dgp_net* net, int32_t* n_steps, int32_t* n_launches);
 int  dgp_net_profile_launch(dgp_net* net, int32_t launch, char* name, int32_t name_cap,
                             double* flops, double* avg_ms);
 
+/* ---- DGP loss, forward + backward w.r.t. the head outputs (dgp_loss in DGP/models/fitdgp.py:848-1144).
+ * Replaces the loss sub-graph evaluated inside sess.run([loss, train_op]) (fitdgp.py:818).
+ * Marker id = frame_in_batch * nj + joint (DGP/dataset.py:187-239). */
+typedef struct dgp_loss_desc {
+    int32_t nt, H, W, nj, nl;             /* frames in batch, scoremap size, joints, limbs (rows of S0) */
+    int32_t n_visible, n_hidden;          /* lengths of visible_marker / hidden_marker */
+    int32_t gm2, gm3;                     /* hidden-loss variants: gm2 in {0,1,2}, gm3 in {0,3} (fitdgp.py:994-1034) */
+    int32_t gauss_len, huber;             /* soft-argmax blur length; 1 = Huber locref loss, 0 = MSE */
+    float   gamma, lengthscale, stride;   /* dgp_cfg.gamma, .lengthscale, .stride (fitdgp.py:645-647) */
+    float   wn_visible, wn_hidden, locref_loss_weight;
+    float   n_frames_total, n_visible_frames_total;   /* data_batcher totals (fitdgp.py:869-873) */
+} dgp_loss_desc;
+
+int  dgp_loss_scratch_bytes(const dgp_loss_desc* d, size_t* out_bytes);
+/* All pointers are device memory.  pred [nt,H,W,nj], locref_pred / locref_map / locref_mask [nt,H,W,2nj],
+ * targets [n_vis_frames*nj, 2] labels in scoremap (row, col) units with NaN already replaced by 0,
+ * visible_in_targets indexes rows of `targets`; S0 [nl,nj], ws / ws_max [nl].
+ * Outputs: dpred, dlocref (same shapes as the predictions), mu [nt*nj,2],
+ * losses[8] = {visible_loss_pred, hidden_loss_pred, visible_loss_locref, ws_loss, total_loss, total_loss_visible,0,0}. */
+int  dgp_loss_fwd_bwd(const dgp_loss_desc* d, const float* pred, const float* locref_pred, const float* targets,
+                      const float* locref_map, const float* locref_mask, const int32_t* visible_marker,
+                      const int32_t* hidden_marker, const int32_t* visible_in_targets, const float* S0,
+                      const float* ws, const float* ws_max, float* dpred, float* dlocref, float* mu,
+                      float* losses, void* scratch, size_t scratch_bytes, void* stream);
+
 /* ---- single-layer entry points (used by the parity tests and by fit_dgp later) ---- */
 
 /* slim.conv2d / conv2d_same semantics on NHWC fp32 with HWIO weights supplied packed by

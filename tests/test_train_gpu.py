@@ -1,0 +1,71 @@
+"""GPU parity tests of the training-step kernels vs the torch-autograd oracle (oracle/dgp_train_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_loss_case(rng, nt, H, W, nj, n_vis_frames, nan_frac, nl):
+    from deepgraphpose_amd import dataset as D
+    vis_frames = np.sort(rng.choice(nt, n_vis_frames, replace=False))
+    hid_frames = np.setdiff1d(np.arange(nt), vis_frames)
+    jl = np.stack([rng.uniform(1, H - 2, (n_vis_frames, nj)), rng.uniform(1, W - 2, (n_vis_frames, nj))], -1)
+    jl[rng.random((n_vis_frames, nj)) < nan_frac] = np.nan
+    vm, hm, vt = D.gen_idx_chunk(vis_frames, hid_frames, jl)
+    lt, lm = D.coord2map(jl, H, W, nj, 8) if n_vis_frames else (np.zeros((0, H, W, 2 * nj)), np.zeros((0, H, W, 2 * nj)))
+    lmap, lmask = np.zeros((nt, H, W, 2 * nj)), np.zeros((nt, H, W, 2 * nj))
+    if n_vis_frames:
+        lmap[vis_frames], lmask[vis_frames] = lt, lm
+    S0 = np.zeros((nl, nj))
+    for l in range(nl):
+        a, b = rng.choice(nj, 2, replace=False)
+        S0[l, a], S0[l, b] = 1, -1
+    batch = dict(targets=jl, locref_map=lmap, locref_mask=lmask, visible_marker=vm, hidden_marker=hm,
+                 visible_marker_in_targets=vt, nt=nt)
+    return batch, S0
+
+
+@pytest.mark.parametrize("gm2,gm3", [(0, 0), (1, 3), (2, 3), (1, 0)])
+@pytest.mark.parametrize("shape", [(5, 12, 16, 3, 2), (11, 60, 80, 4, 1), (3, 9, 7, 2, 0), (2, 10, 10, 3, 2)])
+def test_loss_forward_backward_matches_autograd(lib_built, gm2, gm3, shape):
+    from deepgraphpose_amd.loss import dgp_loss_fwd_bwd, DGPHyper
+    from oracle import dgp_train_oracle as T
+    nt, H, W, nj, nvf = shape
+    rng = np.random.default_rng(nt * 100 + H + gm2 * 7 + gm3)
+    nl = 0 if nj < 2 else 2
+    if shape == (2, 10, 10, 3, 2):           # all frames visible, some NaN joints -> hidden markers in visible frames
+        batch, S0 = _make_loss_case(rng, nt, H, W, nj, nvf, 0.4, nl)
+    else:
+        batch, S0 = _make_loss_case(rng, nt, H, W, nj, nvf, 0.2, nl)
+    pred = (rng.standard_normal((nt, H, W, nj)) * 2).astype(np.float32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for n in range(nt):
+        for j in range(nj):
+            cy, cx = rng.uniform(0, H - 1), rng.uniform(0, W - 1)
+            pred[n, :, :, j] += 6 * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / 6.0)
+    loc = rng.standard_normal((nt, H, W, 2 * nj)).astype(np.float32)
+    hy = DGPHyper(gm2=gm2, gm3=gm3)
+    ws = rng.uniform(5, 20, S0.shape[0])
+    ws_max = rng.uniform(10, 40, S0.shape[0])
+    n_tot, n_vis_tot = 500.0, 37.0
+    cfg = dict(nj=nj, S0=S0, ws=ws, ws_max=ws_max, stride=8.0, gamma=hy.gamma, gauss_len=hy.gauss_len,
+               lengthscale=hy.lengthscale, gm2=gm2, gm3=gm3, wn_visible=hy.wn_visible, wn_hidden=hy.wn_hidden,
+               locref_loss_weight=hy.locref_loss_weight, locref_huber_loss=True, n_frames_total=n_tot,
+               n_visible_frames_total=n_vis_tot)
+    # oracle in float64 (truth) -- the kernels are fp32 with fp64 reductions
+    pt = torch.tensor(pred, dtype=torch.float64, requires_grad=True)
+    lt = torch.tensor(loc, dtype=torch.float64, requires_grad=True)
+    L = T.dgp_loss(pt, lt, batch, cfg)
+    L["total_loss"].backward()
+    losses, dpred, dloc, mu = dgp_loss_fwd_bwd(torch.from_numpy(pred).cuda(), torch.from_numpy(loc).cuda(), batch, hy,
+                                               S0, ws, ws_max, n_tot, n_vis_tot)
+    for k in ("visible_loss_pred", "hidden_loss_pred", "visible_loss_locref", "total_loss", "total_loss_visible"):
+        assert abs(losses[k] - float(L[k])) <= 2e-5 * max(1.0, abs(float(L[k]))), (k, losses[k], float(L[k]))
+    if S0.shape[0]:
+        assert abs(losses["ws_loss"] - float(L["ws_loss"])) <= 2e-5 * max(1.0, abs(float(L["ws_loss"])))
+    np.testing.assert_allclose(mu.cpu().numpy(), L["_mu"].detach().numpy(), atol=2e-5)
+    gp, gl = pt.grad.numpy(), lt.grad.numpy() if lt.grad is not None else np.zeros_like(loc)
+    scale = np.abs(gp).max() + 1e-12
+    assert np.abs(dpred.cpu().numpy() - gp).max() <= 2e-4 * scale + 1e-9
+    assert np.abs(dloc.cpu().numpy() - gl).max() <= 2e-5 * (np.abs(gl).max() + 1e-12) + 1e-10
