@@ -54,6 +54,19 @@ SYMBOLS = {
     "dgp_net_profile_launch": (C.c_int, [_vp, _i32, C.c_char_p, _i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dgp_loss_scratch_bytes": (C.c_int, [C.POINTER(DgpLossDesc), C.POINTER(_sz)]),
     "dgp_loss_fwd_bwd": (C.c_int, [C.POINTER(DgpLossDesc)] + [_vp] * 16 + [_sz, _vp]),
+    "dgp_trainer_create": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "dgp_trainer_destroy": (None, [_vp]),
+    "dgp_trainer_num_tensors": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "dgp_trainer_tensor_info": (C.c_int, [_vp, _i32, C.c_char_p, _i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                          C.POINTER(_i32)]),
+    "dgp_trainer_buffer": (_vp, [_vp, _i32]),
+    "dgp_trainer_upload": (C.c_int, [_vp, _i32, C.c_int64, _vp, C.c_int64]),
+    "dgp_trainer_download": (C.c_int, [_vp, _i32, C.c_int64, _vp, C.c_int64]),
+    "dgp_trainer_workspace_bytes": (C.c_int, [_vp, _i32, C.POINTER(_sz)]),
+    "dgp_trainer_sync_weights": (C.c_int, [_vp, _vp]),
+    "dgp_train_forward": (C.c_int, [_vp, _vp, _i32, _vp, _sz, C.POINTER(_vp), C.POINTER(_vp), _vp]),
+    "dgp_train_backward": (C.c_int, [_vp, _i32, _vp, _sz, _vp, _vp, _vp]),
+    "dgp_sgd_momentum_clip": (C.c_int, [_vp, _f32, _f32, _f32, C.POINTER(_f32), _vp]),
     "dgp_packed_weight_floats": (_sz, [_i32, _i32, _i32, _i32]),
     "dgp_pack_conv_weights": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp]),
     "dgp_conv2d": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

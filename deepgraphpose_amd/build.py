@@ -9,8 +9,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdgp_hip.so")
-SOURCES = ["dgp_kernels.hip", "dgp_loss.hip", "dgp_net.hip"]
-HEADERS = ["dgp_internal.h", os.path.join("..", "..", "include", "dgp_hip.h")]
+SOURCES = ["dgp_kernels.hip", "dgp_loss.hip", "dgp_net.hip", "dgp_train.hip"]
+HEADERS = ["dgp_internal.h", "dgp_engine.h", os.path.join("..", "..", "include", "dgp_hip.h")]
 
 
 def _hipcc() -> str:

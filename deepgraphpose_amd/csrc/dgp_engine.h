@@ -1,0 +1,73 @@
+// Engine-internal types shared by dgp_net.hip (inference engine) and dgp_train.hip (training step).
+#pragma once
+#include "../../include/dgp_hip.h"
+#include "dgp_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace dgp {
+int fail(int code, const std::string& msg);      // sets the thread-local error string
+}
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return dgp::fail(DGP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));  \
+    } while (0)
+
+namespace dgp {
+
+struct ConvLayer {
+    std::string scope;        // TF scope of the conv (".../conv1"), weights = scope + "/weights"
+    int Cin = 0, Cout = 0, CoutP = 0, KH = 1, KW = 1, stride = 1, rate = 1;
+    int nk = 0, ntaps = 1;
+    bool has_bn = true, relu = false;
+    float *d_w = nullptr, *d_scale = nullptr, *d_bias = nullptr;
+};
+
+struct Unit {
+    int sc = -1, c1 = -1, c2 = -1, c3 = -1;
+    int stride = 1, rate = 1;
+    int depth_in = 0, depth = 0, depth_bn = 0;
+};
+
+int coutp_for(int cout);
+int nk_for(int kh, int kw, int cin);
+void tf_same(int n, int k, int s, int d, int* out, int* pad_before);
+int pad_before_for(int n, int k, int stride, int rate, bool conv2d_same_explicit);
+
+}  // namespace dgp
+
+struct dgp_net {
+    dgp_net_desc desc{};
+    int device = 0;
+    std::vector<dgp::ConvLayer> layers;
+    int conv1 = -1, head_part = -1, head_locref = -1;
+    std::vector<dgp::Unit> units;
+    bool loaded = false;
+    // geometry
+    int h1 = 0, w1 = 0, hp = 0, wp = 0, fh = 0, fw = 0;
+    // optional per-launch timing (hipEvent pairs recorded on the caller's stream)
+    bool prof_on = false, prof_in_infer = false;
+    int prof_slots = 0, prof_used = 0, prof_launches = 0, prof_cursor = 0;
+    std::vector<hipEvent_t> prof_ev;          // [slot][launch][2]
+    std::vector<std::string> prof_names;      // per launch of the last profiled forward
+    std::vector<double> prof_flops;
+    void prof_free() {
+        for (auto e : prof_ev) (void)hipEventDestroy(e);
+        prof_ev.clear();
+    }
+    ~dgp_net() {
+        prof_free();
+        for (auto& l : layers) {
+            if (l.d_w) (void)hipFree(l.d_w);
+            if (l.d_scale) (void)hipFree(l.d_scale);
+            if (l.d_bias) (void)hipFree(l.d_bias);
+        }
+    }
+};

@@ -15,13 +15,15 @@ struct ConvArgs {
     const float* scale;   // [Cout] or nullptr (=1)
     const float* bias;    // [Cout] or nullptr (=0)
     const float* res;     // residual NHWC [N,res_H,res_W,Cout] or nullptr
+    const float* mask;    // backward ReLU gate, same shape as out, or nullptr
     float*       out;
     int N, H, W, Cin, log2cin4;
     int Ho, Wo, Cout, CoutP;
     int KH, KW, stride, dil, pad_t, pad_l;
     int ntaps, nk;        // real taps, number of BK steps
     int M;                // N*Ho*Wo
-    int res_s, res_H, res_W;   // res_s == 0: none
+    int res_s, res_H, res_W;   // res_s == 0: none; s >= 1: residual[n, ho*s, wo*s]; -2: residual on the 2x coarser grid
+    int up;                    // 2: data-gradient gather of a stride-2 conv (input on the zero-stuffed grid)
     int relu;
     int out_mode;         // 0: NHWC [M][Cout]; 1: transposed-conv phase scatter
     int dc_nj;            // channels per phase for out_mode 1

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
     // ---- per-thread A row bookkeeping -------------------------------------------------
     const int c = t & 7;        // chunk within the K-step
     const int rg = t >> 3;      // 0..31
-    int hi0[AROWS], wi0[AROWS], pix0[AROWS];
+    int hi0[AROWS], wi0[AROWS], pix0[AROWS], nbase[AROWS];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
@@ -121,10 +121,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
             hi0[i] = ho * p.stride - p.pad_t;
             wi0[i] = wo * p.stride - p.pad_l;
             pix0[i] = (n * p.H + hi0[i]) * p.W + wi0[i];
+            nbase[i] = n * p.H * p.W;
         } else {
             hi0[i] = -(1 << 28);
             wi0[i] = -(1 << 28);
             pix0[i] = 0;
+            nbase[i] = 0;
         }
     }
     const int cin4m1 = (p.Cin >> 2) - 1;
@@ -144,11 +146,24 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
             const int dh = w_kh * p.dil, dw = w_kw * p.dil;
             const int doff = ((dh * p.W + dw) * p.Cin + w_ch) * 4;
             const bool tapok = w_tap < p.ntaps;
+            if (p.up == 2) {
+                // data-gradient of a stride-2 conv: the input (dY) is read on the zero-stuffed grid, i.e. only
+                // where the virtual coordinate is even:  dX[hi] += dY[(hi + pad' + kh' d) / 2] W[kh']
 #pragma unroll
-            for (int i = 0; i < AROWS; ++i) {
-                const int hi = hi0[i] + dh, wi = wi0[i] + dw;
-                const bool ok = tapok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                ra[i] = buf_load16(rs_in, ok ? (unsigned)(rowoff[i] + doff) : OOB);
+                for (int i = 0; i < AROWS; ++i) {
+                    const int hv = hi0[i] + dh, wv = wi0[i] + dw;
+                    const bool ok = tapok && !((hv | wv) & 1) && (unsigned)(hv >> 1) < (unsigned)p.H &&
+                                    (unsigned)(wv >> 1) < (unsigned)p.W;
+                    const unsigned off = (unsigned)((nbase[i] + (hv >> 1) * p.W + (wv >> 1)) * p.Cin + w_ch + 4 * c) << 2;
+                    ra[i] = buf_load16(rs_in, ok ? off : OOB);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < AROWS; ++i) {
+                    const int hi = hi0[i] + dh, wi = wi0[i] + dw;
+                    const bool ok = tapok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                    ra[i] = buf_load16(rs_in, ok ? (unsigned)(rowoff[i] + doff) : OOB);
+                }
             }
             w_ch += 32;
             if (w_ch >= p.Cin) {
@@ -296,6 +311,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
                                           p.res ? (int)p.res_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_out =
         __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_mask =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.mask ? p.mask : p.in), 0,
+                                          p.mask ? (int)p.out_bytes : 0, 0x00020000);
     const int my_c4 = lane % C4;
     const int my_r0 = lane / C4;
     const int co4 = n0 + wave_n0 + 4 * my_c4;
@@ -315,7 +333,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
             }
         __syncthreads();
         unsigned ooff[NV];
-        float4 rres[NV];
+        float4 rres[NV], rmask[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int row = my_r0 + v * (64 / C4);
@@ -325,6 +343,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
             unsigned roff = OOB;
             if (p.res_s == 1) {
                 roff = ooff[v];
+            } else if (p.res_s == -2 && ok) {        // residual lives on the 2x coarser grid (zero-stuffed upsample)
+                const int n = m / HoWo;
+                const int rem = m - n * HoWo;
+                const int ho = rem / p.Wo;
+                const int wo = rem - ho * p.Wo;
+                if (!((ho | wo) & 1))
+                    roff = (unsigned)(((n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1)) * p.Cout + co4) << 2;
             } else if (p.res_s > 1 && ok) {
                 const int n = m / HoWo;
                 const int rem = m - n * HoWo;
@@ -333,6 +358,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
                 roff = (unsigned)(((n * p.res_H + ho * p.res_s) * p.res_W + wo * p.res_s) * p.Cout + co4) << 2;
             }
             rres[v] = buf_load16(rs_res, roff);      // zeros when there is no residual
+            rmask[v] = buf_load16(rs_mask, ooff[v]);  // ReLU gate of the backward pass (zeros when unused)
         }
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -345,6 +371,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
             o.w = a.w * sc4.w + bi4.w + rres[v].w;
             if (p.relu) {
                 o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+            }
+            if (p.mask) {          // d/dx of ReLU: pass the gradient where the saved activation is positive
+                o.x = rmask[v].x > 0.f ? o.x : 0.f; o.y = rmask[v].y > 0.f ? o.y : 0.f;
+                o.z = rmask[v].z > 0.f ? o.z : 0.f; o.w = rmask[v].w > 0.f ? o.w : 0.f;
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)ooff[v], 0, 0);
         }

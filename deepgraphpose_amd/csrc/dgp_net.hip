@@ -5,45 +5,16 @@
 //   (shortcut | conv1 | conv2 | conv3+residual+ReLU) -> transposed-conv heads,
 // every convolution through the one implicit-GEMM kernel.  It owns only the repacked
 // weights; activations live in the caller's workspace.
-#include "../../include/dgp_hip.h"
-#include "dgp_internal.h"
-
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <map>
-#include <string>
-#include <vector>
+#include "dgp_engine.h"
 
 using namespace dgp;
 
 static thread_local std::string g_err;
-static int fail(int code, const std::string& msg) {
+namespace dgp {
+int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t _e = (expr);                                                                \
-        if (_e != hipSuccess)                                                                  \
-            return fail(DGP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));       \
-    } while (0)
-
-namespace {
-
-struct ConvLayer {
-    std::string scope;        // TF scope of the conv (".../conv1"), weights = scope + "/weights"
-    int Cin = 0, Cout = 0, CoutP = 0, KH = 1, KW = 1, stride = 1, rate = 1;
-    int nk = 0, ntaps = 1;
-    bool has_bn = true, relu = false;
-    float *d_w = nullptr, *d_scale = nullptr, *d_bias = nullptr;
-};
-
-struct Unit {
-    int sc = -1, c1 = -1, c2 = -1, c3 = -1;
-    int stride = 1, rate = 1;
-    int depth_in = 0, depth = 0, depth_bn = 0;
-};
 
 int coutp_for(int cout) {
     if (cout <= 32) return 32;
@@ -51,6 +22,26 @@ int coutp_for(int cout) {
     return round_up(cout, 128);
 }
 int nk_for(int kh, int kw, int cin) { return (kh * kw * (cin / 4) + 7) / 8; }
+
+void tf_same(int n, int k, int s, int d, int* out, int* pad_before) {
+    const int keff = (k - 1) * d + 1;
+    *out = (n + s - 1) / s;
+    int total = (*out - 1) * s + keff - n;
+    if (total < 0) total = 0;
+    *pad_before = total / 2;
+}
+
+// conv2d_same / SAME padding-before for a k x k conv with given stride / rate on extent n
+int pad_before_for(int n, int k, int stride, int rate, bool conv2d_same_explicit) {
+    const int keff = (k - 1) * rate + 1;
+    if (conv2d_same_explicit && stride > 1) return (keff - 1) / 2;     // slim conv2d_same
+    int out, pb;
+    tf_same(n, k, stride, rate, &out, &pb);
+    return pb;
+}
+}  // namespace dgp
+
+namespace {
 
 void pack_panels(const float* hwio, int KH, int KW, int Cin, int Cout, float* packed) {
     const int cin4 = Cin / 4, CoutP = coutp_for(Cout), nk = nk_for(KH, KW, Cin);
@@ -67,44 +58,7 @@ void pack_panels(const float* hwio, int KH, int KW, int Cin, int Cout, float* pa
     }
 }
 
-void tf_same(int n, int k, int s, int d, int* out, int* pad_before) {
-    const int keff = (k - 1) * d + 1;
-    *out = (n + s - 1) / s;
-    int total = (*out - 1) * s + keff - n;
-    if (total < 0) total = 0;
-    *pad_before = total / 2;
-}
-
 }  // namespace
-
-struct dgp_net {
-    dgp_net_desc desc{};
-    int device = 0;
-    std::vector<ConvLayer> layers;
-    int conv1 = -1, head_part = -1, head_locref = -1;
-    std::vector<Unit> units;
-    bool loaded = false;
-    // geometry
-    int h1 = 0, w1 = 0, hp = 0, wp = 0, fh = 0, fw = 0;
-    // optional per-launch timing (hipEvent pairs recorded on the caller's stream)
-    bool prof_on = false, prof_in_infer = false;
-    int prof_slots = 0, prof_used = 0, prof_launches = 0, prof_cursor = 0;
-    std::vector<hipEvent_t> prof_ev;          // [slot][launch][2]
-    std::vector<std::string> prof_names;      // per launch of the last profiled forward
-    std::vector<double> prof_flops;
-    void prof_free() {
-        for (auto e : prof_ev) (void)hipEventDestroy(e);
-        prof_ev.clear();
-    }
-    ~dgp_net() {
-        prof_free();
-        for (auto& l : layers) {
-            if (l.d_w) (void)hipFree(l.d_w);
-            if (l.d_scale) (void)hipFree(l.d_scale);
-            if (l.d_bias) (void)hipFree(l.d_bias);
-        }
-    }
-};
 
 static int add_layer(dgp_net* net, const std::string& scope, int cin, int cout, int k, int stride, int rate,
                      bool bn, bool relu) {
@@ -346,15 +300,6 @@ int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, in
     hipError_t e = launch_conv(a, pick_tile(a.M, a.CoutP, l.nk * BK), s);
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("conv launch (") + l.scope + "): " + hipGetErrorString(e));
     return DGP_OK;
-}
-
-// conv2d_same / SAME padding-before for a k x k conv with given stride / rate on extent n
-int pad_before_for(int n, int k, int stride, int rate, bool conv2d_same_explicit) {
-    const int keff = (k - 1) * rate + 1;
-    if (conv2d_same_explicit && stride > 1) return (keff - 1) / 2;     // slim conv2d_same
-    int out, pb;
-    tf_same(n, k, stride, rate, &out, &pb);
-    return pb;
 }
 
 }  // namespace

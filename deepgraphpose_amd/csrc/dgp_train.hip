@@ -1,0 +1,908 @@
+// Training step of the DGP hot path on gfx950: forward with retained activations, backward through the
+// heads / ResNet (data gradients through the same implicit-GEMM kernel, weight gradients through an
+// fp32-MFMA reduction-over-pixels GEMM), BN-affine / bias gradients, global-norm clip + momentum SGD.
+//
+// Reference: sess.run([loss, train_op]) in fit_dgp (DGP/models/fitdgp.py:708-713,818): TF autodiff of
+// dgp_loss w.r.t. ALL trainable variables (conv weights, BN gamma/beta -- moving statistics stay frozen because
+// the net is built with is_training=False, PET/nnet/pose_net.py:52 -- head weights/biases),
+// clip_by_global_norm(10), MomentumOptimizer(0.9).
+#include "dgp_engine.h"
+#include <cstdlib>
+
+using namespace dgp;
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOBT = 0xFFFFFFF0u;
+
+__device__ __forceinline__ float4 bload16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight (re)packing on the device, from the flat master parameter buffer
+// ------------------------------------------------------------------------------------------------
+// forward panels [nk*8][CoutP][4] from HWIO [KH*KW][Cin_real][Cout]
+__global__ void pack_fwd_kernel(const float* __restrict__ w, int taps, int cin_real, int cin, int cout, int coutP,
+                                int nchunks, float* __restrict__ packed) {
+    const long long total = (long long)nchunks * coutP;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(g % coutP);
+        const int q = (int)(g / coutP);
+        const int cin4 = cin >> 2;
+        const int tap = q / cin4, ch = (q - tap * cin4) << 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tap < taps && co < cout) {
+            float* pv = &v.x;
+            for (int e = 0; e < 4; ++e)
+                if (ch + e < cin_real) pv[e] = w[((long long)tap * cin_real + ch + e) * cout + co];
+        }
+        *reinterpret_cast<float4*>(packed + g * 4) = v;
+    }
+}
+
+// head forward panels: W'[khp][kwp][ci][(a,b),c] = w[a+2-2khp][b+2-2kwp][c][ci] (w is [3,3,njt,Cin])
+__global__ void pack_head_fwd_kernel(const float* __restrict__ w, int njt, int cin, int coutP, int nchunks,
+                                     float* __restrict__ packed) {
+    const long long total = (long long)nchunks * coutP;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(g % coutP);
+        const int q = (int)(g / coutP);
+        const int cin4 = cin >> 2;
+        const int tap = q / cin4, ch = (q - tap * cin4) << 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tap < 4 && co < 4 * njt) {
+            const int khp = tap >> 1, kwp = tap & 1, ph = co / njt, c = co - ph * njt;
+            const int ka = (ph >> 1) + 2 - 2 * khp, kb = (ph & 1) + 2 - 2 * kwp;
+            if (ka <= 2 && kb <= 2) {
+                const float* src = w + (((long long)ka * 3 + kb) * njt + c) * cin + ch;
+                v = make_float4(src[0], src[1], src[2], src[3]);
+            }
+        }
+        *reinterpret_cast<float4*>(packed + g * 4) = v;
+    }
+}
+
+__global__ void fold_bn_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ mean, const float* __restrict__ var, float eps, int C,
+                               float* __restrict__ scale, float* __restrict__ bias) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float inv = gamma[c] / sqrtf(var[c] + eps);
+        scale[c] = inv;
+        bias[c] = beta[c] - mean[c] * inv;
+    }
+}
+
+__global__ void head_bias_kernel(const float* __restrict__ b, int njt, float* __restrict__ bias4) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4 * njt) bias4[i] = b[i % njt];
+}
+
+// data-gradient panels: Wd[tap'][co][ci] = W[taps-1-tap'][ci][co] * scale[co]; K' = taps*Cout (co fastest), N' = Cin
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ scale, int taps, int cin,
+                                  int cout, int cinP, int nchunks, float* __restrict__ packed) {
+    const long long total = (long long)nchunks * cinP;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(g % cinP);
+        const int q = (int)(g / cinP);
+        const int cout4 = cout >> 2;
+        const int tapp = q / cout4, co = (q - tapp * cout4) << 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tapp < taps && ci < cin) {
+            const int tap = taps - 1 - tapp;          // spatial flip (row-major taps: flipping both axes reverses the index)
+            const float* src = w + ((long long)tap * cin + ci) * cout + co;
+            v = make_float4(src[0] * scale[co], src[1] * scale[co + 1], src[2] * scale[co + 2], src[3] * scale[co + 3]);
+        }
+        *reinterpret_cast<float4*>(packed + g * 4) = v;
+    }
+}
+
+// head data-gradient panels: "input" channels = phase-major 4*njt padded to cpad, taps 2x2 flipped, N' = Cin
+__global__ void pack_head_dgrad_kernel(const float* __restrict__ w, int njt, int cin, int cpad, int cinP, int nchunks,
+                                       float* __restrict__ packed) {
+    const long long total = (long long)nchunks * cinP;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(g % cinP);
+        const int q = (int)(g / cinP);
+        const int c4 = cpad >> 2;
+        const int tapp = q / c4, cob = (q - tapp * c4) << 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tapp < 4 && ci < cin) {
+            const int tap = 3 - tapp, khp = tap >> 1, kwp = tap & 1;
+            float* pv = &v.x;
+            for (int e = 0; e < 4; ++e) {
+                const int co = cob + e;
+                if (co >= 4 * njt) continue;
+                const int ph = co / njt, c = co - ph * njt;
+                const int ka = (ph >> 1) + 2 - 2 * khp, kb = (ph & 1) + 2 - 2 * kwp;
+                if (ka <= 2 && kb <= 2) pv[e] = w[(((long long)ka * 3 + kb) * njt + c) * cin + ci];
+            }
+        }
+        *reinterpret_cast<float4*>(packed + g * 4) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient: dWraw[k][co] += sum_m A[m][k] * dY[m][co]   (k = (tap, ci), HWIO order)
+// fp32 MFMA with the output tile's rows = k, cols = co and the reduction over pixels m.  LDS images are the
+// natural [pixel][k] / [pixel][co] row-major tiles (no transposes): an MFMA operand register is one
+// ds_read_b32 of 32 consecutive floats.  The pixel range is split across workgroups (grid.z), partial sums
+// are combined with float atomics (256-B wave shapes).
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* x;       // NHWC [N,H,W,Cin]  (forward input of the conv)
+    const float* dy;      // [M, Cdy] masked upstream gradient (M = N*Ho*Wo)
+    float* dw;            // [Kchunks*4][Cdy] accumulated
+    int N, H, W, Cin, log2cin4, Ho, Wo, Cdy;
+    int KW, stride, dil, pad_t, pad_l, ntaps, kchunks;
+    int M, m_per_block;
+    unsigned x_bytes, dy_bytes;
+};
+
+template <int T>      // tile = 64T (k) x 64T (co); 4 waves as 2 x 2, wave tile 32T x 32T
+__global__ __launch_bounds__(256) void wgrad_f32(const WgradArgs p) {
+    constexpr int BR = 64 * T;               // tile extent (both dims)
+    constexpr int CH = BR / 4;               // 16-byte chunks per tile row
+    constexpr int NLD = 32 * CH / 256;       // staged chunks per thread per operand (T=1: 2, T=2: 4)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sA = reinterpret_cast<float*>(smem);          // [2][32][BR]
+    float* sB = sA + 2 * 32 * BR;                        // [2][32][BR]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, half = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int q0 = blockIdx.x * CH;          // first k-chunk of this tile
+    const int n0 = blockIdx.y * BR;          // first output column
+    const int m_lo = blockIdx.z * p.m_per_block;
+    const int m_hi = min(p.M, m_lo + p.m_per_block);
+    const int nsteps = (m_hi - m_lo + 31) / 32;
+    if (nsteps <= 0) return;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+
+    // this thread stages chunk `cc` of pixel rows pr + (256/CH)*i
+    const int cc = t % CH, pr = t / CH;
+    const int q = q0 + cc;
+    const int cin4m1 = (p.Cin >> 2) - 1;
+    const int tap = q >> p.log2cin4, ch = (q & cin4m1) << 2;
+    const bool qok = q < p.kchunks && tap < p.ntaps;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int dh = kh * p.dil - p.pad_t, dw = kw * p.dil - p.pad_l;
+    const int cob = n0 + 4 * cc;
+    const bool cok = cob < p.Cdy;
+    const int HoWo = p.Ho * p.Wo;
+
+    float4 ra[NLD], rb[NLD];
+    auto gload = [&](int step) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int m = m_lo + step * 32 + pr + (256 / CH) * i;
+            unsigned offa = OOBT, offb = OOBT;
+            if (m < m_hi) {
+                const int n = m / HoWo, rem = m - n * HoWo;
+                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                const int hi = ho * p.stride + dh, wi = wo * p.stride + dw;
+                if (qok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                    offa = (unsigned)(((n * p.H + hi) * p.W + wi) * p.Cin + ch) << 2;
+                if (cok) offb = (unsigned)(m * p.Cdy + cob) << 2;
+            }
+            ra[i] = bload16(rs_x, offa);
+            rb[i] = bload16(rs_dy, offb);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int row = pr + (256 / CH) * i;
+            *reinterpret_cast<float4*>(sA + (buf * 32 + row) * BR + 4 * cc) = ra[i];
+            *reinterpret_cast<float4*>(sB + (buf * 32 + row) * BR + 4 * cc) = rb[i];
+        }
+    };
+    floatx16 acc[T][T];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) gload(s + 1);
+        const float* a_base = sA + buf * 32 * BR + wm * 32 * T + l31;
+        const float* b_base = sB + buf * 32 * BR + wn * 32 * T + l31;
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) {
+            const int row = 2 * pp + half;
+            float af[T], bf[T];
+#pragma unroll
+            for (int i = 0; i < T; ++i) af[i] = a_base[row * BR + 32 * i];
+#pragma unroll
+            for (int j = 0; j < T; ++j) bf[j] = b_base[row * BR + 32 * j];
+#pragma unroll
+            for (int i = 0; i < T; ++i)
+#pragma unroll
+                for (int j = 0; j < T; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // C/D layout: col = lane&31 (co), row = (r&3) + 8*(r>>2) + 4*half (k)
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const int co = n0 + wn * 32 * T + 32 * j + l31;
+        if (co >= p.Cdy) continue;
+#pragma unroll
+        for (int i = 0; i < T; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = q0 * 4 + wm * 32 * T + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (k < p.kchunks * 4) atomicAdd(p.dw + (long long)k * p.Cdy + co, acc[i][j][r]);
+            }
+    }
+}
+
+// column sums of dY [M, C] -> out[C] (+=): d beta / d bias
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, int M, int C, int rows_per_block,
+                                                     float* __restrict__ out) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    float s = 0.f;
+    if (c < C)
+        for (int m = m0 + rl; m < m1; m += 4) s += dy[(long long)m * C + c];
+    part[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// dW = scale * dWraw (HWIO, real Cin), dgamma = r * (sum_k W dWraw - mean * dbeta), dbeta = colsum
+__global__ void finalize_bn_conv_grads(const float* __restrict__ dwraw, const float* __restrict__ w,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ var, const float* __restrict__ dbeta_in, float eps,
+                                       int taps, int cin, int cin_real, int cout, float* __restrict__ dW,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co >= cout) return;
+    const float r = 1.f / sqrtf(var[co] + eps);
+    const float s = gamma[co] * r;
+    double dot = 0.0;
+    for (int tp = 0; tp < taps; ++tp)
+        for (int ci = 0; ci < cin_real; ++ci) {
+            const float g = dwraw[((long long)tp * cin + ci) * cout + co];
+            const long long o = ((long long)tp * cin_real + ci) * cout + co;
+            dot += (double)w[o] * (double)g;
+            dW[o] = s * g;
+        }
+    const float db = dbeta_in[co];
+    dbeta[co] = db;
+    dgamma[co] = r * ((float)dot - mean[co] * db);
+}
+
+// head: dw[ka][kb][c][ci] = dW'raw[(khp,kwp)][ci][(a,b),c] (each w element appears once), db[c] = sum_phases colsum
+__global__ void finalize_head_grads(const float* __restrict__ dwraw, const float* __restrict__ colsum, int njt, int cin,
+                                    int cpad, float* __restrict__ dw, float* __restrict__ db) {
+    const long long total = 9ll * njt * cin;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(g % cin);
+        long long r = g / cin;
+        const int c = (int)(r % njt);
+        r /= njt;
+        const int kb = (int)(r % 3), ka = (int)(r / 3);
+        // ka = a + 2 - 2 khp  ->  (ka=0: a=0,khp=1) (ka=1: a=1,khp=1) (ka=2: a=0,khp=0)
+        const int a = ka == 1 ? 1 : 0, khp = ka == 2 ? 0 : 1;
+        const int b = kb == 1 ? 1 : 0, kwp = kb == 2 ? 0 : 1;
+        dw[g] = dwraw[(((long long)(khp * 2 + kwp)) * cin + ci) * cpad + (a * 2 + b) * njt + c];
+    }
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < njt) db[c] = colsum[c] + colsum[njt + c] + colsum[2 * njt + c] + colsum[3 * njt + c];
+}
+
+// d scoremap [N,2h,2w,njt] -> phase-major rows [N*h*w, cpad] (inverse of the forward scatter), zero padded
+__global__ void head_gather_kernel(const float* __restrict__ dsc, int N, int h, int w, int njt, int cpad,
+                                   float* __restrict__ out) {
+    const long long total = (long long)N * h * w * cpad;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(g % cpad);
+        long long m = g / cpad;
+        float v = 0.f;
+        if (co < 4 * njt) {
+            const int ph = co / njt, c = co - ph * njt;
+            const int j = (int)(m % w);
+            m /= w;
+            const int i = (int)(m % h);
+            const int n = (int)(m / h);
+            v = dsc[(((long long)n * 2 * h + 2 * i + (ph >> 1)) * 2 * w + 2 * j + (ph & 1)) * njt + c];
+        }
+        out[g] = v;
+    }
+}
+
+// max-pool 3x3/2 SAME backward fused with the stem's ReLU gate: dC1 = (C1 > 0) * sum over windows whose first
+// maximum is this element of dPool.
+__global__ void maxpool_bwd_kernel(const float* __restrict__ c1, const float* __restrict__ dpool, int N, int H, int W,
+                                   int C, int Ho, int Wo, int pt, int pl, float* __restrict__ dc1) {
+    const long long total = (long long)N * H * W * C;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(g % C);
+        long long r = g / C;
+        const int wi = (int)(r % W);
+        r /= W;
+        const int hi = (int)(r % H);
+        const int n = (int)(r / H);
+        const float v = c1[g];
+        float acc = 0.f;
+        if (v > 0.f) {
+            for (int ho = max(0, (hi + pt - 2 + 1) / 2); ho <= min(Ho - 1, (hi + pt) / 2); ++ho)
+                for (int wo = max(0, (wi + pl - 2 + 1) / 2); wo <= min(Wo - 1, (wi + pl) / 2); ++wo) {
+                    // first maximum (row-major) of window (ho, wo)
+                    float best = -INFINITY;
+                    int bh = -1, bw = -1;
+                    for (int a = 0; a < 3; ++a) {
+                        const int hh = ho * 2 - pt + a;
+                        if ((unsigned)hh >= (unsigned)H) continue;
+                        for (int b = 0; b < 3; ++b) {
+                            const int ww = wo * 2 - pl + b;
+                            if ((unsigned)ww >= (unsigned)W) continue;
+                            const float u = c1[(((long long)n * H + hh) * W + ww) * C + c];
+                            if (u > best) { best = u; bh = hh; bw = ww; }
+                        }
+                    }
+                    if (bh == hi && bw == wi) acc += dpool[(((long long)n * Ho + ho) * Wo + wo) * C + c];
+                }
+        }
+        dc1[g] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimiser: global-norm clip + momentum SGD over the flat trainable buffer
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, double* __restrict__ out) {
+    __shared__ double part[4];
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        s += (double)g[i] * (double)g[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ void momentum_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v, long long n,
+                                float lr, float mom, float clip, const double* __restrict__ sumsq,
+                                float* __restrict__ gnorm_out) {
+    const float gn = (float)sqrt(*sumsq);
+    const float scale = clip / fmaxf(gn, clip);               // tf.clip_by_global_norm
+    if (blockIdx.x == 0 && threadIdx.x == 0 && gnorm_out) *gnorm_out = gn;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float a = mom * v[i] + g[i] * scale;            // accum = momentum * accum + grad
+        v[i] = a;
+        w[i] -= lr * a;                                       // var -= lr * accum
+    }
+}
+
+int grid_for(long long n) {
+    long long b = (n + 255) / 256;
+    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+// ================================================================================================
+// trainer
+// ================================================================================================
+struct TLayer {
+    long long w_off = -1, g_off = -1, b_off = -1;     // offsets into the flat trainable buffer (floats)
+    long long mean_off = -1, var_off = -1;            // offsets into the frozen-statistics buffer
+    int cin_real = 0;
+    float* d_wT = nullptr;                            // data-gradient panels
+    int nkT = 0, cinP = 0, cpad = 0;                  // cpad: padded phase-major channel count (heads)
+};
+
+struct dgp_trainer {
+    dgp_net* net = nullptr;
+    std::vector<TLayer> tl;
+    std::vector<std::string> names;
+    std::vector<long long> offs, sizes;
+    std::vector<int> is_stat;
+    long long n_train = 0, n_stat = 0;
+    float *params = nullptr, *grads = nullptr, *mom = nullptr, *stats = nullptr;
+    double* d_sumsq = nullptr;
+    float* d_gnorm = nullptr;
+    ~dgp_trainer() {
+        for (auto& t : tl) if (t.d_wT) (void)hipFree(t.d_wT);
+        for (void* p : {(void*)params, (void*)grads, (void*)mom, (void*)stats, (void*)d_sumsq, (void*)d_gnorm})
+            if (p) (void)hipFree(p);
+    }
+};
+
+namespace {
+
+int next_pow2(int x) { int p = 4; while (p < x) p <<= 1; return p; }
+
+struct TPlan {
+    // retained activations
+    size_t p0, c1, pool;
+    std::vector<size_t> sc, r1, r2, xo;         // per unit
+    size_t scmap, locref;
+    // gradients
+    size_t g0, g1, dxa, dr1, dr2, dc1, dph0, dph1, dwraw, colsum;
+    size_t total;
+};
+
+size_t al(size_t x) { return (x + 255) / 256 * 256; }
+
+TPlan make_tplan(const dgp_trainer* tr, int B) {
+    const dgp_net* net = tr->net;
+    const dgp_net_desc& d = net->desc;
+    TPlan p;
+    size_t o = 0;
+    auto take = [&](size_t nfl) { size_t r = o; o += al(nfl * sizeof(float)); return r; };
+    p.p0 = take((size_t)B * d.in_h * d.in_w * 4);
+    p.c1 = take((size_t)B * net->h1 * net->w1 * 64);
+    p.pool = take((size_t)B * net->hp * net->wp * 64);
+    int h = net->hp, w = net->wp;
+    size_t xmax = (size_t)B * h * w * 64, r1max = 0, r2max = 0;
+    for (const Unit& u : net->units) {
+        const int ho = (h + u.stride - 1) / u.stride, wo = (w + u.stride - 1) / u.stride;
+        p.sc.push_back(u.sc >= 0 ? take((size_t)B * ho * wo * u.depth) : 0);
+        p.r1.push_back(take((size_t)B * h * w * u.depth_bn));
+        p.r2.push_back(take((size_t)B * ho * wo * u.depth_bn));
+        p.xo.push_back(take((size_t)B * ho * wo * u.depth));
+        xmax = std::max(xmax, (size_t)B * h * w * u.depth_in);
+        xmax = std::max(xmax, (size_t)B * ho * wo * u.depth);
+        r1max = std::max(r1max, (size_t)B * h * w * u.depth_bn);
+        r2max = std::max(r2max, (size_t)B * ho * wo * u.depth_bn);
+        h = ho; w = wo;
+    }
+    const int nj = d.num_joints;
+    p.scmap = take((size_t)B * 4 * h * w * nj);
+    p.locref = take((size_t)B * 4 * h * w * 2 * nj);
+    p.g0 = take(xmax); p.g1 = take(xmax); p.dxa = take(xmax);
+    p.dr1 = take(r1max); p.dr2 = take(r2max);
+    p.dc1 = take((size_t)B * net->h1 * net->w1 * 64);
+    p.dph0 = take((size_t)B * h * w * next_pow2(4 * nj));
+    p.dph1 = take((size_t)B * h * w * next_pow2(8 * nj));
+    size_t wmax = 0;
+    for (size_t li = 0; li < net->layers.size(); ++li) {
+        const ConvLayer& l = net->layers[li];
+        const int cdy = tr->tl[li].cpad ? tr->tl[li].cpad : l.Cout;
+        wmax = std::max(wmax, (size_t)l.KH * l.KW * l.Cin * cdy);
+    }
+    p.dwraw = take(wmax);
+    p.colsum = take(4096);
+    p.total = o;
+    return p;
+}
+
+hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, const float* in, int N, int H, int W,
+                       int Cin, int pad_t, int pad_l, int Ho, int Wo, int Cout, int stride, int up, const float* scale,
+                       const float* bias, const float* res, int res_s, int res_H, int res_W, const float* mask,
+                       bool relu, int out_mode, int dc_nj, float* out, hipStream_t s) {
+    ConvArgs a{};
+    a.in = in; a.wpk = wpk; a.scale = scale; a.bias = bias; a.res = res; a.mask = mask; a.out = out;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.log2cin4 = ilog2(Cin / 4);
+    a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.CoutP = coutP;
+    a.KH = l.KH; a.KW = l.KW; a.stride = stride; a.dil = l.rate; a.pad_t = pad_t; a.pad_l = pad_l;
+    a.ntaps = l.KH * l.KW; a.nk = nk; a.M = N * Ho * Wo;
+    a.res_s = res ? res_s : 0; a.res_H = res_H; a.res_W = res_W; a.up = up;
+    a.relu = relu ? 1 : 0; a.out_mode = out_mode; a.dc_nj = dc_nj;
+    a.in_bytes = (unsigned)((size_t)N * H * W * Cin * 4);
+    a.out_bytes = (unsigned)((size_t)a.M * Cout * 4);
+    a.res_bytes = res ? (unsigned)((size_t)N * res_H * res_W * Cout * 4) : 0u;
+    a.w_bytes = (unsigned)((size_t)nk * 8 * coutP * 16);
+    return launch_conv(a, pick_tile(a.M, coutP, nk * BK), s);
+}
+
+hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const float* dy, int Ho, int Wo, int Cdy, int KH,
+                        int KW, int stride, int dil, int pad_t, int pad_l, float* dwraw, hipStream_t s) {
+    WgradArgs a{};
+    a.x = x; a.dy = dy; a.dw = dwraw; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.log2cin4 = ilog2(Cin / 4);
+    a.Ho = Ho; a.Wo = Wo; a.Cdy = Cdy; a.KW = KW; a.stride = stride; a.dil = dil; a.pad_t = pad_t; a.pad_l = pad_l;
+    a.ntaps = KH * KW; a.kchunks = KH * KW * (Cin / 4); a.M = N * Ho * Wo;
+    a.x_bytes = (unsigned)((size_t)N * H * W * Cin * 4);
+    a.dy_bytes = (unsigned)((size_t)a.M * Cdy * 4);
+    hipError_t e = hipMemsetAsync(dwraw, 0, (size_t)a.kchunks * 4 * Cdy * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    const bool big = (a.kchunks * 4 >= 128 && Cdy >= 128);
+    const int BR = big ? 128 : 64;
+    const int kt = (a.kchunks * 4 + BR - 1) / BR, nt = (Cdy + BR - 1) / BR;
+    int split = std::max(1, 1536 / (kt * nt));
+    int mpb = ((a.M + split - 1) / split + 31) / 32 * 32;
+    if (mpb < 256) mpb = 256;
+    split = (a.M + mpb - 1) / mpb;
+    a.m_per_block = mpb;
+    static bool attr[2] = {false, false};
+    if (big) {
+        if (!attr[1]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f32<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            if (e != hipSuccess) return e;
+            attr[1] = true;
+        }
+        hipLaunchKernelGGL(wgrad_f32<2>, dim3(kt, nt, split), dim3(256), 2 * 2 * 32 * 128 * 4, s, a);
+    } else {
+        hipLaunchKernelGGL(wgrad_f32<1>, dim3(kt, nt, split), dim3(256), 2 * 2 * 32 * 64 * 4, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t colsum_launch(const float* dy, int M, int C, float* out, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    const int rows = 2048;
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, (M + rows - 1) / rows), dim3(256), 0, s, dy, M, C, rows, out);
+    return hipGetLastError();
+}
+
+#define TRY_HIP(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) return fail(DGP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int dgp_trainer_create(dgp_net* net, dgp_trainer** out) {
+    if (!net || !out) return fail(DGP_ERR_INVALID, "dgp_trainer_create: null argument");
+    if (net->head_locref < 0) return fail(DGP_ERR_INVALID, "dgp_trainer_create: the net must be built with_locref (dgp_loss trains both heads)");
+    dgp_trainer* tr = new dgp_trainer();
+    tr->net = net;
+    tr->tl.resize(net->layers.size());
+    auto add = [&](const std::string& name, long long size, bool stat) {
+        long long& ctr = stat ? tr->n_stat : tr->n_train;
+        const long long off = ctr;
+        ctr += (size + 3) / 4 * 4;                 // keep every tensor 16-byte aligned
+        tr->names.push_back(name); tr->offs.push_back(off); tr->sizes.push_back(size); tr->is_stat.push_back(stat ? 1 : 0);
+        return off;
+    };
+    for (size_t li = 0; li < net->layers.size(); ++li) {
+        const ConvLayer& l = net->layers[li];
+        TLayer& t = tr->tl[li];
+        const bool head = ((int)li == net->head_part || (int)li == net->head_locref);
+        if (head) {
+            const int njt = l.Cout / 4;
+            t.cin_real = l.Cin;
+            t.w_off = add(l.scope + "/weights", 9ll * njt * l.Cin, false);
+            t.b_off = add(l.scope + "/biases", njt, false);
+            t.cpad = next_pow2(l.Cout);
+            t.cinP = coutp_for(l.Cin);
+            t.nkT = nk_for(2, 2, t.cpad);
+        } else {
+            t.cin_real = ((int)li == net->conv1) ? 3 : l.Cin;
+            t.w_off = add(l.scope + "/weights", (long long)l.KH * l.KW * t.cin_real * l.Cout, false);
+            t.g_off = add(l.scope + "/BatchNorm/gamma", l.Cout, false);
+            t.b_off = add(l.scope + "/BatchNorm/beta", l.Cout, false);
+            t.mean_off = add(l.scope + "/BatchNorm/moving_mean", l.Cout, true);
+            t.var_off = add(l.scope + "/BatchNorm/moving_variance", l.Cout, true);
+            if ((int)li != net->conv1) {
+                t.cinP = coutp_for(l.Cin);
+                t.nkT = nk_for(l.KH, l.KW, l.Cout);
+            }
+        }
+        if (t.nkT > 0) {
+            if (hipMalloc(&t.d_wT, (size_t)t.nkT * 8 * t.cinP * 16) != hipSuccess) {
+                delete tr;
+                return fail(DGP_ERR_HIP, "dgp_trainer_create: hipMalloc (dgrad panels) failed");
+            }
+        }
+    }
+    const size_t nb = (size_t)tr->n_train * sizeof(float);
+    if (hipMalloc(&tr->params, nb) != hipSuccess || hipMalloc(&tr->grads, nb) != hipSuccess ||
+        hipMalloc(&tr->mom, nb) != hipSuccess || hipMalloc(&tr->stats, (size_t)tr->n_stat * sizeof(float)) != hipSuccess ||
+        hipMalloc(&tr->d_sumsq, sizeof(double)) != hipSuccess || hipMalloc(&tr->d_gnorm, sizeof(float)) != hipSuccess) {
+        delete tr;
+        return fail(DGP_ERR_HIP, "dgp_trainer_create: hipMalloc failed");
+    }
+    (void)hipMemset(tr->params, 0, nb); (void)hipMemset(tr->grads, 0, nb); (void)hipMemset(tr->mom, 0, nb);
+    *out = tr;
+    return DGP_OK;
+}
+
+void dgp_trainer_destroy(dgp_trainer* tr) { delete tr; }
+
+int dgp_trainer_num_tensors(const dgp_trainer* tr, int32_t* n_tensors, int64_t* n_trainable_floats, int64_t* n_stat_floats) {
+    if (!tr) return fail(DGP_ERR_INVALID, "dgp_trainer_num_tensors: null");
+    if (n_tensors) *n_tensors = (int32_t)tr->names.size();
+    if (n_trainable_floats) *n_trainable_floats = tr->n_train;
+    if (n_stat_floats) *n_stat_floats = tr->n_stat;
+    return DGP_OK;
+}
+
+int dgp_trainer_tensor_info(const dgp_trainer* tr, int32_t i, char* name, int32_t cap, int64_t* offset, int64_t* size,
+                            int32_t* is_stat) {
+    if (!tr || i < 0 || i >= (int)tr->names.size()) return fail(DGP_ERR_INVALID, "dgp_trainer_tensor_info: bad index");
+    if (name && cap > 0) { strncpy(name, tr->names[i].c_str(), cap - 1); name[cap - 1] = 0; }
+    if (offset) *offset = tr->offs[i];
+    if (size) *size = tr->sizes[i];
+    if (is_stat) *is_stat = tr->is_stat[i];
+    return DGP_OK;
+}
+
+/* which: 0 params, 1 grads, 2 momentum, 3 frozen statistics */
+float* dgp_trainer_buffer(dgp_trainer* tr, int32_t which) {
+    if (!tr) return nullptr;
+    switch (which) { case 0: return tr->params; case 1: return tr->grads; case 2: return tr->mom; case 3: return tr->stats; }
+    return nullptr;
+}
+
+int dgp_trainer_workspace_bytes(const dgp_trainer* tr, int32_t nt, size_t* out_bytes) {
+    if (!tr || !out_bytes || nt < 1) return fail(DGP_ERR_INVALID, "dgp_trainer_workspace_bytes: bad argument");
+    *out_bytes = make_tplan(tr, nt).total;
+    return DGP_OK;
+}
+
+// master parameters -> forward panels / folded BN / data-gradient panels of the engine
+int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
+    if (!tr) return fail(DGP_ERR_INVALID, "dgp_trainer_sync_weights: null");
+    dgp_net* net = tr->net;
+    hipStream_t s = (hipStream_t)stream;
+    const float eps = net->desc.bn_eps;
+    for (size_t li = 0; li < net->layers.size(); ++li) {
+        ConvLayer& l = net->layers[li];
+        TLayer& t = tr->tl[li];
+        const bool head = ((int)li == net->head_part || (int)li == net->head_locref);
+        const size_t nfl = (size_t)l.nk * 8 * l.CoutP * 4;
+        if (!l.d_w) TRY_HIP(hipMalloc(&l.d_w, nfl * sizeof(float)));
+        if (!l.d_scale) TRY_HIP(hipMalloc(&l.d_scale, l.Cout * sizeof(float)));
+        if (!l.d_bias) TRY_HIP(hipMalloc(&l.d_bias, l.Cout * sizeof(float)));
+        const float* w = tr->params + t.w_off;
+        const long long tot = (long long)l.nk * 8 * l.CoutP;
+        if (head) {
+            const int njt = l.Cout / 4;
+            hipLaunchKernelGGL(pack_head_fwd_kernel, dim3(grid_for(tot)), dim3(256), 0, s, w, njt, l.Cin, l.CoutP, l.nk * 8, l.d_w);
+            hipLaunchKernelGGL(head_bias_kernel, dim3(1), dim3(256), 0, s, tr->params + t.b_off, njt, l.d_bias);
+            const long long totT = (long long)t.nkT * 8 * t.cinP;
+            hipLaunchKernelGGL(pack_head_dgrad_kernel, dim3(grid_for(totT)), dim3(256), 0, s, w, njt, l.Cin, t.cpad, t.cinP,
+                               t.nkT * 8, t.d_wT);
+        } else {
+            hipLaunchKernelGGL(pack_fwd_kernel, dim3(grid_for(tot)), dim3(256), 0, s, w, l.KH * l.KW, t.cin_real, l.Cin, l.Cout,
+                               l.CoutP, l.nk * 8, l.d_w);
+            hipLaunchKernelGGL(fold_bn_kernel, dim3((l.Cout + 255) / 256), dim3(256), 0, s, tr->params + t.g_off,
+                               tr->params + t.b_off, tr->stats + t.mean_off, tr->stats + t.var_off, eps, l.Cout, l.d_scale,
+                               l.d_bias);
+            if (t.d_wT) {
+                const long long totT = (long long)t.nkT * 8 * t.cinP;
+                hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid_for(totT)), dim3(256), 0, s, w, l.d_scale, l.KH * l.KW, l.Cin,
+                                   l.Cout, t.cinP, t.nkT * 8, t.d_wT);
+            }
+        }
+    }
+    TRY_HIP(hipGetLastError());
+    net->loaded = true;
+    return DGP_OK;
+}
+
+int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* workspace, size_t workspace_bytes,
+                      float** scmap, float** locref, void* stream) {
+    if (!tr || !frames || !workspace) return fail(DGP_ERR_INVALID, "dgp_train_forward: null argument");
+    dgp_net* net = tr->net;
+    if (!net->loaded) return fail(DGP_ERR_STATE, "dgp_train_forward: call dgp_trainer_sync_weights first");
+    const TPlan pl = make_tplan(tr, nt);
+    if (workspace_bytes < pl.total) return fail(DGP_ERR_INVALID, "dgp_train_forward: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    auto F = [&](size_t off) { return (float*)(ws + off); };
+    const dgp_net_desc& d = net->desc;
+    const int B = nt;
+    TRY_HIP(launch_preprocess(frames, (long long)B * d.in_h * d.in_w, d.mean_pixel[0], d.mean_pixel[1], d.mean_pixel[2], F(pl.p0), s));
+    const ConvLayer& c1 = net->layers[net->conv1];
+    TRY_HIP(conv_launch(c1, c1.d_w, c1.nk, c1.CoutP, F(pl.p0), B, d.in_h, d.in_w, 4, 3, 3, net->h1, net->w1, 64, 2, 0,
+                        c1.d_scale, c1.d_bias, nullptr, 0, 0, 0, nullptr, true, 0, 0, F(pl.c1), s));
+    TRY_HIP(launch_maxpool(F(pl.c1), B, net->h1, net->w1, 64, F(pl.pool), s));
+    int h = net->hp, w = net->wp;
+    const float* xin = F(pl.pool);
+    for (size_t ui = 0; ui < net->units.size(); ++ui) {
+        const Unit& u = net->units[ui];
+        const int ho = (h + u.stride - 1) / u.stride, wo = (w + u.stride - 1) / u.stride;
+        const float* res = xin;
+        int res_s = u.stride, res_H = h, res_W = w;
+        if (u.sc >= 0) {
+            const ConvLayer& l = net->layers[u.sc];
+            TRY_HIP(conv_launch(l, l.d_w, l.nk, l.CoutP, xin, B, h, w, l.Cin, 0, 0, ho, wo, l.Cout, u.stride, 0, l.d_scale,
+                                l.d_bias, nullptr, 0, 0, 0, nullptr, false, 0, 0, F(pl.sc[ui]), s));
+            res = F(pl.sc[ui]); res_s = 1; res_H = ho; res_W = wo;
+        }
+        const ConvLayer& l1 = net->layers[u.c1];
+        TRY_HIP(conv_launch(l1, l1.d_w, l1.nk, l1.CoutP, xin, B, h, w, l1.Cin, 0, 0, h, w, l1.Cout, 1, 0, l1.d_scale,
+                            l1.d_bias, nullptr, 0, 0, 0, nullptr, true, 0, 0, F(pl.r1[ui]), s));
+        const ConvLayer& l2 = net->layers[u.c2];
+        const int pb_h = pad_before_for(h, 3, u.stride, u.rate, true), pb_w = pad_before_for(w, 3, u.stride, u.rate, true);
+        TRY_HIP(conv_launch(l2, l2.d_w, l2.nk, l2.CoutP, F(pl.r1[ui]), B, h, w, l2.Cin, pb_h, pb_w, ho, wo, l2.Cout,
+                            u.stride, 0, l2.d_scale, l2.d_bias, nullptr, 0, 0, 0, nullptr, true, 0, 0, F(pl.r2[ui]), s));
+        const ConvLayer& l3 = net->layers[u.c3];
+        TRY_HIP(conv_launch(l3, l3.d_w, l3.nk, l3.CoutP, F(pl.r2[ui]), B, ho, wo, l3.Cin, 0, 0, ho, wo, l3.Cout, 1, 0,
+                            l3.d_scale, l3.d_bias, res, res_s, res_H, res_W, nullptr, true, 0, 0, F(pl.xo[ui]), s));
+        xin = F(pl.xo[ui]); h = ho; w = wo;
+    }
+    const ConvLayer& hp = net->layers[net->head_part];
+    TRY_HIP(conv_launch(hp, hp.d_w, hp.nk, hp.CoutP, xin, B, h, w, hp.Cin, 1, 1, h, w, hp.Cout, 1, 0, nullptr, hp.d_bias,
+                        nullptr, 0, 0, 0, nullptr, false, 1, d.num_joints, F(pl.scmap), s));
+    const ConvLayer& hl = net->layers[net->head_locref];
+    TRY_HIP(conv_launch(hl, hl.d_w, hl.nk, hl.CoutP, xin, B, h, w, hl.Cin, 1, 1, h, w, hl.Cout, 1, 0, nullptr, hl.d_bias,
+                        nullptr, 0, 0, 0, nullptr, false, 1, 2 * d.num_joints, F(pl.locref), s));
+    if (scmap) *scmap = F(pl.scmap);
+    if (locref) *locref = F(pl.locref);
+    return DGP_OK;
+}
+
+// One conv layer's parameter gradients: dWraw = A^T dY, d beta = colsum(dY), then the BN-affine algebra.
+static int layer_param_grads(dgp_trainer* tr, size_t li, const float* x, int N, int H, int W, const float* dy, int Ho,
+                             int Wo, int stride, int pad_t, int pad_l, float* dwraw, float* colsum, hipStream_t s) {
+    dgp_net* net = tr->net;
+    const ConvLayer& l = net->layers[li];
+    const TLayer& t = tr->tl[li];
+    TRY_HIP(wgrad_launch(x, N, H, W, l.Cin, dy, Ho, Wo, l.Cout, l.KH, l.KW, stride, l.rate, pad_t, pad_l, dwraw, s));
+    TRY_HIP(colsum_launch(dy, N * Ho * Wo, l.Cout, colsum, s));
+    hipLaunchKernelGGL(finalize_bn_conv_grads, dim3((l.Cout + 127) / 128), dim3(128), 0, s, dwraw, tr->params + t.w_off,
+                       tr->params + t.g_off, tr->stats + t.mean_off, tr->stats + t.var_off, colsum, net->desc.bn_eps,
+                       l.KH * l.KW, l.Cin, t.cin_real, l.Cout, tr->grads + t.w_off, tr->grads + t.g_off, tr->grads + t.b_off);
+    TRY_HIP(hipGetLastError());
+    return DGP_OK;
+}
+
+int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t workspace_bytes, const float* dscmap,
+                       const float* dlocref, void* stream) {
+    if (!tr || !workspace || !dscmap || !dlocref) return fail(DGP_ERR_INVALID, "dgp_train_backward: null argument");
+    dgp_net* net = tr->net;
+    const TPlan pl = make_tplan(tr, nt);
+    if (workspace_bytes < pl.total) return fail(DGP_ERR_INVALID, "dgp_train_backward: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    auto F = [&](size_t off) { return (float*)(ws + off); };
+    const dgp_net_desc& d = net->desc;
+    const int B = nt, nj = d.num_joints;
+    const int nu = (int)net->units.size();
+    // geometry per unit input
+    std::vector<int> hs(nu + 1), wsz(nu + 1);
+    hs[0] = net->hp; wsz[0] = net->wp;
+    for (int ui = 0; ui < nu; ++ui) {
+        const Unit& u = net->units[ui];
+        hs[ui + 1] = (hs[ui] + u.stride - 1) / u.stride;
+        wsz[ui + 1] = (wsz[ui] + u.stride - 1) / u.stride;
+    }
+    const int fh = hs[nu], fw = wsz[nu];
+    float* dwraw = F(pl.dwraw);
+    float* colsum = F(pl.colsum);
+    float* G[2] = {F(pl.g0), F(pl.g1)};
+    int cur = 0;
+    int rc;
+
+    // ---- heads: gather phases, parameter grads, data grad into G[cur] (gated by the last unit's ReLU)
+    const float* feat = F(pl.xo[nu - 1]);
+    {
+        const size_t heads[2] = {(size_t)net->head_part, (size_t)net->head_locref};
+        const float* dsrc[2] = {dscmap, dlocref};
+        float* dph[2] = {F(pl.dph0), F(pl.dph1)};
+        for (int k = 0; k < 2; ++k) {
+            const ConvLayer& l = net->layers[heads[k]];
+            const TLayer& t = tr->tl[heads[k]];
+            const int njt = l.Cout / 4;
+            const long long tot = (long long)B * fh * fw * t.cpad;
+            hipLaunchKernelGGL(head_gather_kernel, dim3(grid_for(tot)), dim3(256), 0, s, dsrc[k], B, fh, fw, njt, t.cpad, dph[k]);
+            TRY_HIP(wgrad_launch(feat, B, fh, fw, l.Cin, dph[k], fh, fw, t.cpad, 2, 2, 1, 1, 1, 1, dwraw, s));
+            TRY_HIP(colsum_launch(dph[k], B * fh * fw, t.cpad, colsum, s));
+            hipLaunchKernelGGL(finalize_head_grads, dim3(grid_for(9ll * njt * l.Cin)), dim3(256), 0, s, dwraw, colsum, njt,
+                               l.Cin, t.cpad, tr->grads + t.w_off, tr->grads + t.b_off);
+            // dfeat (+)= convT: 2x2 taps flipped, pad' = 0; second head accumulates onto the first; gate on the last
+            ConvLayer lt = l;
+            lt.KH = lt.KW = 2; lt.rate = 1;
+            TRY_HIP(conv_launch(lt, t.d_wT, t.nkT, t.cinP, dph[k], B, fh, fw, t.cpad, 0, 0, fh, fw, l.Cin, 1, 0, nullptr, nullptr,
+                                k == 1 ? G[cur] : nullptr, 1, fh, fw, k == 1 ? feat : nullptr, false, 0, 0, G[cur], s));
+        }
+    }
+
+    // ---- bottleneck units, last to first.  G[cur] = d loss / d (unit output), already gated by its ReLU.
+    int stop_after = -1;
+    if (const char* e = getenv("DGP_BWD_STOP")) stop_after = atoi(e);      // debugging aid: leave G of an inner unit in place
+    for (int ui = nu - 1; ui >= 0; --ui) {
+        if (stop_after >= 0 && (nu - 1 - ui) >= stop_after) {
+            if (const char* e2 = getenv("DGP_BWD_DUMP")) {
+                (void)hipStreamSynchronize(s);
+                const size_t n = (size_t)B * hs[ui + 1] * wsz[ui + 1] * net->units[ui].depth;
+                std::vector<float> hbuf(n);
+                (void)hipMemcpy(hbuf.data(), G[cur], n * sizeof(float), hipMemcpyDeviceToHost);
+                FILE* f = fopen(e2, "wb");
+                if (f) { fwrite(hbuf.data(), sizeof(float), n, f); fclose(f); }
+                (void)hipMemcpy(hbuf.data(), F(pl.xo[ui]), n * sizeof(float), hipMemcpyDeviceToHost);
+                f = fopen((std::string(e2) + ".x").c_str(), "wb");
+                if (f) { fwrite(hbuf.data(), sizeof(float), n, f); fclose(f); }
+            }
+            return DGP_OK;
+        }
+        const Unit& u = net->units[ui];
+        const int h = hs[ui], w = wsz[ui], ho = hs[ui + 1], wo = wsz[ui + 1];
+        const float* xin = ui == 0 ? F(pl.pool) : F(pl.xo[ui - 1]);
+        float* Gout = G[cur];
+        float* Gin = G[cur ^ 1];
+        const ConvLayer &l1 = net->layers[u.c1], &l2 = net->layers[u.c2], &l3 = net->layers[u.c3];
+        const TLayer &t1 = tr->tl[u.c1], &t2 = tr->tl[u.c2], &t3 = tr->tl[u.c3];
+        // conv3: params, then dR2 = convT(G) gated by R2 > 0
+        rc = layer_param_grads(tr, u.c3, F(pl.r2[ui]), B, ho, wo, Gout, ho, wo, 1, 0, 0, dwraw, colsum, s);
+        if (rc) return rc;
+        TRY_HIP(conv_launch(l3, t3.d_wT, t3.nkT, t3.cinP, Gout, B, ho, wo, l3.Cout, 0, 0, ho, wo, l3.Cin, 1, 0, nullptr, nullptr,
+                            nullptr, 0, 0, 0, F(pl.r2[ui]), false, 0, 0, F(pl.dr2), s));
+        // conv2: params, then dR1 = convT(dR2) gated by R1 > 0
+        const int pb_h = pad_before_for(h, 3, u.stride, u.rate, true), pb_w = pad_before_for(w, 3, u.stride, u.rate, true);
+        rc = layer_param_grads(tr, u.c2, F(pl.r1[ui]), B, h, w, F(pl.dr2), ho, wo, u.stride, pb_h, pb_w, dwraw, colsum, s);
+        if (rc) return rc;
+        const int keff = 2 * u.rate + 1;
+        TRY_HIP(conv_launch(l2, t2.d_wT, t2.nkT, t2.cinP, F(pl.dr2), B, ho, wo, l2.Cout, keff - 1 - pb_h, keff - 1 - pb_w, h, w,
+                            l2.Cin, 1, u.stride > 1 ? u.stride : 0, nullptr, nullptr, nullptr, 0, 0, 0, F(pl.r1[ui]), false, 0, 0,
+                            F(pl.dr1), s));
+        // shortcut branch
+        const float* dxa = Gout;
+        int dxa_mode = 1;                       // same grid
+        int dxa_h = ho, dxa_w = wo;
+        if (u.sc >= 0) {
+            const ConvLayer& ls = net->layers[u.sc];
+            const TLayer& ts = tr->tl[u.sc];
+            rc = layer_param_grads(tr, u.sc, xin, B, h, w, Gout, ho, wo, u.stride, 0, 0, dwraw, colsum, s);
+            if (rc) return rc;
+            TRY_HIP(conv_launch(ls, ts.d_wT, ts.nkT, ts.cinP, Gout, B, ho, wo, ls.Cout, 0, 0, h, w, ls.Cin, 1,
+                                u.stride > 1 ? u.stride : 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, false, 0, 0, F(pl.dxa), s));
+            dxa = F(pl.dxa); dxa_h = h; dxa_w = w;
+        } else if (u.stride > 1) {
+            dxa_mode = -2;                      // subsample shortcut: gradient lives on the coarser grid
+        }
+        // conv1: params, then dX = (convT(dR1) + dXa) gated by X_in > 0  -> G for the previous unit
+        rc = layer_param_grads(tr, u.c1, xin, B, h, w, F(pl.dr1), h, w, 1, 0, 0, dwraw, colsum, s);
+        if (rc) return rc;
+        TRY_HIP(conv_launch(l1, t1.d_wT, t1.nkT, t1.cinP, F(pl.dr1), B, h, w, l1.Cout, 0, 0, h, w, l1.Cin, 1, 0, nullptr, nullptr,
+                            dxa, dxa_mode, dxa_h, dxa_w, xin, false, 0, 0, Gin, s));
+        cur ^= 1;
+    }
+    // ---- root block: max-pool backward (+ stem ReLU gate), stem weight gradient
+    {
+        int pth = (net->hp - 1) * 2 + 3 - net->h1; if (pth < 0) pth = 0;
+        int ptw = (net->wp - 1) * 2 + 3 - net->w1; if (ptw < 0) ptw = 0;
+        const long long tot = (long long)B * net->h1 * net->w1 * 64;
+        hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(tot)), dim3(256), 0, s, F(pl.c1), G[cur], B, net->h1, net->w1, 64,
+                           net->hp, net->wp, pth / 2, ptw / 2, F(pl.dc1));
+        rc = layer_param_grads(tr, net->conv1, F(pl.p0), B, d.in_h, d.in_w, F(pl.dc1), net->h1, net->w1, 2, 3, 3, dwraw, colsum, s);
+        if (rc) return rc;
+    }
+    (void)nj;
+    TRY_HIP(hipGetLastError());
+    return DGP_OK;
+}
+
+/* host <-> device copies of a slice of one of the flat buffers (which: 0 params, 1 grads, 2 momentum, 3 stats) */
+int dgp_trainer_upload(dgp_trainer* tr, int32_t which, int64_t offset, const float* host, int64_t n) {
+    float* b = dgp_trainer_buffer(tr, which);
+    if (!b || !host || offset < 0 || n < 0) return fail(DGP_ERR_INVALID, "dgp_trainer_upload: bad argument");
+    TRY_HIP(hipMemcpy(b + offset, host, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    return DGP_OK;
+}
+int dgp_trainer_download(dgp_trainer* tr, int32_t which, int64_t offset, float* host, int64_t n) {
+    float* b = dgp_trainer_buffer(tr, which);
+    if (!b || !host || offset < 0 || n < 0) return fail(DGP_ERR_INVALID, "dgp_trainer_download: bad argument");
+    TRY_HIP(hipDeviceSynchronize());
+    TRY_HIP(hipMemcpy(host, b + offset, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return DGP_OK;
+}
+
+int dgp_sgd_momentum_clip(dgp_trainer* tr, float lr, float momentum, float clip_norm, float* gnorm_host_or_null, void* stream) {
+    if (!tr) return fail(DGP_ERR_INVALID, "dgp_sgd_momentum_clip: null");
+    hipStream_t s = (hipStream_t)stream;
+    TRY_HIP(hipMemsetAsync(tr->d_sumsq, 0, sizeof(double), s));
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(tr->n_train)), dim3(256), 0, s, tr->grads, tr->n_train, tr->d_sumsq);
+    hipLaunchKernelGGL(momentum_kernel, dim3(grid_for(tr->n_train)), dim3(256), 0, s, tr->params, tr->grads, tr->mom, tr->n_train,
+                       lr, momentum, clip_norm, tr->d_sumsq, tr->d_gnorm);
+    TRY_HIP(hipGetLastError());
+    if (gnorm_host_or_null) {
+        TRY_HIP(hipStreamSynchronize(s));
+        TRY_HIP(hipMemcpy(gnorm_host_or_null, tr->d_gnorm, sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return DGP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+"""Training step on the MI355X engine: one `Trainer.step` = sess.run([loss, train_op])
+of fit_dgp / fit_dgp_labeledonly (DGP/models/fitdgp.py:818, :505)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, engine
+from .engine import _ptr, _stream
+from .loss import DGPHyper, LOSS_NAMES
+
+
+class Trainer:
+    def __init__(self, depth: int, num_joints: int, in_h: int, in_w: int, max_frames: int = 11, device: int = 0):
+        self.lib = _lib.load()
+        self.net = engine.DGPNet(depth, num_joints, in_h, in_w, max_batch=max_frames, with_locref=True, device=device)
+        self.device = self.net.device
+        h = C.c_void_p()
+        _lib.check(self.lib.dgp_trainer_create(self.net._h, C.byref(h)), "dgp_trainer_create")
+        self._t = h
+        nt, ntr, nst = C.c_int32(), C.c_int64(), C.c_int64()
+        _lib.check(self.lib.dgp_trainer_num_tensors(h, C.byref(nt), C.byref(ntr), C.byref(nst)))
+        self.n_trainable, self.n_stat = ntr.value, nst.value
+        self.table = {}
+        buf = C.create_string_buffer(256)
+        for i in range(nt.value):
+            off, size, st = C.c_int64(), C.c_int64(), C.c_int32()
+            _lib.check(self.lib.dgp_trainer_tensor_info(h, i, buf, 256, C.byref(off), C.byref(size), C.byref(st)))
+            self.table[buf.value.decode()] = (off.value, size.value, bool(st.value))
+        self._ws = None
+        self._ws_nt = 0
+        self._shapes = {}
+
+    def __del__(self):
+        t = getattr(self, "_t", None)
+        if t:
+            self.lib.dgp_trainer_destroy(t)
+            self._t = None
+
+    # ---- parameters ------------------------------------------------------------------------------
+    def load_weights(self, weights: Dict[str, np.ndarray]):
+        missing = [k for k in self.table if k not in weights]
+        if missing:
+            raise _lib.DgpError("missing tensors: %s" % ", ".join(missing[:4]))
+        for k, (off, size, st) in self.table.items():
+            a = np.ascontiguousarray(weights[k], dtype=np.float32)
+            if a.size != size:
+                raise _lib.DgpError("bad size for %s: %d != %d" % (k, a.size, size))
+            self._shapes[k] = a.shape
+            _lib.check(self.lib.dgp_trainer_upload(self._t, 3 if st else 0, off, a.ctypes.data_as(C.c_void_p), size))
+        self.sync()
+
+    def _download(self, which: int) -> Dict[str, np.ndarray]:
+        out = {}
+        for k, (off, size, st) in self.table.items():
+            if st and which != 3 or (not st and which == 3):
+                continue
+            a = np.empty(size, dtype=np.float32)
+            _lib.check(self.lib.dgp_trainer_download(self._t, which, off, a.ctypes.data_as(C.c_void_p), size))
+            out[k] = a.reshape(self._shapes.get(k, (size,)))
+        return out
+
+    def get_weights(self) -> Dict[str, np.ndarray]:
+        w = self._download(0)
+        w.update(self._download(3))
+        return w
+
+    def get_grads(self) -> Dict[str, np.ndarray]:
+        return self._download(1)
+
+    def sync(self):
+        _lib.check(self.lib.dgp_trainer_sync_weights(self._t, _stream(self.device)), "dgp_trainer_sync_weights")
+
+    # ---- one optimisation step -------------------------------------------------------------------
+    def workspace(self, nt: int) -> torch.Tensor:
+        if self._ws is None or nt > self._ws_nt:
+            n = C.c_size_t()
+            _lib.check(self.lib.dgp_trainer_workspace_bytes(self._t, nt, C.byref(n)))
+            self._ws = torch.empty(n.value, dtype=torch.uint8, device=self.device)
+            self._ws_nt = nt
+        return self._ws
+
+    def forward_backward(self, frames: torch.Tensor, batch: dict, hyper: DGPHyper, S0, ws, ws_max, n_frames_total,
+                         n_visible_frames_total, labeled_only: bool = False):
+        """frames uint8 [nt,H,W,3] on device.  Fills the gradient buffer; returns the loss dict."""
+        from .loss import dgp_loss_fwd_bwd
+        nt = frames.shape[0]
+        wsb = self.workspace(nt)
+        sc, lr = C.c_void_p(), C.c_void_p()
+        st = _stream(self.device)
+        _lib.check(self.lib.dgp_train_forward(self._t, _ptr(frames), nt, _ptr(wsb), wsb.numel(), C.byref(sc), C.byref(lr),
+                                              st), "dgp_train_forward")
+        nj, oh, ow = self.net.nj, self.net.out_h, self.net.out_w
+        pred = _view(sc.value, (nt, oh, ow, nj), self.device)
+        loc = _view(lr.value, (nt, oh, ow, 2 * nj), self.device)
+        if labeled_only:          # fit_dgp_labeledonly: total_loss_visible, no hidden / clique terms (fitdgp.py:416)
+            batch = dict(batch, hidden_marker=np.empty(0, dtype=np.int32))
+            S0 = np.zeros((0, nj))
+            ws = ws_max = np.zeros(0)
+        losses, dpred, dloc, mu = dgp_loss_fwd_bwd(pred, loc, batch, hyper, S0, ws, ws_max, n_frames_total,
+                                                   n_visible_frames_total)
+        _lib.check(self.lib.dgp_train_backward(self._t, nt, _ptr(wsb), wsb.numel(), _ptr(dpred), _ptr(dloc), st),
+                   "dgp_train_backward")
+        return losses
+
+    def apply_gradients(self, lr: float, momentum: float = 0.9, clip_norm: float = 10.0) -> float:
+        g = C.c_float()
+        _lib.check(self.lib.dgp_sgd_momentum_clip(self._t, lr, momentum, clip_norm, C.byref(g), _stream(self.device)),
+                   "dgp_sgd_momentum_clip")
+        self.sync()
+        return g.value
+
+    def step(self, frames, batch, hyper: DGPHyper, S0, ws, ws_max, n_frames_total, n_visible_frames_total,
+             labeled_only: bool = False):
+        losses = self.forward_backward(frames, batch, hyper, S0, ws, ws_max, n_frames_total, n_visible_frames_total,
+                                       labeled_only)
+        losses["grad_norm"] = self.apply_gradients(hyper.lr, hyper.momentum, hyper.clip_norm)
+        return losses
+
+
+def _view(ptr: int, shape, device) -> torch.Tensor:
+    """torch view of a device pointer inside the (torch-owned) workspace."""
+    n = int(np.prod(shape))
+    arr = (C.c_float * n).from_address(ptr) if False else None      # not addressable from the host
+    # build a tensor over foreign device memory through the __cuda_array_interface__ protocol
+    class _Holder:
+        pass
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (ptr, False), "version": 2}
+    return torch.as_tensor(h, device=device)

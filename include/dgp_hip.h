@@ -139,6 +139,34 @@ int  dgp_loss_fwd_bwd(const dgp_loss_desc* d, const float* pred, const float* lo
                       const float* ws, const float* ws_max, float* dpred, float* dlocref, float* mu,
                       float* losses, void* scratch, size_t scratch_bytes, void* stream);
 
+/* ---- training step (config 4): replaces sess.run([loss, train_op]) of fit_dgp / fit_dgp_labeledonly
+ * (DGP/models/fitdgp.py:708-713,818; 416-418,501-505).  The trainer owns the master parameters (flat fp32 buffer
+ * of every trainable TF variable: conv weights, BN gamma/beta, head weights/biases), their gradients, the momentum
+ * slots and the frozen BN statistics; activations live in the caller's workspace.
+ *   dgp_trainer_sync_weights : master -> forward panels, folded BN, data-gradient panels (call after every update)
+ *   dgp_train_forward        : forward pass retaining activations; returns device pointers of both head outputs
+ *   dgp_loss_fwd_bwd         : (above) loss and d loss / d heads
+ *   dgp_train_backward       : gradients of all trainables into the flat grads buffer
+ *   dgp_sgd_momentum_clip    : tf.clip_by_global_norm(clip) + MomentumOptimizer(momentum) */
+typedef struct dgp_trainer dgp_trainer;
+int    dgp_trainer_create(dgp_net* net, dgp_trainer** out);            /* net must have with_locref = 1 */
+void   dgp_trainer_destroy(dgp_trainer* tr);
+int    dgp_trainer_num_tensors(const dgp_trainer* tr, int32_t* n_tensors, int64_t* n_trainable_floats,
+                               int64_t* n_stat_floats);
+int    dgp_trainer_tensor_info(const dgp_trainer* tr, int32_t i, char* name, int32_t cap, int64_t* offset,
+                               int64_t* size, int32_t* is_stat);
+float* dgp_trainer_buffer(dgp_trainer* tr, int32_t which);  /* 0 params, 1 grads, 2 momentum, 3 BN statistics */
+int    dgp_trainer_upload(dgp_trainer* tr, int32_t which, int64_t offset, const float* host, int64_t n);
+int    dgp_trainer_download(dgp_trainer* tr, int32_t which, int64_t offset, float* host, int64_t n);
+int    dgp_trainer_workspace_bytes(const dgp_trainer* tr, int32_t nt, size_t* out_bytes);
+int    dgp_trainer_sync_weights(dgp_trainer* tr, void* stream);
+int    dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* workspace, size_t workspace_bytes,
+                         float** scmap, float** locref, void* stream);
+int    dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t workspace_bytes, const float* dscmap,
+                          const float* dlocref, void* stream);
+int    dgp_sgd_momentum_clip(dgp_trainer* tr, float lr, float momentum, float clip_norm, float* gnorm_host_or_null,
+                             void* stream);
+
 /* ---- single-layer entry points (used by the parity tests and by fit_dgp later) ---- */
 
 /* slim.conv2d / conv2d_same semantics on NHWC fp32 with HWIO weights supplied packed by

@@ -69,3 +69,92 @@ def test_loss_forward_backward_matches_autograd(lib_built, gm2, gm3, shape):
     scale = np.abs(gp).max() + 1e-12
     assert np.abs(dpred.cpu().numpy() - gp).max() <= 2e-4 * scale + 1e-9
     assert np.abs(dloc.cpu().numpy() - gl).max() <= 2e-5 * (np.abs(gl).max() + 1e-12) + 1e-10
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def _train_case(seed, hw=(64, 96), nt=3, nj=3, nvf=1, depth=50):
+    from deepgraphpose_amd.synthetic import make_weights, make_frames
+    from deepgraphpose_amd.arch import scoremap_hw
+    rng = np.random.default_rng(seed)
+    H, W = scoremap_hw(*hw)
+    batch, S0 = _make_loss_case(rng, nt, H, W, nj, nvf, 0.0, 2)
+    wts = make_weights(depth, nj, True, seed=seed, head_std=0.05)
+    frames = make_frames(nt, hw[0], hw[1], nj, seed=seed)
+    ws, ws_max = rng.uniform(5, 20, 2), rng.uniform(10, 40, 2)
+    return batch, S0, wts, frames, ws, ws_max
+
+
+def _oracle_grads(wts, frames, batch, S0, ws, ws_max, hy, n_tot, n_vis, depth=50, dtype=torch.float32):
+    from oracle import dgp_train_oracle as T
+    P = T.make_params(wts, dtype)
+    pred, loc = T.network(frames, P, depth, dtype)
+    nj = pred.shape[-1]
+    cfg = dict(nj=nj, S0=S0, ws=ws, ws_max=ws_max, stride=8.0, gamma=hy.gamma, gauss_len=hy.gauss_len,
+               lengthscale=hy.lengthscale, gm2=hy.gm2, gm3=hy.gm3, wn_visible=hy.wn_visible, wn_hidden=hy.wn_hidden,
+               locref_loss_weight=hy.locref_loss_weight, locref_huber_loss=True, n_frames_total=n_tot,
+               n_visible_frames_total=n_vis)
+    L = T.dgp_loss(pred, loc, batch, cfg)
+    L["total_loss"].backward()
+    return P, L
+
+
+def test_full_backward_matches_autograd(lib_built):
+    """Gradients of every trainable tensor (53 convs x {W, gamma, beta} + 2 heads x {W, b}) vs torch autograd."""
+    from deepgraphpose_amd.train import Trainer
+    from deepgraphpose_amd.loss import DGPHyper
+    batch, S0, wts, frames, ws, ws_max = _train_case(3)
+    hy = DGPHyper(gm2=1, gm3=3)
+    n_tot, n_vis = 300.0, 25.0
+    P, L = _oracle_grads(wts, frames, batch, S0, ws, ws_max, hy, n_tot, n_vis, dtype=torch.float64)
+    tr = Trainer(50, 3, 64, 96, max_frames=3)
+    tr.load_weights(wts)
+    losses = tr.forward_backward(torch.from_numpy(frames).cuda(), batch, hy, S0, ws, ws_max, n_tot, n_vis)
+    assert abs(losses["total_loss"] - float(L["total_loss"].detach())) < 1e-4 * max(1, abs(float(L["total_loss"].detach())))
+    g = tr.get_grads()
+    # A ReLU whose pre-activation is ~1e-7 can come out on the other side of zero in the fp32 HIP forward than in
+    # the fp64 oracle (seen: one element of 73 728 in block3/unit_6, activation 7e-7 vs 0) -- the gate then differs
+    # for that single element and every layer upstream of it inherits an O(1e-3) relative L2 error on these tiny
+    # 4x6 feature maps.  So: layers downstream of any gate flip (block4 + heads) must agree to fp32 round-off,
+    # all others to 1e-2 in relative L2, and the global gradient norm to 1e-3.
+    rel, tot_ref, tot_err = {}, 0.0, 0.0
+    for k, t in P.items():
+        if not t.requires_grad:
+            continue
+        ref = t.grad.numpy()
+        d = g[k].reshape(ref.shape) - ref
+        rel[k] = np.linalg.norm(d.ravel()) / (np.linalg.norm(ref.ravel()) + 1e-30)
+        tot_ref += float((ref ** 2).sum())
+        tot_err += float((d ** 2).sum())
+    strict = {k: v for k, v in rel.items() if "block4" in k or k.startswith("pose/")}
+    assert len(strict) == 3 * 10 + 4 and max(strict.values()) < 2e-5, sorted(strict.items(), key=lambda kv: -kv[1])[:4]
+    assert max(rel.values()) < 1e-2, sorted(rel.items(), key=lambda kv: -kv[1])[:4]
+    assert np.sqrt(tot_err / tot_ref) < 3e-3
+
+
+def test_two_optimizer_steps_match_oracle(lib_built):
+    from deepgraphpose_amd.train import Trainer
+    from deepgraphpose_amd.loss import DGPHyper
+    from oracle import dgp_train_oracle as T
+    batch, S0, wts, frames, ws, ws_max = _train_case(5, nvf=2)
+    hy = DGPHyper(gm2=0, gm3=0, lr=0.005)
+    n_tot, n_vis = 300.0, 25.0
+    tr = Trainer(50, 3, 64, 96, max_frames=3)
+    tr.load_weights(wts)
+    P = T.make_params(wts, torch.float32)
+    V = {}
+    ft = torch.from_numpy(frames).cuda()
+    for it in range(2):
+        losses = tr.step(ft, batch, hy, S0, ws, ws_max, n_tot, n_vis)
+        pred, loc = T.network(frames, P, 50, torch.float32)
+        cfg = dict(nj=3, S0=S0, ws=ws, ws_max=ws_max, stride=8.0, gamma=1.0, gauss_len=1, lengthscale=1.0, gm2=0, gm3=0,
+                   wn_visible=5.0, wn_hidden=3.0, locref_loss_weight=0.05, locref_huber_loss=True, n_frames_total=n_tot,
+                   n_visible_frames_total=n_vis)
+        L = T.dgp_loss(pred, loc, batch, cfg)
+        L["total_loss"].backward()
+        gn = T.momentum_step(P, V, hy.lr)
+        assert abs(losses["total_loss"] - float(L["total_loss"].detach())) < 2e-4 * max(1.0, abs(float(L["total_loss"].detach())))
+        assert abs(losses["grad_norm"] - gn) < 2e-3 * gn
+    w = tr.get_weights()
+    for k, t in P.items():
+        ref = t.detach().numpy()
+        assert np.abs(w[k].reshape(ref.shape) - ref).max() <= 1e-4 * (np.abs(ref).max() + 1e-6) + 1e-6, k
