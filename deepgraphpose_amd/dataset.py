@@ -173,3 +173,236 @@ def compute_pred_dims(frame_h: int, frame_w: int) -> Tuple[int, int]:
     """(nx_out, ny_out) of the scoremap for a frame: 2*ceil(H/16), 2*ceil(W/16).  The reference builds and
     runs the whole network on a zero frame just to read this shape (DGP/dataset.py:348-371)."""
     return scoremap_hw(frame_h, frame_w)
+
+
+# =====================================================================================================
+# Dataset / MultiDataset: per-video bookkeeping of the training batches (DGP/dataset.py:305-1036)
+# =====================================================================================================
+import copy
+import os
+from os.path import join, split
+from pathlib import Path
+
+
+def calculate_motion_energy(source) -> np.ndarray:
+    """mean |frame_t - frame_{t-1}| per frame (DGP/dataset.py:29-43).  Frames are uint8 and the reference
+    subtracts them as such, so the difference wraps modulo 256 -- restated as is."""
+    me, prev, n = [], None, 0
+    for frame in source.iter_frames():
+        frame = np.asarray(frame)
+        me.append(0.0 if prev is None else float(np.mean(np.abs(frame - prev))))
+        prev = frame
+        n += 1
+    return np.asarray(me[:n])
+
+
+def get_frame_idxs_from_train_mat(data_array, video: str) -> np.ndarray:
+    """Frame numbers (img<NNN>.png) of the training items that belong to `video` (DGP/dataset.py:272-282)."""
+    idxs = []
+    for dat in data_array:
+        path = str(dat[0][0])
+        if video in os.path.normpath(path).split(os.sep):
+            idxs.append(int(split(path)[-1][3:].split(".")[0]))
+    return np.sort(idxs)
+
+
+def load_train_mat_labels(mat_file: str, video: str, nj: int, stride: float = 8.0):
+    """Labels of one video from DLC's training .mat (PET/dataset/pose_defaultdataset.py:39-76) converted like
+    Dataset._compute_targets (DGP/dataset.py:587-657): targets_2d = flip((xy - stride/2) / stride), NaN = unlabeled.
+    -> (targets_2d [nv, nj, 2] (row, col) in scoremap units, frame_idxs [nv])."""
+    import scipy.io as sio
+    data = sio.loadmat(mat_file)["dataset"][0]
+    frames, targets = [], []
+    for dat in data:
+        path = str(dat[0][0])
+        if video not in os.path.normpath(path).split(os.sep):
+            continue
+        idx = int(split(path)[-1][3:].split(".")[0])
+        if idx in frames:
+            continue
+        t = np.full((nj, 2), np.nan)
+        if len(dat) >= 3:
+            joints = dat[2][0][0]
+            for row in joints:
+                t[int(row[0])] = np.flip((row[1:3].astype(np.float64) - stride / 2) / stride)
+        frames.append(idx)
+        targets.append(t)
+    order = np.argsort(frames)
+    if not frames:
+        return np.empty((0, nj, 2)), np.array([], dtype=int)
+    return np.asarray(targets)[order], np.asarray(frames)[order]
+
+
+class Dataset:
+    """One video: frame source, labeled-frame indices, selected hidden frames, label targets."""
+
+    def __init__(self, video_path, dlc_config, paths, source=None, labels=None, label_idxs=None):
+        from .frames import open_frame_source
+        self.video_path = video_path
+        self.video_name = os.path.basename(str(video_path)).rpartition(".")[0] or os.path.basename(str(video_path))
+        self.video_clip = source if source is not None else open_frame_source(video_path)
+        self.video_n_frames = self.n_frames = int(self.video_clip.n_frames)
+        self.dlc_config = dlc_config
+        self.paths = copy.deepcopy(paths)
+        self.nj = dlc_config.num_joints
+        self.ny_in, self.nx_in = self.video_clip.size           # (width, height) -> nx_in = rows
+        self.nx_out, self.ny_out = compute_pred_dims(self.nx_in, self.ny_in)
+        if labels is None:
+            mat = join(dlc_config["project_path"], dlc_config["dataset"])
+            labels, label_idxs = load_train_mat_labels(mat, self.video_name, self.nj, dlc_config.get("stride", 8.0))
+        self.labels_all, self.labels_idxs_all = np.asarray(labels), np.asarray(label_idxs, dtype=int)
+        self.idxs = {"vis": {"train": np.sort(self.labels_idxs_all), "val": np.array([])}}
+        self.curr_batch = 0
+        self.batch_data = None
+        self.global_offset = 0
+        self._cache = {}
+
+    # -- batch creation ------------------------------------------------------------------------------
+    def create_batches_from_resnet_output(self, batch_info, batches_path):
+        """Name kept from the reference (DGP/dataset.py:373-424); nothing is pushed through a ResNet here --
+        it selects the hidden frames and builds the index sets."""
+        self.paths["batched_data"] = Path(batches_path)
+        self.batch_key = "nsjump=%s_step=%i_ns=%i_nc=%i_max=%i" % (batch_info["ns_jump"], batch_info["step"],
+                                                                   batch_info["ns"], batch_info["nc"],
+                                                                   batch_info["n_max_frames"])
+        pv_idxs = self.idxs["vis"]["train"]
+        ph_idxs = self._find_good_hidden_frames(pv_idxs, batch_info)
+        self.idxs["pv"], self.idxs["ph"] = np.array(pv_idxs), np.array(ph_idxs, dtype=int)
+        chunk_id = np.concatenate([self.idxs["pv"], self.idxs["ph"]]).astype(int)
+        ns_new = np.ceil(batch_info["n_max_frames"] / max(len(chunk_id), 1) / 2)
+        ns_new = int(min(ns_new, batch_info["ns"]))
+        self.idxs["chunk"] = get_neighboring_window(chunk_id, ns_new, self.video_n_frames)
+        self.idxs["pv_chunk"] = np.where(np.isin(self.idxs["chunk"], pv_idxs))[0]
+        self.idxs["ph_chunk"] = np.where(np.isin(self.idxs["chunk"], ph_idxs))[0]
+        self.idxs["ph_all_chunk"] = np.where(~np.isin(self.idxs["chunk"], pv_idxs))[0]
+        self.labels, self.labels_idxs = self.labels_all, self.labels_idxs_all
+
+    def _find_good_hidden_frames(self, pv_idxs, batch_info):
+        """High-motion-energy unlabeled frames, cached as .npy next to the model (DGP/dataset.py:517-556)."""
+        idxs_file = Path(self.paths["batched_data"]) / ("%s__%s_idxs.npy" % (self.video_name, self.batch_key))
+        if os.path.exists(idxs_file):
+            idxs = np.load(idxs_file, allow_pickle=True).item()
+            if len(idxs["pv"]) == len(pv_idxs) and np.all(np.sort(pv_idxs) == np.sort(idxs["pv"])):
+                return idxs["ph"]
+        me = calculate_motion_energy(self.video_clip)
+        order = np.argsort(me).flatten()[::-1]
+        sel = np.sort(select_hidden_frames(batch_info["ns"], np.asarray(pv_idxs), order, self.video_n_frames,
+                                           batch_info["n_max_frames"], batch_info["ns_jump"]))
+        sel = sel[np.arange(0, len(sel), batch_info["step"]).astype(int)]
+        os.makedirs(os.path.dirname(idxs_file), exist_ok=True)
+        np.save(idxs_file, {"pv": np.asarray(pv_idxs), "ph": sel})
+        return sel
+
+    def reset(self):
+        np.random.shuffle(self.idxs["pv"])
+        np.random.shuffle(self.idxs["ph"])
+        self.curr_batch = 0
+
+    # -- batches -------------------------------------------------------------------------------------
+    def load_data(self, idxs_video, pv_idxs):
+        """Random-access frames + the labels of the visible ones (DGP/dataset.py:811-821)."""
+        want = set(int(i) for i in idxs_video)
+        got = {}
+        if hasattr(self.video_clip, "frames"):
+            for i in want:
+                got[i] = self.video_clip.frames[i]
+        elif hasattr(self.video_clip, "files"):
+            from PIL import Image
+            for i in want:
+                with Image.open(self.video_clip.files[i]) as im:
+                    got[i] = np.asarray(im.convert("RGB"))
+        else:                                                   # moviepy clip: seek by time like the reference
+            clip = self.video_clip.clip
+            for i in want:
+                got[i] = np.asarray(clip.get_frame(i * 1.0 / clip.fps))
+        images = np.stack([got[int(i)] for i in idxs_video]).astype(np.uint8)
+        idxs_labels = [int(np.where(self.labels_idxs == i)[0][0]) for i in pv_idxs]
+        return images, self.labels[idxs_labels]
+
+    def next_batch(self, schedule, batch_dict, pv_idxs=None, ph_idxs=None):
+        """-> (pv_idxs, ph_idxs, pv_idxs_b, images u8 [nt,H,W,3], labels [nv,nj,2], batch_mask [nt-1], batch_ts,
+        (visible_marker, hidden_marker, visible_marker_in_targets)); DGP/dataset.py:672-750."""
+        if pv_idxs is None and ph_idxs is None:
+            raise NotImplementedError("schedule-driven batching is legacy; fit_dgp passes explicit frame lists")
+        pv_idxs, ph_idxs = np.asarray(pv_idxs, dtype=int), np.asarray(ph_idxs, dtype=int)
+        idxs_video = np.sort(np.concatenate([pv_idxs, ph_idxs]))
+        images, labels = self.load_data(idxs_video, pv_idxs)
+        pv_idxs_b = np.where(np.isin(idxs_video, pv_idxs))[0]
+        ph_idxs_b = np.where(np.isin(idxs_video, ph_idxs))[0]
+        batch_mask = np.zeros(max(len(idxs_video) - 1, 0), dtype=int)
+        batch_mask[np.where(np.diff(idxs_video) == 1)[0]] = 1
+        pv_chunk = np.where(np.isin(self.idxs["chunk"], pv_idxs))[0]
+        ph_chunk = np.where(np.isin(self.idxs["chunk"], ph_idxs))[0]
+        pv_ts, ph_ts = find_marker_index(pv_chunk, ph_chunk, labels)
+        batch_ts = self.global_offset * self.nj + np.unique(list(pv_ts) + list(ph_ts))
+        addn = gen_idx_chunk(pv_idxs_b, ph_idxs_b, labels)
+        self.batch_data = (pv_idxs, ph_idxs, pv_idxs_b, images, labels, batch_mask, batch_ts, addn)
+        return self.batch_data
+
+
+class MultiDataset:
+    """All videos of a project (DGP/dataset.py:824-1036)."""
+
+    def __init__(self, config_yaml, video_sets=None, shuffle=None, S0=None, sources=None):
+        import yaml
+        from .config import get_train_config
+        self.datasets, self.paths = [], {}
+        with open(config_yaml, "r") as stream:
+            self.proj_config = yaml.safe_load(stream)
+        if video_sets is None:
+            self.proj_config["video_path"] = self.proj_config["video_sets"]
+        else:
+            keys = [split(v)[-1] for v in self.proj_config["video_sets"].keys()]
+            if set(keys) == set(split(v)[-1] for v in video_sets):
+                self.proj_config["video_path"] = self.proj_config["video_sets"]
+            else:
+                self.proj_config["video_path"] = {v: {} for v in video_sets}
+                self.proj_config["video_sets"] = {v: {} for v in video_sets}
+        self.proj_config["video_sets"] = {join(self.proj_config["project_path"], k): v
+                                          for k, v in self.proj_config["video_sets"].items()}
+        self.dlc_config = get_train_config(self.proj_config, shuffle)
+        self.paths["project"] = Path(self.dlc_config.project_path)
+        self.paths["dlc_model"] = Path(self.dlc_config.snapshot_prefix).parent
+        self.paths["batched_data"] = ""
+        self.video_files = list(self.proj_config["video_sets"].keys())
+        assert len(self.video_files) > 0
+        ratios = []
+        for i, vf in enumerate(self.video_files):
+            src = None if sources is None else sources[i]
+            self.datasets.append(Dataset(vf, self.dlc_config, self.paths, source=src))
+            ratios.append(len(self.datasets[-1].idxs["vis"]["train"]))
+        self.batch_ratios = np.array(ratios) / max(np.sum(ratios), 1)
+        self.n_datasets = len(self.datasets)
+        self.nj = self.datasets[0].nj
+        self.S0 = S0
+        self.nx_in = self.ny_in = self.nx_out = self.ny_out = None
+        self.n_visible_frames_total = self.n_hidden_frames_total = self.n_frames_total = 0
+        self.curr_batch = 0
+
+    def __len__(self):
+        return self.n_datasets
+
+    def create_batches_from_resnet_output(self, snapshot, ns_jump=None, ns=10, nc=200, step=2, n_max_frames=1000):
+        self.snapshot = snapshot
+        self.batch_info = dict(ns_jump=ns_jump, ns=ns, nc=nc, step=step, n_max_frames=n_max_frames)
+        self.paths["batched_data"] = self.paths["dlc_model"] / "batched_data" / "snapshot-{}".format(snapshot)
+        for d in self.datasets:
+            d.create_batches_from_resnet_output(self.batch_info, self.paths["batched_data"])
+        d0 = self.datasets[0]
+        self.nx_in, self.ny_in, self.nx_out, self.ny_out = d0.nx_in, d0.ny_in, d0.nx_out, d0.ny_out
+        self.n_visible_frames_total = self.n_hidden_frames_total = self.n_frames_total = 0
+        for d in self.datasets:
+            self.n_visible_frames_total += len(d.idxs["pv"])
+            self.n_hidden_frames_total += len(d.idxs["ph"])
+            d.global_offset = self.n_frames_total
+            self.n_frames_total += len(d.idxs["chunk"])
+
+    def reset(self):
+        for d in self.datasets:
+            d.reset()
+        self.curr_batch = 0
+
+    def next_batch(self, schedule, dataset=None, pv_idxs=None, ph_idxs=None):
+        if dataset is None or pv_idxs is None or ph_idxs is None:
+            raise NotImplementedError("schedule-driven batching is legacy; pass dataset, pv_idxs, ph_idxs")
+        return self.datasets[dataset].next_batch(schedule, self.batch_info, pv_idxs=pv_idxs, ph_idxs=ph_idxs), dataset

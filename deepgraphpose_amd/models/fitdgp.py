@@ -1,0 +1,274 @@
+"""Drop-in counterparts of deepgraphpose/models/fitdgp.py on the MI355X training engine.
+
+  fit_dgp_labeledonly(snapshot, dlcpath, ...)   DGP/models/fitdgp.py:257-546   (step 1)
+  fit_dgp(snapshot, dlcpath, ...)               DGP/models/fitdgp.py:549-845   (step 2)
+  dgp_loss(data_batcher, dgp_cfg)               DGP/models/fitdgp.py:848-1144  (loss pre-computation + closure)
+  fit_dlc(...)                                  DGP/models/fitdgp.py:53-254    (step 0: DLC baseline trainer; NOT built
+                                                yet -- SURVEY.md 8(f) N2 -- raises NotImplementedError)
+
+One iteration = `Trainer.step` (deepgraphpose_amd/train.py) = the reference's sess.run([loss, train_op]).
+Snapshots are `<train dir>/snapshot-step{k}-{it}.npz` and `snapshot-step{k}-final--0.npz` (TF variable names).
+Host-side third-party hooks that are absent here are skipped loudly: imgaug augmentation (`aug`) and the cv2
+Farneback optical flow of the temporal clique (`wt > 0`, reference code path is itself broken -- SURVEY section 5).
+"""
+from __future__ import annotations
+
+import os
+import time
+from os import listdir
+from os.path import isfile, join
+from pathlib import Path
+from random import randint
+
+import numpy as np
+
+from .. import config as dcfg
+from ..dataset import MultiDataset, coord2map
+from ..loss import DGPHyper
+from .fitdgp_util import gen_batch
+
+_VIDEO_EXT = ("avi", "mp4", "mov", "mkv")
+
+
+def _video_sets(dlc_base_path: Path, cfg):
+    """<project>/videos_dgp/* when present, else the project's video_sets (fitdgp.py:589-604).  Directories of
+    frames and .npy stacks are accepted next to real videos (no decoder is required for them)."""
+    video_path = str(dlc_base_path / "videos_dgp")
+    if not os.path.exists(video_path):
+        print(video_path + " does not exist!")
+        return list(cfg["video_sets"])
+    out = []
+    for f in sorted(listdir(video_path)):
+        p = join(video_path, f)
+        if (isfile(p) and (any(f.find(e) > 0 for e in _VIDEO_EXT) or f.endswith(".npy"))) or os.path.isdir(p):
+            out.append(p)
+    return out
+
+
+def _limb_statistics(labels_list, S0, stride, ws, ws_max):
+    """ws_l = ws / mean non-zero limb length, ws_max_l = ws_max * max limb length, in px (fitdgp.py:875-892)."""
+    nj = S0.shape[1]
+    full = np.empty((0, nj, 2))
+    for j in labels_list:
+        if len(j) > 0:
+            full = np.vstack((j, full))
+    j1 = np.copy(full).swapaxes(1, 2).reshape(-1, nj)
+    j1[np.isnan(j1)] = 1e10
+    limb = np.matmul(j1, S0.T)
+    limb[np.abs(limb) > 1e5] = 0
+    limb = np.sqrt(np.sum(np.square(np.reshape(limb, [full.shape[0], 2, -1])), 1))
+    limb = limb.T * stride + stride / 2
+    ws_max_v = np.max(np.nan_to_num(limb), 1) * ws_max if limb.size else np.zeros(S0.shape[0])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        mean_nz = np.true_divide(limb.sum(1), (limb != 0).sum(1)) if limb.size else np.zeros(S0.shape[0])
+    return 1 / (np.nan_to_num(mean_nz) + 1e-20) * ws, ws_max_v
+
+
+def dgp_loss(data_batcher, dgp_cfg):
+    """-> (loss_fn, hyper, S0, ws, ws_max): the loss pre-computation of fitdgp.py:865-892 plus a closure
+    `loss_fn(trainer, frames, batch, labeled_only)` that runs forward + loss + backward on the GPU.  (The
+    reference returns TF tensors and placeholders; the engine needs no graph.)"""
+    hyper = DGPHyper(ws=dgp_cfg.ws, ws_max=dgp_cfg.ws_max, wt=dgp_cfg.wt, wt_max=dgp_cfg.wt_max,
+                     wn_visible=dgp_cfg.wn_visible, wn_hidden=dgp_cfg.wn_hidden, gamma=dgp_cfg.gamma,
+                     gauss_len=dgp_cfg.gauss_len, lengthscale=dgp_cfg.lengthscale, lr=dgp_cfg.lr, gm2=dgp_cfg.gm2,
+                     gm3=dgp_cfg.gm3, stride=dgp_cfg.stride, locref_loss_weight=dgp_cfg.locref_loss_weight,
+                     locref_huber_loss=dgp_cfg.locref_huber_loss)
+    if hyper.gm2 not in (0, 1, 2) or hyper.gm3 not in (0, 3):
+        raise Exception("Not implemented")                        # fitdgp.py:1019, :1036
+    if hyper.wt > 0:
+        raise NotImplementedError("temporal clique (wt > 0): needs cv2 Farneback optical flow and is off by default")
+    S0 = np.asarray(data_batcher.S0, dtype=np.float64).reshape(-1, data_batcher.nj)
+    ws, ws_max = _limb_statistics([d.labels for d in data_batcher.datasets], S0, dgp_cfg.stride, dgp_cfg.ws,
+                                  dgp_cfg.ws_max)
+
+    def loss_fn(trainer, frames, batch, labeled_only=False):
+        return trainer.step(frames, batch, hyper, S0, ws, ws_max, data_batcher.n_frames_total,
+                            data_batcher.n_visible_frames_total, labeled_only=labeled_only)
+
+    return loss_fn, hyper, S0, ws, ws_max
+
+
+def _setup(snapshot, dlcpath, shuffle, trainingsetindex, frame_sources):
+    dlc_base_path = Path(dlcpath)
+    config_path = dlc_base_path / "config.yaml"
+    print("config_path", config_path)
+    cfg = dcfg.read_config(config_path)
+    modelfolder = dcfg.GetModelFolder(cfg["TrainingFraction"][trainingsetindex], shuffle, cfg)
+    train_path = dlc_base_path / modelfolder / "train"
+    video_sets = _video_sets(dlc_base_path, cfg)
+    print("video_sets: ", video_sets)
+    S0 = dcfg.skeleton_matrix(cfg)
+    data_batcher = MultiDataset(config_yaml=config_path, video_sets=video_sets, shuffle=shuffle, S0=S0,
+                                sources=frame_sources)
+    return data_batcher, str(train_path / snapshot)
+
+
+def _make_trainer(data_batcher, init_weights, max_frames):
+    import torch  # noqa: F401
+    from .. import weights_io
+    from ..train import Trainer
+    wts = weights_io.load_weights(init_weights)
+    depth = weights_io.net_depth(wts)
+    nj = data_batcher.nj
+    if "pose/locref_pred/block4/weights" not in wts:
+        raise KeyError("snapshot %s has no pose/locref_pred head (dgp_loss trains both heads)" % init_weights)
+    tr = Trainer(depth, nj, data_batcher.nx_in, data_batcher.ny_in, max_frames=max_frames)
+    tr.load_weights(wts)
+    return tr
+
+
+def _locref_targets(joint_loc, nt, vis_within, nx_out, ny_out, nj, dgp_cfg):
+    lt, lm = coord2map(joint_loc, nx_out, ny_out, nj, dgp_cfg.pos_dist_thresh, dgp_cfg.locref_stdev) \
+        if joint_loc.shape[0] else (np.zeros((0,)), np.zeros((0,)))
+    lmap = np.zeros((nt, nx_out, ny_out, nj * 2))
+    lmask = np.zeros((nt, nx_out, ny_out, nj * 2))
+    if lm.shape[0] != 0:
+        lmap[vis_within], lmask[vis_within] = lt, lm
+    return lmap, lmask
+
+
+def _save(trainer, prefix, step, it, final, debug=""):
+    from .. import weights_io
+    w = trainer.get_weights()
+    base = prefix + "-step" + str(step) + debug
+    weights_io.save_weights(base + "-" + str(it), w)
+    weights_io.save_weights(base + "--0", w)
+    if final:
+        weights_io.save_weights(base + "-final--0", w)
+
+
+def _augment(dgp_cfg):
+    if not dgp_cfg.aug:
+        return None
+    try:
+        import imgaug  # noqa: F401
+    except ImportError:
+        print("imgaug is not installed: data augmentation of labeled frames is skipped (aug=True requested)")
+        return None
+    raise NotImplementedError("imgaug present: wire build_aug/data_aug (DGP/models/fitdgp_util.py:412-451) here")
+
+
+def fit_dlc(snapshot, dlcpath, shuffle=1, step=0, saveiters=1000, displayiters=100, maxiters=200000,
+            trainingsetindex=0):
+    """Step 0 (DLC baseline trainer, DGP/models/fitdgp.py:53-254) is outside round 1."""
+    raise NotImplementedError("fit_dlc (DLC step-0 trainer: binary-disk sigmoid-CE + locref Huber, multi-step LR, "
+                              "scale-jitter loader) is not built yet; start from an existing snapshot via "
+                              "--dlcsnapshot like the reference allows")
+
+
+def fit_dgp_labeledonly(snapshot, dlcpath, shuffle=1, step=1, saveiters=1000, displayiters=5, maxiters=50000, ns=10,
+                        nc=2048, n_max_frames=2000, aug=True, trainingsetindex=0, frame_sources=None):
+    """Run DGP with labeled frames only (fitdgp.py:257-546): batch = one labeled frame, loss =
+    total_loss_visible.  `frame_sources` (new, optional) injects already-open frame sources per video."""
+    import torch
+    data_batcher, init_weights = _setup(snapshot, dlcpath, shuffle, trainingsetindex, frame_sources)
+    dgp_cfg = data_batcher.dlc_config
+    dgp_cfg.update(ws=0, ws_max=1.2, wt=0, wt_max=0, wn_visible=1, wn_hidden=0, gamma=1, gauss_len=1, lengthscale=1,
+                   max_to_keep=5, batch_size=1, n_times_all_frames=100, lr=0.005, gm2=0, gm3=0, aug=aug)
+    final = dgp_cfg.snapshot_prefix + "-step1-final--0.npz"
+    if os.path.isfile(final):
+        print(final, "  exists! DGP with labeled frames has already been run.", flush=True)
+        return None
+    data_batcher.create_batches_from_resnet_output(0, ns_jump=None, step=1, ns=ns, nc=nc, n_max_frames=n_max_frames)
+    nj = data_batcher.nj
+    visible_frame_total = [d.idxs["pv"] for d in data_batcher.datasets]
+    loss_fn, hyper, S0, ws, ws_max = dgp_loss(data_batcher, dgp_cfg)
+    trainer = _make_trainer(data_batcher, init_weights, max_frames=1)
+    nepoch = int(np.min([int(data_batcher.n_visible_frames_total * dgp_cfg.n_times_all_frames), maxiters]))
+    table = np.array([(i, vv) for i, v in enumerate(visible_frame_total) for vv in v]).reshape(-1, 2)
+    batch_ind_all = np.random.randint(0, table.shape[0], size=nepoch)
+    maxiters = batch_ind_all.shape[0]
+    data_batcher.reset()
+    _augment(dgp_cfg)
+    print("Begin Training for {} iterations".format(maxiters))
+    t_start = time.time()
+    it = -1
+    for it in range(maxiters):
+        dataset_i, frame_i = table[batch_ind_all[it]]
+        d = data_batcher.datasets[dataset_i]
+        (vis, hid, _, images, joint_loc, _, _, addn), _ = data_batcher.next_batch(0, dataset_i, np.array([frame_i]),
+                                                                                  np.array([], dtype=int))
+        vm, hm, vt = addn
+        all_frame = np.sort(list(vis) + list(hid))
+        vis_within = [int(np.where(all_frame == i)[0][0]) for i in vis]
+        lmap, lmask = _locref_targets(joint_loc, len(all_frame), vis_within, d.nx_out, d.ny_out, nj, dgp_cfg)
+        batch = dict(targets=joint_loc, locref_map=lmap, locref_mask=lmask, visible_marker=vm, hidden_marker=hm,
+                     visible_marker_in_targets=vt)
+        t0 = time.time()
+        loss_eval = loss_fn(trainer, torch.from_numpy(images).to(trainer.device), batch, labeled_only=True)
+        if it % displayiters == 0 and it > 0:
+            print("\nIteration {}/{}".format(it, maxiters))
+            print("dataset_i: ", dataset_i, " visible_frame_batch_i: ", [frame_i], flush=True)
+            print(" running time: ", time.time() - t0, "\n loss: ", loss_eval, flush=True)
+        if (it % saveiters == 0) or (it + 1) == maxiters:
+            _save(trainer, dgp_cfg.snapshot_prefix, step, it, (it + 1) == maxiters)
+    print("Finished training {} iterations\n".format(it), flush=True)
+    print("\n\n TOTAL TIME ELAPSED: ", time.time() - t_start)
+    return None
+
+
+def fit_dgp(snapshot, dlcpath, batch_size=10, shuffle=1, step=2, saveiters=1000, displayiters=5, maxiters=200000, ns=10,
+            nc=2048, n_max_frames=2000, gm2=0, gm3=0, nepoch=100, wt=0, aug=True, debug="", trainingsetindex=0,
+            frame_sources=None):
+    """Run DGP (fitdgp.py:549-845): batches of `batch_size` consecutive frames of the selected windows, at least
+    one labeled frame per batch, loss = total_loss (visible + hidden CE, locref, spatial clique)."""
+    import torch
+    data_batcher, init_weights = _setup(snapshot, dlcpath, shuffle, trainingsetindex, frame_sources)
+    dgp_cfg = data_batcher.dlc_config
+    dgp_cfg.update(ws=1000, ws_max=1.2, wt=wt, wt_max=0, wn_visible=5, wn_hidden=3, gamma=1, gauss_len=1, lengthscale=1,
+                   max_to_keep=5, batch_size=batch_size, n_times_all_frames=nepoch, lr=0.005, gm2=gm2, gm3=gm3, aug=aug)
+    final = dgp_cfg.snapshot_prefix + "-step{}{}-final--0.npz".format(step, debug)
+    if os.path.isfile(final):
+        print(final, "  exists! DGP has already been run.", flush=True)
+        return None
+    data_batcher.create_batches_from_resnet_output(0, ns_jump=None, step=1, ns=ns, nc=nc, n_max_frames=n_max_frames)
+    nj = data_batcher.nj
+    print("n_hidden_frames_total", data_batcher.n_frames_total - data_batcher.n_visible_frames_total, flush=True)
+    print("n_visible_frames_total", data_batcher.n_visible_frames_total, flush=True)
+    print("n_frames_total", data_batcher.n_frames_total, flush=True)
+    visible_frame_total = [d.idxs["pv"] for d in data_batcher.datasets]
+    hidden_frame_total = [d.idxs["ph"] for d in data_batcher.datasets]
+    all_frame_total = [d.idxs["chunk"] for d in data_batcher.datasets]
+    loss_fn, hyper, S0, ws, ws_max = dgp_loss(data_batcher, dgp_cfg)
+    trainer = _make_trainer(data_batcher, init_weights, max_frames=batch_size + 1)
+    batch_ind_all = gen_batch(visible_frame_total, hidden_frame_total, all_frame_total, dgp_cfg, maxiters)
+    save_iters = max(int(saveiters / dgp_cfg.batch_size), 1)
+    maxiters = len(batch_ind_all)
+    data_batcher.reset()
+    _augment(dgp_cfg)
+    print("Begin Training for {} iterations".format(maxiters))
+    t_start = time.time()
+    it = -1
+    for it in range(maxiters):
+        batch_ind = batch_ind_all[it]
+        dataset_i = int(batch_ind[-1])
+        d = data_batcher.datasets[dataset_i]
+        all_frame_batch = batch_ind[:-1]
+        visible_frame_i = visible_frame_total[dataset_i]
+        all_frame_i = list(all_frame_total[dataset_i]) + list(hidden_frame_total[dataset_i])
+        vis_b = np.sort(np.array([i for i in all_frame_batch if i in visible_frame_i], dtype=int))
+        if len(vis_b) == 0 and len(visible_frame_i) > 0:              # guarantee one labeled frame (fitdgp.py:755-758)
+            vis_b = np.array([visible_frame_i[randint(0, len(visible_frame_i) - 1)]])
+        hid_b = np.sort(np.array([i for i in all_frame_batch if (i in all_frame_i) and (i not in visible_frame_i)],
+                                 dtype=int))
+        (vis, hid, _, images, joint_loc, wt_mask, _, addn), _ = data_batcher.next_batch(0, dataset_i, vis_b, hid_b)
+        vm, hm, vt = addn
+        all_frame = np.sort(list(vis) + list(hid))
+        vis_within = [int(np.where(all_frame == i)[0][0]) for i in vis]
+        lmap, lmask = _locref_targets(joint_loc, len(all_frame), vis_within, d.nx_out, d.ny_out, nj, dgp_cfg)
+        batch = dict(targets=joint_loc, locref_map=lmap, locref_mask=lmask, visible_marker=vm, hidden_marker=hm,
+                     visible_marker_in_targets=vt, wt_batch_mask=wt_mask)
+        t0 = time.time()
+        loss_eval = loss_fn(trainer, torch.from_numpy(images).to(trainer.device), batch)
+        if it % displayiters == 0 and it > 0:
+            print("\nIteration {}/{}".format(it, maxiters))
+            print("dataset_i: ", dataset_i, flush=True)
+            print("visible_frame_batch_i: ", vis_b, flush=True)
+            print("hidden_frame_batch_i: ", hid_b, flush=True)
+            print("\n running time: ", time.time() - t0, flush=True)
+            print("\n loss: ", loss_eval, flush=True)
+        if (it % save_iters == 0) or (it + 1) == maxiters:
+            _save(trainer, dgp_cfg.snapshot_prefix, step, it, (it + 1) == maxiters, debug)
+    print("Finished {} iterations\n".format(it), flush=True)
+    print("\n\n TOTAL TIME ELAPSED: ", time.time() - t_start)
+    return None

@@ -158,3 +158,33 @@ def test_two_optimizer_steps_match_oracle(lib_built):
     for k, t in P.items():
         ref = t.detach().numpy()
         assert np.abs(w[k].reshape(ref.shape) - ref).max() <= 1e-4 * (np.abs(ref).max() + 1e-6) + 1e-6, k
+
+
+def test_fit_dgp_drivers_end_to_end(lib_built, tmp_path):
+    """fit_dgp_labeledonly (step 1) -> fit_dgp (step 2, gm2=1 gm3=3 like the demo) -> estimate_pose on a synthetic DLC
+    project: runs, writes the step snapshots, losses finite and the labeled-only loss decreases on its frame."""
+    import os, random
+    from _project import make_project
+    from deepgraphpose_amd.models.fitdgp import fit_dgp, fit_dgp_labeledonly
+    from deepgraphpose_amd.models.fitdgp_util import get_snapshot_path
+    from deepgraphpose_amd.models.eval import estimate_pose
+    from deepgraphpose_amd import weights_io
+    proj, frames, wts = make_project(tmp_path)
+    np.random.seed(0); random.seed(0)
+    fit_dgp_labeledonly("snapshot-step0-final--0", proj, shuffle=1, step=1, maxiters=4, displayiters=1, aug=False)
+    snap1, cfg_path = get_snapshot_path("snapshot-step1-final--0", proj, shuffle=1)
+    assert os.path.isfile(snap1 + ".npz")
+    w1 = weights_io.load_weights(snap1)
+    assert np.abs(w1["pose/part_pred/block4/weights"] - wts["pose/part_pred/block4/weights"]).max() > 0
+    fit_dgp("snapshot-step1-final--0", proj, batch_size=4, shuffle=1, step=2, maxiters=3, displayiters=1, gm2=1, gm3=3,
+            aug=False, n_max_frames=30, ns=3)
+    snap2, _ = get_snapshot_path("snapshot-step2-final--0", proj, shuffle=1)
+    assert os.path.isfile(snap2 + ".npz")
+    w2 = weights_io.load_weights(snap2)
+    assert all(np.isfinite(v).all() for v in w2.values())
+    # second call is a no-op (skip-if-exists guard, fitdgp.py:656-660)
+    assert fit_dgp("snapshot-step1-final--0", proj, batch_size=4, maxiters=3) is None
+    labels = estimate_pose(str(cfg_path), snap2, os.path.join(proj, "videos", "clip.npy"), os.path.join(proj, "videos_pred"),
+                           shuffle=1, batch_size=8)
+    assert labels["x"].shape == (40, 3) and np.isfinite(labels["x"]).all()
+    assert os.path.isfile(os.path.join(proj, "videos_pred", "clip_labeled.csv"))
