@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Training-step benchmark (BASELINE configs[3]): ResNet-50, 640x480, 4 keypoints, nt = 11 frames
+(1 labeled + 10 unlabeled), gm2=1 gm3=3, skeleton chain; fp32.  Prints one JSON line."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from deepgraphpose_amd.train import Trainer
+from deepgraphpose_amd.loss import DGPHyper
+from deepgraphpose_amd import dataset as D
+from deepgraphpose_amd.arch import conv_macs_per_frame
+from deepgraphpose_amd.synthetic import make_frames, make_weights
+
+H, W, NJ, NT = 480, 640, 4, 11
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+rng = np.random.default_rng(0)
+wts = make_weights(50, NJ, True, seed=0, head_std=0.05)
+frames = torch.from_numpy(make_frames(NT, H, W, NJ, seed=0)).cuda()
+jl = np.stack([rng.uniform(5, 55, (1, NJ)), rng.uniform(5, 75, (1, NJ))], -1)
+vm, hm, vt = D.gen_idx_chunk(np.array([5]), np.setdiff1d(np.arange(NT), [5]), jl)
+lt, lm = D.coord2map(jl, 60, 80, NJ, 17)
+lmap, lmask = np.zeros((NT, 60, 80, 2 * NJ)), np.zeros((NT, 60, 80, 2 * NJ))
+lmap[5], lmask[5] = lt[0], lm[0]
+batch = dict(targets=jl, locref_map=lmap, locref_mask=lmask, visible_marker=vm, hidden_marker=hm, visible_marker_in_targets=vt)
+S0 = np.zeros((3, NJ)); [S0.__setitem__((i, i), 1) or S0.__setitem__((i, i + 1), -1) for i in range(3)]
+hy = DGPHyper(gm2=1, gm3=3)
+tr = Trainer(50, NJ, H, W, max_frames=NT)
+tr.load_weights(wts)
+ws, ws_max = np.full(3, 10.0), np.full(3, 200.0)
+for _ in range(2):
+    losses = tr.step(frames, batch, hy, S0, ws, ws_max, 2000.0, 50.0)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    losses = tr.step(frames, batch, hy, S0, ws, ws_max, 2000.0, 50.0)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps
+fwd = 2.0 * conv_macs_per_frame(H, W, 50, NJ, True) * NT
+print(json.dumps({"metric": "train_step", "ms_per_step": round(dt * 1e3, 2), "frames_per_s": round(NT / dt, 1),
+                  "nt": NT, "dtype": "f32", "approx_tflops(3x fwd conv flops)": round(3 * fwd / dt / 1e12, 1),
+                  "loss": {k: round(v, 5) for k, v in losses.items()}}))
