@@ -63,18 +63,20 @@ constexpr unsigned OOB = 0xFFFFFFF0u;
 // wave-uniform (SALU, advanced incrementally) and each A load costs ~7 VALU ops.  The generic
 // path (WIDE = false, used by the 4-channel stem) recomputes the tap per lane.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool WIDE>
-__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_f32(const ConvArgs p) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;     // threads per workgroup (4 or 8 waves)
     constexpr int WM = BM / WAVES_M;       // wave tile rows
     constexpr int WN = BN / WAVES_N;       // wave tile cols
     constexpr int TM = WM / 32;
     constexpr int TN = WN / 32;
-    constexpr int AROWS = BM / 32;         // A rows staged per thread
-    constexpr int BSLOTS = 8 * BN / 256;   // B 16-byte slots staged per thread
+    constexpr int RG = NT / 8;             // pixel rows covered by one staging pass (8 chunks per row)
+    constexpr int AROWS = BM / RG;         // A rows staged per thread
+    constexpr int BSLOTS = 8 * BN / NT;    // B 16-byte slots staged per thread
     constexpr int LDA = BM + 1;            // slots per chunk plane of A
     constexpr int LDC = WN + 4;            // floats per row of a wave's epilogue staging tile
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-    static_assert(BSLOTS >= 1, "BN too small");
-    static_assert(4 * 32 * LDC * 4 <= (2 * 8 * LDA + 2 * 8 * BN) * 16, "epilogue staging must fit");
+    static_assert(WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8, "4 or 8 waves per workgroup");
+    static_assert(BSLOTS >= 1 && AROWS >= 1, "tile too small for the workgroup");
+    static_assert(WAVES_M * WAVES_N * 32 * LDC * 4 <= (2 * 8 * LDA + 2 * 8 * BN) * 16, "epilogue staging must fit");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* sA = reinterpret_cast<float4*>(smem);     // [2][8][LDA]
@@ -107,12 +109,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
 
     // ---- per-thread A row bookkeeping -------------------------------------------------
     const int c = t & 7;        // chunk within the K-step
-    const int rg = t >> 3;      // 0..31
+    const int rg = t >> 3;      // 0..RG-1
     int hi0[AROWS], wi0[AROWS], pix0[AROWS], nbase[AROWS];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-        const int m = m0 + rg + 32 * i;
+        const int m = m0 + rg + RG * i;
         if (m < p.M) {
             const int n = m / HoWo;
             const int rem = m - n * HoWo;
@@ -191,15 +193,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < BSLOTS; ++i)
             rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                        rs_w, (int)b_lane_off, (int)(kbase + (unsigned)(i * (256 / BN)) * b_row_bytes), 0));
+                        rs_w, (int)b_lane_off, (int)(kbase + (unsigned)(i * (NT / BN)) * b_row_bytes), 0));
     };
     auto lstore = [&](int buf) {
         float4* a = sA + buf * 8 * LDA + c * LDA + rg;
 #pragma unroll
-        for (int i = 0; i < AROWS; ++i) a[32 * i] = ra[i];
+        for (int i = 0; i < AROWS; ++i) a[RG * i] = ra[i];
         float4* b = sB + buf * 8 * BN + t;
 #pragma unroll
-        for (int i = 0; i < BSLOTS; ++i) b[256 * i] = rb[i];
+        for (int i = 0; i < BSLOTS; ++i) b[NT * i] = rb[i];
     };
 
     floatx16 acc[TM][TN];
@@ -390,6 +392,295 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------
+// Loader-specialised variant (Cin >= 32, NHWC output): the workgroup has 4 COMPUTE waves (2 x 2 over the tile)
+// that only issue ds_read_b128 + MFMA, and 4 LOADER waves that only issue buffer loads + ds_write.  A
+// buffer_load costs the issuing wave hundreds of cycles under load (the L2 -> L1 path is the co-bottleneck
+// of this kernel); with the loads on their own waves that stall no longer sits in front of
+// the MFMAs, and every load has a whole K-step (8k cycles) in flight before its LDS write.
+//   step ks:  compute reads buf[ks&1]      | loaders write buf[(ks+1)&1] (loaded during step ks-1),
+//                                          | then issue the loads of step ks+2;   one s_barrier per step.
+// ------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(512, 4) void conv_igemm_f32_ls(const ConvArgs p) {
+    constexpr int WM = BM / 2, WN = BN / 2;        // compute waves 2 x 2
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int NLT = 256;                       // loader threads
+    constexpr int RG = NLT / 8;
+    constexpr int AROWS = BM / RG;
+    constexpr int BSLOTS = 8 * BN / NLT;
+    constexpr int LDA = BM + 1;
+    constexpr int LDC = WN + 4;
+    static_assert(4 * 32 * LDC * 4 <= (2 * 8 * LDA + 2 * 8 * BN) * 16, "epilogue staging must fit");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* sA = reinterpret_cast<float4*>(smem);     // [2][8][LDA]
+    float4* sB = sA + 2 * 8 * LDA;                    // [2][8][BN]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, loc = b >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = tile / p.ntiles;
+    const int nt = tile - mt * p.ntiles;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
+    const int HoWo = p.Ho * p.Wo;
+
+    if (wave >= 4) {
+        // ================================ loader waves ================================
+        const int t = threadIdx.x - 256;
+        const __amdgpu_buffer_rsrc_t rs_in =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)p.in_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (int)p.w_bytes, 0x00020000);
+        const int c = t & 7, rg = t >> 3;
+        int hi0[AROWS], wi0[AROWS], rowoff[AROWS], nbase[AROWS];
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            const int m = m0 + rg + RG * i;
+            if (m < p.M) {
+                const int n = m / HoWo;
+                const int rem = m - n * HoWo;
+                const int ho = rem / p.Wo;
+                const int wo = rem - ho * p.Wo;
+                hi0[i] = ho * p.stride - p.pad_t;
+                wi0[i] = wo * p.stride - p.pad_l;
+                rowoff[i] = (((n * p.H + hi0[i]) * p.W + wi0[i]) * p.Cin + 4 * c) * 4;
+                nbase[i] = n * p.H * p.W;
+            } else {
+                hi0[i] = -(1 << 28); wi0[i] = -(1 << 28); rowoff[i] = 0; nbase[i] = 0;
+            }
+        }
+        const unsigned b_lane_off = (unsigned)(t / BN) * ((unsigned)p.CoutP * 16u) + (unsigned)((n0 + (t & (BN - 1))) * 16);
+        const unsigned b_row_bytes = (unsigned)p.CoutP * 16u;
+        int w_kh = 0, w_kw = 0, w_ch = 0, w_tap = 0;
+        // two register sets: the loads of step ks+3 are issued while those of step ks+2 are still in flight, so
+        // every load has two K-steps to land (one K-step was not enough: the loaders, not the MFMAs, set the pace)
+        float4 ra0[AROWS], rb0[BSLOTS], ra1[AROWS], rb1[BSLOTS];
+        auto gload = [&](int ks, float4 (&ra)[AROWS], float4 (&rb)[BSLOTS]) {
+            const int dh = w_kh * p.dil, dw = w_kw * p.dil;
+            const int doff = ((dh * p.W + dw) * p.Cin + w_ch) * 4;
+            const bool tapok = w_tap < p.ntaps;
+            if (p.up == 2) {
+#pragma unroll
+                for (int i = 0; i < AROWS; ++i) {
+                    const int hv = hi0[i] + dh, wv = wi0[i] + dw;
+                    const bool ok = tapok && !((hv | wv) & 1) && (unsigned)(hv >> 1) < (unsigned)p.H &&
+                                    (unsigned)(wv >> 1) < (unsigned)p.W;
+                    const unsigned off = (unsigned)((nbase[i] + (hv >> 1) * p.W + (wv >> 1)) * p.Cin + w_ch + 4 * c) << 2;
+                    ra[i] = buf_load16(rs_in, ok ? off : OOB);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < AROWS; ++i) {
+                    const int hi = hi0[i] + dh, wi = wi0[i] + dw;
+                    const bool ok = tapok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                    ra[i] = buf_load16(rs_in, ok ? (unsigned)(rowoff[i] + doff) : OOB);
+                }
+            }
+            w_ch += 32;
+            if (w_ch >= p.Cin) {
+                w_ch = 0; ++w_tap;
+                if (++w_kw == p.KW) { w_kw = 0; ++w_kh; }
+            }
+            const unsigned kbase = (unsigned)(ks * 8) * b_row_bytes;
+#pragma unroll
+            for (int i = 0; i < BSLOTS; ++i)
+                rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                            rs_w, (int)b_lane_off, (int)(kbase + (unsigned)(i * (NLT / BN)) * b_row_bytes), 0));
+        };
+        auto lstore = [&](int buf, float4 (&ra)[AROWS], float4 (&rb)[BSLOTS]) {
+            float4* a = sA + buf * 8 * LDA + c * LDA + rg;
+#pragma unroll
+            for (int i = 0; i < AROWS; ++i) a[RG * i] = ra[i];
+            float4* b = sB + buf * 8 * BN + t;
+#pragma unroll
+            for (int i = 0; i < BSLOTS; ++i) b[NLT * i] = rb[i];
+        };
+        gload(0, ra0, rb0);
+        lstore(0, ra0, rb0);
+        if (p.nk > 1) gload(1, ra1, rb1);           // set 1 holds odd steps, set 0 even steps
+        if (p.nk > 2) gload(2, ra0, rb0);
+        __syncthreads();
+        for (int ks = 0; ks < p.nk; ks += 2) {
+            // step ks (even): publish step ks+1 (set 1), refill it with step ks+3
+            if (ks + 1 < p.nk) lstore(1, ra1, rb1);
+            if (ks + 3 < p.nk) gload(ks + 3, ra1, rb1);
+            __syncthreads();
+            if (ks + 1 >= p.nk) break;
+            // step ks+1 (odd): publish step ks+2 (set 0), refill it with step ks+4
+            if (ks + 2 < p.nk) lstore(0, ra0, rb0);
+            if (ks + 4 < p.nk) gload(ks + 4, ra0, rb0);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ================================== compute waves ==================================
+    const int wave_m0 = (wave >> 1) * WM;
+    const int wave_n0 = (wave & 1) * WN;
+    const int half = lane >> 5, l31 = lane & 31;
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#ifdef DGP_DIAG
+    unsigned long long e0, e1, e2, e3, acc_mf = 0, acc_ba = 0;
+    DIAG_STAMP(e0);
+#endif
+    __syncthreads();
+#ifdef DGP_DIAG
+    DIAG_STAMP(e1);
+    const unsigned long long t_pro = e1 - e0;
+#endif
+    for (int ks = 0; ks < p.nk; ++ks) {
+        const int buf = ks & 1;
+        const float4* a_base = sA + buf * 8 * LDA + wave_m0 + l31;
+        const float4* b_base = sB + buf * 8 * BN + wave_n0 + l31;
+        DIAG_STAMP(e1);
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const int chunk = 2 * kc + half;
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = a_base[chunk * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = b_base[chunk * BN + 32 * j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        DIAG_STAMP(e2);
+        __syncthreads();
+        DIAG_STAMP(e3);
+#ifdef DGP_DIAG
+        acc_mf += e2 - e1; acc_ba += e3 - e2;
+#endif
+    }
+#ifdef DGP_DIAG
+    if (p.dbg && threadIdx.x == 0) {
+        unsigned long long* d = p.dbg + 10ull * blockIdx.x;
+        d[0] = t_pro; d[1] = acc_mf + acc_ba; d[2] = 0; d[3] = 0; d[4] = acc_mf; d[5] = 0; d[6] = 0; d[7] = acc_ba;
+    }
+#endif
+
+    // ---- epilogue (compute waves only; wave-private LDS staging, no workgroup barriers: the loader waves are gone)
+    float* sC = reinterpret_cast<float*>(smem) + wave * (32 * LDC);
+    constexpr int C4 = WN / 4;
+    constexpr int NV = 32 * C4 / 64;
+    const __amdgpu_buffer_rsrc_t rs_res =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.in), 0, p.res ? (int)p.res_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_mask =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.mask ? p.mask : p.in), 0, p.mask ? (int)p.out_bytes : 0, 0x00020000);
+    const int my_c4 = lane % C4;
+    const int my_r0 = lane / C4;
+    const int co4 = n0 + wave_n0 + 4 * my_c4;
+    const bool cok = co4 < p.Cout;
+    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), bi4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cok && p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + co4);
+    if (cok && p.bias) bi4 = *reinterpret_cast<const float4*>(p.bias + co4);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own reads of the previous pass are done
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                sC[row * LDC + 32 * j + l31] = acc[i][j][r];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // a wave's LDS ops complete in order
+        unsigned ooff[NV];
+        float4 rres[NV], rmask[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int row = my_r0 + v * (64 / C4);
+            const int m = m0 + wave_m0 + 32 * i + row;
+            const bool ok = cok && m < p.M;
+            ooff[v] = ok ? ((unsigned)(m * p.Cout + co4) << 2) : OOB;
+            unsigned roff = OOB;
+            if (p.res_s == 1) {
+                roff = ooff[v];
+            } else if (p.res_s == -2 && ok) {
+                const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                if (!((ho | wo) & 1)) roff = (unsigned)(((n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1)) * p.Cout + co4) << 2;
+            } else if (p.res_s > 1 && ok) {
+                const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                roff = (unsigned)(((n * p.res_H + ho * p.res_s) * p.res_W + wo * p.res_s) * p.Cout + co4) << 2;
+            }
+            rres[v] = buf_load16(rs_res, roff);
+            rmask[v] = buf_load16(rs_mask, ooff[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int row = my_r0 + v * (64 / C4);
+            const float4 a = *reinterpret_cast<const float4*>(sC + row * LDC + 4 * my_c4);
+            float4 o;
+            o.x = a.x * sc4.x + bi4.x + rres[v].x;
+            o.y = a.y * sc4.y + bi4.y + rres[v].y;
+            o.z = a.z * sc4.z + bi4.z + rres[v].z;
+            o.w = a.w * sc4.w + bi4.w + rres[v].w;
+            if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            if (p.mask) {
+                o.x = rmask[v].x > 0.f ? o.x : 0.f; o.y = rmask[v].y > 0.f ? o.y : 0.f;
+                o.z = rmask[v].z > 0.f ? o.z : 0.f; o.w = rmask[v].w > 0.f ? o.w : 0.f;
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)ooff[v], 0, 0);
+        }
+    }
+}
+
+template <int BM, int BN>
+static hipError_t launch_conv_ls(ConvArgs a, hipStream_t s) {
+    const size_t smem = (size_t)(2 * 8 * (BM + 1) + 2 * 8 * BN) * 16;
+    a.mtiles = (a.M + BM - 1) / BM;
+    a.ntiles = (a.CoutP + BN - 1) / BN;
+    if (a.CoutP % BN != 0 || a.Cin < 32 || a.out_mode != 0) return hipErrorInvalidValue;
+    auto kern = conv_igemm_f32_ls<BM, BN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const long long nwg = (long long)a.mtiles * a.ntiles;
+#ifdef DGP_DIAG
+    static unsigned long long* dbg_buf = nullptr;
+    if (!dbg_buf) (void)hipMalloc(&dbg_buf, 10 * 8 * 65536);
+    a.dbg = nwg <= 65536 ? dbg_buf : nullptr;
+#endif
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), smem, s, a);
+#ifdef DGP_DIAG
+    if (a.dbg) {
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> h(10 * nwg);
+        (void)hipMemcpy(h.data(), a.dbg, 80 * nwg, hipMemcpyDeviceToHost);
+        double v[8] = {0};
+        for (long long b = 0; b < nwg; ++b) for (int k = 0; k < 8; ++k) v[k] += (double)h[10 * b + k];
+        for (int k = 0; k < 8; ++k) v[k] /= (double)nwg;
+        printf("[diag LS %dx%d] tiles %lld nk %d | compute wave 0: first barrier %.0f cyc | per K-step: mfma+ldsread %.0f barrier-wait %.0f\n",
+               BM, BN, nwg, a.nk, v[0], v[4] / a.nk, v[7] / a.nk);
+    }
+#endif
+    return hipGetLastError();
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool WIDE>
 static hipError_t launch_conv_t(ConvArgs a, hipStream_t s) {
     size_t smem = (size_t)(2 * 8 * (BM + 1) + 2 * 8 * BN) * 16;
@@ -413,7 +704,7 @@ static hipError_t launch_conv_t(ConvArgs a, hipStream_t s) {
         attr_done = true;
     }
     const long long nwg = (long long)a.mtiles * a.ntiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), smem, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * WAVES_M * WAVES_N), smem, s, a);
 #ifdef DGP_DIAG
     if (a.dbg) {
         (void)hipStreamSynchronize(s);
@@ -433,15 +724,25 @@ static hipError_t launch_conv_t(ConvArgs a, hipStream_t s) {
 // Tile choice, from scripts/conv_sweep.py on MI355X (ResNet-50 640x480 batch-32 shapes, TFLOP/s for
 // 128x128 / 128x64 / 64x64): the small 64x64 tile (4 workgroups per CU, finest tail) wins for the
 // K-heavy 3x3 convs and for 1x1 convs with a deep K and few output channels; 128x64 wins for the
-// shallow-K, wide-N 1x1 convs (fewer re-reads of the activation rows); 128x128 never won.
+// shallow-K, wide-N 1x1 convs (fewer re-reads of the activation rows); a 128x128 tile shared by 8 waves (same
+// 16 waves per CU as the 64x64 tile, half the L2 traffic per FLOP) wins when Cout >= 512; 128x128 with 4 waves never won.
 int pick_tile(int M, int CoutP, int K) {
     (void)M;
     if (CoutP <= 32) return TILE_128x32;
     if (const char* f = getenv("DGP_FORCE_TILE")) {     // tuning experiments only
         const int v = atoi(f);
-        if (v == TILE_128x128 && CoutP % 128 == 0) return v;
+        if ((v == TILE_128x128 || v == TILE_128x128_W8 || v == TILE_128x128_LS) && CoutP % 128 == 0) return v;
+        if (v == TILE_128x64_LS && CoutP % 64 == 0) return v;
         if ((v == TILE_128x64 || v == TILE_64x64) && CoutP % 64 == 0) return v;
     }
+    static const int rule = getenv("DGP_TILE_RULE") ? atoi(getenv("DGP_TILE_RULE")) : 2;   // A/B switch for tuning runs
+    if (rule >= 2) {
+        // loader-specialised 128x64 (4 compute + 4 loader waves, 3 workgroups per CU, loads two K-steps ahead) won or
+        // tied on every Cin >= 32 layer except the very wide 1x1 convs, where the 8-wave 128x128 tile is ahead
+        if (CoutP >= 1024) return TILE_128x128_W8;
+        return TILE_128x64_LS;             // launch_conv falls back to the generic kernel when Cin < 32
+    }
+    if (rule >= 1 && CoutP >= 512 && !(K >= 4096)) return TILE_128x128_W8;   // wide-N 1x1 convs: 8 waves share a 128x128 tile
     if (K >= 1024 && CoutP <= 512) return TILE_64x64;      // 3x3 convs, deep-K 1x1 reductions
     if (K >= 576 && CoutP <= 256) return TILE_64x64;       // 3x3 convs of block1/2
     return TILE_128x64;
@@ -450,6 +751,7 @@ int pick_tile(int M, int CoutP, int K) {
 hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s) {
     if (a.Cin < 32) {       // generic per-lane tap path (stem / small test shapes)
         if (tile_cfg == TILE_128x32) return launch_conv_t<128, 32, 4, 1, false>(a, s);
+        if (tile_cfg == TILE_128x128_W8 || tile_cfg == TILE_128x128_LS) tile_cfg = TILE_128x128;
         if (a.CoutP % 128 == 0 && tile_cfg == TILE_128x128) return launch_conv_t<128, 128, 2, 2, false>(a, s);
         return launch_conv_t<128, 64, 2, 2, false>(a, s);
     }
@@ -457,6 +759,9 @@ hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s) {
         case TILE_128x32: return launch_conv_t<128, 32, 4, 1, true>(a, s);
         case TILE_128x64: return launch_conv_t<128, 64, 2, 2, true>(a, s);
         case TILE_64x64:  return launch_conv_t<64, 64, 2, 2, true>(a, s);
+        case TILE_128x128_W8: return launch_conv_t<128, 128, 2, 4, true>(a, s);
+        case TILE_128x128_LS: return a.out_mode == 0 ? launch_conv_ls<128, 128>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
+        case TILE_128x64_LS:  return a.out_mode == 0 ? launch_conv_ls<128, 64>(a, s) : launch_conv_t<128, 64, 2, 2, true>(a, s);
         default:          return launch_conv_t<128, 128, 2, 2, true>(a, s);
     }
 }

@@ -30,8 +30,8 @@ for name, N, H, W, Cin, Cout, k, s, r, pad in LAYERS:
     w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
     flops = 2.0 * N * H * W * k * k * Cin * Cout
     res = []
-    for tile in (0, 1, 2):
-        if tile == 0 and Cout % 128: 
+    for tile in (0, 1, 2, 4, 5, 6):
+        if tile in (0, 4, 5) and Cout % 128: 
             res.append("   -  "); continue
         os.environ["DGP_FORCE_TILE"] = str(tile)
         y = engine.conv2d(x, w, stride=s, rate=r, pad_t=pad, pad_l=pad, out_hw=(H, W), relu=True)
@@ -52,4 +52,4 @@ for name, N, H, W, Cin, Cout, k, s, r, pad in LAYERS:
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
         res.append("%6.1f" % (flops / ms / 1e9))
-    print("%-22s GF %7.1f | TF 128x128 %s | 128x64 %s | 64x64 %s" % (name, flops / 1e9, res[0], res[1], res[2]), flush=True)
+    print("%-22s GF %7.1f | TF 128x128 %s | 128x64 %s | 64x64 %s | 128x128/8w %s | LS128x128 %s | LS128x64 %s" % (name, flops / 1e9, res[0], res[1], res[2], res[3], res[4], res[5]), flush=True)

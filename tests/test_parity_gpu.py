@@ -290,3 +290,29 @@ def test_estimate_pose_end_to_end(eng, tmp_path):
     dlc_cfg.net_type = "resnet_101"
     with pytest.raises(KeyError):
         E.setup_dgp_eval_graph(dlc_cfg, snap[:-4])
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 4, 5, 6])
+@pytest.mark.parametrize("case", [(2, 19, 21, 64, 128, 3, 1, 1), (1, 15, 20, 128, 256, 3, 1, 2), (2, 20, 24, 256, 512, 1, 2, 1),
+                                  (1, 30, 40, 1024, 256, 1, 1, 1), (2, 19, 21, 64, 64, 3, 2, 1)])
+def test_every_tile_variant_matches_oracle(eng, case, tile, monkeypatch):
+    """All workgroup shapes of conv_igemm_f32 (incl. the 8-wave and loader-specialised variants) on the same layers,
+    with residual + ReLU in the epilogue."""
+    from oracle import dgp_oracle as O
+    N, H, W, Cin, Cout, k, stride, rate = case
+    if tile in (0, 4, 5) and Cout % 128:
+        pytest.skip("tile needs Cout % 128 == 0")
+    monkeypatch.setenv("DGP_FORCE_TILE", str(tile))
+    rng = np.random.default_rng(tile * 100 + Cin)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    scale = (1 + 0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    ref = O._to_nhwc(O.conv2d_same(O._to_nchw(x), w, stride, rate))
+    res = rng.standard_normal(ref.shape).astype(np.float32)
+    ref = np.maximum(ref * scale + bias + res, 0)
+    keff = (k - 1) * rate + 1
+    pad = (keff - 1) // 2 if stride > 1 else O.tf_same_pads(H, k, stride, rate)[1]
+    y = eng.conv2d(torch.from_numpy(x).cuda(), w, stride=stride, rate=rate, pad_t=pad, pad_l=pad, out_hw=ref.shape[1:3],
+                   scale=scale, bias=bias, residual=torch.from_numpy(res).cuda(), res_stride=1, relu=True).cpu().numpy()
+    assert _rel_err(y, ref) < 2e-5
