@@ -23,6 +23,8 @@ struct ConvArgs {
     int ntaps, nk;        // real taps, number of BK steps
     int M;                // N*Ho*Wo
     int res_s, res_H, res_W;   // res_s == 0: none; s >= 1: residual[n, ho*s, wo*s]; -2: residual on the 2x coarser grid
+    int ksplit;                // > 1: split-K over workgroups into per-split slabs (out_mode 1 only)
+    long long split_stride;    // floats between slabs
     int up;                    // 2: data-gradient gather of a stride-2 conv (input on the zero-stuffed grid)
     int relu;
     int out_mode;         // 0: NHWC [M][Cout]; 1: transposed-conv phase scatter
@@ -36,6 +38,7 @@ enum TileCfg { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_128x32 = 
 
 hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s);
 int        pick_tile(int M, int CoutP, int K);
+hipError_t launch_reduce_slabs(const float* slabs, long long n, long long stride, int nsplit, float* out, hipStream_t s);
 hipError_t launch_maxpool(const float* x, int N, int H, int W, int C, float* y, hipStream_t s);
 hipError_t launch_preprocess(const uint8_t* f, long long npix, float m0, float m1, float m2,
                              float* out, hipStream_t s);

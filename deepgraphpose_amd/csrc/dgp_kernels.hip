@@ -97,6 +97,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_f32(const C
         const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, loc = b >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
+    // split-K (heads only): consecutive tile ids are the K-slices of one output tile
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int split = tile % ksplit;
+    tile /= ksplit;
+    const int nk_loc = p.nk / ksplit;
+    const int ks_begin = split * nk_loc, ks_end = ks_begin + nk_loc;
     const int mt = tile / p.ntiles;
     const int nt = tile - mt * p.ntiles;
     const int m0 = mt * BM;
@@ -138,7 +144,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_f32(const C
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) rowoff[i] = (pix0[i] * p.Cin + 4 * c) * 4;
     // wave-uniform tap walker (WIDE): K-step ks covers tap w_tap, channels [w_ch, w_ch + 32)
-    int w_kh = 0, w_kw = 0, w_ch = 0, w_tap = 0;
+    int w_tap = (ks_begin * 8) >> p.log2cin4;
+    int w_ch = ((ks_begin * 8) & cin4m1) << 2;
+    int w_kh = w_tap / p.KW, w_kw = w_tap - w_kh * p.KW;
 
     float4 ra[AROWS];
     float4 rb[BSLOTS];
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_f32(const C
 #ifdef DGP_DIAG
     if (p.dbg) st0 = __builtin_amdgcn_s_memtime();
 #endif
-    gload(0);
+    gload(ks_begin);
     lstore(0);
     __syncthreads();
 #ifdef DGP_DIAG
@@ -229,10 +237,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_f32(const C
 #ifdef DGP_DIAG
     unsigned long long d0, d1, d2, d3, d4, d5, acc_gl = 0, acc_mf = 0, acc_vm = 0, acc_ls = 0, acc_ba = 0;
 #endif
-    for (int ks = 0; ks < p.nk; ++ks) {
-        const int buf = ks & 1;
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+        const int buf = (ks - ks_begin) & 1;
         DIAG_STAMP(d0);
-        if (ks + 1 < p.nk) gload(ks + 1);           // in flight under the MFMAs below
+        if (ks + 1 < ks_end) gload(ks + 1);          // in flight under the MFMAs below
         DIAG_STAMP(d1);
         const float4* a_base = sA + buf * 8 * LDA + wave_m0 + l31;
         const float4* b_base = sB + buf * 8 * BN + wave_n0 + l31;
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_f32(const C
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         DIAG_STAMP(d3);
 #endif
-        if (ks + 1 < p.nk) lstore(buf ^ 1);
+        if (ks + 1 < ks_end) lstore(buf ^ 1);
         DIAG_STAMP(d4);
         __syncthreads();
         DIAG_STAMP(d5);
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_f32(const C
         for (int j = 0; j < TN; ++j) {
             const int co = n0 + wave_n0 + 32 * j + l31;
             const bool cok = co < p.Cout;
-            const float bi = (cok && p.bias) ? p.bias[co] : 0.f;
+            const float bi = (cok && p.bias && split == 0) ? p.bias[co] : 0.f;
             const int ph = co / p.dc_nj;
             const int cj = co - ph * p.dc_nj;
             const int ph_a = ph >> 1, ph_b = ph & 1;
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_f32(const C
                     const int wo = rem - ho * p.Wo;
                     const long long oidx =
                         (((long long)n * (2 * p.Ho) + 2 * ho + ph_a) * (2 * p.Wo) + 2 * wo + ph_b) * p.dc_nj + cj;
-                    p.out[oidx] = acc[i][j][r] + bi;
+                    p.out[(long long)split * p.split_stride + oidx] = acc[i][j][r] + bi;
                 }
             }
         }
@@ -703,7 +711,8 @@ static hipError_t launch_conv_t(ConvArgs a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    const long long nwg = (long long)a.mtiles * a.ntiles;
+    if (a.ksplit > 1 && (a.out_mode != 1 || a.nk % a.ksplit != 0)) return hipErrorInvalidValue;
+    const long long nwg = (long long)a.mtiles * a.ntiles * (a.ksplit > 1 ? a.ksplit : 1);
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * WAVES_M * WAVES_N), smem, s, a);
 #ifdef DGP_DIAG
     if (a.dbg) {
@@ -740,7 +749,9 @@ int pick_tile(int M, int CoutP, int K) {
         // loader-specialised 128x64 (4 compute + 4 loader waves, 3 workgroups per CU, loads two K-steps ahead) won or
         // tied on every Cin >= 32 layer except the very wide 1x1 convs, where the 8-wave 128x128 tile is ahead
         if (CoutP >= 1024) return TILE_128x128_W8;
-        return TILE_128x64_LS;             // launch_conv falls back to the generic kernel when Cin < 32
+        if (K >= 576) return TILE_128x64_LS;     // 3x3 convs and deep-K 1x1 reductions (MFMA-bound)
+        // shallow-K 1x1 convs of block1/2 are HBM/L2-bound: all 256 threads loading beats 4 loader waves
+        return CoutP >= 512 ? TILE_128x128_W8 : TILE_128x64;
     }
     if (rule >= 1 && CoutP >= 512 && !(K >= 4096)) return TILE_128x128_W8;   // wide-N 1x1 convs: 8 waves share a 128x128 tile
     if (K >= 1024 && CoutP <= 512) return TILE_64x64;      // 3x3 convs, deep-K 1x1 reductions
@@ -764,6 +775,27 @@ hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s) {
         case TILE_128x64_LS:  return a.out_mode == 0 ? launch_conv_ls<128, 64>(a, s) : launch_conv_t<128, 64, 2, 2, true>(a, s);
         default:          return launch_conv_t<128, 128, 2, 2, true>(a, s);
     }
+}
+
+// Deterministic split-K combine for the heads: out[i] = sum_s slab[s][i] in fixed order (no float atomics).
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, long long n4, long long stride,
+                                                           int nsplit, float* __restrict__ out) {
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += (long long)gridDim.x * blockDim.x) {
+        float4 a = *reinterpret_cast<const float4*>(slabs + g * 4);
+        for (int s = 1; s < nsplit; ++s) {
+            const float4 b = *reinterpret_cast<const float4*>(slabs + (long long)s * stride + g * 4);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        *reinterpret_cast<float4*>(out + g * 4) = a;
+    }
+}
+
+hipError_t launch_reduce_slabs(const float* slabs, long long n, long long stride, int nsplit, float* out, hipStream_t s) {
+    const long long n4 = n / 4;
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs, n4, stride, nsplit, out);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------

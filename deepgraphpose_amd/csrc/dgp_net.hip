@@ -223,8 +223,10 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
 
 namespace {
 
+constexpr int HEAD_KSPLIT_MAX = 8;
+
 struct Plan {
-    size_t off_p0, off_c1, off_x0, off_x1, off_sc, off_r1, off_r2, off_scmap, off_locref, total;
+    size_t off_p0, off_c1, off_x0, off_x1, off_sc, off_r1, off_r2, off_scmap, off_locref, off_slabs, total;
 };
 
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -250,6 +252,7 @@ Plan make_plan(const dgp_net* net, int B) {
     p.off_r1 = take(r1); p.off_r2 = take(r2);
     p.off_scmap = take((size_t)B * 4 * net->fh * net->fw * d.num_joints);
     p.off_locref = take((size_t)B * 4 * net->fh * net->fw * 2 * d.num_joints);
+    p.off_slabs = take((size_t)HEAD_KSPLIT_MAX * B * 4 * net->fh * net->fw * 2 * d.num_joints);
     p.total = o;
     return p;
 }
@@ -277,7 +280,7 @@ double conv_flops_of(const ConvLayer& l, int M, bool is_head) {
 
 int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, int W, int pad_t, int pad_l, int Ho, int Wo,
              const float* res, int res_s, int res_H, int res_W, bool relu, int out_mode, int dc_nj, float* out,
-             hipStream_t s) {
+             hipStream_t s, float* slabs = nullptr) {
     ConvArgs a{};
     a.in = in; a.wpk = l.d_w; a.scale = l.has_bn ? l.d_scale : nullptr; a.bias = l.d_bias; a.res = res; a.out = out;
     a.N = N; a.H = H; a.W = W; a.Cin = l.Cin; a.log2cin4 = ilog2(l.Cin / 4);
@@ -297,6 +300,21 @@ int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, in
         a.w_bytes = (unsigned)((size_t)l.nk * 8 * l.CoutP * 16);
     }
     ProfScope ps(net, s, "conv:" + l.scope, conv_flops_of(l, a.M, out_mode == 1));
+    const long long out_n = (long long)N * 4 * Ho * Wo * dc_nj;
+    if (out_mode == 1 && slabs && (out_n & 3) == 0) {
+        // the heads have a tiny N (4*nj channels) and a huge K (4 x 2048): split K so the grid fills the chip;
+        // slabs are summed in a fixed order (deterministic, unlike float atomics)
+        const int mtiles = (a.M + 127) / 128;
+        int ks = 1;
+        while (ks < HEAD_KSPLIT_MAX && mtiles * ks < 1024 && l.nk % (ks * 2) == 0) ks *= 2;
+        if (ks > 1) {
+            a.ksplit = ks; a.split_stride = out_n; a.out = slabs;
+            hipError_t e = launch_conv(a, pick_tile(a.M, a.CoutP, l.nk * BK), s);
+            if (e == hipSuccess) e = launch_reduce_slabs(slabs, out_n, out_n, ks, out, s);
+            if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("head conv (") + l.scope + "): " + hipGetErrorString(e));
+            return DGP_OK;
+        }
+    }
     hipError_t e = launch_conv(a, pick_tile(a.M, a.CoutP, l.nk * BK), s);
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("conv launch (") + l.scope + "): " + hipGetErrorString(e));
     return DGP_OK;
@@ -409,12 +427,13 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     if (features)
         HIP_TRY(hipMemcpyAsync(features, feat, (size_t)B * h * w * 2048 * sizeof(float), hipMemcpyDeviceToDevice, s));
     float* sm = scmap ? scmap : (float*)(ws + pl.off_scmap);
+    float* slabs = (float*)(ws + pl.off_slabs);
     rc = run_conv(net, net->layers[net->head_part], feat, B, h, w, 1, 1, h, w, nullptr, 0, 0, 0, false, 1, d.num_joints,
-                  sm, s);
+                  sm, s, slabs);
     if (rc) return rc;
     if (locref) {
         rc = run_conv(net, net->layers[net->head_locref], feat, B, h, w, 1, 1, h, w, nullptr, 0, 0, 0, false, 1,
-                      2 * d.num_joints, locref, s);
+                      2 * d.num_joints, locref, s, slabs);
         if (rc) return rc;
     }
     if (net->prof_on && net->prof_used < net->prof_slots && !net->prof_in_infer) ++net->prof_used;
