@@ -237,3 +237,94 @@ def plot_dgp(video_file, output_dir="", label_dir=None, proj_cfg_file=None, dgp_
     create_annotated_movie(video_file, labels["x"].T, labels["y"].T, mask_array=mask_array, filename=save_file,
                            dotsize=dotsize, colormap=colormap)
     return save_file
+
+
+def pairwisedistances(DataCombined, scorer1, scorer2, pcutoff=-1, bodyparts=None):
+    """Per-(image, bodypart) Euclidean px distance between two scorers (PET/evaluate.py:22-32)."""
+    mask = DataCombined[scorer2].xs("likelihood", level=1, axis=1) >= pcutoff
+    a, b = (DataCombined[scorer1], DataCombined[scorer2]) if bodyparts is None else \
+        (DataCombined[scorer1][bodyparts], DataCombined[scorer2][bodyparts])
+    sq = (a - b) ** 2
+    rmse = np.sqrt(sq.xs("x", level=1, axis=1) + sq.xs("y", level=1, axis=1))
+    return rmse, rmse[mask]
+
+
+def _read_collected_data(folder, scorer):
+    """CollectedData_<scorer>.h5 (key df_with_missing) when pytables is installed, else the .csv twin
+    (3 header rows: scorer / bodyparts / coords; index = image path)."""
+    import pandas as pd
+    base = join(folder, "CollectedData_" + scorer)
+    try:
+        return pd.read_hdf(base + ".h5", "df_with_missing")
+    except (ImportError, FileNotFoundError):
+        return pd.read_csv(base + ".csv", header=[0, 1, 2], index_col=0)
+
+
+def evaluate_dgp(proj_cfg_file, dgp_model_file, shuffle=1, loc_ref=None, loc_ref_calc="dlc"):
+    """Evaluate a model by RMSE (px) on the human-labeled train/test images (eval.py:656-813).
+
+    loc_ref=True + loc_ref_calc='dlc': DLC hard arg-max + location refinement (HIP `hard_argmax` kernel);
+    loc_ref=False: DGP soft-argmax (HIP `soft_argmax` kernel).  loc_ref_calc='dgp' (soft-argmax weighted locref,
+    eval.py:752-786) is not built.  Returns the RMSE DataFrame over all train/test data."""
+    import pickle
+    import pandas as pd
+    from PIL import Image
+    from ..config import get_train_config, GetTrainingSetFolder
+    from .predict import pose_from_argmax
+    from .. import engine
+    import torch
+
+    with open(proj_cfg_file, "r") as stream:
+        proj_config = yaml.safe_load(stream)
+    proj_config["video_path"] = None
+    dlc_cfg = get_train_config(proj_config, shuffle=shuffle)
+    loc_ref = dlc_cfg.location_refinement if loc_ref is None else loc_ref
+    if not loc_ref:
+        dlc_cfg.location_refinement = False
+    if loc_ref and loc_ref_calc.lower() != "dlc":
+        raise NotImplementedError("loc_ref_calc='dgp' is not built; use 'dlc'")
+    try:
+        dlc_cfg.net_type = "resnet_50"
+        sess, mu_n, softmax_tensor, scmap_t, locref_t, inputs = setup_dgp_eval_graph(dlc_cfg, dgp_model_file, loc_ref=loc_ref)
+    except KeyError:
+        dlc_cfg.net_type = "resnet_101"
+        sess, mu_n, softmax_tensor, scmap_t, locref_t, inputs = setup_dgp_eval_graph(dlc_cfg, dgp_model_file, loc_ref=loc_ref)
+
+    tsfolder = GetTrainingSetFolder(proj_config)
+    scorer_dgp = "DGP"
+    Data = _read_collected_data(join(proj_config["project_path"], str(tsfolder)), proj_config["scorer"])
+    bodyparts = list(proj_config["bodyparts"])
+    meta = join(proj_config["project_path"], str(tsfolder), "Documentation_data-" + proj_config["Task"] + "_" +
+                str(int(proj_config["TrainingFraction"][0] * 100)) + "shuffle" + str(shuffle) + ".pickle")
+    with open(meta, "rb") as f:
+        _, trainIndices, testIndices, _ = pickle.load(f)
+
+    nj = len(dlc_cfg["all_joints_names"])
+    pred = np.ones((len(Data.index), 3 * nj))
+    for i, imagename in enumerate(Data.index):
+        with Image.open(join(proj_config["project_path"], imagename)) as im:
+            image = np.asarray(im.convert("RGB"))
+        if loc_ref:
+            net = sess.net_for(image.shape[0], image.shape[1])
+            fr = torch.from_numpy(np.ascontiguousarray(image[None])).cuda(sess.device)
+            scm, loc = net.forward(fr, want_locref=True)
+            idx, prob, offs = engine.hard_argmax(scm, loc)
+            pose = pose_from_argmax(idx[0].cpu().numpy(), prob[0].cpu().numpy(), offs[0].cpu().numpy(), dlc_cfg.stride,
+                                    dlc_cfg.locref_stdev)
+        else:
+            mu = sess.run(mu_n, feed_dict={inputs: image[None]})
+            p = mu * dlc_cfg.stride + 0.5 * dlc_cfg.stride
+            pose = np.hstack([p[0, :, ::-1], np.ones((nj, 1))])
+        pred[i, :] = pose.flatten()
+    sess.close()
+
+    index = pd.MultiIndex.from_product([[scorer_dgp], dlc_cfg["all_joints_names"], ["x", "y", "likelihood"]],
+                                       names=["scorer", "bodyparts", "coords"])
+    DataMachine = pd.DataFrame(pred, columns=index, index=Data.index.values)
+    DataCombined = pd.concat([Data.T, DataMachine.T], axis=0).T
+    RMSE, _ = pairwisedistances(DataCombined, proj_config["scorer"], scorer_dgp, proj_config["pcutoff"], bodyparts)
+    testerror = np.nanmean(RMSE.iloc[testIndices].values.flatten())
+    trainerror = np.nanmean(RMSE.iloc[trainIndices].values.flatten())
+    print("Train error:", np.round(trainerror, 2), " pixels")
+    print("Test error:", np.round(testerror, 2), " pixels")
+    return RMSE

@@ -44,6 +44,21 @@ def make_project(root, nj=3, n_frames=40, hw=(64, 96), labeled=(3, 11, 19, 30), 
         jj[0, 0] = np.array(joints, dtype=np.int64)
         items[0, k]["joints"] = jj
     sio.savemat(os.path.join(proj, mat_rel), {"dataset": items})
+    # human labels in DLC's CollectedData csv layout + train/test split pickle + the labeled frames as PNGs
+    import pickle
+    from PIL import Image
+    os.makedirs(os.path.join(proj, "labeled-data", "clip"))
+    rows = ["scorer," + ",".join(["me"] * (2 * nj)), "bodyparts," + ",".join(p for p in parts for _ in range(2)),
+            "coords," + ",".join(["x", "y"] * nj)]
+    for k, fi in enumerate(labeled):
+        Image.fromarray(frames[fi]).save(os.path.join(proj, "labeled-data", "clip", "img%03d.png" % fi))
+        xy = {int(r[0]): (r[1], r[2]) for r in items[0, k]["joints"][0, 0]}
+        rows.append("labeled-data/clip/img%03d.png," % fi + ",".join(
+            ("%d,%d" % xy[j]) if j in xy else "," for j in range(nj)))
+    with open(os.path.join(proj, tsdir, "CollectedData_me.csv"), "w") as f:
+        f.write("\n".join(rows) + "\n")
+    with open(os.path.join(proj, tsdir, "Documentation_data-Demo_95shuffle1.pickle"), "wb") as f:
+        pickle.dump([{}, np.arange(len(labeled) - 1), np.array([len(labeled) - 1]), 0.95], f)
     wts = make_weights(depth, nj, True, seed=seed, head_std=0.05)
     weights_io.save_weights(os.path.join(train, "snapshot-step0-final--0"), wts)
     return proj, frames, wts

@@ -188,3 +188,9 @@ def test_fit_dgp_drivers_end_to_end(lib_built, tmp_path):
                            shuffle=1, batch_size=8)
     assert labels["x"].shape == (40, 3) and np.isfinite(labels["x"]).all()
     assert os.path.isfile(os.path.join(proj, "videos_pred", "clip_labeled.csv"))
+    # evaluate_dgp (eval.py:656): RMSE table over the labeled images, both read-out paths
+    from deepgraphpose_amd.models.eval import evaluate_dgp
+    for lr in (True, False):
+        rmse = evaluate_dgp(str(cfg_path), snap2, shuffle=1, loc_ref=lr)
+        assert rmse.shape == (4, 3) and np.isfinite(rmse.values[~np.isnan(rmse.values)]).all()
+        assert np.isnan(rmse.values).sum() == 1          # the one unlabeled joint
