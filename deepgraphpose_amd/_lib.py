@@ -25,7 +25,8 @@ class DgpLossDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("nt", "H", "W", "nj", "nl", "n_visible", "n_hidden", "gm2", "gm3",
                                           "gauss_len", "huber")] + \
                [(n, C.c_float) for n in ("gamma", "lengthscale", "stride", "wn_visible", "wn_hidden",
-                                         "locref_loss_weight", "n_frames_total", "n_visible_frames_total")]
+                                         "locref_loss_weight", "n_frames_total", "n_visible_frames_total")] + \
+               [(n, C.c_int32) for n in ("use_wt", "Hin", "Win")] + [("wt_max", C.c_float)]
 
 
 class DgpConvDesc(C.Structure):
@@ -53,7 +54,7 @@ SYMBOLS = {
     "dgp_net_profile_end": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "dgp_net_profile_launch": (C.c_int, [_vp, _i32, C.c_char_p, _i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dgp_loss_scratch_bytes": (C.c_int, [C.POINTER(DgpLossDesc), C.POINTER(_sz)]),
-    "dgp_loss_fwd_bwd": (C.c_int, [C.POINTER(DgpLossDesc)] + [_vp] * 16 + [_sz, _vp]),
+    "dgp_loss_fwd_bwd": (C.c_int, [C.POINTER(DgpLossDesc)] + [_vp] * 18 + [_sz, _vp]),
     "dgp_trainer_create": (C.c_int, [_vp, C.POINTER(_vp)]),
     "dgp_trainer_destroy": (None, [_vp]),
     "dgp_trainer_num_tensors": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

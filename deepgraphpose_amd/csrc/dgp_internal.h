@@ -64,6 +64,10 @@ struct LossArgs {
     int nt, H, W, nj, nl, n_v, n_h;
     int gm2, gm3, gauss_len, huber;
     float gamma, lengthscale, stride, hidden_scale, clique_scale, locref_weight;
+    // temporal clique (wt > 0)
+    const float* vector_field; const float* wt_batch; float* wt_w;
+    int use_wt, Hin, Win;
+    float wt_max, temporal_scale;
 };
 hipError_t launch_loss(const LossArgs& a, hipStream_t s);
 

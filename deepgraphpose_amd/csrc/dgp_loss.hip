@@ -11,7 +11,12 @@
 // targets (Gaussian target + clique -> mu -> softmax).  Maps are tiny (<= 14 400 px), so every kernel is one
 // workgroup per marker map with LDS-resident probabilities and fp64 wave reductions.
 //
-// The temporal clique (fitdgp.py:1079-1124) is off by default in the reference (wt = 0) and not built yet.
+//   temporal clique ("temporal graph smoothness", wt > 0)                     :1079-1124
+// The temporal term follows the reference's specification of intent (its TF code passes float crop sizes to
+// tf.image.crop_and_resize and cannot build): frame-to-frame displacement of every marker,
+// weighted by min(1/mean-flow, 1)^3 of the optical-flow magnitude inside the +-10 px box of the two positions
+// (bilinear crop_and_resize to the full frame, then mean), Frobenius norm.  The flow weight is treated as a
+// constant in the backward pass (no gradient through the crop boxes).
 #include "dgp_internal.h"
 
 namespace dgp {
@@ -106,6 +111,81 @@ __global__ __launch_bounds__(256) void loss_assemble_clique(LossArgs a) {
     }
     loss = block_sum(loss, red);
     if (threadIdx.x == 0) a.losses[3] = (float)loss;     // ws_loss
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1b: temporal-clique flow weights, one workgroup per (frame pair, joint).
+//   box = bbox of the two marker positions (px) +- 10, clipped to the frame; tf.image.crop_and_resize
+//   (bilinear, extrapolation 0) of the flow-magnitude field to [Hin, Win]; mean; w = min(min(1/(m+1e-10),1)^3,1)
+//   * wt_batch[t] / H / W                                                          fitdgp.py:1085-1118
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void loss_temporal_weights(LossArgs a) {
+    __shared__ double red[8];
+    const int e = blockIdx.x, n = e / a.nj, j = e - n * a.nj;
+    const float* vf = a.vector_field + (long long)n * a.Hin * a.Win;
+    const float r0 = a.t_all[2 * (n * a.nj + j)] * a.stride + 0.5f * a.stride;
+    const float c0 = a.t_all[2 * (n * a.nj + j) + 1] * a.stride + 0.5f * a.stride;
+    const float r1 = a.t_all[2 * ((n + 1) * a.nj + j)] * a.stride + 0.5f * a.stride;
+    const float c1 = a.t_all[2 * ((n + 1) * a.nj + j) + 1] * a.stride + 0.5f * a.stride;
+    const float win = 10.f, Hf = (float)a.Hin, Wf = (float)a.Win;
+    const float y1 = fmaxf(0.f, fminf(r0, r1) - win) / Hf, y2 = fminf(Hf, fmaxf(r0, r1) + win) / Hf;
+    const float x1 = fmaxf(0.f, fminf(c0, c1) - win) / Wf, x2 = fminf(Wf, fmaxf(c0, c1) + win) / Wf;
+    const float hs = a.Hin > 1 ? (y2 - y1) * (Hf - 1.f) / (Hf - 1.f) : 0.f;      // crop_h == Hin
+    const float wsx = a.Win > 1 ? (x2 - x1) * (Wf - 1.f) / (Wf - 1.f) : 0.f;
+    double acc = 0.0;
+    const int total = a.Hin * a.Win;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int iy = i / a.Win, ix = i - iy * a.Win;
+        const float in_y = a.Hin > 1 ? y1 * (Hf - 1.f) + iy * hs : 0.5f * (y1 + y2) * (Hf - 1.f);
+        const float in_x = a.Win > 1 ? x1 * (Wf - 1.f) + ix * wsx : 0.5f * (x1 + x2) * (Wf - 1.f);
+        if (in_y < 0.f || in_y > Hf - 1.f || in_x < 0.f || in_x > Wf - 1.f) continue;     // extrapolation_value = 0
+        const int ty = (int)floorf(in_y), by = (int)ceilf(in_y), lx = (int)floorf(in_x), rx = (int)ceilf(in_x);
+        const float fy = in_y - ty, fx = in_x - lx;
+        const float top = vf[ty * a.Win + lx] + (vf[ty * a.Win + rx] - vf[ty * a.Win + lx]) * fx;
+        const float bot = vf[by * a.Win + lx] + (vf[by * a.Win + rx] - vf[by * a.Win + lx]) * fx;
+        acc += (double)(top + (bot - top) * fy);
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+        const float m = (float)(acc / (double)total);
+        float inv = fminf(1.f / (m + 1e-10f), 1.f);
+        inv = fminf(expf(logf(inv) * 3.f), 1.f);
+        a.wt_w[e] = inv * a.wt_batch[n] / (float)a.H / (float)a.W;
+    }
+}
+
+// K1c: temporal clique loss + d/dt (single workgroup): || (relu(D - wt_max) + wt_max) * w ||_F * scale
+__global__ __launch_bounds__(256) void loss_temporal(LossArgs a) {
+    __shared__ double red[8];
+    const int ne = (a.nt - 1) * a.nj;
+    double ss = 0.0;
+    for (int e = threadIdx.x; e < ne; e += 256) {
+        const int n = e / a.nj, j = e - n * a.nj;
+        const float dr = (a.t_all[2 * ((n + 1) * a.nj + j)] - a.t_all[2 * (n * a.nj + j)]) * a.stride;
+        const float dc = (a.t_all[2 * ((n + 1) * a.nj + j) + 1] - a.t_all[2 * (n * a.nj + j) + 1]) * a.stride;
+        const float D = sqrtf(dr * dr + dc * dc);
+        const float v = (fmaxf(D - a.wt_max, 0.f) + a.wt_max) * a.wt_w[e];
+        ss += (double)v * v;
+    }
+    ss = block_sum(ss, red);
+    const float F = (float)sqrt(ss);
+    const float C = a.temporal_scale;       // n_vis_tot / n_vis_batch / (n_vis_tot + n_hid_tot) / wn_visible
+    if (threadIdx.x == 0) a.losses[6] = F * C;
+    if (F <= 0.f) return;
+    for (int e = threadIdx.x; e < ne; e += 256) {
+        const int n = e / a.nj, j = e - n * a.nj;
+        const float dr = (a.t_all[2 * ((n + 1) * a.nj + j)] - a.t_all[2 * (n * a.nj + j)]) * a.stride;
+        const float dc = (a.t_all[2 * ((n + 1) * a.nj + j) + 1] - a.t_all[2 * (n * a.nj + j) + 1]) * a.stride;
+        const float D = sqrtf(dr * dr + dc * dc);
+        if (!(D > a.wt_max) || D <= 0.f) continue;
+        const float w = a.wt_w[e];
+        const float v = D * w;
+        const float g = C * v / F * w / D * a.stride;        // dL/dD * dD/d(dr) = g * dr
+        atomicAdd(&a.dLdt[2 * ((n + 1) * a.nj + j)], g * dr);
+        atomicAdd(&a.dLdt[2 * ((n + 1) * a.nj + j) + 1], g * dc);
+        atomicAdd(&a.dLdt[2 * (n * a.nj + j)], -g * dr);
+        atomicAdd(&a.dLdt[2 * (n * a.nj + j) + 1], -g * dc);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -354,7 +434,8 @@ __global__ __launch_bounds__(256) void loss_locref_backward(LossArgs a) {
 
 __global__ void loss_finalize(LossArgs a) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        a.losses[4] = a.losses[0] + a.losses[1] + a.losses[2] + (a.nl > 0 ? a.losses[3] : 0.f);   // total_loss
+        a.losses[4] = a.losses[0] + a.losses[1] + a.losses[2] + (a.nl > 0 ? a.losses[3] : 0.f) +
+                      (a.use_wt ? a.losses[6] : 0.f);                                           // total_loss
         a.losses[5] = a.losses[0] + a.losses[2];                                                 // total_loss_visible
     }
 }
@@ -364,6 +445,10 @@ hipError_t launch_loss(const LossArgs& a, hipStream_t s) {
     hipError_t e = hipMemsetAsync(a.dlocref, 0, (size_t)a.nt * a.H * a.W * 2 * a.nj * sizeof(float), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(loss_assemble_clique, dim3(1), dim3(256), 0, s, a);
+    if (a.use_wt && a.nt > 1) {
+        hipLaunchKernelGGL(loss_temporal_weights, dim3((a.nt - 1) * a.nj), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(loss_temporal, dim3(1), dim3(256), 0, s, a);
+    }
     hipLaunchKernelGGL(loss_marker_stats, dim3(nm), dim3(256), 0, s, a);
     hipLaunchKernelGGL(loss_normalisers, dim3(1), dim3(256), 0, s, a);
     const size_t smem = (size_t)2 * a.H * a.W * sizeof(float);

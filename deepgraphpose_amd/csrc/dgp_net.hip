@@ -529,6 +529,7 @@ static size_t loss_scratch_layout(const dgp_loss_desc* d, size_t off[8]) {
     off[4] = take(nm * 4);        // kind
     off[5] = take(nm * 4);        // stats
     off[6] = take(8 * 4);         // norm
+    off[7] = take(nm * 4);        // temporal weights
     return o;
 }
 
@@ -542,8 +543,8 @@ int dgp_loss_scratch_bytes(const dgp_loss_desc* d, size_t* out_bytes) {
 int dgp_loss_fwd_bwd(const dgp_loss_desc* d, const float* pred, const float* locref_pred, const float* targets,
                      const float* locref_map, const float* locref_mask, const int32_t* visible_marker,
                      const int32_t* hidden_marker, const int32_t* visible_in_targets, const float* S0, const float* ws,
-                     const float* ws_max, float* dpred, float* dlocref, float* mu, float* losses, void* scratch,
-                     size_t scratch_bytes, void* stream) {
+                     const float* ws_max, const float* vector_field, const float* wt_batch, float* dpred, float* dlocref,
+                     float* mu, float* losses, void* scratch, size_t scratch_bytes, void* stream) {
     if (!d || !pred || !locref_pred || !dpred || !dlocref || !mu || !losses || !scratch)
         return fail(DGP_ERR_INVALID, "dgp_loss_fwd_bwd: null argument");
     if (d->nt < 1 || d->H < 1 || d->W < 1 || d->nj < 1 || d->nl < 0 || d->n_visible < 0 || d->n_hidden < 0)
@@ -573,6 +574,12 @@ int dgp_loss_fwd_bwd(const dgp_loss_desc* d, const float* pred, const float* loc
     const double n_vis_tot = d->n_visible_frames_total, n_hid_tot = d->n_frames_total - d->n_visible_frames_total;
     const double n_h = d->n_hidden, n_v_eff = d->n_visible > 0 ? d->n_visible : d->n_hidden;     // fitdgp.py:983-984
     a.hidden_scale = (n_h > 0 && n_hid_tot > 0) ? (float)(n_vis_tot / n_hid_tot * n_h / n_v_eff * d->wn_hidden / d->wn_visible) : 0.f;
+    a.use_wt = (d->use_wt && d->nt > 1) ? 1 : 0;
+    if (a.use_wt && (!vector_field || !wt_batch || d->Hin < 1 || d->Win < 1))
+        return fail(DGP_ERR_INVALID, "dgp_loss_fwd_bwd: use_wt needs vector_field [nt-1,Hin,Win] and wt_batch [nt-1]");
+    a.vector_field = vector_field; a.wt_batch = wt_batch; a.wt_w = (float*)(sc + off[7]); a.Hin = d->Hin; a.Win = d->Win;
+    a.wt_max = d->wt_max;
+    a.temporal_scale = n_v_eff > 0 ? (float)(n_vis_tot / n_v_eff / (n_vis_tot + n_hid_tot) / d->wn_visible) : 0.f;
     a.clique_scale = n_v_eff > 0 ? (float)(1.0 / ((double)d->H * d->W) * n_vis_tot / n_v_eff / (n_vis_tot + n_hid_tot) / d->wn_visible) : 0.f;
     e = launch_loss(a, s);
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("loss kernels: ") + hipGetErrorString(e));

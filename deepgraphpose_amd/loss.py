@@ -15,7 +15,7 @@ from . import _lib
 from .engine import _ptr, _stream, _need_cuda
 
 LOSS_NAMES = ("visible_loss_pred", "hidden_loss_pred", "visible_loss_locref", "ws_loss", "total_loss",
-              "total_loss_visible")
+              "total_loss_visible", "wt_loss")
 
 
 @dataclass
@@ -65,9 +65,18 @@ def dgp_loss_fwd_bwd(pred: torch.Tensor, locref_pred: torch.Tensor, batch: dict,
     S0 = np.asarray(S0, dtype=np.float32).reshape(-1, nj)
     nl = S0.shape[0]
     S0d, wsd, wmd = _dev_f32(S0, dev), _dev_f32(ws, dev), _dev_f32(ws_max, dev)
+    use_wt = hyper.wt > 0 and nt > 1 and batch.get("vector_field") is not None
+    vf = wtb = None
+    hin = win = 0
+    if use_wt:          # temporal clique: flow magnitude [nt-1,Hin,Win] (learn_wt) and wt * batch_mask (fitdgp.py:774,905)
+        vf = _dev_f32(batch["vector_field"], dev)
+        hin, win = int(vf.shape[1]), int(vf.shape[2])
+        mask = np.asarray(batch.get("wt_batch_mask", np.ones(nt - 1)), dtype=np.float32)
+        wtb = _dev_f32(np.ones(nt - 1, dtype=np.float32) * hyper.wt * mask, dev)
     d = _lib.DgpLossDesc(nt, H, W, nj, nl, vm.numel(), hm.numel(), hyper.gm2, hyper.gm3, hyper.gauss_len,
                          int(hyper.locref_huber_loss), hyper.gamma, hyper.lengthscale, hyper.stride, hyper.wn_visible,
-                         hyper.wn_hidden, hyper.locref_loss_weight, float(n_frames_total), float(n_visible_frames_total))
+                         hyper.wn_hidden, hyper.locref_loss_weight, float(n_frames_total), float(n_visible_frames_total),
+                         int(use_wt), hin, win, float(hyper.wt_max))
     nb = C.c_size_t()
     _lib.check(lib.dgp_loss_scratch_bytes(C.byref(d), C.byref(nb)), "dgp_loss_scratch_bytes")
     scratch = torch.empty(nb.value, dtype=torch.uint8, device=dev)
@@ -75,7 +84,7 @@ def dgp_loss_fwd_bwd(pred: torch.Tensor, locref_pred: torch.Tensor, batch: dict,
     mu = torch.empty((nt, nj, 2), dtype=torch.float32, device=dev)
     losses = torch.zeros(8, dtype=torch.float32, device=dev)
     _lib.check(lib.dgp_loss_fwd_bwd(C.byref(d), _ptr(pred), _ptr(locref_pred), _ptr(targets), _ptr(lmap), _ptr(lmask),
-                                    _ptr(vm), _ptr(hm), _ptr(vt), _ptr(S0d), _ptr(wsd), _ptr(wmd), _ptr(dpred),
+                                    _ptr(vm), _ptr(hm), _ptr(vt), _ptr(S0d), _ptr(wsd), _ptr(wmd), _ptr(vf), _ptr(wtb), _ptr(dpred),
                                     _ptr(dloc), _ptr(mu), _ptr(losses), _ptr(scratch), scratch.numel(), _stream(dev)),
                "dgp_loss_fwd_bwd")
     lv = losses.cpu().numpy()

@@ -8,8 +8,8 @@
 
 One iteration = `Trainer.step` (deepgraphpose_amd/train.py) = the reference's sess.run([loss, train_op]).
 Snapshots are `<train dir>/snapshot-step{k}-{it}.npz` and `snapshot-step{k}-final--0.npz` (TF variable names).
-Host-side third-party hooks that are absent here are skipped loudly: imgaug augmentation (`aug`) and the cv2
-Farneback optical flow of the temporal clique (`wt > 0`, reference code path is itself broken -- SURVEY section 5).
+Host-side third-party hooks: imgaug augmentation (`aug`, skipped loudly when imgaug is missing) and the cv2 Farneback
+optical flow feeding the temporal clique (`wt > 0`; raises ImportError without OpenCV -- the loss term itself is a HIP kernel).
 """
 from __future__ import annotations
 
@@ -75,8 +75,6 @@ def dgp_loss(data_batcher, dgp_cfg):
                      locref_huber_loss=dgp_cfg.locref_huber_loss)
     if hyper.gm2 not in (0, 1, 2) or hyper.gm3 not in (0, 3):
         raise Exception("Not implemented")                        # fitdgp.py:1019, :1036
-    if hyper.wt > 0:
-        raise NotImplementedError("temporal clique (wt > 0): needs cv2 Farneback optical flow and is off by default")
     S0 = np.asarray(data_batcher.S0, dtype=np.float64).reshape(-1, data_batcher.nj)
     ws, ws_max = _limb_statistics([d.labels for d in data_batcher.datasets], S0, dgp_cfg.stride, dgp_cfg.ws,
                                   dgp_cfg.ws_max)
@@ -258,6 +256,9 @@ def fit_dgp(snapshot, dlcpath, batch_size=10, shuffle=1, step=2, saveiters=1000,
         lmap, lmask = _locref_targets(joint_loc, len(all_frame), vis_within, d.nx_out, d.ny_out, nj, dgp_cfg)
         batch = dict(targets=joint_loc, locref_map=lmap, locref_mask=lmask, visible_marker=vm, hidden_marker=hm,
                      visible_marker_in_targets=vt, wt_batch_mask=wt_mask)
+        if dgp_cfg.wt > 0:                                            # temporal clique: flow field from the host hook
+            from .fitdgp_util import learn_wt
+            batch["vector_field"] = learn_wt(images)
         t0 = time.time()
         loss_eval = loss_fn(trainer, torch.from_numpy(images).to(trainer.device), batch)
         if it % displayiters == 0 and it > 0:

@@ -107,6 +107,23 @@ def gen_batch(visible_frame_total, hidden_frame_total, all_frame_total, dgp_cfg,
     return random.sample(out, len(out))
 
 
+def learn_wt(all_data_batch):
+    """Optical-flow magnitude fields between consecutive frames of a batch, [nt-1, H, W] (fitdgp_util.py:454-467).
+    The flow itself is third-party host code (cv2 Farneback, untouched); without OpenCV this raises."""
+    try:
+        import cv2
+    except ImportError as e:
+        raise ImportError("the temporal clique (wt > 0) needs OpenCV's Farneback optical flow on the host "
+                          "(cv2 is not installed); run with wt=0 or pass batch['vector_field'] yourself") from e
+    fields = []
+    for ff in range(all_data_batch.shape[0] - 1):
+        prvs = cv2.cvtColor(all_data_batch[ff].astype(np.uint8), cv2.COLOR_BGR2GRAY)
+        nxt = cv2.cvtColor(all_data_batch[ff + 1].astype(np.uint8), cv2.COLOR_BGR2GRAY)
+        flow = cv2.calcOpticalFlowFarneback(prvs, nxt, None, 0.5, 3, 15, 3, 5, 1.2, 0)
+        fields.append(np.abs(flow).sum(2))
+    return np.array(fields)
+
+
 # --------------------------------------------------------------------------------------- layout helper
 def get_snapshot_path(snapshot, dlcpath, shuffle=1, trainingsetindex=0):
     """-> (snapshot_path, config_path); fitdgp_util.py:205-229."""

@@ -125,6 +125,8 @@ typedef struct dgp_loss_desc {
     float   gamma, lengthscale, stride;   /* dgp_cfg.gamma, .lengthscale, .stride (fitdgp.py:645-647) */
     float   wn_visible, wn_hidden, locref_loss_weight;
     float   n_frames_total, n_visible_frames_total;   /* data_batcher totals (fitdgp.py:869-873) */
+    int32_t use_wt, Hin, Win;             /* temporal clique (dgp_cfg.wt > 0): flow field size [nt-1, Hin, Win] */
+    float   wt_max;                       /* dgp_cfg.wt_max */
 } dgp_loss_desc;
 
 int  dgp_loss_scratch_bytes(const dgp_loss_desc* d, size_t* out_bytes);
@@ -132,12 +134,14 @@ int  dgp_loss_scratch_bytes(const dgp_loss_desc* d, size_t* out_bytes);
  * targets [n_vis_frames*nj, 2] labels in scoremap (row, col) units with NaN already replaced by 0,
  * visible_in_targets indexes rows of `targets`; S0 [nl,nj], ws / ws_max [nl].
  * Outputs: dpred, dlocref (same shapes as the predictions), mu [nt*nj,2],
- * losses[8] = {visible_loss_pred, hidden_loss_pred, visible_loss_locref, ws_loss, total_loss, total_loss_visible,0,0}. */
+ * losses[8] = {visible_loss_pred, hidden_loss_pred, visible_loss_locref, ws_loss, total_loss, total_loss_visible,
+ *             wt_loss, 0}. */
 int  dgp_loss_fwd_bwd(const dgp_loss_desc* d, const float* pred, const float* locref_pred, const float* targets,
                       const float* locref_map, const float* locref_mask, const int32_t* visible_marker,
                       const int32_t* hidden_marker, const int32_t* visible_in_targets, const float* S0,
-                      const float* ws, const float* ws_max, float* dpred, float* dlocref, float* mu,
-                      float* losses, void* scratch, size_t scratch_bytes, void* stream);
+                      const float* ws, const float* ws_max, const float* vector_field /* [nt-1,Hin,Win] or NULL */,
+                      const float* wt_batch /* [nt-1] = wt * batch_mask, or NULL */, float* dpred, float* dlocref,
+                      float* mu, float* losses, void* scratch, size_t scratch_bytes, void* stream);
 
 /* ---- training step (config 4): replaces sess.run([loss, train_op]) of fit_dgp / fit_dgp_labeledonly
  * (DGP/models/fitdgp.py:708-713,818; 416-418,501-505).  The trainer owns the master parameters (flat fp32 buffer

@@ -226,10 +226,61 @@ def dgp_loss(pred, locref_pred, batch: dict, cfg: dict):
         ws = torch.as_tensor(np.asarray(cfg["ws"])).to(dt)[:, None]
         loss["ws_loss"] = (dist_th * ws).sum() / H / W * n_vis_total / n_v_eff / (n_vis_total + n_hid_total) / cfg["wn_visible"]
         total = total + loss["ws_loss"]
+    if cfg.get("wt", 0) > 0 and nt > 1 and batch.get("vector_field") is not None:        # :1079-1124
+        P_t = t3 * cfg["stride"] + 0.5 * cfg["stride"]
+        dif = torch.sqrt(((P_t[:-1] - P_t[1:]) ** 2).sum(2))                             # [nt-1, nj]
+        vf = np.asarray(batch["vector_field"], dtype=np.float64)
+        mask = np.asarray(batch.get("wt_batch_mask", np.ones(nt - 1)), dtype=np.float64)
+        wt_batch = np.ones(nt - 1) * cfg["wt"] * mask
+        w = temporal_flow_weights(P_t.detach().numpy().astype(np.float64), vf, wt_batch, H, W)   # constant in backward
+        v = (F.relu(dif - cfg["wt_max"]) + cfg["wt_max"]) * torch.as_tensor(w).to(dt)
+        loss["wt_loss"] = torch.sqrt((v ** 2).sum()) * n_vis_total / n_v_eff / (n_vis_total + n_hid_total) / cfg["wn_visible"]
+        total = total + loss["wt_loss"]
     loss["total_loss"] = total
     loss["total_loss_visible"] = loss["visible_loss_pred"] + loss["visible_loss_locref"]
     loss["_mu"] = mu
     return loss
+
+
+def crop_and_resize_mean(img: np.ndarray, box, crop_hw):
+    """mean of tf.image.crop_and_resize(img[None,...,None], [box], [0], crop_hw) (bilinear, extrapolation 0).
+    box = (y1, x1, y2, x2) normalised as TF defines it (y * (H-1) is the source row)."""
+    Himg, Wimg = img.shape
+    ch, cw = crop_hw
+    y1, x1, y2, x2 = box
+    hs = (y2 - y1) * (Himg - 1) / (ch - 1) if ch > 1 else 0.0
+    ws_ = (x2 - x1) * (Wimg - 1) / (cw - 1) if cw > 1 else 0.0
+    iy = y1 * (Himg - 1) + np.arange(ch) * hs if ch > 1 else np.array([0.5 * (y1 + y2) * (Himg - 1)])
+    ix = x1 * (Wimg - 1) + np.arange(cw) * ws_ if cw > 1 else np.array([0.5 * (x1 + x2) * (Wimg - 1)])
+    vy = (iy >= 0) & (iy <= Himg - 1)
+    vx = (ix >= 0) & (ix <= Wimg - 1)
+    iyc, ixc = np.clip(iy, 0, Himg - 1), np.clip(ix, 0, Wimg - 1)
+    ty, by = np.floor(iyc).astype(int), np.ceil(iyc).astype(int)
+    lx, rx = np.floor(ixc).astype(int), np.ceil(ixc).astype(int)
+    fy, fx = (iyc - ty)[:, None], (ixc - lx)[None, :]
+    top = img[ty][:, lx] + (img[ty][:, rx] - img[ty][:, lx]) * fx
+    bot = img[by][:, lx] + (img[by][:, rx] - img[by][:, lx]) * fx
+    out = (top + (bot - top) * fy) * (vy[:, None] & vx[None, :])
+    return out.sum() / (ch * cw)
+
+
+def temporal_flow_weights(P_t: np.ndarray, vector_field: np.ndarray, wt_batch: np.ndarray, H: int, W: int, window=10.0):
+    """fitdgp.py:1085-1118: per (frame pair, joint) weight min(min(1/(mean flow + 1e-10), 1)^3, 1) * wt / H / W, the
+    mean flow taken over the +-10 px box of the two marker positions resampled to the full frame."""
+    ntm1, nj = P_t.shape[0] - 1, P_t.shape[1]
+    Hin, Win = vector_field.shape[1:]
+    w = np.zeros((ntm1, nj))
+    for t in range(ntm1):
+        for j in range(nj):
+            r0, c0 = P_t[t, j]
+            r1, c1 = P_t[t + 1, j]
+            box = (max(0.0, min(r0, r1) - window) / Hin, max(0.0, min(c0, c1) - window) / Win,
+                   min(float(Hin), max(r0, r1) + window) / Hin, min(float(Win), max(c0, c1) + window) / Win)
+            m = crop_and_resize_mean(vector_field[t], box, (Hin, Win))
+            inv = min(1.0 / (m + 1e-10), 1.0)
+            inv = min(np.exp(np.log(inv) * 3), 1.0)
+            w[t, j] = inv * wt_batch[t] / H / W
+    return w
 
 
 # ------------------------------------------------------------------ optimiser (B9)

@@ -194,3 +194,40 @@ def test_fit_dgp_drivers_end_to_end(lib_built, tmp_path):
         rmse = evaluate_dgp(str(cfg_path), snap2, shuffle=1, loc_ref=lr)
         assert rmse.shape == (4, 3) and np.isfinite(rmse.values[~np.isnan(rmse.values)]).all()
         assert np.isnan(rmse.values).sum() == 1          # the one unlabeled joint
+
+
+def test_temporal_clique_matches_oracle(lib_built):
+    """B8 (wt > 0): temporal graph-smoothness term on top of the other terms, flow-weighted, vs the autograd oracle."""
+    from deepgraphpose_amd.loss import dgp_loss_fwd_bwd, DGPHyper
+    from oracle import dgp_train_oracle as T
+    nt, H, W, nj, nvf = 6, 12, 16, 3, 2
+    rng = np.random.default_rng(42)
+    batch, S0 = _make_loss_case(rng, nt, H, W, nj, nvf, 0.0, 2)
+    Hin, Win = 8 * H, 8 * W
+    yy, xx = np.mgrid[0:Hin, 0:Win]
+    vf = np.stack([np.abs(np.sin(xx / 9.0 + t) * np.cos(yy / 7.0)) * rng.uniform(0.2, 3.0) for t in range(nt - 1)]).astype(np.float32)
+    batch["vector_field"] = vf
+    batch["wt_batch_mask"] = np.array([1, 1, 0, 1, 1], dtype=np.float32)
+    pred = (rng.standard_normal((nt, H, W, nj)) * 2).astype(np.float32)
+    for n in range(nt):
+        for j in range(nj):
+            cy, cx = rng.uniform(1, H - 2), rng.uniform(1, W - 2)
+            pred[n, :, :, j] += 7 * np.exp(-((np.mgrid[0:H, 0:W][0] - cy) ** 2 + (np.mgrid[0:H, 0:W][1] - cx) ** 2) / 4.0)
+    loc = rng.standard_normal((nt, H, W, 2 * nj)).astype(np.float32)
+    for wt_max in (0.0, 6.0):
+        hy = DGPHyper(gm2=1, gm3=3, wt=50.0, wt_max=wt_max)
+        ws, ws_max = rng.uniform(5, 20, 2), rng.uniform(10, 40, 2)
+        cfg = dict(nj=nj, S0=S0, ws=ws, ws_max=ws_max, stride=8.0, gamma=1.0, gauss_len=1, lengthscale=1.0, gm2=1, gm3=3,
+                   wn_visible=5.0, wn_hidden=3.0, locref_loss_weight=0.05, locref_huber_loss=True, n_frames_total=500.0,
+                   n_visible_frames_total=37.0, wt=50.0, wt_max=wt_max)
+        pt = torch.tensor(pred, dtype=torch.float64, requires_grad=True)
+        lt = torch.tensor(loc, dtype=torch.float64, requires_grad=True)
+        L = T.dgp_loss(pt, lt, batch, cfg)
+        L["total_loss"].backward()
+        losses, dpred, dloc, mu = dgp_loss_fwd_bwd(torch.from_numpy(pred).cuda(), torch.from_numpy(loc).cuda(), batch, hy, S0, ws,
+                                                   ws_max, 500.0, 37.0)
+        assert float(L["wt_loss"].detach()) > 0
+        assert abs(losses["wt_loss"] - float(L["wt_loss"].detach())) < 1e-4 * float(L["wt_loss"].detach())
+        assert abs(losses["total_loss"] - float(L["total_loss"].detach())) < 1e-4 * abs(float(L["total_loss"].detach()))
+        gp = pt.grad.numpy()
+        assert np.abs(dpred.cpu().numpy() - gp).max() <= 3e-4 * np.abs(gp).max()
