@@ -136,6 +136,7 @@ struct WgradArgs {
     const float* x;       // NHWC [N,H,W,Cin]  (forward input of the conv)
     const float* dy;      // [M, Cdy] masked upstream gradient (M = N*Ho*Wo)
     float* dw;            // [Kchunks*4][Cdy] accumulated
+    float* colsum;        // [Cdy] accumulated column sums of dY (d beta / d bias), or nullptr
     int N, H, W, Cin, log2cin4, Ho, Wo, Cdy;
     int KW, stride, dil, pad_t, pad_l, ntaps, kchunks;
     int M, m_per_block;
@@ -210,9 +211,16 @@ __global__ __launch_bounds__(256) void wgrad_f32(const WgradArgs p) {
     gload(0);
     lstore(0);
     __syncthreads();
+    const bool do_colsum = p.colsum != nullptr && blockIdx.x == 0 && t < BR;     // one k-tile sums dY's columns
+    float csum = 0.f;
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
         if (s + 1 < nsteps) gload(s + 1);
+        if (do_colsum) {
+            const float* col = sB + buf * 32 * BR + t;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) csum += col[r * BR];
+        }
         const float* a_base = sA + buf * 32 * BR + wm * 32 * T + l31;
         const float* b_base = sB + buf * 32 * BR + wn * 32 * T + l31;
 #pragma unroll
@@ -232,6 +240,7 @@ __global__ __launch_bounds__(256) void wgrad_f32(const WgradArgs p) {
         if (s + 1 < nsteps) lstore(buf ^ 1);
         __syncthreads();
     }
+    if (do_colsum && n0 + t < p.Cdy) atomicAdd(p.colsum + n0 + t, csum);
     // C/D layout: col = lane&31 (co), row = (r&3) + 8*(r>>2) + 4*half (k)
 #pragma unroll
     for (int j = 0; j < T; ++j) {
@@ -261,27 +270,42 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
     if (rl == 0 && c < C) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
-// dW = scale * dWraw (HWIO, real Cin), dgamma = r * (sum_k W dWraw - mean * dbeta), dbeta = colsum
-__global__ void finalize_bn_conv_grads(const float* __restrict__ dwraw, const float* __restrict__ w,
-                                       const float* __restrict__ gamma, const float* __restrict__ mean,
-                                       const float* __restrict__ var, const float* __restrict__ dbeta_in, float eps,
-                                       int taps, int cin, int cin_real, int cout, float* __restrict__ dW,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+// dW = scale * dWraw (HWIO, real Cin) and dot[co] += sum_k W[k][co] * dWraw[k][co]   (grid: k-chunks x co-tiles of 64)
+__global__ __launch_bounds__(256) void scale_dw_dot_kernel(const float* __restrict__ dwraw, const float* __restrict__ w,
+                                                           const float* __restrict__ scale, int taps, int cin, int cin_real,
+                                                           int cout, int rows_per_block, float* __restrict__ dW,
+                                                           float* __restrict__ dot) {
+    __shared__ float part[4][64];
+    const int co = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int krows = taps * cin_real;
+    const int k0 = blockIdx.y * rows_per_block, k1 = min(krows, k0 + rows_per_block);
+    float acc = 0.f;
+    if (co < cout) {
+        const float s = scale[co];
+        for (int k = k0 + rl; k < k1; k += 4) {
+            const int tp = k / cin_real, ci = k - tp * cin_real;
+            const float g = dwraw[((long long)tp * cin + ci) * cout + co];
+            const long long o = (long long)k * cout + co;
+            acc += w[o] * g;
+            dW[o] = s * g;
+        }
+    }
+    part[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && co < cout)
+        atomicAdd(dot + co, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// dgamma = r * (dot - mean * dbeta), dbeta = colsum           (r = rsqrt(var + eps))
+__global__ void bn_param_grads_kernel(const float* __restrict__ dot, const float* __restrict__ colsum,
+                                      const float* __restrict__ mean, const float* __restrict__ var, float eps, int cout,
+                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int co = blockIdx.x * blockDim.x + threadIdx.x;
     if (co >= cout) return;
     const float r = 1.f / sqrtf(var[co] + eps);
-    const float s = gamma[co] * r;
-    double dot = 0.0;
-    for (int tp = 0; tp < taps; ++tp)
-        for (int ci = 0; ci < cin_real; ++ci) {
-            const float g = dwraw[((long long)tp * cin + ci) * cout + co];
-            const long long o = ((long long)tp * cin_real + ci) * cout + co;
-            dot += (double)w[o] * (double)g;
-            dW[o] = s * g;
-        }
-    const float db = dbeta_in[co];
+    const float db = colsum[co];
     dbeta[co] = db;
-    dgamma[co] = r * ((float)dot - mean[co] * db);
+    dgamma[co] = r * (dot[co] - mean[co] * db);
 }
 
 // head: dw[ka][kb][c][ci] = dW'raw[(khp,kwp)][ci][(a,b),c] (each w element appears once), db[c] = sum_phases colsum
@@ -477,7 +501,7 @@ TPlan make_tplan(const dgp_trainer* tr, int B) {
         wmax = std::max(wmax, (size_t)l.KH * l.KW * l.Cin * cdy);
     }
     p.dwraw = take(wmax);
-    p.colsum = take(4096);
+    p.colsum = take(2 * 4096);
     p.total = o;
     return p;
 }
@@ -502,15 +526,19 @@ hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, 
 }
 
 hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const float* dy, int Ho, int Wo, int Cdy, int KH,
-                        int KW, int stride, int dil, int pad_t, int pad_l, float* dwraw, hipStream_t s) {
+                        int KW, int stride, int dil, int pad_t, int pad_l, float* dwraw, float* colsum, hipStream_t s) {
     WgradArgs a{};
-    a.x = x; a.dy = dy; a.dw = dwraw; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.log2cin4 = ilog2(Cin / 4);
+    a.x = x; a.dy = dy; a.dw = dwraw; a.colsum = colsum; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.log2cin4 = ilog2(Cin / 4);
     a.Ho = Ho; a.Wo = Wo; a.Cdy = Cdy; a.KW = KW; a.stride = stride; a.dil = dil; a.pad_t = pad_t; a.pad_l = pad_l;
     a.ntaps = KH * KW; a.kchunks = KH * KW * (Cin / 4); a.M = N * Ho * Wo;
     a.x_bytes = (unsigned)((size_t)N * H * W * Cin * 4);
     a.dy_bytes = (unsigned)((size_t)a.M * Cdy * 4);
     hipError_t e = hipMemsetAsync(dwraw, 0, (size_t)a.kchunks * 4 * Cdy * sizeof(float), s);
     if (e != hipSuccess) return e;
+    if (colsum) {       // [0, Cdy): column sums, [Cdy, 2 Cdy): dot products of finalize (zeroed together)
+        e = hipMemsetAsync(colsum, 0, (size_t)2 * Cdy * sizeof(float), s);
+        if (e != hipSuccess) return e;
+    }
     const bool big = (a.kchunks * 4 >= 128 && Cdy >= 128);
     const int BR = big ? 128 : 64;
     const int kt = (a.kchunks * 4 + BR - 1) / BR, nt = (Cdy + BR - 1) / BR;
@@ -740,11 +768,14 @@ static int layer_param_grads(dgp_trainer* tr, size_t li, const float* x, int N, 
     dgp_net* net = tr->net;
     const ConvLayer& l = net->layers[li];
     const TLayer& t = tr->tl[li];
-    TRY_HIP(wgrad_launch(x, N, H, W, l.Cin, dy, Ho, Wo, l.Cout, l.KH, l.KW, stride, l.rate, pad_t, pad_l, dwraw, s));
-    TRY_HIP(colsum_launch(dy, N * Ho * Wo, l.Cout, colsum, s));
-    hipLaunchKernelGGL(finalize_bn_conv_grads, dim3((l.Cout + 127) / 128), dim3(128), 0, s, dwraw, tr->params + t.w_off,
-                       tr->params + t.g_off, tr->stats + t.mean_off, tr->stats + t.var_off, colsum, net->desc.bn_eps,
-                       l.KH * l.KW, l.Cin, t.cin_real, l.Cout, tr->grads + t.w_off, tr->grads + t.g_off, tr->grads + t.b_off);
+    TRY_HIP(wgrad_launch(x, N, H, W, l.Cin, dy, Ho, Wo, l.Cout, l.KH, l.KW, stride, l.rate, pad_t, pad_l, dwraw, colsum, s));
+    float* dot = colsum + l.Cout;
+    const int krows = l.KH * l.KW * t.cin_real;
+    const int rpb = 64;
+    hipLaunchKernelGGL(scale_dw_dot_kernel, dim3((l.Cout + 63) / 64, (krows + rpb - 1) / rpb), dim3(256), 0, s, dwraw,
+                       tr->params + t.w_off, l.d_scale, l.KH * l.KW, l.Cin, t.cin_real, l.Cout, rpb, tr->grads + t.w_off, dot);
+    hipLaunchKernelGGL(bn_param_grads_kernel, dim3((l.Cout + 127) / 128), dim3(128), 0, s, dot, colsum, tr->stats + t.mean_off,
+                       tr->stats + t.var_off, net->desc.bn_eps, l.Cout, tr->grads + t.g_off, tr->grads + t.b_off);
     TRY_HIP(hipGetLastError());
     return DGP_OK;
 }
@@ -788,8 +819,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
             const int njt = l.Cout / 4;
             const long long tot = (long long)B * fh * fw * t.cpad;
             hipLaunchKernelGGL(head_gather_kernel, dim3(grid_for(tot)), dim3(256), 0, s, dsrc[k], B, fh, fw, njt, t.cpad, dph[k]);
-            TRY_HIP(wgrad_launch(feat, B, fh, fw, l.Cin, dph[k], fh, fw, t.cpad, 2, 2, 1, 1, 1, 1, dwraw, s));
-            TRY_HIP(colsum_launch(dph[k], B * fh * fw, t.cpad, colsum, s));
+            TRY_HIP(wgrad_launch(feat, B, fh, fw, l.Cin, dph[k], fh, fw, t.cpad, 2, 2, 1, 1, 1, 1, dwraw, colsum, s));
             hipLaunchKernelGGL(finalize_head_grads, dim3(grid_for(9ll * njt * l.Cin)), dim3(256), 0, s, dwraw, colsum, njt,
                                l.Cin, t.cpad, tr->grads + t.w_off, tr->grads + t.b_off);
             // dfeat (+)= convT: 2x2 taps flipped, pad' = 0; second head accumulates onto the first; gate on the last

@@ -1,0 +1,16 @@
+#!/bin/bash
+# rocprofv3 kernel stats of the training-step benchmark
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/prof_train
+rm -rf "$OUT"; mkdir -p "$OUT"; export TMPDIR=/tmp; cd "$ROOT"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 scripts/bench_train.py 5 > "$OUT/bench.log" 2>&1
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, os
+f = glob.glob(os.path.join(sys.argv[1], "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+steps = 7.0
+for r in rows[:22]:
+    print("%-80s calls %5s  %8.3f ms/step  avg %9.1f us  %5s%%" % (r["Name"].replace("dgp::", "")[:80], r["Calls"], float(r["TotalDurationNs"]) / 1e6 / steps, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+PY
+grep "^{" "$OUT/bench.log" | cut -c1-200
