@@ -155,22 +155,79 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
             im = im.crop(crop_size)
         return np.asarray(im)
 
-    def flush(buf, start):
-        if not buf:
-            return
-        mu, lik = sess.run([mu_n, sess.likelihood], feed_dict={inputs: np.stack(buf)})
-        markers[start:start + len(buf)] = mu
-        likelihoods[start:start + len(buf)] = lik
+    # Host pipeline: a decode thread fills pinned staging buffers, a copy stream moves batch k+1
+    # to the GPU while batch k runs through dgp_infer on the compute stream, and the keypoints of the whole video
+    # come back in ONE device-to-host copy at the end (the reference fetched the full scoremap every frame).
+    import itertools
+    import queue
+    import threading
+    import torch
+    dev = torch.device("cuda", sess.device)
+    frames_it = iter(video_clip.iter_frames())
+    first = next(frames_it, None)
+    if first is None:
+        raise ValueError("no frames in %s" % video_file)
+    f0 = prep(first)
+    hh, ww = f0.shape[:2]
+    net = sess.net_for(hh, ww)
+    nslots = 3
+    pinned = [torch.empty((batch_size, hh, ww, 3), dtype=torch.uint8).pin_memory() for _ in range(nslots)]
+    dbuf = [torch.empty((batch_size, hh, ww, 3), dtype=torch.uint8, device=dev) for _ in range(nslots)]
+    free_slots, ready = queue.Queue(), queue.Queue()
+    for i in range(nslots):
+        free_slots.put(i)
 
-    buf, start, ii = [], 0, -1
-    for ii, frame in enumerate(video_clip.iter_frames()):
-        if ii >= n_frames:
+    def producer():
+        try:
+            slot, fill, count = free_slots.get(), 0, 0
+            for fr in itertools.chain([f0], (prep(x) for x in frames_it)):
+                if count >= n_frames:
+                    break
+                pinned[slot][fill] = torch.from_numpy(np.ascontiguousarray(fr))
+                fill += 1
+                count += 1
+                if fill == batch_size:
+                    ready.put((slot, fill))
+                    slot, fill = free_slots.get(), 0
+            if fill:
+                ready.put((slot, fill))
+            ready.put(None)
+        except BaseException as e:      # surface decode errors in the consumer
+            ready.put(e)
+
+    th = threading.Thread(target=producer, daemon=True)
+    th.start()
+    copy_stream = torch.cuda.Stream(device=dev)
+    compute = torch.cuda.current_stream(dev)
+    mu_all = torch.zeros((n_frames, nj, 2), dtype=torch.float32, device=dev)
+    lik_all = torch.zeros((n_frames, nj), dtype=torch.float32, device=dev)
+    consumed = [None] * nslots            # compute-stream event: last dgp_infer that read dbuf[slot]
+    start = 0
+    while True:
+        item = ready.get()
+        if item is None:
             break
-        buf.append(prep(frame))
-        if len(buf) == batch_size:
-            flush(buf, start)
-            start, buf = ii + 1, []
-    flush(buf, start)
+        if isinstance(item, BaseException):
+            raise item
+        slot, nb = item
+        with torch.cuda.stream(copy_stream):
+            if consumed[slot] is not None:
+                copy_stream.wait_event(consumed[slot])          # do not overwrite frames still being read
+            dbuf[slot][:nb].copy_(pinned[slot][:nb], non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(copy_stream)
+        compute.wait_event(copied)
+        mu, lik, _ = net.infer(dbuf[slot][:nb], sess.gamma, sess.gauss_len)
+        mu_all[start:start + nb], lik_all[start:start + nb] = mu, lik
+        consumed[slot] = torch.cuda.Event()
+        consumed[slot].record(compute)
+        start += nb
+        copied.synchronize()              # the pinned buffer is free again once its H2D copy has completed
+        free_slots.put(slot)
+    th.join()
+    torch.cuda.synchronize(dev)
+    markers[:start] = mu_all[:start].cpu().numpy()
+    likelihoods[:start] = lik_all[:start].cpu().numpy()
     sess.close()
     video_clip.close()
 
