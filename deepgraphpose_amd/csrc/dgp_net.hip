@@ -72,6 +72,36 @@ static int add_layer(dgp_net* net, const std::string& scope, int cin, int cout, 
 extern "C" {
 
 int dgp_version(void) { return DGP_ABI_VERSION; }
+
+// Host-side CRC-32C (Castagnoli), slicing-by-8; checksum of TF tensor-bundle entries (tf_checkpoint.py).
+uint32_t dgp_crc32c(const void* data, size_t n, uint32_t crc) {
+    static uint32_t tab[8][256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            tab[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) tab[t][i] = (tab[t - 1][i] >> 8) ^ tab[0][tab[t - 1][i] & 0xFF];
+        init = true;
+    }
+    const uint8_t* p = (const uint8_t*)data;
+    crc = ~crc;
+    while (n >= 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4);
+        memcpy(&hi, p + 4, 4);
+        lo ^= crc;
+        crc = tab[7][lo & 0xFF] ^ tab[6][(lo >> 8) & 0xFF] ^ tab[5][(lo >> 16) & 0xFF] ^ tab[4][lo >> 24] ^
+              tab[3][hi & 0xFF] ^ tab[2][(hi >> 8) & 0xFF] ^ tab[1][(hi >> 16) & 0xFF] ^ tab[0][hi >> 24];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) crc = tab[0][(crc ^ *p++) & 0xFF] ^ (crc >> 8);
+    return ~crc;
+}
 const char* dgp_last_error(void) { return g_err.c_str(); }
 
 int dgp_net_create(const dgp_net_desc* d, dgp_net** out) {

@@ -127,12 +127,14 @@ def _locref_targets(joint_loc, nt, vis_within, nx_out, ny_out, nj, dgp_cfg):
 
 def _save(trainer, prefix, step, it, final, debug=""):
     from .. import weights_io
+    import os
     w = trainer.get_weights()
     base = prefix + "-step" + str(step) + debug
-    weights_io.save_weights(base + "-" + str(it), w)
-    weights_io.save_weights(base + "--0", w)
+    fmt = os.environ.get("DGP_SNAPSHOT_FORMAT", "npz")          # "tf": V2 bundles a tf.train.Saver can restore
+    weights_io.save_weights(base + "-" + str(it), w, fmt=fmt)
+    weights_io.save_weights(base + "--0", w, fmt=fmt)
     if final:
-        weights_io.save_weights(base + "-final--0", w)
+        weights_io.save_weights(base + "-final--0", w, fmt=fmt)
 
 
 def _augment(dgp_cfg):
