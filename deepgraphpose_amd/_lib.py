@@ -43,6 +43,9 @@ SYMBOLS = {
     "dgp_last_error": (C.c_char_p, []),
     "dgp_net_create": (C.c_int, [C.POINTER(DgpNetDesc), C.POINTER(_vp)]),
     "dgp_net_destroy": (None, [_vp]),
+    "dgp_net_set_input_size": (C.c_int, [_vp, _i32, _i32]),
+    "dgp_dlc_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.c_float, _i32, _vp, _vp, _vp,
+                                       _vp, _sz, _vp]),
     "dgp_net_load_weights": (C.c_int, [_vp, C.POINTER(DgpTensorView), _i32]),
     "dgp_net_workspace_bytes": (C.c_int, [_vp, _i32, C.POINTER(_sz)]),
     "dgp_net_output_dims": (C.c_int, [_vp] + [C.POINTER(_i32)] * 4),

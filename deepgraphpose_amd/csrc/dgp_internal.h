@@ -71,6 +71,17 @@ struct LossArgs {
 };
 hipError_t launch_loss(const LossArgs& a, hipStream_t s);
 
+struct DlcLossArgs {                      // DLC step-0 loss (sigmoid CE on binary disks + locref Huber)
+    const float *pred, *part_targets, *part_weights;          // part_weights may be null (all ones)
+    const float *locref_pred, *locref_targets, *locref_mask;  // locref_pred null = no location refinement
+    float *dpred, *dlocref, *losses;
+    double* acc;
+    long long n_part, n_loc;
+    float locref_loss_weight;
+    int huber;
+};
+hipError_t launch_dlc_loss(const DlcLossArgs& a, hipStream_t s);
+
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
 

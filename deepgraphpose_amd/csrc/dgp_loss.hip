@@ -440,6 +440,73 @@ __global__ void loss_finalize(LossArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// DLC step-0 loss (pose_net.train, DeepLabCut pose_estimation_tensorflow/nnet/pose_net.py:159-190):
+//   part_loss   = tf.losses.sigmoid_cross_entropy(targets, logits, weights)  -> sum(w*ce) / #nonzero(w)
+//   locref_loss = locref_loss_weight * huber(targets, pred, mask)            -> sum(mask*h) / #nonzero(mask)
+// acc[0] = sum w*ce, acc[1] = #nonzero w, acc[2] = sum mask*huber, acc[3] = #nonzero mask   (doubles)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dlc_loss_reduce(DlcLossArgs a) {
+    __shared__ double red[4];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const long long stride = (long long)gridDim.x * blockDim.x, i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long long i = i0; i < a.n_part; i += stride) {
+        const float x = a.pred[i], z = a.part_targets[i];
+        const float w = a.part_weights ? a.part_weights[i] : 1.f;
+        // max(x,0) - x*z + log1p(exp(-|x|))  (tf.nn.sigmoid_cross_entropy_with_logits)
+        const float ce = fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
+        s0 += (double)(w * ce);
+        s1 += w != 0.f ? 1.0 : 0.0;
+    }
+    if (a.locref_pred)
+        for (long long i = i0; i < a.n_loc; i += stride) {
+            const float mk = a.locref_mask[i];
+            const float d = a.locref_pred[i] - a.locref_targets[i], ad = fabsf(d);
+            const float h = a.huber ? (ad < 1.f ? 0.5f * d * d : ad - 0.5f) : d * d;
+            s2 += (double)(mk * h);
+            s3 += mk != 0.f ? 1.0 : 0.0;
+        }
+    s0 = block_sum(s0, red); s1 = block_sum(s1, red); s2 = block_sum(s2, red); s3 = block_sum(s3, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&a.acc[0], s0); atomicAdd(&a.acc[1], s1); atomicAdd(&a.acc[2], s2); atomicAdd(&a.acc[3], s3);
+    }
+}
+
+__global__ __launch_bounds__(256) void dlc_loss_backward(DlcLossArgs a) {
+    const float inv_p = a.acc[1] > 0.0 ? (float)(1.0 / a.acc[1]) : 0.f;
+    const float inv_l = a.acc[3] > 0.0 ? (float)((double)a.locref_loss_weight / a.acc[3]) : 0.f;
+    const long long stride = (long long)gridDim.x * blockDim.x, i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long long i = i0; i < a.n_part; i += stride) {
+        const float x = a.pred[i], z = a.part_targets[i];
+        const float w = a.part_weights ? a.part_weights[i] : 1.f;
+        const float sg = 1.f / (1.f + expf(-x));
+        a.dpred[i] = w * (sg - z) * inv_p;
+    }
+    if (a.locref_pred)
+        for (long long i = i0; i < a.n_loc; i += stride) {
+            const float d = a.locref_pred[i] - a.locref_targets[i];
+            const float de = a.huber ? (fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f)) : 2.f * d;
+            a.dlocref[i] = a.locref_mask[i] * de * inv_l;
+        }
+    if (i0 == 0) {
+        const float pl = a.acc[1] > 0.0 ? (float)(a.acc[0] / a.acc[1]) : 0.f;
+        const float ll = a.acc[3] > 0.0 ? (float)(a.acc[2] / a.acc[3]) * a.locref_loss_weight : 0.f;
+        a.losses[0] = pl; a.losses[1] = ll; a.losses[2] = pl + ll; a.losses[3] = 0.f;
+    }
+}
+
+hipError_t launch_dlc_loss(const DlcLossArgs& a, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(a.acc, 0, 4 * sizeof(double), s);
+    if (e != hipSuccess) return e;
+    long long n = a.n_part > a.n_loc ? a.n_part : a.n_loc;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(dlc_loss_reduce, dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(dlc_loss_backward, dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_loss(const LossArgs& a, hipStream_t s) {
     const int nm = a.nt * a.nj;
     hipError_t e = hipMemsetAsync(a.dlocref, 0, (size_t)a.nt * a.H * a.W * 2 * a.nj * sizeof(float), s);

@@ -165,6 +165,17 @@ int dgp_net_create(const dgp_net_desc* d, dgp_net** out) {
 
 void dgp_net_destroy(dgp_net* net) { delete net; }
 
+int dgp_net_set_input_size(dgp_net* net, int32_t in_h, int32_t in_w) {
+    if (!net) return fail(DGP_ERR_INVALID, "dgp_net_set_input_size: null net");
+    if (in_h < 32 || in_w < 32) return fail(DGP_ERR_INVALID, "dgp_net_set_input_size: frames must be at least 32 x 32");
+    net->desc.in_h = in_h; net->desc.in_w = in_w;
+    int pb;
+    net->h1 = (in_h + 1) / 2; net->w1 = (in_w + 1) / 2;
+    tf_same(net->h1, 3, 2, 1, &net->hp, &pb); tf_same(net->w1, 3, 2, 1, &net->wp, &pb);
+    net->fh = (((net->hp + 1) / 2) + 1) / 2; net->fw = (((net->wp + 1) / 2) + 1) / 2;
+    return DGP_OK;
+}
+
 static const dgp_tensor_view* find_t(const std::map<std::string, const dgp_tensor_view*>& m,
                                      const std::string& k) {
     auto it = m.find(k);
@@ -613,6 +624,28 @@ int dgp_loss_fwd_bwd(const dgp_loss_desc* d, const float* pred, const float* loc
     a.clique_scale = n_v_eff > 0 ? (float)(1.0 / ((double)d->H * d->W) * n_vis_tot / n_v_eff / (n_vis_tot + n_hid_tot) / d->wn_visible) : 0.f;
     e = launch_loss(a, s);
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("loss kernels: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
+int dgp_dlc_loss_fwd_bwd(const float* pred, const float* locref_pred, const float* part_targets,
+                         const float* part_weights, const float* locref_targets, const float* locref_mask, int32_t nt,
+                         int32_t H, int32_t W, int32_t nj, float locref_loss_weight, int32_t huber, float* dpred,
+                         float* dlocref, float* losses, void* scratch, size_t scratch_bytes, void* stream) {
+    if (!pred || !part_targets || !dpred || !losses || !scratch)
+        return fail(DGP_ERR_INVALID, "dgp_dlc_loss_fwd_bwd: null argument");
+    if (locref_pred && (!locref_targets || !locref_mask || !dlocref))
+        return fail(DGP_ERR_INVALID, "dgp_dlc_loss_fwd_bwd: locref targets / mask / gradient missing");
+    if (nt < 1 || H < 1 || W < 1 || nj < 1) return fail(DGP_ERR_INVALID, "dgp_dlc_loss_fwd_bwd: bad shape");
+    if (scratch_bytes < 4 * sizeof(double) || ((uintptr_t)scratch & 7))
+        return fail(DGP_ERR_INVALID, "dgp_dlc_loss_fwd_bwd: scratch must be >= 32 bytes, 8-byte aligned");
+    DlcLossArgs a{};
+    a.pred = pred; a.part_targets = part_targets; a.part_weights = part_weights;
+    a.locref_pred = locref_pred; a.locref_targets = locref_targets; a.locref_mask = locref_mask;
+    a.dpred = dpred; a.dlocref = dlocref; a.losses = losses; a.acc = (double*)scratch;
+    a.n_part = (long long)nt * H * W * nj; a.n_loc = locref_pred ? 2 * a.n_part : 0;
+    a.locref_loss_weight = locref_loss_weight; a.huber = huber;
+    hipError_t e = launch_dlc_loss(a, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dlc loss kernels: ") + hipGetErrorString(e));
     return DGP_OK;
 }
 

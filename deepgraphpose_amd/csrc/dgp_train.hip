@@ -403,7 +403,7 @@ __global__ void momentum_kernel(float* __restrict__ w, const float* __restrict__
                                 float lr, float mom, float clip, const double* __restrict__ sumsq,
                                 float* __restrict__ gnorm_out) {
     const float gn = (float)sqrt(*sumsq);
-    const float scale = clip / fmaxf(gn, clip);               // tf.clip_by_global_norm
+    const float scale = clip > 0.f ? clip / fmaxf(gn, clip) : 1.f;      // tf.clip_by_global_norm; clip <= 0: none
     if (blockIdx.x == 0 && threadIdx.x == 0 && gnorm_out) *gnorm_out = gn;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float a = mom * v[i] + g[i] * scale;            // accum = momentum * accum + grad

@@ -83,12 +83,25 @@ class DGPNet:
                 views[i].shape[j] = a.shape[j] if j < a.ndim else 1
         _lib.check(self.lib.dgp_net_load_weights(self._h, views, len(weights)), "dgp_net_load_weights")
 
+    def set_input_size(self, in_h: int, in_w: int):
+        """Re-plan the geometry for another frame size; weights stay (DLC's step-0 loader changes the size every
+        iteration, pose_defaultdataset.py:131-196)."""
+        if (in_h, in_w) == (self.in_h, self.in_w):
+            return
+        _lib.check(self.lib.dgp_net_set_input_size(self._h, in_h, in_w), "dgp_net_set_input_size")
+        self.in_h, self.in_w = in_h, in_w
+        oh, ow, fh, fw = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(self.lib.dgp_net_output_dims(self._h, C.byref(oh), C.byref(ow), C.byref(fh), C.byref(fw)))
+        self.out_h, self.out_w, self.feat_h, self.feat_w = oh.value, ow.value, fh.value, fw.value
+        self._ws_batch = 0                      # workspace is re-checked against the new geometry
+
     # -- workspace -------------------------------------------------------------------
     def workspace(self, batch: int) -> torch.Tensor:
         if self._ws is None or batch > self._ws_batch:
             n = C.c_size_t()
             _lib.check(self.lib.dgp_net_workspace_bytes(self._h, batch, C.byref(n)), "dgp_net_workspace_bytes")
-            self._ws = torch.empty(n.value, dtype=torch.uint8, device=self.device)
+            if self._ws is None or self._ws.numel() < n.value:
+                self._ws = torch.empty(n.value, dtype=torch.uint8, device=self.device)
             self._ws_batch = batch
         return self._ws
 

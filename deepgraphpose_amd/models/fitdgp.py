@@ -3,8 +3,7 @@
   fit_dgp_labeledonly(snapshot, dlcpath, ...)   DGP/models/fitdgp.py:257-546   (step 1)
   fit_dgp(snapshot, dlcpath, ...)               DGP/models/fitdgp.py:549-845   (step 2)
   dgp_loss(data_batcher, dgp_cfg)               DGP/models/fitdgp.py:848-1144  (loss pre-computation + closure)
-  fit_dlc(...)                                  DGP/models/fitdgp.py:53-254    (step 0: DLC baseline trainer; NOT built
-                                                yet -- SURVEY.md 8(f) N2 -- raises NotImplementedError)
+  fit_dlc(snapshot, dlcpath, ...)               DGP/models/fitdgp.py:53-254    (step 0: DLC baseline trainer)
 
 One iteration = `Trainer.step` (deepgraphpose_amd/train.py) = the reference's sess.run([loss, train_op]).
 Snapshots are `<train dir>/snapshot-step{k}-{it}.npz` and `snapshot-step{k}-final--0.npz` (TF variable names).
@@ -148,12 +147,138 @@ def _augment(dgp_cfg):
     raise NotImplementedError("imgaug present: wire build_aug/data_aug (DGP/models/fitdgp_util.py:412-451) here")
 
 
+def _pretrained_checkpoint(net_type: str, dlc_cfg) -> str:
+    """ImageNet backbone checkpoint `resnet_v1_<depth>.ckpt`.  The reference looks inside the installed deeplabcut
+    package (fitdgp.py:101-106); here: $DGP_PRETRAINED_DIR, <package>/pretrained/, then pose_cfg.yaml's init_weights."""
+    name = net_type.split("_")[0] + "_v1_" + net_type.split("_")[1] + ".ckpt"
+    here = Path(__file__).resolve().parent.parent
+    cands = [Path(os.environ["DGP_PRETRAINED_DIR"]) / name] if os.environ.get("DGP_PRETRAINED_DIR") else []
+    cands += [here / "pretrained" / name, Path(str(dlc_cfg.get("init_weights", "")))]
+    for c in cands:
+        for suffix in ("", ".npz", ".index", ".safetensors"):
+            if str(c) and os.path.isfile(str(c) + suffix):
+                return str(c)
+    raise FileNotFoundError("ImageNet checkpoint %s not found (looked in %s); set DGP_PRETRAINED_DIR or start from a "
+                            "snapshot via the `snapshot` argument" % (name, ", ".join(str(c) for c in cands)))
+
+
+def _fresh_heads(wts, depth, nj, location_refinement, seed=None):
+    """Head variables absent from an ImageNet checkpoint, initialised like slim.conv2d_transpose does
+    (pose_net.py:37-44: xavier/glorot-uniform weights over (fan_in + fan_out)/2, zero biases)."""
+    rng = np.random.RandomState(seed)
+    cin = wts["resnet_v1_%d/block4/unit_3/bottleneck_v1/conv3/weights" % depth].shape[-1]
+    for scope, cout in (("pose/part_pred/block4", nj), ("pose/locref_pred/block4", 2 * nj)):
+        if scope + "/weights" in wts:
+            continue
+        fan_in, fan_out = cout * 9, cin * 9                      # kernel [3,3,out,in]: fan_in = shape[-2]*9, fan_out = shape[-1]*9
+        limit = np.sqrt(3.0 / ((fan_in + fan_out) / 2.0))
+        wts[scope + "/weights"] = rng.uniform(-limit, limit, size=(3, 3, cout, cin)).astype(np.float32)
+        wts[scope + "/biases"] = np.zeros(cout, dtype=np.float32)
+    return wts
+
+
 def fit_dlc(snapshot, dlcpath, shuffle=1, step=0, saveiters=1000, displayiters=100, maxiters=200000,
             trainingsetindex=0):
-    """Step 0 (DLC baseline trainer, DGP/models/fitdgp.py:53-254) is outside round 1."""
-    raise NotImplementedError("fit_dlc (DLC step-0 trainer: binary-disk sigmoid-CE + locref Huber, multi-step LR, "
-                              "scale-jitter loader) is not built yet; start from an existing snapshot via "
-                              "--dlcsnapshot like the reference allows")
+    """Run the DLC baseline trainer (step 0), DGP/models/fitdgp.py:53-254: one randomly scaled / cropped labeled
+    image per iteration (PoseDataset), loss = sigmoid CE on binary target disks + locref Huber (pose_net.train),
+    multi-step learning rate, MomentumOptimizer(0.9) without clipping; snapshots snapshot-step0-{it} and
+    snapshot-step0-final--0.  `snapshot`: a 'snapshot-*' name inside the train folder, or anything else to start
+    from the ImageNet resnet_v1_<depth>.ckpt."""
+    import torch
+    from .. import weights_io
+    from ..dlc_dataset import LearningRate, PoseDataset
+    from ..train import Trainer
+
+    dlc_base_path = Path(dlcpath)
+    config_path = dlc_base_path / "config.yaml"
+    print("config_path", config_path)
+    cfg = dcfg.read_config(config_path)
+    modelfoldername = dcfg.GetModelFolder(cfg["TrainingFraction"][trainingsetindex], shuffle, cfg)
+    pose_config_yaml = Path(os.path.join(cfg["project_path"], str(modelfoldername), "train", "pose_cfg.yaml"))
+
+    dlc_cfg = dcfg.load_config(pose_config_yaml)                  # fitdgp.py:93-111: the reference's overrides
+    dlc_cfg.crop = True
+    dlc_cfg.cropratio = 0.4
+    dlc_cfg.global_scale = 0.8
+    dlc_cfg.multi_step = [[0.001, 10000], [0.005, 430000], [0.002, 730000], [0.001, 1030000]]
+    final = dlc_cfg.snapshot_prefix + "-step0-final--0"
+    if any(os.path.isfile(final + ext) for ext in (".index", ".npz", ".safetensors")):
+        print(final, "  exists! The original DLC has already been run.", flush=True)
+        return None
+    if "snapshot" in snapshot:
+        init_weights = str(dlc_base_path / modelfoldername / "train" / snapshot)
+    else:
+        init_weights = _pretrained_checkpoint(dlc_cfg.net_type, dlc_cfg)
+    dlc_cfg.init_weights = init_weights
+    dlc_cfg.pos_dist_thresh = 8
+    dlc_cfg.output_stride = 16
+
+    if dlc_cfg.batch_size != 1:
+        raise ValueError("fit_dlc: batch_size must be 1 (every sample has its own size)")
+    if dlc_cfg.intermediate_supervision:
+        raise NotImplementedError("intermediate_supervision is off in every DGP configuration and is not built")
+    if dlc_cfg.optimizer != "sgd":
+        raise ValueError("unknown optimizer {}".format(dlc_cfg.optimizer))
+
+    dataset = PoseDataset(dlc_cfg)
+    wts = weights_io.load_weights(init_weights)
+    depth = weights_io.net_depth(wts)
+    nj = int(dlc_cfg.num_joints)
+    if "snapshot" in Path(init_weights).stem:
+        print("Loading already trained DLC with backbone:", dlc_cfg.net_type, flush=True)
+    else:
+        print("Loading ImageNet-pretrained", dlc_cfg.net_type, flush=True)
+        wts = {k: v for k, v in wts.items() if k.startswith("resnet_v1")}
+    wts = _fresh_heads(wts, depth, nj, dlc_cfg.location_refinement)
+    trainer = Trainer(depth, nj, 64, 64, max_frames=1)
+    trainer.load_weights(wts)
+
+    display_iters = max(1, int(dlc_cfg.get("display_iters", 1000) if displayiters is None else displayiters))
+    save_iters = max(1, int(dlc_cfg.get("save_iters", 50000) if saveiters is None else saveiters))
+    max_iter = int(dlc_cfg.multi_step[-1][1]) if maxiters is None else min(int(dlc_cfg.multi_step[-1][1]), int(maxiters))
+    print("Display_iters overwritten as", display_iters, flush=True)
+    print("Save_iters overwritten as", save_iters, flush=True)
+    print("Max_iters overwritten as", max_iter, flush=True)
+
+    lr_gen = LearningRate(dlc_cfg)
+    stats_path = Path(pose_config_yaml).with_name("learning_stats.csv")
+    lrf = open(str(stats_path), "w")
+    cumloss, partloss, locrefloss = 0.0, 0.0, 0.0
+    print("Starting training....", flush=True)
+    dev = trainer.device
+    for it in range(max_iter + 1):
+        current_lr = lr_gen.get_lr(it)
+        batch = dataset.next_batch()
+        img = batch["inputs"]
+        trainer.set_input_size(img.shape[1], img.shape[2])
+        frames = torch.from_numpy(img).to(dev)
+        losses = trainer.forward_backward_dlc(
+            frames, batch["part_score_targets"], batch["locref_targets"], batch["locref_mask"],
+            part_score_weights=batch["part_score_weights"] if dlc_cfg.weigh_part_predictions else None,
+            locref_loss_weight=dlc_cfg.locref_loss_weight, locref_huber_loss=dlc_cfg.locref_huber_loss,
+            location_refinement=dlc_cfg.location_refinement)
+        trainer.apply_gradients(current_lr, 0.9, clip_norm=0.0)  # MomentumOptimizer, no clipping (train.py:94-113)
+
+        partloss += losses["part_loss"]
+        if dlc_cfg.location_refinement:
+            locrefloss += losses["locref_loss"]
+        cumloss += losses["total_loss"]
+        if it % display_iters == 0 and it > 0:
+            vals = (it, "total loss {0:.4f}".format(cumloss / display_iters),
+                    "scoremap loss {0:.4f}".format(partloss / display_iters),
+                    "learning rate {0:.4f}".format(locrefloss / display_iters), current_lr)     # labels as in fitdgp.py:212-230
+            print("iteration: {} loss: {} scmap loss: {} locref loss: {} lr: {}".format(*vals), flush=True)
+            lrf.write("iteration: {}, loss: {}, scmap loss: {}, locref loss: {}, lr: {}\n".format(*vals))
+            lrf.flush()
+        if (it % save_iters == 0 and it != 0) or it == max_iter:
+            fmt = os.environ.get("DGP_SNAPSHOT_FORMAT", "npz")
+            w = trainer.get_weights()
+            weights_io.save_weights(dlc_cfg.snapshot_prefix + "-step" + str(step) + "--" + str(it), w, fmt=fmt)
+            if it == max_iter:
+                weights_io.save_weights(dlc_cfg.snapshot_prefix + "-step" + str(step) + "-final--0", w, fmt=fmt)
+    print("Finish training {} iterations\n".format(it), flush=True)
+    lrf.close()
+    return None
 
 
 def fit_dgp_labeledonly(snapshot, dlcpath, shuffle=1, step=1, saveiters=1000, displayiters=5, maxiters=50000, ns=10,

@@ -79,9 +79,52 @@ class Trainer:
         if self._ws is None or nt > self._ws_nt:
             n = C.c_size_t()
             _lib.check(self.lib.dgp_trainer_workspace_bytes(self._t, nt, C.byref(n)))
-            self._ws = torch.empty(n.value, dtype=torch.uint8, device=self.device)
+            if self._ws is None or self._ws.numel() < n.value:
+                self._ws = torch.empty(n.value, dtype=torch.uint8, device=self.device)
             self._ws_nt = nt
         return self._ws
+
+    def set_input_size(self, in_h: int, in_w: int):
+        self.net.set_input_size(in_h, in_w)
+        self._ws_nt = 0
+
+    def _forward(self, frames: torch.Tensor):
+        nt = frames.shape[0]
+        if tuple(frames.shape[1:]) != (self.net.in_h, self.net.in_w, 3) or frames.dtype != torch.uint8:
+            raise _lib.DgpError("frames must be uint8 [nt,%d,%d,3], got %s %s" % (self.net.in_h, self.net.in_w,
+                                                                                  tuple(frames.shape), frames.dtype))
+        wsb = self.workspace(nt)
+        sc, lr = C.c_void_p(), C.c_void_p()
+        _lib.check(self.lib.dgp_train_forward(self._t, _ptr(frames), nt, _ptr(wsb), wsb.numel(), C.byref(sc), C.byref(lr),
+                                              _stream(self.device)), "dgp_train_forward")
+        nj, oh, ow = self.net.nj, self.net.out_h, self.net.out_w
+        return wsb, _view(sc.value, (nt, oh, ow, nj), self.device), _view(lr.value, (nt, oh, ow, 2 * nj), self.device)
+
+    def forward_backward_dlc(self, frames: torch.Tensor, part_score_targets, locref_targets, locref_mask,
+                             part_score_weights=None, locref_loss_weight: float = 0.05, locref_huber_loss: bool = True,
+                             location_refinement: bool = True):
+        """One DLC step-0 loss + gradients (pose_net.train, pose_net.py:159-190): frames uint8 [nt,H,W,3] on device,
+        targets fp32 device tensors of the scoremap size.  Returns {part_loss, locref_loss, total_loss}."""
+        frames = frames.contiguous()
+        wsb, pred, loc = self._forward(frames)
+        nt = frames.shape[0]
+        f32 = lambda t: None if t is None else torch.as_tensor(t, dtype=torch.float32, device=self.device).contiguous()
+        pt, pw, lt, lm = f32(part_score_targets), f32(part_score_weights), f32(locref_targets), f32(locref_mask)
+        if tuple(pt.shape) != tuple(pred.shape) or (location_refinement and tuple(lt.shape) != tuple(loc.shape)):
+            raise _lib.DgpError("target maps %s do not match the scoremap %s" % (tuple(pt.shape), tuple(pred.shape)))
+        dpred, dloc = torch.empty_like(pred), torch.zeros_like(loc)
+        losses = torch.empty(4, dtype=torch.float32, device=self.device)
+        scratch = torch.empty(4, dtype=torch.float64, device=self.device)
+        st = _stream(self.device)
+        _lib.check(self.lib.dgp_dlc_loss_fwd_bwd(_ptr(pred), _ptr(loc) if location_refinement else None, _ptr(pt),
+                                                 _ptr(pw) if pw is not None else None, _ptr(lt) if location_refinement else None,
+                                                 _ptr(lm) if location_refinement else None, nt, pred.shape[1], pred.shape[2],
+                                                 self.net.nj, float(locref_loss_weight), int(locref_huber_loss), _ptr(dpred),
+                                                 _ptr(dloc), _ptr(losses), _ptr(scratch), 32, st), "dgp_dlc_loss_fwd_bwd")
+        _lib.check(self.lib.dgp_train_backward(self._t, nt, _ptr(wsb), wsb.numel(), _ptr(dpred), _ptr(dloc), st),
+                   "dgp_train_backward")
+        l = losses.cpu().numpy()
+        return {"part_loss": float(l[0]), "locref_loss": float(l[1]), "total_loss": float(l[2])}
 
     def forward_backward(self, frames: torch.Tensor, batch: dict, hyper: DGPHyper, S0, ws, ws_max, n_frames_total,
                          n_visible_frames_total, labeled_only: bool = False):

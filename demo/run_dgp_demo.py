@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Counterpart of the reference's demo/run_dgp_demo.py (same flags, same project layout, same step order):
 
-  step 0  fit_dlc                    -> snapshot-step0-final--0   (DLC baseline; not built yet: pass --dlcsnapshot)
+  step 0  fit_dlc                    -> snapshot-step0-final--0   (DLC baseline; needs resnet_v1_<d>.ckpt in $DGP_PRETRAINED_DIR, or pass --dlcsnapshot)
   step 1  fit_dgp_labeledonly        -> snapshot-step1-final--0
   step 2  fit_dgp (gm2=1, gm3=3)     -> snapshot-step2-final--0
   step 3  plot_dgp / estimate_pose   -> <proj>/videos_pred/<video>_labeled.{csv,h5[,mp4]}

@@ -111,6 +111,11 @@ int  dgp_infer(dgp_net* net, const uint8_t* frames, int32_t batch, void* workspa
  * the caller's stream (no syncs until dgp_net_profile_launch reads them).  Used by bench.py for
  * the roofline object; the reference's only timing is time.time() around sess.run
  * (DGP/models/fitdgp.py:817-828). */
+/* Change the frame size of an existing net (weights stay).  DLC's step-0 loader feeds a differently scaled /
+ * cropped image every iteration (pose_defaultdataset.py:131-196: placeholders [1, None, None, 3]); workspaces
+ * are sized per call from the current geometry. */
+int  dgp_net_set_input_size(dgp_net* net, int32_t in_h, int32_t in_w);
+
 int  dgp_net_profile_begin(dgp_net* net, int32_t max_steps);
 int  dgp_net_profile_end(dgp_net* net, int32_t* n_steps, int32_t* n_launches);
 /* Average duration (ms, over the profiled steps), name and algorithmic FLOPs of launch i. */
@@ -145,6 +150,18 @@ int  dgp_loss_fwd_bwd(const dgp_loss_desc* d, const float* pred, const float* lo
                       const float* ws, const float* ws_max, const float* vector_field /* [nt-1,Hin,Win] or NULL */,
                       const float* wt_batch /* [nt-1] = wt * batch_mask, or NULL */, float* dpred, float* dlocref,
                       float* mu, float* losses, void* scratch, size_t scratch_bytes, void* stream);
+
+/* ---- DLC step-0 loss (fit_dlc: DGP/models/fitdgp.py:124; pose_net.train in DeepLabCut
+ * pose_estimation_tensorflow/nnet/pose_net.py:159-190, huber_loss in nnet/losses.py:16-45):
+ *   part_loss   = sum(w * sigmoid_ce(pred, part_targets)) / #nonzero(w)     (w = part_weights, NULL = all ones)
+ *   locref_loss = locref_loss_weight * sum(mask * huber(locref_pred - locref_targets)) / #nonzero(mask)
+ * All pointers device memory; locref_pred NULL = location_refinement off.  pred/part_* [nt,H,W,nj],
+ * locref_* [nt,H,W,2nj].  Writes dpred, dlocref and losses[4] = {part_loss, locref_loss, total_loss, 0}.
+ * scratch: >= 32 bytes, 8-byte aligned. */
+int  dgp_dlc_loss_fwd_bwd(const float* pred, const float* locref_pred, const float* part_targets,
+                          const float* part_weights, const float* locref_targets, const float* locref_mask, int32_t nt,
+                          int32_t H, int32_t W, int32_t nj, float locref_loss_weight, int32_t huber, float* dpred,
+                          float* dlocref, float* losses, void* scratch, size_t scratch_bytes, void* stream);
 
 /* ---- training step (config 4): replaces sess.run([loss, train_op]) of fit_dgp / fit_dgp_labeledonly
  * (DGP/models/fitdgp.py:708-713,818; 416-418,501-505).  The trainer owns the master parameters (flat fp32 buffer

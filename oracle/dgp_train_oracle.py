@@ -283,13 +283,37 @@ def temporal_flow_weights(P_t: np.ndarray, vector_field: np.ndarray, wt_batch: n
     return w
 
 
+# ------------------------------------------------------------------ DLC step-0 loss (N2)
+def dlc_loss(pred, locref_pred, part_targets, locref_targets, locref_mask, part_weights=None,
+             locref_loss_weight: float = 0.05, huber: bool = True):
+    """pose_net.train (DeepLabCut nnet/pose_net.py:159-190): tf.losses.sigmoid_cross_entropy (weights 1.0 or the
+    part_score_weights map; reduction SUM_BY_NONZERO_WEIGHTS) + locref_loss_weight * huber_loss(..., locref_mask)
+    (nnet/losses.py:16-45, same reduction: sum / number of non-zero weights, 0 when there are none)."""
+    ce = _sigmoid_ce(part_targets, pred)
+    if part_weights is None:
+        part = ce.mean()
+    else:
+        nz = (part_weights != 0).sum()
+        part = (ce * part_weights).sum() / nz if nz > 0 else ce.sum() * 0
+    out = {"part_loss": part, "total_loss": part}
+    if locref_pred is not None:
+        d = locref_pred - locref_targets
+        ad = d.abs()
+        el = torch.where(ad < 1.0, 0.5 * d * d, ad - 0.5) if huber else d * d
+        nz = (locref_mask != 0).sum()
+        loc = locref_loss_weight * ((el * locref_mask).sum() / nz if nz > 0 else el.sum() * 0)
+        out["locref_loss"] = loc
+        out["total_loss"] = part + loc
+    return out
+
+
 # ------------------------------------------------------------------ optimiser (B9)
 def momentum_step(P: Dict[str, torch.Tensor], V: Dict[str, torch.Tensor], lr: float, momentum: float = 0.9,
                   clip: float = 10.0):
     """clip_by_global_norm(10) then MomentumOptimizer: accum = m*accum + g ; var -= lr*accum (fitdgp.py:708-713)."""
     names = [k for k, t in P.items() if t.requires_grad and t.grad is not None]
     gn = torch.sqrt(sum((P[k].grad.double() ** 2).sum() for k in names)).item()
-    scale = clip / max(gn, clip)
+    scale = clip / max(gn, clip) if clip > 0 else 1.0          # clip <= 0: plain MomentumOptimizer (fit_dlc)
     with torch.no_grad():
         for k in names:
             g = P[k].grad * scale

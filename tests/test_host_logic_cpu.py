@@ -149,7 +149,7 @@ def test_weights_io_and_errors(tmp_path):
     with pytest.raises(FileNotFoundError):
         Wio.load_weights(str(tmp_path / "missing"))
     (tmp_path / "tfsnap.index").write_bytes(b"x")
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):                              # not an SSTable -> loud, never silently empty
         Wio.load_weights(str(tmp_path / "tfsnap"))
 
 
@@ -251,3 +251,38 @@ def test_frame_sharding_allgather_gloo_world2(T):
         np.testing.assert_array_equal(c[:, 1], fr / 100)
         np.testing.assert_array_equal(i[:, 0, 0], np.arange(T))             # int32 survives the bit-cast transport
         np.testing.assert_array_equal(i[:, 2, 1], np.full(T, 2))
+
+
+def test_dlc_pose_dataset_samples(tmp_path):
+    """Step-0 loader (pose_defaultdataset.PoseDataset): seeded schedule is reproducible, target maps have the
+    network's scoremap size for every jittered / cropped frame size, disks sit on the scaled labels."""
+    from _project import make_project
+    from deepgraphpose_amd import config as K
+    from deepgraphpose_amd.dlc_dataset import LearningRate, PoseDataset
+    from deepgraphpose_amd.arch import scoremap_hw
+    proj, frames, _ = make_project(tmp_path, hw=(120, 160))
+    cfg = K.get_train_config(K.read_config(os.path.join(proj, "config.yaml")), shuffle=1)
+    cfg.crop, cfg.cropratio, cfg.global_scale, cfg.pos_dist_thresh = True, 0.5, 0.8, 8
+    cfg.minsize, cfg.leftwidth, cfg.rightwidth, cfg.topheight, cfg.bottomheight = 30, 40, 40, 40, 40
+
+    def run(seed, n):
+        np.random.seed(seed); random.seed(seed)
+        ds = PoseDataset(cfg)
+        return [ds.next_batch() for _ in range(n)]
+    a, b = run(4, 9), run(4, 9)
+    sizes = set()
+    for x, y in zip(a, b):
+        assert x["data_item"].im_path == y["data_item"].im_path
+        np.testing.assert_array_equal(x["inputs"], y["inputs"])
+        np.testing.assert_array_equal(x["part_score_targets"], y["part_score_targets"])
+        _, H, W, _ = x["inputs"].shape
+        sizes.add((H, W))
+        assert x["inputs"].dtype == np.uint8
+        assert x["part_score_targets"].shape == (1,) + tuple(scoremap_hw(H, W)) + (3,)
+        assert x["locref_mask"].shape == (1,) + tuple(scoremap_hw(H, W)) + (6,)
+        assert (x["part_score_weights"] == 1).all()
+        np.testing.assert_array_equal(x["locref_mask"][..., 0::2], x["part_score_targets"])
+    assert len(sizes) > 3                                          # scale jitter and crops really change the size
+    assert len({x["data_item"].im_path for x in a[:4]}) == 4       # one pass visits every labeled image once
+    lr = LearningRate(SimpleNamespace(multi_step=[[0.001, 2], [0.005, 4]]))
+    assert [lr.get_lr(i) for i in range(5)] == [0.001, 0.001, 0.001, 0.005, 0.005]

@@ -231,3 +231,120 @@ def test_temporal_clique_matches_oracle(lib_built):
         assert abs(losses["total_loss"] - float(L["total_loss"].detach())) < 1e-4 * abs(float(L["total_loss"].detach()))
         gp = pt.grad.numpy()
         assert np.abs(dpred.cpu().numpy() - gp).max() <= 3e-4 * np.abs(gp).max()
+
+
+def _dlc_targets(rng, H, W, nj, scale=1.0):
+    from deepgraphpose_amd.dataset import compute_target_part_scoremap
+    oh, ow = 2 * -(-H // 16), 2 * -(-W // 16)
+    ids = [np.sort(rng.choice(nj, nj - 1, replace=False))]
+    coords = [np.stack([rng.uniform(4, W - 4, nj - 1), rng.uniform(4, H - 4, nj - 1)], 1)]
+    sc, lmap, lmask = compute_target_part_scoremap(ids, coords, (oh, ow), nj, 8, scale=scale)
+    return sc[None].astype(np.float32), lmap[None].astype(np.float32), lmask[None].astype(np.float32)
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_dlc_loss_kernel_matches_autograd(lib_built, weighted):
+    """N2: sigmoid-CE on binary disks + masked Huber (pose_net.train) forward and d/d heads vs fp64 autograd."""
+    import ctypes as C
+    from deepgraphpose_amd import _lib
+    from deepgraphpose_amd.engine import _ptr
+    from oracle import dgp_train_oracle as T
+    rng = np.random.default_rng(5)
+    nt, H, W, nj = 2, 23, 31, 3
+    pred = (rng.standard_normal((nt, H, W, nj)) * 3).astype(np.float32)
+    loc = (rng.standard_normal((nt, H, W, 2 * nj)) * 1.5).astype(np.float32)
+    pt = (rng.random((nt, H, W, nj)) < 0.1).astype(np.float32)
+    lm = np.repeat(pt, 2, axis=3)
+    lt = rng.standard_normal((nt, H, W, 2 * nj)).astype(np.float32) * lm
+    pw = None
+    if weighted:
+        pw = np.ones_like(pt); pw[..., 1] = 0.0
+    tp = torch.tensor(pred, dtype=torch.float64, requires_grad=True)
+    tl = torch.tensor(loc, dtype=torch.float64, requires_grad=True)
+    L = T.dlc_loss(tp, tl, torch.tensor(pt, dtype=torch.float64), torch.tensor(lt, dtype=torch.float64),
+                   torch.tensor(lm, dtype=torch.float64), None if pw is None else torch.tensor(pw, dtype=torch.float64), 0.05)
+    L["total_loss"].backward()
+    lib = _lib.load()
+    d = lambda a: torch.from_numpy(a).cuda()
+    dp, dl = torch.empty(pred.shape, device="cuda"), torch.empty(loc.shape, device="cuda")
+    losses, scratch = torch.empty(4, device="cuda"), torch.empty(4, dtype=torch.float64, device="cuda")
+    args = [d(pred), d(loc), d(pt), None if pw is None else d(pw), d(lt), d(lm)]
+    _lib.check(lib.dgp_dlc_loss_fwd_bwd(*[None if a is None else _ptr(a) for a in args], nt, H, W, nj, 0.05, 1, _ptr(dp),
+                                        _ptr(dl), _ptr(losses), _ptr(scratch), 32, None))
+    torch.cuda.synchronize()
+    got = losses.cpu().numpy()
+    assert abs(got[0] - float(L["part_loss"])) < 1e-5 * max(1, float(L["part_loss"]))
+    assert abs(got[1] - float(L["locref_loss"])) < 1e-5
+    assert abs(got[2] - float(L["total_loss"])) < 1e-5 * max(1, float(L["total_loss"]))
+    assert np.abs(dp.cpu().numpy() - tp.grad.numpy()).max() < 1e-6 * max(1e-3, np.abs(tp.grad.numpy()).max()) + 1e-10
+    assert np.abs(dl.cpu().numpy() - tl.grad.numpy()).max() < 1e-6 * max(1e-3, np.abs(tl.grad.numpy()).max()) + 1e-10
+    # empty mask: locref loss 0, gradient 0 (div_no_nan)
+    z = torch.zeros_like(d(lm))
+    _lib.check(lib.dgp_dlc_loss_fwd_bwd(_ptr(args[0]), _ptr(args[1]), _ptr(args[2]), None, _ptr(args[4]), _ptr(z), nt, H, W, nj,
+                                        0.05, 1, _ptr(dp), _ptr(dl), _ptr(losses), _ptr(scratch), 32, None))
+    torch.cuda.synchronize()
+    assert float(losses[1]) == 0.0 and float(dl.abs().max()) == 0.0
+
+
+def test_dlc_steps_with_changing_frame_size_match_oracle(lib_built):
+    """fit_dlc inner loop: every iteration has another frame size (scale jitter / crop); two momentum steps without
+    clipping vs the fp32 torch oracle, then a third size for a forward-only parity check of the re-planned net."""
+    from deepgraphpose_amd import synthetic
+    from deepgraphpose_amd.train import Trainer
+    from oracle import dgp_train_oracle as T
+    nj = 3
+    wts = synthetic.make_weights(50, nj, True, seed=11, head_std=0.05)
+    rng = np.random.default_rng(3)
+    tr = Trainer(50, nj, 64, 64, max_frames=1)
+    tr.load_weights(wts)
+    P = T.make_params(wts, torch.float32)
+    V = {}
+    for it, (H, W) in enumerate([(70, 101), (48, 64)]):
+        frames = synthetic.make_frames(1, H, W, nj, seed=it)
+        sc, lmap, lmask = _dlc_targets(rng, H, W, nj)
+        tr.set_input_size(H, W)
+        losses = tr.forward_backward_dlc(torch.from_numpy(frames).cuda(), sc, lmap, lmask, locref_loss_weight=0.05)
+        gn = tr.apply_gradients(0.005, 0.9, clip_norm=0.0)
+        pred, loc = T.network(frames, P, 50, torch.float32)
+        assert tuple(pred.shape) == sc.shape
+        L = T.dlc_loss(pred, loc, torch.from_numpy(sc), torch.from_numpy(lmap), torch.from_numpy(lmask), None, 0.05)
+        L["total_loss"].backward()
+        gn_ref = T.momentum_step(P, V, 0.005, clip=0.0)
+        assert abs(losses["total_loss"] - float(L["total_loss"].detach())) < 2e-4 * max(1.0, float(L["total_loss"].detach()))
+        assert abs(gn - gn_ref) < 3e-3 * gn_ref
+    w = tr.get_weights()
+    for k, t in P.items():
+        ref = t.detach().numpy()
+        assert np.abs(w[k].reshape(ref.shape) - ref).max() <= 1e-4 * (np.abs(ref).max() + 1e-6) + 1e-6, k
+
+
+def test_fit_dlc_driver(lib_built, tmp_path):
+    """fit_dlc (step 0) on the synthetic project from a V1 'ImageNet' checkpoint written by tf_checkpoint: runs, logs,
+    writes snapshot-step0-final--0, and fit_dgp_labeledonly can start from it."""
+    import os, random
+    from _project import make_project
+    from deepgraphpose_amd import tf_checkpoint, weights_io
+    from deepgraphpose_amd.models.fitdgp import fit_dlc, fit_dgp_labeledonly
+    from deepgraphpose_amd.models.fitdgp_util import get_snapshot_path
+    proj, frames, wts = make_project(tmp_path, hw=(96, 128))
+    snap0, _ = get_snapshot_path("snapshot-step0-final--0", proj, shuffle=1)
+    os.remove(snap0 + ".npz")                                   # make_project seeds one; step 0 must create it
+    pre = tmp_path / "pretrained"
+    pre.mkdir()
+    backbone = {k: v for k, v in wts.items() if k.startswith("resnet_v1_50")}
+    backbone["resnet_v1_50/logits/biases"] = np.zeros(1000, dtype=np.float32)
+    tf_checkpoint.write_v1(str(pre / "resnet_v1_50.ckpt"), backbone)
+    os.environ["DGP_PRETRAINED_DIR"] = str(pre)
+    try:
+        np.random.seed(0); random.seed(0)
+        fit_dlc("resnet_v1_50.ckpt", proj, shuffle=1, step=0, saveiters=3, displayiters=2, maxiters=5)
+    finally:
+        del os.environ["DGP_PRETRAINED_DIR"]
+    assert os.path.isfile(snap0 + ".npz") and os.path.isfile(os.path.join(os.path.dirname(snap0), "snapshot-step0--3.npz"))
+    w0 = weights_io.load_weights(snap0)
+    assert all(np.isfinite(v).all() for v in w0.values())
+    assert np.abs(w0["resnet_v1_50/conv1/weights"] - wts["resnet_v1_50/conv1/weights"]).max() > 0
+    stats = open(os.path.join(os.path.dirname(snap0), "learning_stats.csv")).read().strip().splitlines()
+    assert len(stats) == 2 and stats[0].startswith("iteration: 2, loss: total loss ")
+    assert fit_dlc("resnet_v1_50.ckpt", proj, maxiters=5) is None            # skip-if-exists guard (fitdgp.py:113-117)
+    fit_dgp_labeledonly("snapshot-step0-final--0", proj, shuffle=1, step=1, maxiters=2, displayiters=1, aug=False)
