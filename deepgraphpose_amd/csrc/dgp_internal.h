@@ -34,7 +34,7 @@ struct ConvArgs {
     unsigned in_bytes, w_bytes, res_bytes, out_bytes;   // buffer-descriptor extents (< 4 GiB each)
 };
 
-enum TileCfg { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_128x32 = 3, TILE_128x128_W8 = 4, TILE_128x128_LS = 5, TILE_128x64_LS = 6 };
+enum TileCfg { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_128x32 = 3, TILE_128x128_W8 = 4, TILE_128x128_LS = 5, TILE_128x64_LS = 6, TILE_128x128_S6 = 7, TILE_128x128_S3 = 8, TILE_128x64_S6 = 9, TILE_128x128_S6K16 = 10, TILE_128x128_S3K16 = 11 };
 
 hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s);
 int        pick_tile(int M, int CoutP, int K);

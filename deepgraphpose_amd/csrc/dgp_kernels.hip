@@ -400,6 +400,80 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_f32(const C
 #endif
 }
 
+// Epilogue of the loader-specialised kernels (compute waves only; wave-private LDS staging, no workgroup
+// barriers: the loader waves are gone).  acc -> scale/bias/residual/ReLU/mask -> 16-byte stores.
+template <int TM, int TN, int WN>
+__device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[TM][TN], char* smem, int wave, int lane,
+                                            int m0, int n0, int wave_m0, int wave_n0) {
+    constexpr int LDC = WN + 4;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int HoWo = p.Ho * p.Wo;
+    float* sC = reinterpret_cast<float*>(smem) + wave * (32 * LDC);
+    constexpr int C4 = WN / 4;
+    constexpr int NV = 32 * C4 / 64;
+    const __amdgpu_buffer_rsrc_t rs_res =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.in), 0, p.res ? (int)p.res_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_mask =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.mask ? p.mask : p.in), 0, p.mask ? (int)p.out_bytes : 0, 0x00020000);
+    const int my_c4 = lane % C4;
+    const int my_r0 = lane / C4;
+    const int co4 = n0 + wave_n0 + 4 * my_c4;
+    const bool cok = co4 < p.Cout;
+    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), bi4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cok && p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + co4);
+    if (cok && p.bias) bi4 = *reinterpret_cast<const float4*>(p.bias + co4);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own reads of the previous pass are done
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                sC[row * LDC + 32 * j + l31] = acc[i][j][r];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // a wave's LDS ops complete in order
+        unsigned ooff[NV];
+        float4 rres[NV], rmask[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int row = my_r0 + v * (64 / C4);
+            const int m = m0 + wave_m0 + 32 * i + row;
+            const bool ok = cok && m < p.M;
+            ooff[v] = ok ? ((unsigned)(m * p.Cout + co4) << 2) : OOB;
+            unsigned roff = OOB;
+            if (p.res_s == 1) {
+                roff = ooff[v];
+            } else if (p.res_s == -2 && ok) {
+                const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                if (!((ho | wo) & 1)) roff = (unsigned)(((n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1)) * p.Cout + co4) << 2;
+            } else if (p.res_s > 1 && ok) {
+                const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                roff = (unsigned)(((n * p.res_H + ho * p.res_s) * p.res_W + wo * p.res_s) * p.Cout + co4) << 2;
+            }
+            rres[v] = buf_load16(rs_res, roff);
+            rmask[v] = buf_load16(rs_mask, ooff[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int row = my_r0 + v * (64 / C4);
+            const float4 a = *reinterpret_cast<const float4*>(sC + row * LDC + 4 * my_c4);
+            float4 o;
+            o.x = a.x * sc4.x + bi4.x + rres[v].x;
+            o.y = a.y * sc4.y + bi4.y + rres[v].y;
+            o.z = a.z * sc4.z + bi4.z + rres[v].z;
+            o.w = a.w * sc4.w + bi4.w + rres[v].w;
+            if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            if (p.mask) {
+                o.x = rmask[v].x > 0.f ? o.x : 0.f; o.y = rmask[v].y > 0.f ? o.y : 0.f;
+                o.z = rmask[v].z > 0.f ? o.z : 0.f; o.w = rmask[v].w > 0.f ? o.w : 0.f;
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)ooff[v], 0, 0);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Loader-specialised variant (Cin >= 32, NHWC output): the workgroup has 4 COMPUTE waves (2 x 2 over the tile)
 // that only issue ds_read_b128 + MFMA, and 4 LOADER waves that only issue buffer loads + ds_write.  A
@@ -586,71 +660,7 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_f32_ls(const ConvArgs p) {
     }
 #endif
 
-    // ---- epilogue (compute waves only; wave-private LDS staging, no workgroup barriers: the loader waves are gone)
-    float* sC = reinterpret_cast<float*>(smem) + wave * (32 * LDC);
-    constexpr int C4 = WN / 4;
-    constexpr int NV = 32 * C4 / 64;
-    const __amdgpu_buffer_rsrc_t rs_res =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.in), 0, p.res ? (int)p.res_bytes : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_mask =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.mask ? p.mask : p.in), 0, p.mask ? (int)p.out_bytes : 0, 0x00020000);
-    const int my_c4 = lane % C4;
-    const int my_r0 = lane / C4;
-    const int co4 = n0 + wave_n0 + 4 * my_c4;
-    const bool cok = co4 < p.Cout;
-    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), bi4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cok && p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + co4);
-    if (cok && p.bias) bi4 = *reinterpret_cast<const float4*>(p.bias + co4);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own reads of the previous pass are done
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                sC[row * LDC + 32 * j + l31] = acc[i][j][r];
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // a wave's LDS ops complete in order
-        unsigned ooff[NV];
-        float4 rres[NV], rmask[NV];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int row = my_r0 + v * (64 / C4);
-            const int m = m0 + wave_m0 + 32 * i + row;
-            const bool ok = cok && m < p.M;
-            ooff[v] = ok ? ((unsigned)(m * p.Cout + co4) << 2) : OOB;
-            unsigned roff = OOB;
-            if (p.res_s == 1) {
-                roff = ooff[v];
-            } else if (p.res_s == -2 && ok) {
-                const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                if (!((ho | wo) & 1)) roff = (unsigned)(((n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1)) * p.Cout + co4) << 2;
-            } else if (p.res_s > 1 && ok) {
-                const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                roff = (unsigned)(((n * p.res_H + ho * p.res_s) * p.res_W + wo * p.res_s) * p.Cout + co4) << 2;
-            }
-            rres[v] = buf_load16(rs_res, roff);
-            rmask[v] = buf_load16(rs_mask, ooff[v]);
-        }
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int row = my_r0 + v * (64 / C4);
-            const float4 a = *reinterpret_cast<const float4*>(sC + row * LDC + 4 * my_c4);
-            float4 o;
-            o.x = a.x * sc4.x + bi4.x + rres[v].x;
-            o.y = a.y * sc4.y + bi4.y + rres[v].y;
-            o.z = a.z * sc4.z + bi4.z + rres[v].z;
-            o.w = a.w * sc4.w + bi4.w + rres[v].w;
-            if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-            if (p.mask) {
-                o.x = rmask[v].x > 0.f ? o.x : 0.f; o.y = rmask[v].y > 0.f ? o.y : 0.f;
-                o.z = rmask[v].z > 0.f ? o.z : 0.f; o.w = rmask[v].w > 0.f ? o.w : 0.f;
-            }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)ooff[v], 0, 0);
-        }
-    }
+    ls_epilogue<TM, TN, WN>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0);
 }
 
 template <int BM, int BN>
@@ -686,6 +696,261 @@ static hipError_t launch_conv_ls(ConvArgs a, hipStream_t s) {
                BM, BN, nwg, a.nk, v[0], v[4] / a.nk, v[7] / a.nk);
     }
 #endif
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// Split-bf16 variant of the loader-specialised kernel: fp32-equivalent products on the bf16 matrix pipe.
+//
+// Every fp32 operand is cut into three bf16 pieces by truncation, x = x1 + x2 + x3 EXACTLY (3 x 8 significant
+// bits, each piece starts at the leading one of what is left), and a product is accumulated in fp32 as
+//     NT = 6:  x1 y1 + (x1 y2 + x2 y1) + (x2 y2 + x1 y3 + x3 y1)      dropped terms <= 2^-23 |x y|  (fp32-class)
+//     NT = 3:  x1 y1 + (x1 y2 + x2 y1)                                 dropped terms <= 2^-15 |x y|
+// bf16 x bf16 products are exact in fp32, so the only roundings are the fp32 accumulations -- the same kind of
+// error as the fp32 MFMA chain.  v_mfma_f32_32x32x16_bf16 runs 16x the FLOP rate of v_mfma_f32_32x32x2_f32, so six of
+// them per fp32-equivalent product are 2.67x the fp32 matrix peak.
+//
+// The 4 loader waves fetch fp32 (same bytes as the fp32 kernel: the L2 -> L1 path is the other ceiling), split in
+// registers (22 VALU per 16-byte load) and write three bf16 planes in MFMA operand order:
+//     plane[pl][kg = k/8][row][8 bf16]      (16 B per row and k-group; a lane pair writes one 16-B cell)
+// A compute lane (row = lane & 31, half = lane >> 5) reads k-group 2*kk + half of its row with ONE ds_read_b128 per
+// plane; 32 lanes read 512 contiguous bytes.  Plane pitch BM + 4 rows keeps the loaders' 8-byte writes conflict-free.
+// ------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3_bf16(const float4 v, uint2& p1, uint2& p2, uint2& p3) {
+    const unsigned M = 0xFFFF0000u;
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned h1[4], h2[4], h3[4];
+#ifdef DGP_EXP_FAKE_SPLIT       // tuning experiment only (wrong numerics): what the split arithmetic costs
+    p1.x = __builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), 0x07060302);
+    p1.y = __builtin_amdgcn_perm(__float_as_uint(x[3]), __float_as_uint(x[2]), 0x07060302);
+    p2 = p1; p3 = p1;
+    return;
+#endif
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h1[i] = __float_as_uint(x[i]) & M;
+        const float r1 = x[i] - __uint_as_float(h1[i]);           // exact
+        h2[i] = __float_as_uint(r1) & M;
+        h3[i] = __float_as_uint(r1 - __uint_as_float(h2[i]));     // exact; <= 8 significant bits left
+    }
+    p1.x = __builtin_amdgcn_perm(h1[1], h1[0], 0x07060302); p1.y = __builtin_amdgcn_perm(h1[3], h1[2], 0x07060302);
+    p2.x = __builtin_amdgcn_perm(h2[1], h2[0], 0x07060302); p2.y = __builtin_amdgcn_perm(h2[3], h2[2], 0x07060302);
+    p3.x = __builtin_amdgcn_perm(h3[1], h3[0], 0x07060302); p3.y = __builtin_amdgcn_perm(h3[3], h3[2], 0x07060302);
+}
+
+// BK = 32: one workgroup per CU (101 KB of LDS for 128 x 128); BK = 16: half the LDS and <= 128 registers, so TWO
+// workgroups share a CU and one's prologue / epilogue / barrier waits run under the other's MFMAs.
+template <int BM, int BN, int NT, int BK>
+__global__ __launch_bounds__(512, BK == 16 ? 4 : 2) void conv_igemm_split_ls(const ConvArgs p) {
+    constexpr int WM = BM / 2, WN = BN / 2;        // compute waves 2 x 2
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int NLT = 256;                       // loader threads
+    constexpr int CH = BK / 4;                     // 16-byte chunks per row and K-step
+    constexpr int KG = BK / 8;                     // k-groups (8 bf16 = one MFMA operand register quad) per K-step
+    constexpr int RG = NLT / CH;
+    constexpr int AROWS = BM / RG;
+    constexpr int BSLOTS = KG * BN / 128;          // cells per loader lane pair
+    constexpr int NP = NT == 6 ? 3 : 2;            // bf16 planes per operand
+    constexpr int LDA = BM + (BK == 32 ? 4 : 8);   // k-group pitch in rows: the loaders' 8-byte writes of a half-wave cover all banks once
+    constexpr int LDB = BN + 4;
+    constexpr int A_CELLS = NP * KG * LDA, B_CELLS = NP * KG * LDB;     // 16-byte cells per buffer
+    constexpr int LDC = WN + 4;
+    static_assert(NT == 3 || NT == 6, "3 or 6 bf16 products per fp32-equivalent product");
+    static_assert(BK == 16 || BK == 32, "K-step of 16 or 32 floats");
+    static_assert(BN == 128 || BN == 64, "B staging map assumes 64 or 128 columns");     // (launcher sizes LDS for the epilogue too)
+    static_assert(BSLOTS >= 1 && AROWS >= 1, "tile too small for 256 loader lanes");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* sA = reinterpret_cast<uint4*>(smem);       // [2][NP][KG][LDA]
+    uint4* sB = sA + 2 * A_CELLS;                     // [2][NP][KG][LDB]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, loc = b >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = tile / p.ntiles;
+    const int nt = tile - mt * p.ntiles;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
+    const int HoWo = p.Ho * p.Wo;
+    const int nks = p.nk * (32 / BK);               // K-steps of BK floats (weight panels are padded to 32)
+
+    if (wave >= 4) {
+        // ================================ loader waves ================================
+        const int t = threadIdx.x - 256;
+        const __amdgpu_buffer_rsrc_t rs_in =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)p.in_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (int)p.w_bytes, 0x00020000);
+        const int c = t % CH, rg = t / CH;
+        int hi0[AROWS], wi0[AROWS], rowoff[AROWS], nbase[AROWS];
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            const int m = m0 + rg + RG * i;
+            if (m < p.M) {
+                const int n = m / HoWo;
+                const int rem = m - n * HoWo;
+                const int ho = rem / p.Wo;
+                const int wo = rem - ho * p.Wo;
+                hi0[i] = ho * p.stride - p.pad_t;
+                wi0[i] = wo * p.stride - p.pad_l;
+                rowoff[i] = (((n * p.H + hi0[i]) * p.W + wi0[i]) * p.Cin + 4 * c) * 4;
+                nbase[i] = n * p.H * p.W;
+            } else {
+                hi0[i] = -(1 << 28); wi0[i] = -(1 << 28); rowoff[i] = 0; nbase[i] = 0;
+            }
+        }
+        // B: lane pair (2j, 2j+1) owns chunks (2 kg, 2 kg + 1) of one column, so the pair fills one 16-byte LDS cell
+        const unsigned b_row_bytes = (unsigned)p.CoutP * 16u;
+        const int bq = t >> 1, bpar = t & 1;                    // pair index over [kg][col], chunk parity
+        const int bcol = bq & (BN - 1), bkg0 = bq / BN;         // slot i covers k-group bkg0 + i * (128 / BN)
+        const unsigned b_lane_off = (unsigned)(2 * bkg0 + bpar) * b_row_bytes + (unsigned)((n0 + bcol) * 16);
+        int w_kh = 0, w_kw = 0, w_ch = 0, w_tap = 0;
+        float4 ra0[AROWS], rb0[BSLOTS], ra1[AROWS], rb1[BSLOTS];
+        auto gload = [&](int ks, float4 (&ra)[AROWS], float4 (&rb)[BSLOTS]) {
+            const int dh = w_kh * p.dil, dw = w_kw * p.dil;
+            const int doff = ((dh * p.W + dw) * p.Cin + w_ch) * 4;
+            const bool tapok = w_tap < p.ntaps;
+            if (p.up == 2) {
+#pragma unroll
+                for (int i = 0; i < AROWS; ++i) {
+                    const int hv = hi0[i] + dh, wv = wi0[i] + dw;
+                    const bool ok = tapok && !((hv | wv) & 1) && (unsigned)(hv >> 1) < (unsigned)p.H &&
+                                    (unsigned)(wv >> 1) < (unsigned)p.W;
+                    const unsigned off = (unsigned)((nbase[i] + (hv >> 1) * p.W + (wv >> 1)) * p.Cin + w_ch + 4 * c) << 2;
+                    ra[i] = buf_load16(rs_in, ok ? off : OOB);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < AROWS; ++i) {
+                    const int hi = hi0[i] + dh, wi = wi0[i] + dw;
+                    const bool ok = tapok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                    ra[i] = buf_load16(rs_in, ok ? (unsigned)(rowoff[i] + doff) : OOB);
+                }
+            }
+            w_ch += BK;
+            if (w_ch >= p.Cin) {
+                w_ch = 0; ++w_tap;
+                if (++w_kw == p.KW) { w_kw = 0; ++w_kh; }
+            }
+            const unsigned kbase = (unsigned)(ks * CH) * b_row_bytes;
+#pragma unroll
+            for (int i = 0; i < BSLOTS; ++i)
+                rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                            rs_w, (int)b_lane_off, (int)(kbase + (unsigned)(2 * i * (128 / BN)) * b_row_bytes), 0));
+        };
+        auto lstore = [&](int buf, float4 (&ra)[AROWS], float4 (&rb)[BSLOTS]) {
+            uint2* a = reinterpret_cast<uint2*>(sA + buf * A_CELLS) + (((c >> 1) * LDA + rg) * 2 + (c & 1));
+#pragma unroll
+            for (int i = 0; i < AROWS; ++i) {
+                uint2 p1, p2, p3;
+                split3_bf16(ra[i], p1, p2, p3);
+                a[(RG * i) * 2] = p1;
+                a[(KG * LDA + RG * i) * 2] = p2;
+                if (NP == 3) a[(2 * KG * LDA + RG * i) * 2] = p3;
+            }
+            uint2* b = reinterpret_cast<uint2*>(sB + buf * B_CELLS) + ((bkg0 * LDB + bcol) * 2 + bpar);
+#pragma unroll
+            for (int i = 0; i < BSLOTS; ++i) {
+                uint2 p1, p2, p3;
+                split3_bf16(rb[i], p1, p2, p3);
+                const int o = i * (128 / BN) * LDB * 2;
+                b[o] = p1;
+                b[KG * LDB * 2 + o] = p2;
+                if (NP == 3) b[2 * KG * LDB * 2 + o] = p3;
+            }
+        };
+        gload(0, ra0, rb0);
+        lstore(0, ra0, rb0);
+        if (nks > 1) gload(1, ra1, rb1);
+        if (nks > 2) gload(2, ra0, rb0);
+        __syncthreads();
+        for (int ks = 0; ks < nks; ks += 2) {
+            if (ks + 1 < nks) lstore(1, ra1, rb1);
+            if (ks + 3 < nks) gload(ks + 3, ra1, rb1);
+            __syncthreads();
+            if (ks + 1 >= nks) break;
+            if (ks + 2 < nks) lstore(0, ra0, rb0);
+            if (ks + 4 < nks) gload(ks + 4, ra0, rb0);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ================================== compute waves ==================================
+    const int wave_m0 = (wave >> 1) * WM;
+    const int wave_n0 = (wave & 1) * WN;
+    const int half = lane >> 5, l31 = lane & 31;
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    __syncthreads();
+    for (int ks = 0; ks < nks; ++ks) {
+        const int buf = ks & 1;
+        const uint4* a_base = sA + buf * A_CELLS + wave_m0 + l31;
+        const uint4* b_base = sB + buf * B_CELLS + wave_n0 + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int kg = 2 * kk + half;
+            bf16x8 af[NP][TM], bf[NP][TN];
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[pl][i] = __builtin_bit_cast(bf16x8, a_base[(pl * KG + kg) * LDA + 32 * i]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[pl][j] = __builtin_bit_cast(bf16x8, b_base[(pl * KG + kg) * LDB + 32 * j]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    floatx16 a = acc[i][j];
+                    if (NT == 6) {          // smallest terms first
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP - 1][i], bf[0][j], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[NP - 1][j], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], a, 0, 0, 0);
+                    }
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], a, 0, 0, 0);
+                    acc[i][j] = a;
+                }
+        }
+        __syncthreads();
+    }
+    ls_epilogue<TM, TN, WN>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0);
+}
+
+template <int BM, int BN, int NT, int BK>
+static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
+    constexpr int NP = NT == 6 ? 3 : 2;
+    constexpr int KG = BK / 8;
+    const size_t smem_loop = (size_t)2 * (NP * KG * (BM + (BK == 32 ? 4 : 8)) + NP * KG * (BN + 4)) * 16;
+    const size_t smem_epi = (size_t)4 * 32 * (BN / 2 + 4) * 4;
+    const size_t smem = smem_loop > smem_epi ? smem_loop : smem_epi;
+    a.mtiles = (a.M + BM - 1) / BM;
+    a.ntiles = (a.CoutP + BN - 1) / BN;
+    if (a.CoutP % BN != 0 || a.Cin < 32 || a.out_mode != 0) return hipErrorInvalidValue;
+    auto kern = conv_igemm_split_ls<BM, BN, NT, BK>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const long long nwg = (long long)a.mtiles * a.ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), smem, s, a);
     return hipGetLastError();
 }
 
@@ -740,8 +1005,9 @@ int pick_tile(int M, int CoutP, int K) {
     if (CoutP <= 32) return TILE_128x32;
     if (const char* f = getenv("DGP_FORCE_TILE")) {     // tuning experiments only
         const int v = atoi(f);
-        if ((v == TILE_128x128 || v == TILE_128x128_W8 || v == TILE_128x128_LS) && CoutP % 128 == 0) return v;
-        if (v == TILE_128x64_LS && CoutP % 64 == 0) return v;
+        if ((v == TILE_128x128 || v == TILE_128x128_W8 || v == TILE_128x128_LS || v == TILE_128x128_S6 ||
+             v == TILE_128x128_S3 || v == TILE_128x128_S6K16 || v == TILE_128x128_S3K16) && CoutP % 128 == 0) return v;
+        if ((v == TILE_128x64_LS || v == TILE_128x64_S6) && CoutP % 64 == 0) return v;
         if ((v == TILE_128x64 || v == TILE_64x64) && CoutP % 64 == 0) return v;
     }
     static const int rule = getenv("DGP_TILE_RULE") ? atoi(getenv("DGP_TILE_RULE")) : 2;   // A/B switch for tuning runs
@@ -762,7 +1028,8 @@ int pick_tile(int M, int CoutP, int K) {
 hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s) {
     if (a.Cin < 32) {       // generic per-lane tap path (stem / small test shapes)
         if (tile_cfg == TILE_128x32) return launch_conv_t<128, 32, 4, 1, false>(a, s);
-        if (tile_cfg == TILE_128x128_W8 || tile_cfg == TILE_128x128_LS) tile_cfg = TILE_128x128;
+        if (tile_cfg == TILE_128x128_W8 || tile_cfg == TILE_128x128_LS || tile_cfg == TILE_128x128_S6 ||
+            tile_cfg == TILE_128x128_S3 || tile_cfg == TILE_128x128_S6K16 || tile_cfg == TILE_128x128_S3K16) tile_cfg = TILE_128x128;
         if (a.CoutP % 128 == 0 && tile_cfg == TILE_128x128) return launch_conv_t<128, 128, 2, 2, false>(a, s);
         return launch_conv_t<128, 64, 2, 2, false>(a, s);
     }
@@ -773,6 +1040,11 @@ hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s) {
         case TILE_128x128_W8: return launch_conv_t<128, 128, 2, 4, true>(a, s);
         case TILE_128x128_LS: return a.out_mode == 0 ? launch_conv_ls<128, 128>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
         case TILE_128x64_LS:  return a.out_mode == 0 ? launch_conv_ls<128, 64>(a, s) : launch_conv_t<128, 64, 2, 2, true>(a, s);
+        case TILE_128x128_S6: return a.out_mode == 0 ? launch_conv_split<128, 128, 6, 32>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
+        case TILE_128x128_S3: return a.out_mode == 0 ? launch_conv_split<128, 128, 3, 32>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
+        case TILE_128x128_S6K16: return a.out_mode == 0 ? launch_conv_split<128, 128, 6, 16>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
+        case TILE_128x128_S3K16: return a.out_mode == 0 ? launch_conv_split<128, 128, 3, 16>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
+        case TILE_128x64_S6:  return a.out_mode == 0 ? launch_conv_split<128, 64, 6, 32>(a, s) : launch_conv_t<128, 64, 2, 2, true>(a, s);
         default:          return launch_conv_t<128, 128, 2, 2, true>(a, s);
     }
 }

@@ -5,20 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from deepgraphpose_amd import engine
 
-LAYERS = [  # name, N,H,W,Cin,Cout,k,stride,rate,pad
-    ("b1.conv1 256->64", 32, 120, 160, 256, 64, 1, 1, 1, 0),
-    ("b1.conv2 3x3 64", 32, 120, 160, 64, 64, 3, 1, 1, 1),
-    ("b1.conv3 64->256", 32, 120, 160, 64, 256, 1, 1, 1, 0),
-    ("b2.conv2 3x3 128", 32, 60, 80, 128, 128, 3, 1, 1, 1),
-    ("b2.conv3 128->512", 32, 60, 80, 128, 512, 1, 1, 1, 0),
-    ("b3.conv1 1024->256", 32, 30, 40, 1024, 256, 1, 1, 1, 0),
-    ("b3.conv2 3x3 256", 32, 30, 40, 256, 256, 3, 1, 1, 1),
-    ("b3.conv3 256->1024", 32, 30, 40, 256, 1024, 1, 1, 1, 0),
-    ("b4.conv1 2048->512", 32, 30, 40, 2048, 512, 1, 1, 1, 0),
-    ("b4.conv2 3x3d2 512", 32, 30, 40, 512, 512, 3, 1, 2, 2),
-    ("b4.conv3 512->2048", 32, 30, 40, 512, 2048, 1, 1, 1, 0),
-    ("b4.short 1024->2048", 32, 30, 40, 1024, 2048, 1, 1, 1, 0),
-]
+from scripts.conv_sweep_layers import LAYERS
 BIG = int(os.environ.get("SWEEP_BATCH_MULT", "1"))
 only = sys.argv[1:] 
 rng = np.random.default_rng(0)
