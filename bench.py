@@ -32,6 +32,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16)
+
+
+def kernel_peak(kernel: str) -> float:
+    """Matrix-pipe ceiling of a conv kernel in fp32-equivalent TFLOP/s: the split kernels issue 6 (or 3) bf16 MFMAs
+    per fp32-equivalent product, so their ceiling is the dense bf16 peak / 6 (/ 3)."""
+    if kernel.startswith("split6"):
+        return PEAK_BF16_MFMA_TFLOPS / 6.0
+    if kernel.startswith("split3"):
+        return PEAK_BF16_MFMA_TFLOPS / 3.0
+    return PEAK_F32_MFMA_TFLOPS
 H, W, NJ, BATCH = 480, 640, 4, 32
 STRIDE = 8.0
 
@@ -129,23 +140,56 @@ def main():
     conv_ms = sum(ms for _, _, ms in conv)
     conv_flops = sum(f for _, f, _ in conv)
     other_ms = sum(ms for n, _, ms in launches if not n.startswith("conv:"))
-    achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    stack_tf = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    from deepgraphpose_amd.arch import conv_algorithmic_bytes
+    alg_bytes = conv_algorithmic_bytes(H, W, 50, B)
+    # per-kernel breakdown (the engine tags every conv launch with the kernel it ran); the roofline object is for
+    # the DOMINANT kernel = the one with the largest share of the step
+    by_kernel = {}
+    for n, f, ms in conv:
+        k = n.split("|")[1] if "|" in n else "f32"
+        e = by_kernel.setdefault(k, [0, 0.0, 0.0])
+        e[0] += 1; e[1] += f; e[2] += ms
+    dom = max(by_kernel, key=lambda k: by_kernel[k][2])
+    d_n, d_f, d_ms = by_kernel[dom]
+    achieved = d_f / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0
+    peak = kernel_peak(dom)
+    kname = {"f32": "conv_igemm_f32 / conv_igemm_f32_ls (v_mfma_f32_32x32x2_f32)"}.get(
+        dom, "conv_igemm_split_ls<%s> (fp32-equivalent products as %s v_mfma_f32_32x32x16_bf16)" % (dom, dom[5]))
     roofline = {
-        "bound": "mfma", "kernel": "conv_igemm_f32 (all %d conv launches of one step)" % len(conv),
-        "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        "bound": "mfma", "kernel": "%s, %d of the %d conv launches of a step" % (kname, d_n, len(conv)),
+        "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "traffic": None,
+        "peak_basis": ("dense bf16 MFMA peak %.0f TFLOP/s / %s partial products per fp32-equivalent product; achieved counts "
+                       "ALGORITHMIC conv FLOPs" % (PEAK_BF16_MFMA_TFLOPS, dom[5])) if dom.startswith("split")
+                      else "dense fp32 MFMA peak",
+        "kernel_ms_per_step": round(d_ms, 3),
+        "kernels": {k: {"launches": v[0], "ms_per_step": round(v[2], 3), "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 1),
+                        "frac_of_its_peak": round(v[1] / (v[2] * 1e-3) / 1e12 / kernel_peak(k), 4)}
+                    for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][2])},
+        "conv_stack_tflops": round(stack_tf, 2),
+        "conv_stack_vs_fp32_mfma_peak": round(stack_tf / PEAK_F32_MFMA_TFLOPS, 4),
         "algorithmic_gflop_per_frame": round(flop_frame / 1e9, 3),
         "conv_ms_per_step": round(conv_ms, 3), "other_kernels_ms_per_step": round(other_ms, 3),
         "steps_profiled": n_prof,
-        "whole_step_frac": round(flop_frame * B / (elapsed / K) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
     }
-    # HBM traffic of the conv launches of one step, from the committed rocprofv3 PMC passes of this same
-    # command (scripts/profile.sh -> profiles/traffic_r1.json); null when no profile has been taken.
+    # HBM traffic of the dominant kernel, per launch, from the committed rocprofv3 PMC passes of this same command
+    # (scripts/profile.sh -> profiles/traffic_r1.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate
+    # passes); null when no profile of this kernel has been taken.
     tj = os.path.join(ROOT, "profiles", "traffic_r1.json")
     if os.path.exists(tj):
         try:
-            roofline["traffic"] = float(json.load(open(tj))["conv_hbm_bytes_per_step"])
-            roofline["traffic_unit"] = "bytes per step (54 conv launches), PMC FETCH_SIZE x2 + WRITE_SIZE"
+            tr = json.load(open(tj))
+            if dom.startswith("split"):
+                pk = dom.replace("split", "").split("_")                         # "6", "128x128", "k16"
+                key = "conv_igemm_split_ls<%s,%s,%s,%s>" % (pk[1].split("x")[0], pk[1].split("x")[1], pk[0], pk[2][1:])
+                ent = tr.get("per_kernel", {}).get(key)
+                if ent:
+                    roofline["traffic"] = float(ent["hbm_bytes_per_launch"])
+                    roofline["traffic_unit"] = "HBM bytes per launch of the dominant kernel (average), PMC FETCH_SIZE x2 + WRITE_SIZE"
+                    roofline["algorithmic_bytes_per_launch"] = round(sum(
+                        alg_bytes.get(n.split("|")[0], 0.0) for n, _, _ in conv if n.endswith("|" + dom)) / d_n, 1)
+            roofline["conv_stack_hbm_bytes_per_step"] = float(tr["conv_hbm_bytes_per_step"])
         except Exception:
             pass
     if args.layer_table:
@@ -159,6 +203,9 @@ def main():
         "metric": "frames_per_sec", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
         "steps": K, "warmup": Wm, "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "dtype_note": ("fp32 storage, fp32 accumulation; conv products are exact 3-way bf16 splits multiplied on the bf16 "
+                       "matrix pipe (6 partial products, dropped terms <= 2^-23 relative); DGP_CONV_MODE=f32 selects the "
+                       "fp32-MFMA kernels") if any(k.startswith("split") for k in by_kernel) else "fp32 MFMA (bitwise fmaf chains)",
         "config": {"workload": "ResNet-50 640x480x3 u8, 4 keypoints, batch %d/GPU, inference "
                                "(scoremap + DGP soft-argmax + likelihood), BASELINE configs[1]" % B,
                    "frames_per_step_per_gpu": B, "sharding": "contiguous frame shards, 1 RCCL all-gather per run"},

@@ -106,3 +106,25 @@ def conv_macs_per_frame(h: int, w: int, depth: int = 50, nj: int = 4,
     heads = nj * (3 if with_locref else 1)
     macs += hh * ww * 9 * 2048 * heads
     return macs
+
+
+def conv_algorithmic_bytes(h: int, w: int, depth: int = 50, batch: int = 1) -> dict:
+    """{TF scope of a backbone conv: algorithmic HBM bytes of one launch at `batch` frames}: fp32 input read once
+    + output written once + residual read once (conv3) + the weights.  Layer-by-layer execution, no fusion."""
+    name = "resnet_v1_%d" % depth
+    out = {}
+    h1, w1 = same_out(h, 2), same_out(w, 2)
+    out["conv:%s/conv1" % name] = 4.0 * (batch * h * w * 4 + batch * h1 * w1 * 64 + 7 * 7 * 4 * 64)
+    hh, ww = same_out(h1, 2), same_out(w1, 2)
+    for u in resnet_units(depth):
+        ho, wo = same_out(hh, u.stride), same_out(ww, u.stride)
+        pin, pout = batch * hh * ww, batch * ho * wo
+        if u.has_shortcut_conv:
+            out["conv:%s/shortcut" % u.scope] = 4.0 * (pin * u.depth_in + pout * u.depth + u.depth_in * u.depth)
+        out["conv:%s/conv1" % u.scope] = 4.0 * (pin * u.depth_in + pin * u.depth_bottleneck + u.depth_in * u.depth_bottleneck)
+        out["conv:%s/conv2" % u.scope] = 4.0 * (pin * u.depth_bottleneck + pout * u.depth_bottleneck +
+                                                9 * u.depth_bottleneck * u.depth_bottleneck)
+        res = pout * u.depth if u.has_shortcut_conv else (pin if u.stride == 1 else pout) * u.depth
+        out["conv:%s/conv3" % u.scope] = 4.0 * (pout * u.depth_bottleneck + pout * u.depth + res + u.depth_bottleneck * u.depth)
+        hh, ww = ho, wo
+    return out

@@ -38,6 +38,7 @@ enum TileCfg { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_128x32 = 
 
 hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s);
 int        pick_tile(int M, int CoutP, int K);
+const char* conv_kernel_name(const ConvArgs& a, int tile_cfg);
 hipError_t launch_reduce_slabs(const float* slabs, long long n, long long stride, int nsplit, float* out, hipStream_t s);
 hipError_t launch_maxpool(const float* x, int N, int H, int W, int C, float* y, hipStream_t s);
 hipError_t launch_preprocess(const uint8_t* f, long long npix, float m0, float m1, float m2,

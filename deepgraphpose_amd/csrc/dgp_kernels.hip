@@ -13,6 +13,7 @@
 // Wavefront = 64 lanes everywhere.  No CUDA-compat shims; this file only targets gfx950.
 #include "dgp_internal.h"
 #include <cstdlib>
+#include <cstring>
 #include <cstdio>
 #include <vector>
 
@@ -718,15 +719,18 @@ static hipError_t launch_conv_ls(ConvArgs a, hipStream_t s) {
 // ------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+template <bool IS_B = false>
 __device__ __forceinline__ void split3_bf16(const float4 v, uint2& p1, uint2& p2, uint2& p3) {
     const unsigned M = 0xFFFF0000u;
     const float x[4] = {v.x, v.y, v.z, v.w};
     unsigned h1[4], h2[4], h3[4];
-#ifdef DGP_EXP_FAKE_SPLIT       // tuning experiment only (wrong numerics): what the split arithmetic costs
+#ifdef DGP_EXP_FAKE_SPLIT       // tuning experiment only (wrong numerics): what the split arithmetic costs (2: B operand only)
+    if (DGP_EXP_FAKE_SPLIT == 1 || IS_B) {
     p1.x = __builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), 0x07060302);
     p1.y = __builtin_amdgcn_perm(__float_as_uint(x[3]), __float_as_uint(x[2]), 0x07060302);
     p2 = p1; p3 = p1;
     return;
+    }
 #endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -859,7 +863,7 @@ __global__ __launch_bounds__(512, BK == 16 ? 4 : 2) void conv_igemm_split_ls(con
 #pragma unroll
             for (int i = 0; i < BSLOTS; ++i) {
                 uint2 p1, p2, p3;
-                split3_bf16(rb[i], p1, p2, p3);
+                split3_bf16<true>(rb[i], p1, p2, p3);
                 const int o = i * (128 / BN) * LDB * 2;
                 b[o] = p1;
                 b[KG * LDB * 2 + o] = p2;
@@ -1010,7 +1014,16 @@ int pick_tile(int M, int CoutP, int K) {
         if ((v == TILE_128x64_LS || v == TILE_128x64_S6) && CoutP % 64 == 0) return v;
         if ((v == TILE_128x64 || v == TILE_64x64) && CoutP % 64 == 0) return v;
     }
-    static const int rule = getenv("DGP_TILE_RULE") ? atoi(getenv("DGP_TILE_RULE")) : 2;   // A/B switch for tuning runs
+    // rule 3 (default): split-bf16 kernels (fp32-equivalent, 6 bf16 MFMAs per product) wherever the tile fits;
+    // rule 2 (DGP_TILE_RULE=2 or DGP_CONV_MODE=f32): fp32 MFMA everywhere (bitwise fmaf chains)
+    static const int rule = getenv("DGP_TILE_RULE") ? atoi(getenv("DGP_TILE_RULE"))
+                            : (getenv("DGP_CONV_MODE") && !strcmp(getenv("DGP_CONV_MODE"), "f32")) ? 2 : 3;
+    if (rule >= 3) {
+        // 128x128 / BK 16 (two workgroups per CU) won or tied on every shape with Cout % 128 == 0 in
+        // scripts/split_sweep.py; Cout = 64 layers take the 128x64 tile
+        if (CoutP % 128 == 0) return TILE_128x128_S6K16;
+        if (CoutP % 64 == 0) return TILE_128x64_S6;
+    }
     if (rule >= 2) {
         // loader-specialised 128x64 (4 compute + 4 loader waves, 3 workgroups per CU, loads two K-steps ahead) won or
         // tied on every Cin >= 32 layer except the very wide 1x1 convs, where the 8-wave 128x128 tile is ahead
@@ -1023,6 +1036,21 @@ int pick_tile(int M, int CoutP, int K) {
     if (K >= 1024 && CoutP <= 512) return TILE_64x64;      // 3x3 convs, deep-K 1x1 reductions
     if (K >= 576 && CoutP <= 256) return TILE_64x64;       // 3x3 convs of block1/2
     return TILE_128x64;
+}
+
+// Name of the kernel launch_conv will run for (args, tile) -- for the profile table / roofline accounting.
+const char* conv_kernel_name(const ConvArgs& a, int tile_cfg) {
+    if (a.Cin >= 32 && a.out_mode == 0) {
+        switch (tile_cfg) {
+            case TILE_128x128_S6K16: return "split6_128x128_k16";
+            case TILE_128x128_S6:    return "split6_128x128_k32";
+            case TILE_128x64_S6:     return "split6_128x64_k32";
+            case TILE_128x128_S3K16: return "split3_128x128_k16";
+            case TILE_128x128_S3:    return "split3_128x128_k32";
+            default: break;
+        }
+    }
+    return "f32";
 }
 
 hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s) {

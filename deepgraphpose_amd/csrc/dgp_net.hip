@@ -340,7 +340,8 @@ int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, in
         a.in_bytes = (unsigned)inb; a.out_bytes = (unsigned)outb; a.res_bytes = (unsigned)resb;
         a.w_bytes = (unsigned)((size_t)l.nk * 8 * l.CoutP * 16);
     }
-    ProfScope ps(net, s, "conv:" + l.scope, conv_flops_of(l, a.M, out_mode == 1));
+    const int tile_cfg = pick_tile(a.M, a.CoutP, l.nk * BK);
+    ProfScope ps(net, s, "conv:" + l.scope + "|" + conv_kernel_name(a, tile_cfg), conv_flops_of(l, a.M, out_mode == 1));
     const long long out_n = (long long)N * 4 * Ho * Wo * dc_nj;
     if (out_mode == 1 && slabs && (out_n & 3) == 0) {
         // the heads have a tiny N (4*nj channels) and a huge K (4 x 2048): split K so the grid fills the chip;
@@ -350,13 +351,13 @@ int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, in
         while (ks < HEAD_KSPLIT_MAX && mtiles * ks < 1024 && l.nk % (ks * 2) == 0) ks *= 2;
         if (ks > 1) {
             a.ksplit = ks; a.split_stride = out_n; a.out = slabs;
-            hipError_t e = launch_conv(a, pick_tile(a.M, a.CoutP, l.nk * BK), s);
+            hipError_t e = launch_conv(a, tile_cfg, s);
             if (e == hipSuccess) e = launch_reduce_slabs(slabs, out_n, out_n, ks, out, s);
             if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("head conv (") + l.scope + "): " + hipGetErrorString(e));
             return DGP_OK;
         }
     }
-    hipError_t e = launch_conv(a, pick_tile(a.M, a.CoutP, l.nk * BK), s);
+    hipError_t e = launch_conv(a, tile_cfg, s);
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("conv launch (") + l.scope + "): " + hipGetErrorString(e));
     return DGP_OK;
 }
