@@ -40,7 +40,7 @@ def kernel_peak(kernel: str) -> float:
     per fp32-equivalent product, so their ceiling is the dense bf16 peak / 6 (/ 3)."""
     if kernel.startswith("split6"):
         return PEAK_BF16_MFMA_TFLOPS / 6.0
-    if kernel.startswith("split3"):
+    if kernel.startswith("split3") or kernel.startswith("splith3"):     # fp16 dense peak = bf16 dense peak
         return PEAK_BF16_MFMA_TFLOPS / 3.0
     return PEAK_F32_MFMA_TFLOPS
 H, W, NJ, BATCH = 480, 640, 4, 32
@@ -154,14 +154,16 @@ def main():
     d_n, d_f, d_ms = by_kernel[dom]
     achieved = d_f / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0
     peak = kernel_peak(dom)
+    n_mfma = "6" if dom.startswith("split6") else "3"
+    mfma_kind = "f16" if dom.startswith("splith") else "bf16"
     kname = {"f32": "conv_igemm_f32 / conv_igemm_f32_ls (v_mfma_f32_32x32x2_f32)"}.get(
-        dom, "conv_igemm_split_ls<%s> (fp32-equivalent products as %s v_mfma_f32_32x32x16_bf16)" % (dom, dom[5]))
+        dom, "conv_igemm_split_ls<%s> (fp32-class products as %s v_mfma_f32_32x32x16_%s)" % (dom, n_mfma, mfma_kind))
     roofline = {
         "bound": "mfma", "kernel": "%s, %d of the %d conv launches of a step" % (kname, d_n, len(conv)),
         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": None,
-        "peak_basis": ("dense bf16 MFMA peak %.0f TFLOP/s / %s partial products per fp32-equivalent product; achieved counts "
-                       "ALGORITHMIC conv FLOPs" % (PEAK_BF16_MFMA_TFLOPS, dom[5])) if dom.startswith("split")
+        "peak_basis": ("dense %s MFMA peak %.0f TFLOP/s / %s partial products per fp32-class product; achieved counts "
+                       "ALGORITHMIC conv FLOPs" % (mfma_kind, PEAK_BF16_MFMA_TFLOPS, n_mfma)) if dom.startswith("split")
                       else "dense fp32 MFMA peak",
         "kernel_ms_per_step": round(d_ms, 3),
         "kernels": {k: {"launches": v[0], "ms_per_step": round(v[2], 3), "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 1),
@@ -181,8 +183,9 @@ def main():
         try:
             tr = json.load(open(tj))
             if dom.startswith("split"):
-                pk = dom.replace("split", "").split("_")                         # "6", "128x128", "k16"
-                key = "conv_igemm_split_ls<%s,%s,%s,%s>" % (pk[1].split("x")[0], pk[1].split("x")[1], pk[0], pk[2][1:])
+                pk = dom.replace("splith3", "2").replace("split", "").split("_")      # NT, "128x128", "k16[w8]"
+                bk, cw = (pk[2][1:].split("w") + ["4"])[:2]
+                key = "conv_igemm_split_ls<%s,%s,%s,%s,%s>" % (pk[1].split("x")[0], pk[1].split("x")[1], pk[0], bk, cw)
                 ent = tr.get("per_kernel", {}).get(key)
                 if ent:
                     roofline["traffic"] = float(ent["hbm_bytes_per_launch"])
@@ -203,9 +206,11 @@ def main():
         "metric": "frames_per_sec", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
         "steps": K, "warmup": Wm, "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "dtype_note": ("fp32 storage, fp32 accumulation; conv products are exact 3-way bf16 splits multiplied on the bf16 "
-                       "matrix pipe (6 partial products, dropped terms <= 2^-23 relative); DGP_CONV_MODE=f32 selects the "
-                       "fp32-MFMA kernels") if any(k.startswith("split") for k in by_kernel) else "fp32 MFMA (bitwise fmaf chains)",
+        "dtype_note": ("fp32 storage, fp32 accumulation; conv operands are split in registers into fp16 high/low pairs "
+                       "(range-scaled by tracked per-tensor maxima, 22 significant bits, 3 MFMAs per product) or exact "
+                       "3-way bf16 splits (6 MFMAs) and multiplied on the 16-bit matrix pipe; error vs fp64 <= the fp32-MFMA "
+                       "kernels' (scripts/split_sweep.py); DGP_CONV_MODE=f32|bf16x6 select the other paths")
+                      if any(k.startswith("split") for k in by_kernel) else "fp32 MFMA (bitwise fmaf chains)",
         "config": {"workload": "ResNet-50 640x480x3 u8, 4 keypoints, batch %d/GPU, inference "
                                "(scoremap + DGP soft-argmax + likelihood), BASELINE configs[1]" % B,
                    "frames_per_step_per_gpu": B, "sharding": "contiguous frame shards, 1 RCCL all-gather per run"},

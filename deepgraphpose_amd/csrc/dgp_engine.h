@@ -52,6 +52,13 @@ struct dgp_net {
     bool loaded = false;
     // geometry
     int h1 = 0, w1 = 0, hp = 0, wp = 0, fh = 0, fw = 0;
+    // operand ranges of the fp16-split conv kernels: ABSMAX_SLOTS floats per tensor.  d_wmax[li]: weight panel of
+    // layer li (filled at load); d_amax[li]: output of layer li (zeroed and re-tracked every forward);
+    // d_inmax: the centred frame (|pixel - mean| < 256, constant)
+    float *d_wmax = nullptr, *d_amax = nullptr, *d_inmax = nullptr;
+    bool wmax_valid = false;      // false after a trainer re-packed the panels: the forward then runs without ranges
+    const float* wmax(int li) const { return d_wmax ? d_wmax + (size_t)li * dgp::ABSMAX_SLOTS : nullptr; }
+    float* amax(int li) const { return d_amax ? d_amax + (size_t)li * dgp::ABSMAX_SLOTS : nullptr; }
     // optional per-launch timing (hipEvent pairs recorded on the caller's stream)
     bool prof_on = false, prof_in_infer = false;
     int prof_slots = 0, prof_used = 0, prof_launches = 0, prof_cursor = 0;
@@ -69,5 +76,6 @@ struct dgp_net {
             if (l.d_scale) (void)hipFree(l.d_scale);
             if (l.d_bias) (void)hipFree(l.d_bias);
         }
+        for (float* q : {d_wmax, d_amax, d_inmax}) if (q) (void)hipFree(q);
     }
 };

@@ -32,12 +32,20 @@ struct ConvArgs {
     int mtiles, ntiles;
     unsigned long long* dbg;
     unsigned in_bytes, w_bytes, res_bytes, out_bytes;   // buffer-descriptor extents (< 4 GiB each)
+    // dynamic range tracking for the fp16-split kernels (device arrays of ABSMAX_SLOTS floats, may be null; the
+    // tensor's value is the maximum over the slots):
+    const float* in_absmax;   // max |x| over the input tensor (an upper bound is fine), written by its producer
+    const float* w_absmax;    // max |w| over the weight panel
+    float*       out_absmax;  // the epilogue atomically maxes max |out| into this slot (zeroed by the caller)
 };
 
-enum TileCfg { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_128x32 = 3, TILE_128x128_W8 = 4, TILE_128x128_LS = 5, TILE_128x64_LS = 6, TILE_128x128_S6 = 7, TILE_128x128_S3 = 8, TILE_128x64_S6 = 9, TILE_128x128_S6K16 = 10, TILE_128x128_S3K16 = 11 };
+constexpr int ABSMAX_SLOTS = 256;
+
+enum TileCfg { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_128x32 = 3, TILE_128x128_W8 = 4, TILE_128x128_LS = 5, TILE_128x64_LS = 6, TILE_128x128_S6 = 7, TILE_128x128_S3 = 8, TILE_128x64_S6 = 9, TILE_128x128_S6K16 = 10, TILE_128x128_S3K16 = 11, TILE_128x128_S6K16W8 = 12, TILE_128x128_H3K16 = 13, TILE_128x128_H3K16W8 = 14, TILE_128x64_H3 = 15 };
 
 hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s);
-int        pick_tile(int M, int CoutP, int K);
+int        pick_tile(int M, int CoutP, int K, bool have_absmax = false);
+hipError_t launch_absmax(const float* x, long long n, float* out_slots, hipStream_t s);   // slots = max(slots, max |x|)
 const char* conv_kernel_name(const ConvArgs& a, int tile_cfg);
 hipError_t launch_reduce_slabs(const float* slabs, long long n, long long stride, int nsplit, float* out, hipStream_t s);
 hipError_t launch_maxpool(const float* x, int N, int H, int W, int C, float* y, hipStream_t s);

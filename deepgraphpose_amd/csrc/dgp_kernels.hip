@@ -60,6 +60,30 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned 
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
+// Range tracking for the fp16-split kernels.  A tensor's max |x| lives in ABSMAX_SLOTS device floats (the maximum of
+// the slots is the value): producers spread their atomics over the slots -- tens of thousands of waves maxing into
+// ONE address serialise at the memory side (measured: a 0.3 ms layer became 0.9 ms) -- and skip the atomic when the
+// slot already holds a value at least as large.  Non-negative floats order like their bit patterns.
+__device__ __forceinline__ void track_absmax(float* slots, float amax, int lane, int salt) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0) {
+        unsigned* s = reinterpret_cast<unsigned*>(slots) + (salt & (ABSMAX_SLOTS - 1));
+        const unsigned bits = __float_as_uint(amax);
+        if (bits > __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(s, bits);
+    }
+}
+
+// max over the slots; every lane of the calling wave gets the value
+__device__ __forceinline__ float read_absmax(const float* slots, int lane) {
+    static_assert(ABSMAX_SLOTS == 256, "one float4 per lane");
+    const float4 v = reinterpret_cast<const float4*>(slots)[lane];
+    float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    return m;
+}
+
 // WIDE = (Cin >= 32): all 8 chunks of a K-step lie in ONE tap, so tap / channel bookkeeping is
 // wave-uniform (SALU, advanced incrementally) and each A load costs ~7 VALU ops.  The generic
 // path (WIDE = false, used by the 4-channel stem) recomputes the tap per lane.
@@ -332,6 +356,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_f32(const C
     float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), bi4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (cok && p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + co4);
     if (cok && p.bias) bi4 = *reinterpret_cast<const float4*>(p.bias + co4);
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         __syncthreads();      // previous pass (or the main loop) is done with this LDS
@@ -388,8 +413,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_f32(const C
                 o.z = rmask[v].z > 0.f ? o.z : 0.f; o.w = rmask[v].w > 0.f ? o.w : 0.f;
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)ooff[v], 0, 0);
+            if (ooff[v] != OOB) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
     }
+    if (p.out_absmax) track_absmax(p.out_absmax, amax, lane, (int)(blockIdx.x * 8u + (threadIdx.x >> 6)));
 #ifdef DGP_DIAG
     if (p.dbg && t == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -405,7 +432,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_f32(const C
 // barriers: the loader waves are gone).  acc -> scale/bias/residual/ReLU/mask -> 16-byte stores.
 template <int TM, int TN, int WN>
 __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[TM][TN], char* smem, int wave, int lane,
-                                            int m0, int n0, int wave_m0, int wave_n0) {
+                                            int m0, int n0, int wave_m0, int wave_n0, float post = 1.f) {
     constexpr int LDC = WN + 4;
     const int half = lane >> 5, l31 = lane & 31;
     const int HoWo = p.Ho * p.Wo;
@@ -424,6 +451,8 @@ __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[T
     float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), bi4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (cok && p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + co4);
     if (cok && p.bias) bi4 = *reinterpret_cast<const float4*>(p.bias + co4);
+    sc4.x *= post; sc4.y *= post; sc4.z *= post; sc4.w *= post;       // exact: post is a power of two (1 unless fp16-split)
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own reads of the previous pass are done
@@ -471,8 +500,10 @@ __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[T
                 o.z = rmask[v].z > 0.f ? o.z : 0.f; o.w = rmask[v].w > 0.f ? o.w : 0.f;
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)ooff[v], 0, 0);
+            if (ooff[v] != OOB) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
     }
+    if (p.out_absmax) track_absmax(p.out_absmax, amax, lane, (int)(blockIdx.x * 8u + (threadIdx.x >> 6)));
 }
 
 // ------------------------------------------------------------------------------------
@@ -744,11 +775,45 @@ __device__ __forceinline__ void split3_bf16(const float4 v, uint2& p1, uint2& p2
     p3.x = __builtin_amdgcn_perm(h3[1], h3[0], 0x07060302); p3.y = __builtin_amdgcn_perm(h3[3], h3[2], 0x07060302);
 }
 
+// fp16 variant (NT = 2): x * s = h + l with h = fp16(x s), l = fp16(x s - h): 22 significant bits, and a product is
+//     h_x h_y + (h_x l_y + l_x h_y)          dropped l_x l_y <= 2^-22 |x y|: three MFMAs instead of six.
+// fp16 has 5 exponent bits, so both operands are pre-scaled by powers of two (exact) chosen from the tensors' max
+// magnitudes so that max |x s| lies in [2^14, 2^15): no overflow by construction, and every element within 2^-17 of
+// the tensor maximum keeps a NORMAL low part (smaller ones still carry >= 11 bits and an absolute error below
+// 2^-38 of the maximum).  The maxima are device scalars: the producing conv's epilogue tracks max |out|
+// (ConvArgs::out_absmax), the weight panel's is computed at load.  The epilogue undoes the scales exactly.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float pow2_scale_for(const float* absmax, int lane) {
+    // 2^(14 - E) for max = m 2^E (1 <= m < 2); 1 for an all-zero (or untracked) tensor
+    if (!absmax) return 1.f;
+    const unsigned mb = __float_as_uint(read_absmax(absmax, lane));
+    const int be = (int)((mb >> 23) & 0xFF);            // biased exponent
+    if (be == 0 || be == 0xFF) return 1.f;
+    int se = 127 + 14 - (be - 127);
+    se = se < 1 ? 1 : (se > 254 ? 254 : se);
+    return __uint_as_float((unsigned)se << 23);
+}
+
+__device__ __forceinline__ void split2_f16(const float4 v, const float s, uint2& ph, uint2& pl) {
+    const float2v x01 = {v.x * s, v.y * s}, x23 = {v.z * s, v.w * s};
+    const half2v h01 = __builtin_convertvector(x01, half2v), h23 = __builtin_convertvector(x23, half2v);
+    const float2v r01 = x01 - __builtin_convertvector(h01, float2v), r23 = x23 - __builtin_convertvector(h23, float2v);   // exact
+    const half2v l01 = __builtin_convertvector(r01, half2v), l23 = __builtin_convertvector(r23, half2v);
+    ph.x = __builtin_bit_cast(unsigned, h01); ph.y = __builtin_bit_cast(unsigned, h23);
+    pl.x = __builtin_bit_cast(unsigned, l01); pl.y = __builtin_bit_cast(unsigned, l23);
+}
+
 // BK = 32: one workgroup per CU (101 KB of LDS for 128 x 128); BK = 16: half the LDS and <= 128 registers, so TWO
 // workgroups share a CU and one's prologue / epilogue / barrier waits run under the other's MFMAs.
-template <int BM, int BN, int NT, int BK>
-__global__ __launch_bounds__(512, BK == 16 ? 4 : 2) void conv_igemm_split_ls(const ConvArgs p) {
-    constexpr int WM = BM / 2, WN = BN / 2;        // compute waves 2 x 2
+// CW = compute waves: 4 (2 x 2, wave tile BM/2 x BN/2) or 8 (2 x 4, wave tile BM/2 x BN/4: 12-wave workgroups whose
+// small wave tiles fit 85 registers, so a SIMD holds FOUR MFMA-issuing waves of two workgroups instead of two).
+template <int BM, int BN, int NT, int BK, int CW>
+__global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : (BK == 16 ? 4 : 2)) void conv_igemm_split_ls(const ConvArgs p) {
+    constexpr int WAVES_N = CW / 2;
+    constexpr int WM = BM / 2, WN = BN / WAVES_N;  // compute waves 2 x (CW / 2)
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NLT = 256;                       // loader threads
     constexpr int CH = BK / 4;                     // 16-byte chunks per row and K-step
@@ -761,8 +826,9 @@ __global__ __launch_bounds__(512, BK == 16 ? 4 : 2) void conv_igemm_split_ls(con
     constexpr int LDB = BN + 4;
     constexpr int A_CELLS = NP * KG * LDA, B_CELLS = NP * KG * LDB;     // 16-byte cells per buffer
     constexpr int LDC = WN + 4;
-    static_assert(NT == 3 || NT == 6, "3 or 6 bf16 products per fp32-equivalent product");
+    static_assert(NT == 2 || NT == 3 || NT == 6, "6 / 3 bf16 products, or NT = 2: fp16 high/low pair (3 products)");
     static_assert(BK == 16 || BK == 32, "K-step of 16 or 32 floats");
+    static_assert(CW == 4 || CW == 8, "4 or 8 compute waves");
     static_assert(BN == 128 || BN == 64, "B staging map assumes 64 or 128 columns");     // (launcher sizes LDS for the epilogue too)
     static_assert(BSLOTS >= 1 && AROWS >= 1, "tile too small for 256 loader lanes");
 
@@ -785,9 +851,9 @@ __global__ __launch_bounds__(512, BK == 16 ? 4 : 2) void conv_igemm_split_ls(con
     const int HoWo = p.Ho * p.Wo;
     const int nks = p.nk * (32 / BK);               // K-steps of BK floats (weight panels are padded to 32)
 
-    if (wave >= 4) {
+    if (wave >= CW) {
         // ================================ loader waves ================================
-        const int t = threadIdx.x - 256;
+        const int t = threadIdx.x - 64 * CW;
         const __amdgpu_buffer_rsrc_t rs_in =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)p.in_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_w =
@@ -816,6 +882,8 @@ __global__ __launch_bounds__(512, BK == 16 ? 4 : 2) void conv_igemm_split_ls(con
         const int bcol = bq & (BN - 1), bkg0 = bq / BN;         // slot i covers k-group bkg0 + i * (128 / BN)
         const unsigned b_lane_off = (unsigned)(2 * bkg0 + bpar) * b_row_bytes + (unsigned)((n0 + bcol) * 16);
         int w_kh = 0, w_kw = 0, w_ch = 0, w_tap = 0;
+        const float scA = NT == 2 ? pow2_scale_for(p.in_absmax, lane) : 1.f;
+        const float scW = NT == 2 ? pow2_scale_for(p.w_absmax, lane) : 1.f;
         float4 ra0[AROWS], rb0[BSLOTS], ra1[AROWS], rb1[BSLOTS];
         auto gload = [&](int ks, float4 (&ra)[AROWS], float4 (&rb)[BSLOTS]) {
             const int dh = w_kh * p.dil, dw = w_kw * p.dil;
@@ -854,7 +922,8 @@ __global__ __launch_bounds__(512, BK == 16 ? 4 : 2) void conv_igemm_split_ls(con
 #pragma unroll
             for (int i = 0; i < AROWS; ++i) {
                 uint2 p1, p2, p3;
-                split3_bf16(ra[i], p1, p2, p3);
+                if (NT == 2) split2_f16(ra[i], scA, p1, p2);
+                else split3_bf16(ra[i], p1, p2, p3);
                 a[(RG * i) * 2] = p1;
                 a[(KG * LDA + RG * i) * 2] = p2;
                 if (NP == 3) a[(2 * KG * LDA + RG * i) * 2] = p3;
@@ -863,7 +932,8 @@ __global__ __launch_bounds__(512, BK == 16 ? 4 : 2) void conv_igemm_split_ls(con
 #pragma unroll
             for (int i = 0; i < BSLOTS; ++i) {
                 uint2 p1, p2, p3;
-                split3_bf16<true>(rb[i], p1, p2, p3);
+                if (NT == 2) split2_f16(rb[i], scW, p1, p2);
+                else split3_bf16<true>(rb[i], p1, p2, p3);
                 const int o = i * (128 / BN) * LDB * 2;
                 b[o] = p1;
                 b[KG * LDB * 2 + o] = p2;
@@ -888,8 +958,8 @@ __global__ __launch_bounds__(512, BK == 16 ? 4 : 2) void conv_igemm_split_ls(con
     }
 
     // ================================== compute waves ==================================
-    const int wave_m0 = (wave >> 1) * WM;
-    const int wave_n0 = (wave & 1) * WN;
+    const int wave_m0 = (wave / WAVES_N) * WM;
+    const int wave_n0 = (wave % WAVES_N) * WN;
     const int half = lane >> 5, l31 = lane & 31;
     floatx16 acc[TM][TN];
 #pragma unroll
@@ -898,54 +968,84 @@ __global__ __launch_bounds__(512, BK == 16 ? 4 : 2) void conv_igemm_split_ls(con
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#ifdef DGP_DIAG
+    unsigned long long e0, e1, e2, e3, acc_mf = 0, acc_ba = 0;
+    DIAG_STAMP(e0);
+#endif
     __syncthreads();
+#ifdef DGP_DIAG
+    DIAG_STAMP(e1);
+    const unsigned long long t_pro = e1 - e0;
+#endif
     for (int ks = 0; ks < nks; ++ks) {
         const int buf = ks & 1;
+        DIAG_STAMP(e1);
         const uint4* a_base = sA + buf * A_CELLS + wave_m0 + l31;
         const uint4* b_base = sB + buf * B_CELLS + wave_n0 + l31;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             const int kg = 2 * kk + half;
-            bf16x8 af[NP][TM], bf[NP][TN];
+            uint4 af[NP][TM], bf[NP][TN];
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[pl][i] = __builtin_bit_cast(bf16x8, a_base[(pl * KG + kg) * LDA + 32 * i]);
+                for (int i = 0; i < TM; ++i) af[pl][i] = a_base[(pl * KG + kg) * LDA + 32 * i];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[pl][j] = __builtin_bit_cast(bf16x8, b_base[(pl * KG + kg) * LDB + 32 * j]);
+                for (int j = 0; j < TN; ++j) bf[pl][j] = b_base[(pl * KG + kg) * LDB + 32 * j];
             }
+            auto mma = [](const uint4& x, const uint4& y, floatx16 c) {
+                if (NT == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), c, 0, 0, 0);
+                return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), c, 0, 0, 0);
+            };
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     floatx16 a = acc[i][j];
                     if (NT == 6) {          // smallest terms first
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP - 1][i], bf[0][j], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[NP - 1][j], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], a, 0, 0, 0);
+                        a = mma(af[NP - 1][i], bf[0][j], a);
+                        a = mma(af[0][i], bf[NP - 1][j], a);
+                        a = mma(af[1][i], bf[1][j], a);
                     }
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], a, 0, 0, 0);
+                    a = mma(af[1][i], bf[0][j], a);
+                    a = mma(af[0][i], bf[1][j], a);
+                    a = mma(af[0][i], bf[0][j], a);
                     acc[i][j] = a;
                 }
         }
+        DIAG_STAMP(e2);
         __syncthreads();
+        DIAG_STAMP(e3);
+#ifdef DGP_DIAG
+        acc_mf += e2 - e1; acc_ba += e3 - e2;
+#endif
     }
-    ls_epilogue<TM, TN, WN>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0);
+#ifdef DGP_DIAG
+    DIAG_STAMP(e1);
+#endif
+    const float post = NT == 2 ? 1.f / (pow2_scale_for(p.in_absmax, lane) * pow2_scale_for(p.w_absmax, lane)) : 1.f;    // exact
+    ls_epilogue<TM, TN, WN>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
+#ifdef DGP_DIAG
+    DIAG_STAMP(e2);
+    if (p.dbg && threadIdx.x == 0) {
+        unsigned long long* d = p.dbg + 10ull * blockIdx.x;
+        d[0] = t_pro; d[1] = acc_mf + acc_ba; d[2] = e2 - e1; d[3] = 0; d[4] = acc_mf; d[5] = 0; d[6] = 0; d[7] = acc_ba;
+    }
+#endif
 }
 
-template <int BM, int BN, int NT, int BK>
+template <int BM, int BN, int NT, int BK, int CW = 4>
 static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     constexpr int NP = NT == 6 ? 3 : 2;
     constexpr int KG = BK / 8;
+    if (NT == 2 && (!a.in_absmax || !a.w_absmax)) return hipErrorInvalidValue;      // fp16 split needs both ranges
     const size_t smem_loop = (size_t)2 * (NP * KG * (BM + (BK == 32 ? 4 : 8)) + NP * KG * (BN + 4)) * 16;
-    const size_t smem_epi = (size_t)4 * 32 * (BN / 2 + 4) * 4;
+    const size_t smem_epi = (size_t)CW * 32 * (BN / (CW / 2) + 4) * 4;
     const size_t smem = smem_loop > smem_epi ? smem_loop : smem_epi;
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = (a.CoutP + BN - 1) / BN;
     if (a.CoutP % BN != 0 || a.Cin < 32 || a.out_mode != 0) return hipErrorInvalidValue;
-    auto kern = conv_igemm_split_ls<BM, BN, NT, BK>;
+    auto kern = conv_igemm_split_ls<BM, BN, NT, BK, CW>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -954,7 +1054,31 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
         attr_done = true;
     }
     const long long nwg = (long long)a.mtiles * a.ntiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), smem, s, a);
+#ifdef DGP_DIAG
+    static unsigned long long* dbg_buf = nullptr;
+    if (!dbg_buf) (void)hipMalloc(&dbg_buf, 10 * 8 * 65536);
+    a.dbg = nwg <= 65536 ? dbg_buf : nullptr;
+#endif
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * (CW + 4)), smem, s, a);
+#ifdef DGP_DIAG
+    if (a.dbg) {
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> h(10 * nwg);
+        (void)hipMemcpy(h.data(), a.dbg, 80 * nwg, hipMemcpyDeviceToHost);
+        double v[8] = {0};
+        for (long long b = 0; b < nwg; ++b) for (int k = 0; k < 8; ++k) v[k] += (double)h[10 * b + k];
+        for (int k = 0; k < 8; ++k) v[k] /= (double)nwg;
+        const int nks = a.nk * (32 / BK);
+        int occ = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * (CW + 4), smem);
+        hipFuncAttributes fa{};
+        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern));
+        printf("[diag occupancy] blocks/CU %d (smem %zu B, regs %d, static smem %zu, local %zu)\n", occ, smem, fa.numRegs,
+               fa.sharedSizeBytes, fa.localSizeBytes);
+        printf("[diag split %dx%d NT%d BK%d CW%d] tiles %lld K-steps %d | compute wave 0: first barrier %.0f cyc, epilogue %.0f | per K-step: "
+               "ldsread+mfma %.0f barrier-wait %.0f\n", BM, BN, NT, BK, CW, nwg, nks, v[0], v[2], v[4] / nks, v[7] / nks);
+    }
+#endif
     return hipGetLastError();
 }
 
@@ -1004,20 +1128,31 @@ static hipError_t launch_conv_t(ConvArgs a, hipStream_t s) {
 // K-heavy 3x3 convs and for 1x1 convs with a deep K and few output channels; 128x64 wins for the
 // shallow-K, wide-N 1x1 convs (fewer re-reads of the activation rows); a 128x128 tile shared by 8 waves (same
 // 16 waves per CU as the 64x64 tile, half the L2 traffic per FLOP) wins when Cout >= 512; 128x128 with 4 waves never won.
-int pick_tile(int M, int CoutP, int K) {
+int pick_tile(int M, int CoutP, int K, bool have_absmax) {
     (void)M;
     if (CoutP <= 32) return TILE_128x32;
     if (const char* f = getenv("DGP_FORCE_TILE")) {     // tuning experiments only
         const int v = atoi(f);
         if ((v == TILE_128x128 || v == TILE_128x128_W8 || v == TILE_128x128_LS || v == TILE_128x128_S6 ||
-             v == TILE_128x128_S3 || v == TILE_128x128_S6K16 || v == TILE_128x128_S3K16) && CoutP % 128 == 0) return v;
-        if ((v == TILE_128x64_LS || v == TILE_128x64_S6) && CoutP % 64 == 0) return v;
+             v == TILE_128x128_S3 || v == TILE_128x128_S6K16 || v == TILE_128x128_S3K16 || v == TILE_128x128_S6K16W8 ||
+             ((v == TILE_128x128_H3K16 || v == TILE_128x128_H3K16W8) && have_absmax)) && CoutP % 128 == 0) return v;
+        if ((v == TILE_128x64_LS || v == TILE_128x64_S6 || (v == TILE_128x64_H3 && have_absmax)) && CoutP % 64 == 0) return v;
         if ((v == TILE_128x64 || v == TILE_64x64) && CoutP % 64 == 0) return v;
     }
-    // rule 3 (default): split-bf16 kernels (fp32-equivalent, 6 bf16 MFMAs per product) wherever the tile fits;
-    // rule 2 (DGP_TILE_RULE=2 or DGP_CONV_MODE=f32): fp32 MFMA everywhere (bitwise fmaf chains)
+    // rule 4 (default): fp16-split kernels where the caller tracks operand ranges (3 fp16 MFMAs per fp32-class
+    //         product), bf16-split elsewhere;
+    // rule 3 (DGP_CONV_MODE=bf16x6): bf16-split kernels (6 bf16 MFMAs per product, no range requirement);
+    // rule 2 (DGP_CONV_MODE=f32): fp32 MFMA everywhere (bitwise fmaf chains)
     static const int rule = getenv("DGP_TILE_RULE") ? atoi(getenv("DGP_TILE_RULE"))
-                            : (getenv("DGP_CONV_MODE") && !strcmp(getenv("DGP_CONV_MODE"), "f32")) ? 2 : 3;
+                            : !getenv("DGP_CONV_MODE") ? 4
+                            : !strcmp(getenv("DGP_CONV_MODE"), "f32") ? 2
+                            : !strcmp(getenv("DGP_CONV_MODE"), "bf16x6") ? 3 : 4;
+    if (rule >= 4 && have_absmax) {
+        // fp16 high/low split (3 MFMAs per product; needs the operand ranges): the 12-wave 128x128 workgroup won or
+        // tied nearly everywhere in scripts/split_sweep.py
+        if (CoutP % 128 == 0) return TILE_128x128_H3K16W8;
+        if (CoutP % 64 == 0) return TILE_128x64_H3;
+    }
     if (rule >= 3) {
         // 128x128 / BK 16 (two workgroups per CU) won or tied on every shape with Cout % 128 == 0 in
         // scripts/split_sweep.py; Cout = 64 layers take the 128x64 tile
@@ -1043,6 +1178,10 @@ const char* conv_kernel_name(const ConvArgs& a, int tile_cfg) {
     if (a.Cin >= 32 && a.out_mode == 0) {
         switch (tile_cfg) {
             case TILE_128x128_S6K16: return "split6_128x128_k16";
+            case TILE_128x128_S6K16W8: return "split6_128x128_k16w8";
+            case TILE_128x128_H3K16:   return "splith3_128x128_k16";
+            case TILE_128x128_H3K16W8: return "splith3_128x128_k16w8";
+            case TILE_128x64_H3:       return "splith3_128x64_k32";
             case TILE_128x128_S6:    return "split6_128x128_k32";
             case TILE_128x64_S6:     return "split6_128x64_k32";
             case TILE_128x128_S3K16: return "split3_128x128_k16";
@@ -1057,7 +1196,8 @@ hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s) {
     if (a.Cin < 32) {       // generic per-lane tap path (stem / small test shapes)
         if (tile_cfg == TILE_128x32) return launch_conv_t<128, 32, 4, 1, false>(a, s);
         if (tile_cfg == TILE_128x128_W8 || tile_cfg == TILE_128x128_LS || tile_cfg == TILE_128x128_S6 ||
-            tile_cfg == TILE_128x128_S3 || tile_cfg == TILE_128x128_S6K16 || tile_cfg == TILE_128x128_S3K16) tile_cfg = TILE_128x128;
+            tile_cfg == TILE_128x128_S3 || tile_cfg == TILE_128x128_S6K16 || tile_cfg == TILE_128x128_S3K16 ||
+            tile_cfg == TILE_128x128_S6K16W8 || tile_cfg == TILE_128x128_H3K16 || tile_cfg == TILE_128x128_H3K16W8) tile_cfg = TILE_128x128;
         if (a.CoutP % 128 == 0 && tile_cfg == TILE_128x128) return launch_conv_t<128, 128, 2, 2, false>(a, s);
         return launch_conv_t<128, 64, 2, 2, false>(a, s);
     }
@@ -1072,9 +1212,37 @@ hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s) {
         case TILE_128x128_S3: return a.out_mode == 0 ? launch_conv_split<128, 128, 3, 32>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
         case TILE_128x128_S6K16: return a.out_mode == 0 ? launch_conv_split<128, 128, 6, 16>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
         case TILE_128x128_S3K16: return a.out_mode == 0 ? launch_conv_split<128, 128, 3, 16>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
+        case TILE_128x128_S6K16W8: return a.out_mode == 0 ? launch_conv_split<128, 128, 6, 16, 8>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
+        case TILE_128x128_H3K16:   return a.out_mode == 0 ? launch_conv_split<128, 128, 2, 16>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
+        case TILE_128x128_H3K16W8: return a.out_mode == 0 ? launch_conv_split<128, 128, 2, 16, 8>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
+        case TILE_128x64_H3:       return a.out_mode == 0 ? launch_conv_split<128, 64, 2, 32>(a, s) : launch_conv_t<128, 64, 2, 2, true>(a, s);
         case TILE_128x64_S6:  return a.out_mode == 0 ? launch_conv_split<128, 64, 6, 32>(a, s) : launch_conv_t<128, 64, 2, 2, true>(a, s);
         default:          return launch_conv_t<128, 128, 2, 2, true>(a, s);
     }
+}
+
+// max |x| of a tensor into a device scalar (range of an operand of the fp16-split kernels when no producer tracked it)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n4, long long n, float* __restrict__ out) {
+    float m = 0.f;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += (long long)gridDim.x * blockDim.x) {
+        const float4 v = *reinterpret_cast<const float4*>(x + g * 4);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long long i = n4 * 4; i < n; ++i) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(reinterpret_cast<unsigned*>(out) + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (ABSMAX_SLOTS - 1)), __float_as_uint(m));
+}
+
+hipError_t launch_absmax(const float* x, long long n, float* out, hipStream_t s) {
+    const long long n4 = n / 4;
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n4, n, out);
+    return hipGetLastError();
 }
 
 // Deterministic split-K combine for the heads: out[i] = sum_s slab[s][i] in fixed order (no float atomics).

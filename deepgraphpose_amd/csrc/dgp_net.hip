@@ -256,6 +256,26 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
         HIP_TRY(hipMemcpy(l.d_scale, scale.data(), l.Cout * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(l.d_bias, bias.data(), l.Cout * sizeof(float), hipMemcpyHostToDevice));
     }
+    // operand ranges for the fp16-split kernels
+    const size_t nl = net->layers.size();
+    const size_t rb = (size_t)ABSMAX_SLOTS * sizeof(float);
+    if (!net->d_wmax) HIP_TRY(hipMalloc(&net->d_wmax, nl * rb));
+    if (!net->d_amax) HIP_TRY(hipMalloc(&net->d_amax, nl * rb));
+    if (!net->d_inmax) HIP_TRY(hipMalloc(&net->d_inmax, rb));
+    HIP_TRY(hipMemset(net->d_wmax, 0, nl * rb));
+    HIP_TRY(hipMemset(net->d_amax, 0, nl * rb));
+    {
+        std::vector<float> in_rng(ABSMAX_SLOTS, 0.f);
+        in_rng[0] = 256.f;                           // |u8 - mean_pixel| < 256
+        HIP_TRY(hipMemcpy(net->d_inmax, in_rng.data(), rb, hipMemcpyHostToDevice));
+    }
+    for (size_t li = 0; li < nl; ++li) {
+        const ConvLayer& l = net->layers[li];
+        hipError_t e = launch_absmax(l.d_w, (long long)l.nk * 8 * l.CoutP * 4, net->d_wmax + li * ABSMAX_SLOTS, nullptr);
+        if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("weight range: ") + hipGetErrorString(e));
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    net->wmax_valid = true;
     net->loaded = true;
     return DGP_OK;
 }
@@ -321,8 +341,12 @@ double conv_flops_of(const ConvLayer& l, int M, bool is_head) {
 
 int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, int W, int pad_t, int pad_l, int Ho, int Wo,
              const float* res, int res_s, int res_H, int res_W, bool relu, int out_mode, int dc_nj, float* out,
-             hipStream_t s, float* slabs = nullptr) {
+             hipStream_t s, float* slabs = nullptr, const float* in_absmax = nullptr) {
     ConvArgs a{};
+    const int li = (int)(&l - net->layers.data());
+    if (!net->wmax_valid) in_absmax = nullptr;
+    a.in_absmax = in_absmax; a.w_absmax = in_absmax ? net->wmax(li) : nullptr;
+    a.out_absmax = out_mode == 0 ? net->amax(li) : nullptr;
     a.in = in; a.wpk = l.d_w; a.scale = l.has_bn ? l.d_scale : nullptr; a.bias = l.d_bias; a.res = res; a.out = out;
     a.N = N; a.H = H; a.W = W; a.Cin = l.Cin; a.log2cin4 = ilog2(l.Cin / 4);
     a.Ho = Ho; a.Wo = Wo; a.Cout = l.Cout; a.CoutP = l.CoutP;
@@ -340,7 +364,7 @@ int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, in
         a.in_bytes = (unsigned)inb; a.out_bytes = (unsigned)outb; a.res_bytes = (unsigned)resb;
         a.w_bytes = (unsigned)((size_t)l.nk * 8 * l.CoutP * 16);
     }
-    const int tile_cfg = pick_tile(a.M, a.CoutP, l.nk * BK);
+    const int tile_cfg = pick_tile(a.M, a.CoutP, l.nk * BK, a.in_absmax && a.w_absmax);
     ProfScope ps(net, s, "conv:" + l.scope + "|" + conv_kernel_name(a, tile_cfg), conv_flops_of(l, a.M, out_mode == 1));
     const long long out_n = (long long)N * 4 * Ho * Wo * dc_nj;
     if (out_mode == 1 && slabs && (out_n & 3) == 0) {
@@ -426,6 +450,7 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
 
     net->prof_cursor = 0;
     hipError_t e;
+    if (net->d_amax) HIP_TRY(hipMemsetAsync(net->d_amax, 0, net->layers.size() * ABSMAX_SLOTS * sizeof(float), s));   // ranges are per forward
     {
         ProfScope ps(net, s, "preprocess_u8", 0.0);
         e = launch_preprocess(frames, (long long)B * d.in_h * d.in_w, d.mean_pixel[0], d.mean_pixel[1],
@@ -434,7 +459,7 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("preprocess: ") + hipGetErrorString(e));
     // conv1: conv2d_same(7, stride 2): explicit pad 3 before
     rc = run_conv(net, net->layers[net->conv1], P0, B, d.in_h, d.in_w, 3, 3, net->h1, net->w1, nullptr, 0, 0, 0, true, 0,
-                  0, C1, s);
+                  0, C1, s, nullptr, net->d_inmax);
     if (rc) return rc;
     {
         ProfScope ps(net, s, "maxpool3x3s2", 0.0);
@@ -443,6 +468,7 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("maxpool: ") + hipGetErrorString(e));
 
     int cur = 0, h = net->hp, w = net->wp;
+    const float* x_rng = net->amax(net->conv1);      // max-pooling cannot raise the maximum of conv1's output
     for (const Unit& u : net->units) {
         const int ho = (h + u.stride - 1) / u.stride, wo = (w + u.stride - 1) / u.stride;
         const float* xin = X[cur];
@@ -451,18 +477,21 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
         int res_s = u.stride, res_H = h, res_W = w;
         if (u.sc >= 0) {
             // slim.conv2d(1x1, stride, SAME): pad 0, samples x[::s, ::s]
-            rc = run_conv(net, net->layers[u.sc], xin, B, h, w, 0, 0, ho, wo, nullptr, 0, 0, 0, false, 0, 0, SC, s);
+            rc = run_conv(net, net->layers[u.sc], xin, B, h, w, 0, 0, ho, wo, nullptr, 0, 0, 0, false, 0, 0, SC, s, nullptr, x_rng);
             if (rc) return rc;
             res = SC; res_s = 1; res_H = ho; res_W = wo;
         }
-        rc = run_conv(net, net->layers[u.c1], xin, B, h, w, 0, 0, h, w, nullptr, 0, 0, 0, true, 0, 0, R1, s);
+        rc = run_conv(net, net->layers[u.c1], xin, B, h, w, 0, 0, h, w, nullptr, 0, 0, 0, true, 0, 0, R1, s, nullptr, x_rng);
         if (rc) return rc;
         const int pb_h = pad_before_for(h, 3, u.stride, u.rate, true);
         const int pb_w = pad_before_for(w, 3, u.stride, u.rate, true);
-        rc = run_conv(net, net->layers[u.c2], R1, B, h, w, pb_h, pb_w, ho, wo, nullptr, 0, 0, 0, true, 0, 0, R2, s);
+        rc = run_conv(net, net->layers[u.c2], R1, B, h, w, pb_h, pb_w, ho, wo, nullptr, 0, 0, 0, true, 0, 0, R2, s, nullptr,
+                      net->amax(u.c1));
         if (rc) return rc;
-        rc = run_conv(net, net->layers[u.c3], R2, B, ho, wo, 0, 0, ho, wo, res, res_s, res_H, res_W, true, 0, 0, xout, s);
+        rc = run_conv(net, net->layers[u.c3], R2, B, ho, wo, 0, 0, ho, wo, res, res_s, res_H, res_W, true, 0, 0, xout, s,
+                      nullptr, net->amax(u.c2));
         if (rc) return rc;
+        x_rng = net->amax(u.c3);
         cur ^= 1; h = ho; w = wo;
     }
     const float* feat = X[cur];
@@ -663,8 +692,21 @@ int dgp_pack_conv_weights(const float* hwio, int32_t KH, int32_t KW, int32_t Cin
     return DGP_OK;
 }
 
+int dgp_tensor_absmax(const float* x, size_t n, float* absmax_dev, void* stream) {
+    if (!x || !absmax_dev) return fail(DGP_ERR_INVALID, "dgp_tensor_absmax: null argument");
+    hipError_t e = launch_absmax(x, (long long)n, absmax_dev, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("absmax: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
 int dgp_conv2d(const dgp_conv_desc* d, const float* x, const float* packed_w, const float* scale, const float* bias,
                const float* residual, float* y, void* stream) {
+    return dgp_conv2d_ranged(d, x, packed_w, scale, bias, residual, y, nullptr, nullptr, nullptr, stream);
+}
+
+int dgp_conv2d_ranged(const dgp_conv_desc* d, const float* x, const float* packed_w, const float* scale, const float* bias,
+                      const float* residual, float* y, const float* x_absmax, const float* w_absmax, float* y_absmax,
+                      void* stream) {
     if (!d || !x || !packed_w || !y) return fail(DGP_ERR_INVALID, "dgp_conv2d: null argument");
     if (d->Cin < 4 || (d->Cin & 3) || ((d->Cin / 4) & (d->Cin / 4 - 1)))
         return fail(DGP_ERR_INVALID, "dgp_conv2d: Cin must be 4 * 2^k");
@@ -685,7 +727,8 @@ int dgp_conv2d(const dgp_conv_desc* d, const float* x, const float* packed_w, co
         a.in_bytes = (unsigned)inb; a.out_bytes = (unsigned)outb; a.res_bytes = (unsigned)resb;
         a.w_bytes = (unsigned)((size_t)a.nk * 8 * a.CoutP * 16);
     }
-    hipError_t e = launch_conv(a, pick_tile(a.M, a.CoutP, a.nk * BK), (hipStream_t)stream);
+    a.in_absmax = x_absmax; a.w_absmax = w_absmax; a.out_absmax = y_absmax;
+    hipError_t e = launch_conv(a, pick_tile(a.M, a.CoutP, a.nk * BK, x_absmax && w_absmax), (hipStream_t)stream);
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_conv2d: ") + hipGetErrorString(e));
     return DGP_OK;
 }

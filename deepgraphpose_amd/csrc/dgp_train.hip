@@ -705,6 +705,7 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
         }
     }
     TRY_HIP(hipGetLastError());
+    net->wmax_valid = false;      // panels changed: weight ranges of the fp16-split kernels are stale
     net->loaded = true;
     return DGP_OK;
 }

@@ -213,6 +213,17 @@ int  dgp_pack_conv_weights(const float* hwio, int32_t KH, int32_t KW, int32_t Ci
 int  dgp_conv2d(const dgp_conv_desc* d, const float* x, const float* packed_w,
                 const float* scale /*[Cout] or NULL*/, const float* bias /*[Cout] or NULL*/,
                 const float* residual, float* y, void* stream);
+/* Same, with the operand ranges the fp16-split kernels need.  A range is a device array of DGP_ABSMAX_SLOTS floats
+ * whose maximum is (an upper bound of) max |tensor| (producers spread their atomics over the slots); fill one with
+ * dgp_tensor_absmax.  With x_absmax and w_absmax present the fp16 high/low split (3 MFMAs per fp32-class product)
+ * may be used, otherwise the bf16 3-way split (6 MFMAs, no range requirement).  y_absmax (zero it first; may be
+ * NULL) receives max |y| so that y can feed the next ranged call. */
+#define DGP_ABSMAX_SLOTS 256
+int  dgp_conv2d_ranged(const dgp_conv_desc* d, const float* x, const float* packed_w, const float* scale, const float* bias,
+                       const float* residual, float* y, const float* x_absmax, const float* w_absmax, float* y_absmax,
+                       void* stream);
+/* slots = max(slots, max |x[0..n)|) on the device (zero the DGP_ABSMAX_SLOTS floats before the first call). */
+int  dgp_tensor_absmax(const float* x, size_t n, float* absmax_dev, void* stream);
 int  dgp_maxpool_3x3s2_same(const float* x, int32_t N, int32_t H, int32_t W, int32_t C,
                             float* y, void* stream);
 int  dgp_preprocess_u8(const uint8_t* frames, int64_t n_pixels, const float mean[3],

@@ -8,13 +8,14 @@ import numpy as np, torch
 from deepgraphpose_amd import engine, _lib
 from scripts.conv_sweep_layers import LAYERS
 
-TILES = [(int(t.split(":")[0]), t.split(":")[1]) for t in os.environ.get("SWEEP_TILES", "4:W8,7:S6,10:S6k16,8:S3,11:S3k16,9:S6n64").split(",")]
+TILES = [(int(t.split(":")[0]), t.split(":")[1]) for t in os.environ.get("SWEEP_TILES", "4:W8,10:S6k16,12:S6k16w8,13:H3k16,14:H3k16w8,9:S6n64,15:H3n64").split(",")]
 only = sys.argv[1:]
 rng = np.random.default_rng(0)
 lib = _lib.load()
 for name, N, H, W, Cin, Cout, k, s, r, pad in LAYERS:
     if only and not any(o in name for o in only):
         continue
+    N = N * int(os.environ.get("SWEEP_BATCH_MULT", "1")) // int(os.environ.get("SWEEP_BATCH_DIV", "1"))
     x = torch.randn((N, H, W, Cin), device="cuda") * torch.rand((1, 1, 1, Cin), device="cuda") * 3
     x = torch.relu(x)                                     # post-ReLU-like activations
     w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
@@ -22,6 +23,9 @@ for name, N, H, W, Cin, Cout, k, s, r, pad in LAYERS:
     wp = torch.from_numpy(engine.pack_conv_weights(w)).cuda()
     d = _lib.DgpConvDesc(N, H, W, Cin, Cout, k, k, s, r, pad, pad, H, W, 0, 0, 0, 0)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng_dev = torch.zeros(3 * 256, device="cuda")
+    _lib.check(lib.dgp_tensor_absmax(C.c_void_p(x.data_ptr()), x.numel(), C.c_void_p(rng_dev.data_ptr()), st))
+    _lib.check(lib.dgp_tensor_absmax(C.c_void_p(wp.data_ptr()), wp.numel(), C.c_void_p(rng_dev.data_ptr() + 1024), st))
     # fp64 reference on 64 sampled pixels (all channels)
     pix = rng.integers(0, N * H * W, 64)
     xw = torch.nn.functional.pad(x.double(), (0, 0, pad, pad, pad, pad))
@@ -33,13 +37,14 @@ for name, N, H, W, Cin, Cout, k, s, r, pad in LAYERS:
         ref[i] = torch.einsum("abc,abco->o", patch, wt)
     out = []
     for tile, label in TILES:
-        if tile in (0, 4, 5, 7, 8, 10, 11) and Cout % 128:
+        if tile in (0, 4, 5, 7, 8, 10, 11, 12, 13, 14) and Cout % 128:
             out.append("%s   -   " % label); continue
         os.environ["DGP_FORCE_TILE"] = str(tile)
         y = torch.empty((N, H, W, Cout), device="cuda")
         def run():
-            _lib.check(lib.dgp_conv2d(C.byref(d), C.c_void_p(x.data_ptr()), C.c_void_p(wp.data_ptr()), None, None, None,
-                                      C.c_void_p(y.data_ptr()), st))
+            _lib.check(lib.dgp_conv2d_ranged(C.byref(d), C.c_void_p(x.data_ptr()), C.c_void_p(wp.data_ptr()), None, None, None,
+                                             C.c_void_p(y.data_ptr()), C.c_void_p(rng_dev.data_ptr()),
+                                             C.c_void_p(rng_dev.data_ptr() + 1024), C.c_void_p(rng_dev.data_ptr() + 2048), st))
         for _ in range(3): run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
