@@ -30,6 +30,7 @@ struct ConvArgs {
     int out_mode;         // 0: NHWC [M][Cout]; 1: transposed-conv phase scatter
     int dc_nj;            // channels per phase for out_mode 1
     int mtiles, ntiles;
+    int tap_minor;        // split kernels: walk K as (channel chunk, tap) instead of (tap, channel chunk)
     unsigned long long* dbg;
     unsigned in_bytes, w_bytes, res_bytes, out_bytes;   // buffer-descriptor extents (< 4 GiB each)
     // dynamic range tracking for the fp16-split kernels (device arrays of ABSMAX_SLOTS floats, may be null; the
@@ -41,7 +42,7 @@ struct ConvArgs {
 
 constexpr int ABSMAX_SLOTS = 256;
 
-enum TileCfg { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_128x32 = 3, TILE_128x128_W8 = 4, TILE_128x128_LS = 5, TILE_128x64_LS = 6, TILE_128x128_S6 = 7, TILE_128x128_S3 = 8, TILE_128x64_S6 = 9, TILE_128x128_S6K16 = 10, TILE_128x128_S3K16 = 11, TILE_128x128_S6K16W8 = 12, TILE_128x128_H3K16 = 13, TILE_128x128_H3K16W8 = 14, TILE_128x64_H3 = 15 };
+enum TileCfg { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_128x32 = 3, TILE_128x128_W8 = 4, TILE_128x128_LS = 5, TILE_128x64_LS = 6, TILE_128x128_S6 = 7, TILE_128x128_S3 = 8, TILE_128x64_S6 = 9, TILE_128x128_S6K16 = 10, TILE_128x128_S3K16 = 11, TILE_128x128_S6K16W8 = 12, TILE_128x128_H3K16 = 13, TILE_128x128_H3K16W8 = 14, TILE_128x64_H3 = 15, TILE_128x128_H3K32 = 16 };
 
 hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s);
 int        pick_tile(int M, int CoutP, int K, bool have_absmax = false);

@@ -811,7 +811,7 @@ __device__ __forceinline__ void split2_f16(const float4 v, const float s, uint2&
 // CW = compute waves: 4 (2 x 2, wave tile BM/2 x BN/2) or 8 (2 x 4, wave tile BM/2 x BN/4: 12-wave workgroups whose
 // small wave tiles fit 85 registers, so a SIMD holds FOUR MFMA-issuing waves of two workgroups instead of two).
 template <int BM, int BN, int NT, int BK, int CW>
-__global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : (BK == 16 ? 4 : 2)) void conv_igemm_split_ls(const ConvArgs p) {
+__global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2) ? 4 : 2)) void conv_igemm_split_ls(const ConvArgs p) {
     constexpr int WAVES_N = CW / 2;
     constexpr int WM = BM / 2, WN = BN / WAVES_N;  // compute waves 2 x (CW / 2)
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -906,12 +906,21 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : (BK == 16 ? 4 : 2)) vo
                     ra[i] = buf_load16(rs_in, ok ? (unsigned)(rowoff[i] + doff) : OOB);
                 }
             }
-            w_ch += BK;
-            if (w_ch >= p.Cin) {
-                w_ch = 0; ++w_tap;
+            // weight-panel rows of this step: k = tap * Cin + channel, 4 k-values per row
+            const unsigned kbase = (unsigned)(w_tap * (p.Cin >> 2) + (w_ch >> 2)) * b_row_bytes;
+            if (p.tap_minor) {
+                // taps fastest: the 9 taps of one channel chunk re-read nearly the same input pixels back to back,
+                // so most A loads of a 3x3 conv hit the CU's L1 instead of queueing on the L2 path
+                ++w_tap;
                 if (++w_kw == p.KW) { w_kw = 0; ++w_kh; }
+                if (w_tap == p.ntaps) { w_tap = 0; w_kw = 0; w_kh = 0; w_ch += BK; }
+            } else {
+                w_ch += BK;
+                if (w_ch >= p.Cin) {
+                    w_ch = 0; ++w_tap;
+                    if (++w_kw == p.KW) { w_kw = 0; ++w_kh; }
+                }
             }
-            const unsigned kbase = (unsigned)(ks * CH) * b_row_bytes;
 #pragma unroll
             for (int i = 0; i < BSLOTS; ++i)
                 rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
@@ -945,15 +954,38 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : (BK == 16 ? 4 : 2)) vo
         if (nks > 1) gload(1, ra1, rb1);
         if (nks > 2) gload(2, ra0, rb0);
         __syncthreads();
+#ifdef DGP_DIAG
+        unsigned long long l0, l1, l2, l3, t_st = 0, t_ld = 0, t_ba = 0;
+#endif
         for (int ks = 0; ks < nks; ks += 2) {
+            DIAG_STAMP(l0);
             if (ks + 1 < nks) lstore(1, ra1, rb1);
+            DIAG_STAMP(l1);
             if (ks + 3 < nks) gload(ks + 3, ra1, rb1);
+            DIAG_STAMP(l2);
             __syncthreads();
+            DIAG_STAMP(l3);
+#ifdef DGP_DIAG
+            t_st += l1 - l0; t_ld += l2 - l1; t_ba += l3 - l2;
+#endif
             if (ks + 1 >= nks) break;
+            DIAG_STAMP(l0);
             if (ks + 2 < nks) lstore(0, ra0, rb0);
+            DIAG_STAMP(l1);
             if (ks + 4 < nks) gload(ks + 4, ra0, rb0);
+            DIAG_STAMP(l2);
             __syncthreads();
+            DIAG_STAMP(l3);
+#ifdef DGP_DIAG
+            t_st += l1 - l0; t_ld += l2 - l1; t_ba += l3 - l2;
+#endif
         }
+#ifdef DGP_DIAG
+        if (p.dbg && t == 0) {
+            unsigned long long* d = p.dbg + 10ull * blockIdx.x;
+            d[3] = t_st; d[5] = t_ld; d[6] = t_ba;
+        }
+#endif
         return;
     }
 
@@ -1029,7 +1061,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : (BK == 16 ? 4 : 2)) vo
     DIAG_STAMP(e2);
     if (p.dbg && threadIdx.x == 0) {
         unsigned long long* d = p.dbg + 10ull * blockIdx.x;
-        d[0] = t_pro; d[1] = acc_mf + acc_ba; d[2] = e2 - e1; d[3] = 0; d[4] = acc_mf; d[5] = 0; d[6] = 0; d[7] = acc_ba;
+        d[0] = t_pro; d[1] = acc_mf + acc_ba; d[2] = e2 - e1; d[4] = acc_mf; d[7] = acc_ba;
     }
 #endif
 }
@@ -1039,6 +1071,8 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     constexpr int NP = NT == 6 ? 3 : 2;
     constexpr int KG = BK / 8;
     if (NT == 2 && (!a.in_absmax || !a.w_absmax)) return hipErrorInvalidValue;      // fp16 split needs both ranges
+    static const int tap_minor = getenv("DGP_TAP_MINOR") ? atoi(getenv("DGP_TAP_MINOR")) : 1;
+    a.tap_minor = (tap_minor && a.ntaps > 1 && a.nk * 32 == a.ntaps * a.Cin) ? 1 : 0;
     const size_t smem_loop = (size_t)2 * (NP * KG * (BM + (BK == 32 ? 4 : 8)) + NP * KG * (BN + 4)) * 16;
     const size_t smem_epi = (size_t)CW * 32 * (BN / (CW / 2) + 4) * 4;
     const size_t smem = smem_loop > smem_epi ? smem_loop : smem_epi;
@@ -1076,7 +1110,8 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
         printf("[diag occupancy] blocks/CU %d (smem %zu B, regs %d, static smem %zu, local %zu)\n", occ, smem, fa.numRegs,
                fa.sharedSizeBytes, fa.localSizeBytes);
         printf("[diag split %dx%d NT%d BK%d CW%d] tiles %lld K-steps %d | compute wave 0: first barrier %.0f cyc, epilogue %.0f | per K-step: "
-               "ldsread+mfma %.0f barrier-wait %.0f\n", BM, BN, NT, BK, CW, nwg, nks, v[0], v[2], v[4] / nks, v[7] / nks);
+               "ldsread+mfma %.0f barrier-wait %.0f || loader wave: wait+split+ds_write %.0f load-issue %.0f barrier-wait %.0f\n",
+               BM, BN, NT, BK, CW, nwg, nks, v[0], v[2], v[4] / nks, v[7] / nks, v[3] / nks, v[5] / nks, v[6] / nks);
     }
 #endif
     return hipGetLastError();
@@ -1135,7 +1170,8 @@ int pick_tile(int M, int CoutP, int K, bool have_absmax) {
         const int v = atoi(f);
         if ((v == TILE_128x128 || v == TILE_128x128_W8 || v == TILE_128x128_LS || v == TILE_128x128_S6 ||
              v == TILE_128x128_S3 || v == TILE_128x128_S6K16 || v == TILE_128x128_S3K16 || v == TILE_128x128_S6K16W8 ||
-             ((v == TILE_128x128_H3K16 || v == TILE_128x128_H3K16W8) && have_absmax)) && CoutP % 128 == 0) return v;
+             ((v == TILE_128x128_H3K16 || v == TILE_128x128_H3K16W8 || v == TILE_128x128_H3K32) && have_absmax)) &&
+            CoutP % 128 == 0) return v;
         if ((v == TILE_128x64_LS || v == TILE_128x64_S6 || (v == TILE_128x64_H3 && have_absmax)) && CoutP % 64 == 0) return v;
         if ((v == TILE_128x64 || v == TILE_64x64) && CoutP % 64 == 0) return v;
     }
@@ -1148,9 +1184,11 @@ int pick_tile(int M, int CoutP, int K, bool have_absmax) {
                             : !strcmp(getenv("DGP_CONV_MODE"), "f32") ? 2
                             : !strcmp(getenv("DGP_CONV_MODE"), "bf16x6") ? 3 : 4;
     if (rule >= 4 && have_absmax) {
-        // fp16 high/low split (3 MFMAs per product; needs the operand ranges): the 12-wave 128x128 workgroup won or
-        // tied nearly everywhere in scripts/split_sweep.py
-        if (CoutP % 128 == 0) return TILE_128x128_H3K16W8;
+        // fp16 high/low split (3 MFMAs per product; needs the operand ranges).  With the MFMA work cut to a quarter
+        // of the fp32 pipe's, the L2 -> L1 operand path sets the pace: the BK = 32 staging (a lane group fetches a
+        // whole 128-byte line per pixel; BK = 16 fetches half lines) won every shape in scripts/split_sweep.py, and two
+        // planes of fp16 leave room for two such workgroups per CU
+        if (CoutP % 128 == 0) return TILE_128x128_H3K32;
         if (CoutP % 64 == 0) return TILE_128x64_H3;
     }
     if (rule >= 3) {
@@ -1181,6 +1219,7 @@ const char* conv_kernel_name(const ConvArgs& a, int tile_cfg) {
             case TILE_128x128_S6K16W8: return "split6_128x128_k16w8";
             case TILE_128x128_H3K16:   return "splith3_128x128_k16";
             case TILE_128x128_H3K16W8: return "splith3_128x128_k16w8";
+            case TILE_128x128_H3K32:   return "splith3_128x128_k32";
             case TILE_128x64_H3:       return "splith3_128x64_k32";
             case TILE_128x128_S6:    return "split6_128x128_k32";
             case TILE_128x64_S6:     return "split6_128x64_k32";
@@ -1197,7 +1236,8 @@ hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s) {
         if (tile_cfg == TILE_128x32) return launch_conv_t<128, 32, 4, 1, false>(a, s);
         if (tile_cfg == TILE_128x128_W8 || tile_cfg == TILE_128x128_LS || tile_cfg == TILE_128x128_S6 ||
             tile_cfg == TILE_128x128_S3 || tile_cfg == TILE_128x128_S6K16 || tile_cfg == TILE_128x128_S3K16 ||
-            tile_cfg == TILE_128x128_S6K16W8 || tile_cfg == TILE_128x128_H3K16 || tile_cfg == TILE_128x128_H3K16W8) tile_cfg = TILE_128x128;
+            tile_cfg == TILE_128x128_S6K16W8 || tile_cfg == TILE_128x128_H3K16 || tile_cfg == TILE_128x128_H3K16W8 ||
+            tile_cfg == TILE_128x128_H3K32) tile_cfg = TILE_128x128;
         if (a.CoutP % 128 == 0 && tile_cfg == TILE_128x128) return launch_conv_t<128, 128, 2, 2, false>(a, s);
         return launch_conv_t<128, 64, 2, 2, false>(a, s);
     }
@@ -1215,6 +1255,7 @@ hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s) {
         case TILE_128x128_S6K16W8: return a.out_mode == 0 ? launch_conv_split<128, 128, 6, 16, 8>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
         case TILE_128x128_H3K16:   return a.out_mode == 0 ? launch_conv_split<128, 128, 2, 16>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
         case TILE_128x128_H3K16W8: return a.out_mode == 0 ? launch_conv_split<128, 128, 2, 16, 8>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
+        case TILE_128x128_H3K32:   return a.out_mode == 0 ? launch_conv_split<128, 128, 2, 32>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
         case TILE_128x64_H3:       return a.out_mode == 0 ? launch_conv_split<128, 64, 2, 32>(a, s) : launch_conv_t<128, 64, 2, 2, true>(a, s);
         case TILE_128x64_S6:  return a.out_mode == 0 ? launch_conv_split<128, 64, 6, 32>(a, s) : launch_conv_t<128, 64, 2, 2, true>(a, s);
         default:          return launch_conv_t<128, 128, 2, 2, true>(a, s);

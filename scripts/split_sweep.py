@@ -37,7 +37,7 @@ for name, N, H, W, Cin, Cout, k, s, r, pad in LAYERS:
         ref[i] = torch.einsum("abc,abco->o", patch, wt)
     out = []
     for tile, label in TILES:
-        if tile in (0, 4, 5, 7, 8, 10, 11, 12, 13, 14) and Cout % 128:
+        if tile in (0, 4, 5, 7, 8, 10, 11, 12, 13, 14, 16, 17) and Cout % 128:
             out.append("%s   -   " % label); continue
         os.environ["DGP_FORCE_TILE"] = str(tile)
         y = torch.empty((N, H, W, Cout), device="cuda")
