@@ -220,10 +220,17 @@ def pack_conv_weights(w_hwio: np.ndarray) -> np.ndarray:
     return out
 
 
+ABSMAX_SLOTS = 256      # DGP_ABSMAX_SLOTS in include/dgp_hip.h
+
+
 def conv2d(x: torch.Tensor, w_hwio: np.ndarray, stride: int = 1, rate: int = 1, pad_t: int = 0, pad_l: int = 0,
            out_hw: Optional[Tuple[int, int]] = None, scale=None, bias=None, residual: Optional[torch.Tensor] = None,
-           res_stride: int = 0, relu: bool = False) -> torch.Tensor:
-    """Single conv layer through the implicit-GEMM kernel (NHWC fp32)."""
+           res_stride: int = 0, relu: bool = False, ranged: bool = False, return_range: bool = False):
+    """Single conv layer through the implicit-GEMM kernel (NHWC fp32).
+
+    ranged=True measures max |x| and max |w| on the device first (dgp_tensor_absmax) and passes them on, which lets
+    the fp16 high/low split kernels run (dgp_conv2d_ranged); return_range=True also returns max |y| as tracked by the
+    epilogue (a device tensor of DGP_ABSMAX_SLOTS floats whose maximum is the value)."""
     lib = _lib.load()
     _need_cuda(x, torch.float32, "x")
     N, H, W, Cin = x.shape
@@ -241,9 +248,18 @@ def conv2d(x: torch.Tensor, w_hwio: np.ndarray, stride: int = 1, rate: int = 1, 
     rh, rw = (residual.shape[1], residual.shape[2]) if residual is not None else (0, 0)
     d = _lib.DgpConvDesc(N, H, W, Cin, cout, kh, kw, stride, rate, pad_t, pad_l, Ho, Wo, int(relu),
                          res_stride if residual is not None else 0, rh, rw)
-    _lib.check(lib.dgp_conv2d(C.byref(d), _ptr(x), _ptr(wp), _ptr(sc), _ptr(bi), _ptr(residual), _ptr(y),
-                              _stream(dev)), "dgp_conv2d")
-    return y
+    if not (ranged or return_range):
+        _lib.check(lib.dgp_conv2d(C.byref(d), _ptr(x), _ptr(wp), _ptr(sc), _ptr(bi), _ptr(residual), _ptr(y),
+                                  _stream(dev)), "dgp_conv2d")
+        return y
+    rng = torch.zeros((3, ABSMAX_SLOTS), dtype=torch.float32, device=dev)
+    if ranged:
+        _lib.check(lib.dgp_tensor_absmax(_ptr(x), x.numel(), _ptr(rng[0]), _stream(dev)), "dgp_tensor_absmax")
+        _lib.check(lib.dgp_tensor_absmax(_ptr(wp), wp.numel(), _ptr(rng[1]), _stream(dev)), "dgp_tensor_absmax")
+    _lib.check(lib.dgp_conv2d_ranged(C.byref(d), _ptr(x), _ptr(wp), _ptr(sc), _ptr(bi), _ptr(residual), _ptr(y),
+                                     _ptr(rng[0]) if ranged else None, _ptr(rng[1]) if ranged else None, _ptr(rng[2]),
+                                     _stream(dev)), "dgp_conv2d_ranged")
+    return (y, rng[2]) if return_range else y
 
 
 def maxpool_3x3s2_same(x: torch.Tensor) -> torch.Tensor:

@@ -292,15 +292,17 @@ def test_estimate_pose_end_to_end(eng, tmp_path):
         E.setup_dgp_eval_graph(dlc_cfg, snap[:-4])
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 4, 5, 6])
+# fp32-MFMA tiles 0-6; bf16 6-term split 7 / 9 / 10 / 12; bf16 3-term split 8 / 11 (16-bit products: looser bound);
+# fp16 high/low split 13-16 (need operand ranges)
+@pytest.mark.parametrize("tile", [0, 1, 2, 4, 5, 6, 7, 9, 10, 12, 8, 11, 13, 14, 15, 16])
 @pytest.mark.parametrize("case", [(2, 19, 21, 64, 128, 3, 1, 1), (1, 15, 20, 128, 256, 3, 1, 2), (2, 20, 24, 256, 512, 1, 2, 1),
                                   (1, 30, 40, 1024, 256, 1, 1, 1), (2, 19, 21, 64, 64, 3, 2, 1)])
 def test_every_tile_variant_matches_oracle(eng, case, tile, monkeypatch):
-    """All workgroup shapes of conv_igemm_f32 (incl. the 8-wave and loader-specialised variants) on the same layers,
-    with residual + ReLU in the epilogue."""
+    """All workgroup shapes of conv_igemm_f32 (incl. the 8-wave and loader-specialised variants) and of the split
+    kernels conv_igemm_split_ls on the same layers, with residual + ReLU in the epilogue."""
     from oracle import dgp_oracle as O
     N, H, W, Cin, Cout, k, stride, rate = case
-    if tile in (0, 4, 5) and Cout % 128:
+    if tile in (0, 4, 5, 7, 8, 10, 11, 12, 13, 14, 16) and Cout % 128:
         pytest.skip("tile needs Cout % 128 == 0")
     monkeypatch.setenv("DGP_FORCE_TILE", str(tile))
     rng = np.random.default_rng(tile * 100 + Cin)
@@ -313,6 +315,35 @@ def test_every_tile_variant_matches_oracle(eng, case, tile, monkeypatch):
     ref = np.maximum(ref * scale + bias + res, 0)
     keff = (k - 1) * rate + 1
     pad = (keff - 1) // 2 if stride > 1 else O.tf_same_pads(H, k, stride, rate)[1]
-    y = eng.conv2d(torch.from_numpy(x).cuda(), w, stride=stride, rate=rate, pad_t=pad, pad_l=pad, out_hw=ref.shape[1:3],
-                   scale=scale, bias=bias, residual=torch.from_numpy(res).cuda(), res_stride=1, relu=True).cpu().numpy()
-    assert _rel_err(y, ref) < 2e-5
+    y, yr = eng.conv2d(torch.from_numpy(x).cuda(), w, stride=stride, rate=rate, pad_t=pad, pad_l=pad, out_hw=ref.shape[1:3],
+                       scale=scale, bias=bias, residual=torch.from_numpy(res).cuda(), res_stride=1, relu=True,
+                       ranged=tile >= 13, return_range=True)
+    y = y.cpu().numpy()
+    assert _rel_err(y, ref) < (3e-4 if tile in (8, 11) else 2e-5)
+    assert float(yr.max()) == float(np.abs(y).max())                # the epilogue's range tracking is exact
+
+
+def test_fp16_split_keeps_fp32_class_accuracy_over_wide_ranges(eng, monkeypatch):
+    """The fp16 high/low split scales both operands by powers of two taken from their measured maxima: results must stay
+    fp32-class (vs float64) whatever the magnitudes -- tiny / huge weights and activations, one large outlier, zeros,
+    negative values -- and never overflow."""
+    rng = np.random.default_rng(7)
+    N, H, W, Cin, Cout = 2, 12, 16, 128, 128
+    monkeypatch.setenv("DGP_FORCE_TILE", "16")
+    base = rng.standard_normal((N, H, W, Cin))
+    wbase = rng.standard_normal((1, 1, Cin, Cout)) / np.sqrt(Cin)
+    for xs, ws, outlier in ((1.0, 1.0, None), (1e-6, 1e-5, None), (3e4, 2e3, None), (1.0, 1.0, 1e4), (1e-3, 50.0, 7.0), (0.0, 1.0, None)):
+        x = (base * xs).astype(np.float32)
+        if outlier is not None:
+            x[0, 0, 0, 0] = outlier
+        w = (wbase * ws).astype(np.float32)
+        ref = np.einsum("nhwc,co->nhwo", x.astype(np.float64), w[0, 0].astype(np.float64))
+        y32 = eng.conv2d(torch.from_numpy(x).cuda(), w).cpu().numpy()                      # bf16x6 (no ranges)
+        y16 = eng.conv2d(torch.from_numpy(x).cuda(), w, ranged=True).cpu().numpy()         # fp16 split
+        assert np.isfinite(y16).all()
+        # compare row-wise against what float32 inputs allow: |err| <= c * sum_k |x_k w_k| * 2^-22
+        bound = np.einsum("nhwc,co->nhwo", np.abs(x).astype(np.float64), np.abs(w[0, 0]).astype(np.float64)) * 2.0 ** -21 + 1e-300
+        if outlier is not None:     # elements far below the maximum keep >= 11 bits and an absolute error << max * 2^-30
+            bound = bound + float(np.abs(x).max()) * float(np.abs(w).max()) * Cin * 2.0 ** -32
+        assert (np.abs(y16 - ref) <= bound).all(), (xs, ws, outlier, float((np.abs(y16 - ref) / bound).max()))
+        assert (np.abs(y32 - ref) <= bound).all()
