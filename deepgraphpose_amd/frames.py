@@ -22,6 +22,11 @@ class ArraySource:
         for f in self.frames:
             yield f
 
+    def iter_batches(self, n: int) -> Iterator[np.ndarray]:
+        """Contiguous runs of up to n frames (views): lets the staging thread fill a pinned batch with one copy."""
+        for i in range(0, self.n_frames, n):
+            yield self.frames[i:i + n]
+
     def close(self):
         pass
 

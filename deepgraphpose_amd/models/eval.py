@@ -177,8 +177,22 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
     for i in range(nslots):
         free_slots.put(i)
 
+    whole_batches = new_size is None and crop_size is None and hasattr(video_clip, "iter_batches")
+
     def producer():
         try:
+            if whole_batches:       # in-memory stack: one GIL-free copy per batch instead of one python step per frame
+                done = 0
+                for chunk in video_clip.iter_batches(batch_size):
+                    nb = min(len(chunk), n_frames - done)
+                    if nb <= 0:
+                        break
+                    slot = free_slots.get()
+                    np.copyto(pinned[slot][:nb].numpy(), chunk[:nb])
+                    ready.put((slot, nb))
+                    done += nb
+                ready.put(None)
+                return
             slot, fill, count = free_slots.get(), 0, 0
             for fr in itertools.chain([f0], (prep(x) for x in frames_it)):
                 if count >= n_frames:

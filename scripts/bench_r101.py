@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4] shape check: ResNet-101, 1280x720 frames, 20 keypoints, one GPU.  Prints frames/s and parity of
+a few frames against the CPU oracle (slow: the oracle takes ~10 s per frame at this size)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from deepgraphpose_amd import engine, synthetic
+from deepgraphpose_amd.arch import conv_macs_per_frame
+
+H, W, NJ, B = 720, 1280, 20, int(sys.argv[1]) if len(sys.argv) > 1 else 16
+wts = synthetic.make_weights(101, NJ, False, seed=0)
+frames = synthetic.make_frames(B, H, W, NJ, seed=1)
+net = engine.DGPNet(101, NJ, H, W, max_batch=B)
+net.load_weights(wts)
+f = torch.from_numpy(frames).cuda()
+for _ in range(2):
+    mu, conf, idx = net.infer(f)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+K = 5
+for _ in range(K):
+    mu, conf, idx = net.infer(f)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / K
+gf = 2.0 * conv_macs_per_frame(H, W, 101, NJ, False) / 1e9
+print("ResNet-101 %dx%d nj=%d batch %d: %.2f ms/step, %.1f frames/s, %.1f TFLOP/s of algorithmic conv FLOPs (%.1f GFLOP/frame)"
+      % (W, H, NJ, B, dt * 1e3, B / dt, gf * B / dt / 1e3, gf), flush=True)
+if "--parity" in sys.argv:
+    from oracle import dgp_oracle as O
+    ref = O.infer(frames[:1], wts, 101, 8.0, 1.0, 1)
+    d = np.abs(mu[:1].cpu().numpy() - ref["mu"]).max() * 8.0
+    print("parity on 1 frame vs oracle: max |d| = %.2e px, idx exact: %s" % (d, np.array_equal(idx[:1].cpu().numpy(), ref["idx"])))
