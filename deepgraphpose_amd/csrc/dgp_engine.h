@@ -28,6 +28,7 @@ struct ConvLayer {
     int nk = 0, ntaps = 1;
     bool has_bn = true, relu = false;
     float *d_w = nullptr, *d_scale = nullptr, *d_bias = nullptr;
+    void* d_wh3 = nullptr;    // fp16 high/low cells of the panel (fp16-split kernels), built at load
 };
 
 struct Unit {
@@ -75,6 +76,7 @@ struct dgp_net {
             if (l.d_w) (void)hipFree(l.d_w);
             if (l.d_scale) (void)hipFree(l.d_scale);
             if (l.d_bias) (void)hipFree(l.d_bias);
+            if (l.d_wh3) (void)hipFree(l.d_wh3);
         }
         for (float* q : {d_wmax, d_amax, d_inmax}) if (q) (void)hipFree(q);
     }

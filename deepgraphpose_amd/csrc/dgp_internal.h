@@ -37,6 +37,8 @@ struct ConvArgs {
     // tensor's value is the maximum over the slots):
     const float* in_absmax;   // max |x| over the input tensor (an upper bound is fine), written by its producer
     const float* w_absmax;    // max |w| over the weight panel
+    const void*  wh3;         // optional: the weight panel pre-split into fp16 high/low cells (launch_pack_h3), same scale as w_absmax gives
+    unsigned     wh3_bytes;
     float*       out_absmax;  // the epilogue atomically maxes max |out| into this slot (zeroed by the caller)
 };
 
@@ -46,6 +48,8 @@ enum TileCfg { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_128x32 = 
 
 hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s);
 int        pick_tile(int M, int CoutP, int K, bool have_absmax = false);
+// fp32 panel [nk*8][CoutP][4] -> fp16 cells [nk*4 k-groups][2 planes][CoutP][8 halves] in the LDS order of the fp16-split kernels
+hipError_t launch_pack_h3(const float* panel, int nk, int CoutP, const float* w_absmax, void* out, hipStream_t s);
 hipError_t launch_absmax(const float* x, long long n, float* out_slots, hipStream_t s);   // slots = max(slots, max |x|)
 const char* conv_kernel_name(const ConvArgs& a, int tile_cfg);
 hipError_t launch_reduce_slabs(const float* slabs, long long n, long long stride, int nsplit, float* out, hipStream_t s);

@@ -819,7 +819,7 @@ __device__ __forceinline__ void split2_f16(const float4 v, const float s, uint2&
 // workgroups share a CU and one's prologue / epilogue / barrier waits run under the other's MFMAs.
 // CW = compute waves: 4 (2 x 2, wave tile BM/2 x BN/2) or 8 (2 x 4, wave tile BM/2 x BN/4: 12-wave workgroups whose
 // small wave tiles fit 85 registers, so a SIMD holds FOUR MFMA-issuing waves of two workgroups instead of two).
-template <int BM, int BN, int NT, int BK, int CW>
+template <int BM, int BN, int NT, int BK, int CW, bool PB = false>
 __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2) ? 4 : 2)) void conv_igemm_split_ls(const ConvArgs p) {
     constexpr int WAVES_N = CW / 2;
     constexpr int WM = BM / 2, WN = BN / WAVES_N;  // compute waves 2 x (CW / 2)
@@ -838,6 +838,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
     static_assert(NT == 2 || NT == 3 || NT == 6, "6 / 3 bf16 products, or NT = 2: fp16 high/low pair (3 products)");
     static_assert(BK == 16 || BK == 32, "K-step of 16 or 32 floats");
     static_assert(CW == 4 || CW == 8, "4 or 8 compute waves");
+    static_assert(!PB || NT == 2, "pre-split weight cells exist for the fp16 path only");
     static_assert(BN == 128 || BN == 64, "B staging map assumes 64 or 128 columns");     // (launcher sizes LDS for the epilogue too)
     static_assert(BSLOTS >= 1 && AROWS >= 1, "tile too small for 256 loader lanes");
 
@@ -890,6 +891,18 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
         const int bq = t >> 1, bpar = t & 1;                    // pair index over [kg][col], chunk parity
         const int bcol = bq & (BN - 1), bkg0 = bq / BN;         // slot i covers k-group bkg0 + i * (128 / BN)
         const unsigned b_lane_off = (unsigned)(2 * bkg0 + bpar) * b_row_bytes + (unsigned)((n0 + bcol) * 16);
+        // PB: the weights arrive pre-split as 16-byte cells [k-group][plane][col]; slot i of lane t is cell t + 256 i of
+        // the step's [KG][2][BN] block -> no split arithmetic and one ds_write_b128 per cell
+        const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(PB ? p.wh3 : (const void*)p.wpk), 0, PB ? (int)p.wh3_bytes : 0, 0x00020000);
+        unsigned pb_goff[BSLOTS];
+        int pb_cell[BSLOTS];
+#pragma unroll
+        for (int i = 0; i < BSLOTS; ++i) {
+            const int q = t + NLT * i, col = q & (BN - 1), r = q / BN, plane = r & 1, kgl = r >> 1;
+            pb_goff[i] = (unsigned)(((kgl * 2 + plane) * p.CoutP + n0 + col) * 16);
+            pb_cell[i] = (plane * KG + kgl) * LDB + col;
+        }
         int w_kh = 0, w_kw = 0, w_ch = 0, w_tap = 0;
         const float scA = NT == 2 ? pow2_scale_for(p.in_absmax, lane) : 1.f;
         const float scW = NT == 2 ? pow2_scale_for(p.w_absmax, lane) : 1.f;
@@ -930,10 +943,17 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
                     if (++w_kw == p.KW) { w_kw = 0; ++w_kh; }
                 }
             }
+            if (PB) {
+                const unsigned kgbase = (kbase >> 1) * 2u;          // (k-group index) * 2 planes * CoutP * 16 bytes = kbase rows / 2 * 2
 #pragma unroll
-            for (int i = 0; i < BSLOTS; ++i)
-                rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                            rs_w, (int)b_lane_off, (int)(kbase + (unsigned)(2 * i * (128 / BN)) * b_row_bytes), 0));
+                for (int i = 0; i < BSLOTS; ++i)
+                    rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, (int)pb_goff[i], (int)kgbase, 0));
+            } else {
+#pragma unroll
+                for (int i = 0; i < BSLOTS; ++i)
+                    rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                rs_w, (int)b_lane_off, (int)(kbase + (unsigned)(2 * i * (128 / BN)) * b_row_bytes), 0));
+            }
         };
         auto lstore = [&](int buf, float4 (&ra)[AROWS], float4 (&rb)[BSLOTS]) {
             uint2* a = reinterpret_cast<uint2*>(sA + buf * A_CELLS) + (((c >> 1) * LDA + rg) * 2 + (c & 1));
@@ -945,6 +965,11 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
                 a[(RG * i) * 2] = p1;
                 a[(KG * LDA + RG * i) * 2] = p2;
                 if (NP == 3) a[(2 * KG * LDA + RG * i) * 2] = p3;
+            }
+            if (PB) {
+#pragma unroll
+                for (int i = 0; i < BSLOTS; ++i) sB[buf * B_CELLS + pb_cell[i]] = __builtin_bit_cast(uint4, rb[i]);
+                return;
             }
             uint2* b = reinterpret_cast<uint2*>(sB + buf * B_CELLS) + ((bkg0 * LDB + bcol) * 2 + bpar);
 #pragma unroll
@@ -1089,12 +1114,14 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     a.ntiles = (a.CoutP + BN - 1) / BN;
     if (a.CoutP % BN != 0 || a.Cin < 32 || a.out_mode != 0) return hipErrorInvalidValue;
     auto kern = conv_igemm_split_ls<BM, BN, NT, BK, CW>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (NT == 2 && CW == 4 && a.wh3) kern = conv_igemm_split_ls<BM, BN, NT, BK, CW, (NT == 2 && CW == 4)>;     // pre-split weights
+    else a.wh3 = nullptr;
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[a.wh3 ? 1 : 0]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done[a.wh3 ? 1 : 0] = true;
     }
     const long long nwg = (long long)a.mtiles * a.ntiles;
 #ifdef DGP_DIAG
@@ -1269,6 +1296,31 @@ hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s) {
         case TILE_128x64_S6:  return a.out_mode == 0 ? launch_conv_split<128, 64, 6, 32>(a, s) : launch_conv_t<128, 64, 2, 2, true>(a, s);
         default:          return launch_conv_t<128, 128, 2, 2, true>(a, s);
     }
+}
+
+// fp32 weight panel -> fp16 high/low cells in the LDS order of the fp16-split kernels (one thread per k-group x column)
+__global__ __launch_bounds__(256) void pack_h3_kernel(const float4* __restrict__ panel, int nkg, int CoutP,
+                                                      const float* __restrict__ w_absmax, uint4* __restrict__ out) {
+    const float s = pow2_scale_for(w_absmax, threadIdx.x & 63);
+    const long long total = (long long)nkg * CoutP;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int col = (int)(g % CoutP);
+        const long long kg = g / CoutP;
+        uint2 h0, l0, h1, l1;
+        split2_f16(panel[(2 * kg) * CoutP + col], s, h0, l0);
+        split2_f16(panel[(2 * kg + 1) * CoutP + col], s, h1, l1);
+        out[(kg * 2) * CoutP + col] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        out[(kg * 2 + 1) * CoutP + col] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+}
+
+hipError_t launch_pack_h3(const float* panel, int nk, int CoutP, const float* w_absmax, void* out, hipStream_t s) {
+    const long long total = (long long)nk * 4 * CoutP;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_h3_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(panel), nk * 4,
+                       CoutP, w_absmax, reinterpret_cast<uint4*>(out));
+    return hipGetLastError();
 }
 
 // max |x| of a tensor into a device scalar (range of an operand of the fp16-split kernels when no producer tracked it)

@@ -270,9 +270,15 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
         HIP_TRY(hipMemcpy(net->d_inmax, in_rng.data(), rb, hipMemcpyHostToDevice));
     }
     for (size_t li = 0; li < nl; ++li) {
-        const ConvLayer& l = net->layers[li];
+        ConvLayer& l = net->layers[li];
         hipError_t e = launch_absmax(l.d_w, (long long)l.nk * 8 * l.CoutP * 4, net->d_wmax + li * ABSMAX_SLOTS, nullptr);
         if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("weight range: ") + hipGetErrorString(e));
+        if (l.Cin >= 32 && l.CoutP % 64 == 0) {          // layers the fp16-split kernels can take: pre-split cells
+            const size_t bytes = (size_t)l.nk * 8 * l.CoutP * 16;
+            if (!l.d_wh3) HIP_TRY(hipMalloc(&l.d_wh3, bytes));
+            e = launch_pack_h3(l.d_w, l.nk, l.CoutP, net->d_wmax + li * ABSMAX_SLOTS, l.d_wh3, nullptr);
+            if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("weight cells: ") + hipGetErrorString(e));
+        }
     }
     HIP_TRY(hipDeviceSynchronize());
     net->wmax_valid = true;
@@ -346,6 +352,8 @@ int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, in
     const int li = (int)(&l - net->layers.data());
     if (!net->wmax_valid) in_absmax = nullptr;
     a.in_absmax = in_absmax; a.w_absmax = in_absmax ? net->wmax(li) : nullptr;
+    static const bool use_cells = !(getenv("DGP_PRESPLIT_WEIGHTS") && atoi(getenv("DGP_PRESPLIT_WEIGHTS")) == 0);   // A/B switch
+    if (use_cells && in_absmax && l.d_wh3) { a.wh3 = l.d_wh3; a.wh3_bytes = (unsigned)((size_t)l.nk * 8 * l.CoutP * 16); }
     a.out_absmax = out_mode == 0 ? net->amax(li) : nullptr;
     a.in = in; a.wpk = l.d_w; a.scale = l.has_bn ? l.d_scale : nullptr; a.bias = l.d_bias; a.res = res; a.out = out;
     a.N = N; a.H = H; a.W = W; a.Cin = l.Cin; a.log2cin4 = ilog2(l.Cin / 4);
