@@ -29,6 +29,7 @@ struct ConvLayer {
     bool has_bn = true, relu = false;
     float *d_w = nullptr, *d_scale = nullptr, *d_bias = nullptr;
     void* d_wh3 = nullptr;    // fp16 high/low cells of the panel (fp16-split kernels), built at load
+    float* d_w_rows = nullptr;   // stem only: panel for the row walk [7 rows x 8 pixels][CoutP][4] (pixel 7 and channel 3 are zero)
 };
 
 struct Unit {
@@ -77,6 +78,7 @@ struct dgp_net {
             if (l.d_scale) (void)hipFree(l.d_scale);
             if (l.d_bias) (void)hipFree(l.d_bias);
             if (l.d_wh3) (void)hipFree(l.d_wh3);
+            if (l.d_w_rows) (void)hipFree(l.d_w_rows);
         }
         for (float* q : {d_wmax, d_amax, d_inmax}) if (q) (void)hipFree(q);
     }

@@ -31,6 +31,9 @@ struct ConvArgs {
     int dc_nj;            // channels per phase for out_mode 1
     int mtiles, ntiles;
     int tap_minor;        // split kernels: walk K as (channel chunk, tap) instead of (tap, channel chunk)
+    int stem;             // split kernels: 4-channel input walked one kernel ROW per K-step (8 pixels x 4 channels = 128 contiguous bytes);
+                          // chunk c of a row is the pixel wi0 + c, so the width check is per chunk
+    int tap_rows;         // weight-panel rows (of 4 k-values) per tap; 0 = Cin / 4
     unsigned long long* dbg;
     unsigned in_bytes, w_bytes, res_bytes, out_bytes;   // buffer-descriptor extents (< 4 GiB each)
     // dynamic range tracking for the fp16-split kernels (device arrays of ABSMAX_SLOTS floats, may be null; the

@@ -923,13 +923,13 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             } else {
 #pragma unroll
                 for (int i = 0; i < AROWS; ++i) {
-                    const int hi = hi0[i] + dh, wi = wi0[i] + dw;
+                    const int hi = hi0[i] + dh, wi = wi0[i] + dw + (p.stem ? c : 0);
                     const bool ok = tapok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
                     ra[i] = buf_load16(rs_in, ok ? (unsigned)(rowoff[i] + doff) : OOB);
                 }
             }
             // weight-panel rows of this step: k = tap * Cin + channel, 4 k-values per row
-            const unsigned kbase = (unsigned)(w_tap * (p.Cin >> 2) + (w_ch >> 2)) * b_row_bytes;
+            const unsigned kbase = (unsigned)(w_tap * p.tap_rows + (w_ch >> 2)) * b_row_bytes;
             if (p.tap_minor) {
                 // taps fastest: the 9 taps of one channel chunk re-read nearly the same input pixels back to back,
                 // so most A loads of a 3x3 conv hit the CU's L1 instead of queueing on the L2 path
@@ -1106,13 +1106,14 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     constexpr int KG = BK / 8;
     if (NT == 2 && (!a.in_absmax || !a.w_absmax)) return hipErrorInvalidValue;      // fp16 split needs both ranges
     static const int tap_minor = getenv("DGP_TAP_MINOR") ? atoi(getenv("DGP_TAP_MINOR")) : 1;
-    a.tap_minor = (tap_minor && a.ntaps > 1 && a.nk * 32 == a.ntaps * a.Cin) ? 1 : 0;
+    a.tap_minor = (tap_minor && !a.stem && a.ntaps > 1 && a.nk * 32 == a.ntaps * a.Cin) ? 1 : 0;
     const size_t smem_loop = (size_t)2 * (NP * KG * (BM + (BK == 32 ? 4 : 8)) + NP * KG * (BN + 4)) * 16;
     const size_t smem_epi = (size_t)CW * 32 * (BN / (CW / 2) + 4) * 4;
     const size_t smem = smem_loop > smem_epi ? smem_loop : smem_epi;
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = (a.CoutP + BN - 1) / BN;
-    if (a.CoutP % BN != 0 || a.Cin < 32 || a.out_mode != 0) return hipErrorInvalidValue;
+    if (a.CoutP % BN != 0 || (a.Cin < 32 && !a.stem) || a.out_mode != 0) return hipErrorInvalidValue;
+    if (a.tap_rows == 0) a.tap_rows = a.Cin >> 2;
     auto kern = conv_igemm_split_ls<BM, BN, NT, BK, CW>;
     if (NT == 2 && CW == 4 && a.wh3) kern = conv_igemm_split_ls<BM, BN, NT, BK, CW, (NT == 2 && CW == 4)>;     // pre-split weights
     else a.wh3 = nullptr;
@@ -1249,7 +1250,7 @@ int pick_tile(int M, int CoutP, int K, bool have_absmax) {
 
 // Name of the kernel launch_conv will run for (args, tile) -- for the profile table / roofline accounting.
 const char* conv_kernel_name(const ConvArgs& a, int tile_cfg) {
-    if (a.Cin >= 32 && a.out_mode == 0) {
+    if ((a.Cin >= 32 || a.stem) && a.out_mode == 0) {
         switch (tile_cfg) {
             case TILE_128x128_S6K16: return "split6_128x128_k16";
             case TILE_128x128_S6K16W8: return "split6_128x128_k16w8";
@@ -1268,7 +1269,7 @@ const char* conv_kernel_name(const ConvArgs& a, int tile_cfg) {
 }
 
 hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s) {
-    if (a.Cin < 32) {       // generic per-lane tap path (stem / small test shapes)
+    if (a.Cin < 32 && !a.stem) {       // generic per-lane tap path (stem / small test shapes)
         if (tile_cfg == TILE_128x32) return launch_conv_t<128, 32, 4, 1, false>(a, s);
         if (tile_cfg == TILE_128x128_W8 || tile_cfg == TILE_128x128_LS || tile_cfg == TILE_128x128_S6 ||
             tile_cfg == TILE_128x128_S3 || tile_cfg == TILE_128x128_S6K16 || tile_cfg == TILE_128x128_S3K16 ||

@@ -273,7 +273,21 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
         ConvLayer& l = net->layers[li];
         hipError_t e = launch_absmax(l.d_w, (long long)l.nk * 8 * l.CoutP * 4, net->d_wmax + li * ABSMAX_SLOTS, nullptr);
         if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("weight range: ") + hipGetErrorString(e));
-        if (l.Cin >= 32 && l.CoutP % 64 == 0) {          // layers the fp16-split kernels can take: pre-split cells
+        if ((int)li == net->conv1) {
+            // stem as a row walk for the split kernels: K-step kh = the 8 pixels x 4 channels that start at the window's
+            // left edge (one contiguous 128-byte read per output pixel and kernel row); pixel 7 has zero weights
+            std::vector<float> rows((size_t)7 * 8 * l.CoutP * 4, 0.f), host((size_t)l.nk * 8 * l.CoutP * 4);
+            HIP_TRY(hipMemcpy(host.data(), l.d_w, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+            for (int kh = 0; kh < 7; ++kh)
+                for (int kw = 0; kw < 7; ++kw)        // generic panel row = tap (Cin = 4: one row of 4 k-values per tap)
+                    memcpy(&rows[((size_t)(kh * 8 + kw)) * l.CoutP * 4], &host[((size_t)(kh * 7 + kw)) * l.CoutP * 4],
+                           (size_t)l.CoutP * 4 * sizeof(float));
+            if (!l.d_w_rows) HIP_TRY(hipMalloc(&l.d_w_rows, rows.size() * sizeof(float)));
+            HIP_TRY(hipMemcpy(l.d_w_rows, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+            if (!l.d_wh3) HIP_TRY(hipMalloc(&l.d_wh3, rows.size() * sizeof(float)));
+            e = launch_pack_h3(l.d_w_rows, 7, l.CoutP, net->d_wmax + li * ABSMAX_SLOTS, l.d_wh3, nullptr);
+            if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("stem weight cells: ") + hipGetErrorString(e));
+        } else if (l.Cin >= 32 && l.CoutP % 64 == 0) {          // layers the fp16-split kernels can take: pre-split cells
             const size_t bytes = (size_t)l.nk * 8 * l.CoutP * 16;
             if (!l.d_wh3) HIP_TRY(hipMalloc(&l.d_wh3, bytes));
             e = launch_pack_h3(l.d_w, l.nk, l.CoutP, net->d_wmax + li * ABSMAX_SLOTS, l.d_wh3, nullptr);
@@ -352,8 +366,6 @@ int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, in
     const int li = (int)(&l - net->layers.data());
     if (!net->wmax_valid) in_absmax = nullptr;
     a.in_absmax = in_absmax; a.w_absmax = in_absmax ? net->wmax(li) : nullptr;
-    static const bool use_cells = !(getenv("DGP_PRESPLIT_WEIGHTS") && atoi(getenv("DGP_PRESPLIT_WEIGHTS")) == 0);   // A/B switch
-    if (use_cells && in_absmax && l.d_wh3) { a.wh3 = l.d_wh3; a.wh3_bytes = (unsigned)((size_t)l.nk * 8 * l.CoutP * 16); }
     a.out_absmax = out_mode == 0 ? net->amax(li) : nullptr;
     a.in = in; a.wpk = l.d_w; a.scale = l.has_bn ? l.d_scale : nullptr; a.bias = l.d_bias; a.res = res; a.out = out;
     a.N = N; a.H = H; a.W = W; a.Cin = l.Cin; a.log2cin4 = ilog2(l.Cin / 4);
@@ -372,7 +384,15 @@ int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, in
         a.in_bytes = (unsigned)inb; a.out_bytes = (unsigned)outb; a.res_bytes = (unsigned)resb;
         a.w_bytes = (unsigned)((size_t)l.nk * 8 * l.CoutP * 16);
     }
-    const int tile_cfg = pick_tile(a.M, a.CoutP, l.nk * BK, a.in_absmax && a.w_absmax);
+    static const bool stem_rows = !(getenv("DGP_STEM_ROWS") && atoi(getenv("DGP_STEM_ROWS")) == 0);        // A/B switch
+    static const bool f32_mode = getenv("DGP_CONV_MODE") && !strcmp(getenv("DGP_CONV_MODE"), "f32");
+    if (li == net->conv1 && l.d_w_rows && stem_rows && !f32_mode && l.CoutP % 64 == 0) {
+        a.stem = 1; a.tap_rows = 8; a.KH = 7; a.KW = 1; a.ntaps = 7; a.nk = 7; a.wpk = l.d_w_rows;
+        a.w_bytes = (unsigned)((size_t)7 * 8 * l.CoutP * 16);
+    }
+    static const bool use_cells = !(getenv("DGP_PRESPLIT_WEIGHTS") && atoi(getenv("DGP_PRESPLIT_WEIGHTS")) == 0);   // A/B switch
+    if (use_cells && in_absmax && l.d_wh3 && (li != net->conv1 || a.stem)) { a.wh3 = l.d_wh3; a.wh3_bytes = a.w_bytes; }
+    const int tile_cfg = pick_tile(a.M, a.CoutP, a.nk * BK, a.in_absmax && a.w_absmax);
     ProfScope ps(net, s, "conv:" + l.scope + "|" + conv_kernel_name(a, tile_cfg), conv_flops_of(l, a.M, out_mode == 1));
     const long long out_n = (long long)N * 4 * Ho * Wo * dc_nj;
     if (out_mode == 1 && slabs && (out_n & 3) == 0) {
