@@ -349,38 +349,52 @@ __global__ void head_gather_kernel(const float* __restrict__ dsc, int N, int h, 
 
 // max-pool 3x3/2 SAME backward fused with the stem's ReLU gate: dC1 = (C1 > 0) * sum over windows whose first
 // maximum is this element of dPool.
-__global__ void maxpool_bwd_kernel(const float* __restrict__ c1, const float* __restrict__ dpool, int N, int H, int W,
-                                   int C, int Ho, int Wo, int pt, int pl, float* __restrict__ dc1) {
-    const long long total = (long long)N * H * W * C;
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ c1, const float* __restrict__ dpool, int N, int H,
+                                                          int W, int C, int Ho, int Wo, int pt, int pl, float* __restrict__ dc1) {
+    // one thread per pixel and 4 channels (16-byte loads); <= 4 windows contain a pixel, each re-scanned for its first maximum
+    const int C4 = C >> 2;
+    const long long total = (long long)N * H * W * C4;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(g % C);
-        long long r = g / C;
+        const int c4 = (int)(g % C4);
+        long long r = g / C4;
         const int wi = (int)(r % W);
         r /= W;
         const int hi = (int)(r % H);
         const int n = (int)(r / H);
-        const float v = c1[g];
-        float acc = 0.f;
-        if (v > 0.f) {
+        const float4 v = *reinterpret_cast<const float4*>(c1 + g * 4);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (v.x > 0.f || v.y > 0.f || v.z > 0.f || v.w > 0.f) {
             for (int ho = max(0, (hi + pt - 2 + 1) / 2); ho <= min(Ho - 1, (hi + pt) / 2); ++ho)
                 for (int wo = max(0, (wi + pl - 2 + 1) / 2); wo <= min(Wo - 1, (wi + pl) / 2); ++wo) {
-                    // first maximum (row-major) of window (ho, wo)
-                    float best = -INFINITY;
-                    int bh = -1, bw = -1;
+                    // is this pixel the FIRST maximum (row-major) of window (ho, wo), per channel?  It is iff no earlier
+                    // element is >= it and no later element is > it.
+                    bool fx = true, fy = true, fz = true, fw = true;
                     for (int a = 0; a < 3; ++a) {
                         const int hh = ho * 2 - pt + a;
                         if ((unsigned)hh >= (unsigned)H) continue;
                         for (int b = 0; b < 3; ++b) {
                             const int ww = wo * 2 - pl + b;
-                            if ((unsigned)ww >= (unsigned)W) continue;
-                            const float u = c1[(((long long)n * H + hh) * W + ww) * C + c];
-                            if (u > best) { best = u; bh = hh; bw = ww; }
+                            if ((unsigned)ww >= (unsigned)W || (hh == hi && ww == wi)) continue;
+                            const float4 u = *reinterpret_cast<const float4*>(c1 + ((((long long)n * H + hh) * W + ww) * C4 + c4) * 4);
+                            const bool before = hh < hi || (hh == hi && ww < wi);
+                            fx = fx && (before ? u.x < v.x : u.x <= v.x);
+                            fy = fy && (before ? u.y < v.y : u.y <= v.y);
+                            fz = fz && (before ? u.z < v.z : u.z <= v.z);
+                            fw = fw && (before ? u.w < v.w : u.w <= v.w);
                         }
                     }
-                    if (bh == hi && bw == wi) acc += dpool[(((long long)n * Ho + ho) * Wo + wo) * C + c];
+                    const float4 d = *reinterpret_cast<const float4*>(dpool + ((((long long)n * Ho + ho) * Wo + wo) * C4 + c4) * 4);
+                    if (fx) acc.x += d.x;
+                    if (fy) acc.y += d.y;
+                    if (fz) acc.z += d.z;
+                    if (fw) acc.w += d.w;
                 }
+            if (!(v.x > 0.f)) acc.x = 0.f;        // ReLU gate of the stem
+            if (!(v.y > 0.f)) acc.y = 0.f;
+            if (!(v.z > 0.f)) acc.z = 0.f;
+            if (!(v.w > 0.f)) acc.w = 0.f;
         }
-        dc1[g] = acc;
+        *reinterpret_cast<float4*>(dc1 + g * 4) = acc;
     }
 }
 
@@ -895,7 +909,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
     {
         int pth = (net->hp - 1) * 2 + 3 - net->h1; if (pth < 0) pth = 0;
         int ptw = (net->wp - 1) * 2 + 3 - net->w1; if (ptw < 0) ptw = 0;
-        const long long tot = (long long)B * net->h1 * net->w1 * 64;
+        const long long tot = (long long)B * net->h1 * net->w1 * 16;
         hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(tot)), dim3(256), 0, s, F(pl.c1), G[cur], B, net->h1, net->w1, 64,
                            net->hp, net->wp, pth / 2, ptw / 2, F(pl.dc1));
         rc = layer_param_grads(tr, net->conv1, F(pl.p0), B, d.in_h, d.in_w, F(pl.dc1), net->h1, net->w1, 2, 3, 3, dwraw, colsum, s);
