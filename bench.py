@@ -185,8 +185,9 @@ def main():
             if dom.startswith("split"):
                 pk = dom.replace("splith3", "2").replace("split", "").split("_")      # NT, "128x128", "k16[w8]"
                 bk, cw = (pk[2][1:].split("w") + ["4"])[:2]
-                key = "conv_igemm_split_ls<%s,%s,%s,%s,%s>" % (pk[1].split("x")[0], pk[1].split("x")[1], pk[0], bk, cw)
-                ent = tr.get("per_kernel", {}).get(key)
+                key = "conv_igemm_split_ls<%s,%s,%s,%s,%s" % (pk[1].split("x")[0], pk[1].split("x")[1], pk[0], bk, cw)
+                cands = [v for k_, v in tr.get("per_kernel", {}).items() if k_.startswith(key)]       # (+ ",true": pre-split weights)
+                ent = max(cands, key=lambda v: v["launches_per_step"]) if cands else None
                 if ent:
                     roofline["traffic"] = float(ent["hbm_bytes_per_launch"])
                     roofline["traffic_unit"] = "HBM bytes per launch of the dominant kernel (average), PMC FETCH_SIZE x2 + WRITE_SIZE"
