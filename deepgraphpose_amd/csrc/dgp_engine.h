@@ -29,6 +29,10 @@ struct ConvLayer {
     bool has_bn = true, relu = false;
     float *d_w = nullptr, *d_scale = nullptr, *d_bias = nullptr;
     void* d_wh3 = nullptr;    // fp16 high/low cells of the panel (fp16-split kernels), built at load
+    // conv3 of a unit with a shortcut conv: both 1x1 convs as ONE K-concatenated GEMM [R2 | X] [W3 s3 ; Wsc ssc] + (b3 + bsc)
+    float *d_w_fused = nullptr, *d_bias_fused = nullptr;
+    void* d_wh3_fused = nullptr;
+    int nk_fused = 0, cin2 = 0;
     float* d_w_rows = nullptr;   // stem only: panel for the row walk [7 rows x 8 pixels][CoutP][4] (pixel 7 and channel 3 are zero)
 };
 
@@ -58,12 +62,13 @@ struct dgp_net {
     // layer li (filled at load); d_amax[li]: output of layer li (zeroed and re-tracked every forward);
     // d_inmax: the centred frame (|pixel - mean| < 256, constant)
     float *d_wmax = nullptr, *d_amax = nullptr, *d_inmax = nullptr;
-    bool wmax_valid = false;      // false after a trainer re-packed the panels: the forward then runs without ranges
-    const float* wmax(int li) const { return d_wmax ? d_wmax + (size_t)li * dgp::ABSMAX_SLOTS : nullptr; }
+    bool wmax_valid = false;      // false after a trainer re-packed the panels: everything derived from the weights at load time
+                                  // (ranges, fp16 cells, stem row panel, fused shortcut panels) is stale and the forward avoids it
+    const float* wmax(int li) const { return d_wmax ? d_wmax + (size_t)li * dgp::ABSMAX_SLOTS : nullptr; }     // li + n_layers: fused panel of layer li
     float* amax(int li) const { return d_amax ? d_amax + (size_t)li * dgp::ABSMAX_SLOTS : nullptr; }
     // optional per-launch timing (hipEvent pairs recorded on the caller's stream)
     bool prof_on = false, prof_in_infer = false;
-    int prof_slots = 0, prof_used = 0, prof_launches = 0, prof_cursor = 0;
+    int prof_slots = 0, prof_used = 0, prof_launches = 0, prof_cursor = 0, prof_launches_used = 0;
     std::vector<hipEvent_t> prof_ev;          // [slot][launch][2]
     std::vector<std::string> prof_names;      // per launch of the last profiled forward
     std::vector<double> prof_flops;
@@ -79,6 +84,7 @@ struct dgp_net {
             if (l.d_bias) (void)hipFree(l.d_bias);
             if (l.d_wh3) (void)hipFree(l.d_wh3);
             if (l.d_w_rows) (void)hipFree(l.d_w_rows);
+            for (void* q : {(void*)l.d_w_fused, (void*)l.d_bias_fused, l.d_wh3_fused}) if (q) (void)hipFree(q);
         }
         for (float* q : {d_wmax, d_amax, d_inmax}) if (q) (void)hipFree(q);
     }

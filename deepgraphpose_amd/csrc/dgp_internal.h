@@ -34,6 +34,12 @@ struct ConvArgs {
     int stem;             // split kernels: 4-channel input walked one kernel ROW per K-step (8 pixels x 4 channels = 128 contiguous bytes);
                           // chunk c of a row is the pixel wi0 + c, so the width check is per chunk
     int tap_rows;         // weight-panel rows (of 4 k-values) per tap; 0 = Cin / 4
+    // split kernels, 1x1 stride-1 convs only: K-concatenated second source on the same pixel grid (the shortcut conv fused into
+    // conv3: out = [R2 | X] [W3' ; Wsc']).  Cin = cin_split + Cin2; channels >= cin_split come from in2 [M][Cin - cin_split]
+    const float* in2;
+    const float* in2_absmax;
+    unsigned in2_bytes;
+    int cin_split;
     unsigned long long* dbg;
     unsigned in_bytes, w_bytes, res_bytes, out_bytes;   // buffer-descriptor extents (< 4 GiB each)
     // dynamic range tracking for the fp16-split kernels (device arrays of ABSMAX_SLOTS floats, may be null; the

@@ -786,10 +786,13 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float pow2_scale_for(const float* absmax, int lane) {
-    // 2^(14 - E) for max = m 2^E (1 <= m < 2); 1 for an all-zero (or untracked) tensor
+__device__ __forceinline__ float pow2_scale_for(const float* absmax, int lane, const float* absmax2 = nullptr) {
+    // 2^(14 - E) for max = m 2^E (1 <= m < 2); 1 for an all-zero (or untracked) tensor.  absmax2: a second tensor that
+    // shares the scale (K-concatenated sources)
     if (!absmax) return 1.f;
-    const unsigned mb = __float_as_uint(read_absmax(absmax, lane));
+    float mx = read_absmax(absmax, lane);
+    if (absmax2) mx = fmaxf(mx, read_absmax(absmax2, lane));
+    const unsigned mb = __float_as_uint(mx);
     const int be = (int)((mb >> 23) & 0xFF);            // biased exponent
     if (be == 0 || be == 0xFF) return 1.f;
     int se = 127 + 14 - (be - 127);
@@ -868,11 +871,15 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)p.in_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_w =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (int)p.w_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.in2 ? p.in2 : p.in), 0, p.in2 ? (int)p.in2_bytes : 0, 0x00020000);
         const int c = t % CH, rg = t / CH;
         int hi0[AROWS], wi0[AROWS], rowoff[AROWS], nbase[AROWS];
+        unsigned rowoff2[AROWS];          // second source (1x1, same pixel grid): byte offset of pixel m, chunk c
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
             const int m = m0 + rg + RG * i;
+            rowoff2[i] = (p.in2 && m < p.M) ? (unsigned)((m * (p.Cin - p.cin_split) + 4 * c) * 4) : OOB;
             if (m < p.M) {
                 const int n = m / HoWo;
                 const int rem = m - n * HoWo;
@@ -880,7 +887,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
                 const int wo = rem - ho * p.Wo;
                 hi0[i] = ho * p.stride - p.pad_t;
                 wi0[i] = wo * p.stride - p.pad_l;
-                rowoff[i] = (((n * p.H + hi0[i]) * p.W + wi0[i]) * p.Cin + 4 * c) * 4;
+                rowoff[i] = (((n * p.H + hi0[i]) * p.W + wi0[i]) * (p.in2 ? p.cin_split : p.Cin) + 4 * c) * 4;
                 nbase[i] = n * p.H * p.W;
             } else {
                 hi0[i] = -(1 << 28); wi0[i] = -(1 << 28); rowoff[i] = 0; nbase[i] = 0;
@@ -904,7 +911,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             pb_cell[i] = (plane * KG + kgl) * LDB + col;
         }
         int w_kh = 0, w_kw = 0, w_ch = 0, w_tap = 0;
-        const float scA = NT == 2 ? pow2_scale_for(p.in_absmax, lane) : 1.f;
+        const float scA = NT == 2 ? pow2_scale_for(p.in_absmax, lane, p.in2_absmax) : 1.f;
         const float scW = NT == 2 ? pow2_scale_for(p.w_absmax, lane) : 1.f;
         float4 ra0[AROWS], rb0[BSLOTS], ra1[AROWS], rb1[BSLOTS];
         auto gload = [&](int ks, float4 (&ra)[AROWS], float4 (&rb)[BSLOTS]) {
@@ -920,6 +927,10 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
                     const unsigned off = (unsigned)((nbase[i] + (hv >> 1) * p.W + (wv >> 1)) * p.Cin + w_ch + 4 * c) << 2;
                     ra[i] = buf_load16(rs_in, ok ? off : OOB);
                 }
+            } else if (p.in2 && w_ch >= p.cin_split) {        // second source of a K-concatenated 1x1 conv
+                const unsigned d2 = (unsigned)(w_ch - p.cin_split) * 4u;
+#pragma unroll
+                for (int i = 0; i < AROWS; ++i) ra[i] = buf_load16(rs_in2, rowoff2[i] == OOB ? OOB : rowoff2[i] + d2);
             } else {
 #pragma unroll
                 for (int i = 0; i < AROWS; ++i) {
@@ -1089,7 +1100,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
 #ifdef DGP_DIAG
     DIAG_STAMP(e1);
 #endif
-    const float post = NT == 2 ? 1.f / (pow2_scale_for(p.in_absmax, lane) * pow2_scale_for(p.w_absmax, lane)) : 1.f;    // exact
+    const float post = NT == 2 ? 1.f / (pow2_scale_for(p.in_absmax, lane, p.in2_absmax) * pow2_scale_for(p.w_absmax, lane)) : 1.f;    // exact
     ls_epilogue<TM, TN, WN>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
 #ifdef DGP_DIAG
     DIAG_STAMP(e2);
@@ -1114,6 +1125,8 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     a.ntiles = (a.CoutP + BN - 1) / BN;
     if (a.CoutP % BN != 0 || (a.Cin < 32 && !a.stem) || a.out_mode != 0) return hipErrorInvalidValue;
     if (a.tap_rows == 0) a.tap_rows = a.Cin >> 2;
+    if (a.in2 && (a.ntaps != 1 || a.stride != 1 || a.up || a.cin_split % 32 || (a.Cin - a.cin_split) % 32 || a.cin_split <= 0 ||
+                  a.cin_split >= a.Cin || a.H != a.Ho || a.W != a.Wo)) return hipErrorInvalidValue;
     auto kern = conv_igemm_split_ls<BM, BN, NT, BK, CW>;
     if (NT == 2 && CW == 4 && a.wh3) kern = conv_igemm_split_ls<BM, BN, NT, BK, CW, (NT == 2 && CW == 4)>;     // pre-split weights
     else a.wh3 = nullptr;

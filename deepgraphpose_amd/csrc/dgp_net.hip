@@ -189,6 +189,9 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
         if (tensors[i].name) m[tensors[i].name] = &tensors[i];
     HIP_TRY(hipSetDevice(net->device));
     const int nj = net->desc.num_joints;
+    std::map<int, std::vector<float>> keep_w, keep_scale, keep_bias;      // 1x1 convs that get fused (conv3 + shortcut)
+    std::map<int, bool> wanted;
+    for (const Unit& u : net->units) if (u.sc >= 0) { wanted[u.sc] = true; wanted[u.c3] = true; }
     for (size_t li = 0; li < net->layers.size(); ++li) {
         ConvLayer& l = net->layers[li];
         const bool is_head = ((int)li == net->head_part || (int)li == net->head_locref);
@@ -246,6 +249,7 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
                 bias[c] = be->data[c] - mu->data[c] * inv;
             }
         }
+        if (wanted.count((int)li)) { keep_w[(int)li] = hwio; keep_scale[(int)li] = scale; keep_bias[(int)li] = bias; }
         const size_t nfl = (size_t)l.nk * 8 * l.CoutP * 4;
         std::vector<float> packed(nfl);
         pack_panels(hwio.data(), l.KH, l.KW, l.Cin, l.Cout, packed.data());
@@ -259,10 +263,10 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
     // operand ranges for the fp16-split kernels
     const size_t nl = net->layers.size();
     const size_t rb = (size_t)ABSMAX_SLOTS * sizeof(float);
-    if (!net->d_wmax) HIP_TRY(hipMalloc(&net->d_wmax, nl * rb));
+    if (!net->d_wmax) HIP_TRY(hipMalloc(&net->d_wmax, 2 * nl * rb));
     if (!net->d_amax) HIP_TRY(hipMalloc(&net->d_amax, nl * rb));
     if (!net->d_inmax) HIP_TRY(hipMalloc(&net->d_inmax, rb));
-    HIP_TRY(hipMemset(net->d_wmax, 0, nl * rb));
+    HIP_TRY(hipMemset(net->d_wmax, 0, 2 * nl * rb));
     HIP_TRY(hipMemset(net->d_amax, 0, nl * rb));
     {
         std::vector<float> in_rng(ABSMAX_SLOTS, 0.f);
@@ -293,6 +297,33 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
             e = launch_pack_h3(l.d_w, l.nk, l.CoutP, net->d_wmax + li * ABSMAX_SLOTS, l.d_wh3, nullptr);
             if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("weight cells: ") + hipGetErrorString(e));
         }
+    }
+    // conv3 + shortcut conv of a block's first unit as one GEMM over the concatenated channels (BN scales folded into
+    // the weights, biases added): saves writing and re-reading the shortcut tensor
+    for (const Unit& u : net->units) {
+        if (u.sc < 0) continue;
+        ConvLayer& l3 = net->layers[u.c3];
+        const ConvLayer& ls = net->layers[u.sc];
+        if (l3.KH != 1 || ls.KH != 1 || ls.stride != 1 || l3.Cin % 32 || ls.Cin % 32 || l3.Cout != ls.Cout) continue;
+        const int c1 = l3.Cin, c2 = ls.Cin, co = l3.Cout;
+        std::vector<float> w((size_t)(c1 + c2) * co), b(co);
+        const std::vector<float>&w3 = keep_w[u.c3], &wsc = keep_w[u.sc], &s3 = keep_scale[u.c3], &ssc = keep_scale[u.sc];
+        for (int k = 0; k < c1; ++k) for (int o = 0; o < co; ++o) w[(size_t)k * co + o] = w3[(size_t)k * co + o] * s3[o];
+        for (int k = 0; k < c2; ++k) for (int o = 0; o < co; ++o) w[(size_t)(c1 + k) * co + o] = wsc[(size_t)k * co + o] * ssc[o];
+        for (int o = 0; o < co; ++o) b[o] = keep_bias[u.c3][o] + keep_bias[u.sc][o];
+        l3.nk_fused = (c1 + c2) / 32; l3.cin2 = c2;
+        const size_t nfl = (size_t)l3.nk_fused * 8 * l3.CoutP * 4;
+        std::vector<float> packed(nfl);
+        pack_panels(w.data(), 1, 1, c1 + c2, co, packed.data());
+        if (!l3.d_w_fused) HIP_TRY(hipMalloc(&l3.d_w_fused, nfl * sizeof(float)));
+        if (!l3.d_bias_fused) HIP_TRY(hipMalloc(&l3.d_bias_fused, co * sizeof(float)));
+        if (!l3.d_wh3_fused) HIP_TRY(hipMalloc(&l3.d_wh3_fused, nfl * sizeof(float)));
+        HIP_TRY(hipMemcpy(l3.d_w_fused, packed.data(), nfl * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(l3.d_bias_fused, b.data(), co * sizeof(float), hipMemcpyHostToDevice));
+        float* wm = net->d_wmax + (nl + (size_t)u.c3) * ABSMAX_SLOTS;
+        hipError_t e = launch_absmax(l3.d_w_fused, (long long)nfl, wm, nullptr);
+        if (e == hipSuccess) e = launch_pack_h3(l3.d_w_fused, l3.nk_fused, l3.CoutP, wm, l3.d_wh3_fused, nullptr);
+        if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("fused shortcut panel: ") + hipGetErrorString(e));
     }
     HIP_TRY(hipDeviceSynchronize());
     net->wmax_valid = true;
@@ -386,7 +417,7 @@ int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, in
     }
     static const bool stem_rows = !(getenv("DGP_STEM_ROWS") && atoi(getenv("DGP_STEM_ROWS")) == 0);        // A/B switch
     static const bool f32_mode = getenv("DGP_CONV_MODE") && !strcmp(getenv("DGP_CONV_MODE"), "f32");
-    if (li == net->conv1 && l.d_w_rows && stem_rows && !f32_mode && l.CoutP % 64 == 0) {
+    if (li == net->conv1 && l.d_w_rows && net->wmax_valid && stem_rows && !f32_mode && l.CoutP % 64 == 0) {
         a.stem = 1; a.tap_rows = 8; a.KH = 7; a.KW = 1; a.ntaps = 7; a.nk = 7; a.wpk = l.d_w_rows;
         a.w_bytes = (unsigned)((size_t)7 * 8 * l.CoutP * 16);
     }
@@ -411,6 +442,38 @@ int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, in
     }
     hipError_t e = launch_conv(a, tile_cfg, s);
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("conv launch (") + l.scope + "): " + hipGetErrorString(e));
+    return DGP_OK;
+}
+
+// conv3 and the shortcut conv of a unit as one K-concatenated 1x1 conv: out = relu([r2 | x] Wf + bf)
+int run_conv_fused_shortcut(dgp_net* net, const Unit& u, const float* r2, const float* x, int N, int H, int W, float* out,
+                            hipStream_t s, const float* r2_absmax, const float* x_absmax) {
+    const ConvLayer& l = net->layers[u.c3];
+    const ConvLayer& ls = net->layers[u.sc];
+    const int nl = (int)net->layers.size();
+    if (!net->wmax_valid) { r2_absmax = nullptr; x_absmax = nullptr; }
+    ConvArgs a{};
+    a.in = r2; a.in2 = x; a.cin_split = l.Cin; a.Cin = l.Cin + l.cin2; a.log2cin4 = 0;
+    a.wpk = l.d_w_fused; a.scale = nullptr; a.bias = l.d_bias_fused; a.res = nullptr; a.out = out;
+    a.N = N; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.Cout = l.Cout; a.CoutP = l.CoutP;
+    a.KH = 1; a.KW = 1; a.stride = 1; a.dil = 1; a.pad_t = 0; a.pad_l = 0; a.ntaps = 1; a.nk = l.nk_fused; a.M = N * H * W;
+    a.relu = 1; a.out_mode = 0;
+    const double lim = 4294967000.0;
+    const double inb = (double)a.M * l.Cin * 4, in2b = (double)a.M * l.cin2 * 4, outb = (double)a.M * l.Cout * 4;
+    if (inb > lim || in2b > lim || outb > lim)
+        return fail(DGP_ERR_INVALID, "activation tensor exceeds the 4 GiB buffer-descriptor range; lower the batch");
+    a.in_bytes = (unsigned)inb; a.in2_bytes = (unsigned)in2b; a.out_bytes = (unsigned)outb;
+    a.w_bytes = (unsigned)((size_t)l.nk_fused * 8 * l.CoutP * 16);
+    if (r2_absmax && x_absmax) {
+        a.in_absmax = r2_absmax; a.in2_absmax = x_absmax; a.w_absmax = net->wmax(nl + u.c3);
+        a.wh3 = l.d_wh3_fused; a.wh3_bytes = a.w_bytes;
+    }
+    a.out_absmax = net->amax(u.c3);
+    const int tile_cfg = pick_tile(a.M, a.CoutP, a.nk * BK, a.in_absmax && a.w_absmax);
+    ProfScope ps(net, s, "conv:" + l.scope + "+shortcut|" + conv_kernel_name(a, tile_cfg),
+                 conv_flops_of(l, a.M, false) + conv_flops_of(ls, a.M, false));
+    hipError_t e = launch_conv(a, tile_cfg, s);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("fused conv3+shortcut (") + l.scope + "): " + hipGetErrorString(e));
     return DGP_OK;
 }
 
@@ -503,7 +566,11 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
         float* xout = X[cur ^ 1];
         const float* res = xin;
         int res_s = u.stride, res_H = h, res_W = w;
-        if (u.sc >= 0) {
+        static const bool fuse_env = !(getenv("DGP_FUSE_SHORTCUT") && atoi(getenv("DGP_FUSE_SHORTCUT")) == 0);      // A/B switch
+        static const bool f32_mode = getenv("DGP_CONV_MODE") && !strcmp(getenv("DGP_CONV_MODE"), "f32");
+        const bool fuse = fuse_env && !f32_mode && net->wmax_valid && u.sc >= 0 && net->layers[u.c3].d_w_fused && u.stride == 1 && ho == h && wo == w &&
+                          net->layers[u.c3].CoutP % 64 == 0;
+        if (u.sc >= 0 && !fuse) {
             // slim.conv2d(1x1, stride, SAME): pad 0, samples x[::s, ::s]
             rc = run_conv(net, net->layers[u.sc], xin, B, h, w, 0, 0, ho, wo, nullptr, 0, 0, 0, false, 0, 0, SC, s, nullptr, x_rng);
             if (rc) return rc;
@@ -516,8 +583,11 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
         rc = run_conv(net, net->layers[u.c2], R1, B, h, w, pb_h, pb_w, ho, wo, nullptr, 0, 0, 0, true, 0, 0, R2, s, nullptr,
                       net->amax(u.c1));
         if (rc) return rc;
-        rc = run_conv(net, net->layers[u.c3], R2, B, ho, wo, 0, 0, ho, wo, res, res_s, res_H, res_W, true, 0, 0, xout, s,
-                      nullptr, net->amax(u.c2));
+        if (fuse)
+            rc = run_conv_fused_shortcut(net, u, R2, xin, B, h, w, xout, s, net->amax(u.c2), x_rng);
+        else
+            rc = run_conv(net, net->layers[u.c3], R2, B, ho, wo, 0, 0, ho, wo, res, res_s, res_H, res_W, true, 0, 0, xout, s,
+                          nullptr, net->amax(u.c2));
         if (rc) return rc;
         x_rng = net->amax(u.c3);
         cur ^= 1; h = ho; w = wo;
@@ -595,13 +665,17 @@ int dgp_net_profile_begin(dgp_net* net, int32_t max_steps) {
 int dgp_net_profile_end(dgp_net* net, int32_t* n_steps, int32_t* n_launches) {
     if (!net) return fail(DGP_ERR_INVALID, "dgp_net_profile_end: null net");
     net->prof_on = false;
+    // launches actually recorded per step (fused layers make it smaller than the slots reserved by dgp_net_stats)
+    int recorded = 0;
+    while (recorded < net->prof_launches && !net->prof_names[recorded].empty()) ++recorded;
+    net->prof_launches_used = recorded;
     if (n_steps) *n_steps = net->prof_used;
-    if (n_launches) *n_launches = net->prof_launches;
+    if (n_launches) *n_launches = recorded;
     return DGP_OK;
 }
 
 int dgp_net_profile_launch(dgp_net* net, int32_t launch, char* name, int32_t name_cap, double* flops, double* avg_ms) {
-    if (!net || launch < 0 || launch >= net->prof_launches) return fail(DGP_ERR_INVALID, "dgp_net_profile_launch: bad index");
+    if (!net || launch < 0 || launch >= net->prof_launches_used) return fail(DGP_ERR_INVALID, "dgp_net_profile_launch: bad index");
     if (name && name_cap > 0) { strncpy(name, net->prof_names[launch].c_str(), name_cap - 1); name[name_cap - 1] = 0; }
     if (flops) *flops = net->prof_flops[launch];
     double tot = 0; int cnt = 0;
