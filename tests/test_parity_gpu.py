@@ -347,3 +347,33 @@ def test_fp16_split_keeps_fp32_class_accuracy_over_wide_ranges(eng, monkeypatch)
             bound = bound + float(np.abs(x).max()) * float(np.abs(w).max()) * Cin * 2.0 ** -32
         assert (np.abs(y16 - ref) <= bound).all(), (xs, ws, outlier, float((np.abs(y16 - ref) / bound).max()))
         assert (np.abs(y32 - ref) <= bound).all()
+
+
+@pytest.mark.parametrize("mode,extra", [("f32", {}), ("bf16x6", {}), ("f16x3", {"DGP_FUSE_SHORTCUT": "0", "DGP_STEM_ROWS": "0",
+                                                                                "DGP_PRESPLIT_WEIGHTS": "0"})])
+def test_other_conv_modes_keep_parity(eng, mode, extra):
+    """The conv path is chosen once per process (DGP_CONV_MODE and the A/B switches are read at first use), so the
+    non-default paths -- fp32 MFMA, the range-free bf16x6 split, and fp16x3 without fused shortcut / row-walk stem /
+    pre-split weights -- run in a child process: whole-network parity vs the oracle on a small ResNet-50."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent('''
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r)
+        from deepgraphpose_amd import engine, synthetic
+        from oracle import dgp_oracle as O
+        wts = synthetic.make_weights(50, 3, False, seed=2, head_std=0.05)
+        fr = synthetic.make_frames(3, 96, 128, 3, seed=4)
+        net = engine.DGPNet(50, 3, 96, 128, max_batch=3)
+        net.load_weights(wts)
+        mu, conf, idx = net.infer(torch.from_numpy(fr).cuda(), 1.0, 1)
+        ref = O.infer(fr, wts, 50, 8.0, 1.0, 1)
+        d = float(np.abs(mu.cpu().numpy() - ref["mu"]).max() * 8.0)
+        ok = np.array_equal(idx.cpu().numpy(), ref["idx"])
+        print("RESULT", d, ok)
+    ''') % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DGP_CONV_MODE=mode, **extra)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    assert line, out.stdout[-2000:] + out.stderr[-2000:]
+    _, d, ok = line[0].split()
+    assert float(d) < PX_TOL and ok == "True", line[0]
