@@ -97,6 +97,12 @@ def load():
         raise DgpError(
             "libdgp_hip.so not found at %s -- build it with `python -m deepgraphpose_amd.build` "
             "(hipcc --offload-arch=gfx950); deepgraphpose_amd has no CPU fallback" % LIB_PATH)
+    # PyTorch ships its own libamdhip64; load it FIRST so that libdgp_hip.so binds to the same HIP runtime instance as
+    # the tensors and streams it is handed (a second runtime loaded earlier sees "no ROCm-capable device")
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)     # AttributeError if the ABI is incomplete

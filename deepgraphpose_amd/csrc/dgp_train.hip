@@ -256,20 +256,6 @@ __global__ __launch_bounds__(256) void wgrad_f32(const WgradArgs p) {
     }
 }
 
-// column sums of dY [M, C] -> out[C] (+=): d beta / d bias
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, int M, int C, int rows_per_block,
-                                                     float* __restrict__ out) {
-    __shared__ float part[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-    const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
-    float s = 0.f;
-    if (c < C)
-        for (int m = m0 + rl; m < m1; m += 4) s += dy[(long long)m * C + c];
-    part[rl][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (rl == 0 && c < C) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
-}
-
 // dW = scale * dWraw (HWIO, real Cin) and dot[co] += sum_k W[k][co] * dWraw[k][co]   (grid: k-chunks x co-tiles of 64)
 __global__ __launch_bounds__(256) void scale_dw_dot_kernel(const float* __restrict__ dwraw, const float* __restrict__ w,
                                                            const float* __restrict__ scale, int taps, int cin, int cin_real,
@@ -572,14 +558,6 @@ hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const floa
     } else {
         hipLaunchKernelGGL(wgrad_f32<1>, dim3(kt, nt, split), dim3(256), 2 * 2 * 32 * 64 * 4, s, a);
     }
-    return hipGetLastError();
-}
-
-hipError_t colsum_launch(const float* dy, int M, int C, float* out, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s);
-    if (e != hipSuccess) return e;
-    const int rows = 2048;
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, (M + rows - 1) / rows), dim3(256), 0, s, dy, M, C, rows, out);
     return hipGetLastError();
 }
 
