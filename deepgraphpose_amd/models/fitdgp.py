@@ -100,6 +100,16 @@ def _setup(snapshot, dlcpath, shuffle, trainingsetindex, frame_sources):
     return data_batcher, str(train_path / snapshot)
 
 
+def _dp_index(it, n):
+    """Data-parallel runs (torch.distributed initialised, world W > 1): the schedule is identical on every
+    rank (same seeds), iteration `it` of rank r consumes entry it*W + r, and Trainer.step averages the gradients over the
+    ranks -- W windows per optimiser step.  Single process: the reference's schedule, unchanged."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return (it * dist.get_world_size() + dist.get_rank()) % n
+    return it
+
+
 def _make_trainer(data_batcher, init_weights, max_frames):
     import torch  # noqa: F401
     from .. import weights_io
@@ -309,7 +319,7 @@ def fit_dgp_labeledonly(snapshot, dlcpath, shuffle=1, step=1, saveiters=1000, di
     t_start = time.time()
     it = -1
     for it in range(maxiters):
-        dataset_i, frame_i = table[batch_ind_all[it]]
+        dataset_i, frame_i = table[batch_ind_all[_dp_index(it, maxiters)]]
         d = data_batcher.datasets[dataset_i]
         (vis, hid, _, images, joint_loc, _, _, addn), _ = data_batcher.next_batch(0, dataset_i, np.array([frame_i]),
                                                                                   np.array([], dtype=int))
@@ -365,7 +375,7 @@ def fit_dgp(snapshot, dlcpath, batch_size=10, shuffle=1, step=2, saveiters=1000,
     t_start = time.time()
     it = -1
     for it in range(maxiters):
-        batch_ind = batch_ind_all[it]
+        batch_ind = batch_ind_all[_dp_index(it, maxiters)]
         dataset_i = int(batch_ind[-1])
         d = data_batcher.datasets[dataset_i]
         all_frame_batch = batch_ind[:-1]

@@ -149,6 +149,17 @@ class Trainer:
                    "dgp_train_backward")
         return losses
 
+    def grads_tensor(self) -> torch.Tensor:
+        """The flat fp32 gradient buffer of every trainable tensor as a device tensor (no copy)."""
+        ptr = self.lib.dgp_trainer_buffer(self._t, 1)
+        return _view(ptr, (self.n_trainable,), self.device)
+
+    def allreduce_gradients(self, group=None):
+        """Data-parallel step: average the gradients over the ranks (RCCL) before apply_gradients."""
+        from .dist import average_gradients
+        torch.cuda.current_stream(self.device).synchronize()       # backward kernels ran on this stream via the C-ABI
+        average_gradients(self.grads_tensor(), group)
+
     def apply_gradients(self, lr: float, momentum: float = 0.9, clip_norm: float = 10.0) -> float:
         g = C.c_float()
         _lib.check(self.lib.dgp_sgd_momentum_clip(self._t, lr, momentum, clip_norm, C.byref(g), _stream(self.device)),
@@ -160,6 +171,9 @@ class Trainer:
              labeled_only: bool = False):
         losses = self.forward_backward(frames, batch, hyper, S0, ws, ws_max, n_frames_total, n_visible_frames_total,
                                        labeled_only)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.allreduce_gradients()               # data-parallel: mean gradient over the ranks (RCCL)
         losses["grad_norm"] = self.apply_gradients(hyper.lr, hyper.momentum, hyper.clip_norm)
         return losses
 

@@ -253,6 +253,35 @@ def test_frame_sharding_allgather_gloo_world2(T):
         np.testing.assert_array_equal(i[:, 2, 1], np.full(T, 2))
 
 
+def _grad_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from deepgraphpose_amd import dist as dd
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    dd.init_from_env("gloo")
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    dd.average_gradients(g, bucket_floats=256)                  # 4 buckets
+    q.put((rank, g.numpy()))
+    dist.destroy_process_group()
+
+
+def test_gradient_averaging_gloo_world2():
+    """N4: bucketed all-reduce of the flat gradient buffer = the mean over ranks, identical on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    ps = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, g in res:
+        np.testing.assert_array_equal(g, np.arange(1000, dtype=np.float32) * 1.5)
+
+
 def test_dlc_pose_dataset_samples(tmp_path):
     """Step-0 loader (pose_defaultdataset.PoseDataset): seeded schedule is reproducible, target maps have the
     network's scoremap size for every jittered / cropped frame size, disks sit on the scaled labels."""

@@ -131,6 +131,24 @@ def test_full_backward_matches_autograd(lib_built):
     assert np.sqrt(tot_err / tot_ref) < 3e-3
 
 
+def test_flat_gradient_view_matches_named_gradients(lib_built):
+    """N4 plumbing: the flat device view that the RCCL all-reduce averages is the same memory get_grads() downloads."""
+    from deepgraphpose_amd.train import Trainer
+    from deepgraphpose_amd.loss import DGPHyper
+    batch, S0, wts, frames, ws, ws_max = _train_case(7)
+    tr = Trainer(50, 3, 64, 96, max_frames=3)
+    tr.load_weights(wts)
+    tr.forward_backward(torch.from_numpy(frames).cuda(), batch, DGPHyper(gm2=0, gm3=0), S0, ws, ws_max, 300.0, 25.0)
+    flat = tr.grads_tensor().cpu().numpy()
+    named = tr.get_grads()
+    assert flat.size == tr.n_trainable
+    for k, (off, size, st) in tr.table.items():
+        if not st:
+            np.testing.assert_array_equal(flat[off:off + size], named[k].ravel())
+    tr.allreduce_gradients()                                    # world size 1: a no-op that must not touch the buffer
+    np.testing.assert_array_equal(tr.grads_tensor().cpu().numpy(), flat)
+
+
 def test_two_optimizer_steps_match_oracle(lib_built):
     from deepgraphpose_amd.train import Trainer
     from deepgraphpose_amd.loss import DGPHyper
