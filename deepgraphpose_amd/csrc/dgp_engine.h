@@ -62,6 +62,8 @@ struct dgp_net {
     // layer li (filled at load); d_amax[li]: output of layer li (zeroed and re-tracked every forward);
     // d_inmax: the centred frame (|pixel - mean| < 256, constant)
     float *d_wmax = nullptr, *d_amax = nullptr, *d_inmax = nullptr;
+    float* tail_slab = nullptr;   // workspace region for the K-split of a conv grid's tail (set by the running forward)
+    unsigned tail_slab_bytes = 0;
     bool wmax_valid = false;      // false after a trainer re-packed the panels: everything derived from the weights at load time
                                   // (ranges, fp16 cells, stem row panel, fused shortcut panels) is stale and the forward avoids it
     const float* wmax(int li) const { return d_wmax ? d_wmax + (size_t)li * dgp::ABSMAX_SLOTS : nullptr; }     // li + n_layers: fused panel of layer li

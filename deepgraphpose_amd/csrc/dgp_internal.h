@@ -36,6 +36,11 @@ struct ConvArgs {
     int tap_rows;         // weight-panel rows (of 4 k-values) per tap; 0 = Cin / 4
     // split kernels, 1x1 stride-1 convs only: K-concatenated second source on the same pixel grid (the shortcut conv fused into
     // conv3: out = [R2 | X] [W3' ; Wsc']).  Cin = cin_split + Cin2; channels >= cin_split come from in2 [M][Cin - cin_split]
+    // split kernels: K-split of the grid's TAIL.  Blocks >= n_main each compute 1/tail_ksplit of the K range of one of the last
+    // tiles into a slab (raw accumulators); launch_conv then runs tail_fixup to sum the parts in fixed order and apply the epilogue
+    float* slab;
+    unsigned slab_bytes;
+    int n_main, tail_ksplit;
     const float* in2;
     const float* in2_absmax;
     unsigned in2_bytes;

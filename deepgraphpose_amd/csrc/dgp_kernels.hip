@@ -852,8 +852,13 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int tile;
-    {
-        const int nwg = gridDim.x, b = blockIdx.x;
+    int part = -1, tail_slot = 0;                    // part >= 0: this block computes one K-slice of a tail tile into a slab
+    if (p.tail_ksplit > 1 && (int)blockIdx.x >= p.n_main) {
+        tail_slot = (int)blockIdx.x - p.n_main;
+        tile = p.n_main + tail_slot / p.tail_ksplit;
+        part = tail_slot % p.tail_ksplit;
+    } else {
+        const int nwg = p.tail_ksplit > 1 ? p.n_main : (int)gridDim.x, b = blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, loc = b >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
@@ -862,7 +867,9 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
     const int m0 = mt * BM;
     const int n0 = nt * BN;
     const int HoWo = p.Ho * p.Wo;
-    const int nks = p.nk * (32 / BK);               // K-steps of BK floats (weight panels are padded to 32)
+    const int nks_all = p.nk * (32 / BK);           // K-steps of BK floats (weight panels are padded to 32)
+    const int nks = part >= 0 ? nks_all / p.tail_ksplit : nks_all;      // steps of THIS block
+    const int ks0 = part >= 0 ? part * nks : 0;
 
     if (wave >= CW) {
         // ================================ loader waves ================================
@@ -911,6 +918,11 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             pb_cell[i] = (plane * KG + kgl) * LDB + col;
         }
         int w_kh = 0, w_kw = 0, w_ch = 0, w_tap = 0;
+        if (ks0) {                                   // K-slice of a tail tile: start the walker at step ks0
+            if (p.tap_minor) { w_ch = (ks0 / p.ntaps) * BK; w_tap = ks0 % p.ntaps; }
+            else { const int spt = p.Cin > BK ? p.Cin / BK : 1; w_tap = ks0 / spt; w_ch = (ks0 % spt) * BK; }
+            w_kh = w_tap / p.KW; w_kw = w_tap % p.KW;
+        }
         const float scA = NT == 2 ? pow2_scale_for(p.in_absmax, lane, p.in2_absmax) : 1.f;
         const float scW = NT == 2 ? pow2_scale_for(p.w_absmax, lane) : 1.f;
         float4 ra0[AROWS], rb0[BSLOTS], ra1[AROWS], rb1[BSLOTS];
@@ -1100,6 +1112,13 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
 #ifdef DGP_DIAG
     DIAG_STAMP(e1);
 #endif
+    if (part >= 0) {        // raw accumulators of this K-slice -> slab [BM][BN]; tail_fixup sums the slices and applies the epilogue
+        ConvArgs q = p;
+        q.out = p.slab + (size_t)tail_slot * (BM * BN); q.out_bytes = BM * BN * 4; q.Cout = BN; q.M = BM;
+        q.scale = nullptr; q.bias = nullptr; q.res = nullptr; q.mask = nullptr; q.res_s = 0; q.relu = 0; q.out_absmax = nullptr;
+        ls_epilogue<TM, TN, WN>(q, acc, smem, wave, lane, 0, 0, wave_m0, wave_n0, 1.f);
+        return;
+    }
     const float post = NT == 2 ? 1.f / (pow2_scale_for(p.in_absmax, lane, p.in2_absmax) * pow2_scale_for(p.w_absmax, lane)) : 1.f;    // exact
     ls_epilogue<TM, TN, WN>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
 #ifdef DGP_DIAG
@@ -1109,6 +1128,55 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
         d[0] = t_pro; d[1] = acc_mf + acc_ba; d[2] = e2 - e1; d[4] = acc_mf; d[7] = acc_ba;
     }
 #endif
+}
+
+// Second half of the tail K-split: out = epilogue(sum over the K-slices of a tail tile, in fixed order).
+template <int BM, int BN, bool F16>
+__global__ __launch_bounds__(256) void tail_fixup_kernel(const ConvArgs p) {
+    const int lane = threadIdx.x & 63;
+    const float post = F16 ? 1.f / (pow2_scale_for(p.in_absmax, lane, p.in2_absmax) * pow2_scale_for(p.w_absmax, lane)) : 1.f;
+    constexpr int C4 = BN / 4;
+    const int per_tile = BM * C4;
+    const int ntail = (int)gridDim.y;
+    const int HoWo = p.Ho * p.Wo;
+    float amax = 0.f;
+    for (int tt = blockIdx.y; tt < ntail; tt += gridDim.y) {
+        const int tile = p.n_main + tt, mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < per_tile; e += gridDim.x * blockDim.x) {
+            const int row = e / C4, c4 = e - row * C4;
+            const int m = mt * BM + row, co = nt * BN + 4 * c4;
+            if (m >= p.M || co >= p.Cout) continue;
+            const float* sl = p.slab + ((size_t)tt * p.tail_ksplit) * (BM * BN) + (size_t)row * BN + 4 * c4;
+            float4 a = *reinterpret_cast<const float4*>(sl);
+            for (int s = 1; s < p.tail_ksplit; ++s) {
+                const float4 b = *reinterpret_cast<const float4*>(sl + (size_t)s * (BM * BN));
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            float4 sc = make_float4(post, post, post, post), bi = make_float4(0.f, 0.f, 0.f, 0.f), rr = bi;
+            if (p.scale) { const float4 t = *reinterpret_cast<const float4*>(p.scale + co); sc.x *= t.x; sc.y *= t.y; sc.z *= t.z; sc.w *= t.w; }
+            if (p.bias) bi = *reinterpret_cast<const float4*>(p.bias + co);
+            if (p.res) {
+                long long roff = -1;
+                if (p.res_s == 1) roff = (long long)m * p.Cout + co;
+                else {
+                    const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                    if (p.res_s == -2) { if (!((ho | wo) & 1)) roff = (((long long)n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1)) * p.Cout + co; }
+                    else roff = (((long long)n * p.res_H + ho * p.res_s) * p.res_W + wo * p.res_s) * p.Cout + co;
+                }
+                if (roff >= 0) rr = *reinterpret_cast<const float4*>(p.res + roff);
+            }
+            float4 o;
+            o.x = a.x * sc.x + bi.x + rr.x; o.y = a.y * sc.y + bi.y + rr.y; o.z = a.z * sc.z + bi.z + rr.z; o.w = a.w * sc.w + bi.w + rr.w;
+            if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            if (p.mask) {
+                const float4 g = *reinterpret_cast<const float4*>(p.mask + (long long)m * p.Cout + co);
+                o.x = g.x > 0.f ? o.x : 0.f; o.y = g.y > 0.f ? o.y : 0.f; o.z = g.z > 0.f ? o.z : 0.f; o.w = g.w > 0.f ? o.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(p.out + (long long)m * p.Cout + co) = o;
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        }
+    }
+    if (p.out_absmax) track_absmax(p.out_absmax, amax, lane, (int)((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6)));
 }
 
 template <int BM, int BN, int NT, int BK, int CW = 4>
@@ -1137,13 +1205,40 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done[a.wh3 ? 1 : 0] = true;
     }
-    const long long nwg = (long long)a.mtiles * a.ntiles;
+    long long nwg = (long long)a.mtiles * a.ntiles;
+    // Grid tail: with `slots` workgroups resident, the last tiles % slots tiles run on a mostly idle chip.  Split their K range
+    // over up to 4 blocks each (raw slabs + a fixup pass that sums them in fixed order: deterministic) so the last round is full.
+    a.tail_ksplit = 0; a.n_main = (int)nwg;
+    static const int tail_env = getenv("DGP_TAIL_SPLIT") ? atoi(getenv("DGP_TAIL_SPLIT")) : 1;      // A/B switch
+    if (tail_env && a.slab && CW == 4 && BK == 32 && BN == 128) {      // (128 x 64 tiles fit three per CU and gain nothing)
+        static int n_cu = 0;
+        if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+        const long long slots = 2LL * n_cu;            // two workgroups of these kernels fit a CU
+        const long long rem = nwg % slots;
+        const int nks = a.nk * (32 / BK);
+        if (rem > 0 && rem * 4 <= slots * 3) {
+            int ks = (int)(slots / rem);
+            if (ks > 4) ks = 4;
+            while (ks > 1 && (nks % ks != 0 || nks / ks < 4)) --ks;
+            // the fixup pass costs ~10-15 us: with two or more full rounds in front of the tail it only pays for deep-K layers
+            // (measured per layer with DGP_TAIL_SPLIT=0/1: block3 -17 %, block4 N=512 -3..-9 %, block2 +-5 % -> left alone)
+            if (nwg / slots >= 2 && nks < 48) ks = 1;
+            if (ks > 1 && (unsigned long long)rem * ks * BM * BN * 4ull <= a.slab_bytes) {
+                a.tail_ksplit = ks; a.n_main = (int)(nwg - rem);
+                nwg = a.n_main + rem * ks;
+            }
+        }
+    }
 #ifdef DGP_DIAG
     static unsigned long long* dbg_buf = nullptr;
     if (!dbg_buf) (void)hipMalloc(&dbg_buf, 10 * 8 * 65536);
     a.dbg = nwg <= 65536 ? dbg_buf : nullptr;
 #endif
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * (CW + 4)), smem, s, a);
+    if (a.tail_ksplit > 1) {
+        const int ntail = (int)((long long)a.mtiles * a.ntiles - a.n_main);
+        hipLaunchKernelGGL((tail_fixup_kernel<BM, BN, NT == 2>), dim3(BM * BN / 4 / 256, ntail), dim3(256), 0, s, a);
+    }
 #ifdef DGP_DIAG
     if (a.dbg) {
         (void)hipStreamSynchronize(s);

@@ -336,9 +336,10 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
 namespace {
 
 constexpr int HEAD_KSPLIT_MAX = 8;
+constexpr size_t TAIL_SLAB_FLOATS = (size_t)512 * 128 * 128;      // K-split slabs of a grid's tail: <= 512 slices of a 128 x 128 tile (32 MB)
 
 struct Plan {
-    size_t off_p0, off_c1, off_x0, off_x1, off_sc, off_r1, off_r2, off_scmap, off_locref, off_slabs, total;
+    size_t off_p0, off_c1, off_x0, off_x1, off_sc, off_r1, off_r2, off_scmap, off_locref, off_slabs, off_tail, total;
 };
 
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -365,6 +366,7 @@ Plan make_plan(const dgp_net* net, int B) {
     p.off_scmap = take((size_t)B * 4 * net->fh * net->fw * d.num_joints);
     p.off_locref = take((size_t)B * 4 * net->fh * net->fw * 2 * d.num_joints);
     p.off_slabs = take((size_t)HEAD_KSPLIT_MAX * B * 4 * net->fh * net->fw * 2 * d.num_joints);
+    p.off_tail = take(TAIL_SLAB_FLOATS);
     p.total = o;
     return p;
 }
@@ -398,6 +400,7 @@ int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, in
     if (!net->wmax_valid) in_absmax = nullptr;
     a.in_absmax = in_absmax; a.w_absmax = in_absmax ? net->wmax(li) : nullptr;
     a.out_absmax = out_mode == 0 ? net->amax(li) : nullptr;
+    a.slab = net->tail_slab; a.slab_bytes = net->tail_slab_bytes;
     a.in = in; a.wpk = l.d_w; a.scale = l.has_bn ? l.d_scale : nullptr; a.bias = l.d_bias; a.res = res; a.out = out;
     a.N = N; a.H = H; a.W = W; a.Cin = l.Cin; a.log2cin4 = ilog2(l.Cin / 4);
     a.Ho = Ho; a.Wo = Wo; a.Cout = l.Cout; a.CoutP = l.CoutP;
@@ -469,6 +472,7 @@ int run_conv_fused_shortcut(dgp_net* net, const Unit& u, const float* r2, const 
         a.wh3 = l.d_wh3_fused; a.wh3_bytes = a.w_bytes;
     }
     a.out_absmax = net->amax(u.c3);
+    a.slab = net->tail_slab; a.slab_bytes = net->tail_slab_bytes;
     const int tile_cfg = pick_tile(a.M, a.CoutP, a.nk * BK, a.in_absmax && a.w_absmax);
     ProfScope ps(net, s, "conv:" + l.scope + "+shortcut|" + conv_kernel_name(a, tile_cfg),
                  conv_flops_of(l, a.M, false) + conv_flops_of(ls, a.M, false));
@@ -540,6 +544,7 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     int rc;
 
     net->prof_cursor = 0;
+    net->tail_slab = (float*)(ws + pl.off_tail); net->tail_slab_bytes = (unsigned)(TAIL_SLAB_FLOATS * sizeof(float));
     hipError_t e;
     if (net->d_amax) HIP_TRY(hipMemsetAsync(net->d_amax, 0, net->layers.size() * ABSMAX_SLOTS * sizeof(float), s));   // ranges are per forward
     {
