@@ -748,6 +748,11 @@ static hipError_t launch_conv_ls(ConvArgs a, hipStream_t s) {
 // A compute lane (row = lane & 31, half = lane >> 5) reads k-group 2*kk + half of its row with ONE ds_read_b128 per
 // plane; 32 lanes read 512 contiguous bytes.  Plane pitch BM + 4 rows keeps the loaders' 8-byte writes conflict-free.
 // ------------------------------------------------------------------------------------
+#ifdef DGP_EXP_NO_RFL          // tuning experiment: what the waterfall loops around the walker-offset loads cost
+#define DGP_RFL(x) (x)
+#else
+#define DGP_RFL(x) __builtin_amdgcn_readfirstlane(x)
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <bool IS_B = false>
@@ -927,9 +932,9 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
         const float scW = NT == 2 ? pow2_scale_for(p.w_absmax, lane) : 1.f;
         float4 ra0[AROWS], rb0[BSLOTS], ra1[AROWS], rb1[BSLOTS];
         auto gload = [&](int ks, float4 (&ra)[AROWS], float4 (&rb)[BSLOTS]) {
-            const int dh = w_kh * p.dil, dw = w_kw * p.dil;
-            const int doff = ((dh * p.W + dw) * p.Cin + w_ch) * 4;
-            const bool tapok = w_tap < p.ntaps;
+            const int dh = DGP_RFL(w_kh * p.dil), dw = DGP_RFL(w_kw * p.dil);
+            const int doff = DGP_RFL(((dh * p.W + dw) * p.Cin + w_ch) * 4);
+            const bool tapok = DGP_RFL(w_tap) < p.ntaps;
             if (p.up == 2) {
 #pragma unroll
                 for (int i = 0; i < AROWS; ++i) {
@@ -947,12 +952,19 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
 #pragma unroll
                 for (int i = 0; i < AROWS; ++i) {
                     const int hi = hi0[i] + dh, wi = wi0[i] + dw + (p.stem ? c : 0);
-                    const bool ok = tapok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                    bool ok = tapok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+#ifdef DGP_EXP_SKIP_TAPS        // tuning experiments only (wrong numerics). 1: fetch the A operand of 1 tap in 3 (bound on halo
+                                // reuse); 2: no A fetch at all; 3: no A and no B fetch (what is left is issue / LDS / VALU time)
+                    if (DGP_EXP_SKIP_TAPS == 1 && p.ntaps == 9 && (w_tap % 3) != 1) ok = false;
+                    if (DGP_EXP_SKIP_TAPS >= 2) ok = false;
+#endif
                     ra[i] = buf_load16(rs_in, ok ? (unsigned)(rowoff[i] + doff) : OOB);
                 }
             }
             // weight-panel rows of this step: k = tap * Cin + channel, 4 k-values per row
-            const unsigned kbase = (unsigned)(w_tap * p.tap_rows + (w_ch >> 2)) * b_row_bytes;
+            // (readfirstlane: the walker state is wave-uniform but the compiler keeps it in VGPRs and would wrap every load that
+            //  takes it as the scalar offset in a waterfall loop)
+            const unsigned kbase = (unsigned)DGP_RFL((int)((unsigned)(w_tap * p.tap_rows + (w_ch >> 2)) * b_row_bytes));
             if (p.tap_minor) {
                 // taps fastest: the 9 taps of one channel chunk re-read nearly the same input pixels back to back,
                 // so most A loads of a 3x3 conv hit the CU's L1 instead of queueing on the L2 path
@@ -966,6 +978,12 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
                     if (++w_kw == p.KW) { w_kw = 0; ++w_kh; }
                 }
             }
+#ifdef DGP_EXP_SKIP_TAPS
+            if (DGP_EXP_SKIP_TAPS >= 3) {
+#pragma unroll
+                for (int i = 0; i < BSLOTS; ++i) rb[i] = buf_load16(rs_w3, OOB);
+            } else
+#endif
             if (PB) {
                 const unsigned kgbase = (kbase >> 1) * 2u;          // (k-group index) * 2 planes * CoutP * 16 bytes = kbase rows / 2 * 2
 #pragma unroll
