@@ -506,6 +506,34 @@ __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[T
     if (p.out_absmax) track_absmax(p.out_absmax, amax, lane, (int)(blockIdx.x * 8u + (threadIdx.x >> 6)));
 }
 
+// Raw accumulators of a wave tile -> a dense [rows][ld] fp32 matrix (K-split slabs of the grid's tail): same wave-private LDS
+// staging as ls_epilogue, no epilogue arithmetic.
+template <int TM, int TN, int WN>
+__device__ __forceinline__ void ls_store_raw(floatx16 (&acc)[TM][TN], char* smem, int wave, int lane, int wave_m0, int wave_n0,
+                                             float* out, int ld) {
+    constexpr int LDC = WN + 4;
+    constexpr int C4 = WN / 4;
+    constexpr int NV = 32 * C4 / 64;
+    const int half = lane >> 5, l31 = lane & 31;
+    float* sC = reinterpret_cast<float*>(smem) + wave * (32 * LDC);
+    const int my_c4 = lane % C4, my_r0 = lane / C4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sC[((r & 3) + 8 * (r >> 2) + 4 * half) * LDC + 32 * j + l31] = acc[i][j][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int row = my_r0 + v * (64 / C4);
+            *reinterpret_cast<float4*>(out + (size_t)(wave_m0 + 32 * i + row) * ld + wave_n0 + 4 * my_c4) =
+                *reinterpret_cast<const float4*>(sC + row * LDC + 4 * my_c4);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Loader-specialised variant (Cin >= 32, NHWC output): the workgroup has 4 COMPUTE waves (2 x 2 over the tile)
 // that only issue ds_read_b128 + MFMA, and 4 LOADER waves that only issue buffer loads + ds_write.  A
@@ -602,7 +630,10 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_f32_ls(const ConvArgs p) {
                 w_ch = 0; ++w_tap;
                 if (++w_kw == p.KW) { w_kw = 0; ++w_kh; }
             }
-            const unsigned kbase = (unsigned)(ks * 8) * b_row_bytes;
+            // the walker is wave-uniform: say so, or hipcc keeps it in VGPRs / scratch behind exec-masked updates
+            w_tap = __builtin_amdgcn_readfirstlane(w_tap); w_kw = __builtin_amdgcn_readfirstlane(w_kw);
+            w_kh = __builtin_amdgcn_readfirstlane(w_kh); w_ch = __builtin_amdgcn_readfirstlane(w_ch);
+            const unsigned kbase = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(ks * 8) * b_row_bytes));
 #pragma unroll
             for (int i = 0; i < BSLOTS; ++i)
                 rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
@@ -827,7 +858,11 @@ __device__ __forceinline__ void split2_f16(const float4 v, const float s, uint2&
 // workgroups share a CU and one's prologue / epilogue / barrier waits run under the other's MFMAs.
 // CW = compute waves: 4 (2 x 2, wave tile BM/2 x BN/2) or 8 (2 x 4, wave tile BM/2 x BN/4: 12-wave workgroups whose
 // small wave tiles fit 85 registers, so a SIMD holds FOUR MFMA-issuing waves of two workgroups instead of two).
-template <int BM, int BN, int NT, int BK, int CW, bool PB = false>
+// MODE specialises the loader's A-side address walk (same arithmetic, fewer registers and instructions on the common paths):
+//   0  everything at run time (zero-stuffed data-gradient gather `up`, row-walk stem, second source, taps)
+//   1  plain convolution: taps / stride / dilation / padding, nothing else
+//   2  pointwise: 1x1, stride 1, no padding (every row is its own input pixel), optional second source
+template <int BM, int BN, int NT, int BK, int CW, bool PB = false, int MODE = 0>
 __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2) ? 4 : 2)) void conv_igemm_split_ls(const ConvArgs p) {
     constexpr int WAVES_N = CW / 2;
     constexpr int WM = BM / 2, WN = BN / WAVES_N;  // compute waves 2 x (CW / 2)
@@ -886,12 +921,19 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
         const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(p.in2 ? p.in2 : p.in), 0, p.in2 ? (int)p.in2_bytes : 0, 0x00020000);
         const int c = t % CH, rg = t / CH;
-        int hi0[AROWS], wi0[AROWS], rowoff[AROWS], nbase[AROWS];
-        unsigned rowoff2[AROWS];          // second source (1x1, same pixel grid): byte offset of pixel m, chunk c
+        // MODE 2 keeps ONE byte offset per source (row m0 + rg, chunk c): row i of the lane is 32 i pixels further, a wave-uniform
+        // stride, and rows past M fall off the end of the buffer (num_records = M * Cin * 4 exactly), so the hardware range check
+        // zero-fills them -- no per-lane predicate, one v_add per load.  MODE 1 drops the gather base.
+        int hi0[MODE == 2 ? 1 : AROWS], wi0[MODE == 2 ? 1 : AROWS], rowoff[MODE == 2 ? 1 : AROWS], nbase[MODE == 0 ? AROWS : 1];
+        unsigned rowoff2[MODE == 0 ? AROWS : 1];          // second source (1x1, same pixel grid): byte offset of pixel m, chunk c
+        const int cin1 = p.in2 ? p.cin_split : p.Cin, cin2 = p.Cin - cin1;
+        const unsigned rowbase = (unsigned)(((m0 + rg) * cin1 + 4 * c) * 4), rowbase2 = (unsigned)(((m0 + rg) * cin2 + 4 * c) * 4);
+        const int rstride = DGP_RFL(RG * cin1 * 4), rstride2 = DGP_RFL(RG * cin2 * 4);
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
+            if (MODE == 2) break;
             const int m = m0 + rg + RG * i;
-            rowoff2[i] = (p.in2 && m < p.M) ? (unsigned)((m * (p.Cin - p.cin_split) + 4 * c) * 4) : OOB;
+            if (MODE == 0) rowoff2[i] = (p.in2 && m < p.M) ? (unsigned)((m * cin2 + 4 * c) * 4) : OOB;
             if (m < p.M) {
                 const int n = m / HoWo;
                 const int rem = m - n * HoWo;
@@ -899,10 +941,11 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
                 const int wo = rem - ho * p.Wo;
                 hi0[i] = ho * p.stride - p.pad_t;
                 wi0[i] = wo * p.stride - p.pad_l;
-                rowoff[i] = (((n * p.H + hi0[i]) * p.W + wi0[i]) * (p.in2 ? p.cin_split : p.Cin) + 4 * c) * 4;
-                nbase[i] = n * p.H * p.W;
+                rowoff[i] = (((n * p.H + hi0[i]) * p.W + wi0[i]) * cin1 + 4 * c) * 4;
+                if (MODE == 0) nbase[i] = n * p.H * p.W;
             } else {
-                hi0[i] = -(1 << 28); wi0[i] = -(1 << 28); rowoff[i] = 0; nbase[i] = 0;
+                hi0[i] = -(1 << 28); wi0[i] = -(1 << 28); rowoff[i] = 0;
+                if (MODE == 0) nbase[i] = 0;
             }
         }
         // B: lane pair (2j, 2j+1) owns chunks (2 kg, 2 kg + 1) of one column, so the pair fills one 16-byte LDS cell
@@ -914,14 +957,13 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
         // the step's [KG][2][BN] block -> no split arithmetic and one ds_write_b128 per cell
         const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<void*>(PB ? p.wh3 : (const void*)p.wpk), 0, PB ? (int)p.wh3_bytes : 0, 0x00020000);
-        unsigned pb_goff[BSLOTS];
-        int pb_cell[BSLOTS];
-#pragma unroll
-        for (int i = 0; i < BSLOTS; ++i) {
-            const int q = t + NLT * i, col = q & (BN - 1), r = q / BN, plane = r & 1, kgl = r >> 1;
-            pb_goff[i] = (unsigned)(((kgl * 2 + plane) * p.CoutP + n0 + col) * 16);
-            pb_cell[i] = (plane * KG + kgl) * LDB + col;
-        }
+        // cell q = t + 256 i of [KG][2][BN]: the column and the plane do not depend on i and the k-group advances by 256 / (2 BN)
+        // per slot, so both the global offset and the LDS cell are (one lane value) + i * (a wave-uniform stride)
+        constexpr int PB_KG_STEP = NLT / (2 * BN);
+        const int pb_col = t & (BN - 1), pb_r = t / BN, pb_plane = pb_r & 1, pb_kg0 = pb_r >> 1;
+        const unsigned pb_goff0 = (unsigned)(((pb_kg0 * 2 + pb_plane) * p.CoutP + n0 + pb_col) * 16);
+        const int pb_gstride = DGP_RFL(PB_KG_STEP * 2 * p.CoutP * 16);
+        const int pb_cell0 = (pb_plane * KG + pb_kg0) * LDB + pb_col;
         int w_kh = 0, w_kw = 0, w_ch = 0, w_tap = 0;
         if (ks0) {                                   // K-slice of a tail tile: start the walker at step ks0
             if (p.tap_minor) { w_ch = (ks0 / p.ntaps) * BK; w_tap = ks0 % p.ntaps; }
@@ -935,7 +977,16 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             const int dh = DGP_RFL(w_kh * p.dil), dw = DGP_RFL(w_kw * p.dil);
             const int doff = DGP_RFL(((dh * p.W + dw) * p.Cin + w_ch) * 4);
             const bool tapok = DGP_RFL(w_tap) < p.ntaps;
-            if (p.up == 2) {
+            if (MODE == 2) {
+                if (p.in2 && w_ch >= p.cin_split) {       // second source of a K-concatenated 1x1 conv
+                    const int d2 = DGP_RFL((w_ch - p.cin_split) * 4);
+#pragma unroll
+                    for (int i = 0; i < AROWS; ++i) ra[i] = buf_load16(rs_in2, rowbase2 + (unsigned)(d2 + i * rstride2));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < AROWS; ++i) ra[i] = buf_load16(rs_in, rowbase + (unsigned)(doff + i * rstride));
+                }
+            } else if (MODE == 0 && p.up == 2) {
 #pragma unroll
                 for (int i = 0; i < AROWS; ++i) {
                     const int hv = hi0[i] + dh, wv = wi0[i] + dw;
@@ -944,14 +995,14 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
                     const unsigned off = (unsigned)((nbase[i] + (hv >> 1) * p.W + (wv >> 1)) * p.Cin + w_ch + 4 * c) << 2;
                     ra[i] = buf_load16(rs_in, ok ? off : OOB);
                 }
-            } else if (p.in2 && w_ch >= p.cin_split) {        // second source of a K-concatenated 1x1 conv
+            } else if (MODE == 0 && p.in2 && w_ch >= p.cin_split) {        // second source of a K-concatenated 1x1 conv
                 const unsigned d2 = (unsigned)(w_ch - p.cin_split) * 4u;
 #pragma unroll
                 for (int i = 0; i < AROWS; ++i) ra[i] = buf_load16(rs_in2, rowoff2[i] == OOB ? OOB : rowoff2[i] + d2);
             } else {
 #pragma unroll
                 for (int i = 0; i < AROWS; ++i) {
-                    const int hi = hi0[i] + dh, wi = wi0[i] + dw + (p.stem ? c : 0);
+                    const int hi = hi0[i] + dh, wi = wi0[i] + dw + ((MODE == 0 && p.stem) ? c : 0);
                     bool ok = tapok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
 #ifdef DGP_EXP_SKIP_TAPS        // tuning experiments only (wrong numerics). 1: fetch the A operand of 1 tap in 3 (bound on halo
                                 // reuse); 2: no A fetch at all; 3: no A and no B fetch (what is left is issue / LDS / VALU time)
@@ -978,6 +1029,8 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
                     if (++w_kw == p.KW) { w_kw = 0; ++w_kh; }
                 }
             }
+            // the walker is wave-uniform: say so, or hipcc keeps it in VGPRs / scratch behind exec-masked updates
+            w_tap = DGP_RFL(w_tap); w_kw = DGP_RFL(w_kw); w_kh = DGP_RFL(w_kh); w_ch = DGP_RFL(w_ch);
 #ifdef DGP_EXP_SKIP_TAPS
             if (DGP_EXP_SKIP_TAPS >= 3) {
 #pragma unroll
@@ -988,7 +1041,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
                 const unsigned kgbase = (kbase >> 1) * 2u;          // (k-group index) * 2 planes * CoutP * 16 bytes = kbase rows / 2 * 2
 #pragma unroll
                 for (int i = 0; i < BSLOTS; ++i)
-                    rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, (int)pb_goff[i], (int)kgbase, 0));
+                    rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, (int)pb_goff0, (int)kgbase + i * pb_gstride, 0));
             } else {
 #pragma unroll
                 for (int i = 0; i < BSLOTS; ++i)
@@ -1009,7 +1062,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             }
             if (PB) {
 #pragma unroll
-                for (int i = 0; i < BSLOTS; ++i) sB[buf * B_CELLS + pb_cell[i]] = __builtin_bit_cast(uint4, rb[i]);
+                for (int i = 0; i < BSLOTS; ++i) sB[buf * B_CELLS + pb_cell0 + i * (PB_KG_STEP * LDB)] = __builtin_bit_cast(uint4, rb[i]);
                 return;
             }
             uint2* b = reinterpret_cast<uint2*>(sB + buf * B_CELLS) + ((bkg0 * LDB + bcol) * 2 + bpar);
@@ -1131,10 +1184,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
     DIAG_STAMP(e1);
 #endif
     if (part >= 0) {        // raw accumulators of this K-slice -> slab [BM][BN]; tail_fixup sums the slices and applies the epilogue
-        ConvArgs q = p;
-        q.out = p.slab + (size_t)tail_slot * (BM * BN); q.out_bytes = BM * BN * 4; q.Cout = BN; q.M = BM;
-        q.scale = nullptr; q.bias = nullptr; q.res = nullptr; q.mask = nullptr; q.res_s = 0; q.relu = 0; q.out_absmax = nullptr;
-        ls_epilogue<TM, TN, WN>(q, acc, smem, wave, lane, 0, 0, wave_m0, wave_n0, 1.f);
+        ls_store_raw<TM, TN, WN>(acc, smem, wave, lane, wave_m0, wave_n0, p.slab + (size_t)tail_slot * (BM * BN), BN);
         return;
     }
     const float post = NT == 2 ? 1.f / (pow2_scale_for(p.in_absmax, lane, p.in2_absmax) * pow2_scale_for(p.w_absmax, lane)) : 1.f;    // exact
@@ -1213,15 +1263,24 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     if (a.tap_rows == 0) a.tap_rows = a.Cin >> 2;
     if (a.in2 && (a.ntaps != 1 || a.stride != 1 || a.up || a.cin_split % 32 || (a.Cin - a.cin_split) % 32 || a.cin_split <= 0 ||
                   a.cin_split >= a.Cin || a.H != a.Ho || a.W != a.Wo)) return hipErrorInvalidValue;
-    auto kern = conv_igemm_split_ls<BM, BN, NT, BK, CW>;
-    if (NT == 2 && CW == 4 && a.wh3) kern = conv_igemm_split_ls<BM, BN, NT, BK, CW, (NT == 2 && CW == 4)>;     // pre-split weights
-    else a.wh3 = nullptr;
-    static bool attr_done[2] = {false, false};
-    if (!attr_done[a.wh3 ? 1 : 0]) {
+    // loader specialisation (template MODE): pointwise / plain / everything-at-run-time
+    const bool pointwise = a.ntaps == 1 && a.stride == 1 && a.pad_t == 0 && a.pad_l == 0 && !a.up && !a.stem && a.H == a.Ho && a.W == a.Wo;
+    const int mode = (pointwise && (unsigned long long)a.M * (a.in2 ? a.cin_split : a.Cin) * 4ull == a.in_bytes &&
+                      (!a.in2 || (unsigned long long)a.M * (a.Cin - a.cin_split) * 4ull == a.in2_bytes) && a.in_bytes < 4200000000u)
+                         ? 2 : ((a.up || a.in2 || a.stem) ? 0 : 1);
+    constexpr bool CAN_PB = NT == 2 && CW == 4;
+    if (!(CAN_PB && a.wh3)) a.wh3 = nullptr;
+    auto kern = conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 0>;
+    if (a.wh3) kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_PB, 2>
+                    : mode == 1 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_PB, 1> : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_PB, 0>;
+    else kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 2>
+              : mode == 1 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 1> : conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 0>;
+    static bool attr_done[2][3] = {{false, false, false}, {false, false, false}};
+    if (!attr_done[a.wh3 ? 1 : 0][mode]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_done[a.wh3 ? 1 : 0] = true;
+        attr_done[a.wh3 ? 1 : 0][mode] = true;
     }
     long long nwg = (long long)a.mtiles * a.ntiles;
     // Grid tail: with `slots` workgroups resident, the last tiles % slots tiles run on a mostly idle chip.  Split their K range
