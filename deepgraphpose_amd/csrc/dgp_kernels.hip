@@ -453,63 +453,75 @@ __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[T
     if (cok && p.bias) bi4 = *reinterpret_cast<const float4*>(p.bias + co4);
     sc4.x *= post; sc4.y *= post; sc4.z *= post; sc4.w *= post;       // exact: post is a power of two (1 unless fp16-split)
     float amax = 0.f;
+    // Rows go out in chunks of VC (register pressure: 8 rows of residual + gate next to the accumulators spilled them) and the
+    // chunks are software-pipelined: the residual / gate loads of chunk q + 1 are in flight while chunk q is combined and stored,
+    // so a wave pays one HBM round trip per tile instead of one per chunk.  The loads exist only when the layer has them.
+    constexpr int VC = NV > 2 ? 2 : NV;
+    constexpr int CPP = NV / VC;                   // chunks per pass (pass = one 32-row block of the wave tile)
+    constexpr int NQ = TM * CPP;
+    unsigned ooff[2][VC];
+    float4 rres[2][VC];
+    auto issue = [&](int q, int slot) {
+        const int i = q / CPP, v0 = (q % CPP) * VC;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own reads of the previous pass are done
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                sC[row * LDC + 32 * j + l31] = acc[i][j][r];
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // a wave's LDS ops complete in order
-        // rows in chunks of VC (register pressure: 8 rows of residual + gate would be 64 more VGPRs next to the accumulators
-        // and spilled); the residual / gate loads exist only when the layer has them (wave-uniform branches)
-        constexpr int VC = NV > 4 ? 4 : NV;
-#pragma unroll
-        for (int v0 = 0; v0 < NV; v0 += VC) {
-            unsigned ooff[VC];
-            float4 rres[VC], rmask[VC];
-#pragma unroll
-            for (int u = 0; u < VC; ++u) {
-                const int row = my_r0 + (v0 + u) * (64 / C4);
-                const int m = m0 + wave_m0 + 32 * i + row;
-                const bool ok = cok && m < p.M;
-                ooff[u] = ok ? ((unsigned)(m * p.Cout + co4) << 2) : OOB;
-                rres[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.res) {
-                    unsigned roff = OOB;
-                    if (p.res_s == 1) {
-                        roff = ooff[u];
-                    } else if (p.res_s == -2 && ok) {
-                        const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                        if (!((ho | wo) & 1)) roff = (unsigned)(((n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1)) * p.Cout + co4) << 2;
-                    } else if (p.res_s > 1 && ok) {
-                        const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                        roff = (unsigned)(((n * p.res_H + ho * p.res_s) * p.res_W + wo * p.res_s) * p.Cout + co4) << 2;
-                    }
-                    rres[u] = buf_load16(rs_res, roff);
+        for (int u = 0; u < VC; ++u) {
+            const int row = my_r0 + (v0 + u) * (64 / C4);
+            const int m = m0 + wave_m0 + 32 * i + row;
+            const bool ok = cok && m < p.M;
+            ooff[slot][u] = ok ? ((unsigned)(m * p.Cout + co4) << 2) : OOB;
+            rres[slot][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.res) {
+                unsigned roff = OOB;
+                if (p.res_s == 1) {
+                    roff = ooff[slot][u];
+                } else if (p.res_s == -2 && ok) {
+                    const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                    if (!((ho | wo) & 1)) roff = (unsigned)(((n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1)) * p.Cout + co4) << 2;
+                } else if (p.res_s > 1 && ok) {
+                    const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                    roff = (unsigned)(((n * p.res_H + ho * p.res_s) * p.res_W + wo * p.res_s) * p.Cout + co4) << 2;
                 }
-                if (p.mask) rmask[u] = buf_load16(rs_mask, ooff[u]);
+                rres[slot][u] = buf_load16(rs_res, roff);
             }
+        }
+    };
+    issue(0, 0);
 #pragma unroll
-            for (int u = 0; u < VC; ++u) {
-                const int row = my_r0 + (v0 + u) * (64 / C4);
-                const float4 a = *reinterpret_cast<const float4*>(sC + row * LDC + 4 * my_c4);
-                float4 o;
-                o.x = a.x * sc4.x + bi4.x + rres[u].x;
-                o.y = a.y * sc4.y + bi4.y + rres[u].y;
-                o.z = a.z * sc4.z + bi4.z + rres[u].z;
-                o.w = a.w * sc4.w + bi4.w + rres[u].w;
-                if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-                if (p.mask) {
-                    o.x = rmask[u].x > 0.f ? o.x : 0.f; o.y = rmask[u].y > 0.f ? o.y : 0.f;
-                    o.z = rmask[u].z > 0.f ? o.z : 0.f; o.w = rmask[u].w > 0.f ? o.w : 0.f;
+    for (int q = 0; q < NQ; ++q) {
+        const int i = q / CPP, v0 = (q % CPP) * VC, slot = q & 1;
+        if (q % CPP == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own reads of the previous pass are done
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    sC[row * LDC + 32 * j + l31] = acc[i][j][r];
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)ooff[u], 0, 0);
-                if (ooff[u] != OOB) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // a wave's LDS ops complete in order
+        }
+        if (q + 1 < NQ) issue(q + 1, slot ^ 1);
+        float4 rmask[VC];          // ReLU gate of the training step's data-gradient convs: not pipelined (keeps the forward lean)
+        if (p.mask) {
+#pragma unroll
+            for (int u = 0; u < VC; ++u) rmask[u] = buf_load16(rs_mask, ooff[slot][u]);
+        }
+#pragma unroll
+        for (int u = 0; u < VC; ++u) {
+            const int row = my_r0 + (v0 + u) * (64 / C4);
+            const float4 a = *reinterpret_cast<const float4*>(sC + row * LDC + 4 * my_c4);
+            float4 o;
+            o.x = a.x * sc4.x + bi4.x + rres[slot][u].x;
+            o.y = a.y * sc4.y + bi4.y + rres[slot][u].y;
+            o.z = a.z * sc4.z + bi4.z + rres[slot][u].z;
+            o.w = a.w * sc4.w + bi4.w + rres[slot][u].w;
+            if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            if (p.mask) {
+                o.x = rmask[u].x > 0.f ? o.x : 0.f; o.y = rmask[u].y > 0.f ? o.y : 0.f;
+                o.z = rmask[u].z > 0.f ? o.z : 0.f; o.w = rmask[u].w > 0.f ? o.w : 0.f;
             }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)ooff[slot][u], 0, 0);
+            if (ooff[slot][u] != OOB) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
     }
     if (p.out_absmax) track_absmax(p.out_absmax, amax, lane, (int)(blockIdx.x * 8u + (threadIdx.x >> 6)));
