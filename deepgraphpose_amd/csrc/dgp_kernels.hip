@@ -991,8 +991,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             else { const int spt = p.Cin > BK ? p.Cin / BK : 1; w_tap = ks0 / spt; w_ch = (ks0 % spt) * BK; }
             w_kh = w_tap / p.KW; w_kw = w_tap % p.KW;
         }
-        const float scA = NT == 2 ? pow2_scale_for(p.in_absmax, lane, p.in2_absmax) : 1.f;
-        const float scW = NT == 2 ? pow2_scale_for(p.w_absmax, lane) : 1.f;
+        float scA = 1.f, scW = 1.f;           // fp16 operand scales: read AFTER the first operand loads are in flight (below)
         float4 ra0[AROWS], rb0[BSLOTS], ra1[AROWS], rb1[BSLOTS];
         auto gload = [&](int ks, float4 (&ra)[AROWS], float4 (&rb)[BSLOTS]) {
             const int dh = DGP_RFL(w_kh * p.dil), dw = DGP_RFL(w_kw * p.dil);
@@ -1099,8 +1098,12 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             }
         };
         gload(0, ra0, rb0);
-        lstore(0, ra0, rb0);
         if (nks > 1) gload(1, ra1, rb1);
+        if (NT == 2) {                         // the range reads (1 KB each + a wave reduction) overlap the first operand loads
+            scA = pow2_scale_for(p.in_absmax, lane, p.in2_absmax);
+            scW = PB ? 1.f : pow2_scale_for(p.w_absmax, lane);
+        }
+        lstore(0, ra0, rb0);
         if (nks > 2) gload(2, ra0, rb0);
         __syncthreads();
 #ifdef DGP_DIAG
@@ -1149,6 +1152,8 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // exact power of two that undoes the fp16 operand scales; read now, while this wave waits for the first tile anyway
+    const float post = (NT == 2 && part < 0) ? 1.f / (pow2_scale_for(p.in_absmax, lane, p.in2_absmax) * pow2_scale_for(p.w_absmax, lane)) : 1.f;
 #ifdef DGP_DIAG
     unsigned long long e0, e1, e2, e3, acc_mf = 0, acc_ba = 0;
     DIAG_STAMP(e0);
@@ -1208,7 +1213,6 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
         ls_store_raw<TM, TN, WN>(acc, smem, wave, lane, wave_m0, wave_n0, p.slab + (size_t)tail_slot * (BM * BN), BN);
         return;
     }
-    const float post = NT == 2 ? 1.f / (pow2_scale_for(p.in_absmax, lane, p.in2_absmax) * pow2_scale_for(p.w_absmax, lane)) : 1.f;    // exact
     ls_epilogue<TM, TN, WN>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
 #ifdef DGP_DIAG
     DIAG_STAMP(e2);
