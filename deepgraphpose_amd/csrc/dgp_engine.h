@@ -42,6 +42,8 @@ struct Unit {
     int depth_in = 0, depth = 0, depth_bn = 0;
 };
 
+constexpr size_t TAIL_SLAB_FLOATS = (size_t)512 * 128 * 128;      // K-split slabs of a conv grid's tail: <= 512 slices of a 128 x 128 tile (32 MB)
+
 int coutp_for(int cout);
 int nk_for(int kh, int kw, int cin);
 void tf_same(int n, int k, int s, int d, int* out, int* pad_before);

@@ -336,7 +336,6 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
 namespace {
 
 constexpr int HEAD_KSPLIT_MAX = 8;
-constexpr size_t TAIL_SLAB_FLOATS = (size_t)512 * 128 * 128;      // K-split slabs of a grid's tail: <= 512 slices of a 128 x 128 tile (32 MB)
 
 struct Plan {
     size_t off_p0, off_c1, off_x0, off_x1, off_sc, off_r1, off_r2, off_scmap, off_locref, off_slabs, off_tail, total;

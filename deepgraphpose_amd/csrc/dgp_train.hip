@@ -457,7 +457,7 @@ struct TPlan {
     std::vector<size_t> sc, r1, r2, xo;         // per unit
     size_t scmap, locref;
     // gradients
-    size_t g0, g1, dxa, dr1, dr2, dc1, dph0, dph1, dwraw, colsum;
+    size_t g0, g1, dxa, dr1, dr2, dc1, dph0, dph1, dwraw, colsum, tail;
     size_t total;
 };
 
@@ -502,9 +502,13 @@ TPlan make_tplan(const dgp_trainer* tr, int B) {
     }
     p.dwraw = take(wmax);
     p.colsum = take(2 * 4096);
+    p.tail = take(TAIL_SLAB_FLOATS);
     p.total = o;
     return p;
 }
+
+// K-split slab of the running forward / backward pass (a region of the caller's workspace)
+static float* g_tail_slab = nullptr;
 
 hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, const float* in, int N, int H, int W,
                        int Cin, int pad_t, int pad_l, int Ho, int Wo, int Cout, int stride, int up, const float* scale,
@@ -522,6 +526,7 @@ hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, 
     a.out_bytes = (unsigned)((size_t)a.M * Cout * 4);
     a.res_bytes = res ? (unsigned)((size_t)N * res_H * res_W * Cout * 4) : 0u;
     a.w_bytes = (unsigned)((size_t)nk * 8 * coutP * 16);
+    a.slab = g_tail_slab; a.slab_bytes = g_tail_slab ? (unsigned)(TAIL_SLAB_FLOATS * sizeof(float)) : 0u;
     return launch_conv(a, pick_tile(a.M, coutP, nk * BK), s);
 }
 
@@ -712,6 +717,7 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     auto F = [&](size_t off) { return (float*)(ws + off); };
+    g_tail_slab = F(pl.tail);
     const dgp_net_desc& d = net->desc;
     const int B = nt;
     TRY_HIP(launch_preprocess(frames, (long long)B * d.in_h * d.in_w, d.mean_pixel[0], d.mean_pixel[1], d.mean_pixel[2], F(pl.p0), s));
@@ -782,6 +788,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     auto F = [&](size_t off) { return (float*)(ws + off); };
+    g_tail_slab = F(pl.tail);
     const dgp_net_desc& d = net->desc;
     const int B = nt, nj = d.num_joints;
     const int nu = (int)net->units.size();
