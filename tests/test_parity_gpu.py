@@ -377,3 +377,22 @@ def test_other_conv_modes_keep_parity(eng, mode, extra):
     assert line, out.stdout[-2000:] + out.stderr[-2000:]
     _, d, ok = line[0].split()
     assert float(d) < PX_TOL and ok == "True", line[0]
+
+
+def test_inference_net_changes_frame_size(eng):
+    """dgp_net_set_input_size on an inference net: same weights (incl. the load-time derived panels), another geometry,
+    parity at both sizes and back."""
+    from oracle import dgp_oracle as O
+    from deepgraphpose_amd.synthetic import make_frames, make_weights
+    nj = 3
+    wts = make_weights(50, nj, False, seed=9, head_std=0.05)
+    net = eng.DGPNet(50, nj, 96, 128, max_batch=2)
+    net.load_weights(wts)
+    for (h, w) in ((96, 128), (75, 109), (96, 128)):
+        net.set_input_size(h, w)
+        fr = make_frames(2, h, w, nj, seed=h)
+        mu, conf, idx = net.infer(torch.from_numpy(fr).cuda(), 1.0, 1)
+        ref = O.infer(fr, wts, 50, 8.0, 1.0, 1)
+        assert mu.shape == (2, nj, 2) and (net.out_h, net.out_w) == tuple(ref["scmap"].shape[1:3]) if "scmap" in ref else True
+        assert np.abs(mu.cpu().numpy() - ref["mu"]).max() * STRIDE < PX_TOL
+        assert np.array_equal(idx.cpu().numpy(), ref["idx"])
