@@ -883,7 +883,9 @@ __device__ __forceinline__ void split2_f16(const float4 v, const float s, uint2&
 //   0  everything at run time (zero-stuffed data-gradient gather `up`, row-walk stem, second source, taps)
 //   1  plain convolution: taps / stride / dilation / padding, nothing else
 //   2  pointwise: 1x1, stride 1, no padding (every row is its own input pixel), optional second source
-template <int BM, int BN, int NT, int BK, int CW, bool PB = false, int MODE = 0>
+//   CS (fp16 path with pre-split weights only): the loaders stage A as plain fp32 chunks and the COMPUTE waves split their
+//   own operand rows in registers, in the shadow of their MFMAs; the loaders -- the critical path -- carry no arithmetic at all.
+template <int BM, int BN, int NT, int BK, int CW, bool PB = false, int MODE = 0, bool CS = false>
 __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2) ? 4 : 2)) void conv_igemm_split_ls(const ConvArgs p) {
     constexpr int WAVES_N = CW / 2;
     constexpr int WM = BM / 2, WN = BN / WAVES_N;  // compute waves 2 x (CW / 2)
@@ -897,7 +899,9 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
     constexpr int NP = NT == 6 ? 3 : 2;            // bf16 planes per operand
     constexpr int LDA = BM + (BK == 32 ? 4 : 8);   // k-group pitch in rows: the loaders' 8-byte writes of a half-wave cover all banks once
     constexpr int LDB = BN + 4;
-    constexpr int A_CELLS = NP * KG * LDA, B_CELLS = NP * KG * LDB;     // 16-byte cells per buffer
+    constexpr int LDAF = BM + 1;                   // CS: fp32 image [chunk][row][4 floats], one pad slot per chunk plane
+    constexpr int A_CELLS = CS ? CH * LDAF : NP * KG * LDA, B_CELLS = NP * KG * LDB;     // 16-byte cells per buffer
+    static_assert(!CS || (PB && NT == 2 && BK == 32), "compute-side split: fp16 path, pre-split weights, BK 32");
     constexpr int LDC = WN + 4;
     static_assert(NT == 2 || NT == 3 || NT == 6, "6 / 3 bf16 products, or NT = 2: fp16 high/low pair (3 products)");
     static_assert(BK == 16 || BK == 32, "K-step of 16 or 32 floats");
@@ -1070,9 +1074,14 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             }
         };
         auto lstore = [&](int buf, float4 (&ra)[AROWS], float4 (&rb)[BSLOTS]) {
+            if (CS) {
+#pragma unroll
+                for (int i = 0; i < AROWS; ++i) sA[buf * A_CELLS + c * LDAF + rg + RG * i] = __builtin_bit_cast(uint4, ra[i]);
+            }
             uint2* a = reinterpret_cast<uint2*>(sA + buf * A_CELLS) + (((c >> 1) * LDA + rg) * 2 + (c & 1));
 #pragma unroll
             for (int i = 0; i < AROWS; ++i) {
+                if (CS) break;
                 uint2 p1, p2, p3;
                 if (NT == 2) split2_f16(ra[i], scA, p1, p2);
                 else split3_bf16(ra[i], p1, p2, p3);
@@ -1152,6 +1161,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const float scA_c = CS ? pow2_scale_for(p.in_absmax, lane, p.in2_absmax) : 1.f;       // operand scale of the compute-side split
     // exact power of two that undoes the fp16 operand scales; read now, while this wave waits for the first tile anyway
     const float post = (NT == 2 && part < 0) ? 1.f / (pow2_scale_for(p.in_absmax, lane, p.in2_absmax) * pow2_scale_for(p.w_absmax, lane)) : 1.f;
 #ifdef DGP_DIAG
@@ -1175,9 +1185,21 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[pl][i] = a_base[(pl * KG + kg) * LDA + 32 * i];
+                for (int i = 0; i < TM; ++i) if (!CS) af[pl][i] = a_base[(pl * KG + kg) * LDA + 32 * i];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[pl][j] = b_base[(pl * KG + kg) * LDB + 32 * j];
+            }
+            if (CS) {       // k-group kg = chunks 2 kg and 2 kg + 1 of this lane's row, split here into the fp16 high / low operand
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float4 f0 = __builtin_bit_cast(float4, a_base[(2 * kg) * LDAF + 32 * i]);
+                    const float4 f1 = __builtin_bit_cast(float4, a_base[(2 * kg + 1) * LDAF + 32 * i]);
+                    uint2 h0, l0, h1, l1;
+                    split2_f16(f0, scA_c, h0, l0);
+                    split2_f16(f1, scA_c, h1, l1);
+                    af[0][i] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                    af[1][i] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                }
             }
             auto mma = [](const uint4& x, const uint4& y, floatx16 c) {
                 if (NT == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), c, 0, 0, 0);
@@ -1298,14 +1320,20 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     auto kern = conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 0>;
     if (a.wh3) kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_PB, 2>
                     : mode == 1 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_PB, 1> : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_PB, 0>;
+    constexpr bool CAN_CS = CAN_PB && BK == 32;
+    // 2 (default): every fp16 kernel with pre-split weights; 1: 128 x 128 tiles only; 0: loaders split (A/B switch)
+    static const int cs_env = getenv("DGP_COMPUTE_SPLIT") ? atoi(getenv("DGP_COMPUTE_SPLIT")) : 2;
+    const bool cs = CAN_CS && a.wh3 && (cs_env >= 2 || (cs_env == 1 && BN == 128));
+    if (cs) kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 2, CAN_CS>
+                 : mode == 1 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 1, CAN_CS> : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 0, CAN_CS>;
     else kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 2>
               : mode == 1 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 1> : conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 0>;
-    static bool attr_done[2][3] = {{false, false, false}, {false, false, false}};
-    if (!attr_done[a.wh3 ? 1 : 0][mode]) {
+    static bool attr_done[3][3] = {{false, false, false}, {false, false, false}, {false, false, false}};
+    if (!attr_done[cs ? 2 : (a.wh3 ? 1 : 0)][mode]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_done[a.wh3 ? 1 : 0][mode] = true;
+        attr_done[cs ? 2 : (a.wh3 ? 1 : 0)][mode] = true;
     }
     long long nwg = (long long)a.mtiles * a.ntiles;
     // Grid tail: with `slots` workgroups resident, the last tiles % slots tiles run on a mostly idle chip.  Split their K range
