@@ -887,8 +887,11 @@ __device__ __forceinline__ void split2_f16(const float4 v, const float s, uint2&
 //   own operand rows in registers, in the shadow of their MFMAs; the loaders -- the critical path -- carry no arithmetic at all.
 template <int BM, int BN, int NT, int BK, int CW, bool PB = false, int MODE = 0, bool CS = false>
 __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2) ? 4 : 2)) void conv_igemm_split_ls(const ConvArgs p) {
-    constexpr int WAVES_N = CW / 2;
-    constexpr int WM = BM / 2, WN = BN / WAVES_N;  // compute waves 2 x (CW / 2)
+    // compute waves: 2 x (CW / 2) over the tile; with the compute-side split 4 x 1 (each wave owns 32 rows and ALL columns, so no
+    // two waves split the same A rows -- half the split arithmetic for 25 % more B fragment reads)
+    constexpr int WAVES_M = (CS && CW == 4) ? 4 : 2;
+    constexpr int WAVES_N = CW / WAVES_M;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NLT = 256;                       // loader threads
     constexpr int CH = BK / 4;                     // 16-byte chunks per row and K-step
@@ -1302,7 +1305,7 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     static const int tap_minor = getenv("DGP_TAP_MINOR") ? atoi(getenv("DGP_TAP_MINOR")) : 1;
     a.tap_minor = (tap_minor && !a.stem && a.ntaps > 1 && a.nk * 32 == a.ntaps * a.Cin) ? 1 : 0;
     const size_t smem_loop = (size_t)2 * (NP * KG * (BM + (BK == 32 ? 4 : 8)) + NP * KG * (BN + 4)) * 16;
-    const size_t smem_epi = (size_t)CW * 32 * (BN / (CW / 2) + 4) * 4;
+    const size_t smem_epi = (size_t)CW * 32 * (BN + 4) * 4;        // (upper bound: 4 x 1 compute-wave layout of the CS kernels)
     const size_t smem = smem_loop > smem_epi ? smem_loop : smem_epi;
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = (a.CoutP + BN - 1) / BN;
