@@ -270,7 +270,10 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
     HIP_TRY(hipMemset(net->d_amax, 0, nl * rb));
     {
         std::vector<float> in_rng(ABSMAX_SLOTS, 0.f);
-        in_rng[0] = 256.f;                           // |u8 - mean_pixel| < 256
+        float bound = 1.f;                           // max |u8 - mean_pixel| over the three channels
+        for (int c = 0; c < 3; ++c)
+            bound = std::max(bound, std::max(fabsf(net->desc.mean_pixel[c]), fabsf(255.f - net->desc.mean_pixel[c])));
+        in_rng[0] = bound;
         HIP_TRY(hipMemcpy(net->d_inmax, in_rng.data(), rb, hipMemcpyHostToDevice));
     }
     for (size_t li = 0; li < nl; ++li) {
