@@ -8,6 +8,8 @@
 // clip_by_global_norm(10), MomentumOptimizer(0.9).
 #include "dgp_engine.h"
 #include <cstdlib>
+#include <cstring>
+#include <map>
 
 using namespace dgp;
 
@@ -25,8 +27,22 @@ __device__ __forceinline__ float4 bload16(__amdgpu_buffer_rsrc_t r, unsigned off
 // weight (re)packing on the device, from the flat master parameter buffer
 // ------------------------------------------------------------------------------------------------
 // forward panels [nk*8][CoutP][4] from HWIO [KH*KW][Cin_real][Cout]
+// max |v| of what a pack kernel wrote -> the panel's range slots (fp16-split convs of the training step); non-negative floats
+// order like their bit patterns, slots spread the atomics
+__device__ __forceinline__ void pack_track(float* rng, float m) {
+    if (!rng) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(reinterpret_cast<unsigned*>(rng) + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (ABSMAX_SLOTS - 1)), __float_as_uint(m));
+}
+__device__ __forceinline__ float amax4(float m, const float4& v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+
 __global__ void pack_fwd_kernel(const float* __restrict__ w, int taps, int cin_real, int cin, int cout, int coutP,
-                                int nchunks, float* __restrict__ packed) {
+                                int nchunks, float* __restrict__ packed, float* __restrict__ rng) {
+    float mx = 0.f;
     const long long total = (long long)nchunks * coutP;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
         const int co = (int)(g % coutP);
@@ -40,7 +56,9 @@ __global__ void pack_fwd_kernel(const float* __restrict__ w, int taps, int cin_r
                 if (ch + e < cin_real) pv[e] = w[((long long)tap * cin_real + ch + e) * cout + co];
         }
         *reinterpret_cast<float4*>(packed + g * 4) = v;
+        mx = amax4(mx, v);
     }
+    pack_track(rng, mx);
 }
 
 // head forward panels: W'[khp][kwp][ci][(a,b),c] = w[a+2-2khp][b+2-2kwp][c][ci] (w is [3,3,njt,Cin])
@@ -83,7 +101,8 @@ __global__ void head_bias_kernel(const float* __restrict__ b, int njt, float* __
 
 // data-gradient panels: Wd[tap'][co][ci] = W[taps-1-tap'][ci][co] * scale[co]; K' = taps*Cout (co fastest), N' = Cin
 __global__ void pack_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ scale, int taps, int cin,
-                                  int cout, int cinP, int nchunks, float* __restrict__ packed) {
+                                  int cout, int cinP, int nchunks, float* __restrict__ packed, float* __restrict__ rng) {
+    float mx = 0.f;
     const long long total = (long long)nchunks * cinP;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
         const int ci = (int)(g % cinP);
@@ -97,7 +116,9 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, const float* __re
             v = make_float4(src[0] * scale[co], src[1] * scale[co + 1], src[2] * scale[co + 2], src[3] * scale[co + 3]);
         }
         *reinterpret_cast<float4*>(packed + g * 4) = v;
+        mx = amax4(mx, v);
     }
+    pack_track(rng, mx);
 }
 
 // head data-gradient panels: "input" channels = phase-major 4*njt padded to cpad, taps 2x2 flipped, N' = Cin
@@ -440,7 +461,10 @@ struct dgp_trainer {
     float *params = nullptr, *grads = nullptr, *mom = nullptr, *stats = nullptr;
     double* d_sumsq = nullptr;
     float* d_gnorm = nullptr;
+    float* d_rng_pool = nullptr;      // activation / gradient range slots (RANGE_POOL arrays), zeroed per pass
+    float* d_wrng = nullptr;          // weight-panel range slots: [2 * n_layers] (forward panels, data-gradient panels), per sync
     ~dgp_trainer() {
+        for (void* q : {(void*)d_rng_pool, (void*)d_wrng}) if (q) (void)hipFree(q);
         for (auto& t : tl) if (t.d_wT) (void)hipFree(t.d_wT);
         for (void* p : {(void*)params, (void*)grads, (void*)mom, (void*)stats, (void*)d_sumsq, (void*)d_gnorm})
             if (p) (void)hipFree(p);
@@ -510,6 +534,47 @@ TPlan make_tplan(const dgp_trainer* tr, int B) {
 // K-split slab of the running forward / backward pass (a region of the caller's workspace)
 static float* g_tail_slab = nullptr;
 
+// Operand ranges for the fp16-split conv kernels inside the training step.  Every conv launched through conv_launch takes a
+// fresh slot array from a pool for max |out| and records it under its output pointer; a later conv whose input pointer (and
+// weight panel) has a recorded range runs the fp16 kernels, anything else (tensors written by other kernels: pooling, loss
+// gradients, head gathers) falls back to the range-free bf16 split.  The pool is zeroed at the start of each pass.
+struct RangeCtx {
+    float* pool = nullptr;            // RANGE_POOL slot arrays of ABSMAX_SLOTS floats
+    int next = 0;
+    std::map<const void*, const float*> of;     // tensor / panel pointer -> its slot array
+    bool on = false;
+};
+static RangeCtx g_rng;
+constexpr int RANGE_POOL = 512;
+
+static float* range_take() {
+    if (!g_rng.on || !g_rng.pool || g_rng.next >= RANGE_POOL) return nullptr;
+    return g_rng.pool + (size_t)(g_rng.next++) * ABSMAX_SLOTS;
+}
+static const float* range_of(const void* p) {
+    if (!g_rng.on) return nullptr;
+    auto it = g_rng.of.find(p);
+    return it == g_rng.of.end() ? nullptr : it->second;
+}
+
+// start of a forward or a backward pass: fresh activation / gradient slots; the weight-panel ranges of the last sync stay
+static void range_pass_begin(dgp_trainer* tr, hipStream_t s) {
+    static const bool enabled = !(getenv("DGP_TRAIN_F16") && atoi(getenv("DGP_TRAIN_F16")) == 0) &&
+                                !(getenv("DGP_CONV_MODE") && strcmp(getenv("DGP_CONV_MODE"), "f16x3") != 0);
+    g_rng.on = enabled && tr->d_rng_pool && tr->d_wrng;
+    g_rng.pool = tr->d_rng_pool;
+    g_rng.next = 0;
+    g_rng.of.clear();
+    if (!g_rng.on) return;
+    (void)hipMemsetAsync(tr->d_rng_pool, 0, (size_t)RANGE_POOL * ABSMAX_SLOTS * sizeof(float), s);
+    const size_t nl = tr->net->layers.size();
+    for (size_t li = 0; li < nl; ++li) {
+        if (tr->net->layers[li].d_w) g_rng.of[tr->net->layers[li].d_w] = tr->d_wrng + li * ABSMAX_SLOTS;
+        if (tr->tl[li].d_wT) g_rng.of[tr->tl[li].d_wT] = tr->d_wrng + (nl + li) * ABSMAX_SLOTS;
+    }
+}
+
+
 hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, const float* in, int N, int H, int W,
                        int Cin, int pad_t, int pad_l, int Ho, int Wo, int Cout, int stride, int up, const float* scale,
                        const float* bias, const float* res, int res_s, int res_H, int res_W, const float* mask,
@@ -527,7 +592,14 @@ hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, 
     a.res_bytes = res ? (unsigned)((size_t)N * res_H * res_W * Cout * 4) : 0u;
     a.w_bytes = (unsigned)((size_t)nk * 8 * coutP * 16);
     a.slab = g_tail_slab; a.slab_bytes = g_tail_slab ? (unsigned)(TAIL_SLAB_FLOATS * sizeof(float)) : 0u;
-    return launch_conv(a, pick_tile(a.M, coutP, nk * BK), s);
+    const float* rin = range_of(in);
+    const float* rw = range_of(wpk);
+    if (rin && rw && out_mode == 0) { a.in_absmax = rin; a.w_absmax = rw; }
+    if (out_mode == 0) {
+        a.out_absmax = range_take();
+        if (a.out_absmax) g_rng.of[out] = a.out_absmax; else g_rng.of.erase(out);
+    }
+    return launch_conv(a, pick_tile(a.M, coutP, nk * BK, a.in_absmax && a.w_absmax), s);
 }
 
 hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const float* dy, int Ho, int Wo, int Cdy, int KH,
@@ -628,6 +700,11 @@ int dgp_trainer_create(dgp_net* net, dgp_trainer** out) {
         return fail(DGP_ERR_HIP, "dgp_trainer_create: hipMalloc failed");
     }
     (void)hipMemset(tr->params, 0, nb); (void)hipMemset(tr->grads, 0, nb); (void)hipMemset(tr->mom, 0, nb);
+    if (hipMalloc(&tr->d_rng_pool, (size_t)RANGE_POOL * ABSMAX_SLOTS * sizeof(float)) != hipSuccess ||
+        hipMalloc(&tr->d_wrng, (size_t)2 * net->layers.size() * ABSMAX_SLOTS * sizeof(float)) != hipSuccess) {
+        delete tr;
+        return fail(DGP_ERR_HIP, "dgp_trainer_create: hipMalloc failed");
+    }
     *out = tr;
     return DGP_OK;
 }
@@ -671,9 +748,13 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
     dgp_net* net = tr->net;
     hipStream_t s = (hipStream_t)stream;
     const float eps = net->desc.bn_eps;
+    const size_t nl_all = net->layers.size();
+    if (tr->d_wrng) TRY_HIP(hipMemsetAsync(tr->d_wrng, 0, 2 * nl_all * ABSMAX_SLOTS * sizeof(float), s));
     for (size_t li = 0; li < net->layers.size(); ++li) {
         ConvLayer& l = net->layers[li];
         TLayer& t = tr->tl[li];
+        float* rng_f = tr->d_wrng ? tr->d_wrng + li * ABSMAX_SLOTS : nullptr;          // ranges of the panels packed below
+        float* rng_b = tr->d_wrng ? tr->d_wrng + (nl_all + li) * ABSMAX_SLOTS : nullptr;
         const bool head = ((int)li == net->head_part || (int)li == net->head_locref);
         const size_t nfl = (size_t)l.nk * 8 * l.CoutP * 4;
         if (!l.d_w) TRY_HIP(hipMalloc(&l.d_w, nfl * sizeof(float)));
@@ -690,14 +771,14 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
                                t.nkT * 8, t.d_wT);
         } else {
             hipLaunchKernelGGL(pack_fwd_kernel, dim3(grid_for(tot)), dim3(256), 0, s, w, l.KH * l.KW, t.cin_real, l.Cin, l.Cout,
-                               l.CoutP, l.nk * 8, l.d_w);
+                               l.CoutP, l.nk * 8, l.d_w, rng_f);
             hipLaunchKernelGGL(fold_bn_kernel, dim3((l.Cout + 255) / 256), dim3(256), 0, s, tr->params + t.g_off,
                                tr->params + t.b_off, tr->stats + t.mean_off, tr->stats + t.var_off, eps, l.Cout, l.d_scale,
                                l.d_bias);
             if (t.d_wT) {
                 const long long totT = (long long)t.nkT * 8 * t.cinP;
                 hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid_for(totT)), dim3(256), 0, s, w, l.d_scale, l.KH * l.KW, l.Cin,
-                                   l.Cout, t.cinP, t.nkT * 8, t.d_wT);
+                                   l.Cout, t.cinP, t.nkT * 8, t.d_wT, rng_b);
             }
         }
     }
@@ -718,6 +799,7 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     char* ws = (char*)workspace;
     auto F = [&](size_t off) { return (float*)(ws + off); };
     g_tail_slab = F(pl.tail);
+    range_pass_begin(tr, s);
     const dgp_net_desc& d = net->desc;
     const int B = nt;
     TRY_HIP(launch_preprocess(frames, (long long)B * d.in_h * d.in_w, d.mean_pixel[0], d.mean_pixel[1], d.mean_pixel[2], F(pl.p0), s));
@@ -725,6 +807,7 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     TRY_HIP(conv_launch(c1, c1.d_w, c1.nk, c1.CoutP, F(pl.p0), B, d.in_h, d.in_w, 4, 3, 3, net->h1, net->w1, 64, 2, 0,
                         c1.d_scale, c1.d_bias, nullptr, 0, 0, 0, nullptr, true, 0, 0, F(pl.c1), s));
     TRY_HIP(launch_maxpool(F(pl.c1), B, net->h1, net->w1, 64, F(pl.pool), s));
+    if (const float* r = range_of(F(pl.c1))) g_rng.of[F(pl.pool)] = r; else g_rng.of.erase(F(pl.pool));      // max-pooling cannot raise the maximum
     int h = net->hp, w = net->wp;
     const float* xin = F(pl.pool);
     for (size_t ui = 0; ui < net->units.size(); ++ui) {
@@ -789,6 +872,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
     char* ws = (char*)workspace;
     auto F = [&](size_t off) { return (float*)(ws + off); };
     g_tail_slab = F(pl.tail);
+    range_pass_begin(tr, s);
     const dgp_net_desc& d = net->desc;
     const int B = nt, nj = d.num_joints;
     const int nu = (int)net->units.size();
