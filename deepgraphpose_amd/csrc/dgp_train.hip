@@ -277,6 +277,212 @@ __global__ __launch_bounds__(256) void wgrad_f32(const WgradArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient on the 16-bit matrix pipe (fp16 high/low split, 3 MFMAs per fp32-class product; the split and the range
+// scaling are those of conv_igemm_split_ls).  Same tiling as wgrad_f32<2>: 128 (k) x 128 (co) tile,
+// reduction over 32-pixel steps, pixel range split over grid.z, fp32 atomics.  Both MFMA operands want 8 consecutive
+// PIXELS of one channel -- a column of the natural [pixel][channel] tile -- so the LDS images stay row-major (fp16 planes,
+// 256-byte pixel rows, 16-byte chunks XOR-swizzled) and the operands come in through ds_read_b64_tr_b16, the hardware
+// transposed read (scripts/micro/tr_b16.hip checks its lane map): lane 4q+p of a 16-lane group supplies row q / columns
+// 4p..4p+3 of a 4 x 16 block and lane i receives column i.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 half8t __attribute__((ext_vector_type(8)));
+typedef _Float16 half2t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float rng_scale(const float* slots, int lane) {     // 2^(14 - E) for max = m 2^E; 1 for zero / untracked
+    const float4 v = reinterpret_cast<const float4*>(slots)[lane];
+    float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const int be = (int)((__float_as_uint(m) >> 23) & 0xFF);
+    if (be == 0 || be == 0xFF) return 1.f;
+    int se = 127 + 14 - (be - 127);
+    se = se < 1 ? 1 : (se > 254 ? 254 : se);
+    return __uint_as_float((unsigned)se << 23);
+}
+
+__device__ __forceinline__ void split_hl(const float4 v, const float s, uint2& ph, uint2& pl) {
+    const float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
+    const half2t h01 = {(_Float16)x0, (_Float16)x1}, h23 = {(_Float16)x2, (_Float16)x3};
+    float r0 = x0 - (float)h01.x, r1 = x1 - (float)h01.y, r2 = x2 - (float)h23.x, r3 = x3 - (float)h23.y;          // exact
+    asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+    const half2t l01 = {(_Float16)r0, (_Float16)r1}, l23 = {(_Float16)r2, (_Float16)r3};
+    ph.x = __builtin_bit_cast(unsigned, h01); ph.y = __builtin_bit_cast(unsigned, h23);
+    pl.x = __builtin_bit_cast(unsigned, l01); pl.y = __builtin_bit_cast(unsigned, l23);
+}
+
+// byte offset of 16-byte chunk ch (0..15) of pixel row `row` in a [32][128 halves] plane (conflict-free for the 8-byte
+// row-wise writes and the transposed reads: cdna_hip_programming.md T10, image (b))
+__device__ __forceinline__ unsigned swz_off(int row, int ch) { return 256u * row + 16u * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+struct WgradRanges { const float* x_absmax; const float* dy_absmax; };
+
+__global__ __launch_bounds__(256) void wgrad_h3(const WgradArgs p, const WgradRanges rg) {
+    constexpr int BR = 128, CH = 32, NLD = 4;
+    constexpr unsigned PLANE = 32 * 256;          // bytes of one fp16 plane of a 32-pixel tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 buffers][A hi, A lo, B hi, B lo][PLANE]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, half = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int q0 = blockIdx.x * CH;
+    const int n0 = blockIdx.y * BR;
+    const int m_lo = blockIdx.z * p.m_per_block;
+    const int m_hi = min(p.M, m_lo + p.m_per_block);
+    const int nsteps = (m_hi - m_lo + 31) / 32;
+    if (nsteps <= 0) return;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+    const float sx = rng_scale(rg.x_absmax, lane), sy = rng_scale(rg.dy_absmax, lane);
+    const float post = 1.f / (sx * sy);           // exact power of two
+
+    const int cc = t % CH, pr = t / CH;           // this thread stages 4-channel chunk cc of pixel rows pr + 8 i
+    const int q = q0 + cc;
+    const int cin4m1 = (p.Cin >> 2) - 1;
+    const int tap = q >> p.log2cin4, ch = (q & cin4m1) << 2;
+    const bool qok = q < p.kchunks && tap < p.ntaps;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int dh = kh * p.dil - p.pad_t, dw = kw * p.dil - p.pad_l;
+    const int cob = n0 + 4 * cc;
+    const bool cok = cob < p.Cdy;
+    const int HoWo = p.Ho * p.Wo;
+
+    float4 ra[NLD], rb[NLD];
+    // pixel coordinates of this thread's NLD rows, advanced by 32 pixels per step (no integer divisions in the loop: with three
+    // 16-bit MFMAs per product the staging arithmetic, not the matrix pipe, sets the pace of this kernel)
+    const bool pointwise = p.ntaps == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && p.H == p.Ho && p.W == p.Wo;
+    int pn[NLD], pho[NLD], pwo[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int m = m_lo + pr + 8 * i;
+        pn[i] = m / HoWo;
+        const int rem = m - pn[i] * HoWo;
+        pho[i] = rem / p.Wo;
+        pwo[i] = rem - pho[i] * p.Wo;
+    }
+    auto gload = [&](int step) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int m = m_lo + step * 32 + pr + 8 * i;
+            unsigned offa = OOBT, offb = OOBT;
+            if (m < m_hi) {
+                if (pointwise) {
+                    if (qok) offa = (unsigned)(m * p.Cin + ch) << 2;
+                } else {
+                    const int hi = pho[i] * p.stride + dh, wi = pwo[i] * p.stride + dw;
+                    if (qok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                        offa = (unsigned)(((pn[i] * p.H + hi) * p.W + wi) * p.Cin + ch) << 2;
+                }
+                if (cok) offb = (unsigned)(m * p.Cdy + cob) << 2;
+            }
+            ra[i] = bload16(rs_x, offa);
+            rb[i] = bload16(rs_dy, offb);
+            if (!pointwise) {                      // next step: 32 pixels further
+                pwo[i] += 32;
+                while (pwo[i] >= p.Wo) { pwo[i] -= p.Wo; if (++pho[i] == p.Ho) { pho[i] = 0; ++pn[i]; } }
+            }
+        }
+    };
+    float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);          // column sums of dY (d beta / d bias) from the staging registers
+    const bool do_colsum = p.colsum != nullptr && blockIdx.x == 0;
+    auto lstore = [&](int buf) {
+        char* base = smem + buf * (4 * PLANE);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int row = pr + 8 * i;
+            const unsigned o = swz_off(row, cc >> 1) + 8u * (cc & 1);
+            uint2 h, l;
+            split_hl(ra[i], sx, h, l);
+            *reinterpret_cast<uint2*>(base + o) = h;
+            *reinterpret_cast<uint2*>(base + PLANE + o) = l;
+            split_hl(rb[i], sy, h, l);
+            *reinterpret_cast<uint2*>(base + 2 * PLANE + o) = h;
+            *reinterpret_cast<uint2*>(base + 3 * PLANE + o) = l;
+            if (do_colsum) { cs4.x += rb[i].x; cs4.y += rb[i].y; cs4.z += rb[i].z; cs4.w += rb[i].w; }
+        }
+    };
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposed-read addressing: 16-lane group g: columns 16 (g & 1) .. +15 of the 32-wide block, pixel group g >> 1
+    const int g16 = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    const unsigned smem_base = (unsigned)(size_t)smem;
+    auto tr_addr = [&](int buf, int plane, int col0 /* first channel of the 32-wide block */, int pix0) {
+        const int row = pix0 + 8 * (g16 >> 1) + qq;
+        const int col = col0 + 16 * (g16 & 1) + 4 * pp;             // in halves
+        return smem_base + (unsigned)(buf * 4 * PLANE + plane * PLANE) + swz_off(row, col >> 3) + 8u * ((col >> 2) & 1);
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) gload(s + 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            // operands: [operand A/B][block][piece hi/lo] = 8 halves = two transposed reads of 4 pixels each
+            unsigned long long lo4[2][2][2], hi4[2][2][2];
+#pragma unroll
+            for (int op = 0; op < 2; ++op)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        const int col0 = (op == 0 ? wm : wn) * 64 + 32 * b;
+                        const unsigned a0 = tr_addr(buf, 2 * op + pc, col0, 16 * kk);          // pixels 0-3 of this lane's k-group
+                        const unsigned a1 = tr_addr(buf, 2 * op + pc, col0, 16 * kk + 4);      // pixels 4-7 (the row enters the swizzle)
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo4[op][b][pc]) : "v"(a0) : "memory");
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi4[op][b][pc]) : "v"(a1) : "memory");
+                    }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int op = 0; op < 2; ++op)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) asm volatile("" : "+v"(lo4[op][b][pc]), "+v"(hi4[op][b][pc]));
+            auto frag = [&](int op, int b, int pc) {
+                const uint4 u = make_uint4((unsigned)lo4[op][b][pc], (unsigned)(lo4[op][b][pc] >> 32), (unsigned)hi4[op][b][pc],
+                                           (unsigned)(hi4[op][b][pc] >> 32));
+                return __builtin_bit_cast(half8t, u);
+            };
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    floatx16 a = acc[i][j];
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(0, i, 1), frag(1, j, 0), a, 0, 0, 0);      // lo * hi
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(0, i, 0), frag(1, j, 1), a, 0, 0, 0);      // hi * lo
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(0, i, 0), frag(1, j, 0), a, 0, 0, 0);      // hi * hi
+                    acc[i][j] = a;
+                }
+        }
+        if (s + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    if (do_colsum && cok) {
+        atomicAdd(p.colsum + cob, cs4.x); atomicAdd(p.colsum + cob + 1, cs4.y);
+        atomicAdd(p.colsum + cob + 2, cs4.z); atomicAdd(p.colsum + cob + 3, cs4.w);
+    }
+    // C/D layout: col = lane&31 (co), row = (r&3) + 8*(r>>2) + 4*half (k)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = n0 + wn * 64 + 32 * j + l31;
+        if (co >= p.Cdy) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = q0 * 4 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (k < p.kchunks * 4) atomicAdd(p.dw + (long long)k * p.Cdy + co, acc[i][j][r] * post);
+            }
+    }
+}
+
 // dW = scale * dWraw (HWIO, real Cin) and dot[co] += sum_k W[k][co] * dWraw[k][co]   (grid: k-chunks x co-tiles of 64)
 __global__ __launch_bounds__(256) void scale_dw_dot_kernel(const float* __restrict__ dwraw, const float* __restrict__ w,
                                                            const float* __restrict__ scale, int taps, int cin, int cin_real,
@@ -540,7 +746,7 @@ static float* g_tail_slab = nullptr;
 // gradients, head gathers) falls back to the range-free bf16 split.  The pool is zeroed at the start of each pass.
 struct RangeCtx {
     float* pool = nullptr;            // RANGE_POOL slot arrays of ABSMAX_SLOTS floats
-    int next = 0;
+    int next = 0, limit = 0;
     std::map<const void*, const float*> of;     // tensor / panel pointer -> its slot array
     bool on = false;
 };
@@ -548,7 +754,7 @@ static RangeCtx g_rng;
 constexpr int RANGE_POOL = 512;
 
 static float* range_take() {
-    if (!g_rng.on || !g_rng.pool || g_rng.next >= RANGE_POOL) return nullptr;
+    if (!g_rng.on || !g_rng.pool || g_rng.next >= g_rng.limit) return nullptr;
     return g_rng.pool + (size_t)(g_rng.next++) * ABSMAX_SLOTS;
 }
 static const float* range_of(const void* p) {
@@ -557,16 +763,19 @@ static const float* range_of(const void* p) {
     return it == g_rng.of.end() ? nullptr : it->second;
 }
 
-// start of a forward or a backward pass: fresh activation / gradient slots; the weight-panel ranges of the last sync stay
-static void range_pass_begin(dgp_trainer* tr, hipStream_t s) {
+// Start of a forward or a backward pass.  Forward: everything fresh (first half of the pool).  Backward: the forward tensors'
+// ranges stay (weight gradients read the retained activations), gradient tensors take slots from the second half.
+static void range_pass_begin(dgp_trainer* tr, hipStream_t s, bool backward) {
     static const bool enabled = !(getenv("DGP_TRAIN_F16") && atoi(getenv("DGP_TRAIN_F16")) == 0) &&
                                 !(getenv("DGP_CONV_MODE") && strcmp(getenv("DGP_CONV_MODE"), "f16x3") != 0);
     g_rng.on = enabled && tr->d_rng_pool && tr->d_wrng;
     g_rng.pool = tr->d_rng_pool;
-    g_rng.next = 0;
-    g_rng.of.clear();
+    const size_t half_bytes = (size_t)(RANGE_POOL / 2) * ABSMAX_SLOTS * sizeof(float);
+    if (!backward) { g_rng.of.clear(); g_rng.next = 0; g_rng.limit = RANGE_POOL / 2; }
+    else { g_rng.next = RANGE_POOL / 2; g_rng.limit = RANGE_POOL; }
     if (!g_rng.on) return;
-    (void)hipMemsetAsync(tr->d_rng_pool, 0, (size_t)RANGE_POOL * ABSMAX_SLOTS * sizeof(float), s);
+    (void)hipMemsetAsync(reinterpret_cast<char*>(tr->d_rng_pool) + (backward ? half_bytes : 0), 0, half_bytes, s);
+    if (backward) return;
     const size_t nl = tr->net->layers.size();
     for (size_t li = 0; li < nl; ++li) {
         if (tr->net->layers[li].d_w) g_rng.of[tr->net->layers[li].d_w] = tr->d_wrng + li * ABSMAX_SLOTS;
@@ -624,7 +833,20 @@ hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const floa
     if (mpb < 256) mpb = 256;
     split = (a.M + mpb - 1) / mpb;
     a.m_per_block = mpb;
-    static bool attr[2] = {false, false};
+    static bool attr[3] = {false, false, false};
+    static const bool h3_env = !(getenv("DGP_WGRAD_F16") && atoi(getenv("DGP_WGRAD_F16")) == 0);       // A/B switch
+    const float* rx = range_of(x);
+    const float* rdy = range_of(dy);
+    if (big && h3_env && rx && rdy && Cin % 4 == 0) {      // both operand ranges known: 16-bit matrix pipe
+        if (!attr[2]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            if (e != hipSuccess) return e;
+            attr[2] = true;
+        }
+        WgradRanges rg{rx, rdy};
+        hipLaunchKernelGGL(wgrad_h3, dim3(kt, nt, split), dim3(256), 2 * 4 * 32 * 256, s, a, rg);
+        return hipGetLastError();
+    }
     if (big) {
         if (!attr[1]) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f32<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -799,7 +1021,7 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     char* ws = (char*)workspace;
     auto F = [&](size_t off) { return (float*)(ws + off); };
     g_tail_slab = F(pl.tail);
-    range_pass_begin(tr, s);
+    range_pass_begin(tr, s, false);
     const dgp_net_desc& d = net->desc;
     const int B = nt;
     TRY_HIP(launch_preprocess(frames, (long long)B * d.in_h * d.in_w, d.mean_pixel[0], d.mean_pixel[1], d.mean_pixel[2], F(pl.p0), s));
@@ -872,7 +1094,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
     char* ws = (char*)workspace;
     auto F = [&](size_t off) { return (float*)(ws + off); };
     g_tail_slab = F(pl.tail);
-    range_pass_begin(tr, s);
+    range_pass_begin(tr, s, true);
     const dgp_net_desc& d = net->desc;
     const int B = nt, nj = d.num_joints;
     const int nu = (int)net->units.size();
