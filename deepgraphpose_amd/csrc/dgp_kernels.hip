@@ -858,21 +858,32 @@ __device__ __forceinline__ float pow2_scale_for(const float* absmax, int lane, c
 }
 
 __device__ __forceinline__ void split2_f16(const float4 v, const float s, uint2& ph, uint2& pl) {
-#ifdef DGP_SPLIT_PK
+#if defined(DGP_SPLIT_PK)
     const float2v x01 = {v.x * s, v.y * s}, x23 = {v.z * s, v.w * s};
     const half2v h01 = __builtin_convertvector(x01, half2v), h23 = __builtin_convertvector(x23, half2v);
     const float2v r01 = x01 - __builtin_convertvector(h01, float2v), r23 = x23 - __builtin_convertvector(h23, float2v);   // exact
     const half2v l01 = __builtin_convertvector(r01, half2v), l23 = __builtin_convertvector(r23, half2v);
-#else
-    // scalar fp32 arithmetic on purpose: packed fp32 VALU ops (v_pk_mul/fma_f32) are slow beside MFMAs
-    const float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
-    const half2v h01 = {(_Float16)x0, (_Float16)x1}, h23 = {(_Float16)x2, (_Float16)x3};
-    float r0 = x0 - (float)h01.x, r1 = x1 - (float)h01.y, r2 = x2 - (float)h23.x, r3 = x3 - (float)h23.y;          // exact
-    asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));          // keep the four subtractions scalar (no SLP packing)
-    const half2v l01 = {(_Float16)r0, (_Float16)r1}, l23 = {(_Float16)r2, (_Float16)r3};
-#endif
     ph.x = __builtin_bit_cast(unsigned, h01); ph.y = __builtin_bit_cast(unsigned, h23);
     pl.x = __builtin_bit_cast(unsigned, l01); pl.y = __builtin_bit_cast(unsigned, l23);
+#else
+    // 10 VALU per 4 values, written out because hipcc computes the high parts twice (16): h = f16(s x) straight into its half of
+    // the packed register (v_fma_mixlo/hi_f16), r = s x - h exactly in fp32 with h read as an fp16 operand (v_fma_mix_f32),
+    // l = f16(r) packed (v_cvt_pk_f16_f32).  Scalar fp32 arithmetic on purpose: packed fp32 VALU ops are slow beside MFMAs.
+    unsigned h01, h23;
+    float r0, r1, r2, r3;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h01) : "v"(s), "v"(v.x));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(s), "v"(v.y));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h23) : "v"(s), "v"(v.z));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h23) : "v"(s), "v"(v.w));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(s), "v"(v.x), "v"(h01));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(s), "v"(v.y), "v"(h01));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r2) : "v"(s), "v"(v.z), "v"(h23));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r3) : "v"(s), "v"(v.w), "v"(h23));
+    const float2v r01 = {r0, r1}, r23 = {r2, r3};
+    const half2v l01 = __builtin_convertvector(r01, half2v), l23 = __builtin_convertvector(r23, half2v);
+    ph.x = h01; ph.y = h23;
+    pl.x = __builtin_bit_cast(unsigned, l01); pl.y = __builtin_bit_cast(unsigned, l23);
+#endif
 }
 
 // BK = 32: one workgroup per CU (101 KB of LDS for 128 x 128); BK = 16: half the LDS and <= 128 registers, so TWO
