@@ -302,12 +302,20 @@ __device__ __forceinline__ float rng_scale(const float* slots, int lane) {     /
 }
 
 __device__ __forceinline__ void split_hl(const float4 v, const float s, uint2& ph, uint2& pl) {
-    const float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
-    const half2t h01 = {(_Float16)x0, (_Float16)x1}, h23 = {(_Float16)x2, (_Float16)x3};
-    float r0 = x0 - (float)h01.x, r1 = x1 - (float)h01.y, r2 = x2 - (float)h23.x, r3 = x3 - (float)h23.y;          // exact
-    asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+    // same 10-VALU sequence as split2_f16 (dgp_kernels.hip): h = f16(s x) written into its half of the packed register,
+    // r = s x - h exact in fp32 with h read as an fp16 operand, l = f16(r) packed
+    unsigned h01, h23;
+    float r0, r1, r2, r3;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h01) : "v"(s), "v"(v.x));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(s), "v"(v.y));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h23) : "v"(s), "v"(v.z));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h23) : "v"(s), "v"(v.w));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(s), "v"(v.x), "v"(h01));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(s), "v"(v.y), "v"(h01));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r2) : "v"(s), "v"(v.z), "v"(h23));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r3) : "v"(s), "v"(v.w), "v"(h23));
     const half2t l01 = {(_Float16)r0, (_Float16)r1}, l23 = {(_Float16)r2, (_Float16)r3};
-    ph.x = __builtin_bit_cast(unsigned, h01); ph.y = __builtin_bit_cast(unsigned, h23);
+    ph.x = h01; ph.y = h23;
     pl.x = __builtin_bit_cast(unsigned, l01); pl.y = __builtin_bit_cast(unsigned, l23);
 }
 
