@@ -16,6 +16,7 @@
 #include <cstring>
 #include <cstdio>
 #include <vector>
+#include <type_traits>
 
 namespace dgp {
 
@@ -896,7 +897,11 @@ __device__ __forceinline__ void split2_f16(const float4 v, const float s, uint2&
 //   2  pointwise: 1x1, stride 1, no padding (every row is its own input pixel), optional second source
 //   CS (fp16 path with pre-split weights only): the loaders stage A as plain fp32 chunks and the COMPUTE waves split their
 //   own operand rows in registers, in the shadow of their MFMAs; the loaders -- the critical path -- carry no arithmetic at all.
-template <int BM, int BN, int NT, int BK, int CW, bool PB = false, int MODE = 0, bool CS = false>
+//   DMA (CS kernels, MODE 1 / 2, 128 columns): the loaders move both operands with LDS-DMA (buffer_load ... lds: no VGPR round trip,
+//   no ds_write -- ds_write_b128 holds a SIMD pair's LDS data path for 13 cycles and the compute waves' reads queue behind it).
+//   A image: row-major [row][8 chunks] with the chunk slot XOR-swizzled by (row >> 1) & 7 on the SOURCE side (the DMA destination is
+//   lane-linear), three stages (two K-steps of lookahead); B image: the weight cells unpadded, two stages.  80 KB per workgroup.
+template <int BM, int BN, int NT, int BK, int CW, bool PB = false, int MODE = 0, bool CS = false, bool DMA = false>
 __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2) ? 4 : 2)) void conv_igemm_split_ls(const ConvArgs p) {
     // compute waves: 2 x (CW / 2) over the tile; with the compute-side split 4 x 1 (each wave owns 32 rows and ALL columns, so no
     // two waves split the same A rows -- half the split arithmetic for 25 % more B fragment reads)
@@ -912,9 +917,11 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
     constexpr int BSLOTS = KG * BN / 128;          // cells per loader lane pair
     constexpr int NP = NT == 6 ? 3 : 2;            // bf16 planes per operand
     constexpr int LDA = BM + (BK == 32 ? 4 : 8);   // k-group pitch in rows: the loaders' 8-byte writes of a half-wave cover all banks once
-    constexpr int LDB = BN + 4;
+    constexpr int LDB = DMA ? BN : BN + 4;
     constexpr int LDAF = BM + 1;                   // CS: fp32 image [chunk][row][4 floats], one pad slot per chunk plane
-    constexpr int A_CELLS = CS ? CH * LDAF : NP * KG * LDA, B_CELLS = NP * KG * LDB;     // 16-byte cells per buffer
+    constexpr int A_CELLS = DMA ? BM * CH : (CS ? CH * LDAF : NP * KG * LDA), B_CELLS = NP * KG * LDB;     // 16-byte cells per buffer
+    constexpr int NSA = DMA ? 3 : 2;               // A stages
+    static_assert(!DMA || (CS && MODE != 0 && BN == 128 && BM == 128 && CW == 4), "LDS-DMA loaders: CS kernels, plain or pointwise walk, 128 x 128");
     static_assert(!CS || (PB && NT == 2 && BK == 32), "compute-side split: fp16 path, pre-split weights, BK 32");
     constexpr int LDC = WN + 4;
     static_assert(NT == 2 || NT == 3 || NT == 6, "6 / 3 bf16 products, or NT = 2: fp16 high/low pair (3 products)");
@@ -926,7 +933,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* sA = reinterpret_cast<uint4*>(smem);       // [2][NP][KG][LDA]
-    uint4* sB = sA + 2 * A_CELLS;                     // [2][NP][KG][LDB]
+    uint4* sB = sA + NSA * A_CELLS;                   // [2][NP][KG][LDB]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -959,7 +966,8 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (int)p.w_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(p.in2 ? p.in2 : p.in), 0, p.in2 ? (int)p.in2_bytes : 0, 0x00020000);
-        const int c = t % CH, rg = t / CH;
+        const int rg = t / CH;
+        const int c = DMA ? ((t % CH) ^ ((rg >> 1) & 7)) : t % CH;      // DMA: the lane-linear LDS slot t % CH receives chunk slot ^ f(row)
         // MODE 2 keeps ONE byte offset per source (row m0 + rg, chunk c): row i of the lane is 32 i pixels further, a wave-uniform
         // stride, and rows past M fall off the end of the buffer (num_records = M * Cin * 4 exactly), so the hardware range check
         // zero-fills them -- no per-lane predicate, one v_add per load.  MODE 1 drops the gather base.
@@ -1010,8 +1018,95 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             w_kh = w_tap / p.KW; w_kw = w_tap % p.KW;
         }
         float scA = 1.f, scW = 1.f;           // fp16 operand scales: read AFTER the first operand loads are in flight (below)
+        if constexpr (DMA) {
+            typedef __attribute__((address_space(3))) void lds_void;
+            const int lw = wave - CW;                                    // loader wave 0..3: rows 8 lw + 32 i of instruction i
+            const unsigned a_dst0 = (unsigned)DGP_RFL(lw * 8 * 128);      // byte offset inside an A stage
+            const unsigned b_dst0 = (unsigned)DGP_RFL(pb_cell0 * 16);     // lane 0's cell: the wave's 64 cells are consecutive
+            int a_kh = w_kh, a_kw = w_kw, a_ch = w_ch, a_tap = w_tap;     // the A walker runs one K-step ahead of the B walker
+            int b_ch = w_ch, b_tap = w_tap;
+            char* smA = smem;
+            char* smB = smem + NSA * A_CELLS * 16;
+            // one loop, one issue site per operand (the walkers stay in SGPRs): iteration `it` issues B(it + 1) and A(it + 2), waits
+            // until everything but A(it + 2) has landed and meets the compute waves at barrier it + 1
+            static_assert(AROWS == 4 && BSLOTS == 4, "counted waits below assume 4 + 4 DMA instructions per wave and K-step");
+            int sa = 0, sb = 0;
+            for (int it = -2; it < nks; ++it) {
+                if (it >= -1 && it + 1 < nks) {
+                    const unsigned kbase = (unsigned)DGP_RFL((int)((unsigned)(b_tap * p.tap_rows + (b_ch >> 2)) * b_row_bytes));
+                    const unsigned kgbase = (kbase >> 1) * 2u;
+                    char* dst = smB + sb * (B_CELLS * 16) + b_dst0;
+#pragma unroll
+                    for (int i = 0; i < BSLOTS; ++i)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (lds_void*)(dst + i * (PB_KG_STEP * LDB * 16)), 16, (int)pb_goff0,
+                                                                 (int)kgbase + i * pb_gstride, 0, 0);
+                    if (p.tap_minor) {
+                        if (++b_tap == p.ntaps) { b_tap = 0; b_ch += BK; }
+                    } else {
+                        b_ch += BK;
+                        if (b_ch >= p.Cin) { b_ch = 0; ++b_tap; }
+                    }
+                    b_tap = DGP_RFL(b_tap); b_ch = DGP_RFL(b_ch);
+                    sb ^= 1;
+                }
+                const bool moreA = it + 2 < nks;
+                if (moreA) {
+                    const int dh = DGP_RFL(a_kh * p.dil), dw = DGP_RFL(a_kw * p.dil);
+                    const int doff = DGP_RFL(((dh * p.W + dw) * p.Cin + a_ch) * 4);
+                    char* dst = smA + sa * (A_CELLS * 16) + a_dst0;
+                    if (MODE == 2) {
+                        const bool second = p.in2 && a_ch >= p.cin_split;
+                        const int d2 = DGP_RFL((a_ch - p.cin_split) * 4);
+#pragma unroll
+                        for (int i = 0; i < AROWS; ++i) {
+                            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in2, (lds_void*)(dst + i * (32 * 128)), 16,
+                                                                                 (int)(rowbase2 + (unsigned)(d2 + i * rstride2)), 0, 0, 0);
+                            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(dst + i * (32 * 128)), 16,
+                                                                          (int)(rowbase + (unsigned)(doff + i * rstride)), 0, 0, 0);
+                        }
+                    } else {
+                        const bool tapok = DGP_RFL(a_tap) < p.ntaps;
+#pragma unroll
+                        for (int i = 0; i < AROWS; ++i) {
+                            const int hi = hi0[i] + dh, wi = wi0[i] + dw;
+                            const bool ok = tapok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(dst + i * (32 * 128)), 16,
+                                                                     (int)(ok ? (unsigned)(rowoff[i] + doff) : OOB), 0, 0, 0);
+                        }
+                    }
+                    if (p.tap_minor) {
+                        ++a_tap;
+                        if (++a_kw == p.KW) { a_kw = 0; ++a_kh; }
+                        if (a_tap == p.ntaps) { a_tap = 0; a_kw = 0; a_kh = 0; a_ch += BK; }
+                    } else {
+                        a_ch += BK;
+                        if (a_ch >= p.Cin) {
+                            a_ch = 0; ++a_tap;
+                            if (++a_kw == p.KW) { a_kw = 0; ++a_kh; }
+                        }
+                    }
+                    a_tap = DGP_RFL(a_tap); a_kw = DGP_RFL(a_kw); a_kh = DGP_RFL(a_kh); a_ch = DGP_RFL(a_ch);
+                    sa = sa == 2 ? 0 : sa + 1;
+                }
+                if (it >= -1) {
+                    if (moreA) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            return;
+        }
         float4 ra0[AROWS], rb0[BSLOTS], ra1[AROWS], rb1[BSLOTS];
         auto gload = [&](int ks, float4 (&ra)[AROWS], float4 (&rb)[BSLOTS]) {
+#if defined(DGP_X) && DGP_X == 4
+            if (CS) {
+#pragma unroll
+                for (int i = 0; i < AROWS; ++i) asm volatile("" : "+v"(ra[i].x), "+v"(ra[i].y), "+v"(ra[i].z), "+v"(ra[i].w));
+#pragma unroll
+                for (int i = 0; i < BSLOTS; ++i) asm volatile("" : "+v"(rb[i].x), "+v"(rb[i].y), "+v"(rb[i].z), "+v"(rb[i].w));
+                return;
+            }
+#endif
             const int dh = DGP_RFL(w_kh * p.dil), dw = DGP_RFL(w_kw * p.dil);
             const int doff = DGP_RFL(((dh * p.W + dw) * p.Cin + w_ch) * 4);
             const bool tapok = DGP_RFL(w_tap) < p.ntaps;
@@ -1088,6 +1183,15 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             }
         };
         auto lstore = [&](int buf, float4 (&ra)[AROWS], float4 (&rb)[BSLOTS]) {
+#if defined(DGP_X) && DGP_X == 3
+            if (CS) {
+#pragma unroll
+                for (int i = 0; i < AROWS; ++i) asm volatile("" :: "v"(ra[i].x), "v"(ra[i].y), "v"(ra[i].z), "v"(ra[i].w));
+#pragma unroll
+                for (int i = 0; i < BSLOTS; ++i) asm volatile("" :: "v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
+                return;
+            }
+#endif
             if (CS) {
 #pragma unroll
                 for (int i = 0; i < AROWS; ++i) sA[buf * A_CELLS + c * LDAF + rg + RG * i] = __builtin_bit_cast(uint4, ra[i]);
@@ -1186,6 +1290,118 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
 #ifdef DGP_DIAG
     DIAG_STAMP(e1);
     const unsigned long long t_pro = e1 - e0;
+#endif
+#if !defined(DGP_NO_PIPE)
+    static_assert(!DMA || (TM == 1 && TN == 4), "DMA image is read by the pipelined loop only");
+    if constexpr (CS && TM == 1 && TN == 4 && NT == 2 && BK == 32) {
+        // Software-pipelined K loop of the 32 x 128 wave tile.  hipcc's schedule read each B fragment right before its MFMAs
+        // (ds_read, s_waitcnt 0, mfma: ~6 exposed LDS round trips per 16-wide slice); here the 16 B fragments of a K-step flow
+        // through a ring of three fragment PAIRS (24 registers) two pairs ahead of the MFMAs that consume them, the A rows of the
+        // next slice are read and split under the current slice's MFMAs, and the workgroup barrier sits BEFORE the last MFMA group
+        // of a step so that the first reads of the next step fly under it.  Ring slot roles (1 <-> 2) alternate from step to step,
+        // hence the body is instantiated for both parities.  Order per accumulator: a_hi b_lo, a_lo b_hi, a_hi b_hi.
+        const uint4* a_lane = sA + wave_m0 + l31 + 2 * half * LDAF;
+        const uint4* b_lane = sB + wave_n0 + l31 + half * LDB;
+        // DMA image: row-major, chunk c of row r in slot c ^ ((r >> 1) & 7); this lane wants chunks 2 half + {0, 1, 4, 5}
+        const unsigned a_row0 = (unsigned)((wave_m0 + l31) * 128 + (((2 * half) ^ (((wave_m0 + l31) >> 1) & 7)) << 4));
+        unsigned a_cur = a_row0;
+        int sa_c = 0;
+        uint4 ra[2], ah[1], al[1], bq[3][2];
+        auto mma = [](const uint4& x, const uint4& y, floatx16 c) {
+            return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), c, 0, 0, 0);
+        };
+#define DGP_RA(A, KK) do { if constexpr (DMA) {                                                                       \
+            ra[0] = *reinterpret_cast<const uint4*>(smem + (a_cur ^ (unsigned)((4 * (KK)) << 4)));                 \
+            ra[1] = *reinterpret_cast<const uint4*>(smem + (a_cur ^ (unsigned)((4 * (KK) + 1) << 4)));             \
+        } else { ra[0] = (A)[(4 * (KK)) * LDAF]; ra[1] = (A)[(4 * (KK) + 1) * LDAF]; } } while (0)
+#define DGP_RB(B, S, KK, PL, J0) do { bq[S][0] = (B)[((PL) * KG + 2 * (KK)) * LDB + 32 * (J0)];        \
+                                      bq[S][1] = (B)[((PL) * KG + 2 * (KK)) * LDB + 32 * ((J0) + 1)]; } while (0)
+#if defined(DGP_X) && DGP_X == 1
+#define DGP_SPLIT_HALF(KK, C) do { uint2 h_, l_; h_.x = ra[C].x; h_.y = ra[C].y; l_.x = ra[C].z; l_.y = ra[C].w;   \
+        if ((C) == 0) { ah[0].x = h_.x; ah[0].y = h_.y; al[0].x = l_.x; al[0].y = l_.y; }                         \
+        else { ah[0].z = h_.x; ah[0].w = h_.y; al[0].z = l_.x; al[0].w = l_.y; } } while (0)
+#else
+#define DGP_SPLIT_HALF(KK, C) do { uint2 h_, l_; split2_f16(__builtin_bit_cast(float4, ra[C]), scA_c, h_, l_);    \
+        if ((C) == 0) { ah[0].x = h_.x; ah[0].y = h_.y; al[0].x = l_.x; al[0].y = l_.y; }                         \
+        else { ah[0].z = h_.x; ah[0].w = h_.y; al[0].z = l_.x; al[0].w = l_.y; } } while (0)
+#endif
+#define DGP_GL(KK, J0, S) do { acc[0][J0] = mma(ah[0], bq[S][0], acc[0][J0]); acc[0][(J0) + 1] = mma(ah[0], bq[S][1], acc[0][(J0) + 1]); } while (0)
+#define DGP_GH(KK, J0, S) do { acc[0][J0] = mma(al[0], bq[S][0], acc[0][J0]); acc[0][(J0) + 1] = mma(al[0], bq[S][1], acc[0][(J0) + 1]); \
+                               acc[0][J0] = mma(ah[0], bq[S][0], acc[0][J0]); acc[0][(J0) + 1] = mma(ah[0], bq[S][1], acc[0][(J0) + 1]); } while (0)
+#define DGP_FENCE() __builtin_amdgcn_sched_barrier(0)
+        DGP_RA(a_lane, 0);
+        DGP_RB(b_lane, 0, 0, 1, 0);
+        DGP_RB(b_lane, 1, 0, 0, 0);
+#if defined(DGP_X) && DGP_X == 2
+        DGP_RB(b_lane, 2, 0, 0, 2);
+#undef DGP_RB
+#define DGP_RB(B, S, KK, PL, J0) do { asm volatile("" : "+v"(bq[S][0].x), "+v"(bq[S][0].y), "+v"(bq[S][0].z), "+v"(bq[S][0].w), "+v"(bq[S][1].x), "+v"(bq[S][1].y), "+v"(bq[S][1].z), "+v"(bq[S][1].w)); } while (0)
+#endif
+#if defined(DGP_X) && DGP_X == 5
+        auto mma5 = [](const uint4& x, const uint4& y, floatx16 c) { asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w), "v"(y.x), "v"(y.y), "v"(y.z), "v"(y.w)); return c; };
+#define mma mma5
+#endif
+        DGP_FENCE();
+        const uint4* A = a_lane;
+        const uint4* B = b_lane;
+        int da = A_CELLS, db = B_CELLS;            // to the other buffer and back
+        for (int ks = 0; ks < nks; ++ks) {
+            constexpr int S0 = 0, S1 = 1, S2 = 2;
+            DGP_SPLIT_HALF(0, 0);
+            DGP_SPLIT_HALF(0, 1);
+            DGP_FENCE();
+            DGP_RA(A, 1);
+            DGP_RB(B, S2, 0, 1, 2);
+            DGP_FENCE();
+            DGP_GL(0, 0, S0);
+            DGP_FENCE();
+            DGP_RB(B, S0, 0, 0, 2);
+            DGP_FENCE();
+            DGP_GH(0, 0, S1);
+            DGP_FENCE();
+            DGP_RB(B, S1, 1, 1, 0);
+            DGP_FENCE();
+            DGP_GL(0, 2, S2);
+            DGP_FENCE();
+            DGP_RB(B, S2, 1, 0, 0);
+            DGP_FENCE();
+            DGP_GH(0, 2, S0);
+            DGP_FENCE();
+            DGP_RB(B, S0, 1, 1, 2);
+            DGP_SPLIT_HALF(1, 0);
+            DGP_SPLIT_HALF(1, 1);
+            DGP_FENCE();
+            DGP_GL(1, 0, S1);
+            DGP_FENCE();
+            DGP_RB(B, S1, 1, 0, 2);
+            DGP_FENCE();
+            DGP_GH(1, 0, S2);
+            DGP_FENCE();
+            DGP_GL(1, 2, S0);
+            DGP_FENCE();
+            __syncthreads();
+            if constexpr (DMA) { sa_c = sa_c == 2 ? 0 : sa_c + 1; a_cur = a_row0 + (unsigned)(sa_c * (A_CELLS * 16)); }
+            else { A += da; da = -da; }
+            B += db; db = -db;
+            const bool more = ks + 1 < nks;
+            if (more) {
+                DGP_RA(A, 0);
+                DGP_RB(B, S0, 0, 1, 0);
+            }
+            DGP_FENCE();
+            DGP_GH(1, 2, S1);
+            DGP_FENCE();
+            if (more) DGP_RB(B, S1, 0, 0, 0);
+            DGP_FENCE();
+        }
+#undef DGP_RA
+#undef mma
+#undef DGP_RB
+#undef DGP_SPLIT_HALF
+#undef DGP_GL
+#undef DGP_GH
+#undef DGP_FENCE
+    } else
 #endif
     for (int ks = 0; ks < nks; ++ks) {
         const int buf = ks & 1;
@@ -1317,7 +1533,7 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     a.tap_minor = (tap_minor && !a.stem && a.ntaps > 1 && a.nk * 32 == a.ntaps * a.Cin) ? 1 : 0;
     const size_t smem_loop = (size_t)2 * (NP * KG * (BM + (BK == 32 ? 4 : 8)) + NP * KG * (BN + 4)) * 16;
     const size_t smem_epi = (size_t)CW * 32 * (BN + 4) * 4;        // (upper bound: 4 x 1 compute-wave layout of the CS kernels)
-    const size_t smem = smem_loop > smem_epi ? smem_loop : smem_epi;
+    size_t smem = smem_loop > smem_epi ? smem_loop : smem_epi;
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = (a.CoutP + BN - 1) / BN;
     if (a.CoutP % BN != 0 || (a.Cin < 32 && !a.stem) || a.out_mode != 0) return hipErrorInvalidValue;
@@ -1342,12 +1558,22 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
                  : mode == 1 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 1, CAN_CS> : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 0, CAN_CS>;
     else kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 2>
               : mode == 1 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 1> : conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 0>;
-    static bool attr_done[3][3] = {{false, false, false}, {false, false, false}, {false, false, false}};
-    if (!attr_done[cs ? 2 : (a.wh3 ? 1 : 0)][mode]) {
+    // LDS-DMA loaders (A/B switch DGP_DMA=0): 128 x 128 CS kernels with the plain or the pointwise walk
+    constexpr bool CAN_DMA = CAN_CS && BM == 128 && BN == 128;
+    static const int dma_env = getenv("DGP_DMA") ? atoi(getenv("DGP_DMA")) : 1;
+    const bool dma = CAN_DMA && cs && mode != 0 && dma_env;
+    if (dma) {
+        kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 2, CAN_DMA, CAN_DMA>
+                         : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 1, CAN_DMA, CAN_DMA>;
+        smem = (size_t)(3 * BM * 8 + 2 * NP * KG * BN) * 16;           // 3 A stages + 2 B stages = 80 KB
+        if (smem < smem_epi) smem = smem_epi;
+    }
+    static bool attr_done[4][3] = {{false, false, false}, {false, false, false}, {false, false, false}, {false, false, false}};
+    if (!attr_done[dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_done[cs ? 2 : (a.wh3 ? 1 : 0)][mode] = true;
+        attr_done[dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode] = true;
     }
     long long nwg = (long long)a.mtiles * a.ntiles;
     // Grid tail: with `slots` workgroups resident, the last tiles % slots tiles run on a mostly idle chip.  Split their K range
