@@ -486,10 +486,17 @@ __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[T
             }
         }
     };
+#ifdef DGP_DIAG
+    unsigned long long g0, g1, g2, g3, g4;
+    DIAG_STAMP(g0);
+#endif
     issue(0, 0);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int i = q / CPP, v0 = (q % CPP) * VC, slot = q & 1;
+#ifdef DGP_DIAG
+        if (q == 1) DIAG_STAMP(g2);
+#endif
         if (q % CPP == 0) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own reads of the previous pass are done
 #pragma unroll
@@ -500,6 +507,9 @@ __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[T
                     sC[row * LDC + 32 * j + l31] = acc[i][j][r];
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // a wave's LDS ops complete in order
+#ifdef DGP_DIAG
+            if (q == 0) DIAG_STAMP(g1);
+#endif
         }
         if (q + 1 < NQ) issue(q + 1, slot ^ 1);
         float4 rmask[VC];          // ReLU gate of the training step's data-gradient convs: not pipelined (keeps the forward lean)
@@ -525,7 +535,18 @@ __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[T
             if (ooff[slot][u] != OOB) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
     }
+#ifdef DGP_DIAG
+    DIAG_STAMP(g3);
+#endif
     if (p.out_absmax) track_absmax(p.out_absmax, amax, lane, (int)(blockIdx.x * 8u + (threadIdx.x >> 6)));
+#ifdef DGP_DIAG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DIAG_STAMP(g4);
+    if (p.dbg && threadIdx.x == 0) {      // (slots 3, 5, 6 are the loader stamps of the register-staged kernels: read these with DGP_DMA=1)
+        unsigned long long* d = p.dbg + 10ull * blockIdx.x;
+        d[3] = g1 - g0; d[5] = g2 - g1; d[6] = g3 - g2; d[8] = g4 - g3;
+    }
+#endif
 }
 
 // Raw accumulators of a wave tile -> a dense [rows][ld] fp32 matrix (K-split slabs of the grid's tail): same wave-private LDS
@@ -1379,7 +1400,12 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             DGP_FENCE();
             DGP_GL(1, 2, S0);
             DGP_FENCE();
+            DIAG_STAMP(e2);
             __syncthreads();
+            DIAG_STAMP(e3);
+#ifdef DGP_DIAG
+            acc_mf += e2 - e1; acc_ba += e3 - e2; e1 = e3;
+#endif
             if constexpr (DMA) { sa_c = sa_c == 2 ? 0 : sa_c + 1; a_cur = a_row0 + (unsigned)(sa_c * (A_CELLS * 16)); }
             else { A += da; da = -da; }
             B += db; db = -db;
@@ -1627,6 +1653,8 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
         printf("[diag split %dx%d NT%d BK%d CW%d] tiles %lld K-steps %d | compute wave 0: first barrier %.0f cyc, epilogue %.0f | per K-step: "
                "ldsread+mfma %.0f barrier-wait %.0f || loader wave: wait+split+ds_write %.0f load-issue %.0f barrier-wait %.0f\n",
                BM, BN, NT, BK, CW, nwg, nks, v[0], v[2], v[4] / nks, v[7] / nks, v[3] / nks, v[5] / nks, v[6] / nks);
+        double v8 = 0; for (long long b = 0; b < nwg; ++b) v8 += (double)h[10 * b + 8];
+        printf("[diag epilogue, DMA kernels] scale/bias + staging %.0f | chunk 0 %.0f | chunks 1.. %.0f | absmax + drain %.0f (res %d)\n", v[3], v[5], v[6], v8 / nwg, a.res ? 1 : 0);
     }
 #endif
     return hipGetLastError();
