@@ -662,6 +662,7 @@ struct TLayer {
     long long mean_off = -1, var_off = -1;            // offsets into the frozen-statistics buffer
     int cin_real = 0;
     float* d_wT = nullptr;                            // data-gradient panels
+    float* d_wTh3 = nullptr;                          // ... pre-split into fp16 high/low cells (launch_pack_h3), per sync
     int nkT = 0, cinP = 0, cpad = 0;                  // cpad: padded phase-major channel count (heads)
 };
 
@@ -679,7 +680,7 @@ struct dgp_trainer {
     float* d_wrng = nullptr;          // weight-panel range slots: [2 * n_layers] (forward panels, data-gradient panels), per sync
     ~dgp_trainer() {
         for (void* q : {(void*)d_rng_pool, (void*)d_wrng}) if (q) (void)hipFree(q);
-        for (auto& t : tl) if (t.d_wT) (void)hipFree(t.d_wT);
+        for (auto& t : tl) { if (t.d_wT) (void)hipFree(t.d_wT); if (t.d_wTh3) (void)hipFree(t.d_wTh3); }
         for (void* p : {(void*)params, (void*)grads, (void*)mom, (void*)stats, (void*)d_sumsq, (void*)d_gnorm})
             if (p) (void)hipFree(p);
     }
@@ -792,6 +793,13 @@ static void range_pass_begin(dgp_trainer* tr, hipStream_t s, bool backward) {
 }
 
 
+// weight panel -> the same panel pre-split into fp16 cells (filled by dgp_trainer_sync_weights): with the cells and both ranges the
+// conv runs on the compute-side-split / LDS-DMA kernels of the inference engine
+static std::unordered_map<const float*, const float*> g_cells;
+// Opt-in (DGP_TRAIN_CELLS=1): at the 11-frame batches of the DGP step the grids are a fraction of a round and the per-step cell
+// packing costs what the leaner kernels save (21.2-21.8 ms with, 20.7-21.0 ms without, same box); it pays at large batches only.
+static const bool g_train_cells = getenv("DGP_TRAIN_CELLS") && atoi(getenv("DGP_TRAIN_CELLS")) != 0;
+
 hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, const float* in, int N, int H, int W,
                        int Cin, int pad_t, int pad_l, int Ho, int Wo, int Cout, int stride, int up, const float* scale,
                        const float* bias, const float* res, int res_s, int res_H, int res_W, const float* mask,
@@ -811,7 +819,11 @@ hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, 
     a.slab = g_tail_slab; a.slab_bytes = g_tail_slab ? (unsigned)(TAIL_SLAB_FLOATS * sizeof(float)) : 0u;
     const float* rin = range_of(in);
     const float* rw = range_of(wpk);
-    if (rin && rw && out_mode == 0) { a.in_absmax = rin; a.w_absmax = rw; }
+    if (rin && rw && out_mode == 0) {
+        a.in_absmax = rin; a.w_absmax = rw;
+        const auto c = g_cells.find(wpk);
+        if (g_train_cells && c != g_cells.end()) { a.wh3 = c->second; a.wh3_bytes = a.w_bytes; }
+    }
     if (out_mode == 0) {
         a.out_absmax = range_take();
         if (a.out_absmax) g_rng.of[out] = a.out_absmax; else g_rng.of.erase(out);
@@ -1002,6 +1014,11 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
         } else {
             hipLaunchKernelGGL(pack_fwd_kernel, dim3(grid_for(tot)), dim3(256), 0, s, w, l.KH * l.KW, t.cin_real, l.Cin, l.Cout,
                                l.CoutP, l.nk * 8, l.d_w, rng_f);
+            if (g_train_cells && rng_f && l.Cin >= 32) {          // cells of the forward panel, scaled by the range tracked just above
+                if (!l.d_wh3) TRY_HIP(hipMalloc(&l.d_wh3, nfl * sizeof(float)));
+                TRY_HIP(launch_pack_h3(l.d_w, l.nk, l.CoutP, rng_f, l.d_wh3, s));
+                g_cells[l.d_w] = reinterpret_cast<const float*>(l.d_wh3);
+            }
             hipLaunchKernelGGL(fold_bn_kernel, dim3((l.Cout + 255) / 256), dim3(256), 0, s, tr->params + t.g_off,
                                tr->params + t.b_off, tr->stats + t.mean_off, tr->stats + t.var_off, eps, l.Cout, l.d_scale,
                                l.d_bias);
@@ -1009,6 +1026,11 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
                 const long long totT = (long long)t.nkT * 8 * t.cinP;
                 hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid_for(totT)), dim3(256), 0, s, w, l.d_scale, l.KH * l.KW, l.Cin,
                                    l.Cout, t.cinP, t.nkT * 8, t.d_wT, rng_b);
+                if (g_train_cells && rng_b && l.Cout >= 32) {
+                    if (!t.d_wTh3) TRY_HIP(hipMalloc(&t.d_wTh3, (size_t)t.nkT * 8 * t.cinP * 16));
+                    TRY_HIP(launch_pack_h3(t.d_wT, t.nkT, t.cinP, rng_b, t.d_wTh3, s));
+                    g_cells[t.d_wT] = t.d_wTh3;
+                }
             }
         }
     }
