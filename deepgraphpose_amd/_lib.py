@@ -77,6 +77,7 @@ SYMBOLS = {
     "dgp_conv2d": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgp_conv2d_ranged": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgp_tensor_absmax": (C.c_int, [_vp, _sz, _vp, _vp]),
+    "dgp_motion_energy": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, _vp, _vp]),
     "dgp_maxpool_3x3s2_same": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "dgp_preprocess_u8": (C.c_int, [_vp, C.c_int64, C.POINTER(_f32), _vp, _vp]),
 }

@@ -70,6 +70,8 @@ hipError_t launch_reduce_slabs(const float* slabs, long long n, long long stride
 hipError_t launch_maxpool(const float* x, int N, int H, int W, int C, float* y, hipStream_t s);
 hipError_t launch_preprocess(const uint8_t* f, long long npix, float m0, float m1, float m2,
                              float* out, hipStream_t s);
+hipError_t launch_motion_energy(const uint8_t* frames, long long frame_bytes, int n_frames, const uint8_t* prev_frame,
+                                unsigned long long* sums, hipStream_t s);
 hipError_t launch_soft_argmax(const float* scmap, int B, int H, int W, int C, float gamma,
                               int gauss_len, float* mu, float* conf, int* idx, float* pmap,
                               hipStream_t s);

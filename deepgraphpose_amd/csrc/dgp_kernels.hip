@@ -1947,6 +1947,79 @@ hipError_t launch_preprocess(const uint8_t* f, long long npix, float m0, float m
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Motion energy of a frame sequence (DGP/dataset.py:29-43): sums[t] = sum over the bytes of frame t of
+// (f_t - f_{t-1}) mod 256 -- the reference subtracts uint8 arrays, so the difference WRAPS and np.abs is the identity; the mean
+// is sums[t] / frame_bytes on the host (exact in float64).  Integer work: exact, order-independent (integer atomics).
+// A block owns one 4-KiB column of the frame and walks a group of MEG frames with the previous frame's 16 bytes in registers:
+// every byte is read 1 + 1/MEG times.  HBM-bound: algorithmic bytes = n_frames * frame_bytes.
+// ------------------------------------------------------------------------------------------------
+constexpr int MEG = 16;
+__device__ __forceinline__ unsigned bytes_sub_sum(unsigned a, unsigned b, unsigned acc) {
+    const unsigned H = 0x80808080u;
+    const unsigned d = ((a | H) - (b & ~H)) ^ ((a ^ ~b) & H);       // per-byte a - b mod 256, no borrow across bytes
+    return __builtin_amdgcn_sad_u8(d, 0u, acc);                       // + the four bytes of d
+}
+// VEC = 16: frames whose byte size is a multiple of 16 (16-byte loads); VEC = 1: any size, byte loads.  A lane owns MEU units
+// 256 apart (coalesced), so a wave issues MEU loads per frame and one integer atomic per frame.
+constexpr int MEU = 4;
+template <int VEC>
+__global__ __launch_bounds__(256) void motion_energy_kernel(const uint8_t* __restrict__ frames, long long frame_bytes, int n_frames,
+                                                            const uint8_t* __restrict__ prev_frame,
+                                                            unsigned long long* __restrict__ sums) {
+    const long long nu = frame_bytes / VEC;
+    const long long u0 = (long long)blockIdx.x * (256 * MEU) + threadIdx.x;  // first unit of the frame owned by this lane
+    const int t0 = blockIdx.y * MEG, t1 = min(n_frames, t0 + MEG);
+    const uint8_t* pf = t0 > 0 ? frames + (long long)(t0 - 1) * frame_bytes : prev_frame;
+    auto load = [&](const uint8_t* f, int k) {
+        const long long u = u0 + 256 * k;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (u < nu) {
+            if (VEC == 16) v = *reinterpret_cast<const uint4*>(f + u * 16);
+            else v.x = f[u];
+        }
+        return v;
+    };
+    uint4 prev[MEU];
+#pragma unroll
+    for (int k = 0; k < MEU; ++k) prev[k] = pf ? load(pf, k) : make_uint4(0, 0, 0, 0);
+    for (int t = t0; t < t1; ++t) {
+        const uint8_t* f = frames + (long long)t * frame_bytes;
+        uint4 cur[MEU];
+#pragma unroll
+        for (int k = 0; k < MEU; ++k) cur[k] = load(f, k);
+        unsigned s = 0;
+        if (pf) {
+#pragma unroll
+            for (int k = 0; k < MEU; ++k) {
+                s = bytes_sub_sum(cur[k].x, prev[k].x, s);
+                if (VEC == 16) {
+                    s = bytes_sub_sum(cur[k].y, prev[k].y, s); s = bytes_sub_sum(cur[k].z, prev[k].z, s);
+                    s = bytes_sub_sum(cur[k].w, prev[k].w, s);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MEU; ++k) prev[k] = cur[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(sums + t, (unsigned long long)s);
+        pf = f;
+    }
+}
+
+hipError_t launch_motion_energy(const uint8_t* frames, long long frame_bytes, int n_frames, const uint8_t* prev_frame,
+                                unsigned long long* sums, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(sums, 0, (size_t)n_frames * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    const bool vec = (frame_bytes & 15) == 0 && (((uintptr_t)frames | (uintptr_t)prev_frame) & 15) == 0;
+    const long long units = vec ? frame_bytes >> 4 : frame_bytes;
+    const dim3 grid((unsigned)((units + 256 * MEU - 1) / (256 * MEU)), (unsigned)((n_frames + MEG - 1) / MEG));
+    if (vec) hipLaunchKernelGGL(motion_energy_kernel<16>, grid, dim3(256), 0, s, frames, frame_bytes, n_frames, prev_frame, sums);
+    else hipLaunchKernelGGL(motion_energy_kernel<1>, grid, dim3(256), 0, s, frames, frame_bytes, n_frames, prev_frame, sums);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------
 // Block-wide reductions (256 threads = 4 waves of 64).
 // ------------------------------------------------------------------------------------

@@ -856,4 +856,12 @@ int dgp_preprocess_u8(const uint8_t* frames, int64_t n_pixels, const float mean[
     return DGP_OK;
 }
 
+int dgp_motion_energy(const uint8_t* frames, int64_t frame_bytes, int32_t n_frames, const uint8_t* prev_frame, uint64_t* sums,
+                      void* stream) {
+    if (!frames || !sums || frame_bytes <= 0 || n_frames <= 0) return fail(DGP_ERR_INVALID, "dgp_motion_energy: bad argument");
+    hipError_t e = launch_motion_energy(frames, frame_bytes, n_frames, prev_frame, (unsigned long long*)sums, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("motion energy: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
 }  // extern "C"

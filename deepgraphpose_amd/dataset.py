@@ -184,16 +184,51 @@ from os.path import join, split
 from pathlib import Path
 
 
-def calculate_motion_energy(source) -> np.ndarray:
+def calculate_motion_energy(source, backend: str = "auto", chunk: int = 256) -> np.ndarray:
     """mean |frame_t - frame_{t-1}| per frame (DGP/dataset.py:29-43).  Frames are uint8 and the reference
-    subtracts them as such, so the difference wraps modulo 256 -- restated as is."""
-    me, prev, n = [], None, 0
-    for frame in source.iter_frames():
-        frame = np.asarray(frame)
-        me.append(0.0 if prev is None else float(np.mean(np.abs(frame - prev))))
-        prev = frame
-        n += 1
-    return np.asarray(me[:n])
+    subtracts them as such, so the difference wraps modulo 256 -- restated as is.
+
+    backend "hip": chunks of `chunk` frames are staged to the GPU and reduced by `dgp_motion_energy` (exact integer sums, so the
+    result is bit-identical to the numpy loop); "host": the reference's per-frame numpy loop; "auto": "hip" when a GPU is
+    visible (and then the HIP library must load -- no silent fallback), "host" on boxes without one."""
+    if backend == "auto":
+        import torch
+        backend = "hip" if torch.cuda.is_available() else "host"
+    if backend == "host":
+        me, prev, n = [], None, 0
+        for frame in source.iter_frames():
+            frame = np.asarray(frame)
+            me.append(0.0 if prev is None else float(np.mean(np.abs(frame - prev))))
+            prev = frame
+            n += 1
+        return np.asarray(me[:n])
+    if backend != "hip":
+        raise ValueError("calculate_motion_energy: backend must be auto | hip | host, not %r" % (backend,))
+    import torch
+    from . import engine
+    out, prev, pinned = [], None, None
+
+    def batches():
+        if hasattr(source, "iter_batches"):
+            yield from source.iter_batches(chunk)
+            return
+        buf = []
+        for frame in source.iter_frames():
+            buf.append(np.asarray(frame))
+            if len(buf) == chunk:
+                yield np.stack(buf); buf = []
+        if buf:
+            yield np.stack(buf)
+
+    for b in batches():
+        b = np.ascontiguousarray(b, dtype=np.uint8)
+        if pinned is None or pinned.shape[0] < b.shape[0] or tuple(pinned.shape[1:]) != tuple(b.shape[1:]):
+            pinned = torch.empty((max(chunk, b.shape[0]),) + tuple(b.shape[1:]), dtype=torch.uint8).pin_memory()
+        np.copyto(pinned.numpy()[:b.shape[0]], b)
+        dev = pinned[:b.shape[0]].to("cuda", non_blocking=True)
+        out.append(engine.motion_energy(dev, prev))
+        prev = dev[-1].clone()
+    return np.concatenate(out) if out else np.zeros(0)
 
 
 def get_frame_idxs_from_train_mat(data_array, video: str) -> np.ndarray:

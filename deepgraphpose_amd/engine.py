@@ -279,3 +279,25 @@ def preprocess_u8(frames: torch.Tensor, mean=MEAN_PIXEL) -> torch.Tensor:
     _lib.check(lib.dgp_preprocess_u8(_ptr(frames), frames.numel() // 3, m, _ptr(out), _stream(frames.device)),
                "dgp_preprocess_u8")
     return out
+
+
+def motion_energy(frames: torch.Tensor, prev: Optional[torch.Tensor] = None) -> np.ndarray:
+    """Motion energy of a device-resident uint8 frame sequence [T, ...] (DGP/dataset.py:29-43):
+    me[t] = mean over the frame of (f_t - f_{t-1}) mod 256 (the reference's uint8 subtraction wraps), me[0] = 0 unless `prev`
+    (the last frame of the previous chunk) is given.  Integer sums on the device (dgp_motion_energy), float64 division here:
+    bit-identical to the reference's np.mean."""
+    lib = _lib.load()
+    _need_cuda(frames, torch.uint8, "frames")
+    frames = frames.contiguous()
+    T = frames.shape[0]
+    fb = frames.numel() // max(T, 1)
+    if T == 0:
+        return np.zeros(0, dtype=np.float64)
+    if prev is not None:
+        _need_cuda(prev, torch.uint8, "prev")
+        prev = prev.contiguous()
+        if prev.numel() != fb:
+            raise _lib.DgpError("motion_energy: prev has %d bytes, a frame has %d" % (prev.numel(), fb))
+    sums = torch.empty(T, dtype=torch.int64, device=frames.device)
+    _lib.check(lib.dgp_motion_energy(_ptr(frames), fb, T, _ptr(prev), _ptr(sums), _stream(frames.device)), "dgp_motion_energy")
+    return sums.cpu().numpy().astype(np.float64) / float(fb)

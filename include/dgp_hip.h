@@ -228,6 +228,13 @@ int  dgp_maxpool_3x3s2_same(const float* x, int32_t N, int32_t H, int32_t W, int
                             float* y, void* stream);
 int  dgp_preprocess_u8(const uint8_t* frames, int64_t n_pixels, const float mean[3],
                        float* out_nhwc4, void* stream);
+/* Motion energy of a uint8 frame sequence on the device (replaces the per-frame numpy loop of calculate_motion_energy,
+ * DGP/dataset.py:29-43).  sums[t] = sum over the frame's bytes of (frames[t] - frames[t-1]) mod 256 -- the
+ * reference subtracts uint8 arrays, so the difference wraps -- for t >= 1, and for t = 0 against prev_frame (the last frame of
+ * the previous chunk; NULL: sums[0] = 0).  The reference's value is sums[t] / frame_bytes in float64 (exact).  frames:
+ * [n_frames][frame_bytes] device bytes; sums: n_frames device uint64 (overwritten).  Integer sums, bit-exact, order-independent. */
+int  dgp_motion_energy(const uint8_t* frames, int64_t frame_bytes, int32_t n_frames, const uint8_t* prev_frame,
+                       uint64_t* sums, void* stream);
 
 #ifdef __cplusplus
 }

@@ -293,3 +293,18 @@ def infer(frames_u8: np.ndarray, wts: Dict[str, np.ndarray], depth: int = 50,
     yr = markers[:, :, 0] * stride + 0.5 * stride
     return {"x": xr, "y": yr, "likelihoods": lik, "mu": mu, "idx": idx, "scmap": scmap,
             "features": feats}
+
+
+def motion_energy(frames_u8: np.ndarray) -> np.ndarray:
+    """calculate_motion_energy's per-frame loop (DGP/dataset.py:29-43) on an in-memory uint8 clip [T, H, W, 3]: frame 0 gets 0,
+    frame t the np.mean of np.abs(frame_t - frame_{t-1}) -- uint8 arithmetic, so the difference wraps modulo 256 and np.abs is
+    the identity, exactly as in the reference."""
+    frames_u8 = np.asarray(frames_u8)
+    assert frames_u8.dtype == np.uint8
+    me = np.zeros(frames_u8.shape[0])
+    prev = None
+    for t, frame in enumerate(frames_u8):
+        if prev is not None:
+            me[t] = np.mean(np.abs(frame - prev))
+        prev = frame
+    return me

@@ -396,3 +396,40 @@ def test_inference_net_changes_frame_size(eng):
         assert mu.shape == (2, nj, 2) and (net.out_h, net.out_w) == tuple(ref["scmap"].shape[1:3]) if "scmap" in ref else True
         assert np.abs(mu.cpu().numpy() - ref["mu"]).max() * STRIDE < PX_TOL
         assert np.array_equal(idx.cpu().numpy(), ref["idx"])
+
+
+# ---------------------------------------------------------------------------- motion energy (8(f) N4)
+@pytest.mark.parametrize("shape", [(1, 8, 8, 3), (5, 17, 23, 3), (40, 48, 64, 3), (19, 31, 37, 3), (33, 480, 640, 3)])
+def test_motion_energy_is_bit_exact(eng, shape):
+    """Integer work: the device sums must reproduce the reference's wrapped uint8 differences exactly, for frame sizes that
+    are and are not multiples of the 16-byte load (byte-granular kernel), across the 16-frame groups and with a chained chunk."""
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    clip = rng.integers(0, 256, shape, dtype=np.uint8)
+    clip[1:3] = clip[0]                                   # still frames -> exact zeros
+    if shape[0] > 4:
+        clip[4] = 255 - clip[3]                           # large wrapped differences
+    want = O.motion_energy(clip)
+    dev = torch.from_numpy(clip).cuda()
+    got = eng.motion_energy(dev)
+    assert got.dtype == np.float64 and np.array_equal(got, want)
+    if shape[0] > 2:                                      # chunked: the second chunk continues from the first one's last frame
+        k = shape[0] // 2
+        a = eng.motion_energy(dev[:k])
+        b = eng.motion_energy(dev[k:], prev=dev[k - 1])
+        assert np.array_equal(np.concatenate([a, b]), want)
+
+
+def test_calculate_motion_energy_hip_backend_matches_host(eng):
+    from deepgraphpose_amd import dataset as D
+    from deepgraphpose_amd.frames import ArraySource
+    rng = np.random.default_rng(7)
+    clip = rng.integers(0, 256, (70, 24, 32, 3), dtype=np.uint8)
+    host = D.calculate_motion_energy(ArraySource(clip), backend="host")
+    hip = D.calculate_motion_energy(ArraySource(clip), backend="hip", chunk=32)
+    assert np.array_equal(host, hip)
+
+    class FrameOnly:                                       # a source without iter_batches (moviepy-like)
+        def iter_frames(self):
+            yield from clip
+    assert np.array_equal(D.calculate_motion_energy(FrameOnly(), backend="hip", chunk=16), host)
