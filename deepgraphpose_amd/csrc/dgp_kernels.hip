@@ -431,7 +431,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_f32(const C
 
 // Epilogue of the loader-specialised kernels (compute waves only; wave-private LDS staging, no workgroup
 // barriers: the loader waves are gone).  acc -> scale/bias/residual/ReLU/mask -> 16-byte stores.
-template <int TM, int TN, int WN>
+// M16: the caller's accumulators are the 2 x 8 blocks of v_mfma_f32_16x16x32 and it has staged them into the wave's LDS tile itself
+// (block (i, j) register r of lane l = row 16 i + 4 (l >> 4) + r, column 16 j + (l & 15)); `acc` is not read
+template <int TM, int TN, int WN, bool M16 = false>
 __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[TM][TN], char* smem, int wave, int lane,
                                             int m0, int n0, int wave_m0, int wave_n0, float post = 1.f) {
     constexpr int LDC = WN + 4;
@@ -503,8 +505,10 @@ __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[T
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    sC[row * LDC + 32 * j + l31] = acc[i][j][r];
+                    if (!M16) {      // (M16: the caller has staged its 16x16 blocks already)
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        sC[row * LDC + 32 * j + l31] = acc[i][j][r];
+                    }
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // a wave's LDS ops complete in order
 #ifdef DGP_DIAG
@@ -551,7 +555,7 @@ __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[T
 
 // Raw accumulators of a wave tile -> a dense [rows][ld] fp32 matrix (K-split slabs of the grid's tail): same wave-private LDS
 // staging as ls_epilogue, no epilogue arithmetic.
-template <int TM, int TN, int WN>
+template <int TM, int TN, int WN, bool M16 = false>
 __device__ __forceinline__ void ls_store_raw(floatx16 (&acc)[TM][TN], char* smem, int wave, int lane, int wave_m0, int wave_n0,
                                              float* out, int ld) {
     constexpr int LDC = WN + 4;
@@ -566,7 +570,9 @@ __device__ __forceinline__ void ls_store_raw(floatx16 (&acc)[TM][TN], char* smem
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sC[((r & 3) + 8 * (r >> 2) + 4 * half) * LDC + 32 * j + l31] = acc[i][j][r];
+            for (int r = 0; r < 16; ++r) {
+                if (!M16) sC[((r & 3) + 8 * (r >> 2) + 4 * half) * LDC + 32 * j + l31] = acc[i][j][r];
+            }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -1312,6 +1318,123 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
     DIAG_STAMP(e1);
     const unsigned long long t_pro = e1 - e0;
 #endif
+#if !defined(DGP_MFMA32)
+    // 16x16x32 MFMAs in the pipelined loop of the 32 x 128 wave tile: the same FLOPs, LDS bytes and register reads as the 32x32x16
+    // shape in twice as many, half as long matrix instructions -- measured +10 % end to end (block4 3x3: 0.499 -> 0.403 ms)
+    constexpr bool M16 = CS && TM == 1 && TN == 4 && NT == 2 && BK == 32;
+#else
+    constexpr bool M16 = false;
+#endif
+    if constexpr (M16) {
+        // One K-step = one MFMA depth (32).  Per step a wave splits its 2 x 16 rows (A: two fp32 chunks per lane and row block ->
+        // a_hi / a_lo), and walks 16 B fragments f = (column block j = f / 2, plane: low first) through a ring of eight register
+        // quads, seven fragments ahead of the MFMAs (three ahead left every fragment waiting on LDS: 2420 frames/s): low plane -> a_hi b_lo for both row blocks, high plane -> a_lo b_hi, a_hi b_hi.
+        // The barrier sits before the last two fragments' MFMAs and the next step's first reads fly under them.
+        typedef float floatx4 __attribute__((ext_vector_type(4)));
+        const int l15 = lane & 15, g = lane >> 4;
+        floatx4 c[2][8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        const uint4* a_lane = sA + (2 * g) * LDAF + wave_m0 + l15;                 // register-staged image [chunk][row]
+        // DMA image: row-major, chunk ch of row r in slot ch ^ ((r >> 1) & 7) (same for r and r + 16); this lane wants chunks 2 g, 2 g + 1
+        const unsigned a_row0 = (unsigned)((wave_m0 + l15) * 128 + (((2 * g) ^ (((wave_m0 + l15) >> 1) & 7)) << 4));
+        unsigned a_cur = a_row0;
+        int sa_c = 0;
+        const uint4* A = a_lane;
+        const uint4* B = sB + wave_n0 + l15 + g * LDB;
+        int da = A_CELLS, db = B_CELLS;            // to the other buffer and back
+        uint4 ra[2][2], ah[2], al[2], bq[4];
+        auto mma = [](const uint4& x, const uint4& y, floatx4 cc) {
+            return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), cc, 0, 0, 0);
+        };
+#define DGP_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define DGP_RA(I) do { if constexpr (DMA) {                                                                         \
+            ra[I][0] = *reinterpret_cast<const uint4*>(smem + a_cur + (I) * 2048);                                 \
+            ra[I][1] = *reinterpret_cast<const uint4*>(smem + (a_cur ^ 16u) + (I) * 2048);                         \
+        } else { ra[I][0] = A[16 * (I)]; ra[I][1] = A[LDAF + 16 * (I)]; } } while (0)
+#define DGP_RB(F) do { bq[(F) & 3] = B[((((F) & 1) ? 0 : 1) * KG) * LDB + 16 * (((F) & 15) >> 1)]; } while (0)
+#define DGP_SPLIT(I) do { uint2 h0_, l0_, h1_, l1_;                                                                \
+        split2_f16(__builtin_bit_cast(float4, ra[I][0]), scA_c, h0_, l0_);                                         \
+        split2_f16(__builtin_bit_cast(float4, ra[I][1]), scA_c, h1_, l1_);                                         \
+        ah[I] = make_uint4(h0_.x, h0_.y, h1_.x, h1_.y); al[I] = make_uint4(l0_.x, l0_.y, l1_.x, l1_.y); } while (0)
+#define DGP_MM(F) do { constexpr int j_ = (F) >> 1;                                                                \
+        if (((F) & 1) == 0) { c[0][j_] = mma(ah[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(ah[1], bq[(F) & 3], c[1][j_]); }    \
+        else { c[0][j_] = mma(al[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(al[1], bq[(F) & 3], c[1][j_]);         \
+               c[0][j_] = mma(ah[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(ah[1], bq[(F) & 3], c[1][j_]); } } while (0)
+#define DGP_STEP(F) do { DGP_MM(F); DGP_FENCE(); DGP_RB((F) + 4); DGP_FENCE(); } while (0)
+#ifdef DGP_M16_SIMPLE      // debugging aid: the same arithmetic without any software pipelining
+        for (int ks = 0; ks < nks; ++ks) {
+            DGP_RA(0); DGP_RA(1);
+            DGP_SPLIT(0); DGP_SPLIT(1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint4 bl = B[(1 * KG) * LDB + 16 * j], bh = B[16 * j];
+#if DGP_M16_SIMPLE != 2
+                c[0][j] = mma(ah[0], bl, c[0][j]); c[1][j] = mma(ah[1], bl, c[1][j]);
+#endif
+#if DGP_M16_SIMPLE != 3
+                c[0][j] = mma(al[0], bh, c[0][j]); c[1][j] = mma(al[1], bh, c[1][j]);
+#endif
+                c[0][j] = mma(ah[0], bh, c[0][j]); c[1][j] = mma(ah[1], bh, c[1][j]);
+            }
+            __syncthreads();
+            if constexpr (DMA) { sa_c = sa_c == 2 ? 0 : sa_c + 1; a_cur = a_row0 + (unsigned)(sa_c * (A_CELLS * 16)); }
+            else { A += da; da = -da; }
+            B += db; db = -db;
+        }
+#else
+        DGP_RA(0); DGP_RA(1);
+        DGP_RB(0); DGP_RB(1); DGP_RB(2); DGP_RB(3);
+        DGP_FENCE();
+        for (int ks = 0; ks < nks; ++ks) {
+            DGP_SPLIT(0);
+            DGP_SPLIT(1);
+            DGP_FENCE();
+            DGP_STEP(0); DGP_STEP(1); DGP_STEP(2); DGP_STEP(3); DGP_STEP(4); DGP_STEP(5);
+            DGP_STEP(6); DGP_STEP(7); DGP_STEP(8); DGP_STEP(9); DGP_STEP(10); DGP_STEP(11);
+            DGP_MM(12); DGP_FENCE();
+            DGP_MM(13); DGP_FENCE();
+            DIAG_STAMP(e2);
+            __syncthreads();
+            DIAG_STAMP(e3);
+#ifdef DGP_DIAG
+            acc_mf += e2 - e1; acc_ba += e3 - e2; e1 = e3;
+#endif
+            if constexpr (DMA) { sa_c = sa_c == 2 ? 0 : sa_c + 1; a_cur = a_row0 + (unsigned)(sa_c * (A_CELLS * 16)); }
+            else { A += da; da = -da; }
+            B += db; db = -db;
+            const bool more = ks + 1 < nks;
+            if (more) { DGP_RA(0); DGP_RA(1); DGP_RB(0); DGP_RB(1); }
+            DGP_FENCE();
+            DGP_MM(14); DGP_FENCE();
+            if (more) DGP_RB(2);
+            DGP_FENCE();
+            DGP_MM(15); DGP_FENCE();
+            if (more) DGP_RB(3);
+            DGP_FENCE();
+        }
+#endif
+#undef DGP_FENCE
+#undef DGP_RA
+#undef DGP_RB
+#undef DGP_SPLIT
+#undef DGP_MM
+#undef DGP_STEP
+        {      // stage the 16x16 blocks into this wave's LDS tile (what ls_epilogue / ls_store_raw do for the 32x32 blocks)
+            constexpr int LDCW = WN + 4;
+            float* sCw = reinterpret_cast<float*>(smem) + wave * (32 * LDCW);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sCw[(16 * i + 4 * g + r) * LDCW + 16 * j + l15] = c[i][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    } else
 #if !defined(DGP_NO_PIPE)
     static_assert(!DMA || (TM == 1 && TN == 4), "DMA image is read by the pipelined loop only");
     if constexpr (CS && TM == 1 && TN == 4 && NT == 2 && BK == 32) {
@@ -1488,10 +1611,10 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
     DIAG_STAMP(e1);
 #endif
     if (part >= 0) {        // raw accumulators of this K-slice -> slab [BM][BN]; tail_fixup sums the slices and applies the epilogue
-        ls_store_raw<TM, TN, WN>(acc, smem, wave, lane, wave_m0, wave_n0, p.slab + (size_t)tail_slot * (BM * BN), BN);
+        ls_store_raw<TM, TN, WN, M16>(acc, smem, wave, lane, wave_m0, wave_n0, p.slab + (size_t)tail_slot * (BM * BN), BN);
         return;
     }
-    ls_epilogue<TM, TN, WN>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
+    ls_epilogue<TM, TN, WN, M16>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
 #ifdef DGP_DIAG
     DIAG_STAMP(e2);
     if (p.dbg && threadIdx.x == 0) {

@@ -837,6 +837,21 @@ int dgp_conv2d_ranged(const dgp_conv_desc* d, const float* x, const float* packe
         a.w_bytes = (unsigned)((size_t)a.nk * 8 * a.CoutP * 16);
     }
     a.in_absmax = x_absmax; a.w_absmax = w_absmax; a.out_absmax = y_absmax;
+    // DGP_CONV2D_CELLS=1 (tests, tuning): split the panel into fp16 cells per call (grow-only scratch, stream-ordered) so that a single
+    // layer runs on the engine's compute-side-split / LDS-DMA kernels; the network packs its cells once at load instead
+    static const bool cells_env = getenv("DGP_CONV2D_CELLS") && atoi(getenv("DGP_CONV2D_CELLS")) != 0;
+    if (cells_env && x_absmax && w_absmax && d->Cin >= 32) {
+        static void* cells = nullptr;
+        static size_t cells_bytes = 0;
+        if (cells_bytes < a.w_bytes) {
+            if (cells) { (void)hipDeviceSynchronize(); (void)hipFree(cells); }
+            if (hipMalloc(&cells, a.w_bytes) != hipSuccess) return fail(DGP_ERR_HIP, "dgp_conv2d: cell scratch");
+            cells_bytes = a.w_bytes;
+        }
+        hipError_t pe = launch_pack_h3(packed_w, a.nk, a.CoutP, w_absmax, cells, (hipStream_t)stream);
+        if (pe != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_conv2d: pack cells: ") + hipGetErrorString(pe));
+        a.wh3 = cells; a.wh3_bytes = a.w_bytes;
+    }
     hipError_t e = launch_conv(a, pick_tile(a.M, a.CoutP, a.nk * BK, x_absmax && w_absmax), (hipStream_t)stream);
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_conv2d: ") + hipGetErrorString(e));
     return DGP_OK;
