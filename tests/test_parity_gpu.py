@@ -433,3 +433,49 @@ def test_calculate_motion_energy_hip_backend_matches_host(eng):
         def iter_frames(self):
             yield from clip
     assert np.array_equal(D.calculate_motion_energy(FrameOnly(), backend="hip", chunk=16), host)
+
+
+@pytest.mark.parametrize("extra", [{}, {"DGP_DMA": "0"}, {"DGP_COMPUTE_SPLIT": "0"}])
+def test_cell_kernels_match_fp64_per_layer(eng, extra):
+    """Single layers on the engine's pre-split-cell kernels (compute-side split, LDS-DMA loaders, 16x16x32 pipelined loop;
+    DGP_CONV2D_CELLS=1 is read once per process, so this runs in a child): pointwise / 3x3 / dilated / strided shapes with ragged
+    row counts and several K depths against an fp64 reference, plus an exact selection-matrix case that catches any row / column /
+    k permutation (operands chosen so that every product is exact)."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent('''
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r)
+        from deepgraphpose_amd import engine
+        rng = np.random.default_rng(11)
+        worst = 0.0
+        for (N, H, W, Cin, Cout, k, s, r) in [(1, 8, 16, 32, 128, 1, 1, 1), (2, 9, 13, 256, 128, 1, 1, 1), (1, 15, 20, 128, 256, 3, 1, 1),
+                                              (1, 9, 11, 512, 512, 3, 1, 2), (2, 20, 24, 256, 512, 1, 2, 1), (3, 7, 9, 64, 128, 3, 2, 1),
+                                              (1, 30, 40, 2048, 512, 1, 1, 1)]:
+            x = np.maximum(rng.standard_normal((N, H, W, Cin)), 0).astype(np.float32) * rng.uniform(0.1, 3, (1, 1, 1, Cin)).astype(np.float32)
+            w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+            keff = r * (k - 1) + 1
+            Ho, Wo = -(-H // s), -(-W // s)
+            ph, pw = max((Ho - 1) * s + keff - H, 0), max((Wo - 1) * s + keff - W, 0)          # TF SAME
+            y = engine.conv2d(torch.from_numpy(x).cuda(), w, stride=s, rate=r, pad_t=ph // 2, pad_l=pw // 2, out_hw=(Ho, Wo),
+                              ranged=True).cpu().numpy()
+            xt = torch.from_numpy(x).double().permute(0, 3, 1, 2)
+            wt = torch.from_numpy(w).double().permute(3, 2, 0, 1)
+            xp = torch.nn.functional.pad(xt, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+            ref = torch.nn.functional.conv2d(xp, wt, stride=s, dilation=r).permute(0, 2, 3, 1).numpy()
+            assert y.shape == ref.shape, (y.shape, ref.shape)
+            worst = max(worst, float(np.abs(y - ref).max() / np.abs(ref).max()))
+        # exact case: out[m][n] = x[m][n %% 32] with integer x < 2^13 (needs the high AND the low fp16 part)
+        M, Cin, Cout = 128 + 37, 32, 256
+        x = (np.arange(M)[:, None] * 64 + np.arange(Cin)[None, :]).astype(np.float32).reshape(1, 1, M, Cin)
+        w = np.zeros((1, 1, Cin, Cout), np.float32)
+        w[0, 0, np.arange(Cout) %% Cin, np.arange(Cout)] = 1.0
+        y = engine.conv2d(torch.from_numpy(x).cuda(), w, ranged=True).cpu().numpy().reshape(M, Cout)
+        exact = bool(np.array_equal(y, x.reshape(M, Cin)[:, np.arange(Cout) %% Cin]))
+        print("RESULT", worst, exact)
+    ''') % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DGP_CONV2D_CELLS="1", **extra)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    assert line, out.stdout[-2000:] + out.stderr[-2000:]
+    _, worst, exact = line[0].split()
+    assert float(worst) < 3e-6 and exact == "True", line[0]
