@@ -34,6 +34,11 @@ struct ConvLayer {
     void* d_wh3_fused = nullptr;
     int nk_fused = 0, cin2 = 0;
     float* d_w_rows = nullptr;   // stem only: panel for the row walk [7 rows x 8 pixels][CoutP][4] (pixel 7 and channel 3 are zero)
+    // heads only: the transposed conv as ONE pointwise GEMM [pixels x 2048] x [2048 x (4 taps x 4 phases x nj)] + a gather of the
+    // <= 4 tap contributions per output pixel (reads the 2048-channel map once instead of four shifted times)
+    float* d_w_pw = nullptr;
+    void* d_wh3_pw = nullptr;
+    int coutp_pw = 0;
 };
 
 struct Unit {
@@ -88,6 +93,8 @@ struct dgp_net {
             if (l.d_bias) (void)hipFree(l.d_bias);
             if (l.d_wh3) (void)hipFree(l.d_wh3);
             if (l.d_w_rows) (void)hipFree(l.d_w_rows);
+            if (l.d_w_pw) (void)hipFree(l.d_w_pw);
+            if (l.d_wh3_pw) (void)hipFree(l.d_wh3_pw);
             for (void* q : {(void*)l.d_w_fused, (void*)l.d_bias_fused, l.d_wh3_fused}) if (q) (void)hipFree(q);
         }
         for (float* q : {d_wmax, d_amax, d_inmax}) if (q) (void)hipFree(q);

@@ -67,6 +67,7 @@ hipError_t launch_pack_h3(const float* panel, int nk, int CoutP, const float* w_
 hipError_t launch_absmax(const float* x, long long n, float* out_slots, hipStream_t s);   // slots = max(slots, max |x|)
 const char* conv_kernel_name(const ConvArgs& a, int tile_cfg);
 hipError_t launch_reduce_slabs(const float* slabs, long long n, long long stride, int nsplit, float* out, hipStream_t s);
+hipError_t launch_head_gather(const float* T, const float* bias, int B, int h, int w, int njt, int ldt, float* out, hipStream_t s);
 hipError_t launch_maxpool(const float* x, int N, int H, int W, int C, float* y, hipStream_t s);
 hipError_t launch_preprocess(const uint8_t* f, long long npix, float m0, float m1, float m2,
                              float* out, hipStream_t s);

@@ -1998,6 +1998,39 @@ hipError_t launch_reduce_slabs(const float* slabs, long long n, long long stride
     return hipGetLastError();
 }
 
+// Gather of the pointwise head (dgp_net.hip run_head_pointwise): T [B][h][w][ldt] holds, per input pixel, the contributions
+// (tap, phase, joint) -> column (tap * 4 + phase) * njt + joint; output pixel (2 ho + a, 2 wo + b) sums its <= 4 taps in fixed order.
+__global__ __launch_bounds__(256) void head_gather_kernel(const float* __restrict__ T, const float* __restrict__ bias, int B, int h, int w,
+                                                          int njt, int ldt, float* __restrict__ out) {
+    const long long n = (long long)B * 2 * h * 2 * w * njt;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(g % njt);
+        long long r = g / njt;
+        const int x = (int)(r % (2 * w)); r /= 2 * w;
+        const int y = (int)(r % (2 * h));
+        const int b = (int)(r / (2 * h));
+        const int ho = y >> 1, pa = y & 1, wo = x >> 1, pb = x & 1;
+        const int ph = pa * 2 + pb;
+        float acc = bias ? bias[ph * njt + c] : 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap) {
+            const int hi = ho - 1 + (tap >> 1), wi = wo - 1 + (tap & 1);
+            if ((unsigned)hi < (unsigned)h && (unsigned)wi < (unsigned)w)
+                acc += T[(((long long)b * h + hi) * w + wi) * ldt + (tap * 4 + ph) * njt + c];
+        }
+        out[g] = acc;
+    }
+}
+
+hipError_t launch_head_gather(const float* T, const float* bias, int B, int h, int w, int njt, int ldt, float* out, hipStream_t s) {
+    const long long n = (long long)B * 2 * h * 2 * w * njt;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(head_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, s, T, bias, B, h, w, njt, ldt, out);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------
 // 3x3 / stride 2 max-pool, TF 'SAME' padding (pad_before = pad_total/2, padded cells never
 // win).  NHWC fp32, 4 channels (16 B) per thread.  HBM-bound.

@@ -259,6 +259,20 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
         HIP_TRY(hipMemcpy(l.d_w, packed.data(), nfl * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(l.d_scale, scale.data(), l.Cout * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(l.d_bias, bias.data(), l.Cout * sizeof(float), hipMemcpyHostToDevice));
+        if (is_head) {      // the same weights as a pointwise panel: column (tap, phase, joint) of row ci
+            const int cpw = 4 * l.Cout;
+            std::vector<float> wpw((size_t)2048 * cpw);
+            for (int tap = 0; tap < 4; ++tap)
+                for (int ci = 0; ci < 2048; ++ci)
+                    memcpy(&wpw[(size_t)ci * cpw + (size_t)tap * l.Cout], &hwio[((size_t)tap * 2048 + ci) * l.Cout], l.Cout * sizeof(float));
+            l.coutp_pw = coutp_for(cpw);
+            const size_t npw = (size_t)nk_for(1, 1, 2048) * 8 * l.coutp_pw * 4;
+            std::vector<float> ppw(npw);
+            pack_panels(wpw.data(), 1, 1, 2048, cpw, ppw.data());
+            if (!l.d_w_pw) HIP_TRY(hipMalloc(&l.d_w_pw, npw * sizeof(float)));
+            if (!l.d_wh3_pw) HIP_TRY(hipMalloc(&l.d_wh3_pw, npw * sizeof(float)));
+            HIP_TRY(hipMemcpy(l.d_w_pw, ppw.data(), npw * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
     // operand ranges for the fp16-split kernels
     const size_t nl = net->layers.size();
@@ -294,6 +308,12 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
             if (!l.d_wh3) HIP_TRY(hipMalloc(&l.d_wh3, rows.size() * sizeof(float)));
             e = launch_pack_h3(l.d_w_rows, 7, l.CoutP, net->d_wmax + li * ABSMAX_SLOTS, l.d_wh3, nullptr);
             if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("stem weight cells: ") + hipGetErrorString(e));
+        } else if (l.d_w_pw) {                                   // heads: range + cells of the pointwise panel (slot nl + li)
+            const int nkpw = nk_for(1, 1, 2048);
+            float* wm = net->d_wmax + (nl + li) * ABSMAX_SLOTS;
+            e = launch_absmax(l.d_w_pw, (long long)nkpw * 8 * l.coutp_pw * 4, wm, nullptr);
+            if (e == hipSuccess) e = launch_pack_h3(l.d_w_pw, nkpw, l.coutp_pw, wm, l.d_wh3_pw, nullptr);
+            if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("head pointwise panel: ") + hipGetErrorString(e));
         } else if (l.Cin >= 32 && l.CoutP % 64 == 0) {          // layers the fp16-split kernels can take: pre-split cells
             const size_t bytes = (size_t)l.nk * 8 * l.CoutP * 16;
             if (!l.d_wh3) HIP_TRY(hipMalloc(&l.d_wh3, bytes));
@@ -447,6 +467,34 @@ int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, in
     }
     hipError_t e = launch_conv(a, tile_cfg, s);
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("conv launch (") + l.scope + "): " + hipGetErrorString(e));
+    return DGP_OK;
+}
+
+// A head (3x3 / stride-2 SAME transposed conv, run as a 2x2 conv with 4 output phases) as a pointwise GEMM + gather:
+// T[pixel][(tap, phase, joint)] = x[pixel][:] . W'[tap][:][(phase, joint)], then
+// out[2 ho + a][2 wo + b][c] = bias[c] + sum over taps (kh', kw') of T[ho - 1 + kh'][wo - 1 + kw'][(kh', kw'), (a, b), c]
+// (taps outside the map contribute nothing; fixed summation order).  T lives in the (free) R1 region of the workspace.
+int run_head_pointwise(dgp_net* net, const ConvLayer& l, const float* feat, int B, int h, int w, int njt, float* out, hipStream_t s,
+                       float* T, const float* feat_absmax) {
+    const int li = (int)(&l - net->layers.data());
+    const int nl = (int)net->layers.size();
+    ConvArgs a{};
+    a.in = feat; a.wpk = l.d_w_pw; a.wh3 = l.d_wh3_pw; a.out = T;
+    a.in_absmax = feat_absmax; a.w_absmax = net->d_wmax + (size_t)(nl + li) * ABSMAX_SLOTS;
+    a.slab = net->tail_slab; a.slab_bytes = net->tail_slab_bytes;
+    a.N = B; a.H = h; a.W = w; a.Cin = 2048; a.log2cin4 = ilog2(2048 / 4);
+    a.Ho = h; a.Wo = w; a.Cout = l.coutp_pw; a.CoutP = l.coutp_pw;
+    a.KH = 1; a.KW = 1; a.stride = 1; a.dil = 1; a.ntaps = 1; a.nk = nk_for(1, 1, 2048); a.M = B * h * w;
+    a.in_bytes = (unsigned)((size_t)a.M * 2048 * 4); a.out_bytes = (unsigned)((size_t)a.M * l.coutp_pw * 4);
+    a.w_bytes = (unsigned)((size_t)a.nk * 8 * l.coutp_pw * 16); a.wh3_bytes = a.w_bytes;
+    const int tile_cfg = pick_tile(a.M, a.CoutP, a.nk * BK, true);
+    hipError_t e;
+    {
+        ProfScope ps(net, s, "conv:" + l.scope + "(pointwise+gather)|" + conv_kernel_name(a, tile_cfg), conv_flops_of(l, a.M, true));
+        e = launch_conv(a, tile_cfg, s);
+        if (e == hipSuccess) e = launch_head_gather(T, l.d_bias, B, h, w, njt, l.coutp_pw, out, s);
+    }
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("head (") + l.scope + "): " + hipGetErrorString(e));
     return DGP_OK;
 }
 
@@ -604,12 +652,18 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
         HIP_TRY(hipMemcpyAsync(features, feat, (size_t)B * h * w * 2048 * sizeof(float), hipMemcpyDeviceToDevice, s));
     float* sm = scmap ? scmap : (float*)(ws + pl.off_scmap);
     float* slabs = (float*)(ws + pl.off_slabs);
-    rc = run_conv(net, net->layers[net->head_part], feat, B, h, w, 1, 1, h, w, nullptr, 0, 0, 0, false, 1, d.num_joints,
-                  sm, s, slabs);
+    static const bool head_pw = !(getenv("DGP_HEAD_PW") && atoi(getenv("DGP_HEAD_PW")) == 0);      // A/B switch
+    static const bool f16_mode = !getenv("DGP_CONV_MODE") || !strcmp(getenv("DGP_CONV_MODE"), "f16x3");
+    const bool pw = head_pw && f16_mode && net->wmax_valid && x_rng && net->layers[net->head_part].d_wh3_pw;
+    if (pw) rc = run_head_pointwise(net, net->layers[net->head_part], feat, B, h, w, d.num_joints, sm, s, R1, x_rng);
+    else rc = run_conv(net, net->layers[net->head_part], feat, B, h, w, 1, 1, h, w, nullptr, 0, 0, 0, false, 1, d.num_joints,
+                       sm, s, slabs);
     if (rc) return rc;
     if (locref) {
-        rc = run_conv(net, net->layers[net->head_locref], feat, B, h, w, 1, 1, h, w, nullptr, 0, 0, 0, false, 1,
-                      2 * d.num_joints, locref, s, slabs);
+        if (pw && net->layers[net->head_locref].d_wh3_pw)
+            rc = run_head_pointwise(net, net->layers[net->head_locref], feat, B, h, w, 2 * d.num_joints, locref, s, R1, x_rng);
+        else rc = run_conv(net, net->layers[net->head_locref], feat, B, h, w, 1, 1, h, w, nullptr, 0, 0, 0, false, 1,
+                           2 * d.num_joints, locref, s, slabs);
         if (rc) return rc;
     }
     if (net->prof_on && net->prof_used < net->prof_slots && !net->prof_in_infer) ++net->prof_used;
