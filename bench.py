@@ -187,10 +187,12 @@ def main():
                 bk, cw = (pk[2][1:].split("w") + ["4"])[:2]
                 key = "conv_igemm_split_ls<%s,%s,%s,%s,%s" % (pk[1].split("x")[0], pk[1].split("x")[1], pk[0], bk, cw)
                 cands = [v for k_, v in tr.get("per_kernel", {}).items() if k_.startswith(key)]       # (+ ",true": pre-split weights)
-                ent = max(cands, key=lambda v: v["launches_per_step"]) if cands else None
-                if ent:
-                    roofline["traffic"] = float(ent["hbm_bytes_per_launch"])
-                    roofline["traffic_unit"] = "HBM bytes per launch of the dominant kernel (average), PMC FETCH_SIZE x2 + WRITE_SIZE"
+                nl_ = sum(v["launches_per_step"] for v in cands)
+                if cands and nl_ > 0:      # launch-weighted mean over the kernel's loader specialisations (pointwise / 3x3 walk)
+                    roofline["traffic"] = float(sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for v in cands) / nl_)
+                    roofline["traffic_unit"] = ("bytes per launch of the dominant kernel (launch-weighted mean of its loader specialisations), PMC "
+                                                "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE at the L2's memory side: Infinity-Cache hits and "
+                                                "the weights fetched once per XCD are included")
                     roofline["algorithmic_bytes_per_launch"] = round(sum(
                         alg_bytes.get(n.split("|")[0], 0.0) for n, _, _ in conv if n.endswith("|" + dom)) / d_n, 1)
             roofline["conv_stack_hbm_bytes_per_step"] = float(tr["conv_hbm_bytes_per_step"])
