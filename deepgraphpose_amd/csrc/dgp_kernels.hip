@@ -1320,16 +1320,18 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
 #endif
 #if !defined(DGP_MFMA32)
     // 16x16x32 MFMAs in the pipelined loop of the 32 x 128 wave tile: the same FLOPs, LDS bytes and register reads as the 32x32x16
-    // shape in twice as many, half as long matrix instructions -- measured +10 % end to end (block4 3x3: 0.499 -> 0.403 ms)
+    // shape in twice as many, half as long matrix instructions -- +5.3 % end to end (block4 3x3: 0.499 -> 0.453 ms)
     constexpr bool M16 = CS && TM == 1 && TN == 4 && NT == 2 && BK == 32;
 #else
     constexpr bool M16 = false;
 #endif
     if constexpr (M16) {
         // One K-step = one MFMA depth (32).  Per step a wave splits its 2 x 16 rows (A: two fp32 chunks per lane and row block ->
-        // a_hi / a_lo), and walks 16 B fragments f = (column block j = f / 2, plane: low first) through a ring of eight register
-        // quads, seven fragments ahead of the MFMAs (three ahead left every fragment waiting on LDS: 2420 frames/s): low plane -> a_hi b_lo for both row blocks, high plane -> a_lo b_hi, a_hi b_hi.
-        // The barrier sits before the last two fragments' MFMAs and the next step's first reads fly under them.
+        // a_hi / a_lo), and walks 16 B fragments f = (column block j = f / 2, plane: low first) through a ring of four register
+        // quads, three fragments ahead of the MFMAs: low plane -> a_hi b_lo for both row blocks, high plane -> a_lo b_hi, a_hi b_hi.
+        // The barrier sits before the last two fragments' MFMAs and the next step's first reads fly under them.  (An 8-quad ring,
+        // 5-7 ahead, measured the same; the 32 x 64 wave tile of the 128 x 64 kernels on this loop measured 3 % slower: its
+        // register-staged images are laid out for the 32-lane fragment reads.)
         typedef float floatx4 __attribute__((ext_vector_type(4)));
         const int l15 = lane & 15, g = lane >> 4;
         floatx4 c[2][8];
