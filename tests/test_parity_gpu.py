@@ -479,3 +479,51 @@ def test_cell_kernels_match_fp64_per_layer(eng, extra):
     assert line, out.stdout[-2000:] + out.stderr[-2000:]
     _, worst, exact = line[0].split()
     assert float(worst) < 3e-6 and exact == "True", line[0]
+
+
+@pytest.mark.parametrize("cells", ["0", "1"])
+def test_full_size_layers_are_exactly_linear_in_powers_of_two(eng, cells):
+    """Size-independent property at BASELINE's full layer sizes (batch 32, 30x40 maps), where the oracle is too slow: the fp16
+    high/low split scales its operands by powers of two taken from the tracked ranges, so conv(4 x) must equal 4 conv(x) BIT FOR
+    BIT (same mantissas in every partial product), and conv(x; 0.5 w) = 0.5 conv(x; w).  Child process: DGP_CONV2D_CELLS selects
+    the register-staged split kernels (0) or the cell / LDS-DMA / 16x16x32 kernels (1)."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent('''
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r)
+        from deepgraphpose_amd import engine
+        rng = np.random.default_rng(5)
+        ok = True
+        for (N, H, W, Cin, Cout, k, r, pad) in [(32, 30, 40, 512, 512, 3, 2, 2), (32, 30, 40, 2048, 512, 1, 1, 0), (32, 30, 40, 256, 1024, 1, 1, 0)]:
+            x = torch.relu(torch.randn((N, H, W, Cin), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)))
+            w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+            y1 = engine.conv2d(x, w, rate=r, pad_t=pad, pad_l=pad, out_hw=(H, W), ranged=True)
+            y4 = engine.conv2d(x * 4.0, w, rate=r, pad_t=pad, pad_l=pad, out_hw=(H, W), ranged=True)
+            yh = engine.conv2d(x, w * 0.5, rate=r, pad_t=pad, pad_l=pad, out_hw=(H, W), ranged=True)
+            ok = ok and bool(torch.equal(y4, y1 * 4.0)) and bool(torch.equal(yh, y1 * 0.5)) and bool(torch.isfinite(y1).all())
+        print("RESULT", ok)
+    ''') % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DGP_CONV2D_CELLS=cells)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    assert line, out.stdout[-2000:] + out.stderr[-2000:]
+    assert line[0].split()[1] == "True", line[0]
+
+
+def test_full_size_inference_is_deterministic_and_batch_order_free(eng):
+    """BASELINE configs[1] size (ResNet-50, 640x480, batch 32): two runs give bit-identical outputs (no float atomics anywhere: the
+    grid-tail K-split and the heads sum their slices in fixed order), and reversing the frame order permutes the results -- exactly
+    for the integer indices, within the parity tolerance for the coordinates (a frame's pixels land in other tiles, and a tail tile's
+    K-split rounds differently from an unsplit one)."""
+    from deepgraphpose_amd import synthetic
+    B = 32
+    net = eng.DGPNet(50, 4, 480, 640, max_batch=B)
+    net.load_weights(synthetic.make_weights(50, 4, False, seed=0, head_std=0.05))
+    f = torch.from_numpy(synthetic.make_frames(B, 480, 640, 4, seed=1)).cuda()
+    mu1, c1, i1 = [t.clone() for t in net.infer(f, 1.0, 1)]
+    mu2, c2, i2 = [t.clone() for t in net.infer(f, 1.0, 1)]
+    assert torch.equal(mu1, mu2) and torch.equal(c1, c2) and torch.equal(i1, i2)
+    mu3, c3, i3 = net.infer(torch.flip(f, dims=[0]).contiguous(), 1.0, 1)
+    assert torch.equal(torch.flip(i3, dims=[0]), i1)
+    assert float((torch.flip(mu3, dims=[0]) - mu1).abs().max()) * STRIDE < PX_TOL
+    assert float((torch.flip(c3, dims=[0]) - c1).abs().max()) < 1e-4
