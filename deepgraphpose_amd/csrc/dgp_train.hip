@@ -121,6 +121,69 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, const float* __re
     pack_track(rng, mx);
 }
 
+// All non-head layers in ONE launch (the per-layer kernels above cost ~180 dispatches of 4 us + their gaps per step):
+// blockIdx.y = layer, blockIdx.z = job (0: forward panel, 1: data-gradient panel, 2: folded BN).  The data-gradient job folds
+// scale = gamma / sqrt(var + eps) itself (the same expression as fold_bn_kernel, so the same bits) instead of waiting for job 2.
+struct PackDesc {
+    long long w_off, g_off, b_off, mean_off, var_off;
+    int taps, cin_real, cin, cout, coutP, nchunks_f, cinP, nchunks_b;
+    float *d_w, *rng_f, *d_wT, *rng_b, *d_scale, *d_bias;
+};
+__global__ __launch_bounds__(256) void pack_all_kernel(const PackDesc* __restrict__ table, const float* __restrict__ params,
+                                                       const float* __restrict__ stats, float eps) {
+    const PackDesc d = table[blockIdx.y];
+    const float* w = params + d.w_off;
+    if (blockIdx.z == 2) {
+        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < d.cout; c += gridDim.x * blockDim.x) {
+            const float inv = params[d.g_off + c] / sqrtf(stats[d.var_off + c] + eps);
+            d.d_scale[c] = inv;
+            d.d_bias[c] = params[d.b_off + c] - stats[d.mean_off + c] * inv;
+        }
+        return;
+    }
+    float mx = 0.f;
+    if (blockIdx.z == 0) {
+        const long long total = (long long)d.nchunks_f * d.coutP;
+        if ((long long)blockIdx.x * blockDim.x >= total) return;
+        const int cin4 = d.cin >> 2;
+        for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+            const int co = (int)(g % d.coutP);
+            const int q = (int)(g / d.coutP);
+            const int tap = q / cin4, ch = (q - tap * cin4) << 2;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tap < d.taps && co < d.cout) {
+                float* pv = &v.x;
+                for (int e = 0; e < 4; ++e)
+                    if (ch + e < d.cin_real) pv[e] = w[((long long)tap * d.cin_real + ch + e) * d.cout + co];
+            }
+            *reinterpret_cast<float4*>(d.d_w + g * 4) = v;
+            mx = amax4(mx, v);
+        }
+        pack_track(d.rng_f, mx);
+    } else {
+        if (!d.d_wT) return;
+        const long long total = (long long)d.nchunks_b * d.cinP;
+        if ((long long)blockIdx.x * blockDim.x >= total) return;
+        const int cout4 = d.cout >> 2;
+        for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+            const int ci = (int)(g % d.cinP);
+            const int q = (int)(g / d.cinP);
+            const int tapp = q / cout4, co = (q - tapp * cout4) << 2;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tapp < d.taps && ci < d.cin) {
+                const int tap = d.taps - 1 - tapp;
+                const float* src = w + ((long long)tap * d.cin + ci) * d.cout + co;
+                float sc[4];
+                for (int e = 0; e < 4; ++e) sc[e] = params[d.g_off + co + e] / sqrtf(stats[d.var_off + co + e] + eps);
+                v = make_float4(src[0] * sc[0], src[1] * sc[1], src[2] * sc[2], src[3] * sc[3]);
+            }
+            *reinterpret_cast<float4*>(d.d_wT + g * 4) = v;
+            mx = amax4(mx, v);
+        }
+        pack_track(d.rng_b, mx);
+    }
+}
+
 // head data-gradient panels: "input" channels = phase-major 4*njt padded to cpad, taps 2x2 flipped, N' = Cin
 __global__ void pack_head_dgrad_kernel(const float* __restrict__ w, int njt, int cin, int cpad, int cinP, int nchunks,
                                        float* __restrict__ packed) {
@@ -678,8 +741,10 @@ struct dgp_trainer {
     float* d_gnorm = nullptr;
     float* d_rng_pool = nullptr;      // activation / gradient range slots (RANGE_POOL arrays), zeroed per pass
     float* d_wrng = nullptr;          // weight-panel range slots: [2 * n_layers] (forward panels, data-gradient panels), per sync
+    void* d_pack_table = nullptr;     // PackDesc of every non-head layer (pack_all_kernel), built at the first sync
+    int n_pack = 0;
     ~dgp_trainer() {
-        for (void* q : {(void*)d_rng_pool, (void*)d_wrng}) if (q) (void)hipFree(q);
+        for (void* q : {(void*)d_rng_pool, (void*)d_wrng, d_pack_table}) if (q) (void)hipFree(q);
         for (auto& t : tl) { if (t.d_wT) (void)hipFree(t.d_wT); if (t.d_wTh3) (void)hipFree(t.d_wTh3); }
         for (void* p : {(void*)params, (void*)grads, (void*)mom, (void*)stats, (void*)d_sumsq, (void*)d_gnorm})
             if (p) (void)hipFree(p);
@@ -992,6 +1057,9 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
     const float eps = net->desc.bn_eps;
     const size_t nl_all = net->layers.size();
     if (tr->d_wrng) TRY_HIP(hipMemsetAsync(tr->d_wrng, 0, 2 * nl_all * ABSMAX_SLOTS * sizeof(float), s));
+    // one launch for the panels / folded BN of all non-head layers (DGP_PACK_MERGED=0: one launch per layer and job, as before)
+    static const bool merged_env = !(getenv("DGP_PACK_MERGED") && atoi(getenv("DGP_PACK_MERGED")) == 0);
+    const bool merged = merged_env && !g_train_cells;
     for (size_t li = 0; li < net->layers.size(); ++li) {
         ConvLayer& l = net->layers[li];
         TLayer& t = tr->tl[li];
@@ -1004,6 +1072,7 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
         if (!l.d_bias) TRY_HIP(hipMalloc(&l.d_bias, l.Cout * sizeof(float)));
         const float* w = tr->params + t.w_off;
         const long long tot = (long long)l.nk * 8 * l.CoutP;
+        if (!head && merged) continue;        // packed by pack_all_kernel below
         if (head) {
             const int njt = l.Cout / 4;
             hipLaunchKernelGGL(pack_head_fwd_kernel, dim3(grid_for(tot)), dim3(256), 0, s, w, njt, l.Cin, l.CoutP, l.nk * 8, l.d_w);
@@ -1033,6 +1102,29 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
                 }
             }
         }
+    }
+    if (merged) {
+        if (!tr->d_pack_table) {
+            std::vector<PackDesc> tab;
+            for (size_t li = 0; li < net->layers.size(); ++li) {
+                if ((int)li == net->head_part || (int)li == net->head_locref) continue;
+                const ConvLayer& l = net->layers[li];
+                const TLayer& t = tr->tl[li];
+                PackDesc d{};
+                d.w_off = t.w_off; d.g_off = t.g_off; d.b_off = t.b_off; d.mean_off = t.mean_off; d.var_off = t.var_off;
+                d.taps = l.KH * l.KW; d.cin_real = t.cin_real; d.cin = l.Cin; d.cout = l.Cout; d.coutP = l.CoutP;
+                d.nchunks_f = l.nk * 8; d.cinP = t.cinP; d.nchunks_b = t.nkT * 8;
+                d.d_w = l.d_w; d.rng_f = tr->d_wrng ? tr->d_wrng + li * ABSMAX_SLOTS : nullptr;
+                d.d_wT = t.d_wT; d.rng_b = tr->d_wrng ? tr->d_wrng + (nl_all + li) * ABSMAX_SLOTS : nullptr;
+                d.d_scale = l.d_scale; d.d_bias = l.d_bias;
+                tab.push_back(d);
+            }
+            tr->n_pack = (int)tab.size();
+            TRY_HIP(hipMalloc(&tr->d_pack_table, tab.size() * sizeof(PackDesc)));
+            TRY_HIP(hipMemcpy(tr->d_pack_table, tab.data(), tab.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
+        }
+        hipLaunchKernelGGL(pack_all_kernel, dim3(256, (unsigned)tr->n_pack, 3), dim3(256), 0, s,
+                           reinterpret_cast<const PackDesc*>(tr->d_pack_table), tr->params, tr->stats, eps);
     }
     TRY_HIP(hipGetLastError());
     net->wmax_valid = false;      // panels changed: weight ranges of the fp16-split kernels are stale
