@@ -804,8 +804,8 @@ TPlan make_tplan(const dgp_trainer* tr, int B) {
         const int cdy = tr->tl[li].cpad ? tr->tl[li].cpad : l.Cout;
         wmax = std::max(wmax, (size_t)l.KH * l.KW * l.Cin * cdy);
     }
+    p.colsum = take(2 * 4096);      // directly in front of dwraw: wgrad_launch zeroes both with one memset
     p.dwraw = take(wmax);
-    p.colsum = take(2 * 4096);
     p.tail = take(TAIL_SLAB_FLOATS);
     p.total = o;
     return p;
@@ -904,11 +904,17 @@ hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const floa
     a.ntaps = KH * KW; a.kchunks = KH * KW * (Cin / 4); a.M = N * Ho * Wo;
     a.x_bytes = (unsigned)((size_t)N * H * W * Cin * 4);
     a.dy_bytes = (unsigned)((size_t)a.M * Cdy * 4);
-    hipError_t e = hipMemsetAsync(dwraw, 0, (size_t)a.kchunks * 4 * Cdy * sizeof(float), s);
-    if (e != hipSuccess) return e;
-    if (colsum) {       // [0, Cdy): column sums, [Cdy, 2 Cdy): dot products of finalize (zeroed together)
-        e = hipMemsetAsync(colsum, 0, (size_t)2 * Cdy * sizeof(float), s);
+    hipError_t e;
+    if (colsum && colsum + 2 * 4096 == dwraw) {      // the plan's layout: [colsum | dot][dwraw] -> one fill
+        e = hipMemsetAsync(colsum, 0, ((size_t)2 * 4096 + (size_t)a.kchunks * 4 * Cdy) * sizeof(float), s);
         if (e != hipSuccess) return e;
+    } else {
+        e = hipMemsetAsync(dwraw, 0, (size_t)a.kchunks * 4 * Cdy * sizeof(float), s);
+        if (e != hipSuccess) return e;
+        if (colsum) {       // [0, Cdy): column sums, [Cdy, 2 Cdy): dot products of finalize (zeroed together)
+            e = hipMemsetAsync(colsum, 0, (size_t)2 * Cdy * sizeof(float), s);
+            if (e != hipSuccess) return e;
+        }
     }
     const bool big = (a.kchunks * 4 >= 128 && Cdy >= 128);
     const int BR = big ? 128 : 64;
