@@ -592,6 +592,56 @@ __global__ void bn_param_grads_kernel(const float* __restrict__ dot, const float
     dgamma[co] = r * (dot[co] - mean[co] * db);
 }
 
+// The two kernels above for ALL non-head layers in one launch each (blockIdx.z = layer; offsets are relative to the workspace,
+// which the caller may move between steps): every layer keeps its own dWraw / colsum region, so nothing has to be finalised
+// between two layers' weight-gradient GEMMs.
+struct FinDesc {
+    long long dw_off, cs_off;              // bytes from the workspace base
+    long long w_off, g_off, b_off, mean_off, var_off;
+    int taps, cin, cin_real, cout;
+    const float* d_scale;
+};
+__global__ __launch_bounds__(256) void scale_dw_dot_all_kernel(const FinDesc* __restrict__ table, const char* __restrict__ ws,
+                                                               const float* __restrict__ params, float* __restrict__ grads,
+                                                               int rows_per_block) {
+    __shared__ float part[4][64];
+    const FinDesc d = table[blockIdx.z];
+    const int krows = d.taps * d.cin_real;
+    if ((int)blockIdx.x * 64 >= d.cout || (int)blockIdx.y * rows_per_block >= krows) return;
+    const float* dwraw = reinterpret_cast<const float*>(ws + d.dw_off);
+    float* dot = reinterpret_cast<float*>(const_cast<char*>(ws) + d.cs_off) + d.cout;
+    const float* w = params + d.w_off;
+    float* dW = grads + d.w_off;
+    const int co = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int k0 = blockIdx.y * rows_per_block, k1 = min(krows, k0 + rows_per_block);
+    float acc = 0.f;
+    if (co < d.cout) {
+        const float sc = d.d_scale[co];
+        for (int k = k0 + rl; k < k1; k += 4) {
+            const int tp = k / d.cin_real, ci = k - tp * d.cin_real;
+            const float g = dwraw[((long long)tp * d.cin + ci) * d.cout + co];
+            const long long o = (long long)k * d.cout + co;
+            acc += w[o] * g;
+            dW[o] = sc * g;
+        }
+    }
+    part[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && co < d.cout)
+        atomicAdd(dot + co, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+__global__ void bn_param_grads_all_kernel(const FinDesc* __restrict__ table, const char* __restrict__ ws, const float* __restrict__ stats,
+                                          float eps, float* __restrict__ grads) {
+    const FinDesc d = table[blockIdx.y];
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co >= d.cout) return;
+    const float* colsum = reinterpret_cast<const float*>(ws + d.cs_off);
+    const float r = 1.f / sqrtf(stats[d.var_off + co] + eps);
+    const float db = colsum[co];
+    grads[d.b_off + co] = db;
+    grads[d.g_off + co] = r * (colsum[d.cout + co] - stats[d.mean_off + co] * db);
+}
+
 // head: dw[ka][kb][c][ci] = dW'raw[(khp,kwp)][ci][(a,b),c] (each w element appears once), db[c] = sum_phases colsum
 __global__ void finalize_head_grads(const float* __restrict__ dwraw, const float* __restrict__ colsum, int njt, int cin,
                                     int cpad, float* __restrict__ dw, float* __restrict__ db) {
@@ -743,8 +793,10 @@ struct dgp_trainer {
     float* d_wrng = nullptr;          // weight-panel range slots: [2 * n_layers] (forward panels, data-gradient panels), per sync
     void* d_pack_table = nullptr;     // PackDesc of every non-head layer (pack_all_kernel), built at the first sync
     int n_pack = 0;
+    void* d_fin_table = nullptr;      // FinDesc of every non-head layer (deferred weight-gradient finalisation), per batch size
+    int n_fin = 0, fin_B = -1, fin_h = -1, fin_w = -1;
     ~dgp_trainer() {
-        for (void* q : {(void*)d_rng_pool, (void*)d_wrng, d_pack_table}) if (q) (void)hipFree(q);
+        for (void* q : {(void*)d_rng_pool, (void*)d_wrng, d_pack_table, d_fin_table}) if (q) (void)hipFree(q);
         for (auto& t : tl) { if (t.d_wT) (void)hipFree(t.d_wT); if (t.d_wTh3) (void)hipFree(t.d_wTh3); }
         for (void* p : {(void*)params, (void*)grads, (void*)mom, (void*)stats, (void*)d_sumsq, (void*)d_gnorm})
             if (p) (void)hipFree(p);
@@ -762,6 +814,9 @@ struct TPlan {
     size_t scmap, locref;
     // gradients
     size_t g0, g1, dxa, dr1, dr2, dc1, dph0, dph1, dwraw, colsum, tail;
+    // per-layer weight-gradient scratch (non-head layers): [colsum | dot][dWraw], one contiguous region zeroed once per backward pass
+    std::vector<size_t> cs_l, dw_l;
+    size_t dwall = 0, dwall_bytes = 0;
     size_t total;
 };
 
@@ -807,6 +862,15 @@ TPlan make_tplan(const dgp_trainer* tr, int B) {
     p.colsum = take(2 * 4096);      // directly in front of dwraw: wgrad_launch zeroes both with one memset
     p.dwraw = take(wmax);
     p.tail = take(TAIL_SLAB_FLOATS);
+    p.dwall = o;
+    p.cs_l.assign(net->layers.size(), 0); p.dw_l.assign(net->layers.size(), 0);
+    for (size_t li = 0; li < net->layers.size(); ++li) {
+        if ((int)li == net->head_part || (int)li == net->head_locref) continue;
+        const ConvLayer& l = net->layers[li];
+        p.cs_l[li] = take((size_t)2 * l.Cout);
+        p.dw_l[li] = take((size_t)l.KH * l.KW * l.Cin * l.Cout);
+    }
+    p.dwall_bytes = o - p.dwall;
     p.total = o;
     return p;
 }
@@ -897,15 +961,18 @@ hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, 
 }
 
 hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const float* dy, int Ho, int Wo, int Cdy, int KH,
-                        int KW, int stride, int dil, int pad_t, int pad_l, float* dwraw, float* colsum, hipStream_t s) {
+                        int KW, int stride, int dil, int pad_t, int pad_l, float* dwraw, float* colsum, hipStream_t s,
+                        bool zeroed = false) {
     WgradArgs a{};
     a.x = x; a.dy = dy; a.dw = dwraw; a.colsum = colsum; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.log2cin4 = ilog2(Cin / 4);
     a.Ho = Ho; a.Wo = Wo; a.Cdy = Cdy; a.KW = KW; a.stride = stride; a.dil = dil; a.pad_t = pad_t; a.pad_l = pad_l;
     a.ntaps = KH * KW; a.kchunks = KH * KW * (Cin / 4); a.M = N * Ho * Wo;
     a.x_bytes = (unsigned)((size_t)N * H * W * Cin * 4);
     a.dy_bytes = (unsigned)((size_t)a.M * Cdy * 4);
-    hipError_t e;
-    if (colsum && colsum + 2 * 4096 == dwraw) {      // the plan's layout: [colsum | dot][dwraw] -> one fill
+    hipError_t e = hipSuccess;
+    if (zeroed) {
+        // per-layer scratch, zeroed once for the whole pass (dgp_train_backward)
+    } else if (colsum && colsum + 2 * 4096 == dwraw) {      // the plan's layout: [colsum | dot][dwraw] -> one fill
         e = hipMemsetAsync(colsum, 0, ((size_t)2 * 4096 + (size_t)a.kchunks * 4 * Cdy) * sizeof(float), s);
         if (e != hipSuccess) return e;
     } else {
@@ -1195,11 +1262,23 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
 }
 
 // One conv layer's parameter gradients: dWraw = A^T dY, d beta = colsum(dY), then the BN-affine algebra.
+// Deferred finalisation (default; DGP_WGRAD_DEFER=0: per layer as before): every non-head layer accumulates dWraw / colsum in its
+// own region of the workspace (zeroed once per pass) and two launches at the end of dgp_train_backward turn them into dW, d gamma,
+// d beta for all layers -- ~150 dispatches fewer per step than fill + fill + wgrad + scale + bn per layer.
+static const TPlan* g_defer_plan = nullptr;
+static char* g_defer_ws = nullptr;
+
 static int layer_param_grads(dgp_trainer* tr, size_t li, const float* x, int N, int H, int W, const float* dy, int Ho,
                              int Wo, int stride, int pad_t, int pad_l, float* dwraw, float* colsum, hipStream_t s) {
     dgp_net* net = tr->net;
     const ConvLayer& l = net->layers[li];
     const TLayer& t = tr->tl[li];
+    if (g_defer_plan) {
+        TRY_HIP(wgrad_launch(x, N, H, W, l.Cin, dy, Ho, Wo, l.Cout, l.KH, l.KW, stride, l.rate, pad_t, pad_l,
+                             reinterpret_cast<float*>(g_defer_ws + g_defer_plan->dw_l[li]),
+                             reinterpret_cast<float*>(g_defer_ws + g_defer_plan->cs_l[li]), s, true));
+        return DGP_OK;
+    }
     TRY_HIP(wgrad_launch(x, N, H, W, l.Cin, dy, Ho, Wo, l.Cout, l.KH, l.KW, stride, l.rate, pad_t, pad_l, dwraw, colsum, s));
     float* dot = colsum + l.Cout;
     const int krows = l.KH * l.KW * t.cin_real;
@@ -1226,6 +1305,10 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
     const dgp_net_desc& d = net->desc;
     const int B = nt, nj = d.num_joints;
     const int nu = (int)net->units.size();
+    static const bool defer_env = !(getenv("DGP_WGRAD_DEFER") && atoi(getenv("DGP_WGRAD_DEFER")) == 0);
+    g_defer_plan = defer_env ? &pl : nullptr;
+    g_defer_ws = ws;
+    if (defer_env) TRY_HIP(hipMemsetAsync(ws + pl.dwall, 0, pl.dwall_bytes, s));
     // geometry per unit input
     std::vector<int> hs(nu + 1), wsz(nu + 1);
     hs[0] = net->hp; wsz[0] = net->wp;
@@ -1335,6 +1418,38 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         if (rc) return rc;
     }
     (void)nj;
+    if (g_defer_plan) {
+        g_defer_plan = nullptr;
+        if (!tr->d_fin_table || tr->fin_B != B || tr->fin_h != d.in_h || tr->fin_w != d.in_w) {      // offsets follow the plan
+            std::vector<FinDesc> tab;
+            for (size_t li = 0; li < net->layers.size(); ++li) {
+                if ((int)li == net->head_part || (int)li == net->head_locref) continue;
+                const ConvLayer& l = net->layers[li];
+                const TLayer& t = tr->tl[li];
+                FinDesc f{};
+                f.dw_off = (long long)pl.dw_l[li]; f.cs_off = (long long)pl.cs_l[li];
+                f.w_off = t.w_off; f.g_off = t.g_off; f.b_off = t.b_off; f.mean_off = t.mean_off; f.var_off = t.var_off;
+                f.taps = l.KH * l.KW; f.cin = l.Cin; f.cin_real = t.cin_real; f.cout = l.Cout; f.d_scale = l.d_scale;
+                tab.push_back(f);
+            }
+            if (!tr->d_fin_table) TRY_HIP(hipMalloc(&tr->d_fin_table, tab.size() * sizeof(FinDesc)));
+            TRY_HIP(hipStreamSynchronize(s));        // (a previous pass may still read the old table)
+            TRY_HIP(hipMemcpy(tr->d_fin_table, tab.data(), tab.size() * sizeof(FinDesc), hipMemcpyHostToDevice));
+            tr->n_fin = (int)tab.size(); tr->fin_B = B; tr->fin_h = d.in_h; tr->fin_w = d.in_w;
+        }
+        int max_cout = 0, max_krows = 0;
+        for (size_t li = 0; li < net->layers.size(); ++li) {
+            if ((int)li == net->head_part || (int)li == net->head_locref) continue;
+            max_cout = std::max(max_cout, net->layers[li].Cout);
+            max_krows = std::max(max_krows, net->layers[li].KH * net->layers[li].KW * tr->tl[li].cin_real);
+        }
+        const int rpb = 64;
+        const FinDesc* tab = reinterpret_cast<const FinDesc*>(tr->d_fin_table);
+        hipLaunchKernelGGL(scale_dw_dot_all_kernel, dim3((max_cout + 63) / 64, (max_krows + rpb - 1) / rpb, (unsigned)tr->n_fin), dim3(256),
+                           0, s, tab, (const char*)ws, tr->params, tr->grads, rpb);
+        hipLaunchKernelGGL(bn_param_grads_all_kernel, dim3((max_cout + 127) / 128, (unsigned)tr->n_fin), dim3(128), 0, s, tab,
+                           (const char*)ws, tr->stats, d.bn_eps, tr->grads);
+    }
     TRY_HIP(hipGetLastError());
     return DGP_OK;
 }
