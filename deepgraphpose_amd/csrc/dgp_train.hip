@@ -1060,7 +1060,11 @@ hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const floa
     const bool big = (a.kchunks * 4 >= 128 && Cdy >= 128);
     const int BR = big ? 128 : 64;
     const int kt = (a.kchunks * 4 + BR - 1) / BR, nt = (Cdy + BR - 1) / BR;
-    int split = std::max(1, 1536 / (kt * nt));
+    // workgroups per launch: ONE round of resident workgroups (2 per CU).  Every workgroup adds its whole 128 x 128 tile to dW with
+    // float atomics, so more pixel slices mean more atomic traffic, fewer leave CUs idle: 1536 -> 18.4 ms per step, 1024 -> 17.8,
+    // 640 -> 18.2, 512 -> 16.7, 384 -> 17.2, 256 -> 18.1 (DGP_WGRAD_WGS)
+    static const int wgs_target = getenv("DGP_WGRAD_WGS") ? atoi(getenv("DGP_WGRAD_WGS")) : 512;
+    int split = std::max(1, wgs_target / (kt * nt));
     int mpb = ((a.M + split - 1) / split + 31) / 32 * 32;
     if (mpb < 256) mpb = 256;
     split = (a.M + mpb - 1) / mpb;
