@@ -1064,7 +1064,8 @@ hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const floa
     // float atomics, so more pixel slices mean more atomic traffic, fewer leave CUs idle: 1536 -> 18.4 ms per step, 1024 -> 17.8,
     // 640 -> 18.2, 512 -> 16.7, 384 -> 17.2, 256 -> 18.1 (DGP_WGRAD_WGS)
     static const int wgs_target = getenv("DGP_WGRAD_WGS") ? atoi(getenv("DGP_WGRAD_WGS")) : 512;
-    int split = std::max(1, wgs_target / (kt * nt));
+    static const int wgs_small = getenv("DGP_WGRAD_WGS_SMALL") ? atoi(getenv("DGP_WGRAD_WGS_SMALL")) : 1024;      // 64 x 64 tiles: 1024 (16.7 vs 16.9 ms at 512)
+    int split = std::max(1, (big ? wgs_target : wgs_small) / (kt * nt));
     int mpb = ((a.M + split - 1) / split + 31) / 32 * 32;
     if (mpb < 256) mpb = 256;
     split = (a.M + mpb - 1) / mpb;
