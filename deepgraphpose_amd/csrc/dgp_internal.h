@@ -64,6 +64,8 @@ hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s);
 int        pick_tile(int M, int CoutP, int K, bool have_absmax = false);
 // fp32 panel [nk*8][CoutP][4] -> fp16 cells [nk*4 k-groups][2 planes][CoutP][8 halves] in the LDS order of the fp16-split kernels
 hipError_t launch_pack_h3(const float* panel, int nk, int CoutP, const float* w_absmax, void* out, hipStream_t s);
+struct PackH3Desc { const float* panel; int nkg; int CoutP; const float* rng; void* out; };      // nkg = nk * 4 k-groups
+hipError_t launch_pack_h3_all(const PackH3Desc* table_dev, int n, hipStream_t s);
 hipError_t launch_absmax(const float* x, long long n, float* out_slots, hipStream_t s);   // slots = max(slots, max |x|)
 const char* conv_kernel_name(const ConvArgs& a, int tile_cfg);
 hipError_t launch_reduce_slabs(const float* slabs, long long n, long long stride, int nsplit, float* out, hipStream_t s);

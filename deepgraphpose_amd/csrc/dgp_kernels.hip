@@ -1956,6 +1956,31 @@ hipError_t launch_pack_h3(const float* panel, int nk, int CoutP, const float* w_
     return hipGetLastError();
 }
 
+// pack_h3_kernel for a table of panels in one launch (the trainer re-splits every panel after each optimiser step)
+__global__ __launch_bounds__(256) void pack_h3_all_kernel(const PackH3Desc* __restrict__ table) {
+    const PackH3Desc d = table[blockIdx.y];
+    const long long total = (long long)d.nkg * d.CoutP;
+    if ((long long)blockIdx.x * blockDim.x >= total) return;
+    const float s = pow2_scale_for(d.rng, threadIdx.x & 63);
+    const float4* panel = reinterpret_cast<const float4*>(d.panel);
+    uint4* out = reinterpret_cast<uint4*>(d.out);
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int col = (int)(g % d.CoutP);
+        const long long kg = g / d.CoutP;
+        uint2 h0, l0, h1, l1;
+        split2_f16(panel[(2 * kg) * d.CoutP + col], s, h0, l0);
+        split2_f16(panel[(2 * kg + 1) * d.CoutP + col], s, h1, l1);
+        out[(kg * 2) * d.CoutP + col] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        out[(kg * 2 + 1) * d.CoutP + col] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+}
+
+hipError_t launch_pack_h3_all(const PackH3Desc* table_dev, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_h3_all_kernel, dim3(512, (unsigned)n), dim3(256), 0, s, table_dev);
+    return hipGetLastError();
+}
+
 // max |x| of a tensor into a device scalar (range of an operand of the fp16-split kernels when no producer tracked it)
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n4, long long n, float* __restrict__ out) {
     float m = 0.f;

@@ -866,10 +866,12 @@ struct dgp_trainer {
     float* d_wrng = nullptr;          // weight-panel range slots: [2 * n_layers] (forward panels, data-gradient panels), per sync
     void* d_pack_table = nullptr;     // PackDesc of every non-head layer (pack_all_kernel), built at the first sync
     int n_pack = 0;
+    void* d_h3_table = nullptr;       // PackH3Desc of every panel whose cells are rebuilt per sync (DGP_TRAIN_CELLS)
+    int n_h3 = 0;
     void* d_fin_table = nullptr;      // FinDesc of every non-head layer (deferred weight-gradient finalisation), per batch size
     int n_fin = 0, fin_B = -1, fin_h = -1, fin_w = -1;
     ~dgp_trainer() {
-        for (void* q : {(void*)d_rng_pool, (void*)d_wrng, d_pack_table, d_fin_table}) if (q) (void)hipFree(q);
+        for (void* q : {(void*)d_rng_pool, (void*)d_wrng, d_pack_table, d_fin_table, d_h3_table}) if (q) (void)hipFree(q);
         for (auto& t : tl) { if (t.d_wT) (void)hipFree(t.d_wT); if (t.d_wTh3) (void)hipFree(t.d_wTh3); }
         for (void* p : {(void*)params, (void*)grads, (void*)mom, (void*)stats, (void*)d_sumsq, (void*)d_gnorm})
             if (p) (void)hipFree(p);
@@ -999,9 +1001,10 @@ static void range_pass_begin(dgp_trainer* tr, hipStream_t s, bool backward) {
 // weight panel -> the same panel pre-split into fp16 cells (filled by dgp_trainer_sync_weights): with the cells and both ranges the
 // conv runs on the compute-side-split / LDS-DMA kernels of the inference engine
 static std::unordered_map<const float*, const float*> g_cells;
-// Opt-in (DGP_TRAIN_CELLS=1): at the 11-frame batches of the DGP step the grids are a fraction of a round and the per-step cell
-// packing costs what the leaner kernels save (21.2-21.8 ms with, 20.7-21.0 ms without, same box); it pays at large batches only.
-static const bool g_train_cells = getenv("DGP_TRAIN_CELLS") && atoi(getenv("DGP_TRAIN_CELLS")) != 0;
+// Default on (DGP_TRAIN_CELLS=0: the trainer's convs split their weights in the loaders): the cells of all panels are rebuilt by ONE
+// launch per sync (pack_h3_all_kernel), after which forward and data-gradient convs run the engine's compute-side-split / LDS-DMA /
+// 16x16x32 kernels: 17.0 -> 16.2 ms per step.  (With one pack launch per layer and panel the packing cost what the kernels saved.)
+static const bool g_train_cells = !(getenv("DGP_TRAIN_CELLS") && atoi(getenv("DGP_TRAIN_CELLS")) == 0);
 
 hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, const float* in, int N, int H, int W,
                        int Cin, int pad_t, int pad_l, int Ho, int Wo, int Cout, int stride, int up, const float* scale,
@@ -1211,7 +1214,7 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
     if (tr->d_wrng) TRY_HIP(hipMemsetAsync(tr->d_wrng, 0, 2 * nl_all * ABSMAX_SLOTS * sizeof(float), s));
     // one launch for the panels / folded BN of all non-head layers (DGP_PACK_MERGED=0: one launch per layer and job, as before)
     static const bool merged_env = !(getenv("DGP_PACK_MERGED") && atoi(getenv("DGP_PACK_MERGED")) == 0);
-    const bool merged = merged_env && !g_train_cells;
+    const bool merged = merged_env;
     for (size_t li = 0; li < net->layers.size(); ++li) {
         ConvLayer& l = net->layers[li];
         TLayer& t = tr->tl[li];
@@ -1277,6 +1280,30 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
         }
         hipLaunchKernelGGL(pack_all_kernel, dim3(256, (unsigned)tr->n_pack, 3), dim3(256), 0, s,
                            reinterpret_cast<const PackDesc*>(tr->d_pack_table), tr->params, tr->stats, eps);
+        if (g_train_cells && tr->d_wrng) {        // the panels' fp16 cells, split with the ranges the launch above has just tracked
+            if (!tr->d_h3_table) {
+                std::vector<PackH3Desc> tab;
+                for (size_t li = 0; li < net->layers.size(); ++li) {
+                    if ((int)li == net->head_part || (int)li == net->head_locref) continue;
+                    ConvLayer& l = net->layers[li];
+                    TLayer& t = tr->tl[li];
+                    if (l.Cin >= 32) {
+                        if (!l.d_wh3) TRY_HIP(hipMalloc(&l.d_wh3, (size_t)l.nk * 8 * l.CoutP * 16));
+                        tab.push_back(PackH3Desc{l.d_w, l.nk * 4, l.CoutP, tr->d_wrng + li * ABSMAX_SLOTS, l.d_wh3});
+                        g_cells[l.d_w] = reinterpret_cast<const float*>(l.d_wh3);
+                    }
+                    if (t.d_wT && l.Cout >= 32) {
+                        if (!t.d_wTh3) TRY_HIP(hipMalloc(&t.d_wTh3, (size_t)t.nkT * 8 * t.cinP * 16));
+                        tab.push_back(PackH3Desc{t.d_wT, t.nkT * 4, t.cinP, tr->d_wrng + (nl_all + li) * ABSMAX_SLOTS, t.d_wTh3});
+                        g_cells[t.d_wT] = t.d_wTh3;
+                    }
+                }
+                tr->n_h3 = (int)tab.size();
+                TRY_HIP(hipMalloc(&tr->d_h3_table, tab.size() * sizeof(PackH3Desc)));
+                TRY_HIP(hipMemcpy(tr->d_h3_table, tab.data(), tab.size() * sizeof(PackH3Desc), hipMemcpyHostToDevice));
+            }
+            TRY_HIP(launch_pack_h3_all(reinterpret_cast<const PackH3Desc*>(tr->d_h3_table), tr->n_h3, s));
+        }
     }
     TRY_HIP(hipGetLastError());
     net->wmax_valid = false;      // panels changed: weight ranges of the fp16-split kernels are stale
