@@ -83,6 +83,31 @@ __global__ void pack_head_fwd_kernel(const float* __restrict__ w, int njt, int c
     }
 }
 
+// head weights as the pointwise panel of the engine's run_head_pointwise: row ci, column (tap, phase, joint) -> [2048 / 4][coutP][4];
+// W'[khp][kwp][ci][(a,b),c] = w[a+2-2khp][b+2-2kwp][c][ci] (w is [3,3,njt,Cin]); tracks max |panel| for the fp16 cells
+__global__ void pack_head_pw_kernel(const float* __restrict__ w, int njt, int cin, int coutP, float* __restrict__ packed,
+                                    float* __restrict__ rng) {
+    float mx = 0.f;
+    const long long total = (long long)(cin >> 2) * coutP;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int col = (int)(g % coutP);
+        const int ch = (int)(g / coutP) << 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col < 16 * njt) {
+            const int tap = col / (4 * njt), r = col - tap * 4 * njt, ph = r / njt, c = r - ph * njt;
+            const int khp = tap >> 1, kwp = tap & 1;
+            const int ka = (ph >> 1) + 2 - 2 * khp, kb = (ph & 1) + 2 - 2 * kwp;
+            if (ka <= 2 && kb <= 2) {
+                const float* src = w + (((long long)ka * 3 + kb) * njt + c) * cin + ch;
+                v = make_float4(src[0], src[1], src[2], src[3]);
+            }
+        }
+        *reinterpret_cast<float4*>(packed + g * 4) = v;
+        mx = amax4(mx, v);
+    }
+    pack_track(rng, mx);
+}
+
 __global__ void fold_bn_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                const float* __restrict__ mean, const float* __restrict__ var, float eps, int C,
                                float* __restrict__ scale, float* __restrict__ bias) {
@@ -1231,6 +1256,14 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
         if (head) {
             const int njt = l.Cout / 4;
             hipLaunchKernelGGL(pack_head_fwd_kernel, dim3(grid_for(tot)), dim3(256), 0, s, w, njt, l.Cin, l.CoutP, l.nk * 8, l.d_w);
+            if (g_train_cells && merged && rng_f) {      // pointwise form of the same head for the forward pass (cells built below)
+                l.coutp_pw = coutp_for(16 * njt);
+                const size_t npw = (size_t)nk_for(1, 1, l.Cin) * 8 * l.coutp_pw * 4;
+                if (!l.d_w_pw) TRY_HIP(hipMalloc(&l.d_w_pw, npw * sizeof(float)));
+                if (!l.d_wh3_pw) TRY_HIP(hipMalloc(&l.d_wh3_pw, npw * sizeof(float)));
+                hipLaunchKernelGGL(pack_head_pw_kernel, dim3(grid_for((long long)(l.Cin >> 2) * l.coutp_pw)), dim3(256), 0, s, w, njt,
+                                   l.Cin, l.coutp_pw, l.d_w_pw, rng_f);
+            }
             hipLaunchKernelGGL(head_bias_kernel, dim3(1), dim3(256), 0, s, tr->params + t.b_off, njt, l.d_bias);
             const long long totT = (long long)t.nkT * 8 * t.cinP;
             hipLaunchKernelGGL(pack_head_dgrad_kernel, dim3(grid_for(totT)), dim3(256), 0, s, w, njt, l.Cin, t.cpad, t.cinP,
@@ -1297,6 +1330,11 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
                         tab.push_back(PackH3Desc{t.d_wT, t.nkT * 4, t.cinP, tr->d_wrng + (nl_all + li) * ABSMAX_SLOTS, t.d_wTh3});
                         g_cells[t.d_wT] = t.d_wTh3;
                     }
+                }
+                for (int hd : {net->head_part, net->head_locref}) {         // the heads' pointwise panels (range slot of the layer)
+                    ConvLayer& l = net->layers[hd];
+                    if (l.d_w_pw && l.d_wh3_pw)
+                        tab.push_back(PackH3Desc{l.d_w_pw, nk_for(1, 1, l.Cin) * 4, l.coutp_pw, tr->d_wrng + (size_t)hd * ABSMAX_SLOTS, l.d_wh3_pw});
                 }
                 tr->n_h3 = (int)tab.size();
                 TRY_HIP(hipMalloc(&tr->d_h3_table, tab.size() * sizeof(PackH3Desc)));
@@ -1365,12 +1403,30 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
                             l3.d_scale, l3.d_bias, res, res_s, res_H, res_W, nullptr, true, 0, 0, F(pl.xo[ui]), s));
         xin = F(pl.xo[ui]); h = ho; w = wo;
     }
-    const ConvLayer& hp = net->layers[net->head_part];
-    TRY_HIP(conv_launch(hp, hp.d_w, hp.nk, hp.CoutP, xin, B, h, w, hp.Cin, 1, 1, h, w, hp.Cout, 1, 0, nullptr, hp.d_bias,
-                        nullptr, 0, 0, 0, nullptr, false, 1, d.num_joints, F(pl.scmap), s));
-    const ConvLayer& hl = net->layers[net->head_locref];
-    TRY_HIP(conv_launch(hl, hl.d_w, hl.nk, hl.CoutP, xin, B, h, w, hl.Cin, 1, 1, h, w, hl.Cout, 1, 0, nullptr, hl.d_bias,
-                        nullptr, 0, 0, 0, nullptr, false, 1, 2 * d.num_joints, F(pl.locref), s));
+    // heads: pointwise GEMM on the cell kernels + gather of the four taps (as the inference engine) when the feature map's range
+    // and the pointwise cells exist, else the 2x2-conv form on the fp32 kernel
+    static const bool head_pw = !(getenv("DGP_HEAD_PW") && atoi(getenv("DGP_HEAD_PW")) == 0);
+    auto head_forward = [&](const ConvLayer& hd, int li, int njt, float* out) -> hipError_t {
+        const float* rin = range_of(xin);
+        const float* rw = tr->d_wrng ? tr->d_wrng + (size_t)li * ABSMAX_SLOTS : nullptr;
+        if (!(head_pw && g_rng.on && rin && rw && hd.d_wh3_pw && tr->d_h3_table))
+            return conv_launch(hd, hd.d_w, hd.nk, hd.CoutP, xin, B, h, w, hd.Cin, 1, 1, h, w, hd.Cout, 1, 0, nullptr, hd.d_bias,
+                               nullptr, 0, 0, 0, nullptr, false, 1, njt, out, s);
+        float* T = F(pl.g0);                       // gradient scratch: free during the forward pass
+        ConvArgs a{};
+        a.in = xin; a.wpk = hd.d_w_pw; a.wh3 = hd.d_wh3_pw; a.out = T; a.in_absmax = rin; a.w_absmax = rw;
+        a.slab = g_tail_slab; a.slab_bytes = g_tail_slab ? (unsigned)(TAIL_SLAB_FLOATS * sizeof(float)) : 0u;
+        a.N = B; a.H = h; a.W = w; a.Cin = hd.Cin; a.log2cin4 = ilog2(hd.Cin / 4);
+        a.Ho = h; a.Wo = w; a.Cout = hd.coutp_pw; a.CoutP = hd.coutp_pw;
+        a.KH = 1; a.KW = 1; a.stride = 1; a.dil = 1; a.ntaps = 1; a.nk = nk_for(1, 1, hd.Cin); a.M = B * h * w;
+        a.in_bytes = (unsigned)((size_t)a.M * hd.Cin * 4); a.out_bytes = (unsigned)((size_t)a.M * hd.coutp_pw * 4);
+        a.w_bytes = (unsigned)((size_t)a.nk * 8 * hd.coutp_pw * 16); a.wh3_bytes = a.w_bytes;
+        hipError_t e = launch_conv(a, pick_tile(a.M, a.CoutP, a.nk * BK, true), s);
+        if (e != hipSuccess) return e;
+        return launch_head_gather(T, hd.d_bias, B, h, w, njt, hd.coutp_pw, out, s);
+    };
+    TRY_HIP(head_forward(net->layers[net->head_part], net->head_part, d.num_joints, F(pl.scmap)));
+    TRY_HIP(head_forward(net->layers[net->head_locref], net->head_locref, 2 * d.num_joints, F(pl.locref)));
     if (scmap) *scmap = F(pl.scmap);
     if (locref) *locref = F(pl.locref);
     return DGP_OK;
