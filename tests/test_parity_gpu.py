@@ -448,7 +448,8 @@ def test_cell_kernels_match_fp64_per_layer(eng, extra):
         from deepgraphpose_amd import engine
         rng = np.random.default_rng(11)
         worst = 0.0
-        for (N, H, W, Cin, Cout, k, s, r) in [(1, 8, 16, 32, 128, 1, 1, 1), (2, 9, 13, 256, 128, 1, 1, 1), (1, 15, 20, 128, 256, 3, 1, 1),
+        for (N, H, W, Cin, Cout, k, s, r) in [(1, 8, 16, 32, 128, 1, 1, 1), (1, 7, 11, 64, 128, 1, 1, 1), (1, 5, 9, 96 + 32, 256, 1, 1, 1),
+                                              (2, 9, 13, 256, 128, 1, 1, 1), (1, 15, 20, 128, 256, 3, 1, 1),
                                               (1, 9, 11, 512, 512, 3, 1, 2), (2, 20, 24, 256, 512, 1, 2, 1), (3, 7, 9, 64, 128, 3, 2, 1),
                                               (1, 30, 40, 2048, 512, 1, 1, 1)]:
             x = np.maximum(rng.standard_normal((N, H, W, Cin)), 0).astype(np.float32) * rng.uniform(0.1, 3, (1, 1, 1, Cin)).astype(np.float32)
