@@ -54,6 +54,7 @@ SYMBOLS = {
     "dgp_soft_argmax": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "dgp_hard_argmax": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "dgp_infer": (C.c_int, [_vp, _vp, _i32, _vp, _sz, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "dgp_infer_packed": (C.c_int, [_vp, _vp, _i32, _vp, _sz, _f32, _i32, _vp, _vp, _vp]),
     "dgp_net_profile_begin": (C.c_int, [_vp, _i32]),
     "dgp_net_profile_end": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "dgp_net_profile_launch": (C.c_int, [_vp, _i32, C.c_char_p, _i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -77,6 +78,9 @@ SYMBOLS = {
     "dgp_conv2d": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgp_conv2d_ranged": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgp_tensor_absmax": (C.c_int, [_vp, _sz, _vp, _vp]),
+    "dgp_conv2d_wgrad": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dgp_conv2d_dgrad_scratch_bytes": (_sz, [C.POINTER(DgpConvDesc)]),
+    "dgp_conv2d_dgrad": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
     "dgp_motion_energy": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, _vp, _vp]),
     "dgp_maxpool_3x3s2_same": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "dgp_preprocess_u8": (C.c_int, [_vp, C.c_int64, C.POINTER(_f32), _vp, _vp]),

@@ -77,7 +77,7 @@ hipError_t launch_motion_energy(const uint8_t* frames, long long frame_bytes, in
                                 unsigned long long* sums, hipStream_t s);
 hipError_t launch_soft_argmax(const float* scmap, int B, int H, int W, int C, float gamma,
                               int gauss_len, float* mu, float* conf, int* idx, float* pmap,
-                              hipStream_t s);
+                              hipStream_t s, int record_stride = 0);
 hipError_t launch_hard_argmax(const float* scmap, const float* locref, int B, int H, int W, int C,
                               int* idx, float* prob, float* offs, hipStream_t s);
 

@@ -2230,7 +2230,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restrict__ scmap, int H, int W, int C,
                                                           float gamma, int glen, float* __restrict__ mu,
                                                           float* __restrict__ conf, int* __restrict__ idx,
-                                                          float* __restrict__ pmap) {
+                                                          float* __restrict__ pmap, int rs) {
+    // rs = elements per (frame, joint) record: 0 -> three dense arrays mu [.,2], conf [.], idx [.,2]; 5 -> mu / conf / idx point
+    // into ONE packed [.,5] record (row, col, conf, iy, ix) -- the trajectory layout the RCCL all-gather moves
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sp = reinterpret_cast<float*>(smem);       // H*W
     __shared__ double red[3][4];
@@ -2317,8 +2319,9 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
         const float mh = (float)(th / t0);
         const float mw = (float)(tw / t0);
         const long long o = (long long)b * C + cj;
-        mu[o * 2 + 0] = mh;
-        mu[o * 2 + 1] = mw;
+        const long long om = rs ? o * rs : o * 2, oc = rs ? o * rs : o;
+        mu[om + 0] = mh;
+        mu[om + 1] = mw;
         // likelihood window on raw logits
         int h0 = (int)floorf(mh), h1 = (int)ceilf(mh) + 1;
         int w0 = (int)floorf(mw), w1 = (int)ceilf(mw) + 1;
@@ -2332,17 +2335,18 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
             for (int ww = w0; ww < w1; ++ww) {
                 const float x = src[(long long)(hh * W + ww) * C];
                 const float e = expf(x);
-                const float sg = e / (e + 1.f);
-                if (sg > best) { best = sg; bh = hh; bw = ww; }
+                const float sg = e / (e + 1.f);          // x > 88.7: inf / inf = NaN, exactly like the reference's numpy expression
+                // np.argmax treats NaN as the maximum and returns the FIRST one (eval.py:340-343): a NaN wins once and stays
+                if (sg > best || (sg != sg && best == best)) { best = sg; bh = hh; bw = ww; }
             }
-        conf[o] = best;
-        idx[o * 2 + 0] = bh;
-        idx[o * 2 + 1] = bw;
+        conf[oc] = best;
+        idx[om + 0] = bh;
+        idx[om + 1] = bw;
     }
 }
 
 hipError_t launch_soft_argmax(const float* scmap, int B, int H, int W, int C, float gamma, int gauss_len,
-                              float* mu, float* conf, int* idx, float* pmap, hipStream_t s) {
+                              float* mu, float* conf, int* idx, float* pmap, hipStream_t s, int record_stride) {
     const size_t smem = (size_t)H * W * sizeof(float);
     static size_t attr_set = 0;
     if (smem > 64 * 1024 && smem > attr_set) {
@@ -2352,7 +2356,7 @@ hipError_t launch_soft_argmax(const float* scmap, int B, int H, int W, int C, fl
         attr_set = smem;
     }
     hipLaunchKernelGGL(soft_argmax_kernel, dim3((unsigned)(B * C)), dim3(256), smem, s, scmap, H, W, C, gamma,
-                       gauss_len, mu, conf, idx, pmap);
+                       gauss_len, mu, conf, idx, pmap, record_stride);
     return hipGetLastError();
 }
 

@@ -692,21 +692,36 @@ int dgp_hard_argmax(const float* scmap, const float* locref, int32_t B, int32_t 
     return DGP_OK;
 }
 
-int dgp_infer(dgp_net* net, const uint8_t* frames, int32_t batch, void* workspace, size_t workspace_bytes, float gamma,
-              int32_t gauss_len, float* mu, float* conf, int32_t* idx, float* scmap_out, void* stream) {
+static int infer_impl(dgp_net* net, const uint8_t* frames, int32_t batch, void* workspace, size_t workspace_bytes, float gamma,
+                      int32_t gauss_len, float* mu, float* conf, int32_t* idx, float* scmap_out, int record_stride, void* stream) {
     if (!net) return fail(DGP_ERR_INVALID, "dgp_infer: null net");
+    if (!mu || !conf || !idx) return fail(DGP_ERR_INVALID, "dgp_infer: null output");
+    if (gauss_len < 0 || gauss_len > 7) return fail(DGP_ERR_INVALID, "dgp_infer: gauss_len (0..7)");
     net->prof_in_infer = true;
     int rc = dgp_forward(net, frames, batch, workspace, workspace_bytes, scmap_out, nullptr, nullptr, stream);
     net->prof_in_infer = false;
     if (rc) return rc;
     const float* sm = scmap_out ? scmap_out : (const float*)((char*)workspace + make_plan(net, batch).off_scmap);
-    {
+    if (batch > 0) {
         ProfScope ps(net, (hipStream_t)stream, "soft_argmax", 0.0);
-        rc = dgp_soft_argmax(sm, batch, 2 * net->fh, 2 * net->fw, net->desc.num_joints, gamma, gauss_len, mu, conf,
-                             idx, nullptr, stream);
+        hipError_t e = launch_soft_argmax(sm, batch, 2 * net->fh, 2 * net->fw, net->desc.num_joints, gamma, gauss_len, mu, conf, idx,
+                                          nullptr, (hipStream_t)stream, record_stride);
+        if (e != hipSuccess) rc = fail(DGP_ERR_HIP, std::string("soft_argmax: ") + hipGetErrorString(e));
     }
     if (net->prof_on && net->prof_used < net->prof_slots) ++net->prof_used;
     return rc;
+}
+
+int dgp_infer(dgp_net* net, const uint8_t* frames, int32_t batch, void* workspace, size_t workspace_bytes, float gamma,
+              int32_t gauss_len, float* mu, float* conf, int32_t* idx, float* scmap_out, void* stream) {
+    return infer_impl(net, frames, batch, workspace, workspace_bytes, gamma, gauss_len, mu, conf, idx, scmap_out, 0, stream);
+}
+
+int dgp_infer_packed(dgp_net* net, const uint8_t* frames, int32_t batch, void* workspace, size_t workspace_bytes, float gamma,
+                     int32_t gauss_len, float* traj, float* scmap_out, void* stream) {
+    if (!traj) return fail(DGP_ERR_INVALID, "dgp_infer_packed: null trajectory");
+    return infer_impl(net, frames, batch, workspace, workspace_bytes, gamma, gauss_len, traj, traj + 2,
+                      reinterpret_cast<int32_t*>(traj) + 3, scmap_out, 5, stream);
 }
 
 int dgp_net_profile_begin(dgp_net* net, int32_t max_steps) {
@@ -783,6 +798,8 @@ int dgp_loss_fwd_bwd(const dgp_loss_desc* d, const float* pred, const float* loc
         return fail(DGP_ERR_INVALID, "dgp_loss_fwd_bwd: null argument");
     if (d->nt < 1 || d->H < 1 || d->W < 1 || d->nj < 1 || d->nl < 0 || d->n_visible < 0 || d->n_hidden < 0)
         return fail(DGP_ERR_INVALID, "dgp_loss_fwd_bwd: bad shape");
+    if (d->gauss_len < 1 || d->gauss_len > 7)       // 2 gauss_len + 1 taps in a 16-float LDS array; gauss_len 0 would give 0/0 taps
+        return fail(DGP_ERR_INVALID, "dgp_loss_fwd_bwd: gauss_len must be 1..7");
     if (!(d->gm2 == 0 || d->gm2 == 1 || d->gm2 == 2) || !(d->gm3 == 0 || d->gm3 == 3) || (d->gm3 == 3 && d->gm2 == 0))
         return fail(DGP_ERR_INVALID, "dgp_loss_fwd_bwd: Not implemented (gm2 in {0,1,2}, gm3 in {0,3}, gm3=3 needs gm2>0)");
     if ((size_t)2 * d->H * d->W * sizeof(float) > 150 * 1024) return fail(DGP_ERR_INVALID, "dgp_loss_fwd_bwd: map exceeds LDS");

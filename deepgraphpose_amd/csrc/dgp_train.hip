@@ -1064,7 +1064,7 @@ hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, 
 
 hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const float* dy, int Ho, int Wo, int Cdy, int KH,
                         int KW, int stride, int dil, int pad_t, int pad_l, float* dwraw, float* colsum, hipStream_t s,
-                        bool zeroed = false) {
+                        bool zeroed = false, const float* rx_given = nullptr, const float* rdy_given = nullptr) {
     WgradArgs a{};
     a.x = x; a.dy = dy; a.dw = dwraw; a.colsum = colsum; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.log2cin4 = ilog2(Cin / 4);
     a.Ho = Ho; a.Wo = Wo; a.Cdy = Cdy; a.KW = KW; a.stride = stride; a.dil = dil; a.pad_t = pad_t; a.pad_l = pad_l;
@@ -1100,8 +1100,8 @@ hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const floa
     a.m_per_block = mpb;
     static bool attr[3] = {false, false, false};
     static const bool h3_env = !(getenv("DGP_WGRAD_F16") && atoi(getenv("DGP_WGRAD_F16")) == 0);       // A/B switch
-    const float* rx = range_of(x);
-    const float* rdy = range_of(dy);
+    const float* rx = rx_given ? rx_given : range_of(x);
+    const float* rdy = rdy_given ? rdy_given : range_of(dy);
     if (big && h3_env && rx && rdy && Cin % 4 == 0) {      // both operand ranges known: 16-bit matrix pipe
         if (!attr[2]) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -1628,6 +1628,80 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
                            (const char*)ws, tr->stats, d.bn_eps, tr->grads);
     }
     TRY_HIP(hipGetLastError());
+    return DGP_OK;
+}
+
+/* ---- single-layer backward entry points (layer-level parity tests at the real shapes; the trainer calls the same launchers) ---- */
+
+/* dWraw[(tap, ci)][co] = sum_m x[m + tap][ci] * dy[m][co] (HWIO order, Cin rows per tap), colsum[co] = sum_m dy[m][co].
+ * With both ranges (DGP_ABSMAX_SLOTS floats each) the fp16-split kernel wgrad_h3 runs where the tile is 128 x 128, else wgrad_f32. */
+int dgp_conv2d_wgrad(const dgp_conv_desc* d, const float* x, const float* dy, const float* x_absmax, const float* dy_absmax,
+                     float* dw_raw, float* colsum, void* stream) {
+    if (!d || !x || !dy || !dw_raw) return fail(DGP_ERR_INVALID, "dgp_conv2d_wgrad: null argument");
+    if (d->Cin < 4 || (d->Cin & 3) || ((d->Cin / 4) & (d->Cin / 4 - 1)) || (d->Cout & 3))
+        return fail(DGP_ERR_INVALID, "dgp_conv2d_wgrad: Cin must be 4 * 2^k, Cout a multiple of 4");
+    if ((double)d->N * d->H * d->W * d->Cin * 4 > 4294967000.0 || (double)d->N * d->Ho * d->Wo * d->Cout * 4 > 4294967000.0)
+        return fail(DGP_ERR_INVALID, "dgp_conv2d_wgrad: tensor exceeds 4 GiB");
+    hipError_t e = wgrad_launch(x, d->N, d->H, d->W, d->Cin, dy, d->Ho, d->Wo, d->Cout, d->KH, d->KW, d->stride, d->rate, d->pad_t,
+                                d->pad_l, dw_raw, colsum, (hipStream_t)stream, false, x_absmax, dy_absmax);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_conv2d_wgrad: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
+/* dx = gate( convT(dy; w * scale) + dx_add ): the data gradient of the forward conv `d` (x [N,H,W,Cin] -> y [N,Ho,Wo,Cout]).
+ * w_hwio: device HWIO weights; scale: [Cout] device or NULL; mask: [N,H,W,Cin] (gate: mask > 0) or NULL; dx_add: gradient of the
+ * shortcut branch or NULL, on dx's grid (add_mode 1) or on the 2x coarser grid (add_mode -2: the subsample shortcut).
+ * scratch: >= dgp_conv2d_dgrad_scratch_bytes(d) device bytes (data-gradient panel, its fp16 cells, range slots).
+ * ranged != 0: measure max |dy| and run the fp16-split kernels (what the trainer does); 0: bf16x6 split. */
+size_t dgp_conv2d_dgrad_scratch_bytes(const dgp_conv_desc* d) {
+    if (!d) return 0;
+    const size_t panel = (size_t)nk_for(d->KH, d->KW, d->Cout) * 8 * coutp_for(d->Cin) * 16;
+    return 2 * panel + 4 * ABSMAX_SLOTS * sizeof(float) + (size_t)d->Cout * sizeof(float) + 1024;
+}
+
+int dgp_conv2d_dgrad(const dgp_conv_desc* d, const float* dy, const float* w_hwio, const float* scale, const float* mask,
+                     const float* dx_add, int32_t add_mode, float* dx, void* scratch, int32_t ranged, void* stream) {
+    if (!d || !dy || !w_hwio || !dx || !scratch) return fail(DGP_ERR_INVALID, "dgp_conv2d_dgrad: null argument");
+    if ((d->Cout & 31) || (d->Cin & 3)) return fail(DGP_ERR_INVALID, "dgp_conv2d_dgrad: Cout % 32, Cin % 4");
+    hipStream_t s = (hipStream_t)stream;
+    const int taps = d->KH * d->KW, nkT = nk_for(d->KH, d->KW, d->Cout), cinP = coutp_for(d->Cin);
+    const size_t panel_bytes = (size_t)nkT * 8 * cinP * 16;
+    char* sp = (char*)scratch;
+    float* panel = (float*)sp; sp += panel_bytes;
+    void* cells = sp; sp += panel_bytes;
+    float* rng = (float*)sp; sp += 4 * ABSMAX_SLOTS * sizeof(float);       // [0]: dy, [1]: panel, [2]: dx
+    float* ones = (float*)sp;
+    TRY_HIP(hipMemsetAsync(rng, 0, 4 * ABSMAX_SLOTS * sizeof(float), s));
+    if (!scale) {
+        std::vector<float> h(d->Cout, 1.f);
+        TRY_HIP(hipMemcpyAsync(ones, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        TRY_HIP(hipStreamSynchronize(s));
+        scale = ones;
+    }
+    const long long totT = (long long)nkT * 8 * cinP;
+    hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid_for(totT)), dim3(256), 0, s, w_hwio, scale, taps, d->Cin, d->Cout, cinP, nkT * 8,
+                       panel, rng + ABSMAX_SLOTS);
+    ConvArgs a{};
+    const int keff_h = (d->KH - 1) * d->rate + 1, keff_w = (d->KW - 1) * d->rate + 1;
+    a.in = dy; a.wpk = panel; a.out = dx; a.mask = mask; a.res = dx_add;
+    a.N = d->N; a.H = d->Ho; a.W = d->Wo; a.Cin = d->Cout; a.log2cin4 = ilog2(d->Cout / 4);
+    a.Ho = d->H; a.Wo = d->W; a.Cout = d->Cin; a.CoutP = cinP;
+    a.KH = d->KH; a.KW = d->KW; a.stride = 1; a.dil = d->rate; a.pad_t = keff_h - 1 - d->pad_t; a.pad_l = keff_w - 1 - d->pad_l;
+    a.ntaps = taps; a.nk = nkT; a.M = d->N * d->H * d->W;
+    a.up = d->stride > 1 ? d->stride : 0;
+    a.res_s = dx_add ? add_mode : 0;
+    a.res_H = add_mode == -2 ? (d->H + 1) / 2 : d->H; a.res_W = add_mode == -2 ? (d->W + 1) / 2 : d->W;
+    a.in_bytes = (unsigned)((size_t)d->N * d->Ho * d->Wo * d->Cout * 4);
+    a.out_bytes = (unsigned)((size_t)a.M * d->Cin * 4);
+    a.res_bytes = dx_add ? (unsigned)((size_t)d->N * a.res_H * a.res_W * d->Cin * 4) : 0u;
+    a.w_bytes = (unsigned)panel_bytes;
+    if (ranged) {
+        TRY_HIP(launch_absmax(dy, (long long)d->N * d->Ho * d->Wo * d->Cout, rng, s));
+        TRY_HIP(launch_pack_h3(panel, nkT, cinP, rng + ABSMAX_SLOTS, cells, s));
+        a.in_absmax = rng; a.w_absmax = rng + ABSMAX_SLOTS; a.wh3 = cells; a.wh3_bytes = a.w_bytes;
+        a.out_absmax = rng + 2 * ABSMAX_SLOTS;
+    }
+    TRY_HIP(launch_conv(a, pick_tile(a.M, cinP, nkT * BK, a.in_absmax && a.w_absmax), s));
     return DGP_OK;
 }
 

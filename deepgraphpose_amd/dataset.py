@@ -336,20 +336,7 @@ class Dataset:
     # -- batches -------------------------------------------------------------------------------------
     def load_data(self, idxs_video, pv_idxs):
         """Random-access frames + the labels of the visible ones (DGP/dataset.py:811-821)."""
-        want = set(int(i) for i in idxs_video)
-        got = {}
-        if hasattr(self.video_clip, "frames"):
-            for i in want:
-                got[i] = self.video_clip.frames[i]
-        elif hasattr(self.video_clip, "files"):
-            from PIL import Image
-            for i in want:
-                with Image.open(self.video_clip.files[i]) as im:
-                    got[i] = np.asarray(im.convert("RGB"))
-        else:                                                   # moviepy clip: seek by time like the reference
-            clip = self.video_clip.clip
-            for i in want:
-                got[i] = np.asarray(clip.get_frame(i * 1.0 / clip.fps))
+        got = {i: np.asarray(self.video_clip.frame_at(i)) for i in set(int(i) for i in idxs_video)}
         images = np.stack([got[int(i)] for i in idxs_video]).astype(np.uint8)
         idxs_labels = [int(np.where(self.labels_idxs == i)[0][0]) for i in pv_idxs]
         return images, self.labels[idxs_labels]

@@ -169,6 +169,24 @@ class DGPNet:
         return mu, conf, idx
 
 
+    def infer_packed(self, frames: torch.Tensor, traj: torch.Tensor, gamma: float = 1.0, gauss_len: int = 1,
+                     scmap_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Fused frames -> traj [B,nj,5] fp32 lanes (row, col, likelihood, iy, ix; indices as int32 bit patterns): the record
+        layout of the per-video trajectory (dist.unpack_keypoints splits it).  `traj` is a caller-owned contiguous slice of the
+        trajectory buffer, written in place by the soft-argmax kernel."""
+        _need_cuda(frames, torch.uint8, "frames")
+        _need_cuda(traj, torch.float32, "traj")
+        B = frames.shape[0]
+        if tuple(frames.shape[1:]) != (self.in_h, self.in_w, 3):
+            raise _lib.DgpError("frames must be [B,%d,%d,3], got %s" % (self.in_h, self.in_w, tuple(frames.shape)))
+        if tuple(traj.shape) != (B, self.nj, 5):
+            raise _lib.DgpError("traj must be [%d,%d,5], got %s" % (B, self.nj, tuple(traj.shape)))
+        ws = self.workspace(B)
+        _lib.check(self.lib.dgp_infer_packed(self._h, _ptr(frames), B, _ptr(ws), ws.numel(), float(gamma), int(gauss_len),
+                                             _ptr(traj), _ptr(scmap_out), _stream(self.device)), "dgp_infer_packed")
+        return traj
+
+
 # ---------------------------------------------------------------------------------------
 # stand-alone operators
 # ---------------------------------------------------------------------------------------
@@ -260,6 +278,54 @@ def conv2d(x: torch.Tensor, w_hwio: np.ndarray, stride: int = 1, rate: int = 1, 
                                      _ptr(rng[0]) if ranged else None, _ptr(rng[1]) if ranged else None, _ptr(rng[2]),
                                      _stream(dev)), "dgp_conv2d_ranged")
     return (y, rng[2]) if return_range else y
+
+
+def _conv_desc(x_shape, w_shape, stride, rate, pad_t, pad_l, out_hw):
+    N, H, W, Cin = x_shape
+    kh, kw, _, cout = w_shape
+    Ho, Wo = out_hw
+    return _lib.DgpConvDesc(N, H, W, Cin, cout, kh, kw, stride, rate, pad_t, pad_l, Ho, Wo, 0, 0, 0, 0)
+
+
+def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int = 1, rate: int = 1, pad_t: int = 0, pad_l: int = 0,
+                 ranged: bool = True):
+    """Weight gradient of one conv layer through the trainer's kernels: x [N,H,W,Cin], dy [N,Ho,Wo,Cout] ->
+    (dW [k,k,Cin,Cout] HWIO, colsum [Cout]).  ranged: measure both operand ranges first (fp16-split kernel on 128 x 128 tiles)."""
+    lib = _lib.load()
+    _need_cuda(x, torch.float32, "x")
+    _need_cuda(dy, torch.float32, "dy")
+    dev = x.device
+    N, H, W, Cin = x.shape
+    _, Ho, Wo, Cout = dy.shape
+    d = _conv_desc(x.shape, (ksize, ksize, Cin, Cout), stride, rate, pad_t, pad_l, (Ho, Wo))
+    dw = torch.empty((ksize, ksize, Cin, Cout), dtype=torch.float32, device=dev)
+    cs = torch.empty(2 * Cout, dtype=torch.float32, device=dev)
+    rng = torch.zeros((2, ABSMAX_SLOTS), dtype=torch.float32, device=dev)
+    if ranged:
+        _lib.check(lib.dgp_tensor_absmax(_ptr(x), x.numel(), _ptr(rng[0]), _stream(dev)), "dgp_tensor_absmax")
+        _lib.check(lib.dgp_tensor_absmax(_ptr(dy), dy.numel(), _ptr(rng[1]), _stream(dev)), "dgp_tensor_absmax")
+    _lib.check(lib.dgp_conv2d_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(rng[0]) if ranged else None,
+                                    _ptr(rng[1]) if ranged else None, _ptr(dw), _ptr(cs), _stream(dev)), "dgp_conv2d_wgrad")
+    return dw, cs[:Cout]
+
+
+def conv2d_dgrad(dy: torch.Tensor, w_hwio: torch.Tensor, x_hw: Tuple[int, int], stride: int = 1, rate: int = 1, pad_t: int = 0,
+                 pad_l: int = 0, scale: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+                 dx_add: Optional[torch.Tensor] = None, add_mode: int = 1, ranged: bool = True) -> torch.Tensor:
+    """Data gradient of one conv layer through the trainer's kernels: dy [N,Ho,Wo,Cout], w [k,k,Cin,Cout] (device) -> dx [N,H,W,Cin]."""
+    lib = _lib.load()
+    _need_cuda(dy, torch.float32, "dy")
+    _need_cuda(w_hwio, torch.float32, "w_hwio")
+    dev = dy.device
+    N, Ho, Wo, Cout = dy.shape
+    kh, kw, Cin, _ = w_hwio.shape
+    H, W = x_hw
+    d = _conv_desc((N, H, W, Cin), w_hwio.shape, stride, rate, pad_t, pad_l, (Ho, Wo))
+    dx = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dev)
+    scratch = torch.empty(lib.dgp_conv2d_dgrad_scratch_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
+    _lib.check(lib.dgp_conv2d_dgrad(C.byref(d), _ptr(dy), _ptr(w_hwio), _ptr(scale), _ptr(mask), _ptr(dx_add), add_mode, _ptr(dx),
+                                    _ptr(scratch), int(ranged), _stream(dev)), "dgp_conv2d_dgrad")
+    return dx
 
 
 def maxpool_3x3s2_same(x: torch.Tensor) -> torch.Tensor:

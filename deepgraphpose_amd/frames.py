@@ -22,6 +22,9 @@ class ArraySource:
         for f in self.frames:
             yield f
 
+    def frame_at(self, i: int) -> np.ndarray:
+        return self.frames[int(i)]
+
     def iter_batches(self, n: int) -> Iterator[np.ndarray]:
         """Contiguous runs of up to n frames (views): lets the staging thread fill a pinned batch with one copy."""
         for i in range(0, self.n_frames, n):
@@ -42,13 +45,71 @@ class ImageDirSource:
         with Image.open(self.files[0]) as im:
             self.size = im.size
 
+    def _read(self, f):
+        with self._Image.open(f) as im:
+            return np.asarray(im.convert("RGB"))
+
+    def frame_at(self, i: int) -> np.ndarray:
+        return self._read(self.files[int(i)])
+
     def iter_frames(self):
         for f in self.files:
-            with self._Image.open(f) as im:
-                yield np.asarray(im.convert("RGB"))
+            yield self._read(f)
 
     def close(self):
         pass
+
+
+class LabeledDirSource(ImageDirSource):
+    """Pseudo-video from a DLC `labeled-data/<video>/` folder (img<NNN>.png = frame NNN of the video): n_frames = last
+    labeled frame number + 1 and frame t shows the labeled image with the largest number <= t (the first one before that).
+    Labeled frame NNN is therefore exactly img<NNN>.png, so the project's labels stay aligned.  Plumbing only -- the bundled
+    Reaching demo project ships its 55 labeled PNGs but not its video (BASELINE configs[0])."""
+
+    def __init__(self, path: str, fps: float = 30.0):
+        super().__init__(path, fps)
+        import re
+        nums = []
+        for f in self.files:
+            m = re.match(r"img(\d+)\.", os.path.basename(f))
+            if m:
+                nums.append((int(m.group(1)), f))
+        if not nums:
+            raise FileNotFoundError("no img<NNN> frames in %s" % path)
+        nums.sort()
+        self.numbers = np.array([n for n, _ in nums])
+        self.files = [f for _, f in nums]
+        self.n_frames = int(self.numbers[-1]) + 1
+        # a video has ONE frame size: the most common size of the labeled images (the Reaching project mixes 832 x 747 frames with
+        # 640 x 470 crops); images of another size are resized to it
+        from collections import Counter
+        sizes = []
+        for f in self.files:
+            with self._Image.open(f) as im:
+                sizes.append(im.size)
+        self.size = Counter(sizes).most_common(1)[0][0]
+
+    def _read(self, f):
+        with self._Image.open(f) as im:
+            im = im.convert("RGB")
+            if im.size != self.size:
+                im = im.resize(self.size, self._Image.BILINEAR)
+            return np.asarray(im)
+
+    def _file_for(self, t: int) -> str:
+        k = int(np.searchsorted(self.numbers, t, side="right")) - 1
+        return self.files[max(k, 0)]
+
+    def frame_at(self, i: int) -> np.ndarray:
+        return self._read(self._file_for(int(i)))
+
+    def iter_frames(self):
+        last, img = None, None
+        for t in range(self.n_frames):
+            f = self._file_for(t)
+            if f != last:
+                img, last = self._read(f), f
+            yield img
 
 
 class MoviepySource:
@@ -58,6 +119,9 @@ class MoviepySource:
         self.fps = self.clip.fps
         self.n_frames = int(np.ceil(self.clip.fps * self.clip.duration))     # eval.py:257
         self.size = tuple(self.clip.size)
+
+    def frame_at(self, i: int) -> np.ndarray:
+        return np.asarray(self.clip.get_frame(int(i) * 1.0 / self.clip.fps))      # seek by time like DGP/dataset.py:811-821
 
     def iter_frames(self):
         return self.clip.iter_frames()
@@ -78,6 +142,12 @@ def open_frame_source(video_file):
         z = np.load(p)
         return ArraySource(z[z.files[0]])
     if not os.path.exists(p):
+        # <proj>/videos/<name>.avi missing but <proj>/labeled-data/<name>/ present: the labeled frames as a pseudo-video
+        stem = os.path.basename(p).rsplit(".", 1)[0]
+        cand = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(p))), "labeled-data", stem)
+        if os.path.isdir(cand):
+            print("video %s is missing: using the labeled frames in %s as a pseudo-video" % (p, cand), flush=True)
+            return LabeledDirSource(cand)
         raise FileNotFoundError(p)
     try:
         return MoviepySource(p)

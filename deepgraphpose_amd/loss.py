@@ -58,10 +58,27 @@ def dgp_loss_fwd_bwd(pred: torch.Tensor, locref_pred: torch.Tensor, batch: dict,
     _need_cuda(locref_pred, torch.float32, "locref_pred")
     dev = pred.device
     nt, H, W, nj = pred.shape
-    vm, hm = _dev_i32(batch["visible_marker"], dev), _dev_i32(batch["hidden_marker"], dev)
-    vt = _dev_i32(batch["visible_marker_in_targets"], dev)
-    targets = _dev_f32(np.nan_to_num(np.asarray(batch["targets"], dtype=np.float64), nan=0.0).reshape(-1, 2), dev)
+    if tuple(locref_pred.shape) != (nt, H, W, 2 * nj):
+        raise ValueError("locref_pred %s does not match pred %s" % (tuple(locref_pred.shape), tuple(pred.shape)))
+    # the kernels use these arrays as indices: check them here, on the host, before anything is launched
+    vm_h = np.asarray(batch["visible_marker"], dtype=np.int64).ravel()
+    hm_h = np.asarray(batch["hidden_marker"], dtype=np.int64).ravel()
+    vt_h = np.asarray(batch["visible_marker_in_targets"], dtype=np.int64).ravel()
+    tg_h = np.nan_to_num(np.asarray(batch["targets"], dtype=np.float64), nan=0.0).reshape(-1, 2)
+    for name, a, hi in (("visible_marker", vm_h, nt * nj), ("hidden_marker", hm_h, nt * nj),
+                        ("visible_marker_in_targets", vt_h, tg_h.shape[0])):
+        if a.size and (a.min() < 0 or a.max() >= hi):
+            raise ValueError("%s out of range [0, %d): min %d max %d" % (name, hi, a.min(), a.max()))
+    if vt_h.size != vm_h.size:
+        raise ValueError("visible_marker_in_targets has %d entries for %d visible markers" % (vt_h.size, vm_h.size))
+    if not 1 <= int(hyper.gauss_len) <= 7:
+        raise ValueError("gauss_len must be 1..7")
+    vm, hm, vt = _dev_i32(vm_h, dev), _dev_i32(hm_h, dev), _dev_i32(vt_h, dev)
+    targets = _dev_f32(tg_h, dev)
     lmap, lmask = _dev_f32(batch["locref_map"], dev), _dev_f32(batch["locref_mask"], dev)
+    for name, t in (("locref_map", lmap), ("locref_mask", lmask)):
+        if vm_h.size and tuple(t.shape) != (nt, H, W, 2 * nj):
+            raise ValueError("%s %s does not match the prediction grid %s" % (name, tuple(t.shape), (nt, H, W, 2 * nj)))
     S0 = np.asarray(S0, dtype=np.float32).reshape(-1, nj)
     nl = S0.shape[0]
     S0d, wsd, wmd = _dev_f32(S0, dev), _dev_f32(ws, dev), _dev_f32(ws_max, dev)

@@ -47,14 +47,18 @@ class EvalSession:
         self.likelihood, self.idx = _Fetch("likelihood"), _Fetch("mu_likelihoods")
 
     def net_for(self, h: int, w: int):
+        """The engine at frame size h x w.  ONE net is kept: a new size re-plans the layers (dgp_net_set_input_size) and
+        keeps the uploaded, repacked weights -- the TF placeholder was [1, None, None, 3] and accepted any size too."""
         from .. import engine
-        key = (h, w)
-        if key not in self._nets:
+        net = self._nets.get("net")
+        if net is None:
             net = engine.DGPNet(self.depth, self.nj, h, w, max_batch=self.max_batch, with_locref=self.loc_ref,
                                 device=self.device, mean_pixel=self.mean_pixel)
             net.load_weights(self.weights)
-            self._nets = {key: net}          # keep one resident geometry (activations are GBs)
-        return self._nets[key]
+            self._nets["net"] = net
+        elif (net.in_h, net.in_w) != (h, w):
+            net.set_input_size(h, w)
+        return net
 
     def run(self, fetches, feed_dict):
         import torch
@@ -111,9 +115,22 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
                   new_size=None, crop_size=None, batch_size: int = 32):
     """Estimate pose on an arbitrary video (eval.py:217-372).  Returns {'x','y','likelihoods'} [T,nj] float64,
     or the csv path if labels already exist (:247-249).  `batch_size` is new: frames go through the GPU in
-    batches instead of one sess.run per frame."""
+    batches instead of one sess.run per frame.
+
+    Multi-GPU: under torchrun (one process per GPU; RANK / WORLD_SIZE / LOCAL_RANK in the environment, or an
+    already initialised torch.distributed group) rank r decodes and infers only the contiguous frame block
+    shard_range(T, r, W), ONE RCCL all-gather of the packed keypoints reassembles the [T, nj] trajectory on every rank, and rank 0
+    writes the csv / h5.  Every rank returns the full label dict."""
     from ..config import get_train_config
     from ..frames import open_frame_source
+    from .. import dist as ddist
+    import torch.distributed as tdist
+
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not tdist.is_initialized():
+        ddist.init_from_env()                      # before anything touches the GPU
+    world = tdist.get_world_size() if tdist.is_initialized() else 1
+    rank = tdist.get_rank() if tdist.is_initialized() else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
 
     f = os.path.basename(str(video_file)).rsplit(".", 1)
     save_file = join(output_dir, f[0] + "_labeled%s" % save_str)
@@ -135,6 +152,9 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
         dlc_cfg.net_type = "resnet_101"
         sess, mu_n, _, scmap, _, inputs = setup_dgp_eval_graph(dlc_cfg, dgp_model_file)
     sess.max_batch = int(batch_size)
+    sess.device = local_rank
+    lo, hi = ddist.shard_range(n_frames, rank, world)        # this rank's frames
+    n_local = hi - lo
 
     nj = dlc_cfg.num_joints
     markers = np.zeros((n_frames, nj, 2))
@@ -163,8 +183,16 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
     import threading
     import torch
     dev = torch.device("cuda", sess.device)
-    frames_it = iter(video_clip.iter_frames())
-    first = next(frames_it, None)
+    if world > 1 and hasattr(video_clip, "frame_at"):          # a shard starts in the middle of the video: seek
+        frames_it = (video_clip.frame_at(t) for t in range(lo, hi))
+        first = video_clip.frame_at(lo if n_local > 0 else 0)
+        if n_local > 0:
+            next(frames_it)
+    else:
+        frames_it = iter(video_clip.iter_frames())
+        first = next(frames_it, None)
+        for _ in range(lo):                                    # sources without random access: decode up to the shard
+            first = next(frames_it, None)
     if first is None:
         raise ValueError("no frames in %s" % video_file)
     f0 = prep(first)
@@ -183,8 +211,11 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
         try:
             if whole_batches:       # in-memory stack: one GIL-free copy per batch instead of one python step per frame
                 done = 0
-                for chunk in video_clip.iter_batches(batch_size):
-                    nb = min(len(chunk), n_frames - done)
+                src = video_clip.frames[lo:hi] if world > 1 else None
+                chunks = (src[i:i + batch_size] for i in range(0, n_local, batch_size)) if world > 1 else \
+                    video_clip.iter_batches(batch_size)
+                for chunk in chunks:
+                    nb = min(len(chunk), n_local - done)
                     if nb <= 0:
                         break
                     slot = free_slots.get()
@@ -195,7 +226,7 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
                 return
             slot, fill, count = free_slots.get(), 0, 0
             for fr in itertools.chain([f0], (prep(x) for x in frames_it)):
-                if count >= n_frames:
+                if count >= n_local:
                     break
                 pinned[slot][fill] = torch.from_numpy(np.ascontiguousarray(fr))
                 fill += 1
@@ -213,8 +244,7 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
     th.start()
     copy_stream = torch.cuda.Stream(device=dev)
     compute = torch.cuda.current_stream(dev)
-    mu_all = torch.zeros((n_frames, nj, 2), dtype=torch.float32, device=dev)
-    lik_all = torch.zeros((n_frames, nj), dtype=torch.float32, device=dev)
+    traj = torch.zeros((max(n_local, 1), nj, 5), dtype=torch.float32, device=dev)      # packed (row, col, likelihood, iy, ix)
     consumed = [None] * nslots            # compute-stream event: last dgp_infer that read dbuf[slot]
     start = 0
     while True:
@@ -231,8 +261,7 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
             copied = torch.cuda.Event()
             copied.record(copy_stream)
         compute.wait_event(copied)
-        mu, lik, _ = net.infer(dbuf[slot][:nb], sess.gamma, sess.gauss_len)
-        mu_all[start:start + nb], lik_all[start:start + nb] = mu, lik
+        net.infer_packed(dbuf[slot][:nb], traj[start:start + nb], sess.gamma, sess.gauss_len)   # written in place by the kernel
         consumed[slot] = torch.cuda.Event()
         consumed[slot].record(compute)
         start += nb
@@ -240,8 +269,15 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
         free_slots.put(slot)
     th.join()
     torch.cuda.synchronize(dev)
-    markers[:start] = mu_all[:start].cpu().numpy()
-    likelihoods[:start] = lik_all[:start].cpu().numpy()
+    if world > 1:                                  # ONE all-gather per video: 20 bytes per (frame, joint)
+        full = ddist.gather_trajectory(traj[:n_local], n_frames)
+        mu_t, lik_t, _ = ddist.unpack_keypoints(full)
+        markers[:] = mu_t.cpu().numpy()
+        likelihoods[:] = lik_t.cpu().numpy()
+    else:
+        mu_t, lik_t, _ = ddist.unpack_keypoints(traj[:start])
+        markers[:start] = mu_t.cpu().numpy()
+        likelihoods[:start] = lik_t.cpu().numpy()
     sess.close()
     video_clip.close()
 
@@ -250,7 +286,7 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
     xr *= scale_x
     yr *= scale_y
     labels = {"x": xr, "y": yr, "likelihoods": likelihoods}
-    if save_pose:
+    if save_pose and rank == 0:
         if not Path(save_file).parent.exists():
             os.makedirs(os.path.dirname(save_file))
         export_pose_like_dlc(labels, os.path.basename(str(dgp_model_file)), dlc_cfg.all_joints_names, save_file)
@@ -331,12 +367,33 @@ def _read_collected_data(folder, scorer):
         return pd.read_csv(base + ".csv", header=[0, 1, 2], index_col=0)
 
 
+def soft_argmax_locref_pose(locref, softmax_map, stride, locref_stdev):
+    """eval.py:757-786 for one frame: locref [H,W,2nj] (raw head output), softmax_map [H,W,nj] (normalised map of
+    argmax_2d_from_cm) -> pose [nj,3] = (soft-argmax position in px + sum_map(softmax * locref * stdev))[::-1], likelihood 1.
+    The reference builds `pose_hard_st` as well and keeps `pose_hard_st1`; with a normalised map the two agree."""
+    H, W = locref.shape[:2]
+    nj = softmax_map.shape[-1]
+    lr = np.reshape(np.asarray(locref), (H, W, -1, 2)) * locref_stdev
+    xg, yg = np.meshgrid(np.linspace(0, H - 1, H), np.linspace(0, W - 1, W))
+    alpha = np.array([xg, yg]).swapaxes(1, 2)                     # 2 x H x W: (row, col) grids
+    out = []
+    for j in range(nj):
+        st_j = np.expand_dims(softmax_map[:, :, j], 0)
+        lr_j = np.transpose(lr[:, :, j, :], [2, 0, 1])
+        soft = np.sum(np.sum(st_j * alpha, 1), 1) * stride + 0.5 * stride
+        offset = np.sum(np.sum(st_j * lr_j, 1), 1)
+        out.append(np.hstack((soft + offset)[::-1]))
+    return np.hstack((np.array(out), np.ones((nj, 1))))
+
+
 def evaluate_dgp(proj_cfg_file, dgp_model_file, shuffle=1, loc_ref=None, loc_ref_calc="dlc"):
     """Evaluate a model by RMSE (px) on the human-labeled train/test images (eval.py:656-813).
 
     loc_ref=True + loc_ref_calc='dlc': DLC hard arg-max + location refinement (HIP `hard_argmax` kernel);
-    loc_ref=False: DGP soft-argmax (HIP `soft_argmax` kernel).  loc_ref_calc='dgp' (soft-argmax weighted locref,
-    eval.py:752-786) is not built.  Returns the RMSE DataFrame over all train/test data."""
+    loc_ref=False: DGP soft-argmax (HIP `soft_argmax` kernel).  loc_ref=True + any other loc_ref_calc ('dgp'): soft-argmax
+    position plus the softmax-weighted mean location-refinement offset (eval.py:752-786; the normalised map and the locref
+    field come from the HIP kernels, the two small weighted sums are host numpy as in the reference).  Returns the RMSE
+    DataFrame over all train/test data."""
     import pickle
     import pandas as pd
     from PIL import Image
@@ -352,8 +409,6 @@ def evaluate_dgp(proj_cfg_file, dgp_model_file, shuffle=1, loc_ref=None, loc_ref
     loc_ref = dlc_cfg.location_refinement if loc_ref is None else loc_ref
     if not loc_ref:
         dlc_cfg.location_refinement = False
-    if loc_ref and loc_ref_calc.lower() != "dlc":
-        raise NotImplementedError("loc_ref_calc='dgp' is not built; use 'dlc'")
     try:
         dlc_cfg.net_type = "resnet_50"
         sess, mu_n, softmax_tensor, scmap_t, locref_t, inputs = setup_dgp_eval_graph(dlc_cfg, dgp_model_file, loc_ref=loc_ref)
@@ -375,7 +430,10 @@ def evaluate_dgp(proj_cfg_file, dgp_model_file, shuffle=1, loc_ref=None, loc_ref
     for i, imagename in enumerate(Data.index):
         with Image.open(join(proj_config["project_path"], imagename)) as im:
             image = np.asarray(im.convert("RGB"))
-        if loc_ref:
+        if loc_ref and loc_ref_calc.lower() != "dlc":
+            lr, st = sess.run([locref_t, softmax_tensor], feed_dict={inputs: image[None]})
+            pose = soft_argmax_locref_pose(lr[0], st[0], dlc_cfg.stride, dlc_cfg.locref_stdev)
+        elif loc_ref:
             net = sess.net_for(image.shape[0], image.shape[1])
             fr = torch.from_numpy(np.ascontiguousarray(image[None])).cuda(sess.device)
             scm, loc = net.forward(fr, want_locref=True)

@@ -7,7 +7,8 @@
 
 One iteration = `Trainer.step` (deepgraphpose_amd/train.py) = the reference's sess.run([loss, train_op]).
 Snapshots are `<train dir>/snapshot-step{k}-{it}.npz` and `snapshot-step{k}-final--0.npz` (TF variable names).
-Host-side third-party hooks: imgaug augmentation (`aug`, skipped loudly when imgaug is missing) and the cv2 Farneback
+Host-side hooks: augmentation of the labeled frames (`aug`; deepgraphpose_amd/augment.py: imgaug's pipeline when imgaug is
+installed, the numpy / scipy restatement of the same seven augmenters otherwise) and the cv2 Farneback
 optical flow feeding the temporal clique (`wt > 0`; raises ImportError without OpenCV -- the loss term itself is a HIP kernel).
 """
 from __future__ import annotations
@@ -64,9 +65,12 @@ def _limb_statistics(labels_list, S0, stride, ws, ws_max):
 
 
 def dgp_loss(data_batcher, dgp_cfg):
-    """-> (loss_fn, hyper, S0, ws, ws_max): the loss pre-computation of fitdgp.py:865-892 plus a closure
-    `loss_fn(trainer, frames, batch, labeled_only)` that runs forward + loss + backward on the GPU.  (The
-    reference returns TF tensors and placeholders; the engine needs no graph.)"""
+    """-> (loss, total_loss, total_loss_visible, placeholders), the reference's return contract (fitdgp.py:848, 1130-1144):
+    `loss` maps the loss-term names to evaluable handles, `placeholders` holds the same 12 keys, and
+    `TrainSession(trainer, loss.graph).run([loss, train_op], feed_dict)` is the reference's `sess.run([loss, train_op], feed_dict)`
+    (models/session.py).  The pre-computation of fitdgp.py:865-892 (limb statistics -> ws, ws_max) happens here; the loss terms
+    themselves are HIP kernels (csrc/dgp_loss.hip) launched by the session."""
+    from .session import LossGraph
     hyper = DGPHyper(ws=dgp_cfg.ws, ws_max=dgp_cfg.ws_max, wt=dgp_cfg.wt, wt_max=dgp_cfg.wt_max,
                      wn_visible=dgp_cfg.wn_visible, wn_hidden=dgp_cfg.wn_hidden, gamma=dgp_cfg.gamma,
                      gauss_len=dgp_cfg.gauss_len, lengthscale=dgp_cfg.lengthscale, lr=dgp_cfg.lr, gm2=dgp_cfg.gm2,
@@ -77,12 +81,23 @@ def dgp_loss(data_batcher, dgp_cfg):
     S0 = np.asarray(data_batcher.S0, dtype=np.float64).reshape(-1, data_batcher.nj)
     ws, ws_max = _limb_statistics([d.labels for d in data_batcher.datasets], S0, dgp_cfg.stride, dgp_cfg.ws,
                                   dgp_cfg.ws_max)
+    graph = LossGraph(hyper, S0, ws, ws_max, data_batcher.n_frames_total, data_batcher.n_visible_frames_total,
+                      data_batcher.nj)
+    return graph.loss, graph.total_loss, graph.total_loss_visible, graph.placeholders
 
-    def loss_fn(trainer, frames, batch, labeled_only=False):
-        return trainer.step(frames, batch, hyper, S0, ws, ws_max, data_batcher.n_frames_total,
-                            data_batcher.n_visible_frames_total, labeled_only=labeled_only)
 
-    return loss_fn, hyper, S0, ws, ws_max
+def _feed(placeholders, images, joint_loc, lmap, lmask, addn, wt_mask, vector_field, wt, nx_out, ny_out, learning_rate, lr):
+    """The reference's feed_dict (fitdgp.py:796-815), key for key."""
+    vm, hm, vt = addn
+    nt = images.shape[0]
+    xg, yg = np.meshgrid(np.linspace(0, nx_out - 1, nx_out), np.linspace(0, ny_out - 1, ny_out))
+    alpha = np.array([xg, yg]).swapaxes(1, 2)                     # 2 x nx_out x ny_out
+    return {placeholders["inputs"]: images, placeholders["targets"]: joint_loc, placeholders["locref_map"]: lmap,
+            placeholders["locref_mask"]: lmask, placeholders["visible_marker_pl"]: vm, placeholders["hidden_marker_pl"]: hm,
+            placeholders["visible_marker_in_targets_pl"]: vt,
+            placeholders["wt_batch_mask_pl"]: np.asarray(wt_mask if wt_mask is not None else np.ones(max(nt - 1, 0))),
+            placeholders["vector_field_tf"]: vector_field, placeholders["nt_batch_pl"]: nt,
+            placeholders["wt_batch_pl"]: np.ones(max(nt - 1, 0)) * wt, placeholders["alpha_tf"]: alpha, learning_rate: lr}
 
 
 def _setup(snapshot, dlcpath, shuffle, trainingsetindex, frame_sources):
@@ -110,7 +125,7 @@ def _dp_index(it, n):
     return it
 
 
-def _make_trainer(data_batcher, init_weights, max_frames):
+def _make_trainer(data_batcher, init_weights, max_frames, device=0):
     import torch  # noqa: F401
     from .. import weights_io
     from ..train import Trainer
@@ -119,9 +134,21 @@ def _make_trainer(data_batcher, init_weights, max_frames):
     nj = data_batcher.nj
     if "pose/locref_pred/block4/weights" not in wts:
         raise KeyError("snapshot %s has no pose/locref_pred head (dgp_loss trains both heads)" % init_weights)
-    tr = Trainer(depth, nj, data_batcher.nx_in, data_batcher.ny_in, max_frames=max_frames)
+    tr = Trainer(depth, nj, data_batcher.nx_in, data_batcher.ny_in, max_frames=max_frames, device=device)
     tr.load_weights(wts)
     return tr
+
+
+def _frames_to_device(trainer, images):
+    """Batch images -> uint8 device frames; the net follows the batch's resolution (videos of one project may differ in size:
+    the reference's placeholders are [None, None, None, 3])."""
+    import torch
+    img = np.ascontiguousarray(images)
+    if img.dtype != np.uint8:
+        img = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    if (trainer.net.in_h, trainer.net.in_w) != tuple(img.shape[1:3]):
+        trainer.set_input_size(int(img.shape[1]), int(img.shape[2]))
+    return torch.from_numpy(img).to(trainer.device)
 
 
 def _locref_targets(joint_loc, nt, vis_within, nx_out, ny_out, nj, dgp_cfg):
@@ -137,6 +164,10 @@ def _locref_targets(joint_loc, nt, vis_within, nx_out, ny_out, nj, dgp_cfg):
 def _save(trainer, prefix, step, it, final, debug=""):
     from .. import weights_io
     import os
+    if _is_dp():
+        import torch.distributed as dist
+        if dist.get_rank() != 0:                 # every rank holds the same weights: one writer
+            return
     w = trainer.get_weights()
     base = prefix + "-step" + str(step) + debug
     fmt = os.environ.get("DGP_SNAPSHOT_FORMAT", "npz")          # "tf": V2 bundles a tf.train.Saver can restore
@@ -147,14 +178,35 @@ def _save(trainer, prefix, step, it, final, debug=""):
 
 
 def _augment(dgp_cfg):
+    """The augmentation pipeline of the labeled frames (fitdgp.py:446-447, 735-736: build_aug(apply_prob=0.8)), or None."""
     if not dgp_cfg.aug:
         return None
-    try:
-        import imgaug  # noqa: F401
-    except ImportError:
-        print("imgaug is not installed: data augmentation of labeled frames is skipped (aug=True requested)")
-        return None
-    raise NotImplementedError("imgaug present: wire build_aug/data_aug (DGP/models/fitdgp_util.py:412-451) here")
+    from ..augment import build_aug
+    return build_aug(apply_prob=0.8)
+
+
+def _is_dp():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _dp_setup():
+    """Data-parallel runs (torchrun: RANK / WORLD_SIZE in the environment): join the process group BEFORE any GPU use and
+    return (rank, world, local_rank).  The batch schedule must be identical on every rank, so rank 0's RNG seeds are broadcast."""
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return 0, 1, 0
+    import random
+    import torch
+    import torch.distributed as dist
+    from .. import dist as ddist
+    rank, local, world = ddist.init_from_env()
+    seed = torch.tensor([np.random.randint(0, 2 ** 31 - 1)], dtype=torch.int64)
+    if dist.get_backend() == "nccl":
+        seed = seed.cuda(local)
+    dist.broadcast(seed, 0)
+    np.random.seed(int(seed.item()))
+    random.seed(int(seed.item()))
+    return rank, world, local
 
 
 def _pretrained_checkpoint(net_type: str, dlc_cfg) -> str:
@@ -295,7 +347,7 @@ def fit_dgp_labeledonly(snapshot, dlcpath, shuffle=1, step=1, saveiters=1000, di
                         nc=2048, n_max_frames=2000, aug=True, trainingsetindex=0, frame_sources=None):
     """Run DGP with labeled frames only (fitdgp.py:257-546): batch = one labeled frame, loss =
     total_loss_visible.  `frame_sources` (new, optional) injects already-open frame sources per video."""
-    import torch
+    rank, world, local_rank = _dp_setup()
     data_batcher, init_weights = _setup(snapshot, dlcpath, shuffle, trainingsetindex, frame_sources)
     dgp_cfg = data_batcher.dlc_config
     dgp_cfg.update(ws=0, ws_max=1.2, wt=0, wt_max=0, wn_visible=1, wn_hidden=0, gamma=1, gauss_len=1, lengthscale=1,
@@ -307,30 +359,37 @@ def fit_dgp_labeledonly(snapshot, dlcpath, shuffle=1, step=1, saveiters=1000, di
     data_batcher.create_batches_from_resnet_output(0, ns_jump=None, step=1, ns=ns, nc=nc, n_max_frames=n_max_frames)
     nj = data_batcher.nj
     visible_frame_total = [d.idxs["pv"] for d in data_batcher.datasets]
-    loss_fn, hyper, S0, ws, ws_max = dgp_loss(data_batcher, dgp_cfg)
-    trainer = _make_trainer(data_batcher, init_weights, max_frames=1)
+    from .session import Placeholder, TrainSession
+    loss, total_loss, total_loss_visible, placeholders = dgp_loss(data_batcher, dgp_cfg)
+    pipeline = _augment(dgp_cfg)                 # before the expensive setup: a broken augmentation stack fails here
+    trainer = _make_trainer(data_batcher, init_weights, max_frames=1, device=local_rank)
+    learning_rate = Placeholder("learning_rate")
+    train_op = loss.graph.minimize(total_loss_visible, learning_rate)          # fitdgp.py:412-418
+    sess = TrainSession(trainer, loss.graph)
     nepoch = int(np.min([int(data_batcher.n_visible_frames_total * dgp_cfg.n_times_all_frames), maxiters]))
     table = np.array([(i, vv) for i, v in enumerate(visible_frame_total) for vv in v]).reshape(-1, 2)
     batch_ind_all = np.random.randint(0, table.shape[0], size=nepoch)
-    maxiters = batch_ind_all.shape[0]
+    n_sched = batch_ind_all.shape[0]
+    maxiters = max(1, n_sched // world)          # data-parallel: W windows per optimiser step
     data_batcher.reset()
-    _augment(dgp_cfg)
     print("Begin Training for {} iterations".format(maxiters))
     t_start = time.time()
     it = -1
     for it in range(maxiters):
-        dataset_i, frame_i = table[batch_ind_all[_dp_index(it, maxiters)]]
+        dataset_i, frame_i = table[batch_ind_all[_dp_index(it, n_sched)]]
         d = data_batcher.datasets[dataset_i]
         (vis, hid, _, images, joint_loc, _, _, addn), _ = data_batcher.next_batch(0, dataset_i, np.array([frame_i]),
                                                                                   np.array([], dtype=int))
-        vm, hm, vt = addn
         all_frame = np.sort(list(vis) + list(hid))
         vis_within = [int(np.where(all_frame == i)[0][0]) for i in vis]
+        if pipeline is not None and dgp_cfg.wt == 0 and len(vis_within) > 0:      # fitdgp.py:481-482
+            from ..augment import data_aug
+            images, joint_loc = data_aug(images, vis_within, joint_loc, pipeline, dgp_cfg)
         lmap, lmask = _locref_targets(joint_loc, len(all_frame), vis_within, d.nx_out, d.ny_out, nj, dgp_cfg)
-        batch = dict(targets=joint_loc, locref_map=lmap, locref_mask=lmask, visible_marker=vm, hidden_marker=hm,
-                     visible_marker_in_targets=vt)
+        feed_dict = _feed(placeholders, images, joint_loc, lmap, lmask, addn, None, None, 0, d.nx_out, d.ny_out, learning_rate,
+                          dgp_cfg.lr)
         t0 = time.time()
-        loss_eval = loss_fn(trainer, torch.from_numpy(images).to(trainer.device), batch, labeled_only=True)
+        loss_eval, _ = sess.run([loss, train_op], feed_dict)
         if it % displayiters == 0 and it > 0:
             print("\nIteration {}/{}".format(it, maxiters))
             print("dataset_i: ", dataset_i, " visible_frame_batch_i: ", [frame_i], flush=True)
@@ -347,7 +406,7 @@ def fit_dgp(snapshot, dlcpath, batch_size=10, shuffle=1, step=2, saveiters=1000,
             frame_sources=None):
     """Run DGP (fitdgp.py:549-845): batches of `batch_size` consecutive frames of the selected windows, at least
     one labeled frame per batch, loss = total_loss (visible + hidden CE, locref, spatial clique)."""
-    import torch
+    rank, world, local_rank = _dp_setup()
     data_batcher, init_weights = _setup(snapshot, dlcpath, shuffle, trainingsetindex, frame_sources)
     dgp_cfg = data_batcher.dlc_config
     dgp_cfg.update(ws=1000, ws_max=1.2, wt=wt, wt_max=0, wn_visible=5, wn_hidden=3, gamma=1, gauss_len=1, lengthscale=1,
@@ -364,18 +423,23 @@ def fit_dgp(snapshot, dlcpath, batch_size=10, shuffle=1, step=2, saveiters=1000,
     visible_frame_total = [d.idxs["pv"] for d in data_batcher.datasets]
     hidden_frame_total = [d.idxs["ph"] for d in data_batcher.datasets]
     all_frame_total = [d.idxs["chunk"] for d in data_batcher.datasets]
-    loss_fn, hyper, S0, ws, ws_max = dgp_loss(data_batcher, dgp_cfg)
-    trainer = _make_trainer(data_batcher, init_weights, max_frames=batch_size + 1)
+    from .session import Placeholder, TrainSession
+    loss, total_loss, total_loss_visible, placeholders = dgp_loss(data_batcher, dgp_cfg)
+    pipeline = _augment(dgp_cfg)
+    trainer = _make_trainer(data_batcher, init_weights, max_frames=batch_size + 1, device=local_rank)
+    learning_rate = Placeholder("learning_rate")
+    train_op = loss.graph.minimize(total_loss, learning_rate)                  # fitdgp.py:708-713
+    sess = TrainSession(trainer, loss.graph)
     batch_ind_all = gen_batch(visible_frame_total, hidden_frame_total, all_frame_total, dgp_cfg, maxiters)
     save_iters = max(int(saveiters / dgp_cfg.batch_size), 1)
-    maxiters = len(batch_ind_all)
+    n_sched = len(batch_ind_all)
+    maxiters = max(1, n_sched // world)
     data_batcher.reset()
-    _augment(dgp_cfg)
     print("Begin Training for {} iterations".format(maxiters))
     t_start = time.time()
     it = -1
     for it in range(maxiters):
-        batch_ind = batch_ind_all[_dp_index(it, maxiters)]
+        batch_ind = batch_ind_all[_dp_index(it, n_sched)]
         dataset_i = int(batch_ind[-1])
         d = data_batcher.datasets[dataset_i]
         all_frame_batch = batch_ind[:-1]
@@ -387,17 +451,20 @@ def fit_dgp(snapshot, dlcpath, batch_size=10, shuffle=1, step=2, saveiters=1000,
         hid_b = np.sort(np.array([i for i in all_frame_batch if (i in all_frame_i) and (i not in visible_frame_i)],
                                  dtype=int))
         (vis, hid, _, images, joint_loc, wt_mask, _, addn), _ = data_batcher.next_batch(0, dataset_i, vis_b, hid_b)
-        vm, hm, vt = addn
         all_frame = np.sort(list(vis) + list(hid))
         vis_within = [int(np.where(all_frame == i)[0][0]) for i in vis]
+        if pipeline is not None and dgp_cfg.wt == 0 and len(vis_within) > 0:      # fitdgp.py:778-779
+            from ..augment import data_aug
+            images, joint_loc = data_aug(images, vis_within, joint_loc, pipeline, dgp_cfg)
         lmap, lmask = _locref_targets(joint_loc, len(all_frame), vis_within, d.nx_out, d.ny_out, nj, dgp_cfg)
-        batch = dict(targets=joint_loc, locref_map=lmap, locref_mask=lmask, visible_marker=vm, hidden_marker=hm,
-                     visible_marker_in_targets=vt, wt_batch_mask=wt_mask)
+        vector_field = None
         if dgp_cfg.wt > 0:                                            # temporal clique: flow field from the host hook
             from .fitdgp_util import learn_wt
-            batch["vector_field"] = learn_wt(images)
+            vector_field = learn_wt(images)
+        feed_dict = _feed(placeholders, images, joint_loc, lmap, lmask, addn, wt_mask, vector_field, dgp_cfg.wt, d.nx_out,
+                          d.ny_out, learning_rate, dgp_cfg.lr)
         t0 = time.time()
-        loss_eval = loss_fn(trainer, torch.from_numpy(images).to(trainer.device), batch)
+        loss_eval, _ = sess.run([loss, train_op], feed_dict)
         if it % displayiters == 0 and it > 0:
             print("\nIteration {}/{}".format(it, maxiters))
             print("dataset_i: ", dataset_i, flush=True)

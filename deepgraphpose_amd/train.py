@@ -90,6 +90,8 @@ class Trainer:
 
     def _forward(self, frames: torch.Tensor):
         nt = frames.shape[0]
+        if frames.device.type != "cuda" or not frames.is_contiguous():
+            raise _lib.DgpError("frames must be a contiguous device tensor")
         if tuple(frames.shape[1:]) != (self.net.in_h, self.net.in_w, 3) or frames.dtype != torch.uint8:
             raise _lib.DgpError("frames must be uint8 [nt,%d,%d,3], got %s %s" % (self.net.in_h, self.net.in_w,
                                                                                   tuple(frames.shape), frames.dtype))
@@ -130,15 +132,11 @@ class Trainer:
                          n_visible_frames_total, labeled_only: bool = False):
         """frames uint8 [nt,H,W,3] on device.  Fills the gradient buffer; returns the loss dict."""
         from .loss import dgp_loss_fwd_bwd
+        frames = frames.contiguous()
         nt = frames.shape[0]
-        wsb = self.workspace(nt)
-        sc, lr = C.c_void_p(), C.c_void_p()
         st = _stream(self.device)
-        _lib.check(self.lib.dgp_train_forward(self._t, _ptr(frames), nt, _ptr(wsb), wsb.numel(), C.byref(sc), C.byref(lr),
-                                              st), "dgp_train_forward")
-        nj, oh, ow = self.net.nj, self.net.out_h, self.net.out_w
-        pred = _view(sc.value, (nt, oh, ow, nj), self.device)
-        loc = _view(lr.value, (nt, oh, ow, 2 * nj), self.device)
+        wsb, pred, loc = self._forward(frames)          # checks dtype / shape against the net's current input size
+        nj = self.net.nj
         if labeled_only:          # fit_dgp_labeledonly: total_loss_visible, no hidden / clique terms (fitdgp.py:416)
             batch = dict(batch, hidden_marker=np.empty(0, dtype=np.int32))
             S0 = np.zeros((0, nj))

@@ -1,72 +1,207 @@
 #!/usr/bin/env python3
-"""Counterpart of the reference's demo/run_dgp_demo.py (same flags, same project layout, same step order):
+"""Counterpart of the reference's demo/run_dgp_demo.py (same flags, same project layout, same step order, same config
+rewriting around the run):
 
-  step 0  fit_dlc                    -> snapshot-step0-final--0   (DLC baseline; needs resnet_v1_<d>.ckpt in $DGP_PRETRAINED_DIR, or pass --dlcsnapshot)
+  step 0  fit_dlc                    -> snapshot-step0-final--0   (DLC baseline; needs resnet_v1_<d>.ckpt, or pass --dlcsnapshot)
   step 1  fit_dgp_labeledonly        -> snapshot-step1-final--0
   step 2  fit_dgp (gm2=1, gm3=3)     -> snapshot-step2-final--0
   step 3  plot_dgp / estimate_pose   -> <proj>/videos_pred/<video>_labeled.{csv,h5[,mp4]}
 
-    python demo/run_dgp_demo.py --dlcpath <project> --dlcsnapshot snapshot-step0-final--0 [--test]
+    python demo/run_dgp_demo.py --dlcpath data/Reaching-Mackenzie-2018-08-30 [--dlcsnapshot snapshot-step0-final--0] [--test]
 
-Videos are taken from <proj>/videos_dgp/ (real videos need moviepy; directories of frames and .npy stacks work
-without a decoder).  Snapshots are .npz files keyed by TF variable names.
+`update_config_files` / `return_configs` (reference demo/run_dgp_demo.py:30-99) make the bundled project's relative paths absolute
+for the run and restore them afterwards; they apply to the Reaching demo project (a path that ends in
+data/Reaching-Mackenzie-2018-08-30, relative to the working directory like in the reference).  Videos are taken from
+<proj>/videos_dgp/ or the project's video_sets; real videos need moviepy, directories of frames and .npy stacks work without a
+decoder, and a missing video whose labeled frames exist under labeled-data/<name>/ runs on those frames as a pseudo-video.
+Snapshots are .npz files keyed by TF variable names (or TF bundles, DGP_SNAPSHOT_FORMAT=tf).
 """
 import argparse
 import os
 import sys
+from os import listdir
+from os.path import isfile, join
 from pathlib import Path
+
+import yaml
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
-from deepgraphpose_amd.models.eval import plot_dgp                                   # noqa: E402
-from deepgraphpose_amd.models.fitdgp import fit_dgp, fit_dgp_labeledonly, fit_dlc    # noqa: E402
-from deepgraphpose_amd.models.fitdgp_util import get_snapshot_path                   # noqa: E402
+DEMO_PROJECT = join("data", "Reaching-Mackenzie-2018-08-30")
+DEMO_MODEL_FOLDER = join("dlc-models", "iteration-0", "ReachingAug30-trainset95shuffle1")
+DEMO_VIDEO = join("videos", "reachingvideo1.avi")
+
+
+def get_model_cfg_path(base_path, dlcpath, dtype):
+    return join(base_path, dlcpath, DEMO_MODEL_FOLDER, dtype, "pose_cfg.yaml")
+
+
+def get_init_weights_path(base_path):
+    """ImageNet ResNet-50 checkpoint.  The reference looks inside its vendored DeepLabCut tree
+    (src/DeepLabCut/deeplabcut/pose_estimation_tensorflow/models/pretrained/resnet_v1_50.ckpt); here: $DGP_PRETRAINED_DIR, then
+    <repo>/deepgraphpose_amd/pretrained/."""
+    if os.environ.get("DGP_PRETRAINED_DIR"):
+        return join(os.environ["DGP_PRETRAINED_DIR"], "resnet_v1_50.ckpt")
+    return join(str(Path(__file__).resolve().parent.parent), "deepgraphpose_amd", "pretrained", "resnet_v1_50.ckpt")
+
+
+def _checkpoint_exists(path):
+    return any(os.path.exists(path + ext) for ext in ("", ".npz", ".index", ".safetensors"))
+
+
+def update_config_files(dlcpath, need_init_weights=True):
+    """Reference demo/run_dgp_demo.py:30-69: absolute project_path / video path / init_weights for the run."""
+    base_path = os.getcwd()
+    proj_cfg_path = join(base_path, dlcpath, "config.yaml")
+    with open(proj_cfg_path, "r") as f:
+        yaml_cfg = yaml.load(f, Loader=yaml.SafeLoader)
+        yaml_cfg["project_path"] = join(base_path, dlcpath)
+        video_loc = join(base_path, dlcpath, DEMO_VIDEO)
+        try:
+            yaml_cfg["video_sets"][video_loc] = yaml_cfg["video_sets"].pop(DEMO_VIDEO)
+        except KeyError:
+            yaml_cfg["video_sets"][video_loc] = yaml_cfg["video_sets"].pop(video_loc)
+    with open(proj_cfg_path, "w") as f:
+        yaml.dump(yaml_cfg, f)
+
+    model_cfg_path = get_model_cfg_path(base_path, dlcpath, "train")
+    with open(model_cfg_path, "r") as f:
+        yaml_cfg = yaml.load(f, Loader=yaml.SafeLoader)
+        yaml_cfg["init_weights"] = get_init_weights_path(base_path)
+        yaml_cfg["project_path"] = join(base_path, dlcpath)
+    with open(model_cfg_path, "w") as f:
+        yaml.dump(yaml_cfg, f)
+
+    # the reference stops here when the ImageNet weights are missing; they are only read by step 0, so a run that starts from
+    # --dlcsnapshot goes on
+    if need_init_weights and not _checkpoint_exists(yaml_cfg["init_weights"]):
+        raise FileNotFoundError("Must download resnet-50 weights; see README for instructions")
+
+    model_cfg_path = get_model_cfg_path(base_path, dlcpath, "test")
+    if os.path.exists(model_cfg_path):
+        with open(model_cfg_path, "r") as f:
+            yaml_cfg = yaml.load(f, Loader=yaml.SafeLoader)
+            yaml_cfg["init_weights"] = get_init_weights_path(base_path)
+        with open(model_cfg_path, "w") as f:
+            yaml.dump(yaml_cfg, f)
+    return join(base_path, dlcpath)
+
+
+def return_configs(dlcpath=DEMO_PROJECT):
+    """Reference demo/run_dgp_demo.py:72-99: put the relative paths back."""
+    base_path = os.getcwd()
+    proj_cfg_path = join(base_path, dlcpath, "config.yaml")
+    with open(proj_cfg_path, "r") as f:
+        yaml_cfg = yaml.load(f, Loader=yaml.SafeLoader)
+        yaml_cfg["project_path"] = dlcpath
+        video_loc = join(base_path, dlcpath, DEMO_VIDEO)
+        yaml_cfg["video_sets"][DEMO_VIDEO] = yaml_cfg["video_sets"].pop(video_loc)
+    with open(proj_cfg_path, "w") as f:
+        yaml.dump(yaml_cfg, f)
+    for dtype in ("train", "test"):
+        model_cfg_path = get_model_cfg_path(base_path, dlcpath, dtype)
+        if not os.path.exists(model_cfg_path):
+            continue
+        with open(model_cfg_path, "r") as f:
+            yaml_cfg = yaml.load(f, Loader=yaml.SafeLoader)
+            yaml_cfg["init_weights"] = "resnet_v1_50.ckpt"
+            if dtype == "train":
+                yaml_cfg["project_path"] = dlcpath
+        with open(model_cfg_path, "w") as f:
+            yaml.dump(yaml_cfg, f)
+
+
+def _banner(text):
+    pad = " " * 4
+    line = "=" * (len(text) + 10)
+    print("\n%s%s\n%s|    %s    |\n%s%s\n" % (pad, line, pad, text, pad, line), flush=True)
+
+
+def main(argv=None):
+    from deepgraphpose_amd import config as dcfg
+    from deepgraphpose_amd.models.eval import plot_dgp
+    from deepgraphpose_amd.models.fitdgp import fit_dgp, fit_dgp_labeledonly, fit_dlc
+    from deepgraphpose_amd.models.fitdgp_util import get_snapshot_path
+
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--dlcpath", type=str, default=None, help="the absolute path of the DLC project")
+    parser.add_argument("--dlcsnapshot", type=str, default=None, help="use the DLC snapshot to initialize DGP")
+    parser.add_argument("--shuffle", type=int, default=1, help="Project shuffle")
+    parser.add_argument("--batch_size", type=int, default=10,
+                        help="size of the batch, if there are memory issues, decrease it value")
+    parser.add_argument("--test", action="store_true", default=False)
+    input_params = parser.parse_known_args(argv)[0]
+    print(input_params)
+    dlcpath, shuffle, dlcsnapshot = input_params.dlcpath, input_params.shuffle, input_params.dlcsnapshot
+    batch_size, test = input_params.batch_size, input_params.test
+    if dlcpath is None:
+        raise SystemExit("--dlcpath is required")
+
+    update_configs = False
+    demo_rel = None
+    if os.path.normpath(dlcpath) == os.path.normpath(DEMO_PROJECT):
+        demo_rel = dlcpath
+        dlcpath = update_config_files(dlcpath, need_init_weights=dlcsnapshot is None)
+        update_configs = True
+
+    try:
+        # step 0: DLC
+        if dlcsnapshot is None:
+            _banner("Running DLC")
+            snapshot = "resnet_v1_50.ckpt"
+            if test:
+                fit_dlc(snapshot, dlcpath, shuffle=shuffle, step=0, maxiters=2, displayiters=1)
+            else:
+                fit_dlc(snapshot, dlcpath, shuffle=shuffle, step=0)
+            snapshot = "snapshot-step0-final--0"
+        else:
+            snapshot = dlcsnapshot
+
+        # step 1: DGP with labeled frames only
+        _banner("Running DGP with labeled frames only")
+        if test:
+            fit_dgp_labeledonly(snapshot, dlcpath, shuffle=shuffle, step=1, maxiters=2, displayiters=1)
+        else:
+            fit_dgp_labeledonly(snapshot, dlcpath, shuffle=shuffle, step=1)
+        snapshot = "snapshot-step1-final--0"
+
+        # step 2: DGP
+        _banner("Running DGP")
+        step, gm2, gm3 = 2, 1, 3
+        if test:
+            fit_dgp(snapshot, dlcpath, batch_size=batch_size, shuffle=shuffle, step=step, maxiters=5, displayiters=1, gm2=gm2,
+                    gm3=gm3)
+        else:
+            fit_dgp(snapshot, dlcpath, batch_size=batch_size, shuffle=shuffle, step=step, gm2=gm2, gm3=gm3)
+        snapshot = "snapshot-step{}-final--0".format(step)
+
+        # step 3: predict on all videos in videos_dgp
+        _banner("Predict with DGP")
+        snapshot_path, cfg_yaml = get_snapshot_path(snapshot, dlcpath, shuffle=shuffle)
+        cfg = dcfg.read_config(cfg_yaml)
+        video_path = str(Path(dlcpath) / "videos_dgp")
+        if not os.path.exists(video_path):
+            print(video_path + " does not exist!")
+            video_sets = [v if os.path.isabs(v) else join(dlcpath, v) for v in cfg["video_sets"]]
+        else:
+            video_sets = [join(video_path, f) for f in sorted(listdir(video_path))
+                          if (isfile(join(video_path, f)) and (f.find("avi") > 0 or f.find("mp4") > 0 or f.find("mov") > 0 or
+                                                               f.find("mkv") > 0 or f.endswith(".npy")))
+                          or os.path.isdir(join(video_path, f))]
+        video_pred_path = str(Path(dlcpath) / "videos_pred")
+        if not os.path.exists(video_pred_path):
+            os.makedirs(video_pred_path)
+        print("video_sets", video_sets, flush=True)
+        # (--test: the reference first cuts the clip to its first 10 s with moviepy; clip editing is video-codec work outside
+        #  this package, so the first video is processed as it is)
+        for video_file in ([video_sets[0]] if test else video_sets):
+            out = plot_dgp(video_file=str(video_file), output_dir=video_pred_path, proj_cfg_file=str(cfg_yaml),
+                           dgp_model_file=str(snapshot_path), shuffle=shuffle)
+            print("wrote", out, flush=True)
+    finally:
+        if update_configs:
+            return_configs(demo_rel)
+
 
 if __name__ == "__main__":
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--dlcpath", type=str, default=None, help="the path for the DLC project")
-    parser.add_argument("--dlcsnapshot", type=str, default=None, help="use snapshot for dlc (skips step 0)")
-    parser.add_argument("--shuffle", type=int, default=1, help="Project shuffle")
-    parser.add_argument("--batch_size", type=int, default=10, help="size of the batch")
-    parser.add_argument("--test", action="store_true", default=False)
-    args = parser.parse_args()
-    dlcpath, shuffle, batch_size, test = args.dlcpath, args.shuffle, args.batch_size, args.test
-    if dlcpath is None:
-        raise SystemExit("--dlcpath is required (the bundled Reaching demo project ships no videos or checkpoints)")
-
-    # step 0
-    if args.dlcsnapshot is None:
-        snapshot = "resnet_v1_50.ckpt"
-        print("\n\n" + "=" * 80 + "\n|   step 0: fit_dlc\n" + "=" * 80)
-        fit_dlc(snapshot=snapshot, dlcpath=dlcpath, shuffle=shuffle, step=0, saveiters=1000, displayiters=100,
-                maxiters=2 if test else 200000)
-        snapshot = "snapshot-step0-final--0"
-    else:
-        snapshot = args.dlcsnapshot
-
-    # step 1
-    print("\n\n" + "=" * 80 + "\n|   step 1: DGP with labeled frames only\n" + "=" * 80)
-    fit_dgp_labeledonly(snapshot=snapshot, dlcpath=dlcpath, shuffle=shuffle, step=1, saveiters=1000, displayiters=1 if test else 100,
-                        maxiters=2 if test else 50000)
-    snapshot = "snapshot-step1-final--0"
-
-    # step 2
-    print("\n\n" + "=" * 80 + "\n|   step 2: DGP\n" + "=" * 80)
-    fit_dgp(snapshot=snapshot, dlcpath=dlcpath, batch_size=batch_size, shuffle=shuffle, step=2, saveiters=1000,
-            displayiters=1 if test else 100, maxiters=5 if test else 200000, gm2=1, gm3=3)
-    snapshot = "snapshot-step2-final--0"
-
-    # step 3
-    print("\n\n" + "=" * 80 + "\n|   step 3: predict\n" + "=" * 80)
-    snapshot_path, cfg_yaml = get_snapshot_path(snapshot, dlcpath, shuffle=shuffle)
-    video_path = os.path.join(dlcpath, "videos_dgp")
-    if not os.path.exists(video_path):
-        video_path = os.path.join(dlcpath, "videos")
-    videos = [os.path.join(video_path, f) for f in sorted(os.listdir(video_path))
-              if os.path.isdir(os.path.join(video_path, f)) or f.rsplit(".", 1)[-1] in ("avi", "mp4", "mov", "mkv", "npy")]
-    out_dir = os.path.join(dlcpath, "videos_pred")
-    for video in videos[:1] if test else videos:
-        print("video file:", video)
-        out = plot_dgp(video_file=str(video), output_dir=out_dir, proj_cfg_file=str(cfg_yaml), dgp_model_file=str(snapshot_path),
-                       shuffle=shuffle)
-        print("wrote", out)
+    main()

@@ -107,6 +107,14 @@ int  dgp_infer(dgp_net* net, const uint8_t* frames, int32_t batch, void* workspa
                size_t workspace_bytes, float gamma, int32_t gauss_len, float* mu, float* conf,
                int32_t* idx, float* scmap_out, void* stream);
 
+/* Same, written as ONE packed record per (frame, joint): traj [batch, nj, 5] fp32 lanes = (row, col, likelihood, iy, ix) with
+ * the two window indices as int32 bit patterns in lanes 3..4.  This is the layout of the per-video trajectory that the
+ * frame-sharded ranks exchange with a single RCCL all-gather; writing it here keeps torch's cat / copy
+ * kernels out of the per-batch loop. */
+int  dgp_infer_packed(dgp_net* net, const uint8_t* frames, int32_t batch, void* workspace,
+                      size_t workspace_bytes, float gamma, int32_t gauss_len, float* traj,
+                      float* scmap_out, void* stream);
+
 /* ---- measurement: hipEvent pairs around every launch of dgp_forward / dgp_infer, recorded on
  * the caller's stream (no syncs until dgp_net_profile_launch reads them).  Used by bench.py for
  * the roofline object; the reference's only timing is time.time() around sess.run
@@ -222,6 +230,20 @@ int  dgp_conv2d(const dgp_conv_desc* d, const float* x, const float* packed_w,
 int  dgp_conv2d_ranged(const dgp_conv_desc* d, const float* x, const float* packed_w, const float* scale, const float* bias,
                        const float* residual, float* y, const float* x_absmax, const float* w_absmax, float* y_absmax,
                        void* stream);
+/* ---- single-layer BACKWARD entry points: the launchers dgp_train_backward uses, exposed so that the weight-gradient and
+ * data-gradient kernels can be checked layer by layer at the real shapes (no reference counterpart: TF differentiates the graph,
+ * DGP/models/fitdgp.py:708-713).  `d` always describes the FORWARD conv x [N,H,W,Cin] -> y [N,Ho,Wo,Cout].
+ *   dgp_conv2d_wgrad : dw_raw[(kh, kw, ci)][co] = sum over output pixels of x[...] * dy[...] (HWIO order, overwritten) and
+ *                      colsum[co] = sum dy[.., co] (2 * Cout floats, second half scratch; may be NULL).  With both operand ranges
+ *                      (DGP_ABSMAX_SLOTS floats each) and a tile of 128 x 128 the fp16-split kernel runs, else fp32 MFMA.
+ *   dgp_conv2d_dgrad : dx = gate(convT(dy; w * scale) + dx_add); w_hwio device HWIO weights; scale [Cout] or NULL; mask [N,H,W,Cin]
+ *                      or NULL (gate: mask > 0); dx_add NULL, or a gradient on dx's grid (add_mode 1) or on the 2x coarser grid
+ *                      (add_mode -2, the subsample shortcut).  scratch: dgp_conv2d_dgrad_scratch_bytes(d) device bytes. */
+int    dgp_conv2d_wgrad(const dgp_conv_desc* d, const float* x, const float* dy, const float* x_absmax, const float* dy_absmax,
+                        float* dw_raw, float* colsum, void* stream);
+size_t dgp_conv2d_dgrad_scratch_bytes(const dgp_conv_desc* d);
+int    dgp_conv2d_dgrad(const dgp_conv_desc* d, const float* dy, const float* w_hwio, const float* scale, const float* mask,
+                        const float* dx_add, int32_t add_mode, float* dx, void* scratch, int32_t ranged, void* stream);
 /* slots = max(slots, max |x[0..n)|) on the device (zero the DGP_ABSMAX_SLOTS floats before the first call). */
 int  dgp_tensor_absmax(const float* x, size_t n, float* absmax_dev, void* stream);
 int  dgp_maxpool_3x3s2_same(const float* x, int32_t N, int32_t H, int32_t W, int32_t C,

@@ -112,7 +112,7 @@ def resnet_features(frames_u8: np.ndarray, wts: Dict[str, np.ndarray], depth: in
                     return_endpoints: bool = False):
     """PoseNet.extract_features (PET/nnet/pose_net.py:36-54): (x - mean_pixel) ->
     slim resnet_v1_{depth}(global_pool=False, output_stride=16, is_training=False)."""
-    from deepgraphpose_amd.arch import resnet_units   # architecture table only (no compute)
+    from oracle.resnet_plan import units as resnet_units   # the oracle's OWN restatement of slim's plan
     name = "resnet_v1_%d" % depth
     x = frames_u8.astype(np.float32) - np.asarray(MEAN_PIXEL, dtype=np.float32)[None, None, None, :]
     x = _to_nchw(x).contiguous(memory_format=torch.channels_last)

@@ -63,7 +63,7 @@ def _deconv(x, w, b, stride=2):
 
 def network(frames_u8: np.ndarray, P: Dict[str, torch.Tensor], depth: int = 50, dtype=torch.float32):
     """-> (pred [nt,H,W,nj], locref [nt,H,W,2nj]) as NHWC torch tensors attached to the graph of P."""
-    from deepgraphpose_amd.arch import resnet_units
+    from oracle.resnet_plan import units as resnet_units   # the oracle's OWN restatement of slim's plan
     name = "resnet_v1_%d" % depth
     x = torch.from_numpy(frames_u8.astype(np.float32) - np.asarray(O.MEAN_PIXEL, np.float32)).to(dtype)
     x = x.permute(0, 3, 1, 2)

@@ -1,0 +1,231 @@
+"""GPU tests of the round-2 boundary pieces: pose_net drop-in, packed trajectory output, the demo script end to end, RCCL on
+hardware (a fresh child process with RANK=0 WORLD_SIZE=1), frame-sharded estimate_pose, evaluate_dgp(loc_ref_calc='dgp')."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PX_TOL = 1e-3
+
+
+def _child_env(**extra):
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update({k: str(v) for k, v in extra.items()})
+    return env
+
+
+def test_pose_net_drop_in_matches_engine_and_oracle(lib_built):
+    """PoseNet(cfg).extract_features / prediction_layers / test and prediction_layer / dgp_prediction_layer
+    (PET/nnet/pose_net.py:18-90, fitdgp_util.py:18-74) vs the fused engine and the CPU oracle."""
+    from deepgraphpose_amd.config import AttrDict
+    from deepgraphpose_amd.engine import DGPNet
+    from deepgraphpose_amd.nnet.pose_net import PoseNet, dgp_prediction_layer, prediction_layer
+    from deepgraphpose_amd.synthetic import make_frames, make_weights
+    from oracle import dgp_oracle as O
+    nj = 3
+    wts = make_weights(50, nj, True, seed=12, head_std=0.05)
+    frames = make_frames(3, 96, 128, nj, seed=12)
+    cfg = AttrDict(net_type="resnet_50", num_joints=nj, location_refinement=True, intermediate_supervision=False,
+                   mean_pixel=[123.68, 116.779, 103.939], weight_decay=0.0001)
+    pn = PoseNet(cfg)
+    assert cfg.output_stride == 16 and cfg.deconvolutionstride == 2          # pose_net.py:30-34 defaults
+    with pytest.raises(ValueError):
+        pn.extract_features(frames)                                           # no variables bound yet
+    pn.restore(wts)
+    net, end_points = pn.extract_features(frames.astype(np.float32))          # the reference feeds float frames
+    ref = O.infer(frames, wts, 50)
+    assert tuple(net.shape) == (3, 6, 8, 2048) and "resnet_v1_50/block4" in end_points
+    assert np.abs(net.cpu().numpy() - ref["features"]).max() <= 2e-5 * np.abs(ref["features"]).max()
+    heads = pn.prediction_layers(net, end_points)
+    sc_ref, loc_ref = O.pose_heads(ref["features"], wts, True)
+    assert np.abs(heads["part_pred"].cpu().numpy() - sc_ref).max() <= 5e-5 * np.abs(sc_ref).max()
+    assert np.abs(heads["locref"].cpu().numpy() - loc_ref).max() <= 5e-5 * np.abs(loc_ref).max()
+    # the fused engine gives the same maps
+    eng = DGPNet(50, nj, 96, 128, max_batch=4, with_locref=True)
+    eng.load_weights(wts)
+    sc, loc = eng.forward(torch.from_numpy(frames).cuda(), want_locref=True)
+    assert torch.allclose(sc, heads["part_pred"], atol=2e-5 * float(sc.abs().max()))
+    assert torch.allclose(loc, heads["locref"], atol=2e-5 * float(loc.abs().max()))
+    # free functions, explicit variables
+    p2 = prediction_layer(cfg, net, "part_pred", nj, wts)
+    assert torch.equal(p2, heads["part_pred"])
+    p3 = dgp_prediction_layer(wts["pose/part_pred/block4/weights"], wts["pose/part_pred/block4/biases"], cfg, net, "part_pred", nj,
+                              True, 2048, True)
+    assert torch.equal(p3, heads["part_pred"])
+    with pytest.raises(ValueError):
+        dgp_prediction_layer(None, None, cfg, net, "part_pred", nj, False, 2048, True)
+    t = pn.test(frames)
+    assert set(t) == {"part_prob", "locref"} and float(t["part_prob"].min()) >= 0 and float(t["part_prob"].max()) <= 1
+
+
+def test_infer_packed_equals_infer(lib_built):
+    from deepgraphpose_amd import dist as ddist
+    from deepgraphpose_amd.engine import DGPNet
+    from deepgraphpose_amd.synthetic import make_frames, make_weights
+    nj = 4
+    net = DGPNet(50, nj, 64, 96, max_batch=8)
+    net.load_weights(make_weights(50, nj, False, seed=2, head_std=0.05))
+    ft = torch.from_numpy(make_frames(5, 64, 96, nj, seed=2)).cuda()
+    mu, conf, idx = [t.clone() for t in net.infer(ft)]
+    traj = torch.full((9, nj, 5), -7.0, dtype=torch.float32, device="cuda")
+    net.infer_packed(ft, traj[2:7])                          # a slice of a longer trajectory, written in place
+    m2, c2, i2 = ddist.unpack_keypoints(traj[2:7])
+    assert torch.equal(m2, mu) and torch.equal(c2, conf) and torch.equal(i2, idx)
+    assert float(traj[:2].min()) == -7.0 and float(traj[7:].max()) == -7.0      # nothing outside the slice touched
+    with pytest.raises(Exception):
+        net.infer_packed(ft, traj[:4])
+
+
+def test_rccl_all_gather_in_a_fresh_child_process(lib_built, tmp_path):
+    """init_process_group('nccl') (= RCCL) + all_gather_into_tensor + all_reduce on the hardware: a child process launched with
+    RANK=0 WORLD_SIZE=1 before anything touches the GPU there, running the product's own dist.gather_trajectory and
+    average_gradients on device tensors."""
+    code = r'''
+import json, os, sys, torch
+from deepgraphpose_amd import dist as ddist
+rank, local, world = ddist.init_from_env("nccl")
+import torch.distributed as dist
+assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+dev = torch.device("cuda", local)
+g = torch.Generator(device="cuda").manual_seed(3)
+local_traj = torch.randn((37, 4, 5), device=dev, generator=g)
+full = ddist.gather_trajectory(local_traj, 37)
+grads = torch.randn(1 << 20, device=dev, generator=g)
+ref = grads.clone()
+ddist.average_gradients(grads)
+t = torch.ones(8, device=dev); dist.all_reduce(t)
+torch.cuda.synchronize()
+print(json.dumps({"gather_equal": bool(torch.equal(full, local_traj)), "avg_equal": bool(torch.equal(grads, ref)),
+                  "allreduce": float(t.sum().item()), "backend": dist.get_backend()}))
+dist.destroy_process_group()
+'''
+    env = _child_env(RANK=0, WORLD_SIZE=1, LOCAL_RANK=0, MASTER_ADDR="127.0.0.1", MASTER_PORT=29617)
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out == {"gather_equal": True, "avg_equal": True, "allreduce": 8.0, "backend": "nccl"}
+
+
+def _tiny_project(tmp_path, nj=3, T=11, hw=(96, 128)):
+    import yaml
+    from deepgraphpose_amd import weights_io
+    from deepgraphpose_amd.synthetic import make_frames, make_weights
+    parts = ["a", "b", "c"][:nj]
+    proj = tmp_path / "proj"
+    train = proj / "dlc-models" / "iteration-0" / "DemoOct2-trainset95shuffle1" / "train"
+    train.mkdir(parents=True)
+    (proj / "config.yaml").write_text(yaml.safe_dump(dict(Task="Demo", date="Oct2", iteration=0, TrainingFraction=[0.95],
+                                                          bodyparts=parts, skeleton=[], project_path=str(proj))))
+    (train / "pose_cfg.yaml").write_text(yaml.safe_dump(dict(num_joints=nj, all_joints_names=parts, net_type="resnet_50")))
+    wts = make_weights(50, nj, False, seed=9, head_std=0.05)
+    snap = weights_io.save_weights(str(train / "snapshot-step2-final--0"), wts)
+    frames = make_frames(T, hw[0], hw[1], nj, seed=5)
+    np.save(tmp_path / "clip.npy", frames)
+    return proj, snap[:-4], frames, wts
+
+
+def test_estimate_pose_under_torchrun_env_shards_and_gathers(lib_built, tmp_path):
+    """The product entry point under the launcher's environment (one rank): it joins the RCCL group itself, takes
+    shard_range(T, 0, 1), gathers with all_gather_into_tensor and writes the csv -- and matches the single-process call."""
+    proj, snap, frames, wts = _tiny_project(tmp_path)
+    code = r'''
+import json, sys, numpy as np
+from deepgraphpose_amd.models import eval as E
+out = E.estimate_pose(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], shuffle=1, batch_size=4)
+import torch.distributed as dist
+assert dist.is_initialized() and dist.get_backend() == "nccl"
+np.savez(sys.argv[5], **out)
+dist.destroy_process_group()
+'''
+    env = _child_env(RANK=0, WORLD_SIZE=1, LOCAL_RANK=0, MASTER_ADDR="127.0.0.1", MASTER_PORT=29618)
+    # WORLD_SIZE=1 alone does not trigger the init inside estimate_pose; the launcher contract (torchrun) is RANK + WORLD_SIZE
+    # with the group created by init_from_env -> force it the way bench.py does
+    code = "from deepgraphpose_amd import dist as d; d.init_from_env('nccl')\n" + code
+    r = subprocess.run([sys.executable, "-c", code, str(proj / "config.yaml"), snap, str(tmp_path / "clip.npy"),
+                        str(tmp_path / "pred_dist"), str(tmp_path / "out.npz")], env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(tmp_path / "out.npz")
+    from deepgraphpose_amd.models import eval as E
+    ref = E.estimate_pose(str(proj / "config.yaml"), snap, str(tmp_path / "clip.npy"), str(tmp_path / "pred_single"), shuffle=1,
+                          batch_size=4)
+    for k in ("x", "y", "likelihoods"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert os.path.isfile(tmp_path / "pred_dist" / "clip_labeled.csv")
+
+
+def test_shard_ranges_reassemble_bit_exactly(lib_built):
+    """What N ranks would compute: the frames of each shard_range(T, r, W) inferred separately (own batches) and concatenated
+    equal the one-process trajectory on the integer indices bit for bit and on the coordinates within 1e-3 px."""
+    from deepgraphpose_amd import dist as ddist
+    from deepgraphpose_amd.engine import DGPNet
+    from deepgraphpose_amd.synthetic import make_frames, make_weights
+    nj, T = 4, 21
+    net = DGPNet(50, nj, 64, 96, max_batch=8)
+    net.load_weights(make_weights(50, nj, False, seed=3, head_std=0.05))
+    ft = torch.from_numpy(make_frames(T, 64, 96, nj, seed=8)).cuda()
+
+    def run(lo, hi):
+        traj = torch.zeros((hi - lo, nj, 5), dtype=torch.float32, device="cuda")
+        for s in range(lo, hi, 8):
+            e = min(s + 8, hi)
+            net.infer_packed(ft[s:e].contiguous(), traj[s - lo:e - lo])
+        return traj
+    one = run(0, T)
+    for W in (2, 4, 8):
+        parts = [run(*ddist.shard_range(T, r, W)) for r in range(W)]
+        cat = torch.cat(parts, 0)
+        m1, c1, i1 = ddist.unpack_keypoints(one)
+        m2, c2, i2 = ddist.unpack_keypoints(cat)
+        assert torch.equal(i1, i2)
+        assert float((m1 - m2).abs().max()) * 8.0 < PX_TOL
+
+
+def test_run_dgp_demo_test_mode_end_to_end(lib_built, tmp_path):
+    """`demo/run_dgp_demo.py --dlcpath <synthetic project> --dlcsnapshot snapshot-step0-final--0 --test` as a subprocess: steps
+    1-3 run on the GPU, the step snapshots and videos_pred/<video>_labeled.csv (DLC 3-row header, [T, 3 nj]) appear."""
+    from _project import make_project
+    proj, frames, wts = make_project(tmp_path)
+    env = _child_env()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "demo", "run_dgp_demo.py"), "--dlcpath", proj, "--dlcsnapshot",
+                        "snapshot-step0-final--0", "--batch_size", "4", "--test"], env=env, cwd=str(tmp_path), capture_output=True,
+                       text=True, timeout=1800)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    train = os.path.join(proj, "dlc-models", "iteration-0", "DemoOct2-trainset95shuffle1", "train")
+    for step in (1, 2):
+        assert os.path.isfile(os.path.join(train, "snapshot-step%d-final--0.npz" % step))
+    csv = os.path.join(proj, "videos_pred", "clip_labeled.csv")
+    assert os.path.isfile(csv)
+    rows = open(csv).read().strip().split("\n")
+    assert rows[0].startswith("scorer") and rows[1].startswith("bodyparts") and rows[2].startswith("coords")
+    assert len(rows) == 3 + frames.shape[0] and len(rows[3].split(",")) == 1 + 3 * 3
+    assert "Running DGP with labeled frames only" in r.stdout and "Predict with DGP" in r.stdout
+
+
+def test_evaluate_dgp_soft_argmax_locref_readout(lib_built, tmp_path):
+    """evaluate_dgp(loc_ref=True, loc_ref_calc='dgp') (eval.py:752-786): runs on the synthetic project and its per-frame read-out
+    equals the restated numpy of the reference on the oracle's maps."""
+    from _project import make_project
+    from deepgraphpose_amd.models.eval import evaluate_dgp, soft_argmax_locref_pose
+    from deepgraphpose_amd.models.fitdgp_util import get_snapshot_path
+    from oracle import dgp_oracle as O
+    proj, frames, wts = make_project(tmp_path)
+    snap, cfg_path = get_snapshot_path("snapshot-step0-final--0", proj, shuffle=1)
+    rmse = evaluate_dgp(str(cfg_path), snap, shuffle=1, loc_ref=True, loc_ref_calc="dgp")
+    assert rmse.shape == (4, 3) and np.isfinite(rmse.values[~np.isnan(rmse.values)]).all()
+    # closed form on a one-hot softmax map: position of the hot cell + its locref offset, (x, y) order
+    H, W, nj = 6, 7, 2
+    st = np.zeros((H, W, nj)); st[2, 5, 0] = 1.0; st[4, 1, 1] = 1.0
+    lr = np.zeros((H, W, 2 * nj)); lr[2, 5, 0:2] = [0.5, -0.25]; lr[4, 1, 2:4] = [1.0, 2.0]
+    pose = soft_argmax_locref_pose(lr, st, 8.0, 7.2801)
+    np.testing.assert_allclose(pose[0], [5 * 8 + 4 - 0.25 * 7.2801, 2 * 8 + 4 + 0.5 * 7.2801, 1.0])
+    np.testing.assert_allclose(pose[1], [1 * 8 + 4 + 2.0 * 7.2801, 4 * 8 + 4 + 1.0 * 7.2801, 1.0])

@@ -1,0 +1,135 @@
+"""Host-side pieces added in round 2: augmentation of the labeled frames (B10 data_aug), the session-shaped training boundary
+(dgp_loss return contract), the packed trajectory layout, the pose_net weight transform."""
+import numpy as np
+import pytest
+
+
+def _dot_image(H, W, pts, r=2):
+    img = np.zeros((H, W, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for c, (x, y) in enumerate(pts):
+        m = (yy - y) ** 2 + (xx - x) ** 2 <= r * r
+        img[m, c % 3] = 255
+    return img
+
+
+def _centroid(img, ch):
+    yy, xx = np.nonzero(img[..., ch] > 80)
+    return np.array([xx.mean(), yy.mean()])
+
+
+@pytest.mark.parametrize("name", ["fliplr", "rotate", "motion_blur", "coarse_dropout", "elastic", "gaussian_noise", "crop_and_pad"])
+def test_each_augmenter_moves_keypoints_with_the_pixels(name):
+    """A bright dot per keypoint: after the augmenter the dot's centroid is where the transformed keypoint says (<= 1.5 px)."""
+    from deepgraphpose_amd.augment import NumpyAugPipeline
+    H, W = 120, 160
+    pts = np.array([[40.0, 30.0], [100.0, 70.0], [80.0, 95.0]])
+    img = _dot_image(H, W, pts, r=3)
+    for seed in range(6):
+        p = NumpyAugPipeline(1.0, seed=seed)
+        out, kp = getattr(p, name)(img.copy(), pts.copy())
+        assert out.shape == img.shape and out.dtype == np.uint8 and kp.shape == pts.shape
+        for c in range(3):
+            if (out[..., c] > 80).sum() < 5:
+                continue                                 # dot cropped / dropped away
+            if not (0 <= kp[c, 0] < W and 0 <= kp[c, 1] < H):
+                continue
+            assert np.abs(_centroid(out, c) - kp[c]).max() < 1.6, (name, seed, c, _centroid(out, c), kp[c])
+
+
+def test_data_aug_contract_and_nan_labels():
+    """data_aug (fitdgp_util.py:439-451): only the visible frames change, labels go (row, col) cells <-> (x, y) px and back, NaN
+    labels stay NaN, a pipeline that never fires is the identity."""
+    from deepgraphpose_amd.augment import build_aug, data_aug
+
+    class Cfg:
+        stride = 8.0
+    rng = np.random.RandomState(0)
+    batch = rng.randint(0, 255, (5, 64, 96, 3)).astype(np.uint8)
+    jl = np.array([[[3.0, 4.0], [5.0, 6.0], [np.nan, np.nan]], [[1.0, 9.0], [np.nan, np.nan], [6.5, 2.25]]])
+    ident = build_aug(apply_prob=0.0, seed=0, backend="numpy")
+    ident.crop_and_pad = lambda im, kp: (im, kp)         # the last stage has its own probability (0.4)
+    out, jl2 = data_aug(batch, [1, 3], jl, ident, Cfg)
+    assert out.dtype == batch.dtype and np.array_equal(out, batch)
+    np.testing.assert_allclose(jl2, jl, equal_nan=True, atol=1e-12)
+    pipe = build_aug(apply_prob=0.8, seed=3, backend="numpy")
+    out, jl3 = data_aug(batch, [1, 3], jl, pipe, Cfg)
+    assert np.array_equal(out[[0, 2, 4]], batch[[0, 2, 4]]) and not np.array_equal(out[[1, 3]], batch[[1, 3]])
+    assert np.array_equal(np.isnan(jl3), np.isnan(jl)) and jl3.shape == jl.shape
+    a = build_aug(0.8, seed=11, backend="numpy")(images=batch[:2], keypoints=[[(1.0, 2.0)], [(3.0, 4.0)]])
+    b = build_aug(0.8, seed=11, backend="numpy")(images=batch[:2], keypoints=[[(1.0, 2.0)], [(3.0, 4.0)]])
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1]   # seeded -> reproducible
+
+
+def test_dgp_loss_returns_the_reference_contract():
+    """dgp_loss -> (loss, total_loss, total_loss_visible, placeholders) with the reference's 12 placeholder keys (fitdgp.py:1130-1144)
+    and evaluable handles; feed_dict validation happens before any GPU work."""
+    from deepgraphpose_amd.config import AttrDict
+    from deepgraphpose_amd.models.fitdgp import dgp_loss, _feed
+    from deepgraphpose_amd.models.session import LossTensor, Placeholder, TrainOp, TrainSession, PLACEHOLDER_KEYS
+
+    class DS:
+        labels = np.array([[[1.0, 2.0], [4.0, 6.0], [np.nan, np.nan]], [[2.0, 2.0], [5.0, 9.0], [7.0, 1.0]]])
+
+    class DB:
+        S0 = np.array([[1.0, -1.0, 0.0], [0.0, 1.0, -1.0]])
+        nj, datasets, n_frames_total, n_visible_frames_total = 3, [DS()], 40, 2
+    cfg = AttrDict(ws=1000, ws_max=1.2, wt=0, wt_max=0, wn_visible=5, wn_hidden=3, gamma=1, gauss_len=1, lengthscale=1, lr=0.005,
+                   gm2=1, gm3=3, stride=8.0, locref_loss_weight=0.05, locref_huber_loss=True)
+    loss, total_loss, total_loss_visible, placeholders = dgp_loss(DB(), cfg)
+    assert tuple(placeholders) == PLACEHOLDER_KEYS == ("inputs", "targets", "locref_map", "locref_mask", "visible_marker_pl",
+                                                       "hidden_marker_pl", "visible_marker_in_targets_pl", "wt_batch_mask_pl",
+                                                       "vector_field_tf", "nt_batch_pl", "wt_batch_pl", "alpha_tf")
+    assert all(isinstance(v, Placeholder) for v in placeholders.values())
+    assert {"visible_loss_pred", "hidden_loss_pred", "visible_loss_locref", "total_loss"} <= set(loss)
+    assert isinstance(total_loss, LossTensor) and total_loss is loss["total_loss"] and total_loss_visible.name == "total_loss_visible"
+    g = loss.graph
+    assert g.ws.shape == (2,) and g.ws_max.shape == (2,) and np.all(g.ws > 0)
+    lr = Placeholder("learning_rate")
+    op = g.minimize(total_loss, lr)
+    assert isinstance(op, TrainOp) and op.clip_norm == 10.0 and op.momentum == 0.9          # fitdgp.py:709-712
+    with pytest.raises(ValueError):
+        g.minimize(loss["visible_loss_pred"], lr)
+    bad = AttrDict(cfg, gm2=3)
+    with pytest.raises(Exception, match="Not implemented"):
+        dgp_loss(DB(), bad)
+    fd = _feed(placeholders, np.zeros((3, 16, 16, 3), np.uint8), DS.labels[:1], np.zeros((3, 2, 2, 6)), np.zeros((3, 2, 2, 6)),
+               (np.array([0, 1]), np.array([2, 3, 4, 5, 6, 7, 8]), np.array([0, 1])), np.array([1, 0]), None, 0, 2, 2, lr, 0.005)
+    assert len(fd) == 13 and fd[placeholders["nt_batch_pl"]] == 3 and fd[placeholders["alpha_tf"]].shape == (2, 2, 2)
+    sess = TrainSession(trainer=None, graph=g)
+    del fd[placeholders["targets"]]
+    with pytest.raises(KeyError, match="targets"):
+        sess.run([loss, op], fd)
+
+
+def test_packed_trajectory_layout_round_trip():
+    """[T,nj,5] records (row, col, likelihood, iy, ix-as-int32-bits): what dgp_infer_packed writes and the all-gather moves."""
+    import torch
+    from deepgraphpose_amd import dist as ddist
+    rng = np.random.RandomState(1)
+    mu = torch.from_numpy(rng.rand(7, 4, 2).astype(np.float32) * 50)
+    conf = torch.from_numpy(rng.rand(7, 4).astype(np.float32))
+    idx = torch.from_numpy(rng.randint(0, 80, (7, 4, 2)).astype(np.int32))
+    buf = ddist.pack_keypoints(mu, conf, idx)
+    assert buf.shape == (7, 4, 5) and buf.dtype == torch.float32
+    m2, c2, i2 = ddist.unpack_keypoints(buf)
+    assert torch.equal(m2, mu) and torch.equal(c2, conf) and torch.equal(i2, idx)
+    raw = buf.numpy().view(np.int32)
+    assert np.array_equal(raw[..., 3:5], idx.numpy())
+
+
+def test_deconv_phase_weights_reproduce_the_transposed_conv():
+    """pose_net._deconv_as_phase_conv: the 3x3 / stride-2 SAME transposed conv as a 2x2 conv over four output phases."""
+    import torch
+    from deepgraphpose_amd.nnet.pose_net import _deconv_as_phase_conv
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 5, 6, 8)).astype(np.float32)
+    w = rng.standard_normal((3, 3, 3, 8)).astype(np.float32)
+    b = rng.standard_normal(3).astype(np.float32)
+    ref = np.asarray(O.conv2d_transpose_same(x, w, b))
+    wp = _deconv_as_phase_conv(w)
+    xp = torch.nn.functional.pad(torch.from_numpy(x).permute(0, 3, 1, 2), (1, 0, 1, 0))
+    y = torch.nn.functional.conv2d(xp, torch.from_numpy(wp).permute(3, 2, 0, 1)).permute(0, 2, 3, 1)
+    y = y.reshape(2, 5, 6, 2, 2, 3).permute(0, 1, 3, 2, 4, 5).reshape(2, 10, 12, 3).numpy() + b
+    assert np.abs(y - ref).max() < 1e-5

@@ -61,6 +61,25 @@ def test_unit_plan_matches_slim_stack_blocks_dense():
     assert abs(conv_macs_per_frame(720, 1280, 101, 20, True) / 1e9 - 178.73) < 0.01
 
 
+def test_oracle_unit_plan_is_independent_and_agrees_with_the_product():
+    """The oracle walks slim's stack_blocks_dense itself (oracle/resnet_plan.py) -- it must not import the product's table --
+    and the two independently written plans agree unit by unit for both backbones."""
+    import inspect
+    from oracle import resnet_plan, dgp_oracle, dgp_train_oracle
+    from deepgraphpose_amd.arch import resnet_units
+    for mod in (resnet_plan, dgp_oracle, dgp_train_oracle):
+        assert "deepgraphpose_amd.arch import resnet_units" not in inspect.getsource(mod)
+    for depth, n in ((50, 16), (101, 33)):
+        a, b = resnet_plan.units(depth), resnet_units(depth)
+        assert len(a) == len(b) == n
+        for x, y in zip(a, b):
+            assert (x.scope, x.depth_in, x.depth, x.depth_bottleneck, x.stride, x.rate, x.has_shortcut_conv) == \
+                   (y.scope, y.depth_in, y.depth, y.depth_bottleneck, y.stride, y.rate, y.has_shortcut_conv)
+    u = resnet_plan.units(50)
+    assert [x.stride for x in u] == [1, 1, 2, 1, 1, 1, 2] + [1] * 9 and [x.rate for x in u] == [1] * 13 + [2, 2, 2]
+    assert [x.has_shortcut_conv for x in u] == [True, False, False, True, False, False, False, True] + [False] * 5 + [True, False, False]
+
+
 def test_gaussian_taps_constants():
     np.testing.assert_allclose(O.gaussian_taps(1), [0.27406862, 0.45186276, 0.27406862], rtol=1e-6)
     g2 = O.gaussian_taps(2)
