@@ -205,23 +205,32 @@ def test_resnet101_trainer_dense_skeleton_matches_autograd(lib_built):
     hy = DGPHyper(gm2=1, gm3=3)
     n_tot, n_vis = 300.0, 25.0
     P, L = _oracle_grads(wts, frames, batch, S0, ws, ws_max, hy, n_tot, n_vis, depth=101, dtype=torch.float64)
+    P32, _ = _oracle_grads(wts, frames, batch, S0, ws, ws_max, hy, n_tot, n_vis, depth=101, dtype=torch.float32)
     tr = Trainer(101, nj, hw[0], hw[1], max_frames=nt)
     tr.load_weights(wts)
     losses = tr.forward_backward(torch.from_numpy(frames).cuda(), batch, hy, S0, ws, ws_max, n_tot, n_vis)
     ref_total = float(L["total_loss"].detach())
     assert abs(losses["total_loss"] - ref_total) < 1e-4 * max(1, abs(ref_total))
     g = tr.get_grads()
-    rel, tot_ref, tot_err = {}, 0.0, 0.0
+    rel, rel32, tot_ref, tot_err = {}, {}, 0.0, 0.0
     for k, t in P.items():
         if not t.requires_grad:
             continue
         ref = t.grad.numpy()
         d = g[k].reshape(ref.shape) - ref
-        rel[k] = np.linalg.norm(d.ravel()) / (np.linalg.norm(ref.ravel()) + 1e-30)
+        nref = np.linalg.norm(ref.ravel()) + 1e-30
+        rel[k] = np.linalg.norm(d.ravel()) / nref
+        rel32[k] = np.linalg.norm((P32[k].grad.numpy().astype(np.float64) - ref).ravel()) / nref      # fp32 arithmetic's own error
         tot_ref += float((ref ** 2).sum())
         tot_err += float((d ** 2).sum())
+    # With 60 hidden maps some scoremap peaks saturate (c = max sigmoid -> 1) and the gm3 weight (1 - c) loses digits in ANY fp32
+    # evaluation (1e-3 relative here, the same in the fp32 CPU oracle): the bound for the tensors downstream of the loss gradient
+    # only (block4 + heads: no upstream ReLU-gate flips) is therefore round-off (2e-5) plus three times the fp32 oracle's own
+    # distance from the float64 truth, tensor by tensor.
     strict = {k: v for k, v in rel.items() if "block4" in k or k.startswith("pose/")}
-    assert max(strict.values()) < 2e-5, sorted(strict.items(), key=lambda kv: -kv[1])[:4]
+    worst = sorted(((v / (2e-5 + 3 * rel32[k]), k, v, rel32[k]) for k, v in strict.items()), reverse=True)[:4]
+    assert worst[0][0] < 1.0, worst
+    assert rel["pose/locref_pred/block4/weights"] < 2e-5 and rel["pose/locref_pred/block4/biases"] < 2e-5     # no (1 - c) in this branch
     assert max(rel.values()) < 1e-2, sorted(rel.items(), key=lambda kv: -kv[1])[:4]       # single ReLU gate flips upstream, see test_train_gpu
     assert np.sqrt(tot_err / tot_ref) < 3e-3
 
@@ -317,7 +326,7 @@ def test_likelihood_window_saturated_logit_matches_numpy(lib_built):
     s[0, 6, 7, 1] = 30.0                    # large but finite
     s[0, 3, 3, 2] = 91.0
     s[0, 4, 4, 2] = 91.0                    # two saturated cells: mu lands between them
-    mu, conf, idx, _ = engine.soft_argmax(torch.from_numpy(s).cuda(), 1.0, 1, want_pmap=False)
+    mu, conf, idx = engine.soft_argmax(torch.from_numpy(s).cuda(), 1.0, 1, want_pmap=False)
     mu, conf, idx = mu.cpu().numpy(), conf.cpu().numpy(), idx.cpu().numpy()
     with np.errstate(over="ignore", invalid="ignore"):
         iref, lref = O.likelihood_window(s[0], mu[0])
