@@ -73,6 +73,18 @@ struct dgp_net {
     unsigned tail_slab_bytes = 0;
     bool wmax_valid = false;      // false after a trainer re-packed the panels: everything derived from the weights at load time
                                   // (ranges, fp16 cells, stem row panel, fused shortcut panels) is stale and the forward avoids it
+    // H2 activation format (fp16 high / low cells written by the producing epilogue, ConvArgs::in_fmt): scale exponent of every
+    // layer's output tensor (scale = 2^exp, max |tensor| * scale in [2^10, 2^11): 4 bits of headroom under the fp16 limit), set by a
+    // calibration pass -- the first forward after the weights were loaded (or after an overflow was reported) runs layer by layer,
+    // reads each layer's tracked range and re-launches it with the final scale.  Afterwards the scales are frozen: results are a
+    // deterministic function of (frames, scales); a range that outgrows its scale is caught by h2_range_check_kernel (d_flag).
+    static constexpr int H2_NONE = (int)0x80000000;
+    std::vector<int> act_exp;          // per layer; H2_NONE: output is not an H2 tensor.  conv1's entry holds the POOL output's exponent
+    std::vector<char> unit_fuse_ok;    // conv3 + shortcut as one GEMM needs R2 and X on one scale; false: run the shortcut conv separately
+    bool h2_calibrated = false;
+    int h2_head = 4;                   // bits of headroom between a calibrated maximum and the fp16 limit; +3 after every reported overflow
+    int h2_calibrations = 0;
+    int *d_exps = nullptr, *d_flag = nullptr;
     const float* wmax(int li) const { return d_wmax ? d_wmax + (size_t)li * dgp::ABSMAX_SLOTS : nullptr; }     // li + n_layers: fused panel of layer li
     float* amax(int li) const { return d_amax ? d_amax + (size_t)li * dgp::ABSMAX_SLOTS : nullptr; }
     // optional per-launch timing (hipEvent pairs recorded on the caller's stream)
@@ -98,5 +110,6 @@ struct dgp_net {
             for (void* q : {(void*)l.d_w_fused, (void*)l.d_bias_fused, l.d_wh3_fused}) if (q) (void)hipFree(q);
         }
         for (float* q : {d_wmax, d_amax, d_inmax}) if (q) (void)hipFree(q);
+        for (int* q : {d_exps, d_flag}) if (q) (void)hipFree(q);
     }
 };

@@ -54,6 +54,15 @@ struct ConvArgs {
     const void*  wh3;         // optional: the weight panel pre-split into fp16 high/low cells (launch_pack_h3), same scale as w_absmax gives
     unsigned     wh3_bytes;
     float*       out_absmax;  // the epilogue atomically maxes max |out| into this slot (zeroed by the caller)
+    // "H2" activation format (inference engine): a tensor lives in HBM as fp16 high/low cell pairs -- per pixel and 8 channels
+    // [8 halves hi | 8 halves lo] = 32 bytes, the same footprint and the same addresses as 8 fp32 channels -- holding x * scale with
+    // scale = 2^e chosen per tensor by the engine (calibrated, with headroom; host-known, so it travels as a kernel argument).
+    // Consumers copy the cells straight into the MFMA operand image (no split arithmetic in the K loop); producers split once in
+    // the epilogue.  0 = fp32, 1 = H2.
+    int   in_fmt, out_fmt, res_fmt;
+    float in_scale;           // in (and in2) cells hold x * in_scale
+    float out_scale;          // cells written hold out * out_scale
+    float res_inv_scale;      // residual value = (hi + lo) * res_inv_scale
 };
 
 constexpr int ABSMAX_SLOTS = 256;
@@ -70,7 +79,12 @@ hipError_t launch_absmax(const float* x, long long n, float* out_slots, hipStrea
 const char* conv_kernel_name(const ConvArgs& a, int tile_cfg);
 hipError_t launch_reduce_slabs(const float* slabs, long long n, long long stride, int nsplit, float* out, hipStream_t s);
 hipError_t launch_head_gather(const float* T, const float* bias, int B, int h, int w, int njt, int ldt, float* out, hipStream_t s);
-hipError_t launch_maxpool(const float* x, int N, int H, int W, int C, float* y, hipStream_t s);
+hipError_t launch_maxpool(const float* x, int N, int H, int W, int C, float* y, hipStream_t s, float h2_scale = 0.f);   // h2_scale > 0: y in H2 format
+// fp32 NHWC [n_pix][C] <-> H2 cells (C % 8 == 0); scale = the power of two the cells are (to be) stored with
+hipError_t launch_f32_to_h2(const float* x, long long n_groups8, float scale, void* out, hipStream_t s);
+hipError_t launch_h2_to_f32(const void* x, long long n_groups8, float inv_scale, float* out, hipStream_t s);
+// flag[0] |= 1 where a tracked range times the tensor's scale leaves the fp16 range (limit 60000), per layer; exps: scale exponents
+hipError_t launch_h2_range_check(const float* amax_slots, const int* exps, int n_layers, int* flag, hipStream_t s);
 hipError_t launch_preprocess(const uint8_t* f, long long npix, float m0, float m1, float m2,
                              float* out, hipStream_t s);
 hipError_t launch_motion_energy(const uint8_t* frames, long long frame_bytes, int n_frames, const uint8_t* prev_frame,

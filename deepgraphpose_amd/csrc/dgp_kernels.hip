@@ -914,6 +914,125 @@ __device__ __forceinline__ void split2_f16(const float4 v, const float s, uint2&
 #endif
 }
 
+// ---- H2 activation format helpers -------------------------------------------------------------------------------------------
+// 8 consecutive channels of a pixel = one 32-byte cell pair [8 halves high | 8 halves low] holding x * scale (ConvArgs::in_fmt)
+__device__ __forceinline__ void h2_pack8(const float (&v)[8], float scale, uint4& hi, uint4& lo) {
+    uint2 h0, l0, h1, l1;
+    split2_f16(make_float4(v[0], v[1], v[2], v[3]), scale, h0, l0);
+    split2_f16(make_float4(v[4], v[5], v[6], v[7]), scale, h1, l1);
+    hi = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    lo = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+__device__ __forceinline__ void h2_unpack8(const uint4 hi, const uint4 lo, float inv_scale, float (&v)[8]) {
+    const half8 h = __builtin_bit_cast(half8, hi), l = __builtin_bit_cast(half8, lo);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = ((float)h[k] + (float)l[k]) * inv_scale;      // hi + lo is exact in fp32 (22 bits)
+}
+
+// Epilogue of the CS kernels when the OUTPUT tensor is H2 (the inference engine's activations): a lane owns 8 consecutive channels of
+// a row -- two 16-byte reads of the staged tile, the residual's cell pair (H2 or fp32: the same 32 bytes at the same address),
+// scale / bias / residual / ReLU in fp32, max |out| tracking, ONE split with the tensor's scale and two 16-byte stores (32 contiguous
+// bytes per lane, 512 per row of a 128-column tile).  Chunks of two row groups are software-pipelined like ls_epilogue's.
+template <int TM, int TN, int WN, bool M16 = false>
+__device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc)[TM][TN], char* smem, int wave, int lane,
+                                               int m0, int n0, int wave_m0, int wave_n0, float post) {
+    constexpr int LDC = WN + 4;
+    constexpr int C8 = WN / 8;                     // lanes per row
+    constexpr int RPI = 64 / C8;                   // rows per wave-instruction
+    constexpr int NV = 32 / RPI;                   // row groups per 32-row pass
+    constexpr int VC = NV > 2 ? 2 : NV;
+    constexpr int CPP = NV / VC, NQ = TM * CPP;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int HoWo = p.Ho * p.Wo;
+    float* sC = reinterpret_cast<float*>(smem) + wave * (32 * LDC);
+    const __amdgpu_buffer_rsrc_t rs_res =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.in), 0, p.res ? (int)p.res_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+    const int my_c8 = lane % C8, my_r0 = lane / C8;
+    const int co8 = n0 + wave_n0 + 8 * my_c8;
+    const bool cok = co8 < p.Cout;                 // (Cout % 8 == 0 for every H2 tensor)
+    float sc[8], bi[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = post; bi[k] = 0.f; }
+    if (cok && p.scale) {
+        const float4 a = *reinterpret_cast<const float4*>(p.scale + co8), b = *reinterpret_cast<const float4*>(p.scale + co8 + 4);
+        sc[0] *= a.x; sc[1] *= a.y; sc[2] *= a.z; sc[3] *= a.w; sc[4] *= b.x; sc[5] *= b.y; sc[6] *= b.z; sc[7] *= b.w;
+    }
+    if (cok && p.bias) {
+        const float4 a = *reinterpret_cast<const float4*>(p.bias + co8), b = *reinterpret_cast<const float4*>(p.bias + co8 + 4);
+        bi[0] = a.x; bi[1] = a.y; bi[2] = a.z; bi[3] = a.w; bi[4] = b.x; bi[5] = b.y; bi[6] = b.z; bi[7] = b.w;
+    }
+    float amax = 0.f;
+    unsigned ooff[2][VC];
+    uint4 rres[2][VC][2];
+    auto issue = [&](int q, int slot) {
+        const int i = q / CPP, v0 = (q % CPP) * VC;
+#pragma unroll
+        for (int u = 0; u < VC; ++u) {
+            const int row = my_r0 + (v0 + u) * RPI;
+            const int m = m0 + wave_m0 + 32 * i + row;
+            const bool ok = cok && m < p.M;
+            ooff[slot][u] = ok ? ((unsigned)(m * p.Cout + co8) << 2) : OOB;
+            if (p.res) {
+                unsigned roff = OOB;
+                if (p.res_s == 1) {
+                    roff = ooff[slot][u];
+                } else if (p.res_s > 1 && ok) {
+                    const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                    roff = (unsigned)(((n * p.res_H + ho * p.res_s) * p.res_W + wo * p.res_s) * p.Cout + co8) << 2;
+                }
+                rres[slot][u][0] = __builtin_bit_cast(uint4, buf_load16(rs_res, roff));
+                rres[slot][u][1] = __builtin_bit_cast(uint4, buf_load16(rs_res, roff == OOB ? OOB : roff + 16u));
+            }
+        }
+    };
+    issue(0, 0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i = q / CPP, v0 = (q % CPP) * VC, slot = q & 1;
+        if (q % CPP == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (!M16) sC[((r & 3) + 8 * (r >> 2) + 4 * half) * LDC + 32 * j + l31] = acc[i][j][r];
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (q + 1 < NQ) issue(q + 1, slot ^ 1);
+#pragma unroll
+        for (int u = 0; u < VC; ++u) {
+            const int row = my_r0 + (v0 + u) * RPI;
+            const float4 a0 = *reinterpret_cast<const float4*>(sC + row * LDC + 8 * my_c8);
+            const float4 a1 = *reinterpret_cast<const float4*>(sC + row * LDC + 8 * my_c8 + 4);
+            float o[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (p.res) {
+                if (p.res_fmt) h2_unpack8(rres[slot][u][0], rres[slot][u][1], p.res_inv_scale, r);
+                else {
+                    const float4 r0 = __builtin_bit_cast(float4, rres[slot][u][0]), r1 = __builtin_bit_cast(float4, rres[slot][u][1]);
+                    r[0] = r0.x; r[1] = r0.y; r[2] = r0.z; r[3] = r0.w; r[4] = r1.x; r[5] = r1.y; r[6] = r1.z; r[7] = r1.w;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                o[k] = o[k] * sc[k] + bi[k] + r[k];
+                if (p.relu) o[k] = fmaxf(o[k], 0.f);
+            }
+            uint4 hi, lo;
+            h2_pack8(o, p.out_scale, hi, lo);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), rs_out, (int)ooff[slot][u], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), rs_out, (int)(ooff[slot][u] == OOB ? OOB : ooff[slot][u] + 16u), 0, 0);
+            if (ooff[slot][u] != OOB) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(o[k]));
+            }
+        }
+    }
+    if (p.out_absmax) track_absmax(p.out_absmax, amax, lane, (int)(blockIdx.x * 8u + (threadIdx.x >> 6)));
+}
+
 // BK = 32: one workgroup per CU (101 KB of LDS for 128 x 128); BK = 16: half the LDS and <= 128 registers, so TWO
 // workgroups share a CU and one's prologue / epilogue / barrier waits run under the other's MFMAs.
 // CW = compute waves: 4 (2 x 2, wave tile BM/2 x BN/2) or 8 (2 x 4, wave tile BM/2 x BN/4: 12-wave workgroups whose
@@ -928,8 +1047,12 @@ __device__ __forceinline__ void split2_f16(const float4 v, const float s, uint2&
 //   no ds_write -- ds_write_b128 holds a SIMD pair's LDS data path for 13 cycles and the compute waves' reads queue behind it).
 //   A image: row-major [row][8 chunks] with the chunk slot XOR-swizzled by (row >> 1) & 7 on the SOURCE side (the DMA destination is
 //   lane-linear), three stages (two K-steps of lookahead); B image: the weight cells unpadded, two stages.  80 KB per workgroup.
-template <int BM, int BN, int NT, int BK, int CW, bool PB = false, int MODE = 0, bool CS = false, bool DMA = false>
+//   AH2 (CS kernels): the A operand arrives in the H2 activation format (fp16 high / low cells written by the producer's epilogue,
+//   ConvArgs::in_fmt): chunk 2 kg of a row IS the high cell of k-group kg and chunk 2 kg + 1 the low cell, so the loaders are
+//   unchanged (same addresses, same bytes) and the compute waves drop the split -- ds_read + MFMA only.
+template <int BM, int BN, int NT, int BK, int CW, bool PB = false, int MODE = 0, bool CS = false, bool DMA = false, bool AH2 = false>
 __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2) ? 4 : 2)) void conv_igemm_split_ls(const ConvArgs p) {
+    static_assert(!AH2 || CS, "pre-split A operand: compute-side-split kernels only");
     // compute waves: 2 x (CW / 2) over the tile; with the compute-side split 4 x 1 (each wave owns 32 rows and ALL columns, so no
     // two waves split the same A rows -- half the split arithmetic for 25 % more B fragment reads)
     constexpr int WAVES_M = (CS && CW == 4) ? 4 : 2;
@@ -1306,9 +1429,9 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const float scA_c = CS ? pow2_scale_for(p.in_absmax, lane, p.in2_absmax) : 1.f;       // operand scale of the compute-side split
+    const float scA_c = (CS && !AH2) ? pow2_scale_for(p.in_absmax, lane, p.in2_absmax) : 1.f;       // operand scale of the compute-side split
     // exact power of two that undoes the fp16 operand scales; read now, while this wave waits for the first tile anyway
-    const float post = (NT == 2 && part < 0) ? 1.f / (pow2_scale_for(p.in_absmax, lane, p.in2_absmax) * pow2_scale_for(p.w_absmax, lane)) : 1.f;
+    const float post = (NT == 2 && part < 0) ? 1.f / ((AH2 ? p.in_scale : pow2_scale_for(p.in_absmax, lane, p.in2_absmax)) * pow2_scale_for(p.w_absmax, lane)) : 1.f;
 #ifdef DGP_DIAG
     unsigned long long e0, e1, e2, e3, acc_mf = 0, acc_ba = 0;
     DIAG_STAMP(e0);
@@ -1357,10 +1480,15 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             ra[I][1] = *reinterpret_cast<const uint4*>(smem + (a_cur ^ 16u) + (I) * 2048);                         \
         } else { ra[I][0] = A[16 * (I)]; ra[I][1] = A[LDAF + 16 * (I)]; } } while (0)
 #define DGP_RB(F) do { bq[(F) & 3] = B[((((F) & 1) ? 0 : 1) * KG) * LDB + 16 * (((F) & 15) >> 1)]; } while (0)
-#define DGP_SPLIT(I) do { uint2 h0_, l0_, h1_, l1_;                                                                \
+#if defined(DGP_X) && DGP_X == 1      // timing-only stand-in: the A operand as if it arrived pre-split (no split arithmetic)
+#define DGP_SPLIT(I) do { ah[I] = ra[I][0]; al[I] = ra[I][1]; } while (0)
+#else
+#define DGP_SPLIT(I) do { if constexpr (AH2) { ah[I] = ra[I][0]; al[I] = ra[I][1]; break; }                       \
+        uint2 h0_, l0_, h1_, l1_;                                                                                  \
         split2_f16(__builtin_bit_cast(float4, ra[I][0]), scA_c, h0_, l0_);                                         \
         split2_f16(__builtin_bit_cast(float4, ra[I][1]), scA_c, h1_, l1_);                                         \
         ah[I] = make_uint4(h0_.x, h0_.y, h1_.x, h1_.y); al[I] = make_uint4(l0_.x, l0_.y, l1_.x, l1_.y); } while (0)
+#endif
 #define DGP_MM(F) do { constexpr int j_ = (F) >> 1;                                                                \
         if (((F) & 1) == 0) { c[0][j_] = mma(ah[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(ah[1], bq[(F) & 3], c[1][j_]); }    \
         else { c[0][j_] = mma(al[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(al[1], bq[(F) & 3], c[1][j_]);         \
@@ -1439,7 +1567,8 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
     } else
 #if !defined(DGP_NO_PIPE)
     static_assert(!DMA || (TM == 1 && TN == 4), "DMA image is read by the pipelined loop only");
-    if constexpr (CS && TM == 1 && TN == 4 && NT == 2 && BK == 32) {
+    static_assert(!(DMA && AH2) || M16, "pre-split A + DMA image: 16x16x32 loop only");
+    if constexpr (CS && TM == 1 && TN == 4 && NT == 2 && BK == 32 && !AH2) {
         // Software-pipelined K loop of the 32 x 128 wave tile.  hipcc's schedule read each B fragment right before its MFMAs
         // (ds_read, s_waitcnt 0, mfma: ~6 exposed LDS round trips per 16-wide slice); here the 16 B fragments of a K-step flow
         // through a ring of three fragment PAIRS (24 registers) two pairs ahead of the MFMAs that consume them, the A rows of the
@@ -1575,11 +1704,21 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
                 for (int i = 0; i < TM; ++i) {
                     const float4 f0 = __builtin_bit_cast(float4, a_base[(2 * kg) * LDAF + 32 * i]);
                     const float4 f1 = __builtin_bit_cast(float4, a_base[(2 * kg + 1) * LDAF + 32 * i]);
+#if defined(DGP_X) && DGP_X == 1
+                    af[0][i] = __builtin_bit_cast(uint4, f0);
+                    af[1][i] = __builtin_bit_cast(uint4, f1);
+#else
+                    if constexpr (AH2) {       // chunk 2 kg = high cell, chunk 2 kg + 1 = low cell of this row's k-group
+                        af[0][i] = __builtin_bit_cast(uint4, f0);
+                        af[1][i] = __builtin_bit_cast(uint4, f1);
+                        continue;
+                    }
                     uint2 h0, l0, h1, l1;
                     split2_f16(f0, scA_c, h0, l0);
                     split2_f16(f1, scA_c, h1, l1);
                     af[0][i] = make_uint4(h0.x, h0.y, h1.x, h1.y);
                     af[1][i] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+#endif
                 }
             }
             auto mma = [](const uint4& x, const uint4& y, floatx16 c) {
@@ -1616,6 +1755,10 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
         ls_store_raw<TM, TN, WN, M16>(acc, smem, wave, lane, wave_m0, wave_n0, p.slab + (size_t)tail_slot * (BM * BN), BN);
         return;
     }
+    if constexpr (CS) {
+        if (p.out_fmt) ls_epilogue_h2<TM, TN, WN, M16>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
+        else ls_epilogue<TM, TN, WN, M16>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
+    } else
     ls_epilogue<TM, TN, WN, M16>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
 #ifdef DGP_DIAG
     DIAG_STAMP(e2);
@@ -1630,7 +1773,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
 template <int BM, int BN, bool F16>
 __global__ __launch_bounds__(256) void tail_fixup_kernel(const ConvArgs p) {
     const int lane = threadIdx.x & 63;
-    const float post = F16 ? 1.f / (pow2_scale_for(p.in_absmax, lane, p.in2_absmax) * pow2_scale_for(p.w_absmax, lane)) : 1.f;
+    const float post = F16 ? 1.f / ((p.in_fmt ? p.in_scale : pow2_scale_for(p.in_absmax, lane, p.in2_absmax)) * pow2_scale_for(p.w_absmax, lane)) : 1.f;
     constexpr int C4 = BN / 4;
     const int per_tile = BM * C4;
     const int ntail = (int)gridDim.y;
@@ -1675,11 +1818,71 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const ConvArgs p) {
     if (p.out_absmax) track_absmax(p.out_absmax, amax, lane, (int)((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6)));
 }
 
+// tail_fixup_kernel for an H2 output tensor (and an fp32 or H2 residual): a thread owns 8 channels of a row
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void tail_fixup_h2_kernel(const ConvArgs p) {
+    const int lane = threadIdx.x & 63;
+    const float post = 1.f / ((p.in_fmt ? p.in_scale : pow2_scale_for(p.in_absmax, lane, p.in2_absmax)) * pow2_scale_for(p.w_absmax, lane));
+    constexpr int C8 = BN / 8;
+    const int per_tile = BM * C8;
+    const int ntail = (int)gridDim.y;
+    const int HoWo = p.Ho * p.Wo;
+    float amax = 0.f;
+    for (int tt = blockIdx.y; tt < ntail; tt += gridDim.y) {
+        const int tile = p.n_main + tt, mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < per_tile; e += gridDim.x * blockDim.x) {
+            const int row = e / C8, c8 = e - row * C8;
+            const int m = mt * BM + row, co = nt * BN + 8 * c8;
+            if (m >= p.M || co >= p.Cout) continue;
+            const float* sl = p.slab + ((size_t)tt * p.tail_ksplit) * (BM * BN) + (size_t)row * BN + 8 * c8;
+            float o[8];
+            {
+                const float4 a = *reinterpret_cast<const float4*>(sl), b = *reinterpret_cast<const float4*>(sl + 4);
+                o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+            }
+            for (int sidx = 1; sidx < p.tail_ksplit; ++sidx) {
+                const float4 a = *reinterpret_cast<const float4*>(sl + (size_t)sidx * (BM * BN));
+                const float4 b = *reinterpret_cast<const float4*>(sl + (size_t)sidx * (BM * BN) + 4);
+                o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; o[4] += b.x; o[5] += b.y; o[6] += b.z; o[7] += b.w;
+            }
+            float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (p.res) {
+                long long roff = -1;
+                if (p.res_s == 1) roff = (long long)m * p.Cout + co;
+                else {
+                    const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                    roff = (((long long)n * p.res_H + ho * p.res_s) * p.res_W + wo * p.res_s) * p.Cout + co;
+                }
+                const uint4 r0 = *reinterpret_cast<const uint4*>(p.res + roff), r1 = *reinterpret_cast<const uint4*>(p.res + roff + 4);
+                if (p.res_fmt) h2_unpack8(r0, r1, p.res_inv_scale, r);
+                else {
+                    const float4 f0 = __builtin_bit_cast(float4, r0), f1 = __builtin_bit_cast(float4, r1);
+                    r[0] = f0.x; r[1] = f0.y; r[2] = f0.z; r[3] = f0.w; r[4] = f1.x; r[5] = f1.y; r[6] = f1.z; r[7] = f1.w;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float scv = p.scale ? p.scale[co + k] * post : post;
+                o[k] = o[k] * scv + (p.bias ? p.bias[co + k] : 0.f) + r[k];
+                if (p.relu) o[k] = fmaxf(o[k], 0.f);
+                amax = fmaxf(amax, fabsf(o[k]));
+            }
+            uint4 hi, lo;
+            h2_pack8(o, p.out_scale, hi, lo);
+            uint4* dst = reinterpret_cast<uint4*>(p.out + (long long)m * p.Cout + co);
+            dst[0] = hi; dst[1] = lo;
+        }
+    }
+    if (p.out_absmax) track_absmax(p.out_absmax, amax, lane, (int)((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6)));
+}
+
 template <int BM, int BN, int NT, int BK, int CW = 4>
 static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     constexpr int NP = NT == 6 ? 3 : 2;
     constexpr int KG = BK / 8;
-    if (NT == 2 && (!a.in_absmax || !a.w_absmax)) return hipErrorInvalidValue;      // fp16 split needs both ranges
+    if (NT == 2 && ((!a.in_absmax && !a.in_fmt) || !a.w_absmax)) return hipErrorInvalidValue;      // fp16 split needs both ranges (H2 input carries its scale)
+    if ((a.in_fmt || a.out_fmt) && !(NT == 2 && BK == 32 && CW == 4 && a.wh3 && (a.Cout % 8) == 0 && (a.Cin % 8) == 0 && !a.up && !a.stem && !a.mask))
+        return hipErrorInvalidValue;                                                 // H2 tensors: fp16-split cell kernels only
     static const int tap_minor = getenv("DGP_TAP_MINOR") ? atoi(getenv("DGP_TAP_MINOR")) : 1;
     a.tap_minor = (tap_minor && !a.stem && a.ntaps > 1 && a.nk * 32 == a.ntaps * a.Cin) ? 1 : 0;
     const size_t smem_loop = (size_t)2 * (NP * KG * (BM + (BK == 32 ? 4 : 8)) + NP * KG * (BN + 4)) * 16;
@@ -1719,12 +1922,26 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
         smem = (size_t)(3 * BM * 8 + 2 * NP * KG * BN) * 16;           // 3 A stages + 2 B stages = 80 KB
         if (smem < smem_epi) smem = smem_epi;
     }
-    static bool attr_done[4][3] = {{false, false, false}, {false, false, false}, {false, false, false}, {false, false, false}};
-    if (!attr_done[dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode]) {
+    if (a.in_fmt) {        // H2 input: the same kernels without the split (AH2)
+        if (!cs) return hipErrorInvalidValue;
+        if constexpr (CAN_CS) {
+            if (dma) {
+                if constexpr (CAN_DMA)
+                    kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 2, CAN_DMA, CAN_DMA, CAN_DMA>
+                                     : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 1, CAN_DMA, CAN_DMA, CAN_DMA>;
+            } else {
+                kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 2, CAN_CS, false, CAN_CS>
+                     : mode == 1 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 1, CAN_CS, false, CAN_CS>
+                                 : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 0, CAN_CS, false, CAN_CS>;
+            }
+        }
+    } else if (a.out_fmt && !cs) return hipErrorInvalidValue;
+    static bool attr_done[2][4][3] = {};
+    if (!attr_done[a.in_fmt ? 1 : 0][dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_done[dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode] = true;
+        attr_done[a.in_fmt ? 1 : 0][dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode] = true;
     }
     long long nwg = (long long)a.mtiles * a.ntiles;
     // Grid tail: with `slots` workgroups resident, the last tiles % slots tiles run on a mostly idle chip.  Split their K range
@@ -1759,7 +1976,8 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * (CW + 4)), smem, s, a);
     if (a.tail_ksplit > 1) {
         const int ntail = (int)((long long)a.mtiles * a.ntiles - a.n_main);
-        hipLaunchKernelGGL((tail_fixup_kernel<BM, BN, NT == 2>), dim3(BM * BN / 4 / 256, ntail), dim3(256), 0, s, a);
+        if (a.out_fmt) hipLaunchKernelGGL((tail_fixup_h2_kernel<BM, BN>), dim3(BM * BN / 8 / 256, ntail), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((tail_fixup_kernel<BM, BN, NT == 2>), dim3(BM * BN / 4 / 256, ntail), dim3(256), 0, s, a);
     }
 #ifdef DGP_DIAG
     if (a.dbg) {
@@ -2065,7 +2283,7 @@ hipError_t launch_head_gather(const float* T, const float* bias, int B, int h, i
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool3x3s2_same(const float* __restrict__ x, int N, int H, int W,
                                                          int C4, int Ho, int Wo, int pt, int pl,
-                                                         float* __restrict__ y) {
+                                                         float* __restrict__ y, float h2_scale) {
     const long long total = (long long)N * Ho * Wo * C4;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total;
          g += (long long)gridDim.x * blockDim.x) {
@@ -2090,11 +2308,63 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_same(const float* __restrict
                 m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
             }
         }
+        if (h2_scale > 0.f) {      // H2 output: this thread's 4 channels are one half of an 8-channel cell pair [hi 16 B | lo 16 B]
+            uint2 ph, pl2;
+            split2_f16(m, h2_scale, ph, pl2);
+            uint2* cell = reinterpret_cast<uint2*>(y + (g - c4 + (c4 & ~1)) * 4);      // first float slot of the 8-channel group
+            cell[c4 & 1] = ph;
+            cell[2 + (c4 & 1)] = pl2;
+        } else
         *reinterpret_cast<float4*>(y + g * 4) = m;
     }
 }
 
-hipError_t launch_maxpool(const float* x, int N, int H, int W, int C, float* y, hipStream_t s) {
+// fp32 <-> H2 cells, one thread per 8-channel group (test / boundary helpers: the engine's kernels convert in their epilogues)
+__global__ __launch_bounds__(256) void f32_to_h2_kernel(const float4* __restrict__ x, long long ng, float scale, uint4* __restrict__ out) {
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < ng; g += (long long)gridDim.x * blockDim.x) {
+        const float4 a = x[2 * g], b = x[2 * g + 1];
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint4 hi, lo;
+        h2_pack8(v, scale, hi, lo);
+        out[2 * g] = hi; out[2 * g + 1] = lo;
+    }
+}
+__global__ __launch_bounds__(256) void h2_to_f32_kernel(const uint4* __restrict__ x, long long ng, float inv_scale, float4* __restrict__ out) {
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < ng; g += (long long)gridDim.x * blockDim.x) {
+        float v[8];
+        h2_unpack8(x[2 * g], x[2 * g + 1], inv_scale, v);
+        out[2 * g] = make_float4(v[0], v[1], v[2], v[3]); out[2 * g + 1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+hipError_t launch_f32_to_h2(const float* x, long long ng, float scale, void* out, hipStream_t s) {
+    long long blocks = (ng + 255) / 256; if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(f32_to_h2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x), ng, scale, reinterpret_cast<uint4*>(out));
+    return hipGetLastError();
+}
+hipError_t launch_h2_to_f32(const void* x, long long ng, float inv_scale, float* out, hipStream_t s) {
+    long long blocks = (ng + 255) / 256; if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(h2_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(x), ng, inv_scale, reinterpret_cast<float4*>(out));
+    return hipGetLastError();
+}
+
+// One wave per layer: flag[0] |= 1 when max |tensor| * 2^exp of a layer leaves the range the fp16 high parts can hold (inf in the
+// cells); flag[1] counts the launches.  exps[li] == INT_MIN marks a layer whose output is not an H2 tensor.
+__global__ __launch_bounds__(64) void h2_range_check_kernel(const float* __restrict__ amax, const int* __restrict__ exps, int n_layers,
+                                                           int* __restrict__ flag) {
+    const int li = blockIdx.x, lane = threadIdx.x;
+    if (li >= n_layers || exps[li] == (int)0x80000000) return;
+    float mx = 0.f;
+    for (int i = lane; i < ABSMAX_SLOTS; i += 64) mx = fmaxf(mx, amax[(size_t)li * ABSMAX_SLOTS + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0 && (!(ldexpf(mx, exps[li]) < 60000.f))) atomicOr(flag, 1);          // (NaN compares false: flagged too)
+}
+hipError_t launch_h2_range_check(const float* amax_slots, const int* exps, int n_layers, int* flag, hipStream_t s) {
+    hipLaunchKernelGGL(h2_range_check_kernel, dim3((unsigned)n_layers), dim3(64), 0, s, amax_slots, exps, n_layers, flag);
+    return hipGetLastError();
+}
+
+hipError_t launch_maxpool(const float* x, int N, int H, int W, int C, float* y, hipStream_t s, float h2_scale) {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const int pth = ((Ho - 1) * 2 + 3 - H) > 0 ? ((Ho - 1) * 2 + 3 - H) : 0;
     const int ptw = ((Wo - 1) * 2 + 3 - W) > 0 ? ((Wo - 1) * 2 + 3 - W) : 0;
@@ -2102,7 +2372,7 @@ hipError_t launch_maxpool(const float* x, int N, int H, int W, int C, float* y, 
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(maxpool3x3s2_same, dim3((unsigned)blocks), dim3(256), 0, s, x, N, H, W, C / 4, Ho, Wo,
-                       pth / 2, ptw / 2, y);
+                       pth / 2, ptw / 2, y, h2_scale);
     return hipGetLastError();
 }
 

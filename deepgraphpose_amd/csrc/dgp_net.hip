@@ -351,6 +351,12 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
     HIP_TRY(hipDeviceSynchronize());
     net->wmax_valid = true;
     net->loaded = true;
+    net->h2_calibrated = false;                 // new weights, new ranges
+    net->h2_head = 4;
+    net->act_exp.assign(net->layers.size(), 0);
+    net->unit_fuse_ok.assign(net->units.size(), 1);
+    if (!net->d_exps) HIP_TRY(hipMalloc(&net->d_exps, net->layers.size() * sizeof(int)));
+    if (!net->d_flag) { HIP_TRY(hipMalloc(&net->d_flag, 2 * sizeof(int))); HIP_TRY(hipMemset(net->d_flag, 0, 2 * sizeof(int))); }
     return DGP_OK;
 }
 
@@ -414,13 +420,23 @@ double conv_flops_of(const ConvLayer& l, int M, bool is_head) {
     return 2.0 * M * (double)l.KH * l.KW * cin * l.Cout;
 }
 
+// H2 formats / scale exponents of a launch's tensors (all zero: fp32 everywhere)
+struct H2Spec { int in_fmt = 0, in_exp = 0, out_fmt = 0, out_exp = 0, res_fmt = 0, res_exp = 0; };
+
+void apply_h2(ConvArgs& a, const H2Spec& h) {
+    a.in_fmt = h.in_fmt; a.out_fmt = h.out_fmt; a.res_fmt = h.res_fmt;
+    a.in_scale = ldexpf(1.f, h.in_exp); a.out_scale = ldexpf(1.f, h.out_exp); a.res_inv_scale = ldexpf(1.f, -h.res_exp);
+}
+
 int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, int W, int pad_t, int pad_l, int Ho, int Wo,
              const float* res, int res_s, int res_H, int res_W, bool relu, int out_mode, int dc_nj, float* out,
-             hipStream_t s, float* slabs = nullptr, const float* in_absmax = nullptr) {
+             hipStream_t s, float* slabs = nullptr, const float* in_absmax = nullptr, const H2Spec& h2 = H2Spec()) {
     ConvArgs a{};
     const int li = (int)(&l - net->layers.data());
     if (!net->wmax_valid) in_absmax = nullptr;
-    a.in_absmax = in_absmax; a.w_absmax = in_absmax ? net->wmax(li) : nullptr;
+    apply_h2(a, h2);
+    const bool ranged = in_absmax || h2.in_fmt;
+    a.in_absmax = in_absmax; a.w_absmax = ranged ? net->wmax(li) : nullptr;
     a.out_absmax = out_mode == 0 ? net->amax(li) : nullptr;
     a.slab = net->tail_slab; a.slab_bytes = net->tail_slab_bytes;
     a.in = in; a.wpk = l.d_w; a.scale = l.has_bn ? l.d_scale : nullptr; a.bias = l.d_bias; a.res = res; a.out = out;
@@ -447,8 +463,8 @@ int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, in
         a.w_bytes = (unsigned)((size_t)7 * 8 * l.CoutP * 16);
     }
     static const bool use_cells = !(getenv("DGP_PRESPLIT_WEIGHTS") && atoi(getenv("DGP_PRESPLIT_WEIGHTS")) == 0);   // A/B switch
-    if (use_cells && in_absmax && l.d_wh3 && (li != net->conv1 || a.stem)) { a.wh3 = l.d_wh3; a.wh3_bytes = a.w_bytes; }
-    const int tile_cfg = pick_tile(a.M, a.CoutP, a.nk * BK, a.in_absmax && a.w_absmax);
+    if (use_cells && ranged && l.d_wh3 && (li != net->conv1 || a.stem)) { a.wh3 = l.d_wh3; a.wh3_bytes = a.w_bytes; }
+    const int tile_cfg = pick_tile(a.M, a.CoutP, a.nk * BK, ranged && a.w_absmax);
     ProfScope ps(net, s, "conv:" + l.scope + "|" + conv_kernel_name(a, tile_cfg), conv_flops_of(l, a.M, out_mode == 1));
     const long long out_n = (long long)N * 4 * Ho * Wo * dc_nj;
     if (out_mode == 1 && slabs && (out_n & 3) == 0) {
@@ -475,10 +491,11 @@ int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, in
 // out[2 ho + a][2 wo + b][c] = bias[c] + sum over taps (kh', kw') of T[ho - 1 + kh'][wo - 1 + kw'][(kh', kw'), (a, b), c]
 // (taps outside the map contribute nothing; fixed summation order).  T lives in the (free) R1 region of the workspace.
 int run_head_pointwise(dgp_net* net, const ConvLayer& l, const float* feat, int B, int h, int w, int njt, float* out, hipStream_t s,
-                       float* T, const float* feat_absmax) {
+                       float* T, const float* feat_absmax, const H2Spec& h2 = H2Spec()) {
     const int li = (int)(&l - net->layers.data());
     const int nl = (int)net->layers.size();
     ConvArgs a{};
+    apply_h2(a, h2);
     a.in = feat; a.wpk = l.d_w_pw; a.wh3 = l.d_wh3_pw; a.out = T;
     a.in_absmax = feat_absmax; a.w_absmax = net->d_wmax + (size_t)(nl + li) * ABSMAX_SLOTS;
     a.slab = net->tail_slab; a.slab_bytes = net->tail_slab_bytes;
@@ -500,12 +517,13 @@ int run_head_pointwise(dgp_net* net, const ConvLayer& l, const float* feat, int 
 
 // conv3 and the shortcut conv of a unit as one K-concatenated 1x1 conv: out = relu([r2 | x] Wf + bf)
 int run_conv_fused_shortcut(dgp_net* net, const Unit& u, const float* r2, const float* x, int N, int H, int W, float* out,
-                            hipStream_t s, const float* r2_absmax, const float* x_absmax) {
+                            hipStream_t s, const float* r2_absmax, const float* x_absmax, const H2Spec& h2 = H2Spec()) {
     const ConvLayer& l = net->layers[u.c3];
     const ConvLayer& ls = net->layers[u.sc];
     const int nl = (int)net->layers.size();
     if (!net->wmax_valid) { r2_absmax = nullptr; x_absmax = nullptr; }
     ConvArgs a{};
+    apply_h2(a, h2);
     a.in = r2; a.in2 = x; a.cin_split = l.Cin; a.Cin = l.Cin + l.cin2; a.log2cin4 = 0;
     a.wpk = l.d_w_fused; a.scale = nullptr; a.bias = l.d_bias_fused; a.res = nullptr; a.out = out;
     a.N = N; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.Cout = l.Cout; a.CoutP = l.CoutP;
@@ -517,13 +535,13 @@ int run_conv_fused_shortcut(dgp_net* net, const Unit& u, const float* r2, const 
         return fail(DGP_ERR_INVALID, "activation tensor exceeds the 4 GiB buffer-descriptor range; lower the batch");
     a.in_bytes = (unsigned)inb; a.in2_bytes = (unsigned)in2b; a.out_bytes = (unsigned)outb;
     a.w_bytes = (unsigned)((size_t)l.nk_fused * 8 * l.CoutP * 16);
-    if (r2_absmax && x_absmax) {
+    if ((r2_absmax && x_absmax) || h2.in_fmt) {
         a.in_absmax = r2_absmax; a.in2_absmax = x_absmax; a.w_absmax = net->wmax(nl + u.c3);
         a.wh3 = l.d_wh3_fused; a.wh3_bytes = a.w_bytes;
     }
     a.out_absmax = net->amax(u.c3);
     a.slab = net->tail_slab; a.slab_bytes = net->tail_slab_bytes;
-    const int tile_cfg = pick_tile(a.M, a.CoutP, a.nk * BK, a.in_absmax && a.w_absmax);
+    const int tile_cfg = pick_tile(a.M, a.CoutP, a.nk * BK, (a.in_absmax || a.in_fmt) && a.w_absmax);
     ProfScope ps(net, s, "conv:" + l.scope + "+shortcut|" + conv_kernel_name(a, tile_cfg),
                  conv_flops_of(l, a.M, false) + conv_flops_of(ls, a.M, false));
     hipError_t e = launch_conv(a, tile_cfg, s);
@@ -607,64 +625,171 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     rc = run_conv(net, net->layers[net->conv1], P0, B, d.in_h, d.in_w, 3, 3, net->h1, net->w1, nullptr, 0, 0, 0, true, 0,
                   0, C1, s, nullptr, net->d_inmax);
     if (rc) return rc;
+    // ---- activation format of this forward.  H2 (default): every tensor from the pool output to the block4 features lives in HBM as
+    // fp16 high / low cells with a calibrated per-tensor scale, so the conv kernels' K loops are ds_read + MFMA only (DGP_H2=0: fp32
+    // activations, split in the consumers' K loops -- also what the other DGP_CONV_MODEs and a trainer-owned net use).
+    static const bool h2_env = !(getenv("DGP_H2") && atoi(getenv("DGP_H2")) == 0);
+    static const bool f16_mode = !getenv("DGP_CONV_MODE") || !strcmp(getenv("DGP_CONV_MODE"), "f16x3");
+    static const bool head_pw = !(getenv("DGP_HEAD_PW") && atoi(getenv("DGP_HEAD_PW")) == 0);      // A/B switch
+    static const bool fuse_env = !(getenv("DGP_FUSE_SHORTCUT") && atoi(getenv("DGP_FUSE_SHORTCUT")) == 0);      // A/B switch
+    static const bool f32_mode = getenv("DGP_CONV_MODE") && !strcmp(getenv("DGP_CONV_MODE"), "f32");
+    const bool h2 = h2_env && f16_mode && head_pw && net->wmax_valid && net->d_exps && net->layers[net->head_part].d_wh3_pw &&
+                    (net->head_locref < 0 || net->layers[net->head_locref].d_wh3_pw) && net->act_exp.size() == net->layers.size();
+    const bool calib = h2 && !net->h2_calibrated;
+    const int H2_HEAD = net->h2_head;             // bits of headroom between a calibrated maximum and the fp16 limit
+    auto exp_for = [H2_HEAD](float mx) {          // scale exponent that puts mx into [2^(14 - H2_HEAD), 2^(15 - H2_HEAD))
+        if (!(mx > 0.f) || !std::isfinite(mx)) return 0;
+        int ex; (void)frexpf(mx, &ex);            // mx = f 2^ex, f in [0.5, 1)
+        return (14 - H2_HEAD) - (ex - 1);
+    };
+    auto read_range = [&](int li, float* mx) -> int {
+        float host[ABSMAX_SLOTS];
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(host, net->amax(li), sizeof host, hipMemcpyDeviceToHost));
+        float m = 0.f;
+        for (float v : host) m = (v > m || v != v) ? v : m;
+        *mx = m;
+        return DGP_OK;
+    };
+    // calibration: launch, read the layer's range, fix the exponent, launch again if it changed (first forward only: hidden syncs)
+    auto layer = [&](int li, auto&& launch, int forced_exp = dgp_net::H2_NONE, bool* forced_ok = nullptr) -> int {
+        int r = launch();
+        if (r || !calib) return r;
+        float mx = 0.f;
+        if ((r = read_range(li, &mx))) return r;
+        int e = exp_for(mx);
+        if (forced_exp != dgp_net::H2_NONE) {     // must share another tensor's scale (K-concatenated second source)
+            const bool ok = forced_exp <= e + H2_HEAD - 1 && forced_exp >= e - 6;
+            if (forced_ok) *forced_ok = ok;
+            if (ok) e = forced_exp;
+        }
+        if (e != net->act_exp[li]) {
+            net->act_exp[li] = e;
+            HIP_TRY(hipMemsetAsync(net->amax(li), 0, ABSMAX_SLOTS * sizeof(float), s));
+            r = launch();
+        }
+        return r;
+    };
+    if (calib) {
+        float mx = 0.f;
+        if ((rc = read_range(net->conv1, &mx))) return rc;
+        net->act_exp[net->conv1] = exp_for(mx);   // (max-pooling cannot raise the maximum of conv1's output)
+    }
+    const int pool_exp = h2 ? net->act_exp[net->conv1] : 0;
     {
         ProfScope ps(net, s, "maxpool3x3s2", 0.0);
-        e = launch_maxpool(C1, B, net->h1, net->w1, 64, X[0], s);
+        e = launch_maxpool(C1, B, net->h1, net->w1, 64, X[0], s, h2 ? ldexpf(1.f, pool_exp) : 0.f);
     }
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("maxpool: ") + hipGetErrorString(e));
 
     int cur = 0, h = net->hp, w = net->wp;
     const float* x_rng = net->amax(net->conv1);      // max-pooling cannot raise the maximum of conv1's output
+    int x_exp = pool_exp;
+    int ui = 0;
     for (const Unit& u : net->units) {
         const int ho = (h + u.stride - 1) / u.stride, wo = (w + u.stride - 1) / u.stride;
         const float* xin = X[cur];
         float* xout = X[cur ^ 1];
         const float* res = xin;
         int res_s = u.stride, res_H = h, res_W = w;
-        static const bool fuse_env = !(getenv("DGP_FUSE_SHORTCUT") && atoi(getenv("DGP_FUSE_SHORTCUT")) == 0);      // A/B switch
-        static const bool f32_mode = getenv("DGP_CONV_MODE") && !strcmp(getenv("DGP_CONV_MODE"), "f32");
-        const bool fuse = fuse_env && !f32_mode && net->wmax_valid && u.sc >= 0 && net->layers[u.c3].d_w_fused && u.stride == 1 && ho == h && wo == w &&
-                          net->layers[u.c3].CoutP % 64 == 0;
-        if (u.sc >= 0 && !fuse) {
-            // slim.conv2d(1x1, stride, SAME): pad 0, samples x[::s, ::s]
-            rc = run_conv(net, net->layers[u.sc], xin, B, h, w, 0, 0, ho, wo, nullptr, 0, 0, 0, false, 0, 0, SC, s, nullptr, x_rng);
-            if (rc) return rc;
-            res = SC; res_s = 1; res_H = ho; res_W = wo;
-        }
-        rc = run_conv(net, net->layers[u.c1], xin, B, h, w, 0, 0, h, w, nullptr, 0, 0, 0, true, 0, 0, R1, s, nullptr, x_rng);
-        if (rc) return rc;
+        int res_exp = x_exp;
+        const bool can_fuse = fuse_env && !f32_mode && net->wmax_valid && u.sc >= 0 && net->layers[u.c3].d_w_fused && u.stride == 1 && ho == h && wo == w &&
+                              net->layers[u.c3].CoutP % 64 == 0;
+        bool fuse = can_fuse && (!h2 || calib || net->unit_fuse_ok[ui]);
         const int pb_h = pad_before_for(h, 3, u.stride, u.rate, true);
         const int pb_w = pad_before_for(w, 3, u.stride, u.rate, true);
-        rc = run_conv(net, net->layers[u.c2], R1, B, h, w, pb_h, pb_w, ho, wo, nullptr, 0, 0, 0, true, 0, 0, R2, s, nullptr,
-                      net->amax(u.c1));
-        if (rc) return rc;
-        if (fuse)
-            rc = run_conv_fused_shortcut(net, u, R2, xin, B, h, w, xout, s, net->amax(u.c2), x_rng);
-        else
-            rc = run_conv(net, net->layers[u.c3], R2, B, ho, wo, 0, 0, ho, wo, res, res_s, res_H, res_W, true, 0, 0, xout, s,
-                          nullptr, net->amax(u.c2));
-        if (rc) return rc;
+        if (!h2) {
+            if (u.sc >= 0 && !fuse) {
+                // slim.conv2d(1x1, stride, SAME): pad 0, samples x[::s, ::s]
+                rc = run_conv(net, net->layers[u.sc], xin, B, h, w, 0, 0, ho, wo, nullptr, 0, 0, 0, false, 0, 0, SC, s, nullptr, x_rng);
+                if (rc) return rc;
+                res = SC; res_s = 1; res_H = ho; res_W = wo;
+            }
+            rc = run_conv(net, net->layers[u.c1], xin, B, h, w, 0, 0, h, w, nullptr, 0, 0, 0, true, 0, 0, R1, s, nullptr, x_rng);
+            if (rc) return rc;
+            rc = run_conv(net, net->layers[u.c2], R1, B, h, w, pb_h, pb_w, ho, wo, nullptr, 0, 0, 0, true, 0, 0, R2, s, nullptr,
+                          net->amax(u.c1));
+            if (rc) return rc;
+            if (fuse)
+                rc = run_conv_fused_shortcut(net, u, R2, xin, B, h, w, xout, s, net->amax(u.c2), x_rng);
+            else
+                rc = run_conv(net, net->layers[u.c3], R2, B, ho, wo, 0, 0, ho, wo, res, res_s, res_H, res_W, true, 0, 0, xout, s,
+                              nullptr, net->amax(u.c2));
+            if (rc) return rc;
+        } else {
+            auto spec = [&](int in_exp, int out_li, int r_fmt = 0, int r_exp = 0) {
+                H2Spec q; q.in_fmt = 1; q.in_exp = in_exp; q.out_fmt = 1; q.out_exp = net->act_exp[out_li]; q.res_fmt = r_fmt; q.res_exp = r_exp;
+                return q;
+            };
+            rc = layer(u.c1, [&] { return run_conv(net, net->layers[u.c1], xin, B, h, w, 0, 0, h, w, nullptr, 0, 0, 0, true, 0, 0, R1, s,
+                                                   nullptr, nullptr, spec(x_exp, u.c1)); });
+            if (rc) return rc;
+            bool share_ok = true;
+            rc = layer(u.c2, [&] { return run_conv(net, net->layers[u.c2], R1, B, h, w, pb_h, pb_w, ho, wo, nullptr, 0, 0, 0, true, 0, 0, R2, s,
+                                                   nullptr, nullptr, spec(net->act_exp[u.c1], u.c2)); },
+                       (fuse && calib) ? x_exp : dgp_net::H2_NONE, &share_ok);
+            if (rc) return rc;
+            if (calib && can_fuse) { net->unit_fuse_ok[ui] = share_ok ? 1 : 0; fuse = share_ok; }
+            if (u.sc >= 0 && !fuse) {
+                rc = layer(u.sc, [&] { return run_conv(net, net->layers[u.sc], xin, B, h, w, 0, 0, ho, wo, nullptr, 0, 0, 0, false, 0, 0, SC, s,
+                                                       nullptr, nullptr, spec(x_exp, u.sc)); });
+                if (rc) return rc;
+                res = SC; res_s = 1; res_H = ho; res_W = wo; res_exp = net->act_exp[u.sc];
+            }
+            if (fuse)
+                rc = layer(u.c3, [&] { return run_conv_fused_shortcut(net, u, R2, xin, B, h, w, xout, s, nullptr, nullptr,
+                                                                      spec(x_exp, u.c3)); });      // R2 shares X's scale (calibration)
+            else
+                rc = layer(u.c3, [&] { return run_conv(net, net->layers[u.c3], R2, B, ho, wo, 0, 0, ho, wo, res, res_s, res_H, res_W, true, 0,
+                                                       0, xout, s, nullptr, nullptr, spec(net->act_exp[u.c2], u.c3, 1, res_exp)); });
+            if (rc) return rc;
+            x_exp = net->act_exp[u.c3];
+        }
         x_rng = net->amax(u.c3);
         cur ^= 1; h = ho; w = wo;
+        ++ui;
     }
     const float* feat = X[cur];
-    if (features)
-        HIP_TRY(hipMemcpyAsync(features, feat, (size_t)B * h * w * 2048 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (features) {
+        if (h2) {
+            e = launch_h2_to_f32(feat, (long long)B * h * w * 2048 / 8, ldexpf(1.f, -x_exp), features, s);
+            if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("features: ") + hipGetErrorString(e));
+        } else
+            HIP_TRY(hipMemcpyAsync(features, feat, (size_t)B * h * w * 2048 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
     float* sm = scmap ? scmap : (float*)(ws + pl.off_scmap);
     float* slabs = (float*)(ws + pl.off_slabs);
-    static const bool head_pw = !(getenv("DGP_HEAD_PW") && atoi(getenv("DGP_HEAD_PW")) == 0);      // A/B switch
-    static const bool f16_mode = !getenv("DGP_CONV_MODE") || !strcmp(getenv("DGP_CONV_MODE"), "f16x3");
-    const bool pw = head_pw && f16_mode && net->wmax_valid && x_rng && net->layers[net->head_part].d_wh3_pw;
-    if (pw) rc = run_head_pointwise(net, net->layers[net->head_part], feat, B, h, w, d.num_joints, sm, s, R1, x_rng);
+    H2Spec hs;
+    if (h2) { hs.in_fmt = 1; hs.in_exp = x_exp; }
+    const bool pw = h2 || (head_pw && f16_mode && net->wmax_valid && x_rng && net->layers[net->head_part].d_wh3_pw);
+    if (pw) rc = run_head_pointwise(net, net->layers[net->head_part], feat, B, h, w, d.num_joints, sm, s, R1, x_rng, hs);
     else rc = run_conv(net, net->layers[net->head_part], feat, B, h, w, 1, 1, h, w, nullptr, 0, 0, 0, false, 1, d.num_joints,
                        sm, s, slabs);
     if (rc) return rc;
     if (locref) {
         if (pw && net->layers[net->head_locref].d_wh3_pw)
-            rc = run_head_pointwise(net, net->layers[net->head_locref], feat, B, h, w, 2 * d.num_joints, locref, s, R1, x_rng);
+            rc = run_head_pointwise(net, net->layers[net->head_locref], feat, B, h, w, 2 * d.num_joints, locref, s, R1, x_rng, hs);
         else rc = run_conv(net, net->layers[net->head_locref], feat, B, h, w, 1, 1, h, w, nullptr, 0, 0, 0, false, 1,
                            2 * d.num_joints, locref, s, slabs);
         if (rc) return rc;
+    }
+    if (h2) {
+        if (calib) {                      // freeze the scales: the device copy feeds the per-forward range check
+            std::vector<int> ex(net->layers.size(), dgp_net::H2_NONE);
+            ex[net->conv1] = net->act_exp[net->conv1];
+            int k = 0;
+            for (const Unit& u : net->units) {
+                ex[u.c1] = net->act_exp[u.c1]; ex[u.c2] = net->act_exp[u.c2]; ex[u.c3] = net->act_exp[u.c3];
+                if (u.sc >= 0) ex[u.sc] = net->act_exp[u.sc];       // (an unlaunched shortcut conv tracks 0: never flagged)
+                ++k;
+            }
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipMemcpy(net->d_exps, ex.data(), ex.size() * sizeof(int), hipMemcpyHostToDevice));
+            net->h2_calibrated = true;
+            ++net->h2_calibrations;
+        }
+        e = launch_h2_range_check(net->d_amax, net->d_exps, (int)net->layers.size(), net->d_flag, s);
+        if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("range check: ") + hipGetErrorString(e));
     }
     if (net->prof_on && net->prof_used < net->prof_slots && !net->prof_in_infer) ++net->prof_used;
     return DGP_OK;
@@ -925,6 +1050,76 @@ int dgp_conv2d_ranged(const dgp_conv_desc* d, const float* x, const float* packe
     }
     hipError_t e = launch_conv(a, pick_tile(a.M, a.CoutP, a.nk * BK, x_absmax && w_absmax), (hipStream_t)stream);
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_conv2d: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
+/* ---- H2 activation format at the boundary (tests, PoseNet.extract_features): converters, a single conv layer on H2 tensors, and
+ * the engine's range status.  See ConvArgs::in_fmt (csrc/dgp_internal.h) and DESIGN.md section 3. */
+int dgp_f32_to_h2(const float* x, size_t n_floats, int32_t scale_exp, void* out, void* stream) {
+    if (!x || !out || (n_floats & 7)) return fail(DGP_ERR_INVALID, "dgp_f32_to_h2: null argument / length not a multiple of 8");
+    hipError_t e = launch_f32_to_h2(x, (long long)(n_floats / 8), ldexpf(1.f, scale_exp), out, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_f32_to_h2: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
+int dgp_h2_to_f32(const void* x, size_t n_floats, int32_t scale_exp, float* out, void* stream) {
+    if (!x || !out || (n_floats & 7)) return fail(DGP_ERR_INVALID, "dgp_h2_to_f32: null argument / length not a multiple of 8");
+    hipError_t e = launch_h2_to_f32(x, (long long)(n_floats / 8), ldexpf(1.f, -scale_exp), out, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_h2_to_f32: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
+int dgp_conv2d_h2(const dgp_conv_desc* d, const void* x_h2, int32_t x_exp, const float* packed_w, const float* w_absmax,
+                  const float* scale, const float* bias, const void* residual, int32_t res_is_h2, int32_t res_exp, void* y,
+                  int32_t y_is_h2, int32_t y_exp, float* y_absmax, void* cells_scratch, void* stream) {
+    if (!d || !x_h2 || !packed_w || !w_absmax || !y || !cells_scratch) return fail(DGP_ERR_INVALID, "dgp_conv2d_h2: null argument");
+    if (d->Cin < 32 || (d->Cin & 7) || ((d->Cin / 4) & (d->Cin / 4 - 1)) || (d->Cout & 7))
+        return fail(DGP_ERR_INVALID, "dgp_conv2d_h2: Cin must be 4 * 2^k >= 32, Cout a multiple of 8");
+    if (d->res_stride > 0 && !residual) return fail(DGP_ERR_INVALID, "dgp_conv2d_h2: residual missing");
+    ConvArgs a{};
+    a.in = (const float*)x_h2; a.wpk = packed_w; a.scale = scale; a.bias = bias; a.res = d->res_stride > 0 ? (const float*)residual : nullptr;
+    a.out = (float*)y; a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.log2cin4 = ilog2(d->Cin / 4);
+    a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.CoutP = coutp_for(d->Cout);
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.dil = d->rate; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
+    a.ntaps = d->KH * d->KW; a.nk = nk_for(d->KH, d->KW, d->Cin); a.M = d->N * d->Ho * d->Wo;
+    a.res_s = d->res_stride; a.res_H = d->res_H; a.res_W = d->res_W; a.relu = d->relu;
+    const double lim = 4294967000.0;
+    const double inb = (double)d->N * d->H * d->W * d->Cin * 4, outb = (double)a.M * d->Cout * 4;
+    const double resb = a.res ? (double)d->N * d->res_H * d->res_W * d->Cout * 4 : 0.0;
+    if (inb > lim || outb > lim || resb > lim) return fail(DGP_ERR_INVALID, "dgp_conv2d_h2: tensor exceeds 4 GiB");
+    a.in_bytes = (unsigned)inb; a.out_bytes = (unsigned)outb; a.res_bytes = (unsigned)resb;
+    a.w_bytes = (unsigned)((size_t)a.nk * 8 * a.CoutP * 16);
+    H2Spec h; h.in_fmt = 1; h.in_exp = x_exp; h.out_fmt = y_is_h2 ? 1 : 0; h.out_exp = y_exp; h.res_fmt = res_is_h2 ? 1 : 0; h.res_exp = res_exp;
+    apply_h2(a, h);
+    a.w_absmax = w_absmax; a.out_absmax = y_absmax;
+    hipError_t pe = launch_pack_h3(packed_w, a.nk, a.CoutP, w_absmax, cells_scratch, (hipStream_t)stream);
+    if (pe != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_conv2d_h2: pack cells: ") + hipGetErrorString(pe));
+    a.wh3 = cells_scratch; a.wh3_bytes = a.w_bytes;
+    hipError_t e = launch_conv(a, pick_tile(a.M, a.CoutP, a.nk * BK, true), (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_conv2d_h2: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
+int dgp_net_range_status(dgp_net* net, int32_t* overflow, int32_t* calibrations, void* stream) {
+    if (!net) return fail(DGP_ERR_INVALID, "dgp_net_range_status: null net");
+    int flag[2] = {0, 0};
+    if (net->d_flag) {
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        HIP_TRY(hipMemcpy(flag, net->d_flag, sizeof flag, hipMemcpyDeviceToHost));
+        if (flag[0]) {
+            HIP_TRY(hipMemset(net->d_flag, 0, sizeof flag));
+            net->h2_calibrated = false;         // the next forward re-calibrates on its batch, with more headroom: a quiet first
+            net->h2_head = std::min(net->h2_head + 3, 12);      // batch must not under-size the scales again (costs no accuracy up to ~10 bits)
+        }
+    }
+    if (overflow) *overflow = flag[0] ? 1 : 0;
+    if (calibrations) *calibrations = net->h2_calibrations;
+    return DGP_OK;
+}
+
+int dgp_net_recalibrate(dgp_net* net) {
+    if (!net) return fail(DGP_ERR_INVALID, "dgp_net_recalibrate: null net");
+    net->h2_calibrated = false;
     return DGP_OK;
 }
 

@@ -169,6 +169,18 @@ class DGPNet:
         return mu, conf, idx
 
 
+    def range_status(self) -> Tuple[bool, int]:
+        """(overflow, calibrations).  Synchronises the stream.  overflow: a forward since the last call outgrew the calibrated scale of
+        one of its H2 activation tensors (include/dgp_hip.h, "H2"): its results are invalid, the flag is cleared and the next
+        forward re-calibrates on its own batch -- re-run what was computed since the last clean status."""
+        ov, nc = C.c_int32(), C.c_int32()
+        _lib.check(self.lib.dgp_net_range_status(self._h, C.byref(ov), C.byref(nc), _stream(self.device)), "dgp_net_range_status")
+        return bool(ov.value), nc.value
+
+    def recalibrate(self):
+        """Force a calibration pass of the activation scales on the next forward."""
+        _lib.check(self.lib.dgp_net_recalibrate(self._h), "dgp_net_recalibrate")
+
     def infer_packed(self, frames: torch.Tensor, traj: torch.Tensor, gamma: float = 1.0, gauss_len: int = 1,
                      scmap_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Fused frames -> traj [B,nj,5] fp32 lanes (row, col, likelihood, iy, ix; indices as int32 bit patterns): the record
@@ -326,6 +338,62 @@ def conv2d_dgrad(dy: torch.Tensor, w_hwio: torch.Tensor, x_hw: Tuple[int, int], 
     _lib.check(lib.dgp_conv2d_dgrad(C.byref(d), _ptr(dy), _ptr(w_hwio), _ptr(scale), _ptr(mask), _ptr(dx_add), add_mode, _ptr(dx),
                                     _ptr(scratch), int(ranged), _stream(dev)), "dgp_conv2d_dgrad")
     return dx
+
+
+def h2_exp_for(absmax: float, headroom_bits: int = 4) -> int:
+    """The engine's scale rule: exponent e with absmax * 2^e in [2^(14 - headroom), 2^(15 - headroom))."""
+    import math
+    if not (absmax > 0) or not math.isfinite(absmax):
+        return 0
+    return (14 - headroom_bits) - (math.frexp(absmax)[1] - 1)
+
+
+def f32_to_h2(x: torch.Tensor, scale_exp: int) -> torch.Tensor:
+    """fp32 [..., C] (C % 8 == 0) -> H2 cells (fp16 high / low pairs per 8 channels, x * 2^scale_exp), same shape, viewed as fp32 bits."""
+    lib = _lib.load()
+    _need_cuda(x, torch.float32, "x")
+    out = torch.empty_like(x)
+    _lib.check(lib.dgp_f32_to_h2(_ptr(x), x.numel(), int(scale_exp), _ptr(out), _stream(x.device)), "dgp_f32_to_h2")
+    return out
+
+
+def h2_to_f32(x: torch.Tensor, scale_exp: int) -> torch.Tensor:
+    lib = _lib.load()
+    _need_cuda(x, torch.float32, "x")
+    out = torch.empty_like(x)
+    _lib.check(lib.dgp_h2_to_f32(_ptr(x), x.numel(), int(scale_exp), _ptr(out), _stream(x.device)), "dgp_h2_to_f32")
+    return out
+
+
+def conv2d_h2(x_h2: torch.Tensor, x_exp: int, w_hwio: np.ndarray, stride: int = 1, rate: int = 1, pad_t: int = 0, pad_l: int = 0,
+              out_hw: Optional[Tuple[int, int]] = None, scale=None, bias=None, residual: Optional[torch.Tensor] = None,
+              res_stride: int = 0, res_is_h2: bool = False, res_exp: int = 0, relu: bool = False, y_is_h2: bool = True,
+              y_exp: int = 0):
+    """One conv layer on H2 tensors through the engine's cell kernels.  -> (y, y_absmax_slots)."""
+    lib = _lib.load()
+    _need_cuda(x_h2, torch.float32, "x_h2")
+    N, H, W, Cin = x_h2.shape
+    kh, kw, cin2, cout = w_hwio.shape
+    assert cin2 == Cin
+    dev = x_h2.device
+    if out_hw is None:
+        keh, kew = (kh - 1) * rate + 1, (kw - 1) * rate + 1
+        out_hw = ((H + 2 * pad_t - keh) // stride + 1, (W + 2 * pad_l - kew) // stride + 1)
+    Ho, Wo = out_hw
+    wp = torch.from_numpy(pack_conv_weights(w_hwio)).to(dev)
+    sc = None if scale is None else torch.as_tensor(scale, dtype=torch.float32).contiguous().to(dev)
+    bi = None if bias is None else torch.as_tensor(bias, dtype=torch.float32).contiguous().to(dev)
+    y = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=dev)
+    rh, rw = (residual.shape[1], residual.shape[2]) if residual is not None else (0, 0)
+    d = _lib.DgpConvDesc(N, H, W, Cin, cout, kh, kw, stride, rate, pad_t, pad_l, Ho, Wo, int(relu),
+                         res_stride if residual is not None else 0, rh, rw)
+    rng = torch.zeros((2, ABSMAX_SLOTS), dtype=torch.float32, device=dev)
+    _lib.check(lib.dgp_tensor_absmax(_ptr(wp), wp.numel(), _ptr(rng[0]), _stream(dev)), "dgp_tensor_absmax")
+    cells = torch.empty(wp.numel(), dtype=torch.float32, device=dev)
+    _lib.check(lib.dgp_conv2d_h2(C.byref(d), _ptr(x_h2), int(x_exp), _ptr(wp), _ptr(rng[0]), _ptr(sc), _ptr(bi), _ptr(residual),
+                                 int(res_is_h2), int(res_exp), _ptr(y), int(y_is_h2), int(y_exp), _ptr(rng[1]), _ptr(cells),
+                                 _stream(dev)), "dgp_conv2d_h2")
+    return y, rng[1]
 
 
 def maxpool_3x3s2_same(x: torch.Tensor) -> torch.Tensor:

@@ -175,109 +175,131 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
             im = im.crop(crop_size)
         return np.asarray(im)
 
-    # Host pipeline: a decode thread fills pinned staging buffers, a copy stream moves batch k+1
-    # to the GPU while batch k runs through dgp_infer on the compute stream, and the keypoints of the whole video
-    # come back in ONE device-to-host copy at the end (the reference fetched the full scoremap every frame).
-    import itertools
-    import queue
-    import threading
-    import torch
-    dev = torch.device("cuda", sess.device)
-    if world > 1 and hasattr(video_clip, "frame_at"):          # a shard starts in the middle of the video: seek
-        frames_it = (video_clip.frame_at(t) for t in range(lo, hi))
-        first = video_clip.frame_at(lo if n_local > 0 else 0)
-        if n_local > 0:
-            next(frames_it)
-    else:
-        frames_it = iter(video_clip.iter_frames())
-        first = next(frames_it, None)
-        for _ in range(lo):                                    # sources without random access: decode up to the shard
+    def _infer_once(video_clip):
+        nonlocal net_used
+        # Host pipeline: a decode thread fills pinned staging buffers, a copy stream moves batch k+1
+        # to the GPU while batch k runs through dgp_infer on the compute stream, and the keypoints of the whole video
+        # come back in ONE device-to-host copy at the end (the reference fetched the full scoremap every frame).
+        import itertools
+        import queue
+        import threading
+        import torch
+        dev = torch.device("cuda", sess.device)
+        if world > 1 and hasattr(video_clip, "frame_at"):          # a shard starts in the middle of the video: seek
+            frames_it = (video_clip.frame_at(t) for t in range(lo, hi))
+            first = video_clip.frame_at(lo if n_local > 0 else 0)
+            if n_local > 0:
+                next(frames_it)
+        else:
+            frames_it = iter(video_clip.iter_frames())
             first = next(frames_it, None)
-    if first is None:
-        raise ValueError("no frames in %s" % video_file)
-    f0 = prep(first)
-    hh, ww = f0.shape[:2]
-    net = sess.net_for(hh, ww)
-    nslots = 3
-    pinned = [torch.empty((batch_size, hh, ww, 3), dtype=torch.uint8).pin_memory() for _ in range(nslots)]
-    dbuf = [torch.empty((batch_size, hh, ww, 3), dtype=torch.uint8, device=dev) for _ in range(nslots)]
-    free_slots, ready = queue.Queue(), queue.Queue()
-    for i in range(nslots):
-        free_slots.put(i)
+            for _ in range(lo):                                    # sources without random access: decode up to the shard
+                first = next(frames_it, None)
+        if first is None:
+            raise ValueError("no frames in %s" % video_file)
+        f0 = prep(first)
+        hh, ww = f0.shape[:2]
+        net = net_used = sess.net_for(hh, ww)
+        nslots = 3
+        pinned = [torch.empty((batch_size, hh, ww, 3), dtype=torch.uint8).pin_memory() for _ in range(nslots)]
+        dbuf = [torch.empty((batch_size, hh, ww, 3), dtype=torch.uint8, device=dev) for _ in range(nslots)]
+        free_slots, ready = queue.Queue(), queue.Queue()
+        for i in range(nslots):
+            free_slots.put(i)
 
-    whole_batches = new_size is None and crop_size is None and hasattr(video_clip, "iter_batches")
+        whole_batches = new_size is None and crop_size is None and hasattr(video_clip, "iter_batches")
 
-    def producer():
-        try:
-            if whole_batches:       # in-memory stack: one GIL-free copy per batch instead of one python step per frame
-                done = 0
-                src = video_clip.frames[lo:hi] if world > 1 else None
-                chunks = (src[i:i + batch_size] for i in range(0, n_local, batch_size)) if world > 1 else \
-                    video_clip.iter_batches(batch_size)
-                for chunk in chunks:
-                    nb = min(len(chunk), n_local - done)
-                    if nb <= 0:
+        def producer():
+            try:
+                if whole_batches:       # in-memory stack: one GIL-free copy per batch instead of one python step per frame
+                    done = 0
+                    src = video_clip.frames[lo:hi] if world > 1 else None
+                    chunks = (src[i:i + batch_size] for i in range(0, n_local, batch_size)) if world > 1 else \
+                        video_clip.iter_batches(batch_size)
+                    for chunk in chunks:
+                        nb = min(len(chunk), n_local - done)
+                        if nb <= 0:
+                            break
+                        slot = free_slots.get()
+                        np.copyto(pinned[slot][:nb].numpy(), chunk[:nb])
+                        ready.put((slot, nb))
+                        done += nb
+                    ready.put(None)
+                    return
+                slot, fill, count = free_slots.get(), 0, 0
+                for fr in itertools.chain([f0], (prep(x) for x in frames_it)):
+                    if count >= n_local:
                         break
-                    slot = free_slots.get()
-                    np.copyto(pinned[slot][:nb].numpy(), chunk[:nb])
-                    ready.put((slot, nb))
-                    done += nb
-                ready.put(None)
-                return
-            slot, fill, count = free_slots.get(), 0, 0
-            for fr in itertools.chain([f0], (prep(x) for x in frames_it)):
-                if count >= n_local:
-                    break
-                pinned[slot][fill] = torch.from_numpy(np.ascontiguousarray(fr))
-                fill += 1
-                count += 1
-                if fill == batch_size:
+                    pinned[slot][fill] = torch.from_numpy(np.ascontiguousarray(fr))
+                    fill += 1
+                    count += 1
+                    if fill == batch_size:
+                        ready.put((slot, fill))
+                        slot, fill = free_slots.get(), 0
+                if fill:
                     ready.put((slot, fill))
-                    slot, fill = free_slots.get(), 0
-            if fill:
-                ready.put((slot, fill))
-            ready.put(None)
-        except BaseException as e:      # surface decode errors in the consumer
-            ready.put(e)
+                ready.put(None)
+            except BaseException as e:      # surface decode errors in the consumer
+                ready.put(e)
 
-    th = threading.Thread(target=producer, daemon=True)
-    th.start()
-    copy_stream = torch.cuda.Stream(device=dev)
-    compute = torch.cuda.current_stream(dev)
-    traj = torch.zeros((max(n_local, 1), nj, 5), dtype=torch.float32, device=dev)      # packed (row, col, likelihood, iy, ix)
-    consumed = [None] * nslots            # compute-stream event: last dgp_infer that read dbuf[slot]
-    start = 0
-    while True:
-        item = ready.get()
-        if item is None:
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        copy_stream = torch.cuda.Stream(device=dev)
+        compute = torch.cuda.current_stream(dev)
+        traj = torch.zeros((max(n_local, 1), nj, 5), dtype=torch.float32, device=dev)      # packed (row, col, likelihood, iy, ix)
+        consumed = [None] * nslots            # compute-stream event: last dgp_infer that read dbuf[slot]
+        start = 0
+        while True:
+            item = ready.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            slot, nb = item
+            with torch.cuda.stream(copy_stream):
+                if consumed[slot] is not None:
+                    copy_stream.wait_event(consumed[slot])          # do not overwrite frames still being read
+                dbuf[slot][:nb].copy_(pinned[slot][:nb], non_blocking=True)
+                copied = torch.cuda.Event()
+                copied.record(copy_stream)
+            compute.wait_event(copied)
+            net.infer_packed(dbuf[slot][:nb], traj[start:start + nb], sess.gamma, sess.gauss_len)   # written in place by the kernel
+            consumed[slot] = torch.cuda.Event()
+            consumed[slot].record(compute)
+            start += nb
+            copied.synchronize()              # the pinned buffer is free again once its H2D copy has completed
+            free_slots.put(slot)
+        th.join()
+        torch.cuda.synchronize(dev)
+        if world > 1:                                  # ONE all-gather per video: 20 bytes per (frame, joint)
+            full = ddist.gather_trajectory(traj[:n_local], n_frames)
+            mu_t, lik_t, _ = ddist.unpack_keypoints(full)
+            markers[:] = mu_t.cpu().numpy()
+            likelihoods[:] = lik_t.cpu().numpy()
+        else:
+            mu_t, lik_t, _ = ddist.unpack_keypoints(traj[:start])
+            markers[:start] = mu_t.cpu().numpy()
+            likelihoods[:start] = lik_t.cpu().numpy()
+
+    net_used = None
+    for attempt in range(4):
+        if attempt:
+            video_clip.close()
+            video_clip = open_frame_source(video_file)
+        _infer_once(video_clip)
+        # H2 activation scales (include/dgp_hip.h): a batch that outgrew the scales calibrated on the first batch invalidates its
+        # results; the engine then re-calibrates with more headroom and the video is run again (all ranks decide together)
+        overflow = bool(net_used.range_status()[0])
+        if world > 1:
+            import torch
+            flag = torch.tensor([int(overflow)], device="cuda:%d" % sess.device)
+            tdist.all_reduce(flag, op=tdist.ReduceOp.MAX)
+            overflow = bool(flag.item())
+        if not overflow:
             break
-        if isinstance(item, BaseException):
-            raise item
-        slot, nb = item
-        with torch.cuda.stream(copy_stream):
-            if consumed[slot] is not None:
-                copy_stream.wait_event(consumed[slot])          # do not overwrite frames still being read
-            dbuf[slot][:nb].copy_(pinned[slot][:nb], non_blocking=True)
-            copied = torch.cuda.Event()
-            copied.record(copy_stream)
-        compute.wait_event(copied)
-        net.infer_packed(dbuf[slot][:nb], traj[start:start + nb], sess.gamma, sess.gauss_len)   # written in place by the kernel
-        consumed[slot] = torch.cuda.Event()
-        consumed[slot].record(compute)
-        start += nb
-        copied.synchronize()              # the pinned buffer is free again once its H2D copy has completed
-        free_slots.put(slot)
-    th.join()
-    torch.cuda.synchronize(dev)
-    if world > 1:                                  # ONE all-gather per video: 20 bytes per (frame, joint)
-        full = ddist.gather_trajectory(traj[:n_local], n_frames)
-        mu_t, lik_t, _ = ddist.unpack_keypoints(full)
-        markers[:] = mu_t.cpu().numpy()
-        likelihoods[:] = lik_t.cpu().numpy()
+        print("activation ranges outgrew the calibrated scales: re-calibrating and re-running %s" % video_file, flush=True)
     else:
-        mu_t, lik_t, _ = ddist.unpack_keypoints(traj[:start])
-        markers[:start] = mu_t.cpu().numpy()
-        likelihoods[:start] = lik_t.cpu().numpy()
+        raise RuntimeError("activation scales did not settle after 4 passes over %s" % video_file)
     sess.close()
     video_clip.close()
 

@@ -244,6 +244,28 @@ int    dgp_conv2d_wgrad(const dgp_conv_desc* d, const float* x, const float* dy,
 size_t dgp_conv2d_dgrad_scratch_bytes(const dgp_conv_desc* d);
 int    dgp_conv2d_dgrad(const dgp_conv_desc* d, const float* dy, const float* w_hwio, const float* scale, const float* mask,
                         const float* dx_add, int32_t add_mode, float* dx, void* scratch, int32_t ranged, void* stream);
+/* ---- "H2" activation format.  Inside dgp_forward / dgp_infer every tensor from the pool output to the block4 features lives
+ * in HBM as fp16 high / low cell pairs: per pixel and 8 channels [8 halves hi | 8 halves lo] = 32 bytes (the footprint and the
+ * addresses of 8 fp32 channels) holding x * 2^exp, hi = fp16(x 2^exp), lo = fp16(x 2^exp - hi): 22 significant bits.  The
+ * producing conv splits once in its epilogue; the consuming conv's K loop copies the cells into the MFMA operand image and only
+ * issues ds_read + MFMA.  exp is per tensor, calibrated by the FIRST forward after dgp_net_load_weights (layer by layer, with
+ * hidden stream syncs: max |tensor| * 2^exp lands in [2^10, 2^11), 4 bits under the fp16 limit) and frozen afterwards, so the
+ * results are a deterministic function of the frames and the scales.  Every forward checks the tracked ranges against the scales
+ * on the device; dgp_net_range_status reports (and clears) an overflow -- the results of a forward that overflowed are invalid,
+ * the next forward re-calibrates on its own batch and the caller re-runs what it needs.  DGP_H2=0 keeps fp32 activations.
+ * The entry points below expose the format for tests and for features handed out at the boundary. */
+int  dgp_f32_to_h2(const float* x, size_t n_floats, int32_t scale_exp, void* out, void* stream);
+int  dgp_h2_to_f32(const void* x, size_t n_floats, int32_t scale_exp, float* out, void* stream);
+/* dgp_conv2d on H2 tensors: x (H2, exponent x_exp) -> y (H2 with y_exp, or fp32 when y_is_h2 == 0); residual fp32 or H2.
+ * w_absmax: range slots of packed_w (dgp_tensor_absmax); cells_scratch: >= dgp_packed_weight_floats(...) * 4 device bytes. */
+int  dgp_conv2d_h2(const dgp_conv_desc* d, const void* x_h2, int32_t x_exp, const float* packed_w, const float* w_absmax,
+                   const float* scale, const float* bias, const void* residual, int32_t res_is_h2, int32_t res_exp, void* y,
+                   int32_t y_is_h2, int32_t y_exp, float* y_absmax, void* cells_scratch, void* stream);
+/* Synchronises `stream`, then: *overflow = 1 if any forward since the last call outgrew a calibrated scale (the flag is cleared
+ * and the net re-calibrates on its next forward); *calibrations = calibration passes run so far. */
+int  dgp_net_range_status(dgp_net* net, int32_t* overflow, int32_t* calibrations, void* stream);
+int  dgp_net_recalibrate(dgp_net* net);      /* force a calibration pass on the next forward */
+
 /* slots = max(slots, max |x[0..n)|) on the device (zero the DGP_ABSMAX_SLOTS floats before the first call). */
 int  dgp_tensor_absmax(const float* x, size_t n, float* absmax_dev, void* stream);
 int  dgp_maxpool_3x3s2_same(const float* x, int32_t N, int32_t H, int32_t W, int32_t C,

@@ -1,0 +1,166 @@
+"""The H2 activation format of the inference engine (include/dgp_hip.h, "H2"): fp16 high / low cell pairs
+written by the producing epilogue, consumed by K loops that only issue ds_read + MFMA.
+
+Layer tests: fp32 inputs are converted to H2, the conv runs H2 -> H2 (or H2 -> fp32) through the cell kernels, the result is
+converted back and compared with a float64 reference.  Tolerance 2e-5 relative, the same as the fp32-activation layer tests: the
+format keeps 22 significant bits.  Network-level parity of the H2 path is what every test that calls DGPNet.forward / infer
+checks (test_parity_gpu.py); here: calibration, overflow detection and recovery."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_h2_converters_keep_22_bits(lib_built):
+    from deepgraphpose_amd import engine
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn((3, 17, 64), device="cuda", generator=g) * 37.0
+    x[0, 0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 1e-6, 3e4 / 64, 123.456, -7.25], device="cuda")
+    e = engine.h2_exp_for(float(x.abs().max()))
+    assert 2 ** 10 <= float(x.abs().max()) * 2.0 ** e < 2 ** 11
+    back = engine.h2_to_f32(engine.f32_to_h2(x, e), e)
+    err = (back.double() - x.double()).abs()
+    assert float((err / x.double().abs().clamp_min(1e-30)).max()) <= 2.0 ** -22 or float(err.max()) <= 2.0 ** -38 * float(x.abs().max())
+    assert float(err.max()) <= 2.0 ** -22 * float(x.abs().max())
+    # values with <= 22 significant bits survive exactly
+    y = (torch.randint(-2 ** 20, 2 ** 20, (4, 5, 16), device="cuda", generator=g).float()) * 2.0 ** -12
+    e2 = engine.h2_exp_for(float(y.abs().max()))
+    assert torch.equal(engine.h2_to_f32(engine.f32_to_h2(y, e2), e2), y)
+    raw = engine.f32_to_h2(x, e).view(torch.int32).cpu().numpy().reshape(-1, 8)      # cell layout: 4 dwords high halves, 4 dwords low
+    hi = raw[:, :4].copy().view(np.float16).astype(np.float64)
+    lo = raw[:, 4:].copy().view(np.float16).astype(np.float64)
+    np.testing.assert_array_equal(hi + lo, back.cpu().numpy().astype(np.float64).reshape(-1, 8) * 2.0 ** e)
+
+
+H2_CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, rate, residual (0 none, 1 same grid fp32, 2 same grid H2, 3 strided H2), y_is_h2
+    (2, 17, 23, 64, 256, 1, 1, 1, 2, True),        # conv3 of an identity unit (128 x 128 DMA kernel, pointwise loader)
+    (1, 30, 40, 256, 64, 1, 1, 1, 0, True),        # conv1 -> 64 channels (128 x 64 kernel)
+    (2, 19, 21, 64, 64, 3, 1, 1, 0, True),         # 3x3, 128 x 64 kernel
+    (2, 19, 21, 64, 64, 3, 2, 1, 0, True),         # strided 3x3
+    (1, 15, 20, 128, 128, 3, 1, 2, 0, True),       # dilated 3x3, 128 x 128 DMA kernel
+    (1, 30, 40, 512, 512, 3, 1, 2, 1, True),       # block4 conv2 shape (+ an fp32 residual)
+    (2, 20, 24, 256, 512, 1, 2, 1, 0, True),       # strided shortcut conv
+    (2, 10, 12, 512, 1024, 1, 1, 1, 3, True),      # conv3 of a strided unit: residual subsampled from the 2x finer grid
+    (1, 30, 40, 2048, 128, 1, 1, 1, 0, False),     # the head's pointwise GEMM: H2 in, fp32 out
+    (32, 30, 40, 1024, 256, 1, 1, 1, 0, True),     # batch-32 block3 conv1: 600 tiles -> grid-tail K-split + tail_fixup_h2
+]
+
+
+@pytest.mark.parametrize("case", H2_CONV_CASES)
+def test_conv_on_h2_tensors_matches_float64(lib_built, case):
+    from deepgraphpose_amd import engine
+    from oracle import dgp_oracle as O
+    N, H, W, Cin, Cout, k, stride, rate, res_kind, y_h2 = case
+    g = torch.Generator(device="cuda").manual_seed(abs(hash(case)) % (2 ** 31))
+    x = torch.relu(torch.randn((N, H, W, Cin), device="cuda", generator=g)) * 3.0
+    rngw = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    w = (rngw.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    scale = (1 + 0.1 * rngw.standard_normal(Cout)).astype(np.float32)
+    bias = (0.1 * rngw.standard_normal(Cout)).astype(np.float32)
+    keff = (k - 1) * rate + 1
+    pad = (keff - 1) // 2
+    Ho = (H + 2 * pad - keff) // stride + 1 if stride > 1 else H
+    Wo = (W + 2 * pad - keff) // stride + 1 if stride > 1 else W
+    if k == 1 and stride > 1:
+        pad, Ho, Wo = 0, (H + stride - 1) // stride, (W + stride - 1) // stride
+    x_exp = engine.h2_exp_for(float(x.abs().max()))
+    xh = engine.f32_to_h2(x, x_exp)
+    xq = engine.h2_to_f32(xh, x_exp).double()                  # what the cells hold (22 bits): the reference convolves THIS
+    # float64 reference by im2col
+    xp = torch.zeros((N, H + 2 * pad + stride, W + 2 * pad + stride, Cin), dtype=torch.float64, device="cuda")
+    xp[:, pad:pad + H, pad:pad + W] = xq
+    cols = [xp[:, a * rate: a * rate + (Ho - 1) * stride + 1: stride, b * rate: b * rate + (Wo - 1) * stride + 1: stride]
+            for a in range(k) for b in range(k)]
+    ref = torch.stack(cols, 3).reshape(N * Ho * Wo, k * k * Cin) @ torch.from_numpy(w.reshape(-1, Cout)).double().cuda()
+    ref = ref.reshape(N, Ho, Wo, Cout) * torch.from_numpy(scale).double().cuda() + torch.from_numpy(bias).double().cuda()
+    res = res_t = None
+    res_exp, res_stride = 0, 0
+    if res_kind in (1, 2):
+        res = torch.randn((N, Ho, Wo, Cout), device="cuda", generator=g) * 2.0
+        res_stride = 1
+    elif res_kind == 3:
+        res = torch.randn((N, 2 * Ho - 1, 2 * Wo, Cout), device="cuda", generator=g) * 2.0
+        res_stride = 2
+    if res is not None:
+        if res_kind in (2, 3):
+            res_exp = engine.h2_exp_for(float(res.abs().max()))
+            res_t = engine.f32_to_h2(res, res_exp)
+            rq = engine.h2_to_f32(res_t, res_exp).double()
+        else:
+            res_t, rq = res, res.double()
+        ref = ref + (rq if res_stride == 1 else rq[:, ::2, ::2])
+    ref = torch.relu(ref)
+    y_exp = engine.h2_exp_for(float(ref.abs().max()))
+    y, yrng = engine.conv2d_h2(xh, x_exp, w, stride=stride, rate=rate, pad_t=pad, pad_l=pad, out_hw=(Ho, Wo), scale=scale, bias=bias,
+                               residual=res_t, res_stride=res_stride, res_is_h2=res_kind in (2, 3), res_exp=res_exp, relu=True,
+                               y_is_h2=y_h2, y_exp=y_exp)
+    out = engine.h2_to_f32(y, y_exp) if y_h2 else y
+    err = float((out.double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, (case, err)
+    assert abs(float(yrng.max()) - float(ref.abs().max())) <= 1e-4 * float(ref.abs().max())      # tracked range = max |out|
+
+
+def test_calibration_overflow_detection_and_recovery(lib_built):
+    """Scales are calibrated by the first forward and frozen; a later batch whose activations outgrow them is flagged by the
+    device-side range check, dgp_net_range_status reports it, and the next forward re-calibrates and is correct again."""
+    from deepgraphpose_amd.engine import DGPNet
+    from deepgraphpose_amd.synthetic import make_frames, make_weights
+    from oracle import dgp_oracle as O
+    nj = 3
+    wts = make_weights(50, nj, False, seed=31, head_std=0.05)
+    net = DGPNet(50, nj, 64, 96, max_batch=4)
+    net.load_weights(wts)
+    flat = np.full((2, 64, 96, 3), 0, dtype=np.uint8)
+    flat[..., 0], flat[..., 1], flat[..., 2] = 124, 117, 104             # ~ the mean pixel: centred input ~ 0 -> tiny activations
+    frames = make_frames(2, 64, 96, nj, seed=31)
+    net.infer(torch.from_numpy(flat).cuda())
+    ov, ncal = net.range_status()
+    assert not ov and ncal == 1
+    mu_flat, _, _ = [t.clone() for t in net.infer(torch.from_numpy(flat).cuda())]
+    assert net.range_status() == (False, 1)                               # steady state: no re-calibration, no overflow
+    net.infer(torch.from_numpy(frames).cuda())                            # real frames on scales calibrated for ~zero input
+    ov, ncal = net.range_status()
+    assert ov and ncal == 1, "activations 16x beyond the calibrated range must be flagged"
+    mu, conf, idx = [t.cpu().numpy() for t in net.infer(torch.from_numpy(frames).cuda())]      # re-calibrates on this batch
+    ov, ncal = net.range_status()
+    assert not ov and ncal == 2
+    ref = O.infer(frames, wts, 50)
+    assert np.abs(mu - ref["mu"]).max() * 8.0 < 1e-3 and np.array_equal(idx, ref["idx"])
+    # the wider scales still serve the small-activation batch (headroom costs no accuracy): same answer as before within 1e-3 px
+    mu_flat2, _, _ = net.infer(torch.from_numpy(flat).cuda())
+    assert net.range_status() == (False, 2)
+    assert float((mu_flat2 - mu_flat).abs().max()) * 8.0 < 1e-3
+
+
+def test_h2_network_is_deterministic_and_close_to_fp32_activation_path(lib_built, tmp_path):
+    """Same frames twice -> bit-identical outputs; and the H2 engine agrees with the DGP_H2=0 engine (fp32 activations, split in the
+    K loop: the round-1 path) to fp32 round-off on the scoremap -- run in a child process because the switch is read once."""
+    import os, subprocess, sys
+    from deepgraphpose_amd.engine import DGPNet
+    from deepgraphpose_amd.synthetic import make_frames, make_weights
+    nj = 4
+    wts = make_weights(50, nj, False, seed=5, head_std=0.05)
+    frames = make_frames(6, 96, 128, nj, seed=6)
+    net = DGPNet(50, nj, 96, 128, max_batch=8)
+    net.load_weights(wts)
+    ft = torch.from_numpy(frames).cuda()
+    a = net.forward(ft).clone()
+    b = net.forward(ft).clone()
+    assert torch.equal(a, b) and net.range_status() == (False, 1)
+    np.save(tmp_path / "frames.npy", frames)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, torch, sys\n"
+            "from deepgraphpose_amd.engine import DGPNet\n"
+            "from deepgraphpose_amd.synthetic import make_weights\n"
+            "net = DGPNet(50, 4, 96, 128, max_batch=8); net.load_weights(make_weights(50, 4, False, seed=5, head_std=0.05))\n"
+            "sc = net.forward(torch.from_numpy(np.load(sys.argv[1])).cuda())\n"
+            "assert net.range_status() == (False, 0)\n"
+            "np.save(sys.argv[2], sc.cpu().numpy())\n")
+    env = dict(os.environ, DGP_H2="0", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "frames.npy"), str(tmp_path / "sc.npy")], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    sc32 = np.load(tmp_path / "sc.npy")
+    assert np.abs(a.cpu().numpy() - sc32).max() <= 2e-5 * np.abs(sc32).max()
