@@ -1050,9 +1050,11 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
 //   AH2 (CS kernels): the A operand arrives in the H2 activation format (fp16 high / low cells written by the producer's epilogue,
 //   ConvArgs::in_fmt): chunk 2 kg of a row IS the high cell of k-group kg and chunk 2 kg + 1 the low cell, so the loaders are
 //   unchanged (same addresses, same bytes) and the compute waves drop the split -- ds_read + MFMA only.
-template <int BM, int BN, int NT, int BK, int CW, bool PB = false, int MODE = 0, bool CS = false, bool DMA = false, bool AH2 = false>
+//   OH2 (AH2 kernels): the output tensor is H2 too (ls_epilogue_h2); false: fp32 output (the heads' pointwise GEMM).
+template <int BM, int BN, int NT, int BK, int CW, bool PB = false, int MODE = 0, bool CS = false, bool DMA = false, bool AH2 = false, bool OH2 = false>
 __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2) ? 4 : 2)) void conv_igemm_split_ls(const ConvArgs p) {
     static_assert(!AH2 || CS, "pre-split A operand: compute-side-split kernels only");
+    static_assert(!OH2 || AH2, "H2 output: kernels with H2 input only (the stem writes fp32, the pool converts)");
     // compute waves: 2 x (CW / 2) over the tile; with the compute-side split 4 x 1 (each wave owns 32 rows and ALL columns, so no
     // two waves split the same A rows -- half the split arithmetic for 25 % more B fragment reads)
     constexpr int WAVES_M = (CS && CW == 4) ? 4 : 2;
@@ -1755,11 +1757,8 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
         ls_store_raw<TM, TN, WN, M16>(acc, smem, wave, lane, wave_m0, wave_n0, p.slab + (size_t)tail_slot * (BM * BN), BN);
         return;
     }
-    if constexpr (CS) {
-        if (p.out_fmt) ls_epilogue_h2<TM, TN, WN, M16>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
-        else ls_epilogue<TM, TN, WN, M16>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
-    } else
-    ls_epilogue<TM, TN, WN, M16>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
+    if constexpr (OH2) ls_epilogue_h2<TM, TN, WN, M16>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
+    else ls_epilogue<TM, TN, WN, M16>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
 #ifdef DGP_DIAG
     DIAG_STAMP(e2);
     if (p.dbg && threadIdx.x == 0) {
@@ -1922,26 +1921,33 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
         smem = (size_t)(3 * BM * 8 + 2 * NP * KG * BN) * 16;           // 3 A stages + 2 B stages = 80 KB
         if (smem < smem_epi) smem = smem_epi;
     }
-    if (a.in_fmt) {        // H2 input: the same kernels without the split (AH2)
+    if (a.in_fmt) {        // H2 input: the same kernels without the split (AH2); H2 output: epilogue variant (OH2)
         if (!cs) return hipErrorInvalidValue;
         if constexpr (CAN_CS) {
-            if (dma) {
-                if constexpr (CAN_DMA)
-                    kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 2, CAN_DMA, CAN_DMA, CAN_DMA>
-                                     : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 1, CAN_DMA, CAN_DMA, CAN_DMA>;
-            } else {
-                kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 2, CAN_CS, false, CAN_CS>
-                     : mode == 1 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 1, CAN_CS, false, CAN_CS>
-                                 : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 0, CAN_CS, false, CAN_CS>;
+            if (a.out_fmt) {
+                if (dma) {
+                    if constexpr (CAN_DMA)
+                        kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 2, CAN_DMA, CAN_DMA, CAN_DMA, CAN_DMA>
+                                         : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 1, CAN_DMA, CAN_DMA, CAN_DMA, CAN_DMA>;
+                } else {
+                    kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 2, CAN_CS, false, CAN_CS, CAN_CS>
+                         : mode == 1 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 1, CAN_CS, false, CAN_CS, CAN_CS>
+                                     : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 0, CAN_CS, false, CAN_CS, CAN_CS>;
+                }
+            } else {           // fp32 output: pointwise GEMMs only (the heads, layer tests)
+                if (mode != 2) return hipErrorInvalidValue;
+                if (dma) {
+                    if constexpr (CAN_DMA) kern = conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 2, CAN_DMA, CAN_DMA, CAN_DMA, false>;
+                } else kern = conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 2, CAN_CS, false, CAN_CS, false>;
             }
         }
-    } else if (a.out_fmt && !cs) return hipErrorInvalidValue;
-    static bool attr_done[2][4][3] = {};
-    if (!attr_done[a.in_fmt ? 1 : 0][dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode]) {
+    } else if (a.out_fmt) return hipErrorInvalidValue;
+    static bool attr_done[3][4][3] = {};
+    if (!attr_done[a.in_fmt ? (a.out_fmt ? 2 : 1) : 0][dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_done[a.in_fmt ? 1 : 0][dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode] = true;
+        attr_done[a.in_fmt ? (a.out_fmt ? 2 : 1) : 0][dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode] = true;
     }
     long long nwg = (long long)a.mtiles * a.ntiles;
     // Grid tail: with `slots` workgroups resident, the last tiles % slots tiles run on a mostly idle chip.  Split their K range
