@@ -2495,6 +2495,185 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ------------------------------------------------------------------------------------
+// Root block in ONE kernel: uint8 frame -> (x - mean_pixel) -> conv2d_same(64, 7, stride 2) + BN + ReLU -> max_pool2d(3, 2, SAME)
+// -> H2 cells of the pool output.  (PET/nnet/pose_net.py:36-54 -> slim resnet_v1 root block)
+// Layer by layer the root block moves 1.8 GB per 32-frame step (centred fp32 frame out and in, the 64-channel conv1 map out and
+// in) for 46 GFLOP; fused it reads the uint8 frames (29 MB) and writes the pool output (157 MB).
+//   tile      4 x 16 pool pixels <- 9 x 33 conv1 pixels (297 GEMM rows, 19 blocks of 16) <- 23 x 72 input pixels
+//   phase 1   all 512 threads: input pixels -> centred, scaled by 2^6 (|x| < 152: no overflow, static), split into fp16 high / low,
+//             two LDS planes of 8 bytes per pixel (R, G, B, 0): a GEMM row's k-group (2 adjacent pixels) is ONE 16-byte read per plane
+//   phase 2   GEMM M = 304, N = 64, K = 7 kernel rows x (8 pixels x 4 channels) on v_mfma_f32_16x16x32_f16, 3 MFMAs per product; the
+//             whole weight panel (57 KB of pre-split cells, the stem row panel of the layer kernels) stays in LDS for the kernel's
+//             lifetime; a wave owns 2-3 row blocks and all 4 column blocks
+//   phase 3   BN + ReLU, conv1 pixels outside the map := 0 (never win: ReLU outputs are >= 0 and every window holds a real pixel),
+//             tile to LDS as fp32 (aliases the phase-1 planes)
+//   phase 4   3 x 3 / 2 max over the LDS tile, H2 split with the pool output's scale, two 16-byte stores per 8 channels, range tracking
+// One persistent workgroup per CU (140 KB of LDS) walks the tiles.
+// ------------------------------------------------------------------------------------
+struct StemPoolArgs {
+    const unsigned char* frames;      // [B, H, W, 3]
+    const uint4* wcells;              // [7 kernel rows][4 k-groups][2 planes][64][8 halves]  (launch_pack_h3 of the stem row panel)
+    const float* w_absmax;            // its range slots
+    const float* bn_scale; const float* bn_bias;
+    float mean0, mean1, mean2, out_scale;
+    float* out;                       // H2 [B, HP, WP, 64]
+    float* out_absmax;
+    int B, H, W, H1, W1, HP, WP, pbh, pbw, tiles_h, tiles_w, ntiles;
+};
+
+__global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolArgs p) {
+    constexpr int PH = 4, PW = 16, SR = 2 * PH + 1, SC = 2 * PW + 1, MS = SR * SC, NRB = (MS + 15) / 16;     // 9, 33, 297, 19
+    constexpr int IR = 2 * SR + 5, IC = 72;                                                                   // 23 x 72 input pixels
+    constexpr int WCELLS = 7 * 4 * 2 * 64;
+    constexpr int LDC = 68;                                                                                   // floats per conv1 pixel in LDS
+    typedef float floatx4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* sW = reinterpret_cast<uint4*>(smem);
+    char* sU = smem + WCELLS * 16;
+    uint2* sHi = reinterpret_cast<uint2*>(sU);                     // [IR][IC]
+    uint2* sLo = sHi + IR * IC;
+    float* sC = reinterpret_cast<float*>(sU);                      // [NRB * 16][LDC]   (aliases the planes)
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    for (int i = t; i < WCELLS; i += 512) sW[i] = p.wcells[i];
+    const float post = 1.f / (64.f * pow2_scale_for(p.w_absmax, lane));
+    const int nrb = wave < NRB - 16 ? 3 : 2;                       // row blocks wave, wave + 8, wave + 16
+    float sc4[4][1], bi4[4][1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sc4[j][0] = p.bn_scale[16 * j + l15] * post; bi4[j][0] = p.bn_bias[16 * j + l15]; }
+    float amax = 0.f;
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int n = tile / (p.tiles_h * p.tiles_w), rem = tile - n * (p.tiles_h * p.tiles_w);
+        const int ph0 = (rem / p.tiles_w) * PH, pw0 = (rem % p.tiles_w) * PW;
+        const int r0 = 2 * ph0 - p.pbh, c0 = 2 * pw0 - p.pbw;      // first conv1 pixel of the tile
+        const int ir0 = 2 * r0 - 3, ic0 = 2 * c0 - 3;              // first input pixel
+        // ---- phase 1: input pixels -> fp16 high / low planes
+        const unsigned char* fr = p.frames + (size_t)n * p.H * p.W * 3;
+        for (int q = t; q < IR * IC; q += 512) {
+            const int r = q / IC, c = q - r * IC;
+            const int gr = ir0 + r, gc = ic0 + c;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)gr < (unsigned)p.H && (unsigned)gc < (unsigned)p.W) {
+                const unsigned char* px = fr + ((size_t)gr * p.W + gc) * 3;
+                x.x = (float)px[0] - p.mean0; x.y = (float)px[1] - p.mean1; x.z = (float)px[2] - p.mean2;
+            }
+            uint2 h, l;
+            split2_f16(x, 64.f, h, l);
+            sHi[q] = h; sLo[q] = l;
+        }
+        __syncthreads();
+        // ---- phase 2: GEMM
+        floatx4 acc[3][4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        int abase[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            int m = 16 * (wave + 8 * i) + l15;
+            if (m > MS - 1) m = MS - 1;
+            const int rl = m / SC, cl = m - rl * SC;
+            abase[i] = (2 * rl) * IC + 2 * cl + 2 * g;             // pixel index of this lane's k-group in kernel row 0
+        }
+#pragma unroll 1
+        for (int kh = 0; kh < 7; ++kh) {
+            uint4 bh[4], bl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bh[j] = sW[((kh * 4 + g) * 2 + 0) * 64 + 16 * j + l15];
+                bl[j] = sW[((kh * 4 + g) * 2 + 1) * 64 + 16 * j + l15];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (i < nrb) {
+                    const uint4 ah = *reinterpret_cast<const uint4*>(sHi + abase[i] + kh * IC);
+                    const uint4 al = *reinterpret_cast<const uint4*>(sLo + abase[i] + kh * IC);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah), __builtin_bit_cast(half8, bl[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, al), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                          // every wave is done with the planes: the conv1 tile overwrites them
+        // ---- phase 3: BN + ReLU -> LDS tile
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (i < nrb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * (wave + 8 * i) + 4 * g + r;
+                    const int rl = m / SC, cl = m - rl * SC;
+                    const bool ok = m < MS && (unsigned)(r0 + rl) < (unsigned)p.H1 && (unsigned)(c0 + cl) < (unsigned)p.W1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = fmaxf(acc[i][j][r] * sc4[j][0] + bi4[j][0], 0.f);
+                        sC[m * LDC + 16 * j + l15] = ok ? v : 0.f;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 4: 3 x 3 / 2 max-pool of the tile, H2 cells out
+        {
+            const int pp = t >> 3, cg = t & 7;
+            const int ph = pp / PW, pw = pp - ph * PW;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const float* src = sC + ((2 * ph + a) * SC + 2 * pw + b) * LDC + 8 * cg;
+                    const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+                    v[0] = fmaxf(v[0], x0.x); v[1] = fmaxf(v[1], x0.y); v[2] = fmaxf(v[2], x0.z); v[3] = fmaxf(v[3], x0.w);
+                    v[4] = fmaxf(v[4], x1.x); v[5] = fmaxf(v[5], x1.y); v[6] = fmaxf(v[6], x1.z); v[7] = fmaxf(v[7], x1.w);
+                }
+            if (ph0 + ph < p.HP && pw0 + pw < p.WP) {
+                uint4 hi, lo;
+                h2_pack8(v, p.out_scale, hi, lo);
+                uint4* dst = reinterpret_cast<uint4*>(p.out + ((((size_t)n * p.HP + ph0 + ph) * p.WP + pw0 + pw) * 64 + 8 * cg));
+                dst[0] = hi; dst[1] = lo;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) amax = fmaxf(amax, v[k]);
+            }
+        }
+        __syncthreads();                                          // the next tile's planes overwrite the conv1 tile
+    }
+    if (p.out_absmax) track_absmax(p.out_absmax, amax, lane, (int)(blockIdx.x * 8u + (threadIdx.x >> 6)));
+}
+
+hipError_t launch_stem_pool_fused(const unsigned char* frames, int B, int H, int W, const void* wcells, const float* w_absmax,
+                                  const float* bn_scale, const float* bn_bias, float m0, float m1, float m2, float out_scale,
+                                  float* out, float* out_absmax, hipStream_t s) {
+    StemPoolArgs a{};
+    a.frames = frames; a.wcells = reinterpret_cast<const uint4*>(wcells); a.w_absmax = w_absmax; a.bn_scale = bn_scale; a.bn_bias = bn_bias;
+    a.mean0 = m0; a.mean1 = m1; a.mean2 = m2; a.out_scale = out_scale; a.out = out; a.out_absmax = out_absmax;
+    a.B = B; a.H = H; a.W = W; a.H1 = (H + 1) / 2; a.W1 = (W + 1) / 2;
+    a.HP = (a.H1 + 1) / 2; a.WP = (a.W1 + 1) / 2;
+    const int pth = ((a.HP - 1) * 2 + 3 - a.H1) > 0 ? ((a.HP - 1) * 2 + 3 - a.H1) : 0;
+    const int ptw = ((a.WP - 1) * 2 + 3 - a.W1) > 0 ? ((a.WP - 1) * 2 + 3 - a.W1) : 0;
+    a.pbh = pth / 2; a.pbw = ptw / 2;
+    a.tiles_h = (a.HP + 3) / 4; a.tiles_w = (a.WP + 15) / 16; a.ntiles = B * a.tiles_h * a.tiles_w;
+    constexpr size_t smem = (size_t)7 * 4 * 2 * 64 * 16 + (size_t)19 * 16 * 68 * 4;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+    const int grid = a.ntiles < n_cu ? a.ntiles : n_cu;
+    hipLaunchKernelGGL(stem_pool_fused_kernel, dim3((unsigned)grid), dim3(512), smem, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
 // DGP 2-D soft-argmax + likelihood window.  One workgroup per (frame, joint) map.
 //   p = softmax(gamma * s) over H*W; zero-pad by gauss_len; depthwise blur with
 //   outer(g, g), g = exp(-x^2 / (2 sigma^2)) / sum, x = -r..r, r = sigma = gauss_len;

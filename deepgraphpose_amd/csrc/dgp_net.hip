@@ -615,16 +615,6 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     net->tail_slab = (float*)(ws + pl.off_tail); net->tail_slab_bytes = (unsigned)(TAIL_SLAB_FLOATS * sizeof(float));
     hipError_t e;
     if (net->d_amax) HIP_TRY(hipMemsetAsync(net->d_amax, 0, net->layers.size() * ABSMAX_SLOTS * sizeof(float), s));   // ranges are per forward
-    {
-        ProfScope ps(net, s, "preprocess_u8", 0.0);
-        e = launch_preprocess(frames, (long long)B * d.in_h * d.in_w, d.mean_pixel[0], d.mean_pixel[1],
-                              d.mean_pixel[2], P0, s);
-    }
-    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("preprocess: ") + hipGetErrorString(e));
-    // conv1: conv2d_same(7, stride 2): explicit pad 3 before
-    rc = run_conv(net, net->layers[net->conv1], P0, B, d.in_h, d.in_w, 3, 3, net->h1, net->w1, nullptr, 0, 0, 0, true, 0,
-                  0, C1, s, nullptr, net->d_inmax);
-    if (rc) return rc;
     // ---- activation format of this forward.  H2 (default): every tensor from the pool output to the block4 features lives in HBM as
     // fp16 high / low cells with a calibrated per-tensor scale, so the conv kernels' K loops are ds_read + MFMA only (DGP_H2=0: fp32
     // activations, split in the consumers' K loops -- also what the other DGP_CONV_MODEs and a trainer-owned net use).
@@ -633,7 +623,8 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     static const bool head_pw = !(getenv("DGP_HEAD_PW") && atoi(getenv("DGP_HEAD_PW")) == 0);      // A/B switch
     static const bool fuse_env = !(getenv("DGP_FUSE_SHORTCUT") && atoi(getenv("DGP_FUSE_SHORTCUT")) == 0);      // A/B switch
     static const bool f32_mode = getenv("DGP_CONV_MODE") && !strcmp(getenv("DGP_CONV_MODE"), "f32");
-    const bool h2 = h2_env && f16_mode && head_pw && net->wmax_valid && net->d_exps && net->layers[net->head_part].d_wh3_pw &&
+    static const bool cells_env = !(getenv("DGP_PRESPLIT_WEIGHTS") && atoi(getenv("DGP_PRESPLIT_WEIGHTS")) == 0);
+    const bool h2 = h2_env && cells_env && f16_mode && head_pw && net->wmax_valid && net->d_exps && net->layers[net->head_part].d_wh3_pw &&
                     (net->head_locref < 0 || net->layers[net->head_locref].d_wh3_pw) && net->act_exp.size() == net->layers.size();
     const bool calib = h2 && !net->h2_calibrated;
     const int H2_HEAD = net->h2_head;             // bits of headroom between a calibrated maximum and the fp16 limit
@@ -670,18 +661,44 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
         }
         return r;
     };
-    if (calib) {
-        float mx = 0.f;
-        if ((rc = read_range(net->conv1, &mx))) return rc;
-        net->act_exp[net->conv1] = exp_for(mx);   // (max-pooling cannot raise the maximum of conv1's output)
+    // ---- root block.  H2 engine: ONE kernel from the uint8 frame to the pool output's cells (stem_pool_fused_kernel);
+    // otherwise preprocess -> conv1 -> max-pool as three launches
+    static const bool stem_fused_env = !(getenv("DGP_STEM_FUSED") && atoi(getenv("DGP_STEM_FUSED")) == 0);
+    const ConvLayer& lstem = net->layers[net->conv1];
+    const bool stem_fused = h2 && stem_fused_env && lstem.d_wh3 && lstem.d_w_rows && lstem.CoutP == 64 && lstem.d_scale && lstem.d_bias;
+    if (stem_fused) {
+        rc = layer(net->conv1, [&] {
+            ProfScope ps(net, s, "conv:" + lstem.scope + "+pool|stem_pool_fused", conv_flops_of(lstem, B * net->h1 * net->w1, false));
+            hipError_t e2 = launch_stem_pool_fused(frames, B, d.in_h, d.in_w, lstem.d_wh3, net->wmax(net->conv1), lstem.d_scale, lstem.d_bias,
+                                                   d.mean_pixel[0], d.mean_pixel[1], d.mean_pixel[2],
+                                                   ldexpf(1.f, net->act_exp[net->conv1]), X[0], net->amax(net->conv1), s);
+            return e2 == hipSuccess ? (int)DGP_OK : fail(DGP_ERR_HIP, std::string("stem + pool: ") + hipGetErrorString(e2));
+        });
+        if (rc) return rc;
+    } else {
+        {
+            ProfScope ps(net, s, "preprocess_u8", 0.0);
+            e = launch_preprocess(frames, (long long)B * d.in_h * d.in_w, d.mean_pixel[0], d.mean_pixel[1],
+                                  d.mean_pixel[2], P0, s);
+        }
+        if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("preprocess: ") + hipGetErrorString(e));
+        // conv1: conv2d_same(7, stride 2): explicit pad 3 before
+        rc = run_conv(net, net->layers[net->conv1], P0, B, d.in_h, d.in_w, 3, 3, net->h1, net->w1, nullptr, 0, 0, 0, true, 0,
+                      0, C1, s, nullptr, net->d_inmax);
+        if (rc) return rc;
+        if (calib) {
+            float mx = 0.f;
+            if ((rc = read_range(net->conv1, &mx))) return rc;
+            net->act_exp[net->conv1] = exp_for(mx);   // (max-pooling cannot raise the maximum of conv1's output)
+        }
+        {
+            ProfScope ps(net, s, "maxpool3x3s2", 0.0);
+            e = launch_maxpool(C1, B, net->h1, net->w1, 64, X[0], s, h2 ? ldexpf(1.f, net->act_exp[net->conv1]) : 0.f);
+        }
+        if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("maxpool: ") + hipGetErrorString(e));
+
     }
     const int pool_exp = h2 ? net->act_exp[net->conv1] : 0;
-    {
-        ProfScope ps(net, s, "maxpool3x3s2", 0.0);
-        e = launch_maxpool(C1, B, net->h1, net->w1, 64, X[0], s, h2 ? ldexpf(1.f, pool_exp) : 0.f);
-    }
-    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("maxpool: ") + hipGetErrorString(e));
-
     int cur = 0, h = net->hp, w = net->wp;
     const float* x_rng = net->amax(net->conv1);      // max-pooling cannot raise the maximum of conv1's output
     int x_exp = pool_exp;

@@ -350,7 +350,10 @@ def test_fp16_split_keeps_fp32_class_accuracy_over_wide_ranges(eng, monkeypatch)
 
 
 @pytest.mark.parametrize("mode,extra", [("f32", {}), ("bf16x6", {}), ("f16x3", {"DGP_FUSE_SHORTCUT": "0", "DGP_STEM_ROWS": "0",
-                                                                                "DGP_PRESPLIT_WEIGHTS": "0"})])
+                                                                                "DGP_PRESPLIT_WEIGHTS": "0"}),
+                                        ("f16x3", {"DGP_FUSE_SHORTCUT": "0"}),               # H2 engine, shortcut convs as their own launches
+                                        ("f16x3", {"DGP_STEM_FUSED": "0"}),                  # H2 engine, root block as three launches
+                                        ("f16x3", {"DGP_H2": "0"})])                         # fp32 activations (round-1 path)
 def test_other_conv_modes_keep_parity(eng, mode, extra):
     """The conv path is chosen once per process (DGP_CONV_MODE and the A/B switches are read at first use), so the
     non-default paths -- fp32 MFMA, the range-free bf16x6 split, and fp16x3 without fused shortcut / row-walk stem /
