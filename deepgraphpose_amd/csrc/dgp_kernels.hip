@@ -2499,16 +2499,16 @@ __device__ __forceinline__ double wave_sum(double v) {
 // -> H2 cells of the pool output.  (PET/nnet/pose_net.py:36-54 -> slim resnet_v1 root block)
 // Layer by layer the root block moves 1.8 GB per 32-frame step (centred fp32 frame out and in, the 64-channel conv1 map out and
 // in) for 46 GFLOP; fused it reads the uint8 frames (29 MB) and writes the pool output (157 MB).
-//   tile      4 x 16 pool pixels <- 9 x 33 conv1 pixels (297 GEMM rows, 19 blocks of 16) <- 23 x 72 input pixels
+//   tile      5 x 16 pool pixels <- 11 x 33 conv1 pixels (363 GEMM rows, 23 blocks of 16: three per wave) <- 27 x 72 input pixels
 //   phase 1   all 512 threads: input pixels -> centred, scaled by 2^6 (|x| < 152: no overflow, static), split into fp16 high / low,
 //             two LDS planes of 8 bytes per pixel (R, G, B, 0): a GEMM row's k-group (2 adjacent pixels) is ONE 16-byte read per plane
-//   phase 2   GEMM M = 304, N = 64, K = 7 kernel rows x (8 pixels x 4 channels) on v_mfma_f32_16x16x32_f16, 3 MFMAs per product; the
+//   phase 2   GEMM M = 368, N = 64, K = 7 kernel rows x (8 pixels x 4 channels) on v_mfma_f32_16x16x32_f16, 3 MFMAs per product; the
 //             whole weight panel (57 KB of pre-split cells, the stem row panel of the layer kernels) stays in LDS for the kernel's
 //             lifetime; a wave owns 2-3 row blocks and all 4 column blocks
 //   phase 3   BN + ReLU, conv1 pixels outside the map := 0 (never win: ReLU outputs are >= 0 and every window holds a real pixel),
 //             tile to LDS as fp32 (aliases the phase-1 planes)
 //   phase 4   3 x 3 / 2 max over the LDS tile, H2 split with the pool output's scale, two 16-byte stores per 8 channels, range tracking
-// One persistent workgroup per CU (140 KB of LDS) walks the tiles.
+// One persistent workgroup per CU (156 KB of LDS) walks the tiles.
 // ------------------------------------------------------------------------------------
 struct StemPoolArgs {
     const unsigned char* frames;      // [B, H, W, 3]
@@ -2522,8 +2522,9 @@ struct StemPoolArgs {
 };
 
 __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolArgs p) {
-    constexpr int PH = 4, PW = 16, SR = 2 * PH + 1, SC = 2 * PW + 1, MS = SR * SC, NRB = (MS + 15) / 16;     // 9, 33, 297, 19
-    constexpr int IR = 2 * SR + 5, IC = 72;                                                                   // 23 x 72 input pixels
+    constexpr int PH = 5, PW = 16, SR = 2 * PH + 1, SC = 2 * PW + 1, MS = SR * SC, NRB = (MS + 15) / 16;     // 11, 33, 363, 23
+    constexpr int IR = 2 * SR + 5, IC = 72;                                                                   // 27 x 72 input pixels
+    static_assert(NRB <= 24, "three row blocks per wave");
     constexpr int WCELLS = 7 * 4 * 2 * 64;
     constexpr int LDC = 68;                                                                                   // floats per conv1 pixel in LDS
     typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -2537,31 +2538,52 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
     const int l15 = lane & 15, g = lane >> 4;
     for (int i = t; i < WCELLS; i += 512) sW[i] = p.wcells[i];
     const float post = 1.f / (64.f * pow2_scale_for(p.w_absmax, lane));
-    const int nrb = wave < NRB - 16 ? 3 : 2;                       // row blocks wave, wave + 8, wave + 16
+    const int nrb = wave < NRB - 16 ? 3 : 2;                       // row blocks wave, wave + 8, wave + 16 (23 blocks: 3 each, wave 7: 2)
     float sc4[4][1], bi4[4][1];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { sc4[j][0] = p.bn_scale[16 * j + l15] * post; bi4[j][0] = p.bn_bias[16 * j + l15]; }
     float amax = 0.f;
+    // the next tile's input pixels travel in registers: their global loads are issued before the GEMM and land under it
+    constexpr int NPX = (IR * IC + 511) / 512;
+    unsigned pix[NPX][3];
+    auto fetch = [&](int tile) {
+        const int n = tile / (p.tiles_h * p.tiles_w), rem = tile - n * (p.tiles_h * p.tiles_w);
+        const int ir0 = 2 * (2 * (rem / p.tiles_w) * PH - p.pbh) - 3, ic0 = 2 * (2 * (rem % p.tiles_w) * PW - p.pbw) - 3;
+        const unsigned char* fr = p.frames + (size_t)n * p.H * p.W * 3;
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) {
+            const int q = t + 512 * u;
+            const int r = q / IC, c = q - r * IC;
+            const int gr = ir0 + r, gc = ic0 + c;
+            const bool ok = q < IR * IC && (unsigned)gr < (unsigned)p.H && (unsigned)gc < (unsigned)p.W;
+            const unsigned char* px = fr + ((size_t)(ok ? gr : 0) * p.W + (ok ? gc : 0)) * 3;
+            pix[u][0] = px[0]; pix[u][1] = px[1]; pix[u][2] = px[2];
+        }
+    };
+    if ((int)blockIdx.x < p.ntiles) fetch(blockIdx.x);
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int n = tile / (p.tiles_h * p.tiles_w), rem = tile - n * (p.tiles_h * p.tiles_w);
         const int ph0 = (rem / p.tiles_w) * PH, pw0 = (rem % p.tiles_w) * PW;
         const int r0 = 2 * ph0 - p.pbh, c0 = 2 * pw0 - p.pbw;      // first conv1 pixel of the tile
         const int ir0 = 2 * r0 - 3, ic0 = 2 * c0 - 3;              // first input pixel
-        // ---- phase 1: input pixels -> fp16 high / low planes
-        const unsigned char* fr = p.frames + (size_t)n * p.H * p.W * 3;
-        for (int q = t; q < IR * IC; q += 512) {
-            const int r = q / IC, c = q - r * IC;
-            const int gr = ir0 + r, gc = ic0 + c;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)gr < (unsigned)p.H && (unsigned)gc < (unsigned)p.W) {
-                const unsigned char* px = fr + ((size_t)gr * p.W + gc) * 3;
-                x.x = (float)px[0] - p.mean0; x.y = (float)px[1] - p.mean1; x.z = (float)px[2] - p.mean2;
+        // ---- phase 1: input pixels (already in registers) -> fp16 high / low planes
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) {
+            const int q = t + 512 * u;
+            if (q < IR * IC) {
+                const int r = q / IC, c = q - r * IC;
+                const int gr = ir0 + r, gc = ic0 + c;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((unsigned)gr < (unsigned)p.H && (unsigned)gc < (unsigned)p.W) {
+                    x.x = (float)pix[u][0] - p.mean0; x.y = (float)pix[u][1] - p.mean1; x.z = (float)pix[u][2] - p.mean2;
+                }
+                uint2 h, l;
+                split2_f16(x, 64.f, h, l);
+                sHi[q] = h; sLo[q] = l;
             }
-            uint2 h, l;
-            split2_f16(x, 64.f, h, l);
-            sHi[q] = h; sLo[q] = l;
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < p.ntiles) fetch(tile + gridDim.x);
         // ---- phase 2: GEMM
         floatx4 acc[3][4];
 #pragma unroll
@@ -2618,8 +2640,8 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
         }
         __syncthreads();
         // ---- phase 4: 3 x 3 / 2 max-pool of the tile, H2 cells out
-        {
-            const int pp = t >> 3, cg = t & 7;
+        for (int q = t; q < PH * PW * 8; q += 512) {
+            const int pp = q >> 3, cg = q & 7;
             const int ph = pp / PW, pw = pp - ph * PW;
             float v[8];
 #pragma unroll
@@ -2658,8 +2680,8 @@ hipError_t launch_stem_pool_fused(const unsigned char* frames, int B, int H, int
     const int pth = ((a.HP - 1) * 2 + 3 - a.H1) > 0 ? ((a.HP - 1) * 2 + 3 - a.H1) : 0;
     const int ptw = ((a.WP - 1) * 2 + 3 - a.W1) > 0 ? ((a.WP - 1) * 2 + 3 - a.W1) : 0;
     a.pbh = pth / 2; a.pbw = ptw / 2;
-    a.tiles_h = (a.HP + 3) / 4; a.tiles_w = (a.WP + 15) / 16; a.ntiles = B * a.tiles_h * a.tiles_w;
-    constexpr size_t smem = (size_t)7 * 4 * 2 * 64 * 16 + (size_t)19 * 16 * 68 * 4;
+    a.tiles_h = (a.HP + 4) / 5; a.tiles_w = (a.WP + 15) / 16; a.ntiles = B * a.tiles_h * a.tiles_w;
+    constexpr size_t smem = (size_t)7 * 4 * 2 * 64 * 16 + (size_t)23 * 16 * 68 * 4;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
