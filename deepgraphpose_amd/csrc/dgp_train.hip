@@ -877,7 +877,25 @@ struct TLayer {
     int nkT = 0, cinP = 0, cpad = 0;                  // cpad: padded phase-major channel count (heads)
 };
 
+// Per-trainer launch context (was process-global state: two trainers, or a trainer created after another was destroyed, must not
+// see each other's range maps, fp16 cell tables or workspace pointers).  Bound to the calling thread for the duration of an entry point.
+struct TPlanFwd;
+struct RangeCtx {
+    float* pool = nullptr;            // RANGE_POOL slot arrays of ABSMAX_SLOTS floats
+    int next = 0, limit = 0;
+    std::map<const void*, const float*> of;     // tensor / panel pointer -> its slot array
+    bool on = false;
+};
+struct TrainCtx {
+    float* tail_slab = nullptr;                  // K-split slab of the running forward / backward pass (a region of the caller's workspace)
+    RangeCtx rng;
+    std::unordered_map<const float*, const float*> cells;      // weight panel -> the same panel pre-split into fp16 cells
+    const void* defer_plan = nullptr;            // TPlan of the running backward pass when weight-gradient finalisation is deferred
+    char* defer_ws = nullptr;
+};
+
 struct dgp_trainer {
+    TrainCtx ctx;
     dgp_net* net = nullptr;
     std::vector<TLayer> tl;
     std::vector<std::string> names;
@@ -977,29 +995,22 @@ TPlan make_tplan(const dgp_trainer* tr, int B) {
 }
 
 // K-split slab of the running forward / backward pass (a region of the caller's workspace)
-static float* g_tail_slab = nullptr;
+static thread_local TrainCtx* g_ctx = nullptr;      // the trainer whose entry point is running on this thread
 
 // Operand ranges for the fp16-split conv kernels inside the training step.  Every conv launched through conv_launch takes a
 // fresh slot array from a pool for max |out| and records it under its output pointer; a later conv whose input pointer (and
 // weight panel) has a recorded range runs the fp16 kernels, anything else (tensors written by other kernels: pooling, loss
 // gradients, head gathers) falls back to the range-free bf16 split.  The pool is zeroed at the start of each pass.
-struct RangeCtx {
-    float* pool = nullptr;            // RANGE_POOL slot arrays of ABSMAX_SLOTS floats
-    int next = 0, limit = 0;
-    std::map<const void*, const float*> of;     // tensor / panel pointer -> its slot array
-    bool on = false;
-};
-static RangeCtx g_rng;
 constexpr int RANGE_POOL = 512;
 
 static float* range_take() {
-    if (!g_rng.on || !g_rng.pool || g_rng.next >= g_rng.limit) return nullptr;
-    return g_rng.pool + (size_t)(g_rng.next++) * ABSMAX_SLOTS;
+    if (!g_ctx || !g_ctx->rng.on || !g_ctx->rng.pool || g_ctx->rng.next >= g_ctx->rng.limit) return nullptr;
+    return g_ctx->rng.pool + (size_t)(g_ctx->rng.next++) * ABSMAX_SLOTS;
 }
 static const float* range_of(const void* p) {
-    if (!g_rng.on) return nullptr;
-    auto it = g_rng.of.find(p);
-    return it == g_rng.of.end() ? nullptr : it->second;
+    if (!g_ctx || !g_ctx->rng.on) return nullptr;
+    auto it = g_ctx->rng.of.find(p);
+    return it == g_ctx->rng.of.end() ? nullptr : it->second;
 }
 
 // Start of a forward or a backward pass.  Forward: everything fresh (first half of the pool).  Backward: the forward tensors'
@@ -1007,25 +1018,24 @@ static const float* range_of(const void* p) {
 static void range_pass_begin(dgp_trainer* tr, hipStream_t s, bool backward) {
     static const bool enabled = !(getenv("DGP_TRAIN_F16") && atoi(getenv("DGP_TRAIN_F16")) == 0) &&
                                 !(getenv("DGP_CONV_MODE") && strcmp(getenv("DGP_CONV_MODE"), "f16x3") != 0);
-    g_rng.on = enabled && tr->d_rng_pool && tr->d_wrng;
-    g_rng.pool = tr->d_rng_pool;
+    g_ctx->rng.on = enabled && tr->d_rng_pool && tr->d_wrng;
+    g_ctx->rng.pool = tr->d_rng_pool;
     const size_t half_bytes = (size_t)(RANGE_POOL / 2) * ABSMAX_SLOTS * sizeof(float);
-    if (!backward) { g_rng.of.clear(); g_rng.next = 0; g_rng.limit = RANGE_POOL / 2; }
-    else { g_rng.next = RANGE_POOL / 2; g_rng.limit = RANGE_POOL; }
-    if (!g_rng.on) return;
+    if (!backward) { g_ctx->rng.of.clear(); g_ctx->rng.next = 0; g_ctx->rng.limit = RANGE_POOL / 2; }
+    else { g_ctx->rng.next = RANGE_POOL / 2; g_ctx->rng.limit = RANGE_POOL; }
+    if (!g_ctx->rng.on) return;
     (void)hipMemsetAsync(reinterpret_cast<char*>(tr->d_rng_pool) + (backward ? half_bytes : 0), 0, half_bytes, s);
     if (backward) return;
     const size_t nl = tr->net->layers.size();
     for (size_t li = 0; li < nl; ++li) {
-        if (tr->net->layers[li].d_w) g_rng.of[tr->net->layers[li].d_w] = tr->d_wrng + li * ABSMAX_SLOTS;
-        if (tr->tl[li].d_wT) g_rng.of[tr->tl[li].d_wT] = tr->d_wrng + (nl + li) * ABSMAX_SLOTS;
+        if (tr->net->layers[li].d_w) g_ctx->rng.of[tr->net->layers[li].d_w] = tr->d_wrng + li * ABSMAX_SLOTS;
+        if (tr->tl[li].d_wT) g_ctx->rng.of[tr->tl[li].d_wT] = tr->d_wrng + (nl + li) * ABSMAX_SLOTS;
     }
 }
 
 
 // weight panel -> the same panel pre-split into fp16 cells (filled by dgp_trainer_sync_weights): with the cells and both ranges the
 // conv runs on the compute-side-split / LDS-DMA kernels of the inference engine
-static std::unordered_map<const float*, const float*> g_cells;
 // Default on (DGP_TRAIN_CELLS=0: the trainer's convs split their weights in the loaders): the cells of all panels are rebuilt by ONE
 // launch per sync (pack_h3_all_kernel), after which forward and data-gradient convs run the engine's compute-side-split / LDS-DMA /
 // 16x16x32 kernels: 17.0 -> 16.2 ms per step.  (With one pack launch per layer and panel the packing cost what the kernels saved.)
@@ -1043,21 +1053,24 @@ hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, 
     a.ntaps = l.KH * l.KW; a.nk = nk; a.M = N * Ho * Wo;
     a.res_s = res ? res_s : 0; a.res_H = res_H; a.res_W = res_W; a.up = up;
     a.relu = relu ? 1 : 0; a.out_mode = out_mode; a.dc_nj = dc_nj;
+    if ((double)N * H * W * Cin * 4 > 4294967000.0 || (double)a.M * Cout * 4 > 4294967000.0 ||
+        (res && (double)N * res_H * res_W * Cout * 4 > 4294967000.0))
+        return hipErrorInvalidValue;              // 32-bit buffer descriptors: every tensor stays below 4 GiB (lower the batch)
     a.in_bytes = (unsigned)((size_t)N * H * W * Cin * 4);
     a.out_bytes = (unsigned)((size_t)a.M * Cout * 4);
     a.res_bytes = res ? (unsigned)((size_t)N * res_H * res_W * Cout * 4) : 0u;
     a.w_bytes = (unsigned)((size_t)nk * 8 * coutP * 16);
-    a.slab = g_tail_slab; a.slab_bytes = g_tail_slab ? (unsigned)(TAIL_SLAB_FLOATS * sizeof(float)) : 0u;
+    a.slab = g_ctx->tail_slab; a.slab_bytes = g_ctx->tail_slab ? (unsigned)(TAIL_SLAB_FLOATS * sizeof(float)) : 0u;
     const float* rin = range_of(in);
     const float* rw = range_of(wpk);
     if (rin && rw && out_mode == 0) {
         a.in_absmax = rin; a.w_absmax = rw;
-        const auto c = g_cells.find(wpk);
-        if (g_train_cells && c != g_cells.end()) { a.wh3 = c->second; a.wh3_bytes = a.w_bytes; }
+        const auto c = g_ctx->cells.find(wpk);
+        if (g_train_cells && c != g_ctx->cells.end()) { a.wh3 = c->second; a.wh3_bytes = a.w_bytes; }
     }
     if (out_mode == 0) {
         a.out_absmax = range_take();
-        if (a.out_absmax) g_rng.of[out] = a.out_absmax; else g_rng.of.erase(out);
+        if (a.out_absmax) g_ctx->rng.of[out] = a.out_absmax; else g_ctx->rng.of.erase(out);
     }
     return launch_conv(a, pick_tile(a.M, coutP, nk * BK, a.in_absmax && a.w_absmax), s);
 }
@@ -1069,6 +1082,7 @@ hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const floa
     a.x = x; a.dy = dy; a.dw = dwraw; a.colsum = colsum; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.log2cin4 = ilog2(Cin / 4);
     a.Ho = Ho; a.Wo = Wo; a.Cdy = Cdy; a.KW = KW; a.stride = stride; a.dil = dil; a.pad_t = pad_t; a.pad_l = pad_l;
     a.ntaps = KH * KW; a.kchunks = KH * KW * (Cin / 4); a.M = N * Ho * Wo;
+    if ((double)N * H * W * Cin * 4 > 4294967000.0 || (double)a.M * Cdy * 4 > 4294967000.0) return hipErrorInvalidValue;
     a.x_bytes = (unsigned)((size_t)N * H * W * Cin * 4);
     a.dy_bytes = (unsigned)((size_t)a.M * Cdy * 4);
     hipError_t e = hipSuccess;
@@ -1231,6 +1245,7 @@ int dgp_trainer_workspace_bytes(const dgp_trainer* tr, int32_t nt, size_t* out_b
 
 // master parameters -> forward panels / folded BN / data-gradient panels of the engine
 int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
+    if (tr) g_ctx = &tr->ctx;
     if (!tr) return fail(DGP_ERR_INVALID, "dgp_trainer_sync_weights: null");
     dgp_net* net = tr->net;
     hipStream_t s = (hipStream_t)stream;
@@ -1274,7 +1289,7 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
             if (g_train_cells && rng_f && l.Cin >= 32) {          // cells of the forward panel, scaled by the range tracked just above
                 if (!l.d_wh3) TRY_HIP(hipMalloc(&l.d_wh3, nfl * sizeof(float)));
                 TRY_HIP(launch_pack_h3(l.d_w, l.nk, l.CoutP, rng_f, l.d_wh3, s));
-                g_cells[l.d_w] = reinterpret_cast<const float*>(l.d_wh3);
+                g_ctx->cells[l.d_w] = reinterpret_cast<const float*>(l.d_wh3);
             }
             hipLaunchKernelGGL(fold_bn_kernel, dim3((l.Cout + 255) / 256), dim3(256), 0, s, tr->params + t.g_off,
                                tr->params + t.b_off, tr->stats + t.mean_off, tr->stats + t.var_off, eps, l.Cout, l.d_scale,
@@ -1286,7 +1301,7 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
                 if (g_train_cells && rng_b && l.Cout >= 32) {
                     if (!t.d_wTh3) TRY_HIP(hipMalloc(&t.d_wTh3, (size_t)t.nkT * 8 * t.cinP * 16));
                     TRY_HIP(launch_pack_h3(t.d_wT, t.nkT, t.cinP, rng_b, t.d_wTh3, s));
-                    g_cells[t.d_wT] = t.d_wTh3;
+                    g_ctx->cells[t.d_wT] = t.d_wTh3;
                 }
             }
         }
@@ -1323,12 +1338,12 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
                     if (l.Cin >= 32) {
                         if (!l.d_wh3) TRY_HIP(hipMalloc(&l.d_wh3, (size_t)l.nk * 8 * l.CoutP * 16));
                         tab.push_back(PackH3Desc{l.d_w, l.nk * 4, l.CoutP, tr->d_wrng + li * ABSMAX_SLOTS, l.d_wh3});
-                        g_cells[l.d_w] = reinterpret_cast<const float*>(l.d_wh3);
+                        g_ctx->cells[l.d_w] = reinterpret_cast<const float*>(l.d_wh3);
                     }
                     if (t.d_wT && l.Cout >= 32) {
                         if (!t.d_wTh3) TRY_HIP(hipMalloc(&t.d_wTh3, (size_t)t.nkT * 8 * t.cinP * 16));
                         tab.push_back(PackH3Desc{t.d_wT, t.nkT * 4, t.cinP, tr->d_wrng + (nl_all + li) * ABSMAX_SLOTS, t.d_wTh3});
-                        g_cells[t.d_wT] = t.d_wTh3;
+                        g_ctx->cells[t.d_wT] = t.d_wTh3;
                     }
                 }
                 for (int hd : {net->head_part, net->head_locref}) {         // the heads' pointwise panels (range slot of the layer)
@@ -1351,6 +1366,7 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
 
 int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* workspace, size_t workspace_bytes,
                       float** scmap, float** locref, void* stream) {
+    if (tr) g_ctx = &tr->ctx;
     if (!tr || !frames || !workspace) return fail(DGP_ERR_INVALID, "dgp_train_forward: null argument");
     dgp_net* net = tr->net;
     if (!net->loaded) return fail(DGP_ERR_STATE, "dgp_train_forward: call dgp_trainer_sync_weights first");
@@ -1359,7 +1375,7 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     auto F = [&](size_t off) { return (float*)(ws + off); };
-    g_tail_slab = F(pl.tail);
+    g_ctx->tail_slab = F(pl.tail);
     range_pass_begin(tr, s, false);
     const dgp_net_desc& d = net->desc;
     const int B = nt;
@@ -1377,7 +1393,7 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     } else {
         TRY_HIP(launch_maxpool(F(pl.c1), B, net->h1, net->w1, 64, F(pl.pool), s));
     }
-    if (const float* r = range_of(F(pl.c1))) g_rng.of[F(pl.pool)] = r; else g_rng.of.erase(F(pl.pool));      // max-pooling cannot raise the maximum
+    if (const float* r = range_of(F(pl.c1))) g_ctx->rng.of[F(pl.pool)] = r; else g_ctx->rng.of.erase(F(pl.pool));      // max-pooling cannot raise the maximum
     int h = net->hp, w = net->wp;
     const float* xin = F(pl.pool);
     for (size_t ui = 0; ui < net->units.size(); ++ui) {
@@ -1409,13 +1425,13 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     auto head_forward = [&](const ConvLayer& hd, int li, int njt, float* out) -> hipError_t {
         const float* rin = range_of(xin);
         const float* rw = tr->d_wrng ? tr->d_wrng + (size_t)li * ABSMAX_SLOTS : nullptr;
-        if (!(head_pw && g_rng.on && rin && rw && hd.d_wh3_pw && tr->d_h3_table))
+        if (!(head_pw && g_ctx->rng.on && rin && rw && hd.d_wh3_pw && tr->d_h3_table))
             return conv_launch(hd, hd.d_w, hd.nk, hd.CoutP, xin, B, h, w, hd.Cin, 1, 1, h, w, hd.Cout, 1, 0, nullptr, hd.d_bias,
                                nullptr, 0, 0, 0, nullptr, false, 1, njt, out, s);
         float* T = F(pl.g0);                       // gradient scratch: free during the forward pass
         ConvArgs a{};
         a.in = xin; a.wpk = hd.d_w_pw; a.wh3 = hd.d_wh3_pw; a.out = T; a.in_absmax = rin; a.w_absmax = rw;
-        a.slab = g_tail_slab; a.slab_bytes = g_tail_slab ? (unsigned)(TAIL_SLAB_FLOATS * sizeof(float)) : 0u;
+        a.slab = g_ctx->tail_slab; a.slab_bytes = g_ctx->tail_slab ? (unsigned)(TAIL_SLAB_FLOATS * sizeof(float)) : 0u;
         a.N = B; a.H = h; a.W = w; a.Cin = hd.Cin; a.log2cin4 = ilog2(hd.Cin / 4);
         a.Ho = h; a.Wo = w; a.Cout = hd.coutp_pw; a.CoutP = hd.coutp_pw;
         a.KH = 1; a.KW = 1; a.stride = 1; a.dil = 1; a.ntaps = 1; a.nk = nk_for(1, 1, hd.Cin); a.M = B * h * w;
@@ -1436,18 +1452,16 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
 // Deferred finalisation (default; DGP_WGRAD_DEFER=0: per layer as before): every non-head layer accumulates dWraw / colsum in its
 // own region of the workspace (zeroed once per pass) and two launches at the end of dgp_train_backward turn them into dW, d gamma,
 // d beta for all layers -- ~150 dispatches fewer per step than fill + fill + wgrad + scale + bn per layer.
-static const TPlan* g_defer_plan = nullptr;
-static char* g_defer_ws = nullptr;
 
 static int layer_param_grads(dgp_trainer* tr, size_t li, const float* x, int N, int H, int W, const float* dy, int Ho,
                              int Wo, int stride, int pad_t, int pad_l, float* dwraw, float* colsum, hipStream_t s) {
     dgp_net* net = tr->net;
     const ConvLayer& l = net->layers[li];
     const TLayer& t = tr->tl[li];
-    if (g_defer_plan) {
+    if (g_ctx->defer_plan) {
         TRY_HIP(wgrad_launch(x, N, H, W, l.Cin, dy, Ho, Wo, l.Cout, l.KH, l.KW, stride, l.rate, pad_t, pad_l,
-                             reinterpret_cast<float*>(g_defer_ws + g_defer_plan->dw_l[li]),
-                             reinterpret_cast<float*>(g_defer_ws + g_defer_plan->cs_l[li]), s, true));
+                             reinterpret_cast<float*>(g_ctx->defer_ws + ((const TPlan*)g_ctx->defer_plan)->dw_l[li]),
+                             reinterpret_cast<float*>(g_ctx->defer_ws + ((const TPlan*)g_ctx->defer_plan)->cs_l[li]), s, true));
         return DGP_OK;
     }
     TRY_HIP(wgrad_launch(x, N, H, W, l.Cin, dy, Ho, Wo, l.Cout, l.KH, l.KW, stride, l.rate, pad_t, pad_l, dwraw, colsum, s));
@@ -1464,6 +1478,7 @@ static int layer_param_grads(dgp_trainer* tr, size_t li, const float* x, int N, 
 
 int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t workspace_bytes, const float* dscmap,
                        const float* dlocref, void* stream) {
+    if (tr) g_ctx = &tr->ctx;
     if (!tr || !workspace || !dscmap || !dlocref) return fail(DGP_ERR_INVALID, "dgp_train_backward: null argument");
     dgp_net* net = tr->net;
     const TPlan pl = make_tplan(tr, nt);
@@ -1471,14 +1486,14 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     auto F = [&](size_t off) { return (float*)(ws + off); };
-    g_tail_slab = F(pl.tail);
+    g_ctx->tail_slab = F(pl.tail);
     range_pass_begin(tr, s, true);
     const dgp_net_desc& d = net->desc;
     const int B = nt, nj = d.num_joints;
     const int nu = (int)net->units.size();
     static const bool defer_env = !(getenv("DGP_WGRAD_DEFER") && atoi(getenv("DGP_WGRAD_DEFER")) == 0);
-    g_defer_plan = defer_env ? &pl : nullptr;
-    g_defer_ws = ws;
+    g_ctx->defer_plan = defer_env ? &pl : nullptr;
+    g_ctx->defer_ws = ws;
     if (defer_env) TRY_HIP(hipMemsetAsync(ws + pl.dwall, 0, pl.dwall_bytes, s));
     // geometry per unit input
     std::vector<int> hs(nu + 1), wsz(nu + 1);
@@ -1595,8 +1610,8 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         if (rc) return rc;
     }
     (void)nj;
-    if (g_defer_plan) {
-        g_defer_plan = nullptr;
+    if (g_ctx->defer_plan) {
+        g_ctx->defer_plan = nullptr;
         if (!tr->d_fin_table || tr->fin_B != B || tr->fin_h != d.in_h || tr->fin_w != d.in_w) {      // offsets follow the plan
             std::vector<FinDesc> tab;
             for (size_t li = 0; li < net->layers.size(); ++li) {
@@ -1637,6 +1652,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
  * With both ranges (DGP_ABSMAX_SLOTS floats each) the fp16-split kernel wgrad_h3 runs where the tile is 128 x 128, else wgrad_f32. */
 int dgp_conv2d_wgrad(const dgp_conv_desc* d, const float* x, const float* dy, const float* x_absmax, const float* dy_absmax,
                      float* dw_raw, float* colsum, void* stream) {
+    g_ctx = nullptr;              // layer-level call: explicit ranges only
     if (!d || !x || !dy || !dw_raw) return fail(DGP_ERR_INVALID, "dgp_conv2d_wgrad: null argument");
     if (d->Cin < 4 || (d->Cin & 3) || ((d->Cin / 4) & (d->Cin / 4 - 1)) || (d->Cout & 3))
         return fail(DGP_ERR_INVALID, "dgp_conv2d_wgrad: Cin must be 4 * 2^k, Cout a multiple of 4");
@@ -1661,6 +1677,7 @@ size_t dgp_conv2d_dgrad_scratch_bytes(const dgp_conv_desc* d) {
 
 int dgp_conv2d_dgrad(const dgp_conv_desc* d, const float* dy, const float* w_hwio, const float* scale, const float* mask,
                      const float* dx_add, int32_t add_mode, float* dx, void* scratch, int32_t ranged, void* stream) {
+    g_ctx = nullptr;
     if (!d || !dy || !w_hwio || !dx || !scratch) return fail(DGP_ERR_INVALID, "dgp_conv2d_dgrad: null argument");
     if ((d->Cout & 31) || (d->Cin & 3)) return fail(DGP_ERR_INVALID, "dgp_conv2d_dgrad: Cout % 32, Cin % 4");
     hipStream_t s = (hipStream_t)stream;
