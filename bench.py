@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch CPU threads for the baseline (16 was the fastest of 8..128 on the GPU box)")
     ap.add_argument("--layer-table", type=str, default="", help="write the per-launch table (tsv) here")
+    ap.add_argument("--profile-steps", type=int, default=5, help="timed steps instrumented with per-launch hipEvents (roofline)")
     ap.add_argument("--prewarm-seconds", type=float, default=1.5, help="untimed load before the warm-up steps (clock ramp, calibration)")
     ap.add_argument("--sustain-seconds", type=float, default=5.0, help="length of the sustained segment after the timed region")
     args = ap.parse_args()
@@ -137,7 +138,10 @@ def main():
         ddist.gather_trajectory(traj, world * n_local)
     torch.cuda.synchronize(dev)
 
-    net.profile_begin(K)
+    # hipEvent pairs around every launch of the FIRST `prof_steps` steps of the timed region (106 event records per step cost ~4 % of a
+    # step; the remaining steps run uninstrumented).  Per-kernel durations -> the roofline object.
+    prof_steps = min(K, args.profile_steps)
+    net.profile_begin(max(prof_steps, 1))
     barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
