@@ -1954,7 +1954,9 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     // over up to 4 blocks each (raw slabs + a fixup pass that sums them in fixed order: deterministic) so the last round is full.
     a.tail_ksplit = 0; a.n_main = (int)nwg;
     static const int tail_env = getenv("DGP_TAIL_SPLIT") ? atoi(getenv("DGP_TAIL_SPLIT")) : 1;      // A/B switch
-    if (tail_env && a.slab && CW == 4 && BN == 128) {      // (128 x 64 tiles fit three per CU and gain nothing)
+    // (H2 tensors: with the split gone from the K loop the K-split of the tail + its fix-up launch no longer pays -- same-box A/B,
+    //  block3 conv1 -7..-24 %, block4 conv1 -12 %, block4 conv2 -5 % without it, +2.5 % end to end -- so tail_env == 2 is needed to force it)
+    if (tail_env && (!a.in_fmt || tail_env == 2) && a.slab && CW == 4 && BN == 128) {      // (128 x 64 tiles fit three per CU and gain nothing)
         static int n_cu = 0;
         if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
         const long long slots = 2LL * n_cu;            // two workgroups of these kernels fit a CU
