@@ -165,3 +165,15 @@ def test_h2_network_is_deterministic_and_close_to_fp32_activation_path(lib_built
     assert r.returncode == 0, r.stderr[-1500:]
     sc32 = np.load(tmp_path / "sc.npy")
     assert np.abs(a.cpu().numpy() - sc32).max() <= 2e-5 * np.abs(sc32).max()
+
+
+def test_tail_split_fixup_on_h2_tensors_in_a_child_process(lib_built):
+    """The K-split of the grid tail is off by default for H2 launches (measured slower); DGP_TAIL_SPLIT=2 forces it.  The batch-32
+    block3 shape (600 tiles: 88 tail tiles split 4 ways + tail_fixup_h2_kernel) then has to give the same parity."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DGP_TAIL_SPLIT="2", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_h2_gpu.py"), "-q", "-m", "gpu", "-k",
+                        "test_conv_on_h2_tensors_matches_float64 and (case9 or case5)"], env=env, cwd=root, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
