@@ -1073,7 +1073,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
     constexpr int LDAF = BM + 1;                   // CS: fp32 image [chunk][row][4 floats], one pad slot per chunk plane
     constexpr int A_CELLS = DMA ? BM * CH : (CS ? CH * LDAF : NP * KG * LDA), B_CELLS = NP * KG * LDB;     // 16-byte cells per buffer
     constexpr int NSA = DMA ? 3 : 2;               // A stages
-    static_assert(!DMA || (CS && MODE != 0 && BN == 128 && BM == 128 && CW == 4), "LDS-DMA loaders: CS kernels, plain or pointwise walk, 128 x 128");
+    static_assert(!DMA || (CS && MODE != 0 && (BN == 128 || BN == 64) && BM == 128 && CW == 4), "LDS-DMA loaders: CS kernels, plain or pointwise walk, 128 rows");
     static_assert(!CS || (PB && NT == 2 && BK == 32), "compute-side split: fp16 path, pre-split weights, BK 32");
     constexpr int LDC = WN + 4;
     static_assert(NT == 2 || NT == 3 || NT == 6, "6 / 3 bf16 products, or NT = 2: fp16 high/low pair (3 products)");
@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             char* smB = smem + NSA * A_CELLS * 16;
             // one loop, one issue site per operand (the walkers stay in SGPRs): iteration `it` issues B(it + 1) and A(it + 2), waits
             // until everything but A(it + 2) has landed and meets the compute waves at barrier it + 1
-            static_assert(AROWS == 4 && BSLOTS == 4, "counted waits below assume 4 + 4 DMA instructions per wave and K-step");
+            static_assert(AROWS == 4 && (BSLOTS == 4 || BSLOTS == 2), "counted waits below: vmcnt(4) = everything but the newest A stage (4 instructions)");
             int sa = 0, sb = 0;
             for (int it = -2; it < nks; ++it) {
                 if (it >= -1 && it + 1 < nks) {
@@ -1446,7 +1446,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
 #if !defined(DGP_MFMA32)
     // 16x16x32 MFMAs in the pipelined loop of the 32 x 128 wave tile: the same FLOPs, LDS bytes and register reads as the 32x32x16
     // shape in twice as many, half as long matrix instructions -- +5.3 % end to end (block4 3x3: 0.499 -> 0.453 ms)
-    constexpr bool M16 = CS && TM == 1 && TN == 4 && NT == 2 && BK == 32;
+    constexpr bool M16 = CS && TM == 1 && (TN == 4 || (TN == 2 && DMA)) && NT == 2 && BK == 32;      // (32 x 64 wave tiles: DMA images only)
 #else
     constexpr bool M16 = false;
 #endif
@@ -1459,11 +1459,12 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
         // register-staged images are laid out for the 32-lane fragment reads.)
         typedef float floatx4 __attribute__((ext_vector_type(4)));
         const int l15 = lane & 15, g = lane >> 4;
-        floatx4 c[2][8];
+        constexpr int NJ = 2 * TN, NF = 2 * NJ;          // 16-wide column blocks of the wave tile (8 or 4), B fragments per K-step
+        floatx4 c[2][NJ];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) c[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NJ; ++j) c[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
         const uint4* a_lane = sA + (2 * g) * LDAF + wave_m0 + l15;                 // register-staged image [chunk][row]
         // DMA image: row-major, chunk ch of row r in slot ch ^ ((r >> 1) & 7) (same for r and r + 16); this lane wants chunks 2 g, 2 g + 1
         const unsigned a_row0 = (unsigned)((wave_m0 + l15) * 128 + (((2 * g) ^ (((wave_m0 + l15) >> 1) & 7)) << 4));
@@ -1481,7 +1482,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             ra[I][0] = *reinterpret_cast<const uint4*>(smem + a_cur + (I) * 2048);                                 \
             ra[I][1] = *reinterpret_cast<const uint4*>(smem + (a_cur ^ 16u) + (I) * 2048);                         \
         } else { ra[I][0] = A[16 * (I)]; ra[I][1] = A[LDAF + 16 * (I)]; } } while (0)
-#define DGP_RB(F) do { bq[(F) & 3] = B[((((F) & 1) ? 0 : 1) * KG) * LDB + 16 * (((F) & 15) >> 1)]; } while (0)
+#define DGP_RB(F) do { bq[(F) & 3] = B[((((F) & 1) ? 0 : 1) * KG) * LDB + 16 * (((F) % NF) >> 1)]; } while (0)
 #if defined(DGP_X) && DGP_X == 1      // timing-only stand-in: the A operand as if it arrived pre-split (no split arithmetic)
 #define DGP_SPLIT(I) do { ah[I] = ra[I][0]; al[I] = ra[I][1]; } while (0)
 #else
@@ -1501,7 +1502,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             DGP_RA(0); DGP_RA(1);
             DGP_SPLIT(0); DGP_SPLIT(1);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const uint4 bl = B[(1 * KG) * LDB + 16 * j], bh = B[16 * j];
 #if DGP_M16_SIMPLE != 2
                 c[0][j] = mma(ah[0], bl, c[0][j]); c[1][j] = mma(ah[1], bl, c[1][j]);
@@ -1524,6 +1525,25 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             DGP_SPLIT(0);
             DGP_SPLIT(1);
             DGP_FENCE();
+            if constexpr (TN == 2) {       // 32 x 64 wave tile: 8 fragments per step, same ring and barrier placement
+                DGP_STEP(0); DGP_STEP(1); DGP_STEP(2); DGP_STEP(3);
+                DGP_MM(4); DGP_FENCE();
+                DGP_MM(5); DGP_FENCE();
+                __syncthreads();
+                if constexpr (DMA) { sa_c = sa_c == 2 ? 0 : sa_c + 1; a_cur = a_row0 + (unsigned)(sa_c * (A_CELLS * 16)); }
+                else { A += da; da = -da; }
+                B += db; db = -db;
+                const bool more2 = ks + 1 < nks;
+                if (more2) { DGP_RA(0); DGP_RA(1); DGP_RB(0); DGP_RB(1); }
+                DGP_FENCE();
+                DGP_MM(6); DGP_FENCE();
+                if (more2) DGP_RB(2);
+                DGP_FENCE();
+                DGP_MM(7); DGP_FENCE();
+                if (more2) DGP_RB(3);
+                DGP_FENCE();
+                continue;
+            }
             DGP_STEP(0); DGP_STEP(1); DGP_STEP(2); DGP_STEP(3); DGP_STEP(4); DGP_STEP(5);
             DGP_STEP(6); DGP_STEP(7); DGP_STEP(8); DGP_STEP(9); DGP_STEP(10); DGP_STEP(11);
             DGP_MM(12); DGP_FENCE();
@@ -1561,14 +1581,14 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sCw[(16 * i + 4 * g + r) * LDCW + 16 * j + l15] = c[i][j][r];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     } else
 #if !defined(DGP_NO_PIPE)
-    static_assert(!DMA || (TM == 1 && TN == 4), "DMA image is read by the pipelined loop only");
+    static_assert(!DMA || (TM == 1 && (TN == 4 || TN == 2)), "DMA image is read by the pipelined loop only");
     static_assert(!(DMA && AH2) || M16, "pre-split A + DMA image: 16x16x32 loop only");
     if constexpr (CS && TM == 1 && TN == 4 && NT == 2 && BK == 32 && !AH2) {
         // Software-pipelined K loop of the 32 x 128 wave tile.  hipcc's schedule read each B fragment right before its MFMAs
@@ -1912,7 +1932,7 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     else kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 2>
               : mode == 1 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 1> : conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 0>;
     // LDS-DMA loaders (A/B switch DGP_DMA=0): 128 x 128 CS kernels with the plain or the pointwise walk
-    constexpr bool CAN_DMA = CAN_CS && BM == 128 && BN == 128;
+    constexpr bool CAN_DMA = CAN_CS && BM == 128 && (BN == 128 || BN == 64);
     static const int dma_env = getenv("DGP_DMA") ? atoi(getenv("DGP_DMA")) : 1;
     const bool dma = CAN_DMA && cs && mode != 0 && dma_env;
     if (dma) {
