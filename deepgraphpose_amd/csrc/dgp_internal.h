@@ -133,6 +133,8 @@ struct DlcLossArgs {                      // DLC step-0 loss (sigmoid CE on bina
 };
 hipError_t launch_dlc_loss(const DlcLossArgs& a, hipStream_t s);
 
+// hipFuncSetAttribute applies to the CURRENT device: the "done once" flags of the launchers are kept per device
+inline int dgp_device_slot() { int d = 0; (void)hipGetDevice(&d); return d & 15; }
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
 

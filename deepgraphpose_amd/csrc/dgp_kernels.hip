@@ -782,7 +782,8 @@ static hipError_t launch_conv_ls(ConvArgs a, hipStream_t s) {
     a.ntiles = (a.CoutP + BN - 1) / BN;
     if (a.CoutP % BN != 0 || a.Cin < 32 || a.out_mode != 0) return hipErrorInvalidValue;
     auto kern = conv_igemm_f32_ls<BM, BN>;
-    static bool attr_done = false;
+    static bool attr_done_dev[16] = {};
+    bool& attr_done = attr_done_dev[dgp_device_slot()];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1962,7 +1963,8 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
             }
         }
     } else if (a.out_fmt) return hipErrorInvalidValue;
-    static bool attr_done[3][4][3] = {};
+    static bool attr_done_dev[16][3][4][3] = {};
+    auto& attr_done = attr_done_dev[dgp_device_slot()];
     if (!attr_done[a.in_fmt ? (a.out_fmt ? 2 : 1) : 0][dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2047,7 +2049,8 @@ static hipError_t launch_conv_t(ConvArgs a, hipStream_t s) {
 #endif
     if (a.CoutP % BN != 0) return hipErrorInvalidValue;       // weight panels are padded to the tile
     auto kern = conv_igemm_f32<BM, BN, WAVES_M, WAVES_N, WIDE>;
-    static bool attr_done = false;   // per instantiation
+    static bool attr_done_dev[16] = {};   // per instantiation and device
+    bool& attr_done = attr_done_dev[dgp_device_slot()];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2704,7 +2707,8 @@ hipError_t launch_stem_pool_fused(const unsigned char* frames, int B, int H, int
     a.pbh = pth / 2; a.pbw = ptw / 2;
     a.tiles_h = (a.HP + 4) / 5; a.tiles_w = (a.WP + 15) / 16; a.ntiles = B * a.tiles_h * a.tiles_w;
     constexpr size_t smem = (size_t)7 * 4 * 2 * 64 * 16 + (size_t)23 * 16 * 68 * 4;
-    static bool attr = false;
+    static bool attr_dev[16] = {};
+    bool& attr = attr_dev[dgp_device_slot()];
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -2847,7 +2851,8 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
 hipError_t launch_soft_argmax(const float* scmap, int B, int H, int W, int C, float gamma, int gauss_len,
                               float* mu, float* conf, int* idx, float* pmap, hipStream_t s, int record_stride) {
     const size_t smem = (size_t)H * W * sizeof(float);
-    static size_t attr_set = 0;
+    static size_t attr_set_dev[16] = {};
+    size_t& attr_set = attr_set_dev[dgp_device_slot()];
     if (smem > 64 * 1024 && smem > attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(soft_argmax_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

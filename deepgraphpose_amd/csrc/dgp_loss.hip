@@ -519,7 +519,8 @@ hipError_t launch_loss(const LossArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(loss_marker_stats, dim3(nm), dim3(256), 0, s, a);
     hipLaunchKernelGGL(loss_normalisers, dim3(1), dim3(256), 0, s, a);
     const size_t smem = (size_t)2 * a.H * a.W * sizeof(float);
-    static bool attr = false;
+    static bool attr_dev[16] = {};
+    bool& attr = attr_dev[dgp_device_slot()];
     if (!attr) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(loss_ce_backward),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);

@@ -1112,7 +1112,8 @@ hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const floa
     if (mpb < 256) mpb = 256;
     split = (a.M + mpb - 1) / mpb;
     a.m_per_block = mpb;
-    static bool attr[3] = {false, false, false};
+    static bool attr_dev[16][3] = {};
+    auto& attr = attr_dev[dgp_device_slot()];
     static const bool h3_env = !(getenv("DGP_WGRAD_F16") && atoi(getenv("DGP_WGRAD_F16")) == 0);       // A/B switch
     const float* rx = rx_given ? rx_given : range_of(x);
     const float* rdy = rdy_given ? rdy_given : range_of(dy);

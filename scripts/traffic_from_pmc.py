@@ -32,21 +32,23 @@ def load(sub, counter):
 
 fetch, nf = load("pmc_fetch", "FETCH_SIZE")
 write, nw = load("pmc_write", "WRITE_SIZE")
-steps = max(nf.get("soft_argmax_kernel", 0), 1)
+steps_f = max(nf.get("soft_argmax_kernel", 0), 1)       # each pass is normalised by ITS OWN step count (one soft-argmax launch per step)
+steps_w = max(nw.get("soft_argmax_kernel", 0), 1)
+steps = steps_f
 CONV = ("conv_igemm", "stem_pool_fused", "tail_fixup", "head_gather", "maxpool3x3s2", "preprocess_u8", "reduce_slabs")
 per_kernel, tot_fetch, tot_write = {}, 0.0, 0.0
 for k in sorted(set(fetch) | set(write)):
     if not any(c in k for c in CONV):
         continue
-    n = max(nf.get(k, 0), nw.get(k, 0), 1)
     fb, wb = fetch.get(k, 0.0) * 1024.0 * 2.0, write.get(k, 0.0) * 1024.0
-    per_kernel[k] = {"launches_per_step": n / steps, "hbm_bytes_per_launch": (fb + wb) / n,
-                     "fetch_bytes_per_launch_corrected": fb / n, "write_bytes_per_launch": wb / n}
-    tot_fetch += fb
-    tot_write += wb
-res = {"conv_hbm_bytes_per_step": (tot_fetch + tot_write) / steps, "fetch_bytes_per_step_corrected": tot_fetch / steps,
-       "write_bytes_per_step": tot_write / steps, "fetch_correction": 2.0, "steps_in_profile": steps, "per_kernel": per_kernel,
+    fpl, wpl = fb / max(nf.get(k, 0), 1), wb / max(nw.get(k, 0), 1)
+    per_kernel[k] = {"launches_per_step": nf.get(k, 0) / steps_f, "hbm_bytes_per_launch": fpl + wpl,
+                     "fetch_bytes_per_launch_corrected": fpl, "write_bytes_per_launch": wpl}
+    tot_fetch += fb / steps_f
+    tot_write += wb / steps_w
+res = {"conv_hbm_bytes_per_step": tot_fetch + tot_write, "fetch_bytes_per_step_corrected": tot_fetch,
+       "write_bytes_per_step": tot_write, "fetch_correction": 2.0, "steps_in_profile": steps, "per_kernel": per_kernel,
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around bench.py, scripts/profile.sh"}
 json.dump(res, open(out, "w"), indent=1)
-print("conv stack: %.2f GB per step (fetch %.2f corrected, write %.2f), %d steps" % (res["conv_hbm_bytes_per_step"] / 1e9, tot_fetch / steps / 1e9,
-                                                                                   tot_write / steps / 1e9, steps))
+print("conv stack: %.2f GB per step (fetch %.2f corrected over %d steps, write %.2f over %d steps)" % (
+    res["conv_hbm_bytes_per_step"] / 1e9, tot_fetch / 1e9, steps_f, tot_write / 1e9, steps_w))
