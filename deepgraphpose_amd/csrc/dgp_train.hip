@@ -413,6 +413,19 @@ __device__ __forceinline__ unsigned swz_off(int row, int ch) { return 256u * row
 
 struct WgradRanges { const float* x_absmax; const float* dy_absmax; };
 
+#ifdef DGP_DIAG
+// diagnostic build only: s_memtime stamps fence the schedule; read SHARES, not totals (scripts/diag_wgrad.py)
+#define WG_STAMP(x)                                                                     \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+    } while (0)
+__device__ unsigned long long g_wgrad_diag[16];
+#else
+#define WG_STAMP(x)
+#endif
+
 __global__ __launch_bounds__(256) void wgrad_h3(const WgradArgs p, const WgradRanges rg) {
     constexpr int BR = 128, CH = 32, NLD = 4;
     constexpr unsigned PLANE = 32 * 256;          // bytes of one fp16 plane of a 32-pixel tile
@@ -512,12 +525,18 @@ __global__ __launch_bounds__(256) void wgrad_h3(const WgradArgs p, const WgradRa
         return smem_base + (unsigned)(buf * 4 * PLANE + plane * PLANE) + swz_off(row, col >> 3) + 8u * ((col >> 2) & 1);
     };
 
+#ifdef DGP_DIAG
+    unsigned long long T0 = 0, T1 = 0, T2[2] = {0, 0}, T3[2] = {0, 0}, T4 = 0, T5 = 0, TB = 0, TE = 0, dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    WG_STAMP(TB);
+#endif
     gload(0);
     lstore(0);
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
+        WG_STAMP(T0);
         if (s + 1 < nsteps) gload(s + 1);
+        WG_STAMP(T1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             // operands: [operand A/B][block][piece hi/lo] = 8 halves = two transposed reads of 4 pixels each
@@ -541,6 +560,7 @@ __global__ __launch_bounds__(256) void wgrad_h3(const WgradArgs p, const WgradRa
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
                     for (int pc = 0; pc < 2; ++pc) asm volatile("" : "+v"(lo4[op][b][pc]), "+v"(hi4[op][b][pc]));
+            WG_STAMP(T2[kk]);
             auto frag = [&](int op, int b, int pc) {
                 const uint4 u = make_uint4((unsigned)lo4[op][b][pc], (unsigned)(lo4[op][b][pc] >> 32), (unsigned)hi4[op][b][pc],
                                            (unsigned)(hi4[op][b][pc] >> 32));
@@ -556,10 +576,295 @@ __global__ __launch_bounds__(256) void wgrad_h3(const WgradArgs p, const WgradRa
                     a = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(0, i, 0), frag(1, j, 0), a, 0, 0, 0);      // hi * hi
                     acc[i][j] = a;
                 }
+            WG_STAMP(T3[kk]);
         }
         if (s + 1 < nsteps) lstore(buf ^ 1);
+        WG_STAMP(T4);
         __syncthreads();
+#ifdef DGP_DIAG
+        WG_STAMP(T5);
+        dsum[0] += T1 - T0; dsum[1] += T2[0] - T1; dsum[2] += T3[0] - T2[0]; dsum[3] += T2[1] - T3[0];
+        dsum[4] += T3[1] - T2[1]; dsum[5] += T4 - T3[1]; dsum[6] += T5 - T4;
+#endif
     }
+#ifdef DGP_DIAG
+    WG_STAMP(TE);
+#endif
+    if (do_colsum && cok) {
+        atomicAdd(p.colsum + cob, cs4.x); atomicAdd(p.colsum + cob + 1, cs4.y);
+        atomicAdd(p.colsum + cob + 2, cs4.z); atomicAdd(p.colsum + cob + 3, cs4.w);
+    }
+    // C/D layout: col = lane&31 (co), row = (r&3) + 8*(r>>2) + 4*half (k)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = n0 + wn * 64 + 32 * j + l31;
+        if (co >= p.Cdy) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = q0 * 4 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (k < p.kchunks * 4) atomicAdd(p.dw + (long long)k * p.Cdy + co, acc[i][j][r] * post);
+            }
+    }
+#ifdef DGP_DIAG
+    if (lane == 0 && wave == 0) {
+        unsigned long long TF;
+        WG_STAMP(TF);
+        for (int k = 0; k < 7; ++k) atomicAdd(&g_wgrad_diag[k], dsum[k]);
+        atomicAdd(&g_wgrad_diag[7], T0 ? (unsigned long long)nsteps : 0ull);
+        atomicAdd(&g_wgrad_diag[8], TE - TB);        // prologue + loop
+        atomicAdd(&g_wgrad_diag[9], TF - TE);        // atomics epilogue (issue + colsum)
+        atomicAdd(&g_wgrad_diag[10], 1ull);
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad_h3p: wgrad_h3 as an explicit software pipeline.  scripts/diag_wgrad.py stamps on wgrad_h3 (b4.conv2, cycles per 32-pixel
+// step of 4400): staging-load issue 1630, transposed reads 690, the 24 MFMAs 850, split + LDS stores 1100, barrier 130 -- the
+// phases of a wave ran one after the other and the four waves of a workgroup ran them in lock-step, so each shared unit (texture
+// addresser, LDS, matrix pipe) was busy in bursts and idle between them (PMC: TA busy 22 %, L2 hit 83 %, L1->L2 latency 173 cycles,
+// MFMA busy 23 %).  Here every MFMA is followed by a fixed slice of the other work:
+//   first half of a step  : 12 MFMAs on pixel group 0 | transposed reads of group 1 | split + store of the rows loaded one step ago
+//   barrier
+//   second half           : 12 MFMAs on pixel group 1 | transposed reads of the NEXT step's group 0 | global loads for step + 2
+// MFMAs go round the four accumulator blocks (dependent MFMAs are four issues apart).  LDS addresses are 10 lane registers plus
+// instruction offsets (the swizzle XOR splits into a lane part and the constants 4 b and h), staging offsets advance by adds.
+// ------------------------------------------------------------------------------------------------
+template <unsigned OFF>
+__device__ __forceinline__ unsigned long long trr(unsigned base) {
+    unsigned long long v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(OFF) : "memory");
+    return v;
+}
+
+struct WgFrag { unsigned long long v[2][2]; };          // [piece hi/lo][pixels 0-3 / 4-7] of one 32-channel block, one k-group
+
+__device__ __forceinline__ half8t wg_op(const WgFrag& f, int pc) {
+    const uint4 u = make_uint4((unsigned)f.v[pc][0], (unsigned)(f.v[pc][0] >> 32), (unsigned)f.v[pc][1], (unsigned)(f.v[pc][1] >> 32));
+    return __builtin_bit_cast(half8t, u);
+}
+
+__global__ __launch_bounds__(256) void wgrad_h3p(const WgradArgs p, const WgradRanges rg) {
+    constexpr int CH = 32;
+    constexpr unsigned PLANE = 8192u, BUF = 32768u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 buffers][A hi, A lo, B hi, B lo][32 pixels x 256 B]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, half = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int q0 = blockIdx.x * CH;
+    const int n0 = blockIdx.y * 128;
+    const int m_lo = blockIdx.z * p.m_per_block;
+    const int m_hi = min(p.M, m_lo + p.m_per_block);
+    const int nsteps = (m_hi - m_lo + 31) / 32;
+    if (nsteps <= 0) return;
+    const bool pointwise = p.ntaps == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && p.H == p.Ho && p.W == p.Wo;
+    // rows at and beyond m_hi read as zeros through the descriptors' range check where the offset grows with the pixel index
+    const unsigned x_lim = pointwise ? (unsigned)min((long long)p.x_bytes, (long long)m_hi * p.Cin * 4) : p.x_bytes;
+    const unsigned dy_lim = (unsigned)min((long long)p.dy_bytes, (long long)m_hi * p.Cdy * 4);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)x_lim, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)dy_lim, 0x00020000);
+    const float sx = rng_scale(rg.x_absmax, lane), sy = rng_scale(rg.dy_absmax, lane);
+    const float post = 1.f / (sx * sy);
+
+    const int cc = t % CH, pr = t / CH;           // this thread stages 4-channel chunk cc of pixel rows pr + 8 i
+    const int q = q0 + cc;
+    const int cin4m1 = (p.Cin >> 2) - 1;
+    const int tap = q >> p.log2cin4, ch = (q & cin4m1) << 2;
+    const bool qok = q < p.kchunks && tap < p.ntaps;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int dh = kh * p.dil - p.pad_t, dw = kw * p.dil - p.pad_l;
+    const int cob = n0 + 4 * cc;
+    const bool cok = cob < p.Cdy;
+    const int HoWo = p.Ho * p.Wo;
+
+    // staging walkers: byte offsets of this thread's four pixel rows, advanced by 32 pixels per load
+    unsigned offb[4], offa[4];
+    int whi[4], wwi[4], mleft[4];
+    const unsigned stepb = cok ? 32u * (unsigned)p.Cdy * 4u : 0u;
+    const unsigned stepa_pw = qok ? 32u * (unsigned)p.Cin * 4u : 0u;
+    const int hlim = p.Ho * p.stride + dh, wlim = p.Wo * p.stride + dw;
+    const unsigned d_px = (unsigned)(32 * p.stride * p.Cin * 4);
+    const unsigned d_row = (unsigned)((p.stride * p.W - p.Wo * p.stride) * p.Cin * 4);
+    const unsigned d_img = (unsigned)((p.H * p.W - p.Ho * p.stride * p.W) * p.Cin * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m_lo + pr + 8 * i;
+        offb[i] = cok ? (unsigned)(m * p.Cdy + cob) << 2 : OOBT;
+        if (pointwise) {
+            offa[i] = qok ? (unsigned)(m * p.Cin + ch) << 2 : OOBT;
+            whi[i] = wwi[i] = mleft[i] = 0;
+        } else {
+            const int n = m / HoWo, rem = m - n * HoWo;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            whi[i] = ho * p.stride + dh;
+            wwi[i] = wo * p.stride + dw;
+            offa[i] = (unsigned)(((n * p.H + whi[i]) * p.W + wwi[i]) * p.Cin + ch) << 2;
+            mleft[i] = m_hi - m;
+        }
+    }
+    float4 ra[4], rb[4];
+    auto load_a = [&](int i) {
+        if (pointwise) {
+            ra[i] = bload16(rs_x, offa[i]);
+            offa[i] += stepa_pw;
+        } else {
+            const bool ok = qok && mleft[i] > 0 && (unsigned)whi[i] < (unsigned)p.H && (unsigned)wwi[i] < (unsigned)p.W;
+            ra[i] = bload16(rs_x, ok ? offa[i] : OOBT);
+            mleft[i] -= 32;
+            wwi[i] += 32 * p.stride;
+            offa[i] += d_px;
+            while (wwi[i] >= wlim) {
+                wwi[i] -= p.Wo * p.stride;
+                whi[i] += p.stride;
+                offa[i] += d_row;
+                if (whi[i] >= hlim) { whi[i] -= p.Ho * p.stride; offa[i] += d_img; }
+            }
+        }
+    };
+    auto load_b = [&](int i) {
+        rb[i] = bload16(rs_dy, offb[i]);
+        offb[i] += stepb;
+    };
+    float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool do_colsum = p.colsum != nullptr && blockIdx.x == 0;
+
+    // LDS store bases (even / odd i): row pr + 8 i, 16-byte chunk cc >> 1 swizzled, 8-byte half cc & 1
+    const int lw = (cc >> 1) ^ (((pr & 3) << 2) | (pr >> 2));
+    char* wbase[2];
+    wbase[0] = smem + 256 * pr + 16 * lw + 8 * (cc & 1);
+    wbase[1] = smem + 256 * pr + 16 * (lw ^ 2) + 8 * (cc & 1);
+    // transposed-read bases [operand][block b][pixel half h]
+    const int g16 = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    const int f_lane = (qq << 2) | (2 * (g16 >> 1));
+    const unsigned rrow = (unsigned)(size_t)smem + 256u * (8 * (g16 >> 1) + qq) + 8u * (pp & 1);
+    unsigned rbase[2][2][2];
+#pragma unroll
+    for (int op = 0; op < 2; ++op) {
+        const int L = (8 * (op == 0 ? wm : wn) + 2 * (g16 & 1) + (pp >> 1)) ^ f_lane;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) rbase[op][b][h] = rrow + 16u * (unsigned)(L ^ (4 * b) ^ h);
+    }
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    WgFrag F0[2][2], F1[2][2];          // [operand][block]
+
+#define WG_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // one split + store unit: u < 4 -> x row u (planes 0, 1), else dY row u - 4 (planes 2, 3)
+#define WG_UNIT(SB, U)                                                                                               \
+    do {                                                                                                             \
+        constexpr int i_ = (U) & 3;                                                                                  \
+        char* d_ = wbase[i_ & 1] + (SB) * BUF + 2048 * i_ + ((U) < 4 ? 0 : 2 * PLANE);                               \
+        uint2 h_, l_;                                                                                                \
+        if ((U) < 4) split_hl(ra[i_], sx, h_, l_);                                                                   \
+        else {                                                                                                       \
+            split_hl(rb[i_], sy, h_, l_);                                                                            \
+            if (do_colsum) { cs4.x += rb[i_].x; cs4.y += rb[i_].y; cs4.z += rb[i_].z; cs4.w += rb[i_].w; }           \
+        }                                                                                                            \
+        *reinterpret_cast<uint2*>(d_) = h_;                                                                          \
+        *reinterpret_cast<uint2*>(d_ + PLANE) = l_;                                                                  \
+    } while (0)
+#define WG_LOAD(U) do { if ((U) < 4) load_a((U) & 3); else load_b((U) & 3); } while (0)
+    // read slice R (0..7) of a fragment set: two of its sixteen transposed reads
+#define WG_READ2(F, BUFI, KK, R)                                                                                     \
+    do {                                                                                                             \
+        constexpr int op_ = ((R) >> 2) & 1, b_ = ((R) >> 1) & 1, pc_ = (R) & 1;                                      \
+        constexpr unsigned o_ = (BUFI) * BUF + 4096u * (KK) + (2 * op_ + pc_) * PLANE;                               \
+        F[op_][b_].v[pc_][0] = trr<o_>(rbase[op_][b_][0]);                                                           \
+        F[op_][b_].v[pc_][1] = trr<o_ + 1024u>(rbase[op_][b_][1]);                                                   \
+    } while (0)
+    // MFMA number G (0..11) of a half step: term G / 4 (lo*hi, hi*lo, hi*hi), block G % 4
+#define WG_MMA(F, G)                                                                                                 \
+    do {                                                                                                             \
+        constexpr int blk_ = (G) & 3, i_ = blk_ >> 1, j_ = blk_ & 1, term_ = (G) >> 2;                               \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wg_op(F[0][i_], term_ == 0 ? 1 : 0),                    \
+                                                             wg_op(F[1][j_], term_ == 1 ? 1 : 0), acc[i_][j_], 0, 0, 0); \
+    } while (0)
+#define WG_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+    // prologue: step 0 -> buffer 0, step 1 -> registers, fragments of step 0 / pixel group 0
+#pragma unroll
+    for (int u = 0; u < 8; ++u) WG_LOAD(u);
+    WG_UNIT(0, 0); WG_UNIT(0, 1); WG_UNIT(0, 2); WG_UNIT(0, 3); WG_UNIT(0, 4); WG_UNIT(0, 5); WG_UNIT(0, 6); WG_UNIT(0, 7);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) WG_LOAD(u);
+    __syncthreads();
+    WG_READ2(F0, 0, 0, 0); WG_READ2(F0, 0, 0, 1); WG_READ2(F0, 0, 0, 2); WG_READ2(F0, 0, 0, 3);
+    WG_READ2(F0, 0, 0, 4); WG_READ2(F0, 0, 0, 5); WG_READ2(F0, 0, 0, 6); WG_READ2(F0, 0, 0, 7);
+    WG_WAIT_LDS();
+    WG_FENCE();
+
+#if defined(DGP_WX)      // timing-only ablations (results are garbage): scripts/ablate_wgrad.sh
+#if DGP_WX == 1         // no global loads inside the loop
+#undef WG_LOAD
+#define WG_LOAD(U) do { if ((U) < 4) asm volatile("" : "+v"(ra[(U) & 3].x), "+v"(ra[(U) & 3].y), "+v"(ra[(U) & 3].z), "+v"(ra[(U) & 3].w)); else asm volatile("" : "+v"(rb[(U) & 3].x), "+v"(rb[(U) & 3].y), "+v"(rb[(U) & 3].z), "+v"(rb[(U) & 3].w)); } while (0)
+#elif DGP_WX == 2       // no MFMAs
+#undef WG_MMA
+#define WG_MMA(F, G) do { asm volatile("" :: "v"(F[0][0].v[0][0]), "v"(F[0][1].v[0][0]), "v"(F[1][0].v[0][0]), "v"(F[1][1].v[0][0]), "v"(F[0][0].v[1][1]), "v"(F[0][1].v[1][1]), "v"(F[1][0].v[1][1]), "v"(F[1][1].v[1][1])); } while (0)
+#elif DGP_WX == 3       // no transposed reads inside the loop
+#undef WG_READ2
+#define WG_READ2(F, BUFI, KK, R) do { constexpr int op_ = ((R) >> 2) & 1, b_ = ((R) >> 1) & 1, pc_ = (R) & 1; asm volatile("" : "+v"(F[op_][b_].v[pc_][0]), "+v"(F[op_][b_].v[pc_][1])); } while (0)
+#elif DGP_WX == 4       // no split + store inside the loop
+#undef WG_UNIT
+#define WG_UNIT(SB, U) do { asm volatile("" :: "v"(ra[(U) & 3].x), "v"(rb[(U) & 3].x)); } while (0)
+#elif DGP_WX == 5       // no mid-step barrier
+#define __syncthreads() do { } while (0)
+#endif
+#endif
+    // one step on compute buffer CB: stores go to the other buffer, the next step's first fragments come from it
+#define WG_STEP(CB)                                                                                                  \
+    do {                                                                                                             \
+        WG_MMA(F0, 0);  WG_FENCE(); WG_READ2(F1, CB, 1, 0); WG_FENCE();                                              \
+        WG_MMA(F0, 1);  WG_FENCE(); WG_READ2(F1, CB, 1, 1); WG_FENCE();                                              \
+        WG_MMA(F0, 2);  WG_FENCE(); WG_READ2(F1, CB, 1, 2); WG_FENCE();                                              \
+        WG_MMA(F0, 3);  WG_FENCE(); WG_READ2(F1, CB, 1, 3); WG_FENCE();                                              \
+        WG_MMA(F0, 4);  WG_FENCE(); WG_READ2(F1, CB, 1, 4); WG_UNIT(1 - (CB), 0); WG_FENCE();                        \
+        WG_MMA(F0, 5);  WG_FENCE(); WG_READ2(F1, CB, 1, 5); WG_UNIT(1 - (CB), 1); WG_FENCE();                        \
+        WG_MMA(F0, 6);  WG_FENCE(); WG_READ2(F1, CB, 1, 6); WG_UNIT(1 - (CB), 2); WG_FENCE();                        \
+        WG_MMA(F0, 7);  WG_FENCE(); WG_READ2(F1, CB, 1, 7); WG_UNIT(1 - (CB), 3); WG_FENCE();                        \
+        WG_MMA(F0, 8);  WG_FENCE(); WG_UNIT(1 - (CB), 4); WG_FENCE();                                                \
+        WG_MMA(F0, 9);  WG_FENCE(); WG_UNIT(1 - (CB), 5); WG_FENCE();                                                \
+        WG_MMA(F0, 10); WG_FENCE(); WG_UNIT(1 - (CB), 6); WG_FENCE();                                                \
+        WG_MMA(F0, 11); WG_FENCE(); WG_UNIT(1 - (CB), 7); WG_FENCE();                                                \
+        WG_WAIT_LDS();                                                                                               \
+        __syncthreads();                                                                                             \
+        WG_FENCE();                                                                                                  \
+        WG_MMA(F1, 0);  WG_FENCE(); WG_READ2(F0, 1 - (CB), 0, 0); WG_FENCE();                                        \
+        WG_MMA(F1, 1);  WG_FENCE(); WG_READ2(F0, 1 - (CB), 0, 1); WG_FENCE();                                        \
+        WG_MMA(F1, 2);  WG_FENCE(); WG_READ2(F0, 1 - (CB), 0, 2); WG_FENCE();                                        \
+        WG_MMA(F1, 3);  WG_FENCE(); WG_READ2(F0, 1 - (CB), 0, 3); WG_FENCE();                                        \
+        WG_MMA(F1, 4);  WG_FENCE(); WG_READ2(F0, 1 - (CB), 0, 4); WG_LOAD(0); WG_FENCE();                            \
+        WG_MMA(F1, 5);  WG_FENCE(); WG_READ2(F0, 1 - (CB), 0, 5); WG_LOAD(4); WG_FENCE();                            \
+        WG_MMA(F1, 6);  WG_FENCE(); WG_READ2(F0, 1 - (CB), 0, 6); WG_LOAD(1); WG_FENCE();                            \
+        WG_MMA(F1, 7);  WG_FENCE(); WG_READ2(F0, 1 - (CB), 0, 7); WG_LOAD(5); WG_FENCE();                            \
+        WG_MMA(F1, 8);  WG_FENCE(); WG_LOAD(2); WG_FENCE();                                                          \
+        WG_MMA(F1, 9);  WG_FENCE(); WG_LOAD(6); WG_FENCE();                                                          \
+        WG_MMA(F1, 10); WG_FENCE(); WG_LOAD(3); WG_FENCE();                                                          \
+        WG_MMA(F1, 11); WG_FENCE(); WG_LOAD(7); WG_FENCE();                                                          \
+        WG_WAIT_LDS();                                                                                               \
+        WG_FENCE();                                                                                                  \
+    } while (0)
+
+    for (int s = 0; s < nsteps; s += 2) {
+        WG_STEP(0);
+        if (s + 1 < nsteps) WG_STEP(1);
+    }
+#undef WG_STEP
+#undef WG_MMA
+#undef WG_READ2
+#undef WG_LOAD
+#undef WG_UNIT
+#undef WG_FENCE
+#undef WG_WAIT_LDS
+
     if (do_colsum && cok) {
         atomicAdd(p.colsum + cob, cs4.x); atomicAdd(p.colsum + cob + 1, cs4.y);
         atomicAdd(p.colsum + cob + 2, cs4.z); atomicAdd(p.colsum + cob + 3, cs4.w);
@@ -1124,7 +1429,29 @@ hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const floa
             attr[2] = true;
         }
         WgradRanges rg{rx, rdy};
+        static const bool pipe_env = !(getenv("DGP_WGRAD_PIPE") && atoi(getenv("DGP_WGRAD_PIPE")) == 0);      // A/B switch
+        if (pipe_env) {
+            if (!attr[0]) {
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3p), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                if (e != hipSuccess) return e;
+                attr[0] = true;
+            }
+            hipLaunchKernelGGL(wgrad_h3p, dim3(kt, nt, split), dim3(256), 2 * 4 * 32 * 256, s, a, rg);
+            return hipGetLastError();
+        }
+#ifdef DGP_DIAG
+        unsigned long long hz[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_diag), hz, sizeof(hz));
+#endif
         hipLaunchKernelGGL(wgrad_h3, dim3(kt, nt, split), dim3(256), 2 * 4 * 32 * 256, s, a, rg);
+#ifdef DGP_DIAG
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(hz, HIP_SYMBOL(g_wgrad_diag), sizeof(hz));
+        const double ns = (double)hz[7], nw = (double)hz[10];
+        printf("[diag wgrad_h3] K %d Cdy %d M %d grid %dx%dx%d steps/wg %.1f | per step (wave 0, 100 MHz ticks): gload-issue %.1f tr-read0 %.1f "
+               "mfma0 %.1f tr-read1 %.1f mfma1 %.1f split+store %.1f barrier %.1f | per wg: loop %.0f epilogue %.0f\n", a.kchunks * 4, Cdy, a.M,
+               kt, nt, split, ns / nw, hz[0] / ns, hz[1] / ns, hz[2] / ns, hz[3] / ns, hz[4] / ns, hz[5] / ns, hz[6] / ns, hz[8] / nw, hz[9] / nw);
+#endif
         return hipGetLastError();
     }
     if (big) {
