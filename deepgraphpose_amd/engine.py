@@ -128,8 +128,8 @@ class DGPNet:
         return ns.value, out
 
     # -- compute ---------------------------------------------------------------------
-    def forward(self, frames: torch.Tensor, want_locref: bool = False, want_features: bool = False):
-        """frames uint8 [B,H,W,3] on device -> scmap [B,out_h,out_w,nj] (and locref / features)."""
+    def forward(self, frames: torch.Tensor, want_locref: bool = False, want_features: bool = False, check_range: bool = True):
+        """frames uint8 [B,H,W,3] on device -> scmap [B,out_h,out_w,nj] (and locref / features).  check_range: as in infer()."""
         _need_cuda(frames, torch.uint8, "frames")
         B = frames.shape[0]
         if tuple(frames.shape[1:]) != (self.in_h, self.in_w, 3):
@@ -140,8 +140,13 @@ class DGPNet:
                              device=self.device) if want_locref else None
         feats = torch.empty((B, self.feat_h, self.feat_w, 2048), dtype=torch.float32,
                             device=self.device) if want_features else None
-        _lib.check(self.lib.dgp_forward(self._h, _ptr(frames), B, _ptr(ws), ws.numel(), _ptr(scmap), _ptr(locref),
-                                        _ptr(feats), _stream(self.device)), "dgp_forward")
+        for attempt in range(5):
+            _lib.check(self.lib.dgp_forward(self._h, _ptr(frames), B, _ptr(ws), ws.numel(), _ptr(scmap), _ptr(locref),
+                                            _ptr(feats), _stream(self.device)), "dgp_forward")
+            if not check_range or not self.range_status()[0]:
+                break
+        else:
+            raise _lib.DgpError("dgp_forward: activation ranges still overflow after 4 re-calibrations (non-finite weights or input?)")
         out = [scmap]
         if want_locref:
             out.append(locref)
@@ -150,8 +155,12 @@ class DGPNet:
         return out[0] if len(out) == 1 else tuple(out)
 
     def infer(self, frames: torch.Tensor, gamma: float = 1.0, gauss_len: int = 1, out=None,
-              scmap_out: Optional[torch.Tensor] = None):
-        """Fused frames -> (mu [B,nj,2] (row,col), conf [B,nj], idx [B,nj,2] int32)."""
+              scmap_out: Optional[torch.Tensor] = None, check_range: bool = True):
+        """Fused frames -> (mu [B,nj,2] (row,col), conf [B,nj], idx [B,nj,2] int32).
+
+        check_range (default): synchronise and read the H2 range flag after the forward; a batch that outgrew the calibrated
+        activation scales is re-run (the engine re-calibrates on it, up to 4 times, then DgpError).  Streaming callers pass
+        check_range=False and poll range_status() themselves at a point where they can re-run (eval.estimate_pose, bench.py)."""
         _need_cuda(frames, torch.uint8, "frames")
         B = frames.shape[0]
         if tuple(frames.shape[1:]) != (self.in_h, self.in_w, 3):
@@ -163,10 +172,13 @@ class DGPNet:
             idx = torch.empty((B, self.nj, 2), dtype=torch.int32, device=self.device)
         else:
             mu, conf, idx = out
-        _lib.check(self.lib.dgp_infer(self._h, _ptr(frames), B, _ptr(ws), ws.numel(), float(gamma), int(gauss_len),
-                                      _ptr(mu), _ptr(conf), _ptr(idx), _ptr(scmap_out), _stream(self.device)),
-                   "dgp_infer")
-        return mu, conf, idx
+        for attempt in range(5):
+            _lib.check(self.lib.dgp_infer(self._h, _ptr(frames), B, _ptr(ws), ws.numel(), float(gamma), int(gauss_len),
+                                          _ptr(mu), _ptr(conf), _ptr(idx), _ptr(scmap_out), _stream(self.device)),
+                       "dgp_infer")
+            if not check_range or not self.range_status()[0]:
+                return mu, conf, idx
+        raise _lib.DgpError("dgp_infer: activation ranges still overflow after 4 re-calibrations (non-finite weights or input?)")
 
 
     def range_status(self) -> Tuple[bool, int]:

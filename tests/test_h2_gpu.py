@@ -116,23 +116,33 @@ def test_calibration_overflow_detection_and_recovery(lib_built):
     flat = np.full((2, 64, 96, 3), 0, dtype=np.uint8)
     flat[..., 0], flat[..., 1], flat[..., 2] = 124, 117, 104             # ~ the mean pixel: centred input ~ 0 -> tiny activations
     frames = make_frames(2, 64, 96, nj, seed=31)
-    net.infer(torch.from_numpy(flat).cuda())
+    raw = dict(check_range=False)                                         # the streaming contract: the caller polls range_status
+    net.infer(torch.from_numpy(flat).cuda(), **raw)
     ov, ncal = net.range_status()
     assert not ov and ncal == 1
-    mu_flat, _, _ = [t.clone() for t in net.infer(torch.from_numpy(flat).cuda())]
+    mu_flat, _, _ = [t.clone() for t in net.infer(torch.from_numpy(flat).cuda(), **raw)]
     assert net.range_status() == (False, 1)                               # steady state: no re-calibration, no overflow
-    net.infer(torch.from_numpy(frames).cuda())                            # real frames on scales calibrated for ~zero input
+    net.infer(torch.from_numpy(frames).cuda(), **raw)                     # real frames on scales calibrated for ~zero input
     ov, ncal = net.range_status()
     assert ov and ncal == 1, "activations 16x beyond the calibrated range must be flagged"
-    mu, conf, idx = [t.cpu().numpy() for t in net.infer(torch.from_numpy(frames).cuda())]      # re-calibrates on this batch
+    mu, conf, idx = [t.cpu().numpy() for t in net.infer(torch.from_numpy(frames).cuda(), **raw)]      # re-calibrates on this batch
     ov, ncal = net.range_status()
     assert not ov and ncal == 2
     ref = O.infer(frames, wts, 50)
     assert np.abs(mu - ref["mu"]).max() * 8.0 < 1e-3 and np.array_equal(idx, ref["idx"])
     # the wider scales still serve the small-activation batch (headroom costs no accuracy): same answer as before within 1e-3 px
-    mu_flat2, _, _ = net.infer(torch.from_numpy(flat).cuda())
+    mu_flat2, _, _ = net.infer(torch.from_numpy(flat).cuda(), **raw)
     assert net.range_status() == (False, 2)
     assert float((mu_flat2 - mu_flat).abs().max()) * 8.0 < 1e-3
+    # default calls (check_range=True) recover on their own: same sequence on a fresh engine, no polling by the caller
+    net2 = DGPNet(50, nj, 64, 96, max_batch=4)
+    net2.load_weights(wts)
+    net2.infer(torch.from_numpy(flat).cuda())
+    mu2, _, idx2 = [t.cpu().numpy() for t in net2.infer(torch.from_numpy(frames).cuda())]
+    assert net2.range_status() == (False, 2)
+    assert np.abs(mu2 - ref["mu"]).max() * 8.0 < 1e-3 and np.array_equal(idx2, ref["idx"])
+    sc2 = net2.forward(torch.from_numpy(frames).cuda()).cpu().numpy()
+    assert np.isfinite(sc2).all() and net2.range_status() == (False, 2)
 
 
 def test_h2_network_is_deterministic_and_close_to_fp32_activation_path(lib_built, tmp_path):
