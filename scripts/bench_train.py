@@ -35,6 +35,14 @@ for _ in range(steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 fwd = 2.0 * conv_macs_per_frame(H, W, 50, NJ, True) * NT
+# step-level roofline: forward + data-gradient + weight-gradient convolutions = 3 x the forward conv FLOPs (the stem has no data
+# gradient: -1 %), every product as 3 fp16 MFMAs -> nominal ceiling 2500 / 3 TFLOP/s of algorithmic FLOPs.  Per-kernel times of the
+# same command: profiles/r2_train_step_kernel_stats.txt (bash scripts/profile_train.sh).
+ach = 3 * fwd / dt / 1e12
 print(json.dumps({"metric": "train_step", "ms_per_step": round(dt * 1e3, 2), "frames_per_s": round(NT / dt, 1),
-                  "nt": NT, "dtype": "f32", "approx_tflops(3x fwd conv flops)": round(3 * fwd / dt / 1e12, 1),
+                  "nt": NT, "dtype": "f32", "approx_tflops(3x fwd conv flops)": round(ach, 1),
+                  "roofline": {"bound": "mfma", "scope": "whole training step (forward + dgrad + wgrad convs, loss, clip, momentum)",
+                               "achieved": round(ach, 1), "peak": 833.3, "unit": "TFLOP/s", "frac": round(ach / 833.3, 4),
+                               "peak_basis": "dense f16 MFMA peak 2500 TFLOP/s / 3 partial products per fp32-class product",
+                               "algorithmic_gflop_per_step": round(3 * fwd / 1e9, 1)},
                   "loss": {k: round(v, 5) for k, v in losses.items()}}))
