@@ -203,6 +203,15 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
         nslots = 3
         pinned = [torch.empty((batch_size, hh, ww, 3), dtype=torch.uint8).pin_memory() for _ in range(nslots)]
         dbuf = [torch.empty((batch_size, hh, ww, 3), dtype=torch.uint8, device=dev) for _ in range(nslots)]
+        if world > 1 and hasattr(video_clip, "frame_at") and net.range_status()[1] == 0:
+            # every rank calibrates the activation scales on the video's FIRST batch (not on its own shard's), so the frozen scales --
+            # and with them every output bit -- are those of a single-process run
+            nb0 = min(batch_size, n_frames)
+            for t in range(nb0):
+                pinned[0][t] = torch.from_numpy(np.ascontiguousarray(prep(video_clip.frame_at(t))))
+            dbuf[0][:nb0].copy_(pinned[0][:nb0])
+            net.infer_packed(dbuf[0][:nb0], torch.empty((nb0, nj, 5), dtype=torch.float32, device=dev), sess.gamma, sess.gauss_len)
+            torch.cuda.synchronize(dev)
         free_slots, ready = queue.Queue(), queue.Queue()
         for i in range(nslots):
             free_slots.put(i)
