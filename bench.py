@@ -123,7 +123,10 @@ def main():
 
     def barrier():
         if use_pg:
-            dist.barrier(device_ids=[local_rank])
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:                                   # DGP_DIST_BACKEND=gloo: several ranks on one GPU (tests/test_boundary_gpu.py)
+                dist.barrier()
 
     # untimed pre-warm (declared in the output): the first forward calibrates the engine's activation scales (layer-by-layer, with
     # syncs) and the GPU needs ~1 s of load to leave its idle clock state; then the W warm-up steps the contract asks for

@@ -47,9 +47,23 @@ def gather_trajectory(local: torch.Tensor, n_frames: int, group: Optional[dist.P
     if local.shape[0] != per:
         send = torch.zeros((per, nj, k), dtype=local.dtype, device=local.device)
         send[: local.shape[0]] = local
+    if dist.get_backend(group) == "gloo" and send.is_cuda:       # gloo has no device all-gather: stage through the host (tests; CPU-only groups)
+        parts = [torch.empty((per, nj, k), dtype=local.dtype) for _ in range(world)]
+        dist.all_gather(parts, send.contiguous().cpu(), group=group)
+        return torch.cat(parts, 0)[:n_frames].to(local.device)
     out = torch.empty((world * per, nj, k), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, send.contiguous(), group=group)
     return out[:n_frames]
+
+
+def any_rank(flag: bool, device=None, group: Optional[dist.ProcessGroup] = None) -> bool:
+    """True on every rank when `flag` is true on at least one (one all-reduce(MAX) of a single int)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return bool(flag)
+    on_host = dist.get_backend(group) == "gloo" or device is None
+    t = torch.tensor([int(bool(flag))], dtype=torch.int32, device="cpu" if on_host else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(t.item())
 
 
 def average_gradients(flat_grads: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
@@ -83,8 +97,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ       # under torchrun, even with 1 rank
     if (world > 1 or launched) and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None or os.environ.get("DGP_DIST_BACKEND"):      # DGP_DIST_BACKEND=gloo: several ranks on ONE GPU (tests)
+            backend = os.environ.get("DGP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":

@@ -299,11 +299,7 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
         # H2 activation scales (include/dgp_hip.h): a batch that outgrew the scales calibrated on the first batch invalidates its
         # results; the engine then re-calibrates with more headroom and the video is run again (all ranks decide together)
         overflow = bool(net_used.range_status()[0])
-        if world > 1:
-            import torch
-            flag = torch.tensor([int(overflow)], device="cuda:%d" % sess.device)
-            tdist.all_reduce(flag, op=tdist.ReduceOp.MAX)
-            overflow = bool(flag.item())
+        overflow = ddist.any_rank(overflow, device="cuda:%d" % sess.device)
         if not overflow:
             break
         print("activation ranges outgrew the calibrated scales: re-calibrating and re-running %s" % video_file, flush=True)

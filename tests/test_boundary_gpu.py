@@ -163,6 +163,79 @@ dist.destroy_process_group()
     assert os.path.isfile(tmp_path / "pred_dist" / "clip_labeled.csv")
 
 
+def test_estimate_pose_two_ranks_on_one_gpu_equal_single_process(lib_built, tmp_path):
+    """The sharded product path with W = 2 for real: two processes (RANK 0 / 1, both on cuda:0, control plane on gloo via
+    DGP_DIST_BACKEND because RCCL refuses two ranks on one device) run estimate_pose on the same video.  Rank 1's shard starts in
+    the middle (frame_at seek), both calibrate on the video's first batch, the gather reassembles [T, nj], rank 0 alone exports --
+    and the result equals the single-process run bit for bit."""
+    proj, snap, frames, wts = _tiny_project(tmp_path, T=23)
+    code = r'''
+import json, os, sys, numpy as np
+from deepgraphpose_amd.models import eval as E
+out = E.estimate_pose(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], shuffle=1, batch_size=4)
+import torch.distributed as dist
+assert dist.is_initialized() and dist.get_world_size() == 2 and dist.get_backend() == "gloo"
+np.savez(sys.argv[5] + os.environ["RANK"] + ".npz", **out)
+dist.barrier()
+dist.destroy_process_group()
+'''
+    procs = []
+    for rank in (0, 1):
+        env = _child_env(RANK=rank, WORLD_SIZE=2, LOCAL_RANK=0, MASTER_ADDR="127.0.0.1", MASTER_PORT=29631, DGP_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, "-c", code, str(proj / "config.yaml"), snap, str(tmp_path / "clip.npy"),
+                                       str(tmp_path / "pred_w2"), str(tmp_path / "out_rank")], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for pr in procs:
+        try:
+            outs.append(pr.communicate(timeout=900))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for pr, (so, se) in zip(procs, outs):
+        assert pr.returncode == 0, se[-2000:]
+    from deepgraphpose_amd.models import eval as E
+    ref = E.estimate_pose(str(proj / "config.yaml"), snap, str(tmp_path / "clip.npy"), str(tmp_path / "pred_w1"), shuffle=1,
+                          batch_size=4)
+    for rank in (0, 1):
+        got = np.load(str(tmp_path / "out_rank") + "%d.npz" % rank)
+        for k in ("x", "y", "likelihoods"):
+            assert got[k].shape == (23, 3) and np.array_equal(got[k], ref[k]), (rank, k)
+    a = open(tmp_path / "pred_w2" / "clip_labeled.csv").read()
+    b = open(tmp_path / "pred_w1" / "clip_labeled.csv").read()
+    assert a == b
+
+
+def test_bench_two_ranks_on_one_gpu(lib_built):
+    """bench.py's N > 1 path (shard_range of one seeded stream, gather inside the timed region, max-over-ranks time, shard check
+    against rank 0's ring) with two processes on cuda:0 and the control plane on gloo (DGP_DIST_BACKEND): one JSON line from rank 0
+    only, n_gpus 2, every batch of both shards identical to the single-rank result."""
+    procs = []
+    for rank in (0, 1):
+        env = _child_env(RANK=rank, WORLD_SIZE=2, LOCAL_RANK=0, MASTER_ADDR="127.0.0.1", MASTER_PORT=29633, DGP_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+                                       "--batch", "8", "--no-cpu-baseline", "--sustain-seconds", "0.3", "--prewarm-seconds", "0.2"],
+                                      env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for pr in procs:
+        try:
+            outs.append(pr.communicate(timeout=900))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for pr, (so, se) in zip(procs, outs):
+        assert pr.returncode == 0, se[-2000:]
+    lines0 = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    lines1 = [l for l in outs[1][0].splitlines() if l.startswith("{")]
+    assert len(lines0) == 1 and not lines1
+    d = json.loads(lines0[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["shard_check"]["batches_compared"] == 6 and d["shard_check"]["bit_identical_to_rank0"]
+    assert abs(d["value"] - 2 * 5 * 8 / (d["ms_per_step"] * 5 / 1e3)) <= 1e-3 * d["value"]
+
+
 def test_shard_ranges_reassemble_bit_exactly(lib_built):
     """What N ranks would compute: the frames of each shard_range(T, r, W) inferred separately (own batches) and concatenated
     equal the one-process trajectory on the integer indices bit for bit and on the coordinates within 1e-3 px."""
