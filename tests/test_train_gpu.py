@@ -369,3 +369,74 @@ def test_fit_dlc_driver(lib_built, tmp_path):
     assert len(stats) == 2 and stats[0].startswith("iteration: 2, loss: total loss ")
     assert fit_dlc("resnet_v1_50.ckpt", proj, maxiters=5) is None            # skip-if-exists guard (fitdgp.py:113-117)
     fit_dgp_labeledonly("snapshot-step0-final--0", proj, shuffle=1, step=1, maxiters=2, displayiters=1, aug=False)
+
+
+def test_data_parallel_two_ranks_on_one_gpu(lib_built, tmp_path):
+    """N4 on hardware with W = 2: two processes on cuda:0 (control plane on gloo via DGP_DIST_BACKEND; RCCL refuses two ranks per
+    device) run Trainer.step on DIFFERENT windows from the same weights.  The gradient both apply is the mean of the two
+    single-process gradients, and the replicas stay bit-identical after two steps."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import test_train_gpu as TT
+from deepgraphpose_amd import dist as ddist
+from deepgraphpose_amd.train import Trainer
+from deepgraphpose_amd.loss import DGPHyper
+rank, local, world = ddist.init_from_env()
+import torch.distributed as dist
+assert world == 2 and dist.get_backend() == "gloo"
+wts = TT._train_case(7)[2]
+batch, S0, _, frames, ws, ws_max = TT._train_case(20 + rank)
+tr = Trainer(50, 3, 64, 96, max_frames=3)
+tr.load_weights(wts)
+hy = DGPHyper(gm2=1, gm3=3, lr=0.005)
+ft = torch.from_numpy(frames).cuda()
+tr.step(ft, batch, hy, S0, ws, ws_max, 300.0, 25.0)
+g = tr.get_grads()
+tr.step(ft, batch, hy, S0, ws, ws_max, 300.0, 25.0)
+w = tr.get_weights()
+np.savez(sys.argv[2] + "_g%d.npz" % rank, **g)
+np.savez(sys.argv[2] + "_w%d.npz" % rank, **w)
+dist.barrier()
+dist.destroy_process_group()
+'''
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), RANK=str(rank), WORLD_SIZE="2",
+                   LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", DGP_DIST_BACKEND="gloo")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-c", code, os.path.join(root, "tests"), str(tmp_path / "dp")], env=env, cwd=root,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for pr in procs:
+        try:
+            outs.append(pr.communicate(timeout=900))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for pr, (so, se) in zip(procs, outs):
+        assert pr.returncode == 0, se[-2000:]
+    g = [np.load(str(tmp_path / "dp") + "_g%d.npz" % r) for r in (0, 1)]
+    w = [np.load(str(tmp_path / "dp") + "_w%d.npz" % r) for r in (0, 1)]
+    for k in g[0].files:
+        assert np.array_equal(g[0][k], g[1][k]), k            # the all-reduce leaves the same bits on every rank
+    for k in w[0].files:
+        assert np.array_equal(w[0][k], w[1][k]), k            # ... so the replicas never diverge
+    # the averaged gradient = mean of what each window gives alone
+    from deepgraphpose_amd.train import Trainer
+    from deepgraphpose_amd.loss import DGPHyper
+    wts = _train_case(7)[2]
+    single = []
+    for r in (0, 1):
+        batch, S0, _, frames, ws, ws_max = _train_case(20 + r)
+        tr = Trainer(50, 3, 64, 96, max_frames=3)
+        tr.load_weights(wts)
+        tr.forward_backward(torch.from_numpy(frames).cuda(), batch, DGPHyper(gm2=1, gm3=3, lr=0.005), S0, ws, ws_max, 300.0, 25.0)
+        single.append(tr.get_grads())
+    for k in g[0].files:
+        ref = 0.5 * (single[0][k].astype(np.float64) + single[1][k].astype(np.float64))
+        tol = 2e-5 * (np.abs(ref).max() + 1e-12) + 1e-9
+        assert np.abs(g[0][k] - ref).max() <= tol, (k, float(np.abs(g[0][k] - ref).max()), float(np.abs(ref).max()))
