@@ -440,3 +440,51 @@ dist.destroy_process_group()
         ref = 0.5 * (single[0][k].astype(np.float64) + single[1][k].astype(np.float64))
         tol = 2e-5 * (np.abs(ref).max() + 1e-12) + 1e-9
         assert np.abs(g[0][k] - ref).max() <= tol, (k, float(np.abs(g[0][k] - ref).max()), float(np.abs(ref).max()))
+
+
+def test_fit_dgp_driver_two_ranks_on_one_gpu(lib_built, tmp_path):
+    """The fit driver under the launcher's environment with W = 2 (both ranks on cuda:0, gloo control plane): the ranks join the
+    group before touching the GPU, share rank 0's schedule seed, take entries it W + r of the schedule, average gradients every
+    step, and rank 0 alone writes the step snapshots."""
+    import os, subprocess, sys
+    from _project import make_project
+    from deepgraphpose_amd.models.fitdgp_util import get_snapshot_path
+    from deepgraphpose_amd import weights_io
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proj, frames, wts = make_project(tmp_path)
+    code = r'''
+import os, sys, numpy as np, random
+np.random.seed(int(os.environ["RANK"])); random.seed(int(os.environ["RANK"]))      # different local seeds: rank 0's must win
+from deepgraphpose_amd.models.fitdgp import fit_dgp
+fit_dgp("snapshot-step0-final--0", sys.argv[1], batch_size=4, shuffle=1, step=2, maxiters=6, displayiters=1, gm2=1, gm3=3,
+        aug=False, n_max_frames=30, ns=3)
+import torch.distributed as dist
+assert dist.is_initialized() and dist.get_world_size() == 2
+dist.barrier()
+dist.destroy_process_group()
+print("rank", os.environ["RANK"], "done")
+'''
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), RANK=str(rank), WORLD_SIZE="2",
+                   LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29643", DGP_DIST_BACKEND="gloo")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-c", code, proj], env=env, cwd=root, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for pr in procs:
+        try:
+            outs.append(pr.communicate(timeout=900))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for pr, (so, se) in zip(procs, outs):
+        assert pr.returncode == 0, (so[-500:], se[-2000:])
+    snap2, _ = get_snapshot_path("snapshot-step2-final--0", proj, shuffle=1)
+    assert os.path.isfile(snap2 + ".npz")
+    w2 = weights_io.load_weights(snap2)
+    assert all(np.isfinite(v).all() for v in w2.values())
+    assert np.abs(w2["pose/part_pred/block4/weights"] - wts["pose/part_pred/block4/weights"]).max() > 0
+    # 6 schedule entries over 2 ranks = 3 optimiser steps: the iteration snapshot rank 0 wrote is the third
+    assert os.path.isfile(snap2.replace("-final--0", "-3") + ".npz") or os.path.isfile(snap2.replace("-final--0", "-2") + ".npz")
