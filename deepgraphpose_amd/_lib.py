@@ -53,6 +53,7 @@ SYMBOLS = {
     "dgp_forward": (C.c_int, [_vp, _vp, _i32, _vp, _sz, _vp, _vp, _vp, _vp]),
     "dgp_soft_argmax": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "dgp_hard_argmax": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "dgp_pmap_threshold": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "dgp_infer": (C.c_int, [_vp, _vp, _i32, _vp, _sz, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "dgp_infer_packed": (C.c_int, [_vp, _vp, _i32, _vp, _sz, _f32, _i32, _vp, _vp, _vp]),
     "dgp_net_profile_begin": (C.c_int, [_vp, _i32]),

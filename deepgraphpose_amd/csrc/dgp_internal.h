@@ -98,6 +98,7 @@ hipError_t launch_soft_argmax(const float* scmap, int B, int H, int W, int C, fl
                               hipStream_t s, int record_stride = 0);
 hipError_t launch_hard_argmax(const float* scmap, const float* locref, int B, int H, int W, int C,
                               int* idx, float* prob, float* offs, hipStream_t s);
+hipError_t launch_pmap_threshold(float* pmap, int B, int H, int W, int C, float th, float* mu, hipStream_t s);
 
 // Arguments of the DGP loss forward+backward kernels (dgp_loss.hip).
 struct LossArgs {

@@ -2920,4 +2920,52 @@ hipError_t launch_hard_argmax(const float* scmap, const float* locref, int B, in
     return hipGetLastError();
 }
 
+// argmax_2d_from_cm's `th` branch (fitdgp_util.py:377-388) on the normalised blurred softmax the soft-argmax kernel wrote:
+// per (frame, joint) map: m = max p; p < m th -> 0; renormalise; expectation of the (row, col) grid.  One block per map, three
+// strided passes over H W values (the map is a column of the [B,H,W,C] tensor: stride C).
+__global__ __launch_bounds__(256) void pmap_threshold_kernel(float* __restrict__ pmap, int H, int W, int C, float th,
+                                                             float* __restrict__ mu) {
+    __shared__ float red[3][4];
+    const int c = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float* p = pmap + (size_t)b * H * W * C + c;
+    const int n = H * W;
+    float m = 0.f;                                         // p >= 0
+    for (int i = t; i < n; i += 256) m = fmaxf(m, p[(size_t)i * C]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) red[0][wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    const float cut = m * th;
+    float s = 0.f;
+    for (int i = t; i < n; i += 256) { const float v = p[(size_t)i * C]; s += v < cut ? 0.f : v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    __syncthreads();
+    if (lane == 0) red[0][wave] = s;
+    __syncthreads();
+    s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    float sh = 0.f, sw = 0.f;
+    for (int i = t; i < n; i += 256) {
+        const float v = p[(size_t)i * C];
+        const float q = (v < cut ? 0.f : v) / s;           // (+ 1e-100 in the reference: 0 in fp32; an all-zero map gives NaN there too)
+        p[(size_t)i * C] = q;
+        const int h = i / W, w = i - h * W;
+        sh += q * (float)h; sw += q * (float)w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sh += __shfl_xor(sh, o, 64); sw += __shfl_xor(sw, o, 64); }
+    if (lane == 0) { red[1][wave] = sh; red[2][wave] = sw; }
+    __syncthreads();
+    if (t == 0) {
+        mu[((size_t)b * C + c) * 2 + 0] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        mu[((size_t)b * C + c) * 2 + 1] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    }
+}
+
+hipError_t launch_pmap_threshold(float* pmap, int B, int H, int W, int C, float th, float* mu, hipStream_t s) {
+    hipLaunchKernelGGL(pmap_threshold_kernel, dim3(C, B), dim3(256), 0, s, pmap, H, W, C, th, mu);
+    return hipGetLastError();
+}
+
 }  // namespace dgp

@@ -824,6 +824,16 @@ int dgp_soft_argmax(const float* scmap, int32_t B, int32_t H, int32_t W, int32_t
     return DGP_OK;
 }
 
+int dgp_pmap_threshold(float* pmap, int32_t B, int32_t H, int32_t W, int32_t C, float th, float* mu, void* stream) {
+    if (!pmap || !mu) return fail(DGP_ERR_INVALID, "dgp_pmap_threshold: null argument");
+    if (B < 0 || H < 1 || W < 1 || C < 1 || C > 65535 || B > 65535) return fail(DGP_ERR_INVALID, "dgp_pmap_threshold: bad shape");
+    if (!(th >= 0.f)) return fail(DGP_ERR_INVALID, "dgp_pmap_threshold: th must be >= 0");
+    if (B == 0) return DGP_OK;
+    hipError_t e = launch_pmap_threshold(pmap, B, H, W, C, th, mu, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("pmap_threshold: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
 int dgp_hard_argmax(const float* scmap, const float* locref, int32_t B, int32_t H, int32_t W, int32_t C,
                     int32_t* idx, float* prob, float* offs, void* stream) {
     if (!scmap || !idx || !prob || !offs) return fail(DGP_ERR_INVALID, "dgp_hard_argmax: null argument");

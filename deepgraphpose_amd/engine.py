@@ -231,6 +231,19 @@ def soft_argmax(scmap: torch.Tensor, gamma: float = 1.0, gauss_len: int = 2, wan
     return (mu, conf, idx, pmap) if want_pmap else (mu, conf, idx)
 
 
+def pmap_threshold(pmap: torch.Tensor, th: float) -> torch.Tensor:
+    """argmax_2d_from_cm's `th` branch (fitdgp_util.py:377-388): pmap [B,H,W,C] (normalised blurred softmax from soft_argmax) is
+    thresholded at th * max per (frame, joint) map and renormalised IN PLACE; returns mu [B,C,2] (row, col) of the new maps."""
+    lib = _lib.load()
+    _need_cuda(pmap, torch.float32, "pmap")
+    if pmap.dim() != 4 or not pmap.is_contiguous():
+        raise _lib.DgpError("pmap must be a contiguous rank-4 tensor [B,H,W,C]")
+    B, H, W, Cn = pmap.shape
+    mu = torch.empty((B, Cn, 2), dtype=torch.float32, device=pmap.device)
+    _lib.check(lib.dgp_pmap_threshold(_ptr(pmap), B, H, W, Cn, float(th), _ptr(mu), _stream(pmap.device)), "dgp_pmap_threshold")
+    return mu
+
+
 def hard_argmax(scmap: torch.Tensor, locref: Optional[torch.Tensor] = None):
     """HIP DLC arg-max: idx [B,C,2] (row,col), prob [B,C], offs [B,C,2] (dx,dy raw locref)."""
     lib = _lib.load()

@@ -26,9 +26,9 @@ def argmax_2d_from_cm(tensor, nj, gamma=1, gauss_len=2, th=None):
         raise AssertionError("rank(tensor) == 4")                      # fitdgp_util.py:357
     if tensor.shape[-1] != nj:
         raise ValueError("last dimension (%d) != nj (%d)" % (tensor.shape[-1], nj))
-    if th is not None:
-        raise NotImplementedError("th thresholding is never used by the reference drivers (th=None everywhere)")
     mu, _, _, pmap = engine.soft_argmax(tensor.contiguous(), float(gamma), int(gauss_len), want_pmap=True)
+    if th is not None:                                                 # fitdgp_util.py:377-388 (no reference driver passes th)
+        mu = engine.pmap_threshold(pmap, float(th))
     return mu, pmap
 
 

@@ -95,6 +95,11 @@ int  dgp_soft_argmax(const float* scmap, int32_t B, int32_t H, int32_t W, int32_
                      float gamma, int32_t gauss_len, float* mu, float* conf, int32_t* idx,
                      float* pmap, void* stream);
 
+/* argmax_2d_from_cm's `th` branch (DGP/models/fitdgp_util.py:377-388; unused by the reference's drivers): on the pmap that
+ * dgp_soft_argmax wrote, per (frame, joint) map: values below th * max become 0, the map is renormalised IN PLACE and
+ * mu [B,C,2] (row, col) is its expectation. */
+int  dgp_pmap_threshold(float* pmap, int32_t B, int32_t H, int32_t W, int32_t C, float th, float* mu, void* stream);
+
 /* DLC hard arg-max over sigmoid(scmap).  idx [B,C,2] (row, col), prob [B,C],
  * offs [B,C,2] = locref[b,row,col,2c..2c+1] (dx, dy; NOT yet scaled by locref_stdev) or
  * zeros when locref == NULL. */

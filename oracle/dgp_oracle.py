@@ -192,8 +192,8 @@ def gaussian_taps(sigma: float, truncate: float = 1.0, dtype=np.float32) -> np.n
 
 
 def argmax_2d_from_cm(scmap: np.ndarray, gamma: float = 1.0, gauss_len: int = 2,
-                      dtype=np.float32) -> Tuple[np.ndarray, np.ndarray]:
-    """argmax_2d_from_cm (DGP/models/fitdgp_util.py:342-402), th=None branch.
+                      dtype=np.float32, th=None) -> Tuple[np.ndarray, np.ndarray]:
+    """argmax_2d_from_cm (DGP/models/fitdgp_util.py:342-402); th: the thresholding branch (:377-388).
 
     scmap [N,H,W,C] -> (mu [N,C,2] as (row, col), normalised blurred softmax [N,H,W,C]).
     Steps: softmax over H*W of gamma*s; CONSTANT zero pad by gauss_len (:304-310);
@@ -217,6 +217,11 @@ def argmax_2d_from_cm(scmap: np.ndarray, gamma: float = 1.0, gauss_len: int = 2,
             blur += k2[a, b] * pp[:, a:a + oh, b:b + ow]
     tot = blur.sum(axis=(1, 2), keepdims=True, dtype=dtype)
     pn = blur / (tot + dtype(1e-100) if dtype == np.float64 else tot)
+    if th is not None:          # :377-388: per map, values below th * max -> 0, renormalise
+        mst = pn.max(axis=(1, 2), keepdims=True)
+        pn = np.where(pn < mst * dtype(th), dtype(0), pn)
+        tot = pn.sum(axis=(1, 2), keepdims=True, dtype=dtype)
+        pn = pn / (tot + dtype(1e-100) if dtype == np.float64 else tot)
     hh = np.arange(oh, dtype=dtype)[None, :, None]
     ww = np.arange(ow, dtype=dtype)[None, None, :]
     mu_h = (pn * hh).sum(axis=(1, 2), dtype=dtype)

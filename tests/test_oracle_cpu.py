@@ -183,3 +183,22 @@ def test_batch_norm_and_backbone_shapes():
     s, l = O.pose_heads(f, w, True)
     assert s.shape == (1, 8, 10, 3) and l.shape == (1, 8, 10, 6)
     assert np.isfinite(f).all() and f.min() >= 0
+
+
+def test_argmax_2d_threshold_branch_independent_restatement():
+    """th branch of argmax_2d_from_cm (fitdgp_util.py:377-388) against a per-map loop written from the reference's text: st < max*th
+    -> 0, renormalise, expectation over the (row, col) grid."""
+    rng = np.random.default_rng(2)
+    s = (rng.standard_normal((2, 9, 8, 3)) * 3).astype(np.float32)
+    for th in (0.05, 0.5):
+        mu, pm = O.argmax_2d_from_cm(s, 1.0, 1, dtype=np.float64, th=th)
+        _, p0 = O.argmax_2d_from_cm(s, 1.0, 1, dtype=np.float64)
+        for b in range(2):
+            for c in range(3):
+                st = p0[b, :, :, c].copy()
+                st[st < st.max() * th] = 0.0
+                st /= st.sum() + 1e-100
+                np.testing.assert_allclose(pm[b, :, :, c], st, rtol=1e-12, atol=0)
+                rows, cols = np.mgrid[0:9, 0:8]
+                np.testing.assert_allclose(mu[b, c], [(st * rows).sum(), (st * cols).sum()], rtol=1e-12)
+        assert (pm == 0).sum() > 0
