@@ -70,7 +70,7 @@ class EvalSession:
             if frames.dtype != np.uint8:
                 # the reference feeds img_as_ubyte frames cast to fp32 (eval.py:326-328): integral 0..255
                 frames = np.clip(np.rint(frames), 0, 255).astype(np.uint8)
-            frames = torch.from_numpy(np.ascontiguousarray(frames)).cuda(self.device)
+            frames = torch.from_numpy(np.require(frames, requirements=["C", "W"])).cuda(self.device)      # (read-only memmaps: copy)
         B, h, w, _ = frames.shape
         net = self.net_for(h, w)
         names = {f.name for f in fl}
@@ -208,7 +208,7 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
             # and with them every output bit -- are those of a single-process run
             nb0 = min(batch_size, n_frames)
             for t in range(nb0):
-                pinned[0][t] = torch.from_numpy(np.ascontiguousarray(prep(video_clip.frame_at(t))))
+                np.copyto(pinned[0][t].numpy(), prep(video_clip.frame_at(t)))
             dbuf[0][:nb0].copy_(pinned[0][:nb0])
             net.infer_packed(dbuf[0][:nb0], torch.empty((nb0, nj, 5), dtype=torch.float32, device=dev), sess.gamma, sess.gauss_len)
             torch.cuda.synchronize(dev)
@@ -239,7 +239,7 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
                 for fr in itertools.chain([f0], (prep(x) for x in frames_it)):
                     if count >= n_local:
                         break
-                    pinned[slot][fill] = torch.from_numpy(np.ascontiguousarray(fr))
+                    np.copyto(pinned[slot][fill].numpy(), fr)
                     fill += 1
                     count += 1
                     if fill == batch_size:

@@ -302,3 +302,37 @@ def test_evaluate_dgp_soft_argmax_locref_readout(lib_built, tmp_path):
     pose = soft_argmax_locref_pose(lr, st, 8.0, 7.2801)
     np.testing.assert_allclose(pose[0], [5 * 8 + 4 - 0.25 * 7.2801, 2 * 8 + 4 + 0.5 * 7.2801, 1.0])
     np.testing.assert_allclose(pose[1], [1 * 8 + 4 + 2.0 * 7.2801, 4 * 8 + 4 + 1.0 * 7.2801, 1.0])
+
+
+def test_estimate_pose_edge_cases_vs_oracle(lib_built, tmp_path):
+    """estimate_pose options and ragged inputs (eval.py:217-360): a single frame with a larger batch size; odd frame sizes; T not a
+    multiple of the batch; `new_size` (PIL resize, coordinates scaled back to the original frame) and `crop_size` -- each against
+    the CPU oracle run on the frames as the reference would have prepared them."""
+    from PIL import Image
+    from oracle import dgp_oracle as O
+    from deepgraphpose_amd.models import eval as E
+    from deepgraphpose_amd.synthetic import make_frames
+    proj, snap, _, wts = _tiny_project(tmp_path)
+    cfg = str(proj / "config.yaml")
+
+    def run(frames, tag, **kw):
+        np.save(tmp_path / (tag + ".npy"), frames)
+        return E.estimate_pose(cfg, snap, str(tmp_path / (tag + ".npy")), str(tmp_path / ("pred_" + tag)), shuffle=1, **kw)
+
+    def check(out, ref, sx=1.0, sy=1.0):
+        assert out["x"].shape == ref["x"].shape
+        assert np.abs(out["x"] - ref["x"] * sx).max() < PX_TOL * max(sx, 1.0)
+        assert np.abs(out["y"] - ref["y"] * sy).max() < PX_TOL * max(sy, 1.0)
+        assert np.abs(out["likelihoods"] - ref["likelihoods"]).max() < 1e-4
+
+    one = make_frames(1, 96, 128, 3, seed=41)
+    check(run(one, "one", batch_size=8), O.infer(one, wts, 50, 8.0, 1.0, 1))
+    odd = make_frames(7, 75, 101, 3, seed=42)                      # odd sizes, T = 7 over batches of 3 (3 + 3 + 1)
+    check(run(odd, "odd", batch_size=3), O.infer(odd, wts, 50, 8.0, 1.0, 1))
+    big = make_frames(3, 120, 160, 3, seed=43)
+    small = np.stack([np.asarray(Image.fromarray(f).resize(size=(96, 72))) for f in big])       # new_size = (rows 72, cols 96)
+    out = run(big, "resized", batch_size=2, new_size=(72, 96))
+    check(out, O.infer(small, wts, 50, 8.0, 1.0, 1), sx=160 / 96, sy=120 / 72)
+    crop = (8, 16, 136, 112)                                       # PIL box (left, upper, right, lower) -> 96 x 128 frames
+    cropped = np.stack([np.asarray(Image.fromarray(f).crop(crop)) for f in big])
+    check(run(big, "cropped", batch_size=2, crop_size=crop), O.infer(cropped, wts, 50, 8.0, 1.0, 1))
