@@ -298,7 +298,7 @@ def main():
         "activation_format": "H2 (fp16 high/low cells, calibrated per-tensor scales; include/dgp_hip.h)" if n_calib else "fp32",
     }
 
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
         from oracle import dgp_oracle as O      # checker / baseline only
         ncmp = 8
         nthreads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
