@@ -360,7 +360,13 @@ __global__ __launch_bounds__(256) void wgrad_f32(const WgradArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = q0 * 4 + wm * 32 * T + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (k < p.kchunks * 4) atomicAdd(p.dw + (long long)k * p.Cdy + co, acc[i][j][r]);
+                if (k < p.kchunks * 4) {
+#if defined(DGP_WX) && DGP_WX == 6
+                    p.dw[(long long)k * p.Cdy + co] = acc[i][j][r];
+#else
+                    atomicAdd(p.dw + (long long)k * p.Cdy + co, acc[i][j][r]);
+#endif
+                }
             }
     }
 }
@@ -604,7 +610,13 @@ __global__ __launch_bounds__(256) void wgrad_h3(const WgradArgs p, const WgradRa
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = q0 * 4 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (k < p.kchunks * 4) atomicAdd(p.dw + (long long)k * p.Cdy + co, acc[i][j][r] * post);
+                if (k < p.kchunks * 4) {
+#if defined(DGP_WX) && DGP_WX == 6
+                    p.dw[(long long)k * p.Cdy + co] = acc[i][j][r] * post;
+#else
+                    atomicAdd(p.dw + (long long)k * p.Cdy + co, acc[i][j][r] * post);
+#endif
+                }
             }
     }
 #ifdef DGP_DIAG
@@ -879,7 +891,13 @@ __global__ __launch_bounds__(256) void wgrad_h3p(const WgradArgs p, const WgradR
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = q0 * 4 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (k < p.kchunks * 4) atomicAdd(p.dw + (long long)k * p.Cdy + co, acc[i][j][r] * post);
+                if (k < p.kchunks * 4) {
+#if defined(DGP_WX) && DGP_WX == 6
+                    p.dw[(long long)k * p.Cdy + co] = acc[i][j][r] * post;
+#else
+                    atomicAdd(p.dw + (long long)k * p.Cdy + co, acc[i][j][r] * post);
+#endif
+                }
             }
     }
 }
