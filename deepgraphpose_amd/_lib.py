@@ -84,6 +84,7 @@ SYMBOLS = {
     "dgp_conv2d_h2": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "dgp_net_range_status": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), _vp]),
     "dgp_net_recalibrate": (C.c_int, [_vp]),
+    "dgp_net_widen": (C.c_int, [_vp]),
     "dgp_conv2d_wgrad": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgp_conv2d_dgrad_scratch_bytes": (_sz, [C.POINTER(DgpConvDesc)]),
     "dgp_conv2d_dgrad": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),

@@ -193,6 +193,11 @@ class DGPNet:
         """Force a calibration pass of the activation scales on the next forward."""
         _lib.check(self.lib.dgp_net_recalibrate(self._h), "dgp_net_recalibrate")
 
+    def widen(self):
+        """Re-calibrate on the next forward with 3 more bits of headroom -- what range_status() does on an overflow -- for a rank
+        that follows another rank's overflow in a sharded run."""
+        _lib.check(self.lib.dgp_net_widen(self._h), "dgp_net_widen")
+
     def infer_packed(self, frames: torch.Tensor, traj: torch.Tensor, gamma: float = 1.0, gauss_len: int = 1,
                      scmap_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Fused frames -> traj [B,nj,5] fp32 lanes (row, col, likelihood, iy, ix; indices as int32 bit patterns): the record

@@ -203,9 +203,10 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
         nslots = 3
         pinned = [torch.empty((batch_size, hh, ww, 3), dtype=torch.uint8).pin_memory() for _ in range(nslots)]
         dbuf = [torch.empty((batch_size, hh, ww, 3), dtype=torch.uint8, device=dev) for _ in range(nslots)]
-        if world > 1 and hasattr(video_clip, "frame_at") and net.range_status()[1] == 0:
+        if world > 1 and hasattr(video_clip, "frame_at"):
             # every rank calibrates the activation scales on the video's FIRST batch (not on its own shard's), so the frozen scales --
-            # and with them every output bit -- are those of a single-process run
+            # and with them every output bit -- are those of a single-process run (also on the re-run after a range overflow)
+            net.recalibrate()
             nb0 = min(batch_size, n_frames)
             for t in range(nb0):
                 np.copyto(pinned[0][t].numpy(), prep(video_clip.frame_at(t)))
@@ -299,7 +300,10 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
         # H2 activation scales (include/dgp_hip.h): a batch that outgrew the scales calibrated on the first batch invalidates its
         # results; the engine then re-calibrates with more headroom and the video is run again (all ranks decide together)
         overflow = bool(net_used.range_status()[0])
-        overflow = ddist.any_rank(overflow, device="cuda:%d" % sess.device)
+        anywhere = ddist.any_rank(overflow, device="cuda:%d" % sess.device)
+        if anywhere and not overflow:
+            net_used.widen()                    # follow the rank that overflowed: same headroom everywhere
+        overflow = anywhere
         if not overflow:
             break
         print("activation ranges outgrew the calibrated scales: re-calibrating and re-running %s" % video_file, flush=True)

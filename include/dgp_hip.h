@@ -270,6 +270,9 @@ int  dgp_conv2d_h2(const dgp_conv_desc* d, const void* x_h2, int32_t x_exp, cons
  * and the net re-calibrates on its next forward); *calibrations = calibration passes run so far. */
 int  dgp_net_range_status(dgp_net* net, int32_t* overflow, int32_t* calibrations, void* stream);
 int  dgp_net_recalibrate(dgp_net* net);      /* force a calibration pass on the next forward */
+/* What dgp_net_range_status does to the engine when it reports an overflow (re-calibrate on the next forward with 3 more bits of
+ * headroom), for a rank that did not overflow itself but must follow one that did (sharded runs stay bit-identical). */
+int  dgp_net_widen(dgp_net* net);
 
 /* slots = max(slots, max |x[0..n)|) on the device (zero the DGP_ABSMAX_SLOTS floats before the first call). */
 int  dgp_tensor_absmax(const float* x, size_t n, float* absmax_dev, void* stream);

@@ -143,6 +143,11 @@ def test_calibration_overflow_detection_and_recovery(lib_built):
     assert np.abs(mu2 - ref["mu"]).max() * 8.0 < 1e-3 and np.array_equal(idx2, ref["idx"])
     sc2 = net2.forward(torch.from_numpy(frames).cuda()).cpu().numpy()
     assert np.isfinite(sc2).all() and net2.range_status() == (False, 2)
+    # widen(): what a rank does when ANOTHER rank of a sharded run overflowed -- re-calibration with 3 more bits of headroom
+    net2.widen()
+    mu3, _, idx3 = [t.cpu().numpy() for t in net2.infer(torch.from_numpy(frames).cuda())]
+    assert net2.range_status() == (False, 3)
+    assert np.abs(mu3 - ref["mu"]).max() * 8.0 < 1e-3 and np.array_equal(idx3, ref["idx"])
 
 
 def test_h2_network_is_deterministic_and_close_to_fp32_activation_path(lib_built, tmp_path):
