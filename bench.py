@@ -71,9 +71,10 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch CPU threads for the baseline (16 was the fastest of 8..128 on the GPU box)")
     ap.add_argument("--layer-table", type=str, default="", help="write the per-launch table (tsv) here")
-    ap.add_argument("--profile-steps", type=int, default=5, help="timed steps instrumented with per-launch hipEvents (roofline)")
+    ap.add_argument("--profile-steps", type=int, default=3, help="timed steps instrumented with per-launch hipEvents (roofline)")
     ap.add_argument("--prewarm-seconds", type=float, default=1.5, help="untimed load before the warm-up steps (clock ramp, calibration)")
     ap.add_argument("--sustain-seconds", type=float, default=5.0, help="length of the sustained segment after the timed region")
+    ap.add_argument("--streams", type=int, default=2, help="engines / HIP streams the batches are dealt to (1: single stream)")
     args = ap.parse_args()
 
     from deepgraphpose_amd import dist as ddist
@@ -91,8 +92,11 @@ def main():
 
     B, K, Wm = args.batch, args.steps, args.warmup
     wts = make_weights(50, NJ, False, seed=0, head_std=0.05)
-    net = engine.DGPNet(50, NJ, H, W, max_batch=B, device=local_rank)
-    net.load_weights(wts)
+    # two engines on two HIP streams, batches dealt in turn (engine.DGPPipeline): the grid tail of one batch's layers runs under the
+    # other batch's kernels.  --streams 1 is the plain single-stream loop
+    pipe = engine.DGPPipeline(50, NJ, H, W, max_batch=B, device=local_rank, n_streams=max(1, args.streams))
+    pipe.load_weights(wts)
+    net = pipe.nets[0]
 
     # ONE seeded synthetic stream for the whole job: global batch g holds frames [g B, (g + 1) B) of the stream and
     # is ring[g % RING] -- a device-resident ring of RING distinct batches, identical on every rank (seed 100), so that the
@@ -115,9 +119,15 @@ def main():
     traj = torch.zeros((n_local, NJ, 5), dtype=torch.float32, device=dev)
     scratch = torch.zeros((B, NJ, 5), dtype=torch.float32, device=dev)
 
-    def step(i, record=True):
+    scratches = [scratch] + [torch.zeros_like(scratch) for _ in range(len(pipe.nets) - 1)]
+
+    def step(i, record=True, sequential=False):
         # the soft-argmax kernel writes the packed (row, col, likelihood, iy, ix) records straight into the trajectory slice
-        net.infer_packed(ring[(g0 + i) % RING], traj[i * B:(i + 1) * B] if record else scratch, 1.0, 1)
+        out = traj[i * B:(i + 1) * B] if record else scratches[pipe._next if not sequential else 0]
+        if sequential:       # on the caller's stream, engine 0: the steps instrumented with per-launch events
+            net.infer_packed(ring[(g0 + i) % RING], out, 1.0, 1)
+        else:
+            pipe.submit(ring[(g0 + i) % RING], out, 1.0, 1)
 
     use_pg = dist.is_initialized()
 
@@ -132,7 +142,7 @@ def main():
     # syncs) and the GPU needs ~1 s of load to leave its idle clock state; then the W warm-up steps the contract asks for
     # (every rank calibrates on the SAME batch, ring[0], so that the frozen scales -- and with them every output bit -- do not depend
     #  on which shard a rank owns)
-    net.infer_packed(ring[0], scratch, 1.0, 1)
+    pipe.calibrate(ring[0])
     torch.cuda.synchronize(dev)
     p0 = time.perf_counter()
     while time.perf_counter() - p0 < args.prewarm_seconds:
@@ -141,6 +151,7 @@ def main():
         torch.cuda.synchronize(dev)
     for i in range(Wm):
         step(i % max(K, 1), record=False)
+    pipe.join()
     if use_pg:      # warm the collective too
         ddist.gather_trajectory(traj, world * n_local)
     torch.cuda.synchronize(dev)
@@ -153,7 +164,8 @@ def main():
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(K):
-        step(i)
+        step(i, sequential=i < prof_steps)      # instrumented steps run alone (per-launch durations are not shared with a second batch)
+    pipe.join()
     full = ddist.gather_trajectory(traj, world * n_local)
     torch.cuda.synchronize(dev)
     barrier()
@@ -172,6 +184,7 @@ def main():
                 s_steps += 1
             if sclk is None and s_steps >= 64:
                 sclk = _read_sclk_mhz(local_rank)
+            pipe.join()
             torch.cuda.synchronize(dev)
             if time.perf_counter() - s0 >= args.sustain_seconds:
                 break
@@ -180,7 +193,7 @@ def main():
                      "sclk_mhz_under_load": sclk}
         barrier()
 
-    range_overflow, n_calib = net.range_status()          # a forward that outgrew the calibrated activation scales would be invalid
+    range_overflow, n_calib = pipe.range_status()         # a forward that outgrew the calibrated activation scales would be invalid
     assert not range_overflow, "activation ranges outgrew the calibrated scales during the run"
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if use_pg:
@@ -294,6 +307,8 @@ def main():
         "sustained": sustained,
         "shard_check": shard_check,
         "prewarm_seconds": args.prewarm_seconds,
+        "streams": {"n": len(pipe.nets), "note": "batches are dealt in turn to n engines on n HIP streams (engine.DGPPipeline); the "
+                    "`steps_profiled` instrumented steps run alone on one stream, the other timed steps overlap pairwise"},
         "range_overflow": bool(range_overflow),
         "activation_format": "H2 (fp16 high/low cells, calibrated per-tensor scales; include/dgp_hip.h)" if n_calib else "fp32",
     }

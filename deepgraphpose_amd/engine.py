@@ -216,6 +216,101 @@ class DGPNet:
         return traj
 
 
+class DGPPipeline:
+    """Two engines on two HIP streams, batches dealt to them in turn.
+
+    A forward is a chain of ~50 dependent launches; most layers' grids do not fill a whole number of rounds of the 512 resident
+    workgroups, so the tail of every layer runs on a partly idle chip.  With a second, independent batch in flight on another
+    stream the hardware fills those tails with the other batch's workgroups: +5 % frames/s on ResNet-50 640x480 batch 32
+    (scripts/two_stream_probe.py: 4279 -> 4492 over 300 steps; a third stream adds nothing).  Every engine keeps its own repacked
+    weights and workspace (one forward at a time per dgp_net, include/dgp_hip.h); all engines calibrate their activation scales on
+    the SAME batch (`calibrate`), so which engine a batch lands on does not change a bit of its result.
+
+    submit() enqueues one batch and returns at once; join() makes the caller's stream wait for everything submitted."""
+
+    def __init__(self, depth: int = 50, num_joints: int = 4, in_h: int = 480, in_w: int = 640, max_batch: int = 32,
+                 with_locref: bool = False, device: int = 0, n_streams: int = 2, mean_pixel=MEAN_PIXEL,
+                 first: Optional[DGPNet] = None):
+        """first: an existing engine of the same configuration to adopt as engine 0 (its weights stay loaded)."""
+        if n_streams < 1:
+            raise _lib.DgpError("n_streams must be >= 1")
+        self.nets = [first] if first is not None else []
+        while len(self.nets) < n_streams:
+            self.nets.append(DGPNet(depth, num_joints, in_h, in_w, max_batch, with_locref, device, mean_pixel))
+        self.device = self.nets[0].device
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
+        self.nj, self.max_batch = num_joints, max_batch
+        self._next = 0
+        self._calibrated = False
+        n0 = self.nets[0]
+        self.in_h, self.in_w, self.out_h, self.out_w = n0.in_h, n0.in_w, n0.out_h, n0.out_w
+
+    def load_weights(self, weights: Dict[str, np.ndarray]):
+        for n in self.nets:
+            n.load_weights(weights)
+        self._calibrated = False
+
+    def set_input_size(self, in_h: int, in_w: int):
+        for n in self.nets:
+            n.set_input_size(in_h, in_w)
+        n0 = self.nets[0]
+        self.in_h, self.in_w, self.out_h, self.out_w = n0.in_h, n0.in_w, n0.out_h, n0.out_w
+
+    def calibrate(self, frames: torch.Tensor, gamma: float = 1.0, gauss_len: int = 1):
+        """Run `frames` through every engine (each calibrates on it after load_weights / recalibrate / an overflow); synchronises."""
+        scratch = torch.empty((frames.shape[0], self.nj, 5), dtype=torch.float32, device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        for n, st in zip(self.nets, self.streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                n.infer_packed(frames, scratch, gamma, gauss_len)
+            st.synchronize()
+        self._calibrated = True
+
+    def submit(self, frames: torch.Tensor, traj: torch.Tensor, gamma: float = 1.0, gauss_len: int = 1) -> "torch.cuda.Event":
+        """infer_packed(frames -> traj) on the next engine's stream, ordered after the work already on the caller's current stream.
+        Returns the event recorded behind it (frames / traj may be reused once it has completed).  The first batch after
+        load_weights / recalibrate / an overflow goes through EVERY engine first (calibrate), so all engines share its scales."""
+        if not self._calibrated:
+            self.calibrate(frames, gamma, gauss_len)
+        i = self._next
+        self._next = (i + 1) % len(self.nets)
+        st = self.streams[i]
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(st):
+            self.nets[i].infer_packed(frames, traj, gamma, gauss_len)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        return ev
+
+    def join(self):
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            cur.wait_stream(st)
+
+    def range_status(self) -> Tuple[bool, int]:
+        """(any engine overflowed, calibrations of the first engine); an overflow on one engine widens ALL of them, so that they
+        keep identical scales after the re-calibration (calibrate() again before re-running)."""
+        res = [n.range_status() for n in self.nets]
+        ov = any(r[0] for r in res)
+        if ov:
+            for n, r in zip(self.nets, res):
+                if not r[0]:
+                    n.widen()
+            self._calibrated = False
+        return ov, res[0][1]
+
+    def recalibrate(self):
+        for n in self.nets:
+            n.recalibrate()
+        self._calibrated = False
+
+    def widen(self):
+        for n in self.nets:
+            n.widen()
+        self._calibrated = False
+
+
 # ---------------------------------------------------------------------------------------
 # stand-alone operators
 # ---------------------------------------------------------------------------------------

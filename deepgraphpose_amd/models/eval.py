@@ -60,6 +60,22 @@ class EvalSession:
             net.set_input_size(h, w)
         return net
 
+    def pipe_for(self, h: int, w: int, n_streams: int = 2):
+        """The streaming form of net_for: engine.DGPPipeline (n engines on n HIP streams, batches dealt in turn) whose engine 0 is
+        net_for's engine; the further engines load the same weights once."""
+        from .. import engine
+        net = self.net_for(h, w)
+        pipe = self._nets.get("pipe")
+        if pipe is None:
+            pipe = engine.DGPPipeline(self.depth, self.nj, h, w, max_batch=self.max_batch, with_locref=self.loc_ref,
+                                      device=self.device, n_streams=n_streams, mean_pixel=self.mean_pixel, first=net)
+            for n in pipe.nets[1:]:
+                n.load_weights(self.weights)
+            self._nets["pipe"] = pipe
+        elif (pipe.in_h, pipe.in_w) != (h, w):
+            pipe.set_input_size(h, w)
+        return pipe
+
     def run(self, fetches, feed_dict):
         import torch
         from .. import engine
@@ -199,8 +215,9 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
             raise ValueError("no frames in %s" % video_file)
         f0 = prep(first)
         hh, ww = f0.shape[:2]
-        net = net_used = sess.net_for(hh, ww)
-        nslots = 3
+        # two engines on two HIP streams, batches dealt in turn (engine.DGPPipeline; DGP_EVAL_STREAMS=1: one engine, A/B)
+        net = net_used = sess.pipe_for(hh, ww, n_streams=max(1, int(os.environ.get("DGP_EVAL_STREAMS", "2"))))
+        nslots = 4                                # two batches on the engines, one being copied, one being decoded
         pinned = [torch.empty((batch_size, hh, ww, 3), dtype=torch.uint8).pin_memory() for _ in range(nslots)]
         dbuf = [torch.empty((batch_size, hh, ww, 3), dtype=torch.uint8, device=dev) for _ in range(nslots)]
         if world > 1 and hasattr(video_clip, "frame_at"):
@@ -211,7 +228,7 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
             for t in range(nb0):
                 np.copyto(pinned[0][t].numpy(), prep(video_clip.frame_at(t)))
             dbuf[0][:nb0].copy_(pinned[0][:nb0])
-            net.infer_packed(dbuf[0][:nb0], torch.empty((nb0, nj, 5), dtype=torch.float32, device=dev), sess.gamma, sess.gauss_len)
+            net.calibrate(dbuf[0][:nb0], sess.gamma, sess.gauss_len)
             torch.cuda.synchronize(dev)
         free_slots, ready = queue.Queue(), queue.Queue()
         for i in range(nslots):
@@ -273,13 +290,13 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
                 copied = torch.cuda.Event()
                 copied.record(copy_stream)
             compute.wait_event(copied)
-            net.infer_packed(dbuf[slot][:nb], traj[start:start + nb], sess.gamma, sess.gauss_len)   # written in place by the kernel
-            consumed[slot] = torch.cuda.Event()
-            consumed[slot].record(compute)
+            # written in place by the soft-argmax kernel; the event marks the end of this batch on its engine's stream
+            consumed[slot] = net.submit(dbuf[slot][:nb], traj[start:start + nb], sess.gamma, sess.gauss_len)
             start += nb
             copied.synchronize()              # the pinned buffer is free again once its H2D copy has completed
             free_slots.put(slot)
         th.join()
+        net.join()
         torch.cuda.synchronize(dev)
         if world > 1:                                  # ONE all-gather per video: 20 bytes per (frame, joint)
             full = ddist.gather_trajectory(traj[:n_local], n_frames)

@@ -37,3 +37,19 @@ def alt(K):
 alt(4); torch.cuda.synchronize()
 t0 = time.perf_counter(); alt(20); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print("%-20s %.3f ms / 32 frames  %.0f frames/s" % ("alternate 2 x 32", dt / 20 * 1e3, 32 * 20 / dt), flush=True)
+
+# three engines / three streams
+nets.append(engine.DGPNet(50, NJ, H, W, max_batch=32)); nets[2].load_weights(wts); streams.append(torch.cuda.Stream())
+def alt3(K):
+    for i in range(K):
+        with torch.cuda.stream(streams[i % 3]):
+            nets[i % 3].infer(frames, check_range=False)
+alt3(6); torch.cuda.synchronize()
+t0 = time.perf_counter(); alt3(21); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print("%-20s %.3f ms / 32 frames  %.0f frames/s" % ("alternate 3 x 32", dt / 21 * 1e3, 32 * 21 / dt), flush=True)
+# sustained 2-stream: 300 steps
+alt(10); torch.cuda.synchronize()
+t0 = time.perf_counter(); alt(300); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print("%-20s %.3f ms / 32 frames  %.0f frames/s" % ("alternate 2 x 32, 300 steps", dt / 300 * 1e3, 32 * 300 / dt), flush=True)
+t0 = time.perf_counter(); one(300); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print("%-20s %.3f ms / 32 frames  %.0f frames/s" % ("1 stream x 32, 300 steps", dt / 300 * 1e3, 32 * 300 / dt), flush=True)

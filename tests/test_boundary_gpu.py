@@ -336,3 +336,39 @@ def test_estimate_pose_edge_cases_vs_oracle(lib_built, tmp_path):
     crop = (8, 16, 136, 112)                                       # PIL box (left, upper, right, lower) -> 96 x 128 frames
     cropped = np.stack([np.asarray(Image.fromarray(f).crop(crop)) for f in big])
     check(run(big, "cropped", batch_size=2, crop_size=crop), O.infer(cropped, wts, 50, 8.0, 1.0, 1))
+
+
+def test_pipeline_two_engines_equal_single_engine(lib_built):
+    """engine.DGPPipeline (two engines on two HIP streams, batches dealt in turn): every batch's packed records equal what ONE engine
+    calibrated on the same first batch computes, bit for bit, whichever engine they landed on; ragged last batch; a re-calibration
+    (widen) keeps the engines on identical scales."""
+    from deepgraphpose_amd.engine import DGPNet, DGPPipeline
+    from deepgraphpose_amd.synthetic import make_frames, make_weights
+    nj, T, B = 4, 45, 8
+    wts = make_weights(50, nj, False, seed=13, head_std=0.05)
+    ft = torch.from_numpy(make_frames(T, 64, 96, nj, seed=14)).cuda()
+    one = DGPNet(50, nj, 64, 96, max_batch=B)
+    one.load_weights(wts)
+    ref = torch.zeros((T, nj, 5), dtype=torch.float32, device="cuda")
+    for s in range(0, T, B):
+        one.infer_packed(ft[s:s + B].contiguous(), ref[s:s + B])
+    assert one.range_status() == (False, 1)
+    pipe = DGPPipeline(50, nj, 64, 96, max_batch=B, n_streams=2)
+    pipe.load_weights(wts)
+    got = torch.zeros_like(ref)
+    events = [pipe.submit(ft[s:s + B].contiguous(), got[s:s + B]) for s in range(0, T, B)]      # 6 batches, the last of 5 frames
+    pipe.join()
+    torch.cuda.synchronize()
+    assert all(e.query() for e in events)
+    assert pipe.range_status() == (False, 1) and [n.range_status()[1] for n in pipe.nets] == [1, 1]
+    assert torch.equal(got, ref)
+    pipe.widen()                                            # e.g. another rank overflowed: all engines re-calibrate together
+    got2 = torch.zeros_like(ref)
+    for s in range(0, T, B):
+        pipe.submit(ft[s:s + B].contiguous(), got2[s:s + B])
+    pipe.join()
+    torch.cuda.synchronize()
+    assert [n.range_status() for n in pipe.nets] == [(False, 2), (False, 2)]
+    m1, c1, i1 = [t.cpu().numpy() for t in __import__("deepgraphpose_amd.dist", fromlist=["x"]).unpack_keypoints(got2)]
+    m0, c0, i0 = [t.cpu().numpy() for t in __import__("deepgraphpose_amd.dist", fromlist=["x"]).unpack_keypoints(ref)]
+    assert np.array_equal(i1, i0) and np.abs(m1 - m0).max() * 8.0 < PX_TOL
