@@ -1215,6 +1215,27 @@ struct TrainCtx {
     std::unordered_map<const float*, const float*> cells;      // weight panel -> the same panel pre-split into fp16 cells
     const void* defer_plan = nullptr;            // TPlan of the running backward pass when weight-gradient finalisation is deferred
     char* defer_ws = nullptr;
+    // Weight gradients on a second stream: the data-gradient chain is the critical path of the backward pass
+    // and its 11-frame grids leave CUs idle; a layer's weight gradient only needs (x, dY) and is not needed before the finalisation
+    // launches, so it runs on `s2` behind an event and the chain goes on.  readers: events recorded on s2 behind the launches that
+    // READ a gradient buffer -- the chain waits for them before it overwrites that buffer.
+    hipStream_t s2 = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_next = 0;
+    std::multimap<const void*, hipEvent_t> readers;
+    bool overlap = false;                        // set for the duration of a backward pass
+    ~TrainCtx() {
+        for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+        if (s2) (void)hipStreamDestroy(s2);
+    }
+    hipEvent_t take_event() {
+        if (ev_next == ev_pool.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            ev_pool.push_back(e);
+        }
+        return ev_pool[ev_next++];
+    }
 };
 
 struct dgp_trainer {
@@ -1254,7 +1275,7 @@ struct TPlan {
     std::vector<size_t> sc, r1, r2, xo;         // per unit
     size_t scmap, locref;
     // gradients
-    size_t g0, g1, dxa, dr1, dr2, dc1, dph0, dph1, dwraw, colsum, tail;
+    size_t g0, g1, dxa, dr1, dr2, dxa_b, dr1_b, dr2_b, dc1, dph0, dph1, dwraw, colsum, tail;      // (_b: second copies, units alternate)
     // per-layer weight-gradient scratch (non-head layers): [colsum | dot][dWraw], one contiguous region zeroed once per backward pass
     std::vector<size_t> cs_l, dw_l;
     size_t dwall = 0, dwall_bytes = 0;
@@ -1292,6 +1313,7 @@ TPlan make_tplan(const dgp_trainer* tr, int B) {
     p.locref = take((size_t)B * 4 * h * w * 2 * nj);
     p.g0 = take(xmax); p.g1 = take(xmax); p.dxa = take(xmax);
     p.dr1 = take(r1max); p.dr2 = take(r2max);
+    p.dxa_b = take(xmax); p.dr1_b = take(r1max); p.dr2_b = take(r2max);
     p.dc1 = take((size_t)B * net->h1 * net->w1 * 64);
     p.dph0 = take((size_t)B * h * w * next_pow2(4 * nj));
     p.dph1 = take((size_t)B * h * w * next_pow2(8 * nj));
@@ -1805,9 +1827,23 @@ static int layer_param_grads(dgp_trainer* tr, size_t li, const float* x, int N, 
     const ConvLayer& l = net->layers[li];
     const TLayer& t = tr->tl[li];
     if (g_ctx->defer_plan) {
+        hipStream_t ws_ = s;
+        hipEvent_t done = nullptr;
+        if (g_ctx->overlap) {                    // behind everything enqueued on the chain's stream so far (dY's producer included)
+            hipEvent_t ready = g_ctx->take_event();
+            done = g_ctx->take_event();
+            if (!ready || !done) return fail(DGP_ERR_HIP, "weight-gradient stream: hipEventCreate failed");
+            TRY_HIP(hipEventRecord(ready, s));
+            TRY_HIP(hipStreamWaitEvent(g_ctx->s2, ready, 0));
+            ws_ = g_ctx->s2;
+        }
         TRY_HIP(wgrad_launch(x, N, H, W, l.Cin, dy, Ho, Wo, l.Cout, l.KH, l.KW, stride, l.rate, pad_t, pad_l,
                              reinterpret_cast<float*>(g_ctx->defer_ws + ((const TPlan*)g_ctx->defer_plan)->dw_l[li]),
-                             reinterpret_cast<float*>(g_ctx->defer_ws + ((const TPlan*)g_ctx->defer_plan)->cs_l[li]), s, true));
+                             reinterpret_cast<float*>(g_ctx->defer_ws + ((const TPlan*)g_ctx->defer_plan)->cs_l[li]), ws_, true));
+        if (done) {
+            TRY_HIP(hipEventRecord(done, g_ctx->s2));
+            g_ctx->readers.emplace((const void*)dy, done);
+        }
         return DGP_OK;
     }
     TRY_HIP(wgrad_launch(x, N, H, W, l.Cin, dy, Ho, Wo, l.Cout, l.KH, l.KW, stride, l.rate, pad_t, pad_l, dwraw, colsum, s));
@@ -1841,6 +1877,44 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
     g_ctx->defer_plan = defer_env ? &pl : nullptr;
     g_ctx->defer_ws = ws;
     if (defer_env) TRY_HIP(hipMemsetAsync(ws + pl.dwall, 0, pl.dwall_bytes, s));
+    // weight gradients on their own stream beside the data-gradient chain (DGP_WGRAD_OVERLAP=0: one stream, A/B)
+    static const bool overlap_env = !(getenv("DGP_WGRAD_OVERLAP") && atoi(getenv("DGP_WGRAD_OVERLAP")) == 0);
+    TrainCtx* const ctx = g_ctx;
+    if (defer_env && overlap_env) {
+        if (!ctx->s2) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);         // lo: numerically greatest = least urgent
+            static const int prio_mode = getenv("DGP_WGRAD_PRIO") ? atoi(getenv("DGP_WGRAD_PRIO")) : 0;      // 0 least urgent, 1 default, 2 most urgent
+            TRY_HIP(hipStreamCreateWithPriority(&ctx->s2, hipStreamNonBlocking, prio_mode == 0 ? lo : prio_mode == 2 ? hi : 0));
+        }
+        ctx->overlap = true;
+        ctx->ev_next = 0;
+        ctx->readers.clear();
+    }
+    // join: the chain's stream waits for every weight gradient (before the finalisation launches, and on every exit path)
+    struct Join {
+        TrainCtx* c; hipStream_t s;
+        void operator()() {
+            if (!c->overlap) return;
+            c->overlap = false;
+            c->readers.clear();
+            hipEvent_t e = c->take_event();
+            if (e && hipEventRecord(e, c->s2) == hipSuccess) (void)hipStreamWaitEvent(s, e, 0);
+            else (void)hipStreamSynchronize(c->s2);
+        }
+        ~Join() { (*this)(); }
+    } join{ctx, s};
+    // the chain is about to overwrite `buf`: wait for the weight-gradient launches that still read it
+    auto before_write = [&](const void* buf) -> hipError_t {
+        if (!ctx->overlap) return hipSuccess;
+        auto range = ctx->readers.equal_range(buf);
+        for (auto it = range.first; it != range.second; ++it) {
+            hipError_t e2 = hipStreamWaitEvent(s, it->second, 0);
+            if (e2 != hipSuccess) return e2;
+        }
+        ctx->readers.erase(range.first, range.second);
+        return hipSuccess;
+    };
     // geometry per unit input
     std::vector<int> hs(nu + 1), wsz(nu + 1);
     hs[0] = net->hp; wsz[0] = net->wp;
@@ -1904,19 +1978,26 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         float* Gin = G[cur ^ 1];
         const ConvLayer &l1 = net->layers[u.c1], &l2 = net->layers[u.c2], &l3 = net->layers[u.c3];
         const TLayer &t1 = tr->tl[u.c1], &t2 = tr->tl[u.c2], &t3 = tr->tl[u.c3];
+        // gradient buffers of this unit (units alternate between two sets: a weight gradient still reading unit ui + 1's dR1 / dR2 on
+        // the second stream does not hold this unit's chain back)
+        float* const DR2 = F((ui & 1) ? pl.dr2_b : pl.dr2);
+        float* const DR1 = F((ui & 1) ? pl.dr1_b : pl.dr1);
+        float* const DXA = F((ui & 1) ? pl.dxa_b : pl.dxa);
         // conv3: params, then dR2 = convT(G) gated by R2 > 0
         rc = layer_param_grads(tr, u.c3, F(pl.r2[ui]), B, ho, wo, Gout, ho, wo, 1, 0, 0, dwraw, colsum, s);
         if (rc) return rc;
+        TRY_HIP(before_write(DR2));
         TRY_HIP(conv_launch(l3, t3.d_wT, t3.nkT, t3.cinP, Gout, B, ho, wo, l3.Cout, 0, 0, ho, wo, l3.Cin, 1, 0, nullptr, nullptr,
-                            nullptr, 0, 0, 0, F(pl.r2[ui]), false, 0, 0, F(pl.dr2), s));
+                            nullptr, 0, 0, 0, F(pl.r2[ui]), false, 0, 0, DR2, s));
         // conv2: params, then dR1 = convT(dR2) gated by R1 > 0
         const int pb_h = pad_before_for(h, 3, u.stride, u.rate, true), pb_w = pad_before_for(w, 3, u.stride, u.rate, true);
-        rc = layer_param_grads(tr, u.c2, F(pl.r1[ui]), B, h, w, F(pl.dr2), ho, wo, u.stride, pb_h, pb_w, dwraw, colsum, s);
+        rc = layer_param_grads(tr, u.c2, F(pl.r1[ui]), B, h, w, DR2, ho, wo, u.stride, pb_h, pb_w, dwraw, colsum, s);
         if (rc) return rc;
         const int keff = 2 * u.rate + 1;
-        TRY_HIP(conv_launch(l2, t2.d_wT, t2.nkT, t2.cinP, F(pl.dr2), B, ho, wo, l2.Cout, keff - 1 - pb_h, keff - 1 - pb_w, h, w,
+        TRY_HIP(before_write(DR1));
+        TRY_HIP(conv_launch(l2, t2.d_wT, t2.nkT, t2.cinP, DR2, B, ho, wo, l2.Cout, keff - 1 - pb_h, keff - 1 - pb_w, h, w,
                             l2.Cin, 1, u.stride > 1 ? u.stride : 0, nullptr, nullptr, nullptr, 0, 0, 0, F(pl.r1[ui]), false, 0, 0,
-                            F(pl.dr1), s));
+                            DR1, s));
         // shortcut branch
         const float* dxa = Gout;
         int dxa_mode = 1;                       // same grid
@@ -1926,16 +2007,18 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
             const TLayer& ts = tr->tl[u.sc];
             rc = layer_param_grads(tr, u.sc, xin, B, h, w, Gout, ho, wo, u.stride, 0, 0, dwraw, colsum, s);
             if (rc) return rc;
+            TRY_HIP(before_write(DXA));
             TRY_HIP(conv_launch(ls, ts.d_wT, ts.nkT, ts.cinP, Gout, B, ho, wo, ls.Cout, 0, 0, h, w, ls.Cin, 1,
-                                u.stride > 1 ? u.stride : 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, false, 0, 0, F(pl.dxa), s));
-            dxa = F(pl.dxa); dxa_h = h; dxa_w = w;
+                                u.stride > 1 ? u.stride : 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, false, 0, 0, DXA, s));
+            dxa = DXA; dxa_h = h; dxa_w = w;
         } else if (u.stride > 1) {
             dxa_mode = -2;                      // subsample shortcut: gradient lives on the coarser grid
         }
         // conv1: params, then dX = (convT(dR1) + dXa) gated by X_in > 0  -> G for the previous unit
-        rc = layer_param_grads(tr, u.c1, xin, B, h, w, F(pl.dr1), h, w, 1, 0, 0, dwraw, colsum, s);
+        rc = layer_param_grads(tr, u.c1, xin, B, h, w, DR1, h, w, 1, 0, 0, dwraw, colsum, s);
         if (rc) return rc;
-        TRY_HIP(conv_launch(l1, t1.d_wT, t1.nkT, t1.cinP, F(pl.dr1), B, h, w, l1.Cout, 0, 0, h, w, l1.Cin, 1, 0, nullptr, nullptr,
+        TRY_HIP(before_write(Gin));              // (the G of two units ago: its conv3 / shortcut weight gradients)
+        TRY_HIP(conv_launch(l1, t1.d_wT, t1.nkT, t1.cinP, DR1, B, h, w, l1.Cout, 0, 0, h, w, l1.Cin, 1, 0, nullptr, nullptr,
                             dxa, dxa_mode, dxa_h, dxa_w, xin, false, 0, 0, Gin, s));
         cur ^= 1;
     }
@@ -1956,6 +2039,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         if (rc) return rc;
     }
     (void)nj;
+    join();                                      // every weight gradient has landed before the finalisation reads them
     if (g_ctx->defer_plan) {
         g_ctx->defer_plan = nullptr;
         if (!tr->d_fin_table || tr->fin_B != B || tr->fin_h != d.in_h || tr->fin_w != d.in_w) {      // offsets follow the plan
