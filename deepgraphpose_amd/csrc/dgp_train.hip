@@ -1764,15 +1764,40 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     if (const float* r = range_of(F(pl.c1))) g_ctx->rng.of[F(pl.pool)] = r; else g_ctx->rng.of.erase(F(pl.pool));      // max-pooling cannot raise the maximum
     int h = net->hp, w = net->wp;
     const float* xin = F(pl.pool);
+    static const bool side_env = !(getenv("DGP_WGRAD_OVERLAP") && atoi(getenv("DGP_WGRAD_OVERLAP")) == 0);
+    if (side_env && !g_ctx->s2) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        TRY_HIP(hipStreamCreateWithPriority(&g_ctx->s2, hipStreamNonBlocking, lo));
+    }
+    const bool side = side_env && g_ctx->s2;
+    g_ctx->ev_next = 0;                          // (the previous backward pass has joined: its events are free again)
     for (size_t ui = 0; ui < net->units.size(); ++ui) {
         const Unit& u = net->units[ui];
         const int ho = (h + u.stride - 1) / u.stride, wo = (w + u.stride - 1) / u.stride;
         const float* res = xin;
         int res_s = u.stride, res_H = h, res_W = w;
+        hipEvent_t sc_done = nullptr;
         if (u.sc >= 0) {
+            // the projection shortcut only meets the main branch at conv3's residual add: it runs on the trainer's second stream
+            // beside conv1 / conv2 (no K-split slab for it: the slab belongs to the chain's launches)
             const ConvLayer& l = net->layers[u.sc];
-            TRY_HIP(conv_launch(l, l.d_w, l.nk, l.CoutP, xin, B, h, w, l.Cin, 0, 0, ho, wo, l.Cout, u.stride, 0, l.d_scale,
-                                l.d_bias, nullptr, 0, 0, 0, nullptr, false, 0, 0, F(pl.sc[ui]), s));
+            hipStream_t ss = s;
+            float* const slab_keep = g_ctx->tail_slab;
+            if (side) {
+                hipEvent_t ready = g_ctx->take_event();
+                sc_done = g_ctx->take_event();
+                if (!ready || !sc_done) return fail(DGP_ERR_HIP, "shortcut stream: hipEventCreate failed");
+                TRY_HIP(hipEventRecord(ready, s));
+                TRY_HIP(hipStreamWaitEvent(g_ctx->s2, ready, 0));
+                ss = g_ctx->s2;
+                g_ctx->tail_slab = nullptr;
+            }
+            hipError_t esc = conv_launch(l, l.d_w, l.nk, l.CoutP, xin, B, h, w, l.Cin, 0, 0, ho, wo, l.Cout, u.stride, 0, l.d_scale,
+                                         l.d_bias, nullptr, 0, 0, 0, nullptr, false, 0, 0, F(pl.sc[ui]), ss);
+            g_ctx->tail_slab = slab_keep;
+            TRY_HIP(esc);
+            if (sc_done) TRY_HIP(hipEventRecord(sc_done, g_ctx->s2));
             res = F(pl.sc[ui]); res_s = 1; res_H = ho; res_W = wo;
         }
         const ConvLayer& l1 = net->layers[u.c1];
@@ -1783,6 +1808,7 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
         TRY_HIP(conv_launch(l2, l2.d_w, l2.nk, l2.CoutP, F(pl.r1[ui]), B, h, w, l2.Cin, pb_h, pb_w, ho, wo, l2.Cout,
                             u.stride, 0, l2.d_scale, l2.d_bias, nullptr, 0, 0, 0, nullptr, true, 0, 0, F(pl.r2[ui]), s));
         const ConvLayer& l3 = net->layers[u.c3];
+        if (sc_done) TRY_HIP(hipStreamWaitEvent(s, sc_done, 0));
         TRY_HIP(conv_launch(l3, l3.d_w, l3.nk, l3.CoutP, F(pl.r2[ui]), B, ho, wo, l3.Cin, 0, 0, ho, wo, l3.Cout, 1, 0,
                             l3.d_scale, l3.d_bias, res, res_s, res_H, res_W, nullptr, true, 0, 0, F(pl.xo[ui]), s));
         xin = F(pl.xo[ui]); h = ho; w = wo;
