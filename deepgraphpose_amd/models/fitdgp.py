@@ -209,6 +209,54 @@ def _dp_setup():
     return rank, world, local
 
 
+def _prefetched(make_item, n_items: int, depth=None):
+    """make_item(0), make_item(1), ... in order, built by ONE background thread up to `depth` items ahead of the consumer: the host
+    work of iteration it + 1 (frame reads, augmentation, target maps) runs while the GPU trains on iteration it.  A single producer
+    keeps the order of every random draw, so a run is the same with or without prefetching (DGP_FIT_PREFETCH=0: inline)."""
+    import queue
+    import threading
+    if depth is None:
+        depth = int(os.environ.get("DGP_FIT_PREFETCH", "2"))
+    if depth <= 0 or n_items <= 1:
+        for i in range(n_items):
+            yield make_item(i)
+        return
+    q = queue.Queue(maxsize=depth)
+    stop = threading.Event()
+
+    def work():
+        try:
+            for i in range(n_items):
+                item = make_item(i)
+                while not stop.is_set():
+                    try:
+                        q.put((item, None), timeout=0.1)
+                        break
+                    except queue.Full:
+                        pass
+                if stop.is_set():
+                    return
+        except BaseException as e:      # surfaces in the consumer
+            while not stop.is_set():
+                try:
+                    q.put((None, e), timeout=0.1)
+                    break
+                except queue.Full:
+                    pass
+
+    th = threading.Thread(target=work, name="dgp-batch-prefetch", daemon=True)
+    th.start()
+    try:
+        for _ in range(n_items):
+            item, err = q.get()
+            if err is not None:
+                raise err
+            yield item
+    finally:
+        stop.set()
+        th.join(timeout=5.0)
+
+
 def _pretrained_checkpoint(net_type: str, dlc_cfg) -> str:
     """ImageNet backbone checkpoint `resnet_v1_<depth>.ckpt`.  The reference looks inside the installed deeplabcut
     package (fitdgp.py:101-106); here: $DGP_PRETRAINED_DIR, <package>/pretrained/, then pose_cfg.yaml's init_weights."""
@@ -308,9 +356,8 @@ def fit_dlc(snapshot, dlcpath, shuffle=1, step=0, saveiters=1000, displayiters=1
     cumloss, partloss, locrefloss = 0.0, 0.0, 0.0
     print("Starting training....", flush=True)
     dev = trainer.device
-    for it in range(max_iter + 1):
+    for it, batch in enumerate(_prefetched(lambda _i: dataset.next_batch(), max_iter + 1)):      # image read / scale / targets one step ahead
         current_lr = lr_gen.get_lr(it)
-        batch = dataset.next_batch()
         img = batch["inputs"]
         trainer.set_input_size(img.shape[1], img.shape[2])
         frames = torch.from_numpy(img).to(dev)
@@ -375,7 +422,8 @@ def fit_dgp_labeledonly(snapshot, dlcpath, shuffle=1, step=1, saveiters=1000, di
     print("Begin Training for {} iterations".format(maxiters))
     t_start = time.time()
     it = -1
-    for it in range(maxiters):
+
+    def make_batch(it):                          # host side of one iteration (runs one iteration ahead on the prefetch thread)
         dataset_i, frame_i = table[batch_ind_all[_dp_index(it, n_sched)]]
         d = data_batcher.datasets[dataset_i]
         (vis, hid, _, images, joint_loc, _, _, addn), _ = data_batcher.next_batch(0, dataset_i, np.array([frame_i]),
@@ -388,6 +436,9 @@ def fit_dgp_labeledonly(snapshot, dlcpath, shuffle=1, step=1, saveiters=1000, di
         lmap, lmask = _locref_targets(joint_loc, len(all_frame), vis_within, d.nx_out, d.ny_out, nj, dgp_cfg)
         feed_dict = _feed(placeholders, images, joint_loc, lmap, lmask, addn, None, None, 0, d.nx_out, d.ny_out, learning_rate,
                           dgp_cfg.lr)
+        return dataset_i, frame_i, feed_dict
+
+    for it, (dataset_i, frame_i, feed_dict) in enumerate(_prefetched(make_batch, maxiters)):
         t0 = time.time()
         loss_eval, _ = sess.run([loss, train_op], feed_dict)
         if it % displayiters == 0 and it > 0:
@@ -438,7 +489,8 @@ def fit_dgp(snapshot, dlcpath, batch_size=10, shuffle=1, step=2, saveiters=1000,
     print("Begin Training for {} iterations".format(maxiters))
     t_start = time.time()
     it = -1
-    for it in range(maxiters):
+
+    def make_batch(it):                          # host side of one iteration (runs one iteration ahead on the prefetch thread)
         batch_ind = batch_ind_all[_dp_index(it, n_sched)]
         dataset_i = int(batch_ind[-1])
         d = data_batcher.datasets[dataset_i]
@@ -463,6 +515,9 @@ def fit_dgp(snapshot, dlcpath, batch_size=10, shuffle=1, step=2, saveiters=1000,
             vector_field = learn_wt(images)
         feed_dict = _feed(placeholders, images, joint_loc, lmap, lmask, addn, wt_mask, vector_field, dgp_cfg.wt, d.nx_out,
                           d.ny_out, learning_rate, dgp_cfg.lr)
+        return dataset_i, vis_b, hid_b, feed_dict
+
+    for it, (dataset_i, vis_b, hid_b, feed_dict) in enumerate(_prefetched(make_batch, maxiters)):
         t0 = time.time()
         loss_eval, _ = sess.run([loss, train_op], feed_dict)
         if it % displayiters == 0 and it > 0:
