@@ -335,3 +335,16 @@ def test_likelihood_window_saturated_logit_matches_numpy(lib_built):
     assert np.isnan(conf[0, 0])
     ok = ~np.isnan(lref)
     assert np.abs(conf[0][ok] - lref[ok]).max() < 2e-6
+
+
+def test_full_size_backward_is_stable_across_repeats(lib_built):
+    """Race check for the weight gradients on the trainer's second stream (and the alternating gradient buffers): repeated
+    forward/backward passes of the full-size step (640x480, 11 frames) from the same weights give the same gradients up to the order
+    of the float atomics (~3e-7 of the largest gradient); a stale read of an overwritten buffer would show as a jump."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "soak_train_overlap.py"), "8"], cwd=root, capture_output=True,
+                       text=True, timeout=900, env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-800:])
+    worst = float(r.stdout.strip().splitlines()[-1].split("first pass")[1].split()[0])
+    assert worst < 1e-5, r.stdout[-400:]
