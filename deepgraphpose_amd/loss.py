@@ -48,18 +48,16 @@ def _dev_f32(a, dev):
     return torch.as_tensor(np.asarray(a, dtype=np.float32), device=dev).contiguous()
 
 
-def dgp_loss_fwd_bwd(pred: torch.Tensor, locref_pred: torch.Tensor, batch: dict, hyper: DGPHyper, S0, ws, ws_max,
-                     n_frames_total: float, n_visible_frames_total: float):
-    """pred [nt,H,W,nj], locref_pred [nt,H,W,2nj] device fp32.  batch: targets [nv,nj,2] (NaN = unlabeled),
-    locref_map / locref_mask [nt,H,W,2nj], visible_marker, hidden_marker, visible_marker_in_targets.
-    -> (losses dict of python floats, dpred, dlocref, mu [nt,nj,2])."""
+class LossInputs:
+    """Device-resident inputs of one loss evaluation (dgp_loss_prepare): everything that does not depend on the network's output."""
+    __slots__ = ("desc", "dev", "shape", "targets", "lmap", "lmask", "vm", "hm", "vt", "S0", "ws", "ws_max", "vf", "wtb", "scratch")
+
+
+def dgp_loss_prepare(nt: int, H: int, W: int, nj: int, batch: dict, hyper: DGPHyper, S0, ws, ws_max, n_frames_total: float,
+                     n_visible_frames_total: float, dev) -> LossInputs:
+    """Host validation + upload of the batch's index / target arrays.  Independent of the forward pass, so the trainer calls it
+    BEFORE launching the forward: the loss kernels then follow the forward on the stream without the GPU waiting for the host."""
     lib = _lib.load()
-    _need_cuda(pred, torch.float32, "pred")
-    _need_cuda(locref_pred, torch.float32, "locref_pred")
-    dev = pred.device
-    nt, H, W, nj = pred.shape
-    if tuple(locref_pred.shape) != (nt, H, W, 2 * nj):
-        raise ValueError("locref_pred %s does not match pred %s" % (tuple(locref_pred.shape), tuple(pred.shape)))
     # the kernels use these arrays as indices: check them here, on the host, before anything is launched
     vm_h = np.asarray(batch["visible_marker"], dtype=np.int64).ravel()
     hm_h = np.asarray(batch["hidden_marker"], dtype=np.int64).ravel()
@@ -73,36 +71,72 @@ def dgp_loss_fwd_bwd(pred: torch.Tensor, locref_pred: torch.Tensor, batch: dict,
         raise ValueError("visible_marker_in_targets has %d entries for %d visible markers" % (vt_h.size, vm_h.size))
     if not 1 <= int(hyper.gauss_len) <= 7:
         raise ValueError("gauss_len must be 1..7")
-    vm, hm, vt = _dev_i32(vm_h, dev), _dev_i32(hm_h, dev), _dev_i32(vt_h, dev)
-    targets = _dev_f32(tg_h, dev)
-    lmap, lmask = _dev_f32(batch["locref_map"], dev), _dev_f32(batch["locref_mask"], dev)
-    for name, t in (("locref_map", lmap), ("locref_mask", lmask)):
+    li = LossInputs()
+    li.dev, li.shape = dev, (nt, H, W, nj)
+    li.vm, li.hm, li.vt = _dev_i32(vm_h, dev), _dev_i32(hm_h, dev), _dev_i32(vt_h, dev)
+    li.targets = _dev_f32(tg_h, dev)
+    li.lmap, li.lmask = _dev_f32(batch["locref_map"], dev), _dev_f32(batch["locref_mask"], dev)
+    for name, t in (("locref_map", li.lmap), ("locref_mask", li.lmask)):
         if vm_h.size and tuple(t.shape) != (nt, H, W, 2 * nj):
             raise ValueError("%s %s does not match the prediction grid %s" % (name, tuple(t.shape), (nt, H, W, 2 * nj)))
     S0 = np.asarray(S0, dtype=np.float32).reshape(-1, nj)
     nl = S0.shape[0]
-    S0d, wsd, wmd = _dev_f32(S0, dev), _dev_f32(ws, dev), _dev_f32(ws_max, dev)
+    li.S0, li.ws, li.ws_max = _dev_f32(S0, dev), _dev_f32(ws, dev), _dev_f32(ws_max, dev)
     use_wt = hyper.wt > 0 and nt > 1 and batch.get("vector_field") is not None
-    vf = wtb = None
+    li.vf = li.wtb = None
     hin = win = 0
     if use_wt:          # temporal clique: flow magnitude [nt-1,Hin,Win] (learn_wt) and wt * batch_mask (fitdgp.py:774,905)
-        vf = _dev_f32(batch["vector_field"], dev)
-        hin, win = int(vf.shape[1]), int(vf.shape[2])
+        li.vf = _dev_f32(batch["vector_field"], dev)
+        hin, win = int(li.vf.shape[1]), int(li.vf.shape[2])
         mask = np.asarray(batch.get("wt_batch_mask", np.ones(nt - 1)), dtype=np.float32)
-        wtb = _dev_f32(np.ones(nt - 1, dtype=np.float32) * hyper.wt * mask, dev)
-    d = _lib.DgpLossDesc(nt, H, W, nj, nl, vm.numel(), hm.numel(), hyper.gm2, hyper.gm3, hyper.gauss_len,
-                         int(hyper.locref_huber_loss), hyper.gamma, hyper.lengthscale, hyper.stride, hyper.wn_visible,
-                         hyper.wn_hidden, hyper.locref_loss_weight, float(n_frames_total), float(n_visible_frames_total),
-                         int(use_wt), hin, win, float(hyper.wt_max))
+        li.wtb = _dev_f32(np.ones(nt - 1, dtype=np.float32) * hyper.wt * mask, dev)
+    li.desc = _lib.DgpLossDesc(nt, H, W, nj, nl, li.vm.numel(), li.hm.numel(), hyper.gm2, hyper.gm3, hyper.gauss_len,
+                               int(hyper.locref_huber_loss), hyper.gamma, hyper.lengthscale, hyper.stride, hyper.wn_visible,
+                               hyper.wn_hidden, hyper.locref_loss_weight, float(n_frames_total), float(n_visible_frames_total),
+                               int(use_wt), hin, win, float(hyper.wt_max))
     nb = C.c_size_t()
-    _lib.check(lib.dgp_loss_scratch_bytes(C.byref(d), C.byref(nb)), "dgp_loss_scratch_bytes")
-    scratch = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+    _lib.check(lib.dgp_loss_scratch_bytes(C.byref(li.desc), C.byref(nb)), "dgp_loss_scratch_bytes")
+    li.scratch = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+    return li
+
+
+def dgp_loss_launch(li: LossInputs, pred: torch.Tensor, locref_pred: torch.Tensor):
+    """Enqueue the loss forward + backward kernels on the current stream: -> (losses [8] DEVICE tensor in LOSS_NAMES order, dpred,
+    dlocref, mu [nt,nj,2]).  No host synchronisation."""
+    lib = _lib.load()
+    _need_cuda(pred, torch.float32, "pred")
+    _need_cuda(locref_pred, torch.float32, "locref_pred")
+    nt, H, W, nj = li.shape
+    if tuple(pred.shape) != (nt, H, W, nj):
+        raise ValueError("pred %s does not match the prepared batch %s" % (tuple(pred.shape), (nt, H, W, nj)))
+    if tuple(locref_pred.shape) != (nt, H, W, 2 * nj):
+        raise ValueError("locref_pred %s does not match pred %s" % (tuple(locref_pred.shape), tuple(pred.shape)))
+    dev = pred.device
     dpred, dloc = torch.empty_like(pred), torch.empty_like(locref_pred)
     mu = torch.empty((nt, nj, 2), dtype=torch.float32, device=dev)
     losses = torch.zeros(8, dtype=torch.float32, device=dev)
-    _lib.check(lib.dgp_loss_fwd_bwd(C.byref(d), _ptr(pred), _ptr(locref_pred), _ptr(targets), _ptr(lmap), _ptr(lmask),
-                                    _ptr(vm), _ptr(hm), _ptr(vt), _ptr(S0d), _ptr(wsd), _ptr(wmd), _ptr(vf), _ptr(wtb), _ptr(dpred),
-                                    _ptr(dloc), _ptr(mu), _ptr(losses), _ptr(scratch), scratch.numel(), _stream(dev)),
-               "dgp_loss_fwd_bwd")
+    _lib.check(lib.dgp_loss_fwd_bwd(C.byref(li.desc), _ptr(pred), _ptr(locref_pred), _ptr(li.targets), _ptr(li.lmap), _ptr(li.lmask),
+                                    _ptr(li.vm), _ptr(li.hm), _ptr(li.vt), _ptr(li.S0), _ptr(li.ws), _ptr(li.ws_max), _ptr(li.vf),
+                                    _ptr(li.wtb), _ptr(dpred), _ptr(dloc), _ptr(mu), _ptr(losses), _ptr(li.scratch), li.scratch.numel(),
+                                    _stream(dev)), "dgp_loss_fwd_bwd")
+    return losses, dpred, dloc, mu
+
+
+def losses_to_dict(losses: torch.Tensor) -> dict:
     lv = losses.cpu().numpy()
-    return {k: float(lv[i]) for i, k in enumerate(LOSS_NAMES)}, dpred, dloc, mu
+    return {k: float(lv[i]) for i, k in enumerate(LOSS_NAMES)}
+
+
+def dgp_loss_fwd_bwd(pred: torch.Tensor, locref_pred: torch.Tensor, batch: dict, hyper: DGPHyper, S0, ws, ws_max,
+                     n_frames_total: float, n_visible_frames_total: float):
+    """pred [nt,H,W,nj], locref_pred [nt,H,W,2nj] device fp32.  batch: targets [nv,nj,2] (NaN = unlabeled),
+    locref_map / locref_mask [nt,H,W,2nj], visible_marker, hidden_marker, visible_marker_in_targets.
+    -> (losses dict of python floats, dpred, dlocref, mu [nt,nj,2]).  (= dgp_loss_prepare + dgp_loss_launch + a read-back.)"""
+    _need_cuda(pred, torch.float32, "pred")
+    _need_cuda(locref_pred, torch.float32, "locref_pred")
+    nt, H, W, nj = pred.shape
+    if tuple(locref_pred.shape) != (nt, H, W, 2 * nj):
+        raise ValueError("locref_pred %s does not match pred %s" % (tuple(locref_pred.shape), tuple(pred.shape)))
+    li = dgp_loss_prepare(nt, H, W, nj, batch, hyper, S0, ws, ws_max, n_frames_total, n_visible_frames_total, pred.device)
+    losses, dpred, dloc, mu = dgp_loss_launch(li, pred, locref_pred)
+    return losses_to_dict(losses), dpred, dloc, mu

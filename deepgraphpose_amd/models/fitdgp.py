@@ -154,8 +154,8 @@ def _frames_to_device(trainer, images):
 def _locref_targets(joint_loc, nt, vis_within, nx_out, ny_out, nj, dgp_cfg):
     lt, lm = coord2map(joint_loc, nx_out, ny_out, nj, dgp_cfg.pos_dist_thresh, dgp_cfg.locref_stdev) \
         if joint_loc.shape[0] else (np.zeros((0,)), np.zeros((0,)))
-    lmap = np.zeros((nt, nx_out, ny_out, nj * 2))
-    lmask = np.zeros((nt, nx_out, ny_out, nj * 2))
+    lmap = np.zeros((nt, nx_out, ny_out, nj * 2), dtype=np.float32)       # fp32 here (on the prefetch thread): the trainer's upload of
+    lmask = np.zeros((nt, nx_out, ny_out, nj * 2), dtype=np.float32)      # the two maps is then a plain copy, no conversion pass
     if lm.shape[0] != 0:
         lmap[vis_within], lmask[vis_within] = lt, lm
     return lmap, lmask

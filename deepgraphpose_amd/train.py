@@ -131,21 +131,24 @@ class Trainer:
     def forward_backward(self, frames: torch.Tensor, batch: dict, hyper: DGPHyper, S0, ws, ws_max, n_frames_total,
                          n_visible_frames_total, labeled_only: bool = False):
         """frames uint8 [nt,H,W,3] on device.  Fills the gradient buffer; returns the loss dict."""
-        from .loss import dgp_loss_fwd_bwd
+        from .loss import dgp_loss_launch, dgp_loss_prepare, losses_to_dict
         frames = frames.contiguous()
         nt = frames.shape[0]
         st = _stream(self.device)
-        wsb, pred, loc = self._forward(frames)          # checks dtype / shape against the net's current input size
         nj = self.net.nj
         if labeled_only:          # fit_dgp_labeledonly: total_loss_visible, no hidden / clique terms (fitdgp.py:416)
             batch = dict(batch, hidden_marker=np.empty(0, dtype=np.int32))
             S0 = np.zeros((0, nj))
             ws = ws_max = np.zeros(0)
-        losses, dpred, dloc, mu = dgp_loss_fwd_bwd(pred, loc, batch, hyper, S0, ws, ws_max, n_frames_total,
-                                                   n_visible_frames_total)
+        # host-side order: loss inputs validated and uploaded first, then forward, loss kernels and the whole backward pass are
+        # enqueued back to back; the losses are read back (the one synchronisation) after everything is in flight
+        li = dgp_loss_prepare(nt, self.net.out_h, self.net.out_w, nj, batch, hyper, S0, ws, ws_max, n_frames_total,
+                              n_visible_frames_total, self.device)
+        wsb, pred, loc = self._forward(frames)          # checks dtype / shape against the net's current input size
+        losses, dpred, dloc, mu = dgp_loss_launch(li, pred, loc)
         _lib.check(self.lib.dgp_train_backward(self._t, nt, _ptr(wsb), wsb.numel(), _ptr(dpred), _ptr(dloc), st),
                    "dgp_train_backward")
-        return losses
+        return losses_to_dict(losses)
 
     def grads_tensor(self) -> torch.Tensor:
         """The flat fp32 gradient buffer of every trainable tensor as a device tensor (no copy)."""

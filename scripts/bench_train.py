@@ -18,7 +18,7 @@ frames = torch.from_numpy(make_frames(NT, H, W, NJ, seed=0)).cuda()
 jl = np.stack([rng.uniform(5, 55, (1, NJ)), rng.uniform(5, 75, (1, NJ))], -1)
 vm, hm, vt = D.gen_idx_chunk(np.array([5]), np.setdiff1d(np.arange(NT), [5]), jl)
 lt, lm = D.coord2map(jl, 60, 80, NJ, 17)
-lmap, lmask = np.zeros((NT, 60, 80, 2 * NJ)), np.zeros((NT, 60, 80, 2 * NJ))
+lmap, lmask = np.zeros((NT, 60, 80, 2 * NJ), np.float32), np.zeros((NT, 60, 80, 2 * NJ), np.float32)      # as the fit drivers build them
 lmap[5], lmask[5] = lt[0], lm[0]
 batch = dict(targets=jl, locref_map=lmap, locref_mask=lmask, visible_marker=vm, hidden_marker=hm, visible_marker_in_targets=vt)
 S0 = np.zeros((3, NJ)); [S0.__setitem__((i, i), 1) or S0.__setitem__((i, i + 1), -1) for i in range(3)]
