@@ -1389,7 +1389,10 @@ static const bool g_train_cells = !(getenv("DGP_TRAIN_CELLS") && atoi(getenv("DG
 hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, const float* in, int N, int H, int W,
                        int Cin, int pad_t, int pad_l, int Ho, int Wo, int Cout, int stride, int up, const float* scale,
                        const float* bias, const float* res, int res_s, int res_H, int res_W, const float* mask,
-                       bool relu, int out_mode, int dc_nj, float* out, hipStream_t s) {
+                       bool relu, int out_mode, int dc_nj, float* out, hipStream_t s, const void* in_key = nullptr,
+                       const void* out_key = nullptr) {
+    // in_key / out_key: the tensors whose range slots this launch reads / feeds when `in` / `out` are frame ranges inside them
+    // (the forward pass as two sub-batch chains: both chains max into the slot of the whole tensor)
     ConvArgs a{};
     a.in = in; a.wpk = wpk; a.scale = scale; a.bias = bias; a.res = res; a.mask = mask; a.out = out;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.log2cin4 = ilog2(Cin / 4);
@@ -1406,7 +1409,7 @@ hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, 
     a.res_bytes = res ? (unsigned)((size_t)N * res_H * res_W * Cout * 4) : 0u;
     a.w_bytes = (unsigned)((size_t)nk * 8 * coutP * 16);
     a.slab = g_ctx->tail_slab; a.slab_bytes = g_ctx->tail_slab ? (unsigned)(TAIL_SLAB_FLOATS * sizeof(float)) : 0u;
-    const float* rin = range_of(in);
+    const float* rin = range_of(in_key ? in_key : in);
     const float* rw = range_of(wpk);
     if (rin && rw && out_mode == 0) {
         a.in_absmax = rin; a.w_absmax = rw;
@@ -1414,8 +1417,10 @@ hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, 
         if (g_train_cells && c != g_ctx->cells.end()) { a.wh3 = c->second; a.wh3_bytes = a.w_bytes; }
     }
     if (out_mode == 0) {
-        a.out_absmax = range_take();
-        if (a.out_absmax) g_ctx->rng.of[out] = a.out_absmax; else g_ctx->rng.of.erase(out);
+        const void* ok = out_key ? out_key : out;
+        const float* have = out_key ? range_of(out_key) : nullptr;       // the other chain registered the tensor's slot already
+        a.out_absmax = have ? const_cast<float*>(have) : range_take();
+        if (a.out_absmax) g_ctx->rng.of[ok] = a.out_absmax; else g_ctx->rng.of.erase(ok);
     }
     return launch_conv(a, pick_tile(a.M, coutP, nk * BK, a.in_absmax && a.w_absmax), s);
 }
@@ -1747,71 +1752,112 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     range_pass_begin(tr, s, false);
     const dgp_net_desc& d = net->desc;
     const int B = nt;
-    TRY_HIP(launch_preprocess(frames, (long long)B * d.in_h * d.in_w, d.mean_pixel[0], d.mean_pixel[1], d.mean_pixel[2], F(pl.p0), s));
-    const ConvLayer& c1 = net->layers[net->conv1];
-    TRY_HIP(conv_launch(c1, c1.d_w, c1.nk, c1.CoutP, F(pl.p0), B, d.in_h, d.in_w, 4, 3, 3, net->h1, net->w1, 64, 2, 0,
-                        c1.d_scale, c1.d_bias, nullptr, 0, 0, 0, nullptr, true, 0, 0, F(pl.c1), s));
-    static const bool pool_idx = !(getenv("DGP_POOL_IDX") && atoi(getenv("DGP_POOL_IDX")) == 0);       // A/B switch (0: re-scan in backward)
-    if (pool_idx) {
-        int pth = (net->hp - 1) * 2 + 3 - net->h1; if (pth < 0) pth = 0;
-        int ptw = (net->wp - 1) * 2 + 3 - net->w1; if (ptw < 0) ptw = 0;
-        const long long totp = (long long)B * net->hp * net->wp * 16;
-        hipLaunchKernelGGL(maxpool_fwd_idx_kernel, dim3(grid_for(totp)), dim3(256), 0, s, F(pl.c1), B, net->h1, net->w1, 16, net->hp,
-                           net->wp, pth / 2, ptw / 2, F(pl.pool), reinterpret_cast<uchar4*>(ws + pl.pidx));
-    } else {
-        TRY_HIP(launch_maxpool(F(pl.c1), B, net->h1, net->w1, 64, F(pl.pool), s));
-    }
-    if (const float* r = range_of(F(pl.c1))) g_ctx->rng.of[F(pl.pool)] = r; else g_ctx->rng.of.erase(F(pl.pool));      // max-pooling cannot raise the maximum
-    int h = net->hp, w = net->wp;
-    const float* xin = F(pl.pool);
+    // The forward pass as TWO chains of frames (DGP_FWD_CHAINS=1: one): frames [0, n1) on the caller's stream, [n1, B) on the trainer's
+    // second stream.  At 11 frames the grids of block3 / block4 cover half of the chip, and two independent chains drift apart so that
+    // one chain's small or tail-heavy layers run under the other's.  Both chains write frame ranges of the SAME activation tensors
+    // (the backward pass sees one batch) and max into the same range slots.
     static const bool side_env = !(getenv("DGP_WGRAD_OVERLAP") && atoi(getenv("DGP_WGRAD_OVERLAP")) == 0);
+    static const int chains_env = getenv("DGP_FWD_CHAINS") ? atoi(getenv("DGP_FWD_CHAINS")) : 2;
     if (side_env && !g_ctx->s2) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         TRY_HIP(hipStreamCreateWithPriority(&g_ctx->s2, hipStreamNonBlocking, lo));
     }
-    const bool side = side_env && g_ctx->s2;
     g_ctx->ev_next = 0;                          // (the previous backward pass has joined: its events are free again)
-    for (size_t ui = 0; ui < net->units.size(); ++ui) {
+    const bool two = side_env && g_ctx->s2 && chains_env >= 2 && B >= 4;
+    const int n1 = two ? (B + 1) / 2 : B;
+    const ConvLayer& c1 = net->layers[net->conv1];
+    static const bool pool_idx = !(getenv("DGP_POOL_IDX") && atoi(getenv("DGP_POOL_IDX")) == 0);       // A/B switch (0: re-scan in backward)
+    if (two) {
+        hipEvent_t ready = g_ctx->take_event();
+        if (!ready) return fail(DGP_ERR_HIP, "forward chains: hipEventCreate failed");
+        TRY_HIP(hipEventRecord(ready, s));       // frames, weights and the zeroed range slots are in place
+        TRY_HIP(hipStreamWaitEvent(g_ctx->s2, ready, 0));
+    }
+    int h = net->hp, w = net->wp;
+    const float* xin = F(pl.pool);
+    // host enqueue order: stage by stage, chain 0 then chain 1 (a chain enqueued whole before the other would start a millisecond late)
+    struct Chain { int n0, nB; hipStream_t cs; bool second; int hh, ww; size_t x_off; int x_c; };
+    Chain chains[2] = {{0, n1, s, false, net->hp, net->wp, pl.pool, 64}, {n1, B - n1, g_ctx->s2, true, net->hp, net->wp, pl.pool, 64}};
+    const int nchains = two ? 2 : 1;
+    float* const slab_keep = g_ctx->tail_slab;
+    struct Restore { float*& ref; float* v; ~Restore() { ref = v; } } restore{g_ctx->tail_slab, slab_keep};
+    auto root = [&](Chain& c) -> int {
+        g_ctx->tail_slab = c.second ? nullptr : slab_keep;      // the K-split slab belongs to the first chain's launches
+        const int n0 = c.n0, nB = c.nB;
+        hipStream_t cs = c.cs;
+        auto at = [&](size_t off, size_t per_frame) { return F(off) + (size_t)n0 * per_frame; };
+        const size_t px_in = (size_t)d.in_h * d.in_w, px1 = (size_t)net->h1 * net->w1, pxp = (size_t)net->hp * net->wp;
+        TRY_HIP(launch_preprocess(frames + (size_t)n0 * px_in * 3, (long long)nB * d.in_h * d.in_w, d.mean_pixel[0], d.mean_pixel[1],
+                                  d.mean_pixel[2], at(pl.p0, px_in * 4), cs));
+        TRY_HIP(conv_launch(c1, c1.d_w, c1.nk, c1.CoutP, at(pl.p0, px_in * 4), nB, d.in_h, d.in_w, 4, 3, 3, net->h1, net->w1, 64, 2, 0,
+                            c1.d_scale, c1.d_bias, nullptr, 0, 0, 0, nullptr, true, 0, 0, at(pl.c1, px1 * 64), cs, F(pl.p0), F(pl.c1)));
+        if (pool_idx) {
+            int pth = (net->hp - 1) * 2 + 3 - net->h1; if (pth < 0) pth = 0;
+            int ptw = (net->wp - 1) * 2 + 3 - net->w1; if (ptw < 0) ptw = 0;
+            const long long totp = (long long)nB * net->hp * net->wp * 16;
+            hipLaunchKernelGGL(maxpool_fwd_idx_kernel, dim3(grid_for(totp)), dim3(256), 0, cs, at(pl.c1, px1 * 64), nB, net->h1, net->w1, 16,
+                               net->hp, net->wp, pth / 2, ptw / 2, at(pl.pool, pxp * 64),
+                               reinterpret_cast<uchar4*>(ws + pl.pidx) + (size_t)n0 * pxp * 16);
+        } else {
+            TRY_HIP(launch_maxpool(at(pl.c1, px1 * 64), nB, net->h1, net->w1, 64, at(pl.pool, pxp * 64), cs));
+        }
+        if (!c.second) {    // max-pooling cannot raise the maximum
+            if (const float* r = range_of(F(pl.c1))) g_ctx->rng.of[F(pl.pool)] = r; else g_ctx->rng.of.erase(F(pl.pool));
+        }
+        return DGP_OK;
+    };
+    auto unit = [&](Chain& c, size_t ui) -> int {
+        g_ctx->tail_slab = c.second ? nullptr : slab_keep;
+        const int n0 = c.n0, nB = c.nB, hh = c.hh, ww = c.ww;
+        hipStream_t cs = c.cs;
+        auto at = [&](size_t off, size_t per_frame) { return F(off) + (size_t)n0 * per_frame; };
         const Unit& u = net->units[ui];
-        const int ho = (h + u.stride - 1) / u.stride, wo = (w + u.stride - 1) / u.stride;
-        const float* res = xin;
-        int res_s = u.stride, res_H = h, res_W = w;
-        hipEvent_t sc_done = nullptr;
+        const int ho = (hh + u.stride - 1) / u.stride, wo = (ww + u.stride - 1) / u.stride;
+        const size_t pin = (size_t)hh * ww, pout = (size_t)ho * wo;
+        const float* x = at(c.x_off, pin * c.x_c);
+        const float* res = x;
+        int res_s = u.stride, res_H = hh, res_W = ww;
         if (u.sc >= 0) {
-            // the projection shortcut only meets the main branch at conv3's residual add: it runs on the trainer's second stream
-            // beside conv1 / conv2 (no K-split slab for it: the slab belongs to the chain's launches)
             const ConvLayer& l = net->layers[u.sc];
-            hipStream_t ss = s;
-            float* const slab_keep = g_ctx->tail_slab;
-            if (side) {
-                hipEvent_t ready = g_ctx->take_event();
-                sc_done = g_ctx->take_event();
-                if (!ready || !sc_done) return fail(DGP_ERR_HIP, "shortcut stream: hipEventCreate failed");
-                TRY_HIP(hipEventRecord(ready, s));
-                TRY_HIP(hipStreamWaitEvent(g_ctx->s2, ready, 0));
-                ss = g_ctx->s2;
-                g_ctx->tail_slab = nullptr;
-            }
-            hipError_t esc = conv_launch(l, l.d_w, l.nk, l.CoutP, xin, B, h, w, l.Cin, 0, 0, ho, wo, l.Cout, u.stride, 0, l.d_scale,
-                                         l.d_bias, nullptr, 0, 0, 0, nullptr, false, 0, 0, F(pl.sc[ui]), ss);
-            g_ctx->tail_slab = slab_keep;
-            TRY_HIP(esc);
-            if (sc_done) TRY_HIP(hipEventRecord(sc_done, g_ctx->s2));
-            res = F(pl.sc[ui]); res_s = 1; res_H = ho; res_W = wo;
+            TRY_HIP(conv_launch(l, l.d_w, l.nk, l.CoutP, x, nB, hh, ww, l.Cin, 0, 0, ho, wo, l.Cout, u.stride, 0, l.d_scale,
+                                l.d_bias, nullptr, 0, 0, 0, nullptr, false, 0, 0, at(pl.sc[ui], pout * u.depth), cs, F(c.x_off),
+                                F(pl.sc[ui])));
+            res = at(pl.sc[ui], pout * u.depth); res_s = 1; res_H = ho; res_W = wo;
         }
         const ConvLayer& l1 = net->layers[u.c1];
-        TRY_HIP(conv_launch(l1, l1.d_w, l1.nk, l1.CoutP, xin, B, h, w, l1.Cin, 0, 0, h, w, l1.Cout, 1, 0, l1.d_scale,
-                            l1.d_bias, nullptr, 0, 0, 0, nullptr, true, 0, 0, F(pl.r1[ui]), s));
+        TRY_HIP(conv_launch(l1, l1.d_w, l1.nk, l1.CoutP, x, nB, hh, ww, l1.Cin, 0, 0, hh, ww, l1.Cout, 1, 0, l1.d_scale,
+                            l1.d_bias, nullptr, 0, 0, 0, nullptr, true, 0, 0, at(pl.r1[ui], pin * u.depth_bn), cs, F(c.x_off),
+                            F(pl.r1[ui])));
         const ConvLayer& l2 = net->layers[u.c2];
-        const int pb_h = pad_before_for(h, 3, u.stride, u.rate, true), pb_w = pad_before_for(w, 3, u.stride, u.rate, true);
-        TRY_HIP(conv_launch(l2, l2.d_w, l2.nk, l2.CoutP, F(pl.r1[ui]), B, h, w, l2.Cin, pb_h, pb_w, ho, wo, l2.Cout,
-                            u.stride, 0, l2.d_scale, l2.d_bias, nullptr, 0, 0, 0, nullptr, true, 0, 0, F(pl.r2[ui]), s));
+        const int pb_h = pad_before_for(hh, 3, u.stride, u.rate, true), pb_w = pad_before_for(ww, 3, u.stride, u.rate, true);
+        TRY_HIP(conv_launch(l2, l2.d_w, l2.nk, l2.CoutP, at(pl.r1[ui], pin * u.depth_bn), nB, hh, ww, l2.Cin, pb_h, pb_w, ho, wo,
+                            l2.Cout, u.stride, 0, l2.d_scale, l2.d_bias, nullptr, 0, 0, 0, nullptr, true, 0, 0,
+                            at(pl.r2[ui], pout * u.depth_bn), cs, F(pl.r1[ui]), F(pl.r2[ui])));
         const ConvLayer& l3 = net->layers[u.c3];
-        if (sc_done) TRY_HIP(hipStreamWaitEvent(s, sc_done, 0));
-        TRY_HIP(conv_launch(l3, l3.d_w, l3.nk, l3.CoutP, F(pl.r2[ui]), B, ho, wo, l3.Cin, 0, 0, ho, wo, l3.Cout, 1, 0,
-                            l3.d_scale, l3.d_bias, res, res_s, res_H, res_W, nullptr, true, 0, 0, F(pl.xo[ui]), s));
-        xin = F(pl.xo[ui]); h = ho; w = wo;
+        TRY_HIP(conv_launch(l3, l3.d_w, l3.nk, l3.CoutP, at(pl.r2[ui], pout * u.depth_bn), nB, ho, wo, l3.Cin, 0, 0, ho, wo, l3.Cout,
+                            1, 0, l3.d_scale, l3.d_bias, res, res_s, res_H, res_W, nullptr, true, 0, 0,
+                            at(pl.xo[ui], pout * u.depth), cs, F(pl.r2[ui]), F(pl.xo[ui])));
+        c.x_off = pl.xo[ui]; c.x_c = u.depth; c.hh = ho; c.ww = wo;
+        return DGP_OK;
+    };
+    {
+        int rc0;
+        for (int ci = 0; ci < nchains; ++ci) if ((rc0 = root(chains[ci]))) return rc0;
+        for (size_t ui = 0; ui < net->units.size(); ++ui)
+            for (int ci = 0; ci < nchains; ++ci) if ((rc0 = unit(chains[ci], ui))) return rc0;
+        g_ctx->tail_slab = slab_keep;
+        if (two) {
+            hipEvent_t done = g_ctx->take_event();
+            if (!done) return fail(DGP_ERR_HIP, "forward chains: hipEventCreate failed");
+            TRY_HIP(hipEventRecord(done, g_ctx->s2));
+            TRY_HIP(hipStreamWaitEvent(s, done, 0));
+        }
+    }
+    for (size_t ui = 0; ui < net->units.size(); ++ui) {
+        const Unit& u = net->units[ui];
+        h = (h + u.stride - 1) / u.stride; w = (w + u.stride - 1) / u.stride;
+        xin = F(pl.xo[ui]);
     }
     // heads: pointwise GEMM on the cell kernels + gather of the four taps (as the inference engine) when the feature map's range
     // and the pointwise cells exist, else the 2x2-conv form on the fp32 kernel
