@@ -81,7 +81,9 @@ class TrainSession:
         for k in need:
             if ph[k] not in feed:
                 raise KeyError("feed_dict lacks placeholder %r" % k)
-        images = np.asarray(feed[ph["inputs"]])
+        images = feed[ph["inputs"]]
+        if not (hasattr(images, "is_cuda") and images.is_cuda):      # (a device tensor: frames the fit drivers uploaded ahead of time)
+            images = np.asarray(images)
         nt = images.shape[0]
         if ph["nt_batch_pl"] in feed and int(feed[ph["nt_batch_pl"]]) != nt:
             raise ValueError("nt_batch_pl = %s but inputs hold %d frames" % (feed[ph["nt_batch_pl"]], nt))
