@@ -1207,6 +1207,12 @@ struct RangeCtx {
     float* pool = nullptr;            // RANGE_POOL slot arrays of ABSMAX_SLOTS floats
     int next = 0, limit = 0;
     std::map<const void*, const float*> of;     // tensor / panel pointer -> its slot array
+    // second forward chain (frames [n1, B)): its own slot arrays, CHAIN2_OFF arrays above the first chain's and taken in the same
+    // order, so that each chain's scales depend on its own frames only (deterministic) and one elementwise max after the join
+    // gives the backward pass the ranges of the whole tensors
+    std::map<const void*, const float*> of2;
+    int next2 = 0;
+    bool chain2 = false;
     bool on = false;
 };
 struct TrainCtx {
@@ -1346,16 +1352,35 @@ static thread_local TrainCtx* g_ctx = nullptr;      // the trainer whose entry p
 // fresh slot array from a pool for max |out| and records it under its output pointer; a later conv whose input pointer (and
 // weight panel) has a recorded range runs the fp16 kernels, anything else (tensors written by other kernels: pooling, loss
 // gradients, head gathers) falls back to the range-free bf16 split.  The pool is zeroed at the start of each pass.
-constexpr int RANGE_POOL = 512;
+constexpr int RANGE_POOL = 768;             // forward chain 1 [0, 256) | forward chain 2 [256, 512) | backward [512, 768)
+constexpr int RANGE_FWD = 256;
+
+__global__ __launch_bounds__(256) void range_merge_kernel(float* __restrict__ a, const float* __restrict__ b, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const float x = a[i], y = b[i]; a[i] = (y > x || y != y) ? y : x; }      // non-negative maxima; a NaN stays
+}
 
 static float* range_take() {
-    if (!g_ctx || !g_ctx->rng.on || !g_ctx->rng.pool || g_ctx->rng.next >= g_ctx->rng.limit) return nullptr;
+    if (!g_ctx || !g_ctx->rng.on || !g_ctx->rng.pool) return nullptr;
+    if (g_ctx->rng.chain2) {
+        if (g_ctx->rng.next2 >= RANGE_FWD) return nullptr;
+        return g_ctx->rng.pool + (size_t)(RANGE_FWD + g_ctx->rng.next2++) * ABSMAX_SLOTS;
+    }
+    if (g_ctx->rng.next >= g_ctx->rng.limit) return nullptr;
     return g_ctx->rng.pool + (size_t)(g_ctx->rng.next++) * ABSMAX_SLOTS;
 }
 static const float* range_of(const void* p) {
     if (!g_ctx || !g_ctx->rng.on) return nullptr;
+    if (g_ctx->rng.chain2) {                     // the chain's own tensors first; weight panels are shared
+        auto it2 = g_ctx->rng.of2.find(p);
+        if (it2 != g_ctx->rng.of2.end()) return it2->second;
+    }
     auto it = g_ctx->rng.of.find(p);
     return it == g_ctx->rng.of.end() ? nullptr : it->second;
+}
+static void range_set(const void* p, const float* slot) {
+    auto& m = g_ctx->rng.chain2 ? g_ctx->rng.of2 : g_ctx->rng.of;
+    if (slot) m[p] = slot; else m.erase(p);
 }
 
 // Start of a forward or a backward pass.  Forward: everything fresh (first half of the pool).  Backward: the forward tensors'
@@ -1365,11 +1390,13 @@ static void range_pass_begin(dgp_trainer* tr, hipStream_t s, bool backward) {
                                 !(getenv("DGP_CONV_MODE") && strcmp(getenv("DGP_CONV_MODE"), "f16x3") != 0);
     g_ctx->rng.on = enabled && tr->d_rng_pool && tr->d_wrng;
     g_ctx->rng.pool = tr->d_rng_pool;
-    const size_t half_bytes = (size_t)(RANGE_POOL / 2) * ABSMAX_SLOTS * sizeof(float);
-    if (!backward) { g_ctx->rng.of.clear(); g_ctx->rng.next = 0; g_ctx->rng.limit = RANGE_POOL / 2; }
-    else { g_ctx->rng.next = RANGE_POOL / 2; g_ctx->rng.limit = RANGE_POOL; }
+    const size_t fwd_bytes = (size_t)(2 * RANGE_FWD) * ABSMAX_SLOTS * sizeof(float);
+    const size_t bwd_bytes = (size_t)(RANGE_POOL - 2 * RANGE_FWD) * ABSMAX_SLOTS * sizeof(float);
+    g_ctx->rng.chain2 = false;
+    if (!backward) { g_ctx->rng.of.clear(); g_ctx->rng.of2.clear(); g_ctx->rng.next = 0; g_ctx->rng.next2 = 0; g_ctx->rng.limit = RANGE_FWD; }
+    else { g_ctx->rng.next = 2 * RANGE_FWD; g_ctx->rng.limit = RANGE_POOL; }
     if (!g_ctx->rng.on) return;
-    (void)hipMemsetAsync(reinterpret_cast<char*>(tr->d_rng_pool) + (backward ? half_bytes : 0), 0, half_bytes, s);
+    (void)hipMemsetAsync(reinterpret_cast<char*>(tr->d_rng_pool) + (backward ? fwd_bytes : 0), 0, backward ? bwd_bytes : fwd_bytes, s);
     if (backward) return;
     const size_t nl = tr->net->layers.size();
     for (size_t li = 0; li < nl; ++li) {
@@ -1391,8 +1418,8 @@ hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, 
                        const float* bias, const float* res, int res_s, int res_H, int res_W, const float* mask,
                        bool relu, int out_mode, int dc_nj, float* out, hipStream_t s, const void* in_key = nullptr,
                        const void* out_key = nullptr) {
-    // in_key / out_key: the tensors whose range slots this launch reads / feeds when `in` / `out` are frame ranges inside them
-    // (the forward pass as two sub-batch chains: both chains max into the slot of the whole tensor)
+    // in_key / out_key: the tensors under whose names this launch looks up / registers range slots when `in` / `out` are frame ranges
+    // inside them (the forward pass as two chains of frames; each chain keeps its own slots, merged after the join)
     ConvArgs a{};
     a.in = in; a.wpk = wpk; a.scale = scale; a.bias = bias; a.res = res; a.mask = mask; a.out = out;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.log2cin4 = ilog2(Cin / 4);
@@ -1417,10 +1444,8 @@ hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, 
         if (g_train_cells && c != g_ctx->cells.end()) { a.wh3 = c->second; a.wh3_bytes = a.w_bytes; }
     }
     if (out_mode == 0) {
-        const void* ok = out_key ? out_key : out;
-        const float* have = out_key ? range_of(out_key) : nullptr;       // the other chain registered the tensor's slot already
-        a.out_absmax = have ? const_cast<float*>(have) : range_take();
-        if (a.out_absmax) g_ctx->rng.of[ok] = a.out_absmax; else g_ctx->rng.of.erase(ok);
+        a.out_absmax = range_take();
+        range_set(out_key ? out_key : out, a.out_absmax);
     }
     return launch_conv(a, pick_tile(a.M, coutP, nk * BK, a.in_absmax && a.w_absmax), s);
 }
@@ -1784,6 +1809,7 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     struct Restore { float*& ref; float* v; ~Restore() { ref = v; } } restore{g_ctx->tail_slab, slab_keep};
     auto root = [&](Chain& c) -> int {
         g_ctx->tail_slab = c.second ? nullptr : slab_keep;      // the K-split slab belongs to the first chain's launches
+        g_ctx->rng.chain2 = c.second;
         const int n0 = c.n0, nB = c.nB;
         hipStream_t cs = c.cs;
         auto at = [&](size_t off, size_t per_frame) { return F(off) + (size_t)n0 * per_frame; };
@@ -1802,13 +1828,12 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
         } else {
             TRY_HIP(launch_maxpool(at(pl.c1, px1 * 64), nB, net->h1, net->w1, 64, at(pl.pool, pxp * 64), cs));
         }
-        if (!c.second) {    // max-pooling cannot raise the maximum
-            if (const float* r = range_of(F(pl.c1))) g_ctx->rng.of[F(pl.pool)] = r; else g_ctx->rng.of.erase(F(pl.pool));
-        }
+        range_set(F(pl.pool), range_of(F(pl.c1)));      // max-pooling cannot raise the maximum
         return DGP_OK;
     };
     auto unit = [&](Chain& c, size_t ui) -> int {
         g_ctx->tail_slab = c.second ? nullptr : slab_keep;
+        g_ctx->rng.chain2 = c.second;
         const int n0 = c.n0, nB = c.nB, hh = c.hh, ww = c.ww;
         hipStream_t cs = c.cs;
         auto at = [&](size_t off, size_t per_frame) { return F(off) + (size_t)n0 * per_frame; };
@@ -1847,11 +1872,18 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
         for (size_t ui = 0; ui < net->units.size(); ++ui)
             for (int ci = 0; ci < nchains; ++ci) if ((rc0 = unit(chains[ci], ui))) return rc0;
         g_ctx->tail_slab = slab_keep;
+        g_ctx->rng.chain2 = false;
         if (two) {
             hipEvent_t done = g_ctx->take_event();
             if (!done) return fail(DGP_ERR_HIP, "forward chains: hipEventCreate failed");
             TRY_HIP(hipEventRecord(done, g_ctx->s2));
             TRY_HIP(hipStreamWaitEvent(s, done, 0));
+            if (g_ctx->rng.on && g_ctx->rng.next2 > 0) {      // ranges of the whole tensors = max of the chains' (same slot order)
+                if (g_ctx->rng.next2 != g_ctx->rng.next) return fail(DGP_ERR_STATE, "forward chains took different numbers of range slots");
+                const int nfl = g_ctx->rng.next2 * ABSMAX_SLOTS;
+                hipLaunchKernelGGL(range_merge_kernel, dim3((nfl + 255) / 256), dim3(256), 0, s, g_ctx->rng.pool,
+                                   g_ctx->rng.pool + (size_t)RANGE_FWD * ABSMAX_SLOTS, nfl);
+            }
         }
     }
     for (size_t ui = 0; ui < net->units.size(); ++ui) {
