@@ -144,8 +144,19 @@ class Trainer:
         # uploaded (0.4 ms of host work); then the loss kernels and the whole backward pass are enqueued back to back, and the losses
         # are read back (the one synchronisation) after everything is in flight
         wsb, pred, loc = self._forward(frames)          # checks dtype / shape against the net's current input size
-        li = dgp_loss_prepare(nt, self.net.out_h, self.net.out_w, nj, batch, hyper, S0, ws, ws_max, n_frames_total,
-                              n_visible_frames_total, self.device)
+        main = torch.cuda.current_stream(self.device)
+        if getattr(self, "_upload_stream", None) is None:
+            self._upload_stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._upload_stream):    # the uploads run beside the forward instead of queueing behind it
+            li = dgp_loss_prepare(nt, self.net.out_h, self.net.out_w, nj, batch, hyper, S0, ws, ws_max, n_frames_total,
+                                  n_visible_frames_total, self.device)
+            uploaded = torch.cuda.Event()
+            uploaded.record(self._upload_stream)
+        main.wait_event(uploaded)
+        for name in li.__slots__:
+            t = getattr(li, name, None)
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(main)
         losses, dpred, dloc, mu = dgp_loss_launch(li, pred, loc)
         _lib.check(self.lib.dgp_train_backward(self._t, nt, _ptr(wsb), wsb.numel(), _ptr(dpred), _ptr(dloc), st),
                    "dgp_train_backward")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline summary of one training step from a rocprofv3 --kernel-trace csv: per stream busy time, union, overlap, idle gaps."""
 import csv, glob, sys, os
-f = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)[0]
+f = sorted(glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1]
 rows = [r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # steps are delimited by momentum_kernel (one per step); take the span between the last two
@@ -26,3 +26,11 @@ print("time with 0 / 1 / >=2 kernels in flight: %.3f / %.3f / %.3f ms" % (t_by[0
 names = lambda v: [n.split("(")[0][-24:] for _, _, n in v]
 for sid, v in by.items():
     print("stream %s last kernels: %s" % (sid, ", ".join(names(v)[-3:])))
+
+# idle gaps (no kernel in flight) longer than 30 us
+ivs = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in step)
+cur_end = ivs[0][1]
+for s_, e_, n_ in ivs[1:]:
+    if s_ - cur_end > 30000:
+        print("idle %.3f ms before %-40s at %.3f ms" % ((s_ - cur_end) / 1e6, n_.replace("(anonymous namespace)::", "").split("(")[0][-40:], (s_ - t0) / 1e6))
+    cur_end = max(cur_end, e_)
