@@ -2046,8 +2046,18 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
             const int njt = l.Cout / 4;
             const long long tot = (long long)B * fh * fw * t.cpad;
             hipLaunchKernelGGL(head_gather_kernel, dim3(grid_for(tot)), dim3(256), 0, s, dsrc[k], B, fh, fw, njt, t.cpad, dph[k]);
-            TRY_HIP(wgrad_launch(feat, B, fh, fw, l.Cin, dph[k], fh, fw, t.cpad, 2, 2, 1, 1, 1, 1, dwraw, colsum, s));
-            hipLaunchKernelGGL(finalize_head_grads, dim3(grid_for(9ll * njt * l.Cin)), dim3(256), 0, s, dwraw, colsum, njt,
+            // the head's parameter gradients (fill + wgrad + finalise through the shared dwraw / colsum scratch, in stream order) go to the
+            // second stream when the pass overlaps: the chain only needs dph[k] for the data gradient below
+            hipStream_t hs_ = s;
+            if (ctx->overlap) {
+                hipEvent_t ready = ctx->take_event();
+                if (!ready) return fail(DGP_ERR_HIP, "weight-gradient stream: hipEventCreate failed");
+                TRY_HIP(hipEventRecord(ready, s));
+                TRY_HIP(hipStreamWaitEvent(ctx->s2, ready, 0));
+                hs_ = ctx->s2;
+            }
+            TRY_HIP(wgrad_launch(feat, B, fh, fw, l.Cin, dph[k], fh, fw, t.cpad, 2, 2, 1, 1, 1, 1, dwraw, colsum, hs_));
+            hipLaunchKernelGGL(finalize_head_grads, dim3(grid_for(9ll * njt * l.Cin)), dim3(256), 0, hs_, dwraw, colsum, njt,
                                l.Cin, t.cpad, tr->grads + t.w_off, tr->grads + t.b_off);
             // dfeat (+)= convT: 2x2 taps flipped, pad' = 0; second head accumulates onto the first; gate on the last
             ConvLayer lt = l;
