@@ -133,3 +133,44 @@ def test_deconv_phase_weights_reproduce_the_transposed_conv():
     y = torch.nn.functional.conv2d(xp, torch.from_numpy(wp).permute(3, 2, 0, 1)).permute(0, 2, 3, 1)
     y = y.reshape(2, 5, 6, 2, 2, 3).permute(0, 1, 3, 2, 4, 5).reshape(2, 10, 12, 3).numpy() + b
     assert np.abs(y - ref).max() < 1e-5
+
+
+def test_prefetched_keeps_order_propagates_errors_and_stops(monkeypatch):
+    """fitdgp._prefetched: items come in order from ONE producer thread (so every random draw happens in schedule order, with or
+    without prefetching), a producer exception surfaces in the consumer at the right item, and abandoning the generator stops the
+    producer."""
+    import threading
+    import time
+    from deepgraphpose_amd.models.fitdgp import _prefetched
+    rng = np.random.RandomState(5)
+    made = []
+
+    def make(i):
+        made.append((i, threading.get_ident()))
+        return i, float(rng.random_sample())
+    got = list(_prefetched(make, 20, depth=3))
+    ref_rng = np.random.RandomState(5)
+    assert got == [(i, float(ref_rng.random_sample())) for i in range(20)]
+    assert len({t for _, t in made}) == 1 and made[0][1] != threading.get_ident()
+    assert list(_prefetched(lambda i: i * i, 5, depth=0)) == [0, 1, 4, 9, 16]          # inline mode
+
+    def boom(i):
+        if i == 3:
+            raise ValueError("bad frame %d" % i)
+        return i
+    out = []
+    with pytest.raises(ValueError, match="bad frame 3"):
+        for v in _prefetched(boom, 10, depth=2):
+            out.append(v)
+    assert out == [0, 1, 2]
+    count = [0]
+
+    def slow(i):
+        count[0] += 1
+        time.sleep(0.01)
+        return i
+    gen = _prefetched(slow, 1000, depth=2)
+    assert next(gen) == 0
+    gen.close()                                   # consumer walks away: the producer must stop, not build 1000 items
+    time.sleep(0.2)
+    assert count[0] < 20
