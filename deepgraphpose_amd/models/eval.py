@@ -483,7 +483,7 @@ def evaluate_dgp(proj_cfg_file, dgp_model_file, shuffle=1, loc_ref=None, loc_ref
             pose = soft_argmax_locref_pose(lr[0], st[0], dlc_cfg.stride, dlc_cfg.locref_stdev)
         elif loc_ref:
             net = sess.net_for(image.shape[0], image.shape[1])
-            fr = torch.from_numpy(np.ascontiguousarray(image[None])).cuda(sess.device)
+            fr = torch.from_numpy(np.require(image[None], requirements=["C", "W"])).cuda(sess.device)
             scm, loc = net.forward(fr, want_locref=True)
             idx, prob, offs = engine.hard_argmax(scm, loc)
             pose = pose_from_argmax(idx[0].cpu().numpy(), prob[0].cpu().numpy(), offs[0].cpu().numpy(), dlc_cfg.stride,
