@@ -372,3 +372,55 @@ def test_pipeline_two_engines_equal_single_engine(lib_built):
     m1, c1, i1 = [t.cpu().numpy() for t in __import__("deepgraphpose_amd.dist", fromlist=["x"]).unpack_keypoints(got2)]
     m0, c0, i0 = [t.cpu().numpy() for t in __import__("deepgraphpose_amd.dist", fromlist=["x"]).unpack_keypoints(ref)]
     assert np.array_equal(i1, i0) and np.abs(m1 - m0).max() * 8.0 < PX_TOL
+
+
+def test_pipeline_overflow_widens_every_engine(lib_built):
+    """DGPPipeline.range_status: scales calibrated on a near-empty batch overflow on real frames on whichever engine gets them; the
+    status call reports it, gives EVERY engine the wider headroom, and the next submit re-calibrates all of them on its batch -- after
+    which both engines again produce the single-engine bits."""
+    from deepgraphpose_amd.engine import DGPNet, DGPPipeline
+    from deepgraphpose_amd.synthetic import make_frames, make_weights
+    nj, B = 3, 4
+    wts = make_weights(50, nj, False, seed=31, head_std=0.05)
+    flat = np.zeros((B, 64, 96, 3), dtype=np.uint8)
+    flat[..., 0], flat[..., 1], flat[..., 2] = 124, 117, 104
+    real = torch.from_numpy(make_frames(3 * B, 64, 96, nj, seed=32)).cuda()
+    pipe = DGPPipeline(50, nj, 64, 96, max_batch=B, n_streams=2)
+    pipe.load_weights(wts)
+    out = torch.zeros((3 * B, nj, 5), device="cuda")
+    pipe.submit(torch.from_numpy(flat).cuda(), out[:B])            # calibrates both engines on ~zero activations
+    pipe.join(); torch.cuda.synchronize()
+    assert pipe.range_status() == (False, 1)
+    pipe.submit(real[:B].contiguous(), out[:B])                    # engine 1 overflows
+    pipe.join(); torch.cuda.synchronize()
+    ov, _ = pipe.range_status()
+    assert ov and not pipe._calibrated
+    for s in range(0, 3 * B, B):                                   # re-run: the first submit re-calibrates BOTH engines on its batch
+        pipe.submit(real[s:s + B].contiguous(), out[s:s + B])
+    pipe.join(); torch.cuda.synchronize()
+    assert pipe.range_status()[0] is False and [n.range_status()[1] for n in pipe.nets] == [2, 2]
+    one = DGPNet(50, nj, 64, 96, max_batch=B)
+    one.load_weights(wts)
+    one.widen()                                                    # same headroom as the widened engines, calibrated on the same batch
+    ref = torch.zeros_like(out)
+    for s in range(0, 3 * B, B):
+        one.infer_packed(real[s:s + B].contiguous(), ref[s:s + B])
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+
+
+def test_frame_uploader_matches_plain_upload(lib_built):
+    """fitdgp._FrameUploader (pinned staging + own stream, used from the fit drivers' prefetch thread): the device frames equal a plain
+    upload, float images are rounded like _frames_to_device does, buffers are reused across calls of different sizes."""
+    from deepgraphpose_amd.models.fitdgp import _FrameUploader
+    up = _FrameUploader(0, slots=2)
+    rng = np.random.RandomState(0)
+    for shape in [(3, 64, 96, 3), (5, 64, 96, 3), (2, 32, 48, 3), (5, 64, 96, 3)]:
+        img = rng.randint(0, 256, shape).astype(np.uint8)
+        dev = up(img)
+        torch.cuda.current_stream().wait_event(dev._dgp_ready)
+        assert dev.dtype == torch.uint8 and tuple(dev.shape) == shape and np.array_equal(dev.cpu().numpy(), img)
+    f = rng.uniform(0, 255, (2, 16, 16, 3))
+    dev = up(f)
+    torch.cuda.current_stream().wait_event(dev._dgp_ready)
+    assert np.array_equal(dev.cpu().numpy(), np.clip(np.rint(f), 0, 255).astype(np.uint8))
