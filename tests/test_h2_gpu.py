@@ -192,3 +192,29 @@ def test_tail_split_fixup_on_h2_tensors_in_a_child_process(lib_built):
                         "test_conv_on_h2_tensors_matches_float64 and (case9 or case5)"], env=env, cwd=root, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
+
+
+def test_extreme_frames_keep_parity(lib_built):
+    """Frames far from the synthetic blobs the other tests use -- all black, all white, uniform noise, one saturated channel -- through
+    the H2 engine (calibration on this very batch): finite outputs, no range overflow, coordinates within 1e-3 px of the oracle and
+    bit-exact window indices."""
+    from deepgraphpose_amd.engine import DGPNet
+    from deepgraphpose_amd.synthetic import make_weights
+    from oracle import dgp_oracle as O
+    nj = 3
+    wts = make_weights(50, nj, False, seed=41, head_std=0.05)
+    rng = np.random.RandomState(3)
+    fr = np.zeros((5, 64, 96, 3), dtype=np.uint8)
+    fr[1] = 255
+    fr[2] = rng.randint(0, 256, (64, 96, 3))
+    fr[3, ..., 0] = 255
+    fr[4, 20:40, 30:60] = rng.randint(0, 256, (20, 30, 3))
+    net = DGPNet(50, nj, 64, 96, max_batch=8)
+    net.load_weights(wts)
+    mu, conf, idx = [t.cpu().numpy() for t in net.infer(torch.from_numpy(fr).cuda())]
+    assert net.range_status()[0] is False
+    assert np.isfinite(mu).all() and np.isfinite(conf).all()
+    ref = O.infer(fr, wts, 50)
+    assert np.abs(mu - ref["mu"]).max() * 8.0 < 1e-3, np.abs(mu - ref["mu"]).max() * 8.0
+    assert np.array_equal(idx, ref["idx"])
+    assert np.abs(conf - ref["likelihoods"]).max() < 1e-4
