@@ -48,9 +48,20 @@ STRIDE = 8.0
 
 
 def _read_sclk_mhz(card_index: int = 0):
-    """Current shader clock from sysfs (the line marked '*' in pp_dpm_sclk), or None when unreadable."""
+    """Current shader clock of THIS process's GPU from sysfs (the line marked '*' in pp_dpm_sclk of the card whose PCI address matches
+    torch's device `card_index`; a box exposes every card of the node in sysfs), or None when unreadable."""
     import glob
-    for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+    want = None
+    try:
+        pr = torch.cuda.get_device_properties(card_index)
+        want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        pass
+    paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+    if want is not None:
+        matched = [q for q in paths if want in os.path.realpath(os.path.dirname(q)).lower()]
+        paths = matched or paths
+    for path in paths:
         try:
             for line in open(path).read().splitlines():
                 if line.strip().endswith("*"):
