@@ -302,6 +302,14 @@ def main():
             for i, (n, fl, ms) in enumerate(launches):
                 f.write("%d\t%s\t%.3f\t%.4f\t%.2f\n" % (i, n, fl / 1e9, ms, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0))
 
+    if sustained and sustained.get("sclk_mhz_under_load"):
+        # informative only: the chip is power-limited under this load, so the matrix pipe never sees its 2400 MHz rating
+        mhz = float(sustained["sclk_mhz_under_load"])
+        if 500.0 <= mhz <= 2400.0:
+            roofline["peak_at_sustained_clock"] = round(roofline["peak"] * mhz / 2400.0, 1)
+            roofline["frac_at_sustained_clock"] = round(roofline["achieved"] / (roofline["peak"] * mhz / 2400.0), 4)
+            roofline["sustained_clock_note"] = ("sclk %d MHz read from sysfs during the sustained segment (rated 2400): `frac` stays "
+                                                "against the rated peak" % int(mhz))
     out = {
         "metric": "frames_per_sec", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
         "steps": K, "warmup": Wm, "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True,
