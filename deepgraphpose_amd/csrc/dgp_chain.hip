@@ -1,0 +1,637 @@
+// gfx950 (MI355X / CDNA4): the bottleneck "chain" kernel of the H2 inference engine.
+//
+// One launch computes, for a tile of output pixels, the END of bottleneck unit k and the BEGINNING of unit k + 1
+// (PET/nnet/pose_net.py:46-52 -> slim resnet_v1 `bottleneck`; conv3 has no activation, the ReLU follows the add):
+//
+//     X'  = relu( bn3(R2 . W3) + shortcut )        shortcut = X (identity), X[::2, ::2] (subsample), or (X . Wsc) K-concatenated
+//     R1' = relu( bn1'(X' . W1') )                 conv1 of the next unit (1x1, stride 1)
+//
+// X' is written to HBM once (the next unit's shortcut needs it) and is consumed by conv1 of the next unit STRAIGHT FROM THE
+// ACCUMULATOR REGISTERS: the 4C-wide tensor is read from HBM once per unit (as the residual) instead of twice, and conv1 costs no
+// launch of its own.  Layer by layer the stride-1 units of block1 moved 78.7 MB per frame, of which 19.7 MB is this second read.
+//
+// Why no LDS tile is needed between the two GEMMs.  v_mfma_f32_16x16x32_f16 computes D = A B with A[i = lane & 15][k-group lane >> 4],
+// B[k-group lane >> 4][j = lane & 15] and D[i = 4 (lane >> 4) + r][j = lane & 15].  With the WEIGHTS as the A operand and the PIXELS
+// as the B operand (the transposed product), a lane ends up with 4 consecutive output channels of ONE pixel per 16-channel block.
+// The weight columns are permuted at pack time so that blocks (2q, 2q + 1) hold channels 32 q + 8 g + 4 b + r (g = lane >> 4,
+// b = block parity): two blocks give the lane 8 consecutive channels of pixel lane & 15 -- exactly one H2 cell (hi 16 B | lo 16 B,
+// written with two 16-byte stores) AND exactly the B-operand fragment (pixel lane & 15, k-group g) of the next GEMM's K-step q.
+// So the epilogue of conv3 (BN affine, residual, ReLU, range tracking, fp16 high / low split) produces the operand of conv1 in place.
+// Pointwise convs have no halo: a wave owns its 16 or 32 pixel rows through both GEMMs and never exchanges activations.
+//
+// What goes through LDS: only the weights.  Per 32 output channels `jp` of conv3 a chunk holds conv3's fragments for those columns
+// (all K-steps), conv1's fragments for those 32 K rows (all columns) and the BN affine of those channels, in FRAGMENT ORDER (1 KiB =
+// 64 lanes x 16 B per MFMA operand, so LDS-DMA copies linearly and ds_read_b128 is conflict-free).  Loader waves stream the chunks
+// through a ring of NS slots (L2-resident after the first tile), one s_barrier per chunk; workgroups are persistent over tiles and
+// the chunk sequence simply wraps around.
+//
+// Arithmetic is the engine's: fp16 high / low operand pairs, three MFMAs per product (h h + h l + l h), fp32 accumulation, the same
+// epilogue formula as ls_epilogue_h2 -- so outputs agree with the layer-by-layer path to accumulation-order rounding.
+#include "dgp_internal.h"
+#include "dgp_device.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+namespace dgp {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ floatx4 mma16(const uint4& a, const uint4& b, floatx4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ uint4 ld16(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    // voffset carries the per-lane offset (OOB for rows past M: the hardware range check zero-fills / drops), soffset the
+    // wave-uniform part -- the SGPR offset takes no part in the range check, so OOB stays OOB whatever is added here
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ void st16(__amdgpu_buffer_rsrc_t r, const uint4& v, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, soff, 0);
+}
+
+// conv3 (+ shortcut, ReLU) -> X' -> conv1 -> R1' for the RB row blocks of one wave, one weight chunk per 32 channels of X'
+// (the ring protocol is the caller's: `slot` is the chunk to read first, one barrier per chunk).  ph / pl: the B-operand fragments
+// (pixel lane & 15, k-group lane >> 4) of conv3's K-steps -- R2 first, then the K-concatenated source.
+template <int C, int C1, int CIN2, int RES, int RB, int NS, int PD, int CHUNK>
+__device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring, int& slot, const uint4 (&ph)[RB][(C + CIN2) / 32],
+                                           const uint4 (&pl)[RB][(C + CIN2) / 32], const unsigned (&xoff)[RB], const unsigned (&roff)[RB],
+                                           const unsigned (&r1off)[RB], const __amdgpu_buffer_rsrc_t rs_s2, const __amdgpu_buffer_rsrc_t rs_xo,
+                                           const __amdgpu_buffer_rsrc_t rs_r1, float& amax_x, float& amax_r1, const int lane) {
+    constexpr int C4 = 4 * C, KS1 = (C + CIN2) / 32, NJP = C4 / 32, NCB = C1 / 16;
+    constexpr int F1 = KS1 * 4, F2 = NCB * 2;
+    static_assert(NJP % PD == 0 && PD >= 2, "chunk loop is unrolled PD times");
+    const int g = lane >> 4;
+    floatx4 a2[RB][NCB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) a2[rb][cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    uint4 res[PD][RB][2];
+    auto fetch_res = [&](int jp, int buf) {
+        if constexpr (RES != 0) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                res[buf][rb][0] = ld16(rs_s2, roff[rb], jp * 128);
+                res[buf][rb][1] = ld16(rs_s2, roff[rb], jp * 128 + 16);
+            }
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < PD - 1; ++u) fetch_res(u, u);
+    for (int jp0 = 0; jp0 < NJP; jp0 += PD) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            const int jp = jp0 + u;
+            if (jp + PD - 1 < NJP) fetch_res(jp + PD - 1, (u + PD - 1) % PD);
+            const uint4* Wc = ring + slot * (CHUNK / 16);          // the chunk; W: this lane's 16 bytes of fragment 0
+            const uint4* W = Wc + lane;
+            // ---- conv3 for channels [32 jp, 32 jp + 32): two 16-channel blocks, transposed product (weights = A operand)
+            floatx4 a1[RB][2];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) { a1[rb][0] = floatx4{0.f, 0.f, 0.f, 0.f}; a1[rb][1] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int s = 0; s < KS1; ++s)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const uint4 wh = W[((s * 2 + b) * 2 + 0) * 64], wl = W[((s * 2 + b) * 2 + 1) * 64];
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) a1[rb][b] = mma16(wl, ph[rb][s], a1[rb][b]);
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) a1[rb][b] = mma16(wh, pl[rb][s], a1[rb][b]);
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) a1[rb][b] = mma16(wh, ph[rb][s], a1[rb][b]);
+                }
+            // ---- epilogue of conv3 = operand of conv1: BN affine (x the power of two that undoes the operand scales), shortcut,
+            // ReLU, range, split
+            const float4 sa = __builtin_bit_cast(float4, Wc[(F1 + F2) * 64 + 2 * g]), sb = __builtin_bit_cast(float4, Wc[(F1 + F2) * 64 + 2 * g + 1]);
+            const float4 ba = __builtin_bit_cast(float4, Wc[(F1 + F2) * 64 + 8 + 2 * g]), bb = __builtin_bit_cast(float4, Wc[(F1 + F2) * 64 + 8 + 2 * g + 1]);
+            const float sc[8] = {sa.x * p.post1, sa.y * p.post1, sa.z * p.post1, sa.w * p.post1,
+                                 sb.x * p.post1, sb.y * p.post1, sb.z * p.post1, sb.w * p.post1};
+            const float bi[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+            uint4 xh[RB], xl[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                float o[8], r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if constexpr (RES != 0) h2_unpack8(res[u][rb][0], res[u][rb][1], p.res_inv_scale, r);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    o[k] = a1[rb][k >> 2][k & 3] * sc[k] + bi[k] + r[k];
+                    o[k] = fmaxf(o[k], 0.f);
+                }
+                h2_pack8(o, p.xout_scale, xh[rb], xl[rb]);
+                st16(rs_xo, xh[rb], xoff[rb], jp * 128);
+                st16(rs_xo, xl[rb], xoff[rb], jp * 128 + 16);
+                if (xoff[rb] != OOB) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) amax_x = fmaxf(amax_x, o[k]);
+                }
+            }
+            // ---- conv1 of the next unit: K-step jp, all C1 columns
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const uint4 wh = W[(F1 + cb * 2 + 0) * 64], wl = W[(F1 + cb * 2 + 1) * 64];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) a2[rb][cb] = mma16(wl, xh[rb], a2[rb][cb]);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) a2[rb][cb] = mma16(wh, xl[rb], a2[rb][cb]);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) a2[rb][cb] = mma16(wh, xh[rb], a2[rb][cb]);
+            }
+            slot = slot + 1 == NS ? 0 : slot + 1;
+            // (not __syncthreads(): its fences would drain the residual prefetch and the stores; the ring only needs this
+            // wave's LDS reads of the slot to have completed)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                          // B(it): this slot may be refilled
+        }
+    }
+    // ---- epilogue of conv1: BN affine, ReLU, range, split, store R1' (block pair q = 32 channels, 8 per lane)
+#pragma unroll
+    for (int q = 0; q < NCB / 2; ++q) {
+        const float4 s0 = *reinterpret_cast<const float4*>(p.sc1 + 32 * q + 8 * g), s1 = *reinterpret_cast<const float4*>(p.sc1 + 32 * q + 8 * g + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bi1 + 32 * q + 8 * g), b1 = *reinterpret_cast<const float4*>(p.bi1 + 32 * q + 8 * g + 4);
+        const float sc[8] = {s0.x * p.post2, s0.y * p.post2, s0.z * p.post2, s0.w * p.post2,
+                             s1.x * p.post2, s1.y * p.post2, s1.z * p.post2, s1.w * p.post2};
+        const float bi[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = fmaxf(a2[rb][2 * q + (k >> 2)][k & 3] * sc[k] + bi[k], 0.f);
+            uint4 hi, lo;
+            h2_pack8(o, p.r1_scale, hi, lo);
+            st16(rs_r1, hi, r1off[rb], q * 128);
+            st16(rs_r1, lo, r1off[rb], q * 128 + 16);
+            if (r1off[rb] != OOB) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) amax_r1 = fmaxf(amax_r1, o[k]);
+            }
+        }
+    }
+}
+
+// C     channels of R2 (conv3's K), C4 = 4 C channels of X'
+// C1    output channels of the next unit's conv1 (C inside a block, 2 C across a block boundary)
+// CIN2  channels of the K-concatenated shortcut source (0: none)
+// RES   0 none (CIN2 > 0), 1 residual on the same pixel grid, 2 residual[n, 2 ho, 2 wo] (subsample of a stride-2 unit)
+// RB    16-row blocks per wave (1 or 2); NCW compute waves, NLW loader waves, NS ring slots, PD residual buffers (PD - 1 chunks ahead)
+template <int C, int C1, int CIN2, int RES, int RB, int NCW, int NLW, int NS, int PD>
+__global__ __launch_bounds__(64 * (NCW + NLW)) void chain_kernel(const ChainArgs p) {
+    constexpr int C4 = 4 * C;
+    constexpr int KSA = C / 32, KSB = CIN2 / 32, KS1 = KSA + KSB;      // K-steps of conv3: R2, then the second source
+    constexpr int NJP = C4 / 32;                                       // chunks per tile
+    constexpr int NCB = C1 / 16;                                       // 16-channel blocks of conv1's output
+    constexpr int F1 = KS1 * 4, F2 = NCB * 2, NF = F1 + F2 + 1;        // 1-KiB fragments per chunk: conv3 [s][b][plane], conv1 [cb][plane], affine
+    constexpr int CHUNK = NF * 1024;
+    constexpr int TILE = 16 * RB * NCW;
+    static_assert(NJP % PD == 0 && PD >= 2, "chunk loop is unrolled PD times");
+    static_assert(RES == 0 || CIN2 == 0, "residual or K-concatenated shortcut, not both");
+    static_assert(NS == 3, "ring protocol below: chunk it + 2 is issued after barrier it - 1");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int my_tiles = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * NJP;                                  // chunks this workgroup consumes
+
+    if (wave >= NCW) {
+        // ================================ loader waves: weight chunks -> LDS ring ================================
+        const int lw = wave - NCW;
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wfrag), 0, (int)p.w_bytes, 0x00020000);
+        int jp = 0, slot = 0;
+        // wave lw copies fragments lw, lw + NLW, ...: NIW instructions per chunk (a compile-time count: the waits below are counted)
+        auto run = [&](auto niw) {
+            constexpr int NIW = decltype(niw)::value;
+            auto issue = [&]() {
+                char* dst = smem + slot * CHUNK;
+                const int gbase = jp * CHUNK;
+#pragma unroll
+                for (int i = 0; i < NIW; ++i) {
+                    const int f = lw + i * NLW;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + f * 1024), 16, lane * 16, gbase + f * 1024, 0, 0);
+                }
+                jp = jp + 1 == NJP ? 0 : jp + 1;
+                slot = slot + 1 == NS ? 0 : slot + 1;
+            };
+            if (total > 0) issue();
+            if (total > 1) { issue(); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                              // B(-1): chunk 0 has landed
+            for (int it = 0; it < total; ++it) {
+                if (it + 2 < total) { issue(); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory"); }      // chunk it + 1 has landed
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                          // B(it)
+            }
+        };
+        constexpr int NI_HI = (NF + NLW - 1) / NLW, NI_LO = NF / NLW;
+        if (lw < NF % NLW || NI_HI == NI_LO) run(std::integral_constant<int, NI_HI>());
+        else run(std::integral_constant<int, NI_LO>());
+        return;
+    }
+
+    // ================================== compute waves ==================================
+    const int l15 = lane & 15, g = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rs_r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.r2), 0, (int)p.r2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_s2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src2 ? p.src2 : p.r2), 0,
+                                                                            p.src2 ? (int)p.src2_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_xo = __builtin_amdgcn_make_buffer_rsrc(p.xout, 0, (int)p.xout_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r1 = __builtin_amdgcn_make_buffer_rsrc(p.r1out, 0, (int)p.r1_bytes, 0x00020000);
+    const uint4* ring = reinterpret_cast<const uint4*>(smem);
+    int slot = 0;
+    float amax_x = 0.f, amax_r1 = 0.f;
+    __builtin_amdgcn_s_barrier();                                      // B(-1)
+    for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+        unsigned xoff[RB], roff[RB], r1off[RB];
+        uint4 ph[RB][KS1], pl[RB][KS1];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int m = t * TILE + (wave * RB + rb) * 16 + l15;
+            const bool ok = m < p.M;
+            xoff[rb] = ok ? (unsigned)m * (unsigned)(C4 * 4) + (unsigned)(g * 32) : OOB;
+            r1off[rb] = ok ? (unsigned)m * (unsigned)(C1 * 4) + (unsigned)(g * 32) : OOB;
+            if (RES == 2) {
+                const int n = m / p.HoWo, rem = m - n * p.HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                roff[rb] = ok ? (unsigned)((n * p.res_H + 2 * ho) * p.res_W + 2 * wo) * (unsigned)(C4 * 4) + (unsigned)(g * 32) : OOB;
+            } else roff[rb] = xoff[rb];
+            const unsigned aoff = ok ? (unsigned)m * (unsigned)(C * 4) + (unsigned)(g * 32) : OOB;
+#pragma unroll
+            for (int s = 0; s < KSA; ++s) { ph[rb][s] = ld16(rs_r2, aoff, s * 128); pl[rb][s] = ld16(rs_r2, aoff, s * 128 + 16); }
+            if constexpr (KSB > 0) {
+                const unsigned boff = ok ? (unsigned)m * (unsigned)(CIN2 * 4) + (unsigned)(g * 32) : OOB;
+#pragma unroll
+                for (int s = 0; s < KSB; ++s) { ph[rb][KSA + s] = ld16(rs_s2, boff, s * 128); pl[rb][KSA + s] = ld16(rs_s2, boff, s * 128 + 16); }
+            }
+        }
+        chain_tail<C, C1, CIN2, RES, RB, NS, PD, CHUNK>(p, ring, slot, ph, pl, xoff, roff, r1off, rs_s2, rs_xo, rs_r1, amax_x, amax_r1, lane);
+    }
+    // both tensors are post-ReLU: max = max |.|
+    if (p.xout_absmax) track_absmax(p.xout_absmax, amax_x, lane, (int)(blockIdx.x * 8u + (unsigned)wave));
+    if (p.r1_absmax) track_absmax(p.r1_absmax, amax_r1, lane, (int)(blockIdx.x * 8u + (unsigned)wave) + 97);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Unit kernel (block1, C = 64): conv2 of unit k (3x3, stride 1, SAME) IN FRONT of the chain, so that one launch runs
+//     R1 --conv2 + BN + ReLU--> R2 --conv3 + BN (+ shortcut) + ReLU--> X' --conv1' + BN + ReLU--> R1'
+// with R2 never leaving the registers: conv2's accumulators come out of the transposed product in the same lane layout as conv3's,
+// and two 16-channel blocks are again one B-operand fragment of the next GEMM.  Layer by layer a stride-1 unit of block1 moved
+// 78.7 MB per frame; here it reads R1 (4.9, + halo) and X (19.7) and writes X' (19.7) and R1' (4.9).
+//
+// conv2 needs neighbours: a workgroup owns a TH x 16 pixel tile of ONE frame (wave w = row w, lane & 15 = column) and its
+// (TH + 2) x 18 halo tile of R1 lives in LDS -- filled by the loader wave with LDS-DMA (out-of-image pixels: the hardware range check
+// writes the zeros of SAME padding) while the previous tile runs its pointwise stage, which no longer reads the halo buffer.  Pixel
+// hp of the halo tile is 256 B = 16 slots of 16 B (cell c: slot 2c high, 2c + 1 low) = one row of LDS banks, so slot s is stored
+// at s ^ (hp & 15): the 16 lanes of a ds_read_b128 service group (16 different columns) then touch (nearly) all 16 bank groups.
+// The swizzle is applied on the SOURCE side (the DMA destination is lane-linear): lane L of instruction i fills slot L & 15 of
+// pixel 4 i + (L >> 4) with global slot (L & 15) ^ (hp & 15).
+// Weights: 9 chunks for conv2 (one tap each: [ks][cb][plane] fragments + conv2's BN affine) followed by the chain's chunks, through
+// the same ring; 9 + 8 barriers per tile.
+// Tiles are dealt so that workgroups on one XCD (blockIdx & 7) work on neighbouring tiles: halo rows are re-read from that L2.
+template <int C, int C1, int CIN2, int RES, int NCW, int NLW, int PD>
+__global__ __launch_bounds__(64 * (NCW + NLW)) void unit_kernel(const ChainArgs p) {
+    constexpr int NS = 3;
+    constexpr int TH = NCW, TW = 16, HW = TW + 2, HPIX = (TH + 2) * HW;
+    constexpr int PIXB = C * 4;
+    static_assert(C == 64, "one pixel of R1 = 16 slots of 16 bytes (the bank swizzle)");
+    constexpr int NHI = (HPIX * PIXB + 1023) / 1024;               // DMA instructions per halo tile (4 pixels each; the last may run past
+    constexpr int HALO_BYTES = NHI * 1024;                         // the tile: those lanes are out of range and write zeros into the pad)
+    static_assert(NLW == 1 || NLW == 2, "one or two loader waves");
+    constexpr int C4 = 4 * C, KS1 = (C + CIN2) / 32, NJP = C4 / 32, NCB = C1 / 16;
+    constexpr int NFJ = KS1 * 4 + NCB * 2 + 1;                      // fragments of a chain chunk
+    constexpr int KS2 = C / 32, NCB2 = C / 16, NF2 = KS2 * NCB2 * 2 + 1;      // conv2: fragments per tap + the affine fragment
+    constexpr int NFMAX = NFJ > NF2 ? NFJ : NF2, CHUNK = NFMAX * 1024;
+    constexpr int STEPS = 9 + NJP;
+    constexpr int HPP = (NHI + NJP - 1) / NJP;                      // halo instructions issued per pointwise step
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* halo = smem;
+    char* ringb = smem + HALO_BYTES;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    const int vwg = (G & 7) == 0 ? (b & 7) * (G >> 3) + (b >> 3) : b;           // workgroups of one XCD take consecutive tiles
+    const int my_tiles = vwg < p.ntiles ? (p.ntiles - vwg + G - 1) / G : 0;
+    const int total = my_tiles * STEPS;
+    const int tpf = p.TY * p.TX;
+
+    if (wave >= NCW) {
+        // ================================ loader waves: halo tiles + weight chunks ================================
+        // wave lw copies the fragments / halo instructions i with i % NLW == lw
+        const int lw = wave - NCW;
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wfrag), 0, (int)p.w_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.r1in), 0, (int)p.r1in_bytes, 0x00020000);
+        auto halo_issue = [&](int tile, int i0, int i1) {
+            const int f = tile / tpf, rem = tile - f * tpf, ty = rem / p.TX, tx = rem - ty * p.TX;
+            for (int i = i0 + lw; i < i1; i += NLW) {
+                const int hp = 4 * i + (lane >> 4);
+                const int hy = (hp * 57) >> 10, hx = hp - HW * hy;                 // hp / 18 (exact for hp < 400)
+                const int gy = ty * TH - 1 + hy, gx = tx * TW - 1 + hx;
+                const bool ok = hp < HPIX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                const unsigned off = ok ? (unsigned)((f * p.H + gy) * p.W + gx) * (unsigned)PIXB + (unsigned)((((lane & 15) ^ (hp & 15))) << 4) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(halo + i * 1024), 16, (int)off, 0, 0, 0);
+            }
+        };
+        int st = 0, slot = 0;                                          // step and ring slot of the NEXT chunk to issue
+        // instructions of THIS wave per chunk: compile-time counts for the counted waits
+        constexpr int N2_0 = (NF2 + NLW - 1) / NLW, N2_1 = NF2 / NLW, NJ_0 = (NFJ + NLW - 1) / NLW, NJ_1 = NFJ / NLW;
+        auto issue = [&]() {
+            char* dst = ringb + slot * CHUNK;
+            if (st < 9) {
+#pragma unroll
+                for (int k = 0; k < N2_0; ++k) {
+                    const int i = lw + k * NLW;
+                    if (i < NF2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + i * 1024), 16, lane * 16, st * (NF2 * 1024) + i * 1024, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NJ_0; ++k) {
+                    const int i = lw + k * NLW;
+                    if (i < NFJ) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + i * 1024), 16, lane * 16,
+                                                                          9 * (NF2 * 1024) + (st - 9) * (NFJ * 1024) + i * 1024, 0, 0);
+                }
+            }
+            const bool was_conv2 = st < 9;
+            st = st + 1 == STEPS ? 0 : st + 1;
+            slot = slot + 1 == NS ? 0 : slot + 1;
+            return was_conv2;
+        };
+        auto wait_all_but_newest = [&](bool conv2_chunk) {             // everything older than the chunk just issued has landed
+            if (conv2_chunk) {
+                if (lw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N2_0) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N2_1) : "memory");
+            } else {
+                if (lw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ_0) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ_1) : "memory");
+            }
+        };
+        if (total > 0) {
+            halo_issue(vwg, 0, NHI);
+            issue();
+            wait_all_but_newest(issue());                              // (STEPS >= 2: both are conv2 chunks)
+        }
+        __builtin_amdgcn_s_barrier();                                  // B(-1): the first halo tile and chunk 0 have landed
+        int cur_st = 0, tile = vwg;
+        for (int it = 0; it < total; ++it) {
+            // the pointwise stage of this tile no longer reads the halo buffer (every wave passed barrier 8): fetch the next tile's
+            if (cur_st >= 9 && tile + G < p.ntiles) {
+                const int i0 = (cur_st - 9) * HPP, i1 = i0 + HPP < NHI ? i0 + HPP : NHI;
+                halo_issue(tile + G, i0, i1);
+            }
+            if (it + 2 < total) wait_all_but_newest(issue());
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                              // B(it)
+            if (++cur_st == STEPS) { cur_st = 0; tile += G; }
+        }
+        return;
+    }
+
+    // ================================== compute waves ==================================
+    const int l15 = lane & 15, g = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rs_s2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src2), 0, (int)p.src2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_xo = __builtin_amdgcn_make_buffer_rsrc(p.xout, 0, (int)p.xout_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r1 = __builtin_amdgcn_make_buffer_rsrc(p.r1out, 0, (int)p.r1_bytes, 0x00020000);
+    const uint4* ring = reinterpret_cast<const uint4*>(ringb);
+    int slot = 0;
+    float amax_x = 0.f, amax_r1 = 0.f, amax_r2 = 0.f;
+    __builtin_amdgcn_s_barrier();                                      // B(-1)
+    for (int tile = vwg; tile < p.ntiles; tile += G) {
+        const int f = tile / tpf, rem = tile - f * tpf, ty = rem / p.TX, tx = rem - ty * p.TX;
+        const int y = ty * TH + wave, x = tx * TW + l15;
+        const bool ok = y < p.H && x < p.W;
+        const int m = (f * p.H + y) * p.W + x;
+        unsigned xoff[1], roff[1], r1off[1];
+        xoff[0] = ok ? (unsigned)m * (unsigned)(C4 * 4) + (unsigned)(g * 32) : OOB;
+        roff[0] = xoff[0];
+        r1off[0] = ok ? (unsigned)m * (unsigned)(C1 * 4) + (unsigned)(g * 32) : OOB;
+        uint4 ph[1][KS1], pl[1][KS1];
+        if constexpr (CIN2 > 0) {                                      // the K-concatenated source at this wave's pixels (used after conv2)
+            const unsigned boff = ok ? (unsigned)m * (unsigned)(CIN2 * 4) + (unsigned)(g * 32) : OOB;
+#pragma unroll
+            for (int s = 0; s < CIN2 / 32; ++s) { ph[0][KS2 + s] = ld16(rs_s2, boff, s * 128); pl[0][KS2 + s] = ld16(rs_s2, boff, s * 128 + 16); }
+        }
+        // ---- conv2: 9 taps x KS2 K-steps, A... the pixel fragment comes from the halo tile (shifted by the tap), weights from the ring
+        floatx4 acc[NCB2];
+#pragma unroll
+        for (int cb = 0; cb < NCB2; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+        uint4 aff[KS2][4];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const uint4* Wc = ring + slot * (CHUNK / 16);
+            const uint4* W = Wc + lane;
+            const int hp = (wave + t / 3) * HW + l15 + t % 3;
+            const char* hrow = halo + hp * PIXB;
+            const int sw = hp & 15;
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {
+                const int sl = 2 * (4 * ks + g);
+                const uint4 ah = *reinterpret_cast<const uint4*>(hrow + ((sl ^ sw) << 4));
+                const uint4 al = *reinterpret_cast<const uint4*>(hrow + (((sl + 1) ^ sw) << 4));
+#pragma unroll
+                for (int cb = 0; cb < NCB2; ++cb) {
+                    const uint4 wh = W[((ks * NCB2 + cb) * 2 + 0) * 64], wl = W[((ks * NCB2 + cb) * 2 + 1) * 64];
+                    acc[cb] = mma16(wl, ah, acc[cb]);
+                    acc[cb] = mma16(wh, al, acc[cb]);
+                    acc[cb] = mma16(wh, ah, acc[cb]);
+                }
+            }
+            if (t == 8) {                                              // conv2's BN affine rides in the last tap's chunk
+#pragma unroll
+                for (int q = 0; q < KS2; ++q) {
+                    aff[q][0] = Wc[(NF2 - 1) * 64 + 8 * q + 2 * g]; aff[q][1] = Wc[(NF2 - 1) * 64 + 8 * q + 2 * g + 1];
+                    aff[q][2] = Wc[(NF2 - 1) * 64 + 16 + 8 * q + 2 * g]; aff[q][3] = Wc[(NF2 - 1) * 64 + 16 + 8 * q + 2 * g + 1];
+                }
+            }
+            slot = slot + 1 == NS ? 0 : slot + 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        // ---- epilogue of conv2 = operand of conv3: BN affine, ReLU, range, split with R2's scale
+#pragma unroll
+        for (int q = 0; q < KS2; ++q) {
+            const float4 sa = __builtin_bit_cast(float4, aff[q][0]), sb = __builtin_bit_cast(float4, aff[q][1]);
+            const float4 ba = __builtin_bit_cast(float4, aff[q][2]), bb = __builtin_bit_cast(float4, aff[q][3]);
+            const float sc[8] = {sa.x * p.post0, sa.y * p.post0, sa.z * p.post0, sa.w * p.post0, sb.x * p.post0, sb.y * p.post0, sb.z * p.post0, sb.w * p.post0};
+            const float bi[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = fmaxf(acc[2 * q + (k >> 2)][k & 3] * sc[k] + bi[k], 0.f);
+            h2_pack8(o, p.r2_scale, ph[0][q], pl[0][q]);
+            if (ok) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) amax_r2 = fmaxf(amax_r2, o[k]);
+            }
+        }
+        chain_tail<C, C1, CIN2, RES, 1, NS, PD, CHUNK>(p, ring, slot, ph, pl, xoff, roff, r1off, rs_s2, rs_xo, rs_r1, amax_x, amax_r1, lane);
+    }
+    if (p.xout_absmax) track_absmax(p.xout_absmax, amax_x, lane, (int)(blockIdx.x * 8u + (unsigned)wave));
+    if (p.r1_absmax) track_absmax(p.r1_absmax, amax_r1, lane, (int)(blockIdx.x * 8u + (unsigned)wave) + 97);
+    if (p.r2_absmax) track_absmax(p.r2_absmax, amax_r2, lane, (int)(blockIdx.x * 8u + (unsigned)wave) + 41);
+}
+
+// fp32 fragments -> fp16 high / low fragment pairs in chunk order.  src per chunk: pairs x [64 lanes][8 floats] then the affine
+// fragment [256 floats]; out per chunk: 2 pairs + 1 fragments of 1 KiB (pairs as [hi][lo], affine copied).
+// s1 / s2: the powers of two conv3's / conv1's weights are stored with.
+__global__ __launch_bounds__(256) void chain_pack_kernel(const float4* __restrict__ src, int n_chunks, int f1_pairs, int f2_pairs,
+                                                         float s1, float s2, uint4* __restrict__ out) {
+    const int pairs = f1_pairs + f2_pairs;
+    const int nf = 2 * pairs + 1;
+    const long long src_chunk = (long long)pairs * 128 + 64;      // float4s
+    const long long total = (long long)n_chunks * (pairs + 1) * 64;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ln = (int)(i & 63);
+        const long long fp = i >> 6;
+        const int ch = (int)(fp / (pairs + 1)), pr = (int)(fp % (pairs + 1));
+        uint4* o = out + ((long long)ch * nf + 2 * pr) * 64 + ln;
+        if (pr == pairs) {
+            o[0] = __builtin_bit_cast(uint4, src[ch * src_chunk + (long long)pairs * 128 + ln]);
+            continue;
+        }
+        const float4* sp = src + ch * src_chunk + (long long)pr * 128 + ln * 2;
+        uint2 h0, l0, h1, l1;
+        const float sc = pr < f1_pairs ? s1 : s2;
+        split2_f16(sp[0], sc, h0, l0);
+        split2_f16(sp[1], sc, h1, l1);
+        o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        o[64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+}
+
+hipError_t launch_chain_pack(const float* src, int n_chunks, int f1_pairs, int f2_pairs, float s1, float s2, void* out, hipStream_t s) {
+    const long long total = (long long)n_chunks * (f1_pairs + f2_pairs + 1) * 64;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(chain_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(src), n_chunks, f1_pairs,
+                       f2_pairs, s1, s2, reinterpret_cast<uint4*>(out));
+    return hipGetLastError();
+}
+
+namespace {
+
+template <int C, int C1, int CIN2, int RES, int RB, int NCW, int NLW, int PD>
+hipError_t launch_chain_t(const ChainArgs& a0, hipStream_t s) {
+    constexpr int NS = 3;
+    constexpr int NF = (C + CIN2) / 32 * 4 + C1 / 16 * 2 + 1;
+    constexpr int LDS = NS * NF * 1024;
+    static_assert(LDS <= 160 * 1024, "ring does not fit the LDS");
+    auto kern = chain_kernel<C, C1, CIN2, RES, RB, NCW, NLW, NS, PD>;
+    static bool attr_done[16] = {};
+    static int wgs_per_cu[16] = {};
+    const int dev = dgp_device_slot();
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        int occ = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * (NCW + NLW), LDS);
+        if (e != hipSuccess) return e;
+        static const int force = getenv("DGP_CHAIN_WGS") ? atoi(getenv("DGP_CHAIN_WGS")) : 0;      // tuning: resident workgroups per CU
+        wgs_per_cu[dev] = force > 0 ? force : (occ < 1 ? 1 : occ);
+        attr_done[dev] = true;
+    }
+    ChainArgs a = a0;
+    constexpr int TILE = 16 * RB * NCW;
+    a.ntiles = (a.M + TILE - 1) / TILE;
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    int grid = ncu * wgs_per_cu[dev];
+    if (grid > a.ntiles) grid = a.ntiles;
+    if (grid < 1) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * (NCW + NLW)), LDS, s, a);
+    return hipGetLastError();
+}
+
+template <int C, int C1, int CIN2, int RES, int NCW, int NLW, int PD>
+hipError_t launch_unit_t(const ChainArgs& a0, int N, hipStream_t s) {
+    constexpr int NFJ = (C + CIN2) / 32 * 4 + C1 / 16 * 2 + 1, NF2 = (C / 32) * (C / 16) * 2 + 1, NFMAX = NFJ > NF2 ? NFJ : NF2;
+    constexpr int LDS = ((NCW + 2) * 18 * C * 4 + 1023) / 1024 * 1024 + 3 * NFMAX * 1024;
+    static_assert(LDS <= 160 * 1024, "halo tile + ring do not fit the LDS");
+    auto kern = unit_kernel<C, C1, CIN2, RES, NCW, NLW, PD>;
+    static bool attr_done[16] = {};
+    static int wgs_per_cu[16] = {};
+    const int dev = dgp_device_slot();
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        int occ = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * (NCW + NLW), LDS);
+        if (e != hipSuccess) return e;
+        static const int force = getenv("DGP_CHAIN_WGS") ? atoi(getenv("DGP_CHAIN_WGS")) : 0;
+        wgs_per_cu[dev] = force > 0 ? force : (occ < 1 ? 1 : occ);
+        attr_done[dev] = true;
+    }
+    ChainArgs a = a0;
+    a.TY = (a.H + NCW - 1) / NCW; a.TX = (a.W + 15) / 16;
+    a.ntiles = N * a.TY * a.TX;
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    int grid = ncu * wgs_per_cu[dev];
+    if (grid > a.ntiles) grid = a.ntiles;
+    if (grid < 1) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * (NCW + NLW)), LDS, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool chain_supported(int C, int C1, int CIN2, int res) {
+    if (C == 64 && C1 == 64 && CIN2 == 0 && res == 1) return true;
+    if (C == 64 && C1 == 64 && CIN2 == 64 && res == 0) return true;
+    if (C == 64 && C1 == 128 && CIN2 == 0 && res == 2) return true;
+    if (C == 128 && C1 == 128 && CIN2 == 0 && res == 1) return true;
+    if (C == 128 && C1 == 256 && CIN2 == 0 && res == 2) return true;
+    return false;
+}
+
+bool unit_supported(int C, int C1, int CIN2, int res) {
+    return C == 64 && C1 == 64 && ((CIN2 == 0 && res == 1) || (CIN2 == 64 && res == 0));
+}
+
+hipError_t launch_unit(const ChainArgs& a, int N, int C, int C1, int CIN2, int res, hipStream_t s) {
+    static const int cfg = getenv("DGP_UNIT_CFG") ? atoi(getenv("DGP_UNIT_CFG")) : 0;      // tuning: tile rows / loader waves
+    if (C == 64 && C1 == 64 && CIN2 == 0 && res == 1) {
+        if (cfg == 1) return launch_unit_t<64, 64, 0, 1, 4, 1, 4>(a, N, s);
+        if (cfg == 2) return launch_unit_t<64, 64, 0, 1, 8, 2, 4>(a, N, s);
+        if (cfg == 3) return launch_unit_t<64, 64, 0, 1, 10, 2, 4>(a, N, s);
+        return launch_unit_t<64, 64, 0, 1, 10, 2, 2>(a, N, s);
+    }
+    if (C == 64 && C1 == 64 && CIN2 == 64 && res == 0) {
+        if (cfg == 2) return launch_unit_t<64, 64, 64, 0, 8, 2, 2>(a, N, s);
+        return launch_unit_t<64, 64, 64, 0, 10, 2, 2>(a, N, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+int chain_frags_per_chunk(int C, int C1, int CIN2) { return (C + CIN2) / 32 * 4 + C1 / 16 * 2 + 1; }
+
+const char* chain_kernel_name(int C, int C1, int CIN2, int res) {
+    static thread_local char buf[64];
+    snprintf(buf, sizeof buf, "chain_c%d_n%d_%s", C, C1, res == 0 ? "sc" : (res == 2 ? "s2" : "id"));
+    (void)CIN2;
+    return buf;
+}
+
+hipError_t launch_chain(const ChainArgs& a, int C, int C1, int CIN2, int res, hipStream_t s) {
+    static const int cfg = getenv("DGP_CHAIN_CFG") ? atoi(getenv("DGP_CHAIN_CFG")) : 0;      // tuning: alternative workgroup shapes
+    //                                                                        C   C1  CIN2 RES RB NCW NLW PD
+    if (C == 64 && C1 == 64 && CIN2 == 0 && res == 1) {
+        if (cfg == 1) return launch_chain_t<64, 64, 0, 1, 2, 5, 1, 4>(a, s);
+        if (cfg == 2) return launch_chain_t<64, 64, 0, 1, 2, 4, 1, 2>(a, s);
+        if (cfg == 3) return launch_chain_t<64, 64, 0, 1, 1, 11, 1, 4>(a, s);
+        return launch_chain_t<64, 64, 0, 1, 1, 8, 1, 4>(a, s);
+    }
+    if (C == 64 && C1 == 64 && CIN2 == 64 && res == 0) {
+        if (cfg == 1) return launch_chain_t<64, 64, 64, 0, 2, 5, 1, 2>(a, s);
+        return launch_chain_t<64, 64, 64, 0, 1, 8, 1, 2>(a, s);
+    }
+    if (C == 64 && C1 == 128 && CIN2 == 0 && res == 2) {
+        if (cfg == 1) return launch_chain_t<64, 128, 0, 2, 2, 5, 1, 4>(a, s);
+        return launch_chain_t<64, 128, 0, 2, 1, 8, 1, 4>(a, s);
+    }
+    if (C == 128 && C1 == 128 && CIN2 == 0 && res == 1) {
+        if (cfg == 2) return launch_chain_t<128, 128, 0, 1, 1, 12, 2, 2>(a, s);
+        return launch_chain_t<128, 128, 0, 1, 1, 8, 2, 4>(a, s);
+    }
+    if (C == 128 && C1 == 256 && CIN2 == 0 && res == 2) {
+        return launch_chain_t<128, 256, 0, 2, 1, 6, 2, 4>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace dgp

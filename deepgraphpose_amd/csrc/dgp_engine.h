@@ -47,6 +47,26 @@ struct Unit {
     int depth_in = 0, depth = 0, depth_bn = 0;
 };
 
+// conv3 of unit k (+ shortcut, ReLU) and conv1 of unit k + 1 as ONE launch (dgp_chain.hip): the weight fragments of both convs in
+// chunk order, built at load.  Scales: the fragments hold w * 2^w3_exp / w * 2^w1_exp (max |w| 2^exp in [2^14, 2^15)).
+struct ChainPlan {
+    bool ok = false;
+    int C = 0, C1 = 0, CIN2 = 0, res = 0;     // res: 0 K-concatenated shortcut conv, 1 identity, 2 subsample (stride-2 unit)
+    void* d_frags = nullptr;
+    unsigned frag_bytes = 0;
+    float *d_sc1 = nullptr, *d_bi1 = nullptr; // conv1's BN affine
+    int w3_exp = 0, w1_exp = 0;
+    bool unit = false;                        // the fragments start with conv2's 9 tap chunks: the unit kernel runs conv2 too
+    int w2_exp = 0;
+    unsigned head_bytes = 0;                  // bytes of conv2's chunks in front of the chain's (0 when unit is false)
+};
+// host: build the chunked fragments (see ChainArgs) and upload them.  w3cat [(C + CIN2)][4 C], w1 [4 C][C1] row-major; sc3 may be null (= 1)
+// w2 (optional, HWIO [3][3][C][C] of a stride-1 conv2 with BN affine sc2 / bi2): build the unit kernel's fragments when an instance exists
+int build_chain_plan(ChainPlan& pl, int C, int C1, int CIN2, int res, const float* w3cat, const float* sc3, const float* bi3,
+                     const float* w1, const float* sc1, const float* bi1, const float* w2 = nullptr, const float* sc2 = nullptr,
+                     const float* bi2 = nullptr);
+void free_chain_plan(ChainPlan& pl);
+
 constexpr size_t TAIL_SLAB_FLOATS = (size_t)512 * 128 * 128;      // K-split slabs of a conv grid's tail: <= 512 slices of a 128 x 128 tile (32 MB)
 
 int coutp_for(int cout);
@@ -62,6 +82,7 @@ struct dgp_net {
     std::vector<dgp::ConvLayer> layers;
     int conv1 = -1, head_part = -1, head_locref = -1;
     std::vector<dgp::Unit> units;
+    std::vector<dgp::ChainPlan> chains;       // chains[ui]: conv3 of unit ui + conv1 of unit ui + 1 (ok = false: layer by layer)
     bool loaded = false;
     // geometry
     int h1 = 0, w1 = 0, hp = 0, wp = 0, fh = 0, fw = 0;
@@ -109,6 +130,7 @@ struct dgp_net {
             if (l.d_wh3_pw) (void)hipFree(l.d_wh3_pw);
             for (void* q : {(void*)l.d_w_fused, (void*)l.d_bias_fused, l.d_wh3_fused}) if (q) (void)hipFree(q);
         }
+        for (auto& c : chains) dgp::free_chain_plan(c);
         for (float* q : {d_wmax, d_amax, d_inmax}) if (q) (void)hipFree(q);
         for (int* q : {d_exps, d_flag}) if (q) (void)hipFree(q);
     }

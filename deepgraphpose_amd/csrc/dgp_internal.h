@@ -134,6 +134,42 @@ struct DlcLossArgs {                      // DLC step-0 loss (sigmoid CE on bina
 };
 hipError_t launch_dlc_loss(const DlcLossArgs& a, hipStream_t s);
 
+// Arguments of the bottleneck chain kernel (dgp_chain.hip): conv3 of unit k (+ shortcut, ReLU) -> X' -> conv1 of unit k + 1 -> R1',
+// all tensors H2.  Weight chunks: per 32 channels of X' the fp16 fragment pairs of conv3 (those columns), of conv1 (those K rows),
+// and one fragment with the BN affine of those channels (32 scales | 32 biases).
+struct ChainArgs {
+    const void* r2;           // H2 [M][C], cells hold R2 * 2^e
+    const void* src2;         // residual X (H2, C4 channels; res 1: [M], res 2: [N, res_H, res_W]) or K-concatenated source [M][CIN2]
+    void* xout;               // H2 [M][C4]
+    void* r1out;              // H2 [M][C1]
+    const void* wfrag;        // C4 / 32 chunks of chain_frags_per_chunk() KiB
+    const float* sc1;         // [C1] conv1's BN scale
+    const float* bi1;         // [C1]
+    float post1, post2;       // exact powers of two that undo the operand scales: 1 / (R2 scale x conv3 weight scale), 1 / (X' scale x conv1 weight scale)
+    float res_inv_scale, xout_scale, r1_scale;
+    float* xout_absmax; float* r1_absmax;
+    int M, HoWo, Wo, res_H, res_W;
+    int ntiles;
+    unsigned r2_bytes, src2_bytes, xout_bytes, r1_bytes, w_bytes;
+    // unit kernel (conv2 in front of the chain; r2 is not used: R2 stays in registers)
+    const void* r1in;         // H2 [N, H, W, C]: conv2's input (the unit's conv1 output)
+    unsigned r1in_bytes;
+    int H, W, TY, TX;         // frame size (stride 1: output = input grid), tiles per frame
+    float post0, r2_scale;    // 1 / (R1 scale x conv2 weight scale); scale R2's fragments are split with
+    float* r2_absmax;
+};
+bool chain_supported(int C, int C1, int CIN2, int res);          // res: 0 K-concatenated shortcut, 1 identity, 2 subsample of a stride-2 unit
+int  chain_frags_per_chunk(int C, int C1, int CIN2);
+hipError_t launch_chain(const ChainArgs& a, int C, int C1, int CIN2, int res, hipStream_t s);
+const char* chain_kernel_name(int C, int C1, int CIN2, int res);
+// the unit kernel: conv2 (3x3, stride 1) in front of the chain.  Weight chunks: 9 conv2 chunks (one tap each: (C / 32) (C / 16) fragment
+// pairs + the affine fragment) followed by the chain's chunks.  a.H / a.W / a.r1in describe conv2's input; N frames
+bool unit_supported(int C, int C1, int CIN2, int res);
+hipError_t launch_unit(const ChainArgs& a, int N, int C, int C1, int CIN2, int res, hipStream_t s);
+// fp32 fragments -> fp16 high / low fragment pairs.  src per chunk: (f1_pairs + f2_pairs) x [64 lanes][8 floats], then the affine
+// fragment [64 floats... 256 floats]; out per chunk: 2 (f1_pairs + f2_pairs) + 1 KiB-fragments
+hipError_t launch_chain_pack(const float* src, int n_chunks, int f1_pairs, int f2_pairs, float s1, float s2, void* out, hipStream_t s);
+
 // hipFuncSetAttribute applies to the CURRENT device: the "done once" flags of the launchers are kept per device
 inline int dgp_device_slot() { int d = 0; (void)hipGetDevice(&d); return d & 15; }
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }

@@ -39,6 +39,95 @@ int pad_before_for(int n, int k, int stride, int rate, bool conv2d_same_explicit
     tf_same(n, k, stride, rate, &out, &pb);
     return pb;
 }
+static int pow2_exp_for_max(float mx) {        // e with max * 2^e in [2^14, 2^15) -- the weight scale of the fp16 split (pow2_scale_for)
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 0;
+    int ex; (void)frexpf(mx, &ex);             // mx = f 2^ex, f in [0.5, 1)
+    return 14 - (ex - 1);
+}
+
+void free_chain_plan(ChainPlan& pl) {
+    for (void* q : {pl.d_frags, (void*)pl.d_sc1, (void*)pl.d_bi1}) if (q) (void)hipFree(q);
+    pl = ChainPlan();
+}
+
+int build_chain_plan(ChainPlan& pl, int C, int C1, int CIN2, int res, const float* w3cat, const float* sc3, const float* bi3,
+                     const float* w1, const float* sc1, const float* bi1, const float* w2, const float* sc2, const float* bi2) {
+    free_chain_plan(pl);
+    if (!chain_supported(C, C1, CIN2, res)) return DGP_OK;       // (ok stays false: the engine runs the two convs layer by layer)
+    const bool unit = w2 && unit_supported(C, C1, CIN2, res);
+    const int C4 = 4 * C, KS1 = (C + CIN2) / 32, NJP = C4 / 32, NCB = C1 / 16;
+    const int pairs = KS1 * 2 + NCB;
+    const size_t chunk_f = (size_t)pairs * 512 + 256;             // floats of the fp32 staging image per chunk
+    const int KS2 = C / 32, NCB2 = C / 16, pairs2 = KS2 * NCB2;
+    const size_t chunk2_f = (size_t)pairs2 * 512 + 256;
+    std::vector<float> src((size_t)NJP * chunk_f, 0.f), src2(unit ? 9 * chunk2_f : 0, 0.f);
+    float m3 = 0.f, m1 = 0.f, m2 = 0.f;
+    for (size_t i = 0; i < (size_t)(C + CIN2) * C4; ++i) m3 = std::max(m3, fabsf(w3cat[i]));
+    for (size_t i = 0; i < (size_t)C4 * C1; ++i) m1 = std::max(m1, fabsf(w1[i]));
+    // column of MFMA row i of 16-channel block cb: the permutation that gives a lane 8 consecutive channels per block pair
+    auto col_of = [](int cb, int i) { return 32 * (cb >> 1) + 8 * (i >> 2) + 4 * (cb & 1) + (i & 3); };
+    for (int jp = 0; jp < NJP; ++jp) {
+        float* ch = src.data() + (size_t)jp * chunk_f;
+        for (int s = 0; s < KS1; ++s)
+            for (int b = 0; b < 2; ++b) {
+                float* f = ch + (size_t)(s * 2 + b) * 512;
+                for (int ln = 0; ln < 64; ++ln) {
+                    const int g = ln >> 4, i = ln & 15, col = 32 * jp + col_of(b, i);
+                    for (int j = 0; j < 8; ++j) f[ln * 8 + j] = w3cat[(size_t)(32 * s + 8 * g + j) * C4 + col];
+                }
+            }
+        for (int cb = 0; cb < NCB; ++cb) {
+            float* f = ch + (size_t)(KS1 * 2 + cb) * 512;
+            for (int ln = 0; ln < 64; ++ln) {
+                const int g = ln >> 4, i = ln & 15, col = col_of(cb, i);
+                for (int j = 0; j < 8; ++j) f[ln * 8 + j] = w1[(size_t)(32 * jp + 8 * g + j) * C1 + col];
+            }
+        }
+        float* af = ch + (size_t)pairs * 512;
+        for (int c = 0; c < 32; ++c) { af[c] = sc3 ? sc3[32 * jp + c] : 1.f; af[32 + c] = bi3 ? bi3[32 * jp + c] : 0.f; }
+    }
+    if (unit) {
+        for (size_t i = 0; i < (size_t)9 * C * C; ++i) m2 = std::max(m2, fabsf(w2[i]));
+        for (int t = 0; t < 9; ++t) {
+            float* ch = src2.data() + (size_t)t * chunk2_f;
+            for (int ks = 0; ks < KS2; ++ks)
+                for (int cb = 0; cb < NCB2; ++cb) {
+                    float* f = ch + (size_t)(ks * NCB2 + cb) * 512;
+                    for (int ln = 0; ln < 64; ++ln) {
+                        const int g = ln >> 4, i = ln & 15, col = col_of(cb, i);
+                        for (int j = 0; j < 8; ++j) f[ln * 8 + j] = w2[((size_t)t * C + 32 * ks + 8 * g + j) * C + col];
+                    }
+                }
+            float* af = ch + (size_t)pairs2 * 512;
+            for (int c = 0; c < C; ++c) { af[c] = sc2 ? sc2[c] : 1.f; af[C + c] = bi2 ? bi2[c] : 0.f; }
+        }
+    }
+    pl.C = C; pl.C1 = C1; pl.CIN2 = CIN2; pl.res = res; pl.unit = unit;
+    pl.w3_exp = pow2_exp_for_max(m3); pl.w1_exp = pow2_exp_for_max(m1); pl.w2_exp = pow2_exp_for_max(m2);
+    const int nf = chain_frags_per_chunk(C, C1, CIN2), nf2 = 2 * pairs2 + 1;
+    const size_t head = unit ? (size_t)9 * nf2 * 1024 : 0;
+    pl.frag_bytes = (unsigned)(head + (size_t)NJP * nf * 1024);
+    pl.head_bytes = (unsigned)head;
+    float *d_src = nullptr, *d_src2 = nullptr;
+    HIP_TRY(hipMalloc(&d_src, src.size() * sizeof(float)));
+    hipError_t e = hipMemcpy(d_src, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&pl.d_frags, pl.frag_bytes);
+    if (e == hipSuccess && unit) e = hipMalloc(&d_src2, src2.size() * sizeof(float));
+    if (e == hipSuccess && unit) e = hipMemcpy(d_src2, src2.data(), src2.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && unit) e = launch_chain_pack(d_src2, 9, pairs2, 0, ldexpf(1.f, pl.w2_exp), 1.f, pl.d_frags, nullptr);
+    if (e == hipSuccess) e = launch_chain_pack(d_src, NJP, KS1 * 2, NCB, ldexpf(1.f, pl.w3_exp), ldexpf(1.f, pl.w1_exp), (char*)pl.d_frags + head, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(d_src);
+    if (d_src2) (void)hipFree(d_src2);
+    if (e == hipSuccess) e = hipMalloc(&pl.d_sc1, C1 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&pl.d_bi1, C1 * sizeof(float));
+    std::vector<float> one(C1, 1.f), zero(C1, 0.f);
+    if (e == hipSuccess) e = hipMemcpy(pl.d_sc1, sc1 ? sc1 : one.data(), C1 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pl.d_bi1, bi1 ? bi1 : zero.data(), C1 * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { free_chain_plan(pl); return fail(DGP_ERR_HIP, std::string("chain plan: ") + hipGetErrorString(e)); }
+    pl.ok = true;
+    return DGP_OK;
+}
 }  // namespace dgp
 
 namespace {
@@ -191,7 +280,7 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
     const int nj = net->desc.num_joints;
     std::map<int, std::vector<float>> keep_w, keep_scale, keep_bias;      // 1x1 convs that get fused (conv3 + shortcut)
     std::map<int, bool> wanted;
-    for (const Unit& u : net->units) if (u.sc >= 0) { wanted[u.sc] = true; wanted[u.c3] = true; }
+    for (const Unit& u : net->units) { wanted[u.c1] = true; wanted[u.c2] = true; wanted[u.c3] = true; if (u.sc >= 0) wanted[u.sc] = true; }
     for (size_t li = 0; li < net->layers.size(); ++li) {
         ConvLayer& l = net->layers[li];
         const bool is_head = ((int)li == net->head_part || (int)li == net->head_locref);
@@ -348,6 +437,36 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
         if (e == hipSuccess) e = launch_pack_h3(l3.d_w_fused, l3.nk_fused, l3.CoutP, wm, l3.d_wh3_fused, nullptr);
         if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("fused shortcut panel: ") + hipGetErrorString(e));
     }
+    // conv3 of unit k (+ shortcut) and conv1 of unit k + 1 as one launch (dgp_chain.hip) wherever a kernel instance exists
+    for (auto& c : net->chains) free_chain_plan(c);
+    net->chains.assign(net->units.size(), ChainPlan());
+    for (size_t ui = 0; ui + 1 < net->units.size(); ++ui) {
+        const Unit &u = net->units[ui], &un = net->units[ui + 1];
+        const ConvLayer &l3 = net->layers[u.c3], &l1 = net->layers[un.c1];
+        if (l3.KH != 1 || l1.KH != 1 || l1.stride != 1 || l3.Cout != 4 * l3.Cin || l1.Cin != l3.Cout) continue;
+        const int C = l3.Cin, C1 = l1.Cout;
+        const ConvLayer& l2 = net->layers[u.c2];
+        const bool c2_plain = l2.KH == 3 && l2.stride == 1 && l2.rate == 1 && l2.Cin == C && l2.Cout == C;      // conv2 the unit kernel can take
+        const float *w2 = c2_plain ? keep_w[u.c2].data() : nullptr, *s2 = c2_plain ? keep_scale[u.c2].data() : nullptr,
+                    *b2 = c2_plain ? keep_bias[u.c2].data() : nullptr;
+        int rc2;
+        if (u.sc >= 0) {
+            const ConvLayer& ls = net->layers[u.sc];
+            if (ls.stride != 1 || u.stride != 1 || !l3.d_w_fused) continue;
+            const int c2 = ls.Cin, co = l3.Cout;
+            std::vector<float> w((size_t)(C + c2) * co), b(co);
+            const std::vector<float>&w3 = keep_w[u.c3], &wsc = keep_w[u.sc], &s3 = keep_scale[u.c3], &ssc = keep_scale[u.sc];
+            for (int k = 0; k < C; ++k) for (int o = 0; o < co; ++o) w[(size_t)k * co + o] = w3[(size_t)k * co + o] * s3[o];
+            for (int k = 0; k < c2; ++k) for (int o = 0; o < co; ++o) w[(size_t)(C + k) * co + o] = wsc[(size_t)k * co + o] * ssc[o];
+            for (int o = 0; o < co; ++o) b[o] = keep_bias[u.c3][o] + keep_bias[u.sc][o];
+            rc2 = build_chain_plan(net->chains[ui], C, C1, c2, 0, w.data(), nullptr, b.data(), keep_w[un.c1].data(),
+                                   keep_scale[un.c1].data(), keep_bias[un.c1].data(), w2, s2, b2);
+        } else {
+            rc2 = build_chain_plan(net->chains[ui], C, C1, 0, u.stride == 1 ? 1 : 2, keep_w[u.c3].data(), keep_scale[u.c3].data(),
+                                   keep_bias[u.c3].data(), keep_w[un.c1].data(), keep_scale[un.c1].data(), keep_bias[un.c1].data(), w2, s2, b2);
+        }
+        if (rc2) return rc2;
+    }
     HIP_TRY(hipDeviceSynchronize());
     net->wmax_valid = true;
     net->loaded = true;
@@ -386,6 +505,7 @@ Plan make_plan(const dgp_net* net, int B) {
         if (u.sc >= 0) sc = std::max(sc, (size_t)B * ho * wo * u.depth);
         h = ho; w = wo;
     }
+    r1 = r2 = std::max(r1, r2);       // the unit kernel ping-pongs conv1's output between the two regions
     Plan p{};
     size_t o = 0;
     auto take = [&](size_t nfloats) { size_t r = o; o += align256(nfloats * sizeof(float)); return r; };
@@ -549,6 +669,50 @@ int run_conv_fused_shortcut(dgp_net* net, const Unit& u, const float* r2, const 
     return DGP_OK;
 }
 
+// conv3 of unit ui (+ shortcut, ReLU) and conv1 of unit ui + 1 as one launch (dgp_chain.hip).  r2 [M][C]; x: the unit's input (identity
+// shortcut [M][4C], stride-2 unit [N, H, W, 4C], or the K-concatenated source of the shortcut conv [M][CIN2]); all tensors H2
+// r1in != null: the unit kernel -- conv2 of unit ui runs in the same launch, reading R1 (r1in) with its halo; r2 is not used
+int run_chain(dgp_net* net, int ui, const float* r2, const float* x, int N, int Ho, int Wo, int H, int W, float* xout, float* r1out,
+              hipStream_t s, int x_exp, const float* r1in = nullptr) {
+    const ChainPlan& cp = net->chains[ui];
+    const Unit &u = net->units[ui], &un = net->units[ui + 1];
+    const ConvLayer &l3 = net->layers[u.c3], &l1 = net->layers[un.c1];
+    ChainArgs a{};
+    a.r2 = r2; a.src2 = x; a.xout = xout; a.r1out = r1out; a.sc1 = cp.d_sc1; a.bi1 = cp.d_bi1;
+    a.wfrag = (const char*)cp.d_frags + (r1in ? 0 : cp.head_bytes);
+    a.M = N * Ho * Wo; a.HoWo = Ho * Wo; a.Wo = Wo; a.res_H = H; a.res_W = W;
+    if (r1in) {                                   // unit kernel: conv2 (stride 1: Ho x Wo = H x W) in front
+        const ConvLayer& l2 = net->layers[u.c2];
+        a.r1in = r1in; a.H = H; a.W = W;
+        a.post0 = ldexpf(1.f, -(net->act_exp[u.c1] + cp.w2_exp));
+        a.r2_scale = ldexpf(1.f, net->act_exp[u.c2]);
+        a.r2_absmax = net->amax(u.c2);
+        a.r1in_bytes = (unsigned)((size_t)N * H * W * l2.Cin * 4);
+    }
+    a.post1 = ldexpf(1.f, -(net->act_exp[u.c2] + cp.w3_exp));
+    a.post2 = ldexpf(1.f, -(net->act_exp[u.c3] + cp.w1_exp));
+    a.res_inv_scale = ldexpf(1.f, -x_exp);
+    a.xout_scale = ldexpf(1.f, net->act_exp[u.c3]);
+    a.r1_scale = ldexpf(1.f, net->act_exp[un.c1]);
+    a.xout_absmax = net->amax(u.c3); a.r1_absmax = net->amax(un.c1);
+    const double lim = 4294967000.0;
+    const double r2b = (double)a.M * cp.C * 4, xob = (double)a.M * cp.C * 16, r1b = (double)a.M * cp.C1 * 4;
+    const double s2b = cp.res == 0 ? (double)a.M * cp.CIN2 * 4 : (double)N * H * W * cp.C * 16;
+    if (r2b > lim || xob > lim || r1b > lim || s2b > lim)
+        return fail(DGP_ERR_INVALID, "activation tensor exceeds the 4 GiB buffer-descriptor range; lower the batch");
+    a.r2_bytes = (unsigned)r2b; a.xout_bytes = (unsigned)xob; a.r1_bytes = (unsigned)r1b; a.src2_bytes = (unsigned)s2b;
+    a.w_bytes = cp.frag_bytes - (r1in ? 0 : cp.head_bytes);
+    double flops = conv_flops_of(l3, a.M, false) + conv_flops_of(l1, a.M, false);
+    if (u.sc >= 0) flops += conv_flops_of(net->layers[u.sc], a.M, false);
+    if (r1in) flops += conv_flops_of(net->layers[u.c2], a.M, false);
+    std::string kname = chain_kernel_name(cp.C, cp.C1, cp.CIN2, cp.res);
+    if (r1in) kname = "unit" + kname.substr(5);
+    ProfScope ps(net, s, "conv:" + (r1in ? net->layers[u.c2].scope + "+" : std::string()) + l3.scope + (u.sc >= 0 ? "+shortcut" : "") + "+" + l1.scope + "|" + kname, flops);
+    hipError_t e = r1in ? launch_unit(a, N, cp.C, cp.C1, cp.CIN2, cp.res, s) : launch_chain(a, cp.C, cp.C1, cp.CIN2, cp.res, s);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("chain launch (") + l3.scope + "): " + hipGetErrorString(e));
+    return DGP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -699,6 +863,13 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
 
     }
     const int pool_exp = h2 ? net->act_exp[net->conv1] : 0;
+    // conv3(k) + conv1(k + 1) as one launch (DGP_CHAIN=0: layer by layer).  Calibration runs layer by layer (it needs every tensor's
+    // range before the next layer runs) and is followed by a second, chained pass, so results never depend on which pass produced them
+    static const bool chain_env = !(getenv("DGP_CHAIN") && atoi(getenv("DGP_CHAIN")) == 0);
+    const bool chain_on = h2 && !calib && chain_env && net->chains.size() == net->units.size();
+    static const bool unit_env = !(getenv("DGP_UNIT") && atoi(getenv("DGP_UNIT")) == 0);      // conv2 inside the chain launch (block1)
+    bool r1_ready = false;                            // R1 of this unit came out of the previous unit's chain launch
+    float *Ra = R1, *Rb = R2;
     int cur = 0, h = net->hp, w = net->wp;
     const float* x_rng = net->amax(net->conv1);      // max-pooling cannot raise the maximum of conv1's output
     int x_exp = pool_exp;
@@ -738,26 +909,44 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
                 H2Spec q; q.in_fmt = 1; q.in_exp = in_exp; q.out_fmt = 1; q.out_exp = net->act_exp[out_li]; q.res_fmt = r_fmt; q.res_exp = r_exp;
                 return q;
             };
-            rc = layer(u.c1, [&] { return run_conv(net, net->layers[u.c1], xin, B, h, w, 0, 0, h, w, nullptr, 0, 0, 0, true, 0, 0, R1, s,
-                                                   nullptr, nullptr, spec(x_exp, u.c1)); });
-            if (rc) return rc;
+            // Ra: this unit's conv1 output; Rb: its conv2 output (the chain writes the NEXT unit's conv1 output back into Ra; the unit
+            // kernel, which still reads Ra's halos while it writes, into Rb -- the two regions then trade places)
+            if (!r1_ready) {
+                rc = layer(u.c1, [&] { return run_conv(net, net->layers[u.c1], xin, B, h, w, 0, 0, h, w, nullptr, 0, 0, 0, true, 0, 0, Ra, s,
+                                                       nullptr, nullptr, spec(x_exp, u.c1)); });
+                if (rc) return rc;
+            }
+            r1_ready = false;
+            const bool chain_ok = chain_on && (size_t)ui + 1 < net->units.size() && net->chains[ui].ok;
+            // the K-concatenated shortcut needs R2 on X's scale: known from calibration (unit_fuse_ok) before conv2 runs
+            const bool unit_k = chain_ok && unit_env && net->chains[ui].unit && (net->chains[ui].res != 0 || fuse);
             bool share_ok = true;
-            rc = layer(u.c2, [&] { return run_conv(net, net->layers[u.c2], R1, B, h, w, pb_h, pb_w, ho, wo, nullptr, 0, 0, 0, true, 0, 0, R2, s,
-                                                   nullptr, nullptr, spec(net->act_exp[u.c1], u.c2)); },
-                       (fuse && calib) ? x_exp : dgp_net::H2_NONE, &share_ok);
-            if (rc) return rc;
+            if (!unit_k) {
+                rc = layer(u.c2, [&] { return run_conv(net, net->layers[u.c2], Ra, B, h, w, pb_h, pb_w, ho, wo, nullptr, 0, 0, 0, true, 0, 0, Rb, s,
+                                                       nullptr, nullptr, spec(net->act_exp[u.c1], u.c2)); },
+                           (fuse && calib) ? x_exp : dgp_net::H2_NONE, &share_ok);
+                if (rc) return rc;
+            }
             if (calib && can_fuse) { net->unit_fuse_ok[ui] = share_ok ? 1 : 0; fuse = share_ok; }
+            const bool chain = chain_ok && (net->chains[ui].res != 0 || fuse);
             if (u.sc >= 0 && !fuse) {
                 rc = layer(u.sc, [&] { return run_conv(net, net->layers[u.sc], xin, B, h, w, 0, 0, ho, wo, nullptr, 0, 0, 0, false, 0, 0, SC, s,
                                                        nullptr, nullptr, spec(x_exp, u.sc)); });
                 if (rc) return rc;
                 res = SC; res_s = 1; res_H = ho; res_W = wo; res_exp = net->act_exp[u.sc];
             }
-            if (fuse)
-                rc = layer(u.c3, [&] { return run_conv_fused_shortcut(net, u, R2, xin, B, h, w, xout, s, nullptr, nullptr,
+            if (unit_k) {
+                rc = run_chain(net, ui, nullptr, xin, B, ho, wo, h, w, xout, Rb, s, x_exp, Ra);
+                std::swap(Ra, Rb);
+                r1_ready = true;
+            } else if (chain) {
+                rc = run_chain(net, ui, Rb, xin, B, ho, wo, h, w, xout, Ra, s, x_exp);
+                r1_ready = true;
+            } else if (fuse)
+                rc = layer(u.c3, [&] { return run_conv_fused_shortcut(net, u, Rb, xin, B, h, w, xout, s, nullptr, nullptr,
                                                                       spec(x_exp, u.c3)); });      // R2 shares X's scale (calibration)
             else
-                rc = layer(u.c3, [&] { return run_conv(net, net->layers[u.c3], R2, B, ho, wo, 0, 0, ho, wo, res, res_s, res_H, res_W, true, 0,
+                rc = layer(u.c3, [&] { return run_conv(net, net->layers[u.c3], Rb, B, ho, wo, 0, 0, ho, wo, res, res_s, res_H, res_W, true, 0,
                                                        0, xout, s, nullptr, nullptr, spec(net->act_exp[u.c2], u.c3, 1, res_exp)); });
             if (rc) return rc;
             x_exp = net->act_exp[u.c3];
@@ -808,6 +997,7 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
         e = launch_h2_range_check(net->d_amax, net->d_exps, (int)net->layers.size(), net->d_flag, s);
         if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("range check: ") + hipGetErrorString(e));
     }
+    if (calib && chain_env) return dgp_forward(net, frames, batch, workspace, workspace_bytes, scmap, locref, features, stream);   // the chained pass
     if (net->prof_on && net->prof_used < net->prof_slots && !net->prof_in_infer) ++net->prof_used;
     return DGP_OK;
 }
@@ -1124,6 +1314,68 @@ int dgp_conv2d_h2(const dgp_conv_desc* d, const void* x_h2, int32_t x_exp, const
     a.wh3 = cells_scratch; a.wh3_bytes = a.w_bytes;
     hipError_t e = launch_conv(a, pick_tile(a.M, a.CoutP, a.nk * BK, true), (hipStream_t)stream);
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_conv2d_h2: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
+/* conv3 (+ shortcut, ReLU) of a bottleneck unit and conv1 of the next unit as ONE launch on H2 tensors (the engine's chain kernel,
+ * csrc/dgp_chain.hip) -- layer-level entry for tests: weights and BN affines are HOST arrays, packed per call. */
+int dgp_chain_h2(int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t C1, int32_t CIN2, int32_t res_mode, int32_t res_H, int32_t res_W,
+                 const void* r2_h2, int32_t r2_exp, const void* src2_h2, int32_t src2_exp,
+                 const float* w3cat, const float* scale3, const float* bias3, const float* w1, const float* scale1, const float* bias1,
+                 void* xout_h2, int32_t xout_exp, void* r1_h2, int32_t r1_exp, float* xout_absmax, float* r1_absmax, void* stream) {
+    if (!r2_h2 || !src2_h2 || !w3cat || !w1 || !xout_h2 || !r1_h2) return fail(DGP_ERR_INVALID, "dgp_chain_h2: null argument");
+    if (!chain_supported(C, C1, CIN2, res_mode))
+        return fail(DGP_ERR_INVALID, "dgp_chain_h2: no kernel instance for this (C, C1, CIN2, res_mode)");
+    if (res_mode == 0 && src2_exp != r2_exp) return fail(DGP_ERR_INVALID, "dgp_chain_h2: the K-concatenated source must share R2's scale");
+    ChainPlan cp;
+    int rc = build_chain_plan(cp, C, C1, CIN2, res_mode, w3cat, scale3, bias3, w1, scale1, bias1);
+    if (rc) return rc;
+    ChainArgs a{};
+    a.r2 = r2_h2; a.src2 = src2_h2; a.xout = xout_h2; a.r1out = r1_h2; a.wfrag = cp.d_frags; a.sc1 = cp.d_sc1; a.bi1 = cp.d_bi1;
+    a.M = N * Ho * Wo; a.HoWo = Ho * Wo; a.Wo = Wo; a.res_H = res_H; a.res_W = res_W;
+    a.post1 = ldexpf(1.f, -(r2_exp + cp.w3_exp)); a.post2 = ldexpf(1.f, -(xout_exp + cp.w1_exp));
+    a.res_inv_scale = ldexpf(1.f, -src2_exp); a.xout_scale = ldexpf(1.f, xout_exp); a.r1_scale = ldexpf(1.f, r1_exp);
+    a.xout_absmax = xout_absmax; a.r1_absmax = r1_absmax;
+    a.r2_bytes = (unsigned)((size_t)a.M * C * 4); a.xout_bytes = (unsigned)((size_t)a.M * C * 16); a.r1_bytes = (unsigned)((size_t)a.M * C1 * 4);
+    a.src2_bytes = (unsigned)(res_mode == 0 ? (size_t)a.M * CIN2 * 4 : (size_t)N * res_H * res_W * C * 16);
+    a.w_bytes = cp.frag_bytes;
+    hipError_t e = launch_chain(a, C, C1, CIN2, res_mode, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);       // (the fragments are freed below)
+    free_chain_plan(cp);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_chain_h2: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
+/* The unit kernel at layer level (tests): conv2 (3x3, stride 1, SAME) + BN + ReLU of a bottleneck unit, its conv3 + shortcut + ReLU and
+ * conv1 of the next unit in one launch; R2 never leaves the registers. */
+int dgp_unit_h2(int32_t N, int32_t H, int32_t W, int32_t C, int32_t C1, int32_t CIN2, int32_t res_mode,
+                const void* r1_h2, int32_t r1_exp, const void* src2_h2, int32_t src2_exp,
+                const float* w2, const float* scale2, const float* bias2, int32_t r2_exp,
+                const float* w3cat, const float* scale3, const float* bias3, const float* w1, const float* scale1, const float* bias1,
+                void* xout_h2, int32_t xout_exp, void* r1out_h2, int32_t r1out_exp, float* r2_absmax, float* xout_absmax, float* r1_absmax,
+                void* stream) {
+    if (!r1_h2 || !src2_h2 || !w2 || !w3cat || !w1 || !xout_h2 || !r1out_h2) return fail(DGP_ERR_INVALID, "dgp_unit_h2: null argument");
+    if (!unit_supported(C, C1, CIN2, res_mode))
+        return fail(DGP_ERR_INVALID, "dgp_unit_h2: no kernel instance for this (C, C1, CIN2, res_mode)");
+    if (res_mode == 0 && src2_exp != r2_exp) return fail(DGP_ERR_INVALID, "dgp_unit_h2: the K-concatenated source must share R2's scale");
+    if (r1_h2 == r1out_h2) return fail(DGP_ERR_INVALID, "dgp_unit_h2: r1out must not alias r1 (halo reads)");
+    ChainPlan cp;
+    int rc = build_chain_plan(cp, C, C1, CIN2, res_mode, w3cat, scale3, bias3, w1, scale1, bias1, w2, scale2, bias2);
+    if (rc) return rc;
+    ChainArgs a{};
+    a.r1in = r1_h2; a.src2 = src2_h2; a.xout = xout_h2; a.r1out = r1out_h2; a.wfrag = cp.d_frags; a.sc1 = cp.d_sc1; a.bi1 = cp.d_bi1;
+    a.M = N * H * W; a.HoWo = H * W; a.Wo = W; a.res_H = H; a.res_W = W; a.H = H; a.W = W;
+    a.post0 = ldexpf(1.f, -(r1_exp + cp.w2_exp)); a.r2_scale = ldexpf(1.f, r2_exp);
+    a.post1 = ldexpf(1.f, -(r2_exp + cp.w3_exp)); a.post2 = ldexpf(1.f, -(xout_exp + cp.w1_exp));
+    a.res_inv_scale = ldexpf(1.f, -src2_exp); a.xout_scale = ldexpf(1.f, xout_exp); a.r1_scale = ldexpf(1.f, r1out_exp);
+    a.r2_absmax = r2_absmax; a.xout_absmax = xout_absmax; a.r1_absmax = r1_absmax;
+    a.r1in_bytes = (unsigned)((size_t)a.M * C * 4); a.xout_bytes = (unsigned)((size_t)a.M * C * 16); a.r1_bytes = (unsigned)((size_t)a.M * C1 * 4);
+    a.src2_bytes = (unsigned)(res_mode == 0 ? (size_t)a.M * CIN2 * 4 : (size_t)a.M * C * 16);
+    a.w_bytes = cp.frag_bytes;
+    hipError_t e = launch_unit(a, N, C, C1, CIN2, res_mode, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    free_chain_plan(cp);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_unit_h2: ") + hipGetErrorString(e));
     return DGP_OK;
 }
 

@@ -266,6 +266,28 @@ int  dgp_h2_to_f32(const void* x, size_t n_floats, int32_t scale_exp, float* out
 int  dgp_conv2d_h2(const dgp_conv_desc* d, const void* x_h2, int32_t x_exp, const float* packed_w, const float* w_absmax,
                    const float* scale, const float* bias, const void* residual, int32_t res_is_h2, int32_t res_exp, void* y,
                    int32_t y_is_h2, int32_t y_exp, float* y_absmax, void* cells_scratch, void* stream);
+/* The engine's chain kernel at layer level (tests): conv3 of a bottleneck unit + shortcut + ReLU (X', written once) and conv1 of the
+ * NEXT unit (R1') in one launch; conv1 takes X' from the accumulator registers, so the 4C-wide tensor is not re-read.  Replaces two
+ * slim.conv2d calls of consecutive `bottleneck` units (PET/nnet/pose_net.py:46-52 -> slim resnet_v1.bottleneck: conv3 without
+ * activation, relu(shortcut + residual), then conv1 of the next unit).  All device tensors H2 with the given exponents; weights
+ * (row-major [K][N], K = C (+ CIN2 rows of the BN-folded shortcut conv), N = 4 C; w1 [4 C][C1]) and BN affines are HOST arrays.
+ * res_mode: 0 K-concatenated shortcut conv (src2 = its input [M][CIN2], same exponent as r2), 1 identity (src2 = X [M][4C]),
+ * 2 subsample of a stride-2 unit (src2 = X [N, res_H, res_W, 4C], read at (2 ho, 2 wo)).  DGP_ERR_INVALID when no kernel instance
+ * exists for the shape.  Synchronises the stream (per-call weight packing). */
+int  dgp_chain_h2(int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t C1, int32_t CIN2, int32_t res_mode, int32_t res_H, int32_t res_W,
+                  const void* r2_h2, int32_t r2_exp, const void* src2_h2, int32_t src2_exp,
+                  const float* w3cat, const float* scale3, const float* bias3, const float* w1, const float* scale1, const float* bias1,
+                  void* xout_h2, int32_t xout_exp, void* r1_h2, int32_t r1_exp, float* xout_absmax, float* r1_absmax, void* stream);
+/* The engine's unit kernel at layer level (tests; block1 shapes, C = 64): additionally conv2 (3x3, stride 1, SAME, BN, ReLU) of the
+ * unit in front -- slim `bottleneck`'s conv2 -> conv3 -> add -> relu and the next unit's conv1 in ONE launch.  r1 [N, H, W, C] is
+ * conv2's input (read with a one-pixel halo: r1out must be another buffer); R2 exists only in registers (r2_exp: the scale its fp16
+ * fragments are split with; its range is tracked into r2_absmax).  w2: HWIO [3][3][C][C] host array.  Other arguments as dgp_chain_h2. */
+int  dgp_unit_h2(int32_t N, int32_t H, int32_t W, int32_t C, int32_t C1, int32_t CIN2, int32_t res_mode,
+                 const void* r1_h2, int32_t r1_exp, const void* src2_h2, int32_t src2_exp,
+                 const float* w2, const float* scale2, const float* bias2, int32_t r2_exp,
+                 const float* w3cat, const float* scale3, const float* bias3, const float* w1, const float* scale1, const float* bias1,
+                 void* xout_h2, int32_t xout_exp, void* r1out_h2, int32_t r1out_exp, float* r2_absmax, float* xout_absmax, float* r1_absmax,
+                 void* stream);
 /* Synchronises `stream`, then: *overflow = 1 if any forward since the last call outgrew a calibrated scale (the flag is cleared
  * and the net re-calibrates on its next forward); *calibrations = calibration passes run so far. */
 int  dgp_net_range_status(dgp_net* net, int32_t* overflow, int32_t* calibrations, void* stream);
