@@ -54,13 +54,14 @@ __device__ __forceinline__ void st16(__amdgpu_buffer_rsrc_t r, const uint4& v, u
 // conv3 (+ shortcut, ReLU) -> X' -> conv1 -> R1' for the RB row blocks of one wave, one weight chunk per 32 channels of X'
 // (the ring protocol is the caller's: `slot` is the chunk to read first, one barrier per chunk).  ph / pl: the B-operand fragments
 // (pixel lane & 15, k-group lane >> 4) of conv3's K-steps -- R2 first, then the K-concatenated source.
-template <int C, int C1, int CIN2, int RES, int RB, int NS, int PD, int CHUNK>
+template <int C, int C1, int CIN2, int RES, int RB, int NS, int PD, int CHUNK, int WR>
 __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring, int& slot, const uint4 (&ph)[RB][(C + CIN2) / 32],
                                            const uint4 (&pl)[RB][(C + CIN2) / 32], const unsigned (&xoff)[RB], const unsigned (&roff)[RB],
                                            const unsigned (&r1off)[RB], const __amdgpu_buffer_rsrc_t rs_s2, const __amdgpu_buffer_rsrc_t rs_xo,
                                            const __amdgpu_buffer_rsrc_t rs_r1, float& amax_x, float& amax_r1, const int lane) {
     constexpr int C4 = 4 * C, KS1 = (C + CIN2) / 32, NJP = C4 / 32, NCB = C1 / 16;
     constexpr int F1 = KS1 * 4, F2 = NCB * 2;
+    static_assert(WR >= 2 && WR % 2 == 0, "weight fragments in flight: pairs share the ring");
     static_assert(NJP % PD == 0 && PD >= 2, "chunk loop is unrolled PD times");
     const int g = lane >> 4;
     floatx4 a2[RB][NCB];
@@ -91,17 +92,29 @@ __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring
             floatx4 a1[RB][2];
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) { a1[rb][0] = floatx4{0.f, 0.f, 0.f, 0.f}; a1[rb][1] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+            // The weight fragments of the step flow through a ring of WR registers, WR fragments ahead of the MFMAs that use them
+            // (hipcc's own schedule was ds_read -> s_waitcnt 0 -> 2-3 MFMAs: one exposed LDS round trip per fragment pair).  The
+            // fences keep the program order; the waits are then counted by the compiler.
+            uint4 wq[WR];
+#pragma unroll
+            for (int f = 0; f < WR && f < F1 + F2; ++f) wq[f] = W[f * 64];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < KS1; ++s)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    const uint4 wh = W[((s * 2 + b) * 2 + 0) * 64], wl = W[((s * 2 + b) * 2 + 1) * 64];
+                    const int f0 = (s * 2 + b) * 2;
+                    const uint4 wh = wq[f0 % WR], wl = wq[(f0 + 1) % WR];
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb) a1[rb][b] = mma16(wl, ph[rb][s], a1[rb][b]);
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb) a1[rb][b] = mma16(wh, pl[rb][s], a1[rb][b]);
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb) a1[rb][b] = mma16(wh, ph[rb][s], a1[rb][b]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (f0 + WR < F1 + F2) wq[f0 % WR] = W[(f0 + WR) * 64];
+                    if (f0 + 1 + WR < F1 + F2) wq[(f0 + 1) % WR] = W[(f0 + 1 + WR) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             // ---- epilogue of conv3 = operand of conv1: BN affine (x the power of two that undoes the operand scales), shortcut,
             // ReLU, range, split
@@ -129,15 +142,21 @@ __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring
                 }
             }
             // ---- conv1 of the next unit: K-step jp, all C1 columns
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
-                const uint4 wh = W[(F1 + cb * 2 + 0) * 64], wl = W[(F1 + cb * 2 + 1) * 64];
+                const int f0 = F1 + cb * 2;
+                const uint4 wh = wq[f0 % WR], wl = wq[(f0 + 1) % WR];
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) a2[rb][cb] = mma16(wl, xh[rb], a2[rb][cb]);
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) a2[rb][cb] = mma16(wh, xl[rb], a2[rb][cb]);
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) a2[rb][cb] = mma16(wh, xh[rb], a2[rb][cb]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (f0 + WR < F1 + F2) wq[f0 % WR] = W[(f0 + WR) * 64];
+                if (f0 + 1 + WR < F1 + F2) wq[(f0 + 1) % WR] = W[(f0 + 1 + WR) * 64];
+                __builtin_amdgcn_sched_barrier(0);
             }
             slot = slot + 1 == NS ? 0 : slot + 1;
             // (not __syncthreads(): its fences would drain the residual prefetch and the stores; the ring only needs this
@@ -175,8 +194,9 @@ __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring
 // C1    output channels of the next unit's conv1 (C inside a block, 2 C across a block boundary)
 // CIN2  channels of the K-concatenated shortcut source (0: none)
 // RES   0 none (CIN2 > 0), 1 residual on the same pixel grid, 2 residual[n, 2 ho, 2 wo] (subsample of a stride-2 unit)
-// RB    16-row blocks per wave (1 or 2); NCW compute waves, NLW loader waves, NS ring slots, PD residual buffers (PD - 1 chunks ahead)
-template <int C, int C1, int CIN2, int RES, int RB, int NCW, int NLW, int NS, int PD>
+// RB    16-row blocks per wave (1 or 2); NCW compute waves, NLW loader waves, NS ring slots, PD residual buffers (PD - 1 chunks ahead),
+//       WR weight fragments in flight per wave
+template <int C, int C1, int CIN2, int RES, int RB, int NCW, int NLW, int NS, int PD, int WR>
 __global__ __launch_bounds__(64 * (NCW + NLW)) void chain_kernel(const ChainArgs p) {
     constexpr int C4 = 4 * C;
     constexpr int KSA = C / 32, KSB = CIN2 / 32, KS1 = KSA + KSB;      // K-steps of conv3: R2, then the second source
@@ -187,7 +207,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void chain_kernel(const ChainArgs
     constexpr int TILE = 16 * RB * NCW;
     static_assert(NJP % PD == 0 && PD >= 2, "chunk loop is unrolled PD times");
     static_assert(RES == 0 || CIN2 == 0, "residual or K-concatenated shortcut, not both");
-    static_assert(NS == 3, "ring protocol below: chunk it + 2 is issued after barrier it - 1");
+    static_assert(NS == 2 || NS == 3, "ring protocols of the loader below");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -213,14 +233,27 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void chain_kernel(const ChainArgs
                 jp = jp + 1 == NJP ? 0 : jp + 1;
                 slot = slot + 1 == NS ? 0 : slot + 1;
             };
-            if (total > 0) issue();
-            if (total > 1) { issue(); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory"); }
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                              // B(-1): chunk 0 has landed
-            for (int it = 0; it < total; ++it) {
-                if (it + 2 < total) { issue(); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory"); }      // chunk it + 1 has landed
+            if constexpr (NS == 3) {
+                // chunk it + 2 is issued after barrier it - 1 (every wave has left slot (it - 1) % 3); chunk it + 1 has landed before barrier it
+                if (total > 0) issue();
+                if (total > 1) { issue(); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory"); }
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();                          // B(it)
+                __builtin_amdgcn_s_barrier();                          // B(-1): chunk 0 has landed
+                for (int it = 0; it < total; ++it) {
+                    if (it + 2 < total) { issue(); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory"); }
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                      // B(it)
+                }
+            } else {
+                // two slots (large chunks): chunk it + 1 is issued after barrier it - 1 and must land during step it
+                if (total > 0) issue();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                          // B(-1)
+                for (int it = 0; it < total; ++it) {
+                    if (it + 1 < total) issue();
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                      // B(it)
+                }
             }
         };
         constexpr int NI_HI = (NF + NLW - 1) / NLW, NI_LO = NF / NLW;
@@ -262,7 +295,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void chain_kernel(const ChainArgs
                 for (int s = 0; s < KSB; ++s) { ph[rb][KSA + s] = ld16(rs_s2, boff, s * 128); pl[rb][KSA + s] = ld16(rs_s2, boff, s * 128 + 16); }
             }
         }
-        chain_tail<C, C1, CIN2, RES, RB, NS, PD, CHUNK>(p, ring, slot, ph, pl, xoff, roff, r1off, rs_s2, rs_xo, rs_r1, amax_x, amax_r1, lane);
+        chain_tail<C, C1, CIN2, RES, RB, NS, PD, CHUNK, WR>(p, ring, slot, ph, pl, xoff, roff, r1off, rs_s2, rs_xo, rs_r1, amax_x, amax_r1, lane);
     }
     // both tensors are post-ReLU: max = max |.|
     if (p.xout_absmax) track_absmax(p.xout_absmax, amax_x, lane, (int)(blockIdx.x * 8u + (unsigned)wave));
@@ -286,7 +319,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void chain_kernel(const ChainArgs
 // Weights: 9 chunks for conv2 (one tap each: [ks][cb][plane] fragments + conv2's BN affine) followed by the chain's chunks, through
 // the same ring; 9 + 8 barriers per tile.
 // Tiles are dealt so that workgroups on one XCD (blockIdx & 7) work on neighbouring tiles: halo rows are re-read from that L2.
-template <int C, int C1, int CIN2, int RES, int NCW, int NLW, int PD>
+template <int C, int C1, int CIN2, int RES, int NCW, int NLW, int PD, int WR>
 __global__ __launch_bounds__(64 * (NCW + NLW)) void unit_kernel(const ChainArgs p) {
     constexpr int NS = 3;
     constexpr int TH = NCW, TW = 16, HW = TW + 2, HPIX = (TH + 2) * HW;
@@ -419,17 +452,32 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void unit_kernel(const ChainArgs 
             const int hp = (wave + t / 3) * HW + l15 + t % 3;
             const char* hrow = halo + hp * PIXB;
             const int sw = hp & 15;
+            // pixel fragments of the tap (all K-steps) first, then the weight fragments through the ring (see chain_tail)
+            uint4 ah[KS2], al[KS2];
 #pragma unroll
             for (int ks = 0; ks < KS2; ++ks) {
                 const int sl = 2 * (4 * ks + g);
-                const uint4 ah = *reinterpret_cast<const uint4*>(hrow + ((sl ^ sw) << 4));
-                const uint4 al = *reinterpret_cast<const uint4*>(hrow + (((sl + 1) ^ sw) << 4));
+                ah[ks] = *reinterpret_cast<const uint4*>(hrow + ((sl ^ sw) << 4));
+                al[ks] = *reinterpret_cast<const uint4*>(hrow + (((sl + 1) ^ sw) << 4));
+            }
+            constexpr int NW2 = KS2 * NCB2 * 2;
+            uint4 wq[WR];
+#pragma unroll
+            for (int f = 0; f < WR && f < NW2; ++f) wq[f] = W[f * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {
 #pragma unroll
                 for (int cb = 0; cb < NCB2; ++cb) {
-                    const uint4 wh = W[((ks * NCB2 + cb) * 2 + 0) * 64], wl = W[((ks * NCB2 + cb) * 2 + 1) * 64];
-                    acc[cb] = mma16(wl, ah, acc[cb]);
-                    acc[cb] = mma16(wh, al, acc[cb]);
-                    acc[cb] = mma16(wh, ah, acc[cb]);
+                    const int f0 = (ks * NCB2 + cb) * 2;
+                    const uint4 wh = wq[f0 % WR], wl = wq[(f0 + 1) % WR];
+                    acc[cb] = mma16(wl, ah[ks], acc[cb]);
+                    acc[cb] = mma16(wh, al[ks], acc[cb]);
+                    acc[cb] = mma16(wh, ah[ks], acc[cb]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (f0 + WR < NW2) wq[f0 % WR] = W[(f0 + WR) * 64];
+                    if (f0 + 1 + WR < NW2) wq[(f0 + 1) % WR] = W[(f0 + 1 + WR) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (t == 8) {                                              // conv2's BN affine rides in the last tap's chunk
@@ -459,7 +507,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void unit_kernel(const ChainArgs 
                 for (int k = 0; k < 8; ++k) amax_r2 = fmaxf(amax_r2, o[k]);
             }
         }
-        chain_tail<C, C1, CIN2, RES, 1, NS, PD, CHUNK>(p, ring, slot, ph, pl, xoff, roff, r1off, rs_s2, rs_xo, rs_r1, amax_x, amax_r1, lane);
+        chain_tail<C, C1, CIN2, RES, 1, NS, PD, CHUNK, WR>(p, ring, slot, ph, pl, xoff, roff, r1off, rs_s2, rs_xo, rs_r1, amax_x, amax_r1, lane);
     }
     if (p.xout_absmax) track_absmax(p.xout_absmax, amax_x, lane, (int)(blockIdx.x * 8u + (unsigned)wave));
     if (p.r1_absmax) track_absmax(p.r1_absmax, amax_r1, lane, (int)(blockIdx.x * 8u + (unsigned)wave) + 97);
@@ -505,13 +553,12 @@ hipError_t launch_chain_pack(const float* src, int n_chunks, int f1_pairs, int f
 
 namespace {
 
-template <int C, int C1, int CIN2, int RES, int RB, int NCW, int NLW, int PD>
+template <int C, int C1, int CIN2, int RES, int RB, int NCW, int NLW, int PD, int NS = 3, int WR = 4>
 hipError_t launch_chain_t(const ChainArgs& a0, hipStream_t s) {
-    constexpr int NS = 3;
     constexpr int NF = (C + CIN2) / 32 * 4 + C1 / 16 * 2 + 1;
     constexpr int LDS = NS * NF * 1024;
     static_assert(LDS <= 160 * 1024, "ring does not fit the LDS");
-    auto kern = chain_kernel<C, C1, CIN2, RES, RB, NCW, NLW, NS, PD>;
+    auto kern = chain_kernel<C, C1, CIN2, RES, RB, NCW, NLW, NS, PD, WR>;
     static bool attr_done[16] = {};
     static int wgs_per_cu[16] = {};
     const int dev = dgp_device_slot();
@@ -537,12 +584,12 @@ hipError_t launch_chain_t(const ChainArgs& a0, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int C, int C1, int CIN2, int RES, int NCW, int NLW, int PD>
+template <int C, int C1, int CIN2, int RES, int NCW, int NLW, int PD, int WR = 4>
 hipError_t launch_unit_t(const ChainArgs& a0, int N, hipStream_t s) {
     constexpr int NFJ = (C + CIN2) / 32 * 4 + C1 / 16 * 2 + 1, NF2 = (C / 32) * (C / 16) * 2 + 1, NFMAX = NFJ > NF2 ? NFJ : NF2;
     constexpr int LDS = ((NCW + 2) * 18 * C * 4 + 1023) / 1024 * 1024 + 3 * NFMAX * 1024;
     static_assert(LDS <= 160 * 1024, "halo tile + ring do not fit the LDS");
-    auto kern = unit_kernel<C, C1, CIN2, RES, NCW, NLW, PD>;
+    auto kern = unit_kernel<C, C1, CIN2, RES, NCW, NLW, PD, WR>;
     static bool attr_done[16] = {};
     static int wgs_per_cu[16] = {};
     const int dev = dgp_device_slot();
@@ -576,6 +623,7 @@ bool chain_supported(int C, int C1, int CIN2, int res) {
     if (C == 64 && C1 == 128 && CIN2 == 0 && res == 2) return true;
     if (C == 128 && C1 == 128 && CIN2 == 0 && res == 1) return true;
     if (C == 128 && C1 == 256 && CIN2 == 0 && res == 2) return true;
+    if (C == 256 && C1 == 256 && CIN2 == 0 && res == 1) return true;
     return false;
 }
 
@@ -586,14 +634,14 @@ bool unit_supported(int C, int C1, int CIN2, int res) {
 hipError_t launch_unit(const ChainArgs& a, int N, int C, int C1, int CIN2, int res, hipStream_t s) {
     static const int cfg = getenv("DGP_UNIT_CFG") ? atoi(getenv("DGP_UNIT_CFG")) : 0;      // tuning: tile rows / loader waves
     if (C == 64 && C1 == 64 && CIN2 == 0 && res == 1) {
-        if (cfg == 1) return launch_unit_t<64, 64, 0, 1, 4, 1, 4>(a, N, s);
-        if (cfg == 2) return launch_unit_t<64, 64, 0, 1, 8, 2, 4>(a, N, s);
-        if (cfg == 3) return launch_unit_t<64, 64, 0, 1, 10, 2, 4>(a, N, s);
-        return launch_unit_t<64, 64, 0, 1, 10, 2, 2>(a, N, s);
+        if (cfg == 1) return launch_unit_t<64, 64, 0, 1, 10, 2, 2, 2>(a, N, s);
+        if (cfg == 2) return launch_unit_t<64, 64, 0, 1, 10, 2, 2, 4>(a, N, s);
+        return launch_unit_t<64, 64, 0, 1, 8, 2, 2, 4>(a, N, s);
     }
     if (C == 64 && C1 == 64 && CIN2 == 64 && res == 0) {
-        if (cfg == 2) return launch_unit_t<64, 64, 64, 0, 8, 2, 2>(a, N, s);
-        return launch_unit_t<64, 64, 64, 0, 10, 2, 2>(a, N, s);
+        if (cfg == 1) return launch_unit_t<64, 64, 64, 0, 10, 2, 2, 4>(a, N, s);
+        if (cfg == 2) return launch_unit_t<64, 64, 64, 0, 10, 2, 2, 8>(a, N, s);
+        return launch_unit_t<64, 64, 64, 0, 8, 2, 2, 8>(a, N, s);
     }
     return hipErrorInvalidValue;
 }
@@ -625,11 +673,19 @@ hipError_t launch_chain(const ChainArgs& a, int C, int C1, int CIN2, int res, hi
         return launch_chain_t<64, 128, 0, 2, 1, 8, 1, 4>(a, s);
     }
     if (C == 128 && C1 == 128 && CIN2 == 0 && res == 1) {
-        if (cfg == 2) return launch_chain_t<128, 128, 0, 1, 1, 12, 2, 2>(a, s);
-        return launch_chain_t<128, 128, 0, 1, 1, 8, 2, 4>(a, s);
+        if (cfg == 1) return launch_chain_t<128, 128, 0, 1, 1, 8, 2, 4, 3, 4>(a, s);
+        if (cfg == 2) return launch_chain_t<128, 128, 0, 1, 1, 8, 2, 2, 3, 8>(a, s);
+        if (cfg == 3) return launch_chain_t<128, 128, 0, 1, 1, 6, 2, 2, 3, 8>(a, s);
+        return launch_chain_t<128, 128, 0, 1, 1, 8, 2, 2, 3, 4>(a, s);
     }
     if (C == 128 && C1 == 256 && CIN2 == 0 && res == 2) {
         return launch_chain_t<128, 256, 0, 2, 1, 6, 2, 4>(a, s);
+    }
+    if (C == 256 && C1 == 256 && CIN2 == 0 && res == 1) {          // 65-KiB chunks: two ring slots, one workgroup per CU
+        if (cfg == 1) return launch_chain_t<256, 256, 0, 1, 1, 4, 2, 2, 2, 8>(a, s);
+        if (cfg == 2) return launch_chain_t<256, 256, 0, 1, 1, 6, 2, 2, 2, 8>(a, s);
+        if (cfg == 3) return launch_chain_t<256, 256, 0, 1, 1, 5, 2, 2, 2, 4>(a, s);
+        return launch_chain_t<256, 256, 0, 1, 1, 5, 2, 2, 2, 8>(a, s);
     }
     return hipErrorInvalidValue;
 }

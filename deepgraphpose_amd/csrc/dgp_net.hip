@@ -445,6 +445,10 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
         const ConvLayer &l3 = net->layers[u.c3], &l1 = net->layers[un.c1];
         if (l3.KH != 1 || l1.KH != 1 || l1.stride != 1 || l3.Cout != 4 * l3.Cin || l1.Cin != l3.Cout) continue;
         const int C = l3.Cin, C1 = l1.Cout;
+        // block3 (C = 256): the kernel instance exists and is tested, but with 65-KiB weight chunks per 80 pixels it is paced by the
+        // weight stream (0.18 ms per pair against 0.17 layer by layer on the batch-32 shapes): off unless DGP_CHAIN_WIDE=1
+        static const bool wide_env = getenv("DGP_CHAIN_WIDE") && atoi(getenv("DGP_CHAIN_WIDE")) != 0;
+        if (C > 128 && !wide_env) continue;
         const ConvLayer& l2 = net->layers[u.c2];
         const bool c2_plain = l2.KH == 3 && l2.stride == 1 && l2.rate == 1 && l2.Cin == C && l2.Cout == C;      // conv2 the unit kernel can take
         const float *w2 = c2_plain ? keep_w[u.c2].data() : nullptr, *s2 = c2_plain ? keep_scale[u.c2].data() : nullptr,

@@ -17,6 +17,8 @@ CASES = [
     (2, 15, 20, 64, 128, 0, 2),       # stride-2 unit at the end of block1 -> block2 unit_1's conv1
     (2, 15, 20, 128, 128, 0, 1),      # identity unit of block2
     (2, 8, 10, 128, 256, 0, 2),       # end of block2 -> block3 unit_1's conv1
+    (2, 30, 40, 256, 256, 0, 1),      # identity unit of block3 (65-KiB weight chunks: two-slot ring)
+    (32, 30, 40, 256, 256, 0, 1),     # ... at batch 32 (480 tiles over 256 persistent workgroups)
     (32, 120, 160, 64, 64, 0, 1),     # full batch-32 640x480 shape of block1 (4800 tiles: persistent workgroups wrap the chunk ring)
 ]
 
