@@ -11,6 +11,8 @@ reassembles the [T, nj] trajectory: weak scaling.
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...            # no launcher: spawns its own N worker processes (one per GPU, RCCL over 127.0.0.1)
+    python bench.py --gpus N --scaling strong --total-batches 1024   # ONE fixed stream of 32768 frames split over the N ranks
 
 Rank 0 prints ONE JSON line.  Extra objects: "roofline" (conv kernel, MFMA-bound, fp32 matrix
 peak) from hipEvent pairs recorded around every launch inside the timed region, and
@@ -33,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16)
+PEAK_HBM_TBPS = 8.0               # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s measured for a plain copy)
 
 
 def kernel_peak(kernel: str) -> float:
@@ -40,7 +43,7 @@ def kernel_peak(kernel: str) -> float:
     per fp32-equivalent product, so their ceiling is the dense bf16 peak / 6 (/ 3)."""
     if kernel.startswith("split6"):
         return PEAK_BF16_MFMA_TFLOPS / 6.0
-    if kernel.startswith("split3") or kernel.startswith("splith3") or kernel.startswith("stem_pool_fused"):     # fp16 dense peak = bf16 dense peak
+    if kernel.startswith(("split3", "splith3", "stem_pool_fused", "chain_", "unit_")):     # fp16 dense peak = bf16 dense peak
         return PEAK_BF16_MFMA_TFLOPS / 3.0
     return PEAK_F32_MFMA_TFLOPS
 H, W, NJ, BATCH = 480, 640, 4, 32
@@ -71,6 +74,89 @@ def _read_sclk_mhz(card_index: int = 0):
     return None
 
 
+def spawn_workers(args) -> None:
+    """`python bench.py --gpus N` without a launcher: start N worker processes (one per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    their environment, exactly what torch.distributed.run would set), relay rank 0's JSON line and exit with the workers' worst return
+    code.  This parent never initialises the GPU (no HIP call, no torch.cuda query) and never exec()s."""
+    import socket
+    import subprocess
+    n = max(1, args.gpus)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    visible = int(os.environ.get("DGP_BENCH_VISIBLE_GPUS", n))      # tests: several ranks on one GPU (with DGP_DIST_BACKEND=gloo)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % max(1, visible)), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), DGP_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{"):
+            line = ln
+        else:
+            print(ln, flush=True)
+    if line is not None:
+        try:
+            d = json.loads(line)
+            d["launcher"] = "bench.py spawned %d worker process(es) itself (no torch.distributed.run)" % n
+            line = json.dumps(d)
+        except ValueError:
+            pass
+        print(line, flush=True)
+    rc = max(abs(c) for c in rcs)
+    if rc or line is None:
+        raise SystemExit(rc or 1)
+
+
+def strict_f32_child(args) -> None:
+    """Fresh process started by the N = 1 run with DGP_CONV_MODE=f32 in its environment: the same workload on the fp32 MFMA kernels
+    (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain; fp32 activations), a few steps, one small JSON line."""
+    from deepgraphpose_amd import engine
+    from deepgraphpose_amd.arch import conv_macs_per_frame
+    from deepgraphpose_amd.synthetic import make_frames, make_weights
+    assert os.environ.get("DGP_CONV_MODE") == "f32"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    B, K = args.batch, max(3, min(args.steps, 10))
+    wts = make_weights(50, NJ, False, seed=0, head_std=0.05)
+    net = engine.DGPNet(50, NJ, H, W, max_batch=B, device=0)
+    net.load_weights(wts)
+    base = make_frames(8, H, W, NJ, seed=100)
+    g = torch.Generator().manual_seed(1234)
+    sel = torch.randint(0, base.shape[0], (B,), generator=g).numpy()
+    noise = torch.randint(-3, 4, (B, H, W, 3), generator=g, dtype=torch.int16).numpy()
+    fr = torch.from_numpy(np.clip(base[sel].astype(np.int16) + noise, 0, 255).astype(np.uint8)).to(dev)      # = ring[0] of the main run
+    out = torch.zeros((B, NJ, 5), dtype=torch.float32, device=dev)
+    for _ in range(3):
+        net.infer_packed(fr, out, 1.0, 1)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(K):
+        net.infer_packed(fr, out, 1.0, 1)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    fps = K * B / (t1 - t0)
+    res = {"frames_per_s": round(fps, 1), "steps": K, "ms_per_step": round((t1 - t0) / K * 1e3, 3),
+           "frac_of_fp32_mfma_peak": round(fps * 2.0 * conv_macs_per_frame(H, W, 50, NJ, False) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+           "kernels": "conv_igemm_f32 / conv_igemm_f32_ls (DGP_CONV_MODE=f32: IEEE fp32 products and activations)"}
+    if not args.no_cpu_baseline:
+        from oracle import dgp_oracle as O      # checker only
+        ncmp = 4
+        ref = O.infer(fr[:ncmp].cpu().numpy(), wts, 50, STRIDE, 1.0, 1)
+        m, c, ix = net.infer(fr[:ncmp].contiguous(), 1.0, 1)
+        m = m.cpu().numpy().astype(np.float64)
+        ex = m[:, :, 1] * STRIDE + 0.5 * STRIDE - ref["x"][:ncmp]
+        ey = m[:, :, 0] * STRIDE + 0.5 * STRIDE - ref["y"][:ncmp]
+        res["px_max"] = float(np.sqrt(ex ** 2 + ey ** 2).max())
+        res["idx_bit_exact"] = bool(np.array_equal(ix.cpu().numpy(), ref["idx"][:ncmp]))
+    print(json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,7 +172,18 @@ def main():
     ap.add_argument("--prewarm-seconds", type=float, default=1.5, help="untimed load before the warm-up steps (clock ramp, calibration)")
     ap.add_argument("--sustain-seconds", type=float, default=5.0, help="length of the sustained segment after the timed region")
     ap.add_argument("--streams", type=int, default=2, help="engines / HIP streams the batches are dealt to (1: single stream)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --steps batches per GPU; strong: --total-batches batches in all, rank r runs its contiguous share")
+    ap.add_argument("--total-batches", type=int, default=1024, help="strong scaling: batches of the one fixed stream (1024 x 32 = 32768 frames)")
+    ap.add_argument("--no-strict-f32", action="store_true", help="skip the DGP_CONV_MODE=f32 child run (IEEE fp32 MFMA tier) after the timed region")
+    ap.add_argument("--strict-f32-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.strict_f32_child:
+        return strict_f32_child(args)
+    # No launcher around us and more than one GPU asked for (or DGP_BENCH_FORCE_SPAWN=1): this process only spawns the workers -- it never
+    # touches the GPU -- and relays rank 0's line.
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("DGP_BENCH_FORCE_SPAWN") == "1"):
+        return spawn_workers(args)
 
     from deepgraphpose_amd import dist as ddist
     from deepgraphpose_amd import engine
@@ -102,6 +199,10 @@ def main():
     torch.cuda.set_device(dev)
 
     B, K, Wm = args.batch, args.steps, args.warmup
+    if args.scaling == "strong":      # one fixed stream, independent of N: rank r runs batches [r TB / N, (r + 1) TB / N)
+        if args.total_batches % world:
+            raise SystemExit("bench.py: --total-batches %d must be a multiple of --gpus %d" % (args.total_batches, world))
+        K = args.total_batches // world
     wts = make_weights(50, NJ, False, seed=0, head_std=0.05)
     # two engines on two HIP streams, batches dealt in turn (engine.DGPPipeline): the grid tail of one batch's layers runs under the
     # other batch's kernels.  --streams 1 is the plain single-stream loop
@@ -237,23 +338,23 @@ def main():
     conv_flops = sum(f for _, f, _ in conv)
     other_ms = sum(ms for n, _, ms in launches if not n.startswith("conv:"))
     stack_tf = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    from deepgraphpose_amd.arch import conv_algorithmic_bytes
-    alg_bytes = conv_algorithmic_bytes(H, W, 50, B)
+    from deepgraphpose_amd.arch import launch_algorithmic_bytes
+    alg_bytes = {n: launch_algorithmic_bytes(n, H, W, 50, B) for n, _, _ in conv}      # per launch name (fused launches: external tensors only)
     # per-kernel breakdown (the engine tags every conv launch with the kernel it ran); the roofline object is for
     # the DOMINANT kernel = the one with the largest share of the step
     by_kernel = {}
     for n, f, ms in conv:
         k = n.split("|")[1] if "|" in n else "f32"
-        e = by_kernel.setdefault(k, [0, 0.0, 0.0])
-        e[0] += 1; e[1] += f; e[2] += ms
+        e = by_kernel.setdefault(k, [0, 0.0, 0.0, 0.0])
+        e[0] += 1; e[1] += f; e[2] += ms; e[3] += alg_bytes.get(n, 0.0)
     dom = max(by_kernel, key=lambda k: by_kernel[k][2])
-    d_n, d_f, d_ms = by_kernel[dom]
+    d_n, d_f, d_ms, _ = by_kernel[dom]
     achieved = d_f / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0
     peak = kernel_peak(dom)
     n_mfma = "6" if dom.startswith("split6") else "3"
     mfma_kind = "f16" if dom.startswith("splith") else "bf16"
     kname = {"f32": "conv_igemm_f32 / conv_igemm_f32_ls (v_mfma_f32_32x32x2_f32)"}.get(
-        dom, "conv_igemm_split_ls<%s> (fp32-class products as %s v_mfma_f32_32x32x16_%s)" % (dom, n_mfma, mfma_kind))
+        dom, "conv_igemm_split_ls<%s> (fp32-class products as %s v_mfma_f32_16x16x32_%s)" % (dom, n_mfma, mfma_kind))
     roofline = {
         "bound": "mfma", "kernel": "%s, %d of the %d conv launches of a step" % (kname, d_n, len(conv)),
         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
@@ -262,9 +363,16 @@ def main():
                        "ALGORITHMIC conv FLOPs" % (mfma_kind, PEAK_BF16_MFMA_TFLOPS, n_mfma)) if dom.startswith("split")
                       else "dense fp32 MFMA peak",
         "kernel_ms_per_step": round(d_ms, 3),
+        # every conv kernel against BOTH roofs: matrix pipe (algorithmic FLOPs) and HBM (algorithmic bytes of its launches: tensors
+        # that enter or leave a launch once + weights; the chain / unit kernels keep X' / R2 on chip, so their bytes are fewer)
         "kernels": {k: {"launches": v[0], "ms_per_step": round(v[2], 3), "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 1),
-                        "frac_of_its_peak": round(v[1] / (v[2] * 1e-3) / 1e12 / kernel_peak(k), 4)}
+                        "frac_of_its_peak": round(v[1] / (v[2] * 1e-3) / 1e12 / kernel_peak(k), 4),
+                        "algorithmic_gb_per_step": round(v[3] / 1e9, 3),
+                        "hbm_tbps_algorithmic": round(v[3] / (v[2] * 1e-3) / 1e12, 2),
+                        "frac_of_hbm_peak": round(v[3] / (v[2] * 1e-3) / 1e12 / PEAK_HBM_TBPS, 4),
+                        "bound": "hbm" if v[3] / (v[2] * 1e-3) / 1e12 / PEAK_HBM_TBPS > v[1] / (v[2] * 1e-3) / 1e12 / kernel_peak(k) else "mfma"}
                     for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][2])},
+        "conv_stack_algorithmic_gb_per_step": round(sum(alg_bytes.values()) / 1e9, 3),
         "conv_stack_tflops": round(stack_tf, 2),
         "conv_stack_vs_fp32_mfma_peak": round(stack_tf / PEAK_F32_MFMA_TFLOPS, 4),
         "algorithmic_gflop_per_frame": round(flop_frame / 1e9, 3),
@@ -274,9 +382,7 @@ def main():
     # HBM traffic of the dominant kernel, per launch, from the committed rocprofv3 PMC passes of this same command
     # (scripts/profile.sh -> profiles/traffic_r1.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate
     # passes); null when no profile of this kernel has been taken.
-    tj = os.path.join(ROOT, "profiles", "traffic_r2.json")
-    if not os.path.exists(tj):
-        tj = os.path.join(ROOT, "profiles", "traffic_r1.json")
+    tj = next((q for q in (os.path.join(ROOT, "profiles", "traffic_r%d.json" % r) for r in (3, 2, 1)) if os.path.exists(q)), "")
     if os.path.exists(tj):
         try:
             tr = json.load(open(tj))
@@ -291,8 +397,7 @@ def main():
                     roofline["traffic_unit"] = ("bytes per launch of the dominant kernel (launch-weighted mean of its loader specialisations), PMC "
                                                 "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE at the L2's memory side: Infinity-Cache hits and "
                                                 "the weights fetched once per XCD are included")
-                    roofline["algorithmic_bytes_per_launch"] = round(sum(
-                        alg_bytes.get(n.split("|")[0], 0.0) for n, _, _ in conv if n.endswith("|" + dom)) / d_n, 1)
+                    roofline["algorithmic_bytes_per_launch"] = round(by_kernel[dom][3] / d_n, 1)
             roofline["conv_stack_hbm_bytes_per_step"] = float(tr["conv_hbm_bytes_per_step"])
             roofline["traffic_source"] = "profiles/%s (rocprofv3 --pmc passes of this command, NOT measured in this run)" % os.path.basename(tj)
         except Exception:
@@ -315,7 +420,7 @@ def main():
     out = {
         "metric": "frames_per_sec", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
         "steps": K, "warmup": Wm, "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "dtype_note": ("fp32-class arithmetic: fp32 accumulation, every operand carries 22 significant bits as an fp16 high/low pair (products as "
                        "3 MFMAs on the 16-bit matrix pipe); activations live in HBM in that form (H2 cells, same bytes as fp32, scaled by a "
                        "calibrated power of two per tensor), weights are pre-split at load; error vs fp64 <= the fp32-MFMA kernels' "
@@ -323,7 +428,8 @@ def main():
                       if any(k.startswith("split") for k in by_kernel) else "fp32 MFMA (bitwise fmaf chains)",
         "config": {"workload": "ResNet-50 640x480x3 u8, 4 keypoints, batch %d/GPU, inference "
                                "(scoremap + DGP soft-argmax + likelihood), BASELINE configs[1]" % B,
-                   "frames_per_step_per_gpu": B, "sharding": "contiguous frame shards, 1 RCCL all-gather per run"},
+                   "frames_per_step_per_gpu": B, "sharding": "contiguous frame shards, 1 RCCL all-gather per run",
+                   "total_frames": world * n_local},
         "roofline": roofline,
         "sustained": sustained,
         "shard_check": shard_check,
@@ -371,6 +477,22 @@ def main():
             "px_rmse": float(np.sqrt((err ** 2).mean())), "px_max": float(err.max()), "frames": ncmp,
             "idx_bit_exact": bool(np.array_equal(ix.cpu().numpy(), ref["idx"][:ncmp])),
         }
+    if world == 1 and not args.no_strict_f32:
+        # the IEEE-fp32 tier beside the fp32-class one, timed in THIS run: a fresh child process (the conv mode is read once per
+        # process) runs the same workload on the fp32 MFMA kernels for a few steps
+        import subprocess
+        env = dict(os.environ, DGP_CONV_MODE="f32")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE"):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.abspath(__file__), "--strict-f32-child", "--batch", str(B), "--steps", "8"]
+        if args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        try:
+            cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+            ln = [q for q in cp.stdout.splitlines() if q.startswith("{")]
+            out["strict_f32"] = json.loads(ln[-1]) if cp.returncode == 0 and ln else {"error": (cp.stderr or cp.stdout)[-300:]}
+        except Exception as e:      # noqa: BLE001 -- the main line must still be printed
+            out["strict_f32"] = {"error": repr(e)[:300]}
     print(json.dumps(out), flush=True)
     if use_pg:
         dist.destroy_process_group()

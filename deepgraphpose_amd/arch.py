@@ -108,6 +108,70 @@ def conv_macs_per_frame(h: int, w: int, depth: int = 50, nj: int = 4,
     return macs
 
 
+def launch_algorithmic_bytes(name: str, h: int, w: int, depth: int = 50, batch: int = 1) -> float:
+    """Algorithmic HBM bytes of ONE backbone launch of the engine, from its profile name ("conv:<scope>[+<scope>...]|<kernel>",
+    dgp_net_profile_launch): every tensor that enters or leaves the launch once (4 bytes per value: H2 cells are as large as fp32)
+    plus the weights.  Tensors that stay inside a fused launch are not counted: the shortcut tensor of conv3+shortcut, X' between
+    conv3 and the next unit's conv1 (chain kernel: written once, not re-read), R2 between conv2 and conv3 (unit kernel).
+    0.0 for names that are not backbone convs (stem, heads)."""
+    body = name.split("|")[0]
+    if not body.startswith("conv:"):
+        return 0.0
+    if body.endswith("/conv1+pool"):      # fused root block: uint8 frames in, pool output out, 7x7x3x64 weights
+        h1, w1 = same_out(h, 2), same_out(w, 2)
+        return float(batch * h * w * 3 + 4 * batch * same_out(h1, 2) * same_out(w1, 2) * 64 + 4 * 7 * 7 * 3 * 64)
+    toks = body[5:].split("+")
+    units = {u.scope: (i, u) for i, u in enumerate(resnet_units(depth))}
+    plan = resnet_units(depth)
+    # geometry of every unit's input
+    h1, w1 = same_out(h, 2), same_out(w, 2)
+    hh, ww = same_out(h1, 2), same_out(w1, 2)
+    geo = []
+    for u in plan:
+        ho, wo = same_out(hh, u.stride), same_out(ww, u.stride)
+        geo.append((batch * hh * ww, batch * ho * wo))
+        hh, ww = ho, wo
+    convs = []                      # (unit index, which)
+    for t in toks:
+        if t == "shortcut":
+            convs.append((convs[-1][0], "shortcut"))
+            continue
+        scope, _, which = t.rpartition("/")
+        if scope not in units:
+            return 0.0
+        convs.append((units[scope][0], which))
+    have = set(convs)
+    total = 0.0
+    for ui, which in convs:
+        u = plan[ui]
+        pin, pout = geo[ui]
+        if which == "conv1":
+            total += u.depth_in * u.depth_bottleneck                                    # weights
+            total += pin * u.depth_bottleneck                                           # R1 out
+            if (ui - 1, "conv3") not in have:
+                total += pin * u.depth_in                                               # X in (chain: comes from the registers)
+        elif which == "conv2":
+            total += 9 * u.depth_bottleneck * u.depth_bottleneck
+            total += pin * u.depth_bottleneck                                           # R1 in
+            if (ui, "conv3") not in have:
+                total += pout * u.depth_bottleneck                                      # R2 out (unit kernel: stays in registers)
+        elif which == "conv3":
+            total += u.depth_bottleneck * u.depth + pout * u.depth                      # weights, X' out
+            if (ui, "conv2") not in have:
+                total += pout * u.depth_bottleneck                                      # R2 in
+            if (ui, "shortcut") in have:
+                total += pin * u.depth_in                                               # the shortcut conv's input, read once
+            elif u.has_shortcut_conv:
+                total += pout * u.depth                                                 # separately computed shortcut tensor
+            else:
+                total += (pin if u.stride == 1 else pout) * u.depth                     # identity / subsampled residual
+        elif which == "shortcut":
+            total += u.depth_in * u.depth
+            if (ui, "conv3") not in have:
+                total += pin * u.depth_in + pout * u.depth
+    return 4.0 * total
+
+
 def conv_algorithmic_bytes(h: int, w: int, depth: int = 50, batch: int = 1) -> dict:
     """{TF scope of a backbone conv: algorithmic HBM bytes of one launch at `batch` frames}: fp32 input read once
     + output written once + residual read once (conv3) + the weights.  Layer-by-layer execution, no fusion."""

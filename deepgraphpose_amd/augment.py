@@ -21,6 +21,8 @@ import numpy as np
 class NumpyAugPipeline:
     def __init__(self, apply_prob: float = 0.5, seed=None):
         self.p = float(apply_prob)
+        if seed is None:        # reproducible under np.random.seed(...) like the rest of the fit drivers' schedule (not OS entropy)
+            seed = int(np.random.randint(0, 2 ** 31 - 1))
         self.rng = np.random.RandomState(seed)
         self.bulk = np.random.Generator(np.random.PCG64(int(self.rng.randint(0, 2 ** 31 - 1))))      # per-pixel noise fields
         # the elastic warp runs on torch's CPU thread pool, from the fit drivers' prefetch thread, next to the thread that feeds the

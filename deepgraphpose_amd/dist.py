@@ -66,6 +66,15 @@ def any_rank(flag: bool, device=None, group: Optional[dist.ProcessGroup] = None)
     return bool(t.item())
 
 
+def from_rank0(flag: bool, group: Optional[dist.ProcessGroup] = None) -> bool:
+    """Rank 0's value of `flag` on every rank (a decision all ranks must take together, e.g. "the labels already exist")."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return bool(flag)
+    box = [bool(flag)]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return bool(box[0])
+
+
 def average_gradients(flat_grads: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
                       bucket_floats: int = 16 * 1024 * 1024) -> torch.Tensor:
     """Data-parallel training: mean of the flat gradient buffer over the ranks, in place.

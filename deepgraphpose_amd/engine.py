@@ -61,6 +61,10 @@ class DGPNet:
         self.out_h, self.out_w, self.feat_h, self.feat_w = oh.value, ow.value, fh.value, fw.value
         self._ws: Optional[torch.Tensor] = None
         self._ws_batch = 0
+        # bookkeeping of the H2 activation scales for callers that keep several engines in step (DGPPipeline): widen_count = how often
+        # the headroom was raised since load_weights, scale_epoch = bumped by everything that invalidates the calibrated scales
+        self.widen_count = 0
+        self.scale_epoch = 0
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -82,6 +86,8 @@ class DGPNet:
             for j in range(4):
                 views[i].shape[j] = a.shape[j] if j < a.ndim else 1
         _lib.check(self.lib.dgp_net_load_weights(self._h, views, len(weights)), "dgp_net_load_weights")
+        self.widen_count = 0                    # (the library resets the headroom with the weights)
+        self.scale_epoch += 1
 
     def set_input_size(self, in_h: int, in_w: int):
         """Re-plan the geometry for another frame size; weights stay (DLC's step-0 loader changes the size every
@@ -187,16 +193,22 @@ class DGPNet:
         forward re-calibrates on its own batch -- re-run what was computed since the last clean status."""
         ov, nc = C.c_int32(), C.c_int32()
         _lib.check(self.lib.dgp_net_range_status(self._h, C.byref(ov), C.byref(nc), _stream(self.device)), "dgp_net_range_status")
+        if ov.value:                       # the library widened this engine's headroom and will re-calibrate
+            self.widen_count += 1
+            self.scale_epoch += 1
         return bool(ov.value), nc.value
 
     def recalibrate(self):
         """Force a calibration pass of the activation scales on the next forward."""
         _lib.check(self.lib.dgp_net_recalibrate(self._h), "dgp_net_recalibrate")
+        self.scale_epoch += 1
 
     def widen(self):
         """Re-calibrate on the next forward with 3 more bits of headroom -- what range_status() does on an overflow -- for a rank
         that follows another rank's overflow in a sharded run."""
         _lib.check(self.lib.dgp_net_widen(self._h), "dgp_net_widen")
+        self.widen_count += 1
+        self.scale_epoch += 1
 
     def infer_packed(self, frames: torch.Tensor, traj: torch.Tensor, gamma: float = 1.0, gauss_len: int = 1,
                      scmap_out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -242,6 +254,7 @@ class DGPPipeline:
         self.nj, self.max_batch = num_joints, max_batch
         self._next = 0
         self._calibrated = False
+        self._epochs = [n.scale_epoch for n in self.nets]
         n0 = self.nets[0]
         self.in_h, self.in_w, self.out_h, self.out_w = n0.in_h, n0.in_w, n0.out_h, n0.out_w
 
@@ -266,11 +279,14 @@ class DGPPipeline:
                 n.infer_packed(frames, scratch, gamma, gauss_len)
             st.synchronize()
         self._calibrated = True
+        self._epochs = [n.scale_epoch for n in self.nets]
 
     def submit(self, frames: torch.Tensor, traj: torch.Tensor, gamma: float = 1.0, gauss_len: int = 1) -> "torch.cuda.Event":
         """infer_packed(frames -> traj) on the next engine's stream, ordered after the work already on the caller's current stream.
         Returns the event recorded behind it (frames / traj may be reused once it has completed).  The first batch after
         load_weights / recalibrate / an overflow goes through EVERY engine first (calibrate), so all engines share its scales."""
+        if self._calibrated and [n.scale_epoch for n in self.nets] != self._epochs:
+            self._resync()                  # an engine was re-calibrated behind the pipeline's back (EvalSession shares engine 0)
         if not self._calibrated:
             self.calibrate(frames, gamma, gauss_len)
         i = self._next
@@ -283,6 +299,17 @@ class DGPPipeline:
             ev.record(st)
         return ev
 
+    def _resync(self):
+        """Engines whose scales were touched individually (a synchronous forward on a shared engine overflowed and re-calibrated on its
+        own batch): give every engine the widest headroom any of them has and calibrate all of them again on ONE batch -- the next
+        one submitted -- so that which engine a batch lands on does not change a bit of its result."""
+        target = max(n.widen_count for n in self.nets)
+        for n in self.nets:
+            while n.widen_count < target:
+                n.widen()
+            n.recalibrate()
+        self._calibrated = False
+
     def join(self):
         cur = torch.cuda.current_stream(self.device)
         for st in self.streams:
@@ -290,7 +317,10 @@ class DGPPipeline:
 
     def range_status(self) -> Tuple[bool, int]:
         """(any engine overflowed, calibrations of the first engine); an overflow on one engine widens ALL of them, so that they
-        keep identical scales after the re-calibration (calibrate() again before re-running)."""
+        keep identical scales after the re-calibration (calibrate() again before re-running).  Waits for every engine's stream first:
+        the flag is written by the range check at the end of each forward, on the engine's own (non-blocking) stream."""
+        for st in self.streams:
+            st.synchronize()
         res = [n.range_status() for n in self.nets]
         ov = any(r[0] for r in res)
         if ov:

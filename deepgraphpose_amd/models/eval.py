@@ -127,6 +127,10 @@ def setup_dgp_eval_graph(dlc_cfg, dgp_model_file, loc_ref=False, gauss_len=1, ga
     return sess, sess.mu_n, sess.softmax_tensor, sess.scmap, sess.locref, sess.inputs
 
 
+# counters of the last estimate_pose call (tests, soak runs): chunks processed and chunks re-run after a range overflow
+RUN_STATS = {"chunks": 0, "chunk_reruns": 0}
+
+
 def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle=1, save_pose=True, save_str="",
                   new_size=None, crop_size=None, batch_size: int = 32):
     """Estimate pose on an arbitrary video (eval.py:217-372).  Returns {'x','y','likelihoods'} [T,nj] float64,
@@ -150,8 +154,8 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
 
     f = os.path.basename(str(video_file)).rsplit(".", 1)
     save_file = join(output_dir, f[0] + "_labeled%s" % save_str)
-    if os.path.exists(save_file + ".csv"):
-        print("labels already exist! video at %s will not be processed" % video_file)
+    if ddist.from_rank0(os.path.exists(save_file + ".csv")):      # rank 0 decides for everyone: a per-rank test could diverge and leave
+        print("labels already exist! video at %s will not be processed" % video_file)      # some ranks alone in the collectives below
         return save_file + ".csv"
 
     video_clip = open_frame_source(video_file)
@@ -217,18 +221,24 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
         hh, ww = f0.shape[:2]
         # two engines on two HIP streams, batches dealt in turn (engine.DGPPipeline; DGP_EVAL_STREAMS=1: one engine, A/B)
         net = net_used = sess.pipe_for(hh, ww, n_streams=max(1, int(os.environ.get("DGP_EVAL_STREAMS", "2"))))
-        nslots = 4                                # two batches on the engines, one being copied, one being decoded
+        nslots = 4                                # pinned staging: one batch being decoded, one being copied, two of slack
         pinned = [torch.empty((batch_size, hh, ww, 3), dtype=torch.uint8).pin_memory() for _ in range(nslots)]
-        dbuf = [torch.empty((batch_size, hh, ww, 3), dtype=torch.uint8, device=dev) for _ in range(nslots)]
+        # The frames of a CHUNK of batches stay on the device until the chunk's range check has come back clean: a chunk whose
+        # activations outgrew the calibrated H2 scales is re-run from HBM, without decoding anything again (DGP_EVAL_CHUNK_BATCHES,
+        # default 64 batches, capped at 4 GB of frames)
+        batch_bytes = batch_size * hh * ww * 3
+        chunk_batches = max(1, min(int(os.environ.get("DGP_EVAL_CHUNK_BATCHES", "64")), int(4e9 // max(batch_bytes, 1)) or 1))
+        dchunk = torch.empty((chunk_batches, batch_size, hh, ww, 3), dtype=torch.uint8, device=dev)
+        cal_batch = None                          # the batch every engine (and every rank) calibrates its activation scales on
         if world > 1 and hasattr(video_clip, "frame_at"):
             # every rank calibrates the activation scales on the video's FIRST batch (not on its own shard's), so the frozen scales --
-            # and with them every output bit -- are those of a single-process run (also on the re-run after a range overflow)
+            # and with them every output bit -- are those of a single-process run
             net.recalibrate()
             nb0 = min(batch_size, n_frames)
             for t in range(nb0):
                 np.copyto(pinned[0][t].numpy(), prep(video_clip.frame_at(t)))
-            dbuf[0][:nb0].copy_(pinned[0][:nb0])
-            net.calibrate(dbuf[0][:nb0], sess.gamma, sess.gauss_len)
+            cal_batch = pinned[0][:nb0].to(dev)
+            net.calibrate(cal_batch, sess.gamma, sess.gauss_len)
             torch.cuda.synchronize(dev)
         free_slots, ready = queue.Queue(), queue.Queue()
         for i in range(nslots):
@@ -274,30 +284,64 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
         copy_stream = torch.cuda.Stream(device=dev)
         compute = torch.cuda.current_stream(dev)
         traj = torch.zeros((max(n_local, 1), nj, 5), dtype=torch.float32, device=dev)      # packed (row, col, likelihood, iy, ix)
-        consumed = [None] * nslots            # compute-stream event: last dgp_infer that read dbuf[slot]
-        start = 0
-        while True:
-            item = ready.get()
-            if item is None:
-                break
+        start, finished = 0, False
+        # every rank runs the SAME number of chunk rounds (a short shard ends with empty ones): the decision to re-calibrate after a
+        # range overflow is a collective
+        per_rank = -(-n_frames // world)
+        n_rounds = max(1, -(-(-(-per_rank // batch_size)) // chunk_batches))
+        for rnd in range(n_rounds):
+            entries = []                          # (slot in dchunk, frames, offset in traj) of this chunk
+            while len(entries) < chunk_batches and not finished:
+                item = ready.get()
+                if item is None:
+                    finished = True
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                slot, nb = item
+                k = len(entries)
+                with torch.cuda.stream(copy_stream):
+                    dchunk[k][:nb].copy_(pinned[slot][:nb], non_blocking=True)
+                    copied = torch.cuda.Event()
+                    copied.record(copy_stream)
+                compute.wait_event(copied)
+                if cal_batch is None:
+                    cal_batch = dchunk[k][:nb].clone()
+                # written in place by the soft-argmax kernel, on the next engine's stream
+                net.submit(dchunk[k][:nb], traj[start:start + nb], sess.gamma, sess.gauss_len)
+                entries.append((k, nb, start))
+                start += nb
+                copied.synchronize()              # the pinned buffer is free again once its H2D copy has completed
+                free_slots.put(slot)
+            # H2 activation scales (include/dgp_hip.h): a batch that outgrew the scales calibrated on the first batch invalidates the
+            # results since the last clean check, i.e. THIS chunk's.  All ranks decide together; every engine of every rank then
+            # re-calibrates on the calibration batch with 3 more bits of headroom (same scales everywhere again) and the ranks whose
+            # chunk overflowed re-run it from the frames still resident in HBM.
+            for attempt in range(5):
+                net.join()
+                torch.cuda.synchronize(dev)
+                overflow = bool(net.range_status()[0])
+                anywhere = ddist.any_rank(overflow, device="cuda:%d" % sess.device)
+                if not anywhere:
+                    break
+                if attempt == 4:
+                    raise RuntimeError("activation scales did not settle after 4 re-calibrations in %s" % video_file)
+                if not overflow:
+                    net.widen()                   # follow the rank that overflowed: same headroom everywhere
+                net.calibrate(cal_batch, sess.gamma, sess.gauss_len)
+                if overflow:
+                    print("activation ranges outgrew the calibrated scales: re-calibrated, re-running frames %d-%d of %s"
+                          % (lo + entries[0][2] if entries else lo, lo + start, video_file), flush=True)
+                    RUN_STATS["chunk_reruns"] += 1
+                    for k, nb, off in entries:
+                        net.submit(dchunk[k][:nb], traj[off:off + nb], sess.gamma, sess.gauss_len)
+            RUN_STATS["chunks"] += 1 if entries else 0
+        if not finished:
+            item = ready.get()                    # the producer's end marker
             if isinstance(item, BaseException):
                 raise item
-            slot, nb = item
-            with torch.cuda.stream(copy_stream):
-                if consumed[slot] is not None:
-                    copy_stream.wait_event(consumed[slot])          # do not overwrite frames still being read
-                dbuf[slot][:nb].copy_(pinned[slot][:nb], non_blocking=True)
-                copied = torch.cuda.Event()
-                copied.record(copy_stream)
-            compute.wait_event(copied)
-            # written in place by the soft-argmax kernel; the event marks the end of this batch on its engine's stream
-            consumed[slot] = net.submit(dbuf[slot][:nb], traj[start:start + nb], sess.gamma, sess.gauss_len)
-            start += nb
-            copied.synchronize()              # the pinned buffer is free again once its H2D copy has completed
-            free_slots.put(slot)
+            assert item is None, "more frames than the shard holds"
         th.join()
-        net.join()
-        torch.cuda.synchronize(dev)
         if world > 1:                                  # ONE all-gather per video: 20 bytes per (frame, joint)
             full = ddist.gather_trajectory(traj[:n_local], n_frames)
             mu_t, lik_t, _ = ddist.unpack_keypoints(full)
@@ -309,23 +353,8 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
             likelihoods[:start] = lik_t.cpu().numpy()
 
     net_used = None
-    for attempt in range(4):
-        if attempt:
-            video_clip.close()
-            video_clip = open_frame_source(video_file)
-        _infer_once(video_clip)
-        # H2 activation scales (include/dgp_hip.h): a batch that outgrew the scales calibrated on the first batch invalidates its
-        # results; the engine then re-calibrates with more headroom and the video is run again (all ranks decide together)
-        overflow = bool(net_used.range_status()[0])
-        anywhere = ddist.any_rank(overflow, device="cuda:%d" % sess.device)
-        if anywhere and not overflow:
-            net_used.widen()                    # follow the rank that overflowed: same headroom everywhere
-        overflow = anywhere
-        if not overflow:
-            break
-        print("activation ranges outgrew the calibrated scales: re-calibrating and re-running %s" % video_file, flush=True)
-    else:
-        raise RuntimeError("activation scales did not settle after 4 passes over %s" % video_file)
+    RUN_STATS["chunks"] = RUN_STATS["chunk_reruns"] = 0
+    _infer_once(video_clip)
     sess.close()
     video_clip.close()
 
@@ -338,6 +367,8 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
         if not Path(save_file).parent.exists():
             os.makedirs(os.path.dirname(save_file))
         export_pose_like_dlc(labels, os.path.basename(str(dgp_model_file)), dlc_cfg.all_joints_names, save_file)
+    if world > 1:
+        tdist.barrier()                # the csv / h5 is complete before any rank goes on (callers read it back)
     return labels
 
 
@@ -377,11 +408,17 @@ def plot_dgp(video_file, output_dir="", label_dir=None, proj_cfg_file=None, dgp_
     if label_dir is None:
         label_dir = output_dir
     label_file = join(label_dir, f[0] + "_labeled%s.csv" % save_str)
-    if not os.path.exists(label_file):
-        estimate_pose(proj_cfg_file, dgp_model_file, video_file, label_dir, shuffle=shuffle, save_str=save_str,
-                      new_size=new_size)
-    labels = load_pose_from_dlc_to_dict(label_file)
+    from .. import dist as ddist
+    import torch.distributed as tdist
+    labels = None
+    if not ddist.from_rank0(os.path.exists(label_file)):
+        labels = estimate_pose(proj_cfg_file, dgp_model_file, video_file, label_dir, shuffle=shuffle, save_str=save_str,
+                               new_size=new_size)
+    if not isinstance(labels, dict):                       # labels were there already (estimate_pose returns the csv path then)
+        labels = load_pose_from_dlc_to_dict(label_file)
     mask_array = labels["likelihoods"].T > mask_threshold
+    if tdist.is_available() and tdist.is_initialized() and tdist.get_rank() != 0:
+        return label_file                                  # sharded run: rank 0 alone renders the movie
     try:
         from moviepy.editor import VideoFileClip  # noqa: F401
     except ImportError:

@@ -149,6 +149,7 @@ class _FrameUploader:
         self.device = torch.device("cuda", device) if isinstance(device, int) else device
         self.stream = torch.cuda.Stream(device=self.device)
         self.slots, self.pinned, self.turn = slots, [None] * slots, 0
+        self.copied = [None] * slots              # event behind the last H2D copy issued from each staging buffer
 
     def __call__(self, images):
         import torch
@@ -157,6 +158,8 @@ class _FrameUploader:
             img = np.clip(np.rint(img), 0, 255).astype(np.uint8)
         k = self.turn
         self.turn = (k + 1) % self.slots
+        if self.copied[k] is not None:
+            self.copied[k].synchronize()          # the copy queued from this buffer `slots` items ago must have read it (any prefetch depth)
         if self.pinned[k] is None or self.pinned[k].numel() < img.size:
             self.pinned[k] = torch.empty(img.size, dtype=torch.uint8).pin_memory()
         stage = self.pinned[k][:img.size].view(img.shape)
@@ -166,6 +169,7 @@ class _FrameUploader:
             ev = torch.cuda.Event()
             ev.record(self.stream)
         dev._dgp_ready = ev
+        self.copied[k] = ev
         return dev
 
 
@@ -338,6 +342,9 @@ def fit_dlc(snapshot, dlcpath, shuffle=1, step=0, saveiters=1000, displayiters=1
     from ..dlc_dataset import LearningRate, PoseDataset
     from ..train import Trainer
 
+    # data-parallel like the other fit drivers: every rank draws the SAME sample sequence (seeds broadcast by _dp_setup) and takes
+    # every W-th sample, Trainer averages the gradients over the ranks, rank 0 alone writes snapshots and the learning-stats file
+    rank, world, local_rank = _dp_setup()
     dlc_base_path = Path(dlcpath)
     config_path = dlc_base_path / "config.yaml"
     print("config_path", config_path)
@@ -379,7 +386,7 @@ def fit_dlc(snapshot, dlcpath, shuffle=1, step=0, saveiters=1000, displayiters=1
         print("Loading ImageNet-pretrained", dlc_cfg.net_type, flush=True)
         wts = {k: v for k, v in wts.items() if k.startswith("resnet_v1")}
     wts = _fresh_heads(wts, depth, nj, dlc_cfg.location_refinement)
-    trainer = Trainer(depth, nj, 64, 64, max_frames=1)
+    trainer = Trainer(depth, nj, 64, 64, max_frames=1, device=local_rank)
     trainer.load_weights(wts)
 
     display_iters = max(1, int(dlc_cfg.get("display_iters", 1000) if displayiters is None else displayiters))
@@ -391,12 +398,22 @@ def fit_dlc(snapshot, dlcpath, shuffle=1, step=0, saveiters=1000, displayiters=1
 
     lr_gen = LearningRate(dlc_cfg)
     stats_path = Path(pose_config_yaml).with_name("learning_stats.csv")
-    lrf = open(str(stats_path), "w")
+    lrf = open(str(stats_path) if rank == 0 else os.devnull, "w")
     cumloss, partloss, locrefloss = 0.0, 0.0, 0.0
     print("Starting training....", flush=True)
     dev = trainer.device
-    for it, batch in enumerate(_prefetched(lambda _i: dataset.next_batch(), max_iter + 1)):      # image read / scale / targets one step ahead
-        current_lr = lr_gen.get_lr(it)
+
+    def next_sample(_i):                      # W samples per optimiser step: rank r trains on sample it * W + r of the common sequence
+        batch = None
+        for r in range(world):
+            b = dataset.next_batch()
+            if r == rank:
+                batch = b
+        return batch
+
+    max_iter = max(1, max_iter // world) if world > 1 else max_iter
+    for it, batch in enumerate(_prefetched(next_sample, max_iter + 1)):      # image read / scale / targets one step ahead
+        current_lr = lr_gen.get_lr(it * world)
         img = batch["inputs"]
         trainer.set_input_size(img.shape[1], img.shape[2])
         frames = torch.from_numpy(img).to(dev)
@@ -405,6 +422,8 @@ def fit_dlc(snapshot, dlcpath, shuffle=1, step=0, saveiters=1000, displayiters=1
             part_score_weights=batch["part_score_weights"] if dlc_cfg.weigh_part_predictions else None,
             locref_loss_weight=dlc_cfg.locref_loss_weight, locref_huber_loss=dlc_cfg.locref_huber_loss,
             location_refinement=dlc_cfg.location_refinement)
+        if world > 1:
+            trainer.allreduce_gradients()         # mean gradient over the ranks (RCCL): replicas stay bit-identical
         trainer.apply_gradients(current_lr, 0.9, clip_norm=0.0)  # MomentumOptimizer, no clipping (train.py:94-113)
 
         partloss += losses["part_loss"]
@@ -418,7 +437,7 @@ def fit_dlc(snapshot, dlcpath, shuffle=1, step=0, saveiters=1000, displayiters=1
             print("iteration: {} loss: {} scmap loss: {} locref loss: {} lr: {}".format(*vals), flush=True)
             lrf.write("iteration: {}, loss: {}, scmap loss: {}, locref loss: {}, lr: {}\n".format(*vals))
             lrf.flush()
-        if (it % save_iters == 0 and it != 0) or it == max_iter:
+        if rank == 0 and ((it % save_iters == 0 and it != 0) or it == max_iter):
             fmt = os.environ.get("DGP_SNAPSHOT_FORMAT", "npz")
             w = trainer.get_weights()
             weights_io.save_weights(dlc_cfg.snapshot_prefix + "-step" + str(step) + "--" + str(it), w, fmt=fmt)

@@ -32,10 +32,12 @@ def load(sub, counter):
 
 fetch, nf = load("pmc_fetch", "FETCH_SIZE")
 write, nw = load("pmc_write", "WRITE_SIZE")
-steps_f = max(nf.get("soft_argmax_kernel", 0), 1)       # each pass is normalised by ITS OWN step count (one soft-argmax launch per step)
-steps_w = max(nw.get("soft_argmax_kernel", 0), 1)
+# each pass is normalised by ITS OWN number of forward passes: one h2_range_check launch per forward (the calibration call runs two:
+# the layer-by-layer pass and the chained pass that follows it); engines without H2: one soft-argmax launch per step
+steps_f = max(nf.get("h2_range_check_kernel", 0) or nf.get("soft_argmax_kernel", 0), 1)
+steps_w = max(nw.get("h2_range_check_kernel", 0) or nw.get("soft_argmax_kernel", 0), 1)
 steps = steps_f
-CONV = ("conv_igemm", "stem_pool_fused", "tail_fixup", "head_gather", "maxpool3x3s2", "preprocess_u8", "reduce_slabs")
+CONV = ("conv_igemm", "chain_kernel", "unit_kernel", "stem_pool_fused", "tail_fixup", "head_gather", "maxpool3x3s2", "preprocess_u8", "reduce_slabs")
 per_kernel, tot_fetch, tot_write = {}, 0.0, 0.0
 for k in sorted(set(fetch) | set(write)):
     if not any(c in k for c in CONV):

@@ -236,6 +236,42 @@ def test_bench_two_ranks_on_one_gpu(lib_built):
     assert abs(d["value"] - 2 * 5 * 8 / (d["ms_per_step"] * 5 / 1e3)) <= 1e-3 * d["value"]
 
 
+def _run_bench(args, **env_extra):
+    env = _child_env(**env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert cp.returncode == 0, (cp.stdout[-1500:], cp.stderr[-1500:])
+    lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_through_its_own_spawner(lib_built):
+    """`python bench.py --gpus N` with no launcher around it spawns its N workers itself (the parent never touches the GPU) and relays
+    rank 0's line.  Here N = 1 through the spawner (DGP_BENCH_FORCE_SPAWN=1): RCCL group of one rank, the strict-fp32 child run included."""
+    d = _run_bench(["--gpus", "1", "--steps", "6", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--sustain-seconds", "0.3",
+                    "--prewarm-seconds", "0.2"], DGP_BENCH_FORCE_SPAWN=1)
+    assert "spawned 1 worker" in d["launcher"] and d["n_gpus"] == 1 and d["steps"] == 6 and d["value"] > 0
+    assert d["roofline"]["frac"] > 0 and d["shard_check"]["indices_identical"]
+    sf = d["strict_f32"]
+    assert "error" not in sf and sf["frames_per_s"] > 0 and 0 < sf["frac_of_fp32_mfma_peak"] < 1
+    assert sf["frames_per_s"] < d["value"]                  # the IEEE-fp32 tier is the slower one
+    kern = d["roofline"]["kernels"]
+    assert any(k.startswith("chain_") or k.startswith("unit_") for k in kern)       # the fused bottleneck launches are in the table
+    assert all(v["bound"] in ("hbm", "mfma") for v in kern.values())
+
+
+def test_bench_strong_scaling_two_ranks_through_the_spawner(lib_built):
+    """--scaling strong: ONE fixed stream (--total-batches) split over the ranks, through bench.py's own spawner; two ranks on the one
+    GPU of the box (gloo control plane), result identical batch by batch to rank 0's ring."""
+    d = _run_bench(["--gpus", "2", "--scaling", "strong", "--total-batches", "8", "--warmup", "1", "--batch", "8", "--no-cpu-baseline",
+                    "--sustain-seconds", "0.2", "--prewarm-seconds", "0.2"], DGP_DIST_BACKEND="gloo", DGP_BENCH_VISIBLE_GPUS=1)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 4 and d["config"]["total_frames"] == 64
+    assert d["shard_check"]["batches_compared"] == 4 and d["shard_check"]["indices_identical"]
+    assert "spawned 2 worker" in d["launcher"] and "strict_f32" not in d
+
+
 def test_shard_ranges_reassemble_bit_exactly(lib_built):
     """What N ranks would compute: the frames of each shard_range(T, r, W) inferred separately (own batches) and concatenated
     equal the one-process trajectory on the integer indices bit for bit and on the coordinates within 1e-3 px."""
@@ -302,6 +338,27 @@ def test_evaluate_dgp_soft_argmax_locref_readout(lib_built, tmp_path):
     pose = soft_argmax_locref_pose(lr, st, 8.0, 7.2801)
     np.testing.assert_allclose(pose[0], [5 * 8 + 4 - 0.25 * 7.2801, 2 * 8 + 4 + 0.5 * 7.2801, 1.0])
     np.testing.assert_allclose(pose[1], [1 * 8 + 4 + 2.0 * 7.2801, 4 * 8 + 4 + 1.0 * 7.2801, 1.0])
+
+
+def test_estimate_pose_reruns_only_the_chunk_that_overflowed(lib_built, tmp_path, monkeypatch):
+    """A video whose first frames are flat (tiny activations: the H2 scales calibrated on the first batch are far too small) followed by
+    real frames.  The range check of the chunk the real frames land in reports the overflow; estimate_pose re-calibrates and
+    re-runs THAT chunk from the frames still resident in HBM -- one chunk re-run, not the video -- and every frame matches the oracle."""
+    from oracle import dgp_oracle as O
+    from deepgraphpose_amd.models import eval as E
+    from deepgraphpose_amd.synthetic import make_frames
+    proj, snap, _, wts = _tiny_project(tmp_path)
+    T_flat, T_real = 16, 24
+    flat = np.zeros((T_flat, 64, 96, 3), np.uint8)
+    flat[..., 0], flat[..., 1], flat[..., 2] = 124, 117, 104
+    frames = np.concatenate([flat, make_frames(T_real, 64, 96, 3, seed=77)], 0)
+    np.save(tmp_path / "mixed.npy", frames)
+    monkeypatch.setenv("DGP_EVAL_CHUNK_BATCHES", "2")                 # chunks of 2 batches of 4 frames: the real frames start in chunk 2
+    out = E.estimate_pose(str(proj / "config.yaml"), snap, str(tmp_path / "mixed.npy"), str(tmp_path / "pred_mixed"), shuffle=1,
+                          batch_size=4)
+    assert E.RUN_STATS["chunks"] == 5 and E.RUN_STATS["chunk_reruns"] == 1, E.RUN_STATS
+    ref = O.infer(frames, wts, 50, 8.0, 1.0, 1)
+    assert np.abs(out["x"] - ref["x"]).max() < 1e-3 and np.abs(out["y"] - ref["y"]).max() < 1e-3
 
 
 def test_estimate_pose_edge_cases_vs_oracle(lib_built, tmp_path):
