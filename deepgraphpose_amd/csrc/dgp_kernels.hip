@@ -1358,6 +1358,8 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
 #else
     constexpr bool M16 = false;
 #endif
+    static_assert(!DMA || (TM == 1 && (TN == 4 || TN == 2)), "DMA image is read by the pipelined loop only");
+    static_assert(!(DMA && AH2) || M16, "pre-split A + DMA image: 16x16x32 loop only");
     if constexpr (M16) {
         // One K-step = one MFMA depth (32).  Per step a wave splits its 2 x 16 rows (A: two fp32 chunks per lane and row block ->
         // a_hi / a_lo), and walks 16 B fragments f = (column block j = f / 2, plane: low first) through a ring of four register
@@ -1496,8 +1498,9 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
         }
     } else
 #if !defined(DGP_NO_PIPE)
-    static_assert(!DMA || (TM == 1 && (TN == 4 || TN == 2)), "DMA image is read by the pipelined loop only");
-    static_assert(!(DMA && AH2) || M16, "pre-split A + DMA image: 16x16x32 loop only");
+    // (nothing but the next `if constexpr` may stand between this `else` and its statement: two static_asserts used to, which made
+    //  THEM the else branch and let the generic K loop below run -- as nks extra barriers, its MFMAs being dead code -- after the
+    //  16x16x32 loop as well.  Harmless while a block ran one tile; found when a persistent variant desynchronised its barriers)
     if constexpr (CS && TM == 1 && TN == 4 && NT == 2 && BK == 32 && !AH2) {
         // Software-pipelined K loop of the 32 x 128 wave tile.  hipcc's schedule read each B fragment right before its MFMAs
         // (ds_read, s_waitcnt 0, mfma: ~6 exposed LDS round trips per 16-wide slice); here the 16 B fragments of a K-step flow
