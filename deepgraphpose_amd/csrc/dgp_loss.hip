@@ -118,10 +118,16 @@ __global__ __launch_bounds__(256) void loss_assemble_clique(LossArgs a) {
 //   box = bbox of the two marker positions (px) +- 10, clipped to the frame; tf.image.crop_and_resize
 //   (bilinear, extrapolation 0) of the flow-magnitude field to [Hin, Win]; mean; w = min(min(1/(m+1e-10),1)^3,1)
 //   * wt_batch[t] / H / W                                                          fitdgp.py:1085-1118
+// The boxes are functions of the (differentiable) hidden targets and TF's crop_and_resize has a gradient with respect to them
+// (CropAndResizeGradBoxes: d sample / d in_y = bottom - top, d in_y / d y1 = (Hin - 1) - iy, d in_y / d y2 = iy at crop height
+// = image height; likewise in x), so the weight is NOT a constant of the backward pass: wt_w[ne + 4 e + {0,1,2,3}] =
+// dw / d (r0, c0, r1, c1), through min / max of the two positions (a tie shares the gradient evenly, like tf.reduce_min), the
+// clamps to the frame (no gradient where the clamp is active) and min(., 1)^3 (none while the mean flow is <= 1).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void loss_temporal_weights(LossArgs a) {
     __shared__ double red[8];
     const int e = blockIdx.x, n = e / a.nj, j = e - n * a.nj;
+    const int ne = (a.nt - 1) * a.nj;
     const float* vf = a.vector_field + (long long)n * a.Hin * a.Win;
     const float r0 = a.t_all[2 * (n * a.nj + j)] * a.stride + 0.5f * a.stride;
     const float c0 = a.t_all[2 * (n * a.nj + j) + 1] * a.stride + 0.5f * a.stride;
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256) void loss_temporal_weights(LossArgs a) {
     const float x1 = fmaxf(0.f, fminf(c0, c1) - win) / Wf, x2 = fminf(Wf, fmaxf(c0, c1) + win) / Wf;
     const float hs = a.Hin > 1 ? (y2 - y1) * (Hf - 1.f) / (Hf - 1.f) : 0.f;      // crop_h == Hin
     const float wsx = a.Win > 1 ? (x2 - x1) * (Wf - 1.f) / (Wf - 1.f) : 0.f;
-    double acc = 0.0;
+    double acc = 0.0, gy1 = 0.0, gy2 = 0.0, gx1 = 0.0, gx2 = 0.0;
     const int total = a.Hin * a.Win;
     for (int i = threadIdx.x; i < total; i += 256) {
         const int iy = i / a.Win, ix = i - iy * a.Win;
@@ -141,20 +147,43 @@ __global__ __launch_bounds__(256) void loss_temporal_weights(LossArgs a) {
         if (in_y < 0.f || in_y > Hf - 1.f || in_x < 0.f || in_x > Wf - 1.f) continue;     // extrapolation_value = 0
         const int ty = (int)floorf(in_y), by = (int)ceilf(in_y), lx = (int)floorf(in_x), rx = (int)ceilf(in_x);
         const float fy = in_y - ty, fx = in_x - lx;
-        const float top = vf[ty * a.Win + lx] + (vf[ty * a.Win + rx] - vf[ty * a.Win + lx]) * fx;
-        const float bot = vf[by * a.Win + lx] + (vf[by * a.Win + rx] - vf[by * a.Win + lx]) * fx;
+        const float tl = vf[ty * a.Win + lx], tr = vf[ty * a.Win + rx], bl = vf[by * a.Win + lx], br = vf[by * a.Win + rx];
+        const float top = tl + (tr - tl) * fx;
+        const float bot = bl + (br - bl) * fx;
         acc += (double)(top + (bot - top) * fy);
+        const float dvy = bot - top, dvx = (1.f - fy) * (tr - tl) + fy * (br - bl);
+        if (a.Hin > 1) { gy1 += (double)(dvy * ((Hf - 1.f) - (float)iy)); gy2 += (double)(dvy * (float)iy); }
+        else { gy1 += 0.5 * (double)(dvy * (Hf - 1.f)); gy2 += 0.5 * (double)(dvy * (Hf - 1.f)); }
+        if (a.Win > 1) { gx1 += (double)(dvx * ((Wf - 1.f) - (float)ix)); gx2 += (double)(dvx * (float)ix); }
+        else { gx1 += 0.5 * (double)(dvx * (Wf - 1.f)); gx2 += 0.5 * (double)(dvx * (Wf - 1.f)); }
     }
     acc = block_sum(acc, red);
+    gy1 = block_sum(gy1, red); gy2 = block_sum(gy2, red); gx1 = block_sum(gx1, red); gx2 = block_sum(gx2, red);
     if (threadIdx.x == 0) {
         const float m = (float)(acc / (double)total);
-        float inv = fminf(1.f / (m + 1e-10f), 1.f);
+        const float inv0 = 1.f / (m + 1e-10f);
+        float inv = fminf(inv0, 1.f);
         inv = fminf(expf(logf(inv) * 3.f), 1.f);
-        a.wt_w[e] = inv * a.wt_batch[n] / (float)a.H / (float)a.W;
+        const float k = a.wt_batch[n] / (float)a.H / (float)a.W;
+        a.wt_w[e] = inv * k;
+        // dw / dm: only where 1 / (m + eps) < 1 (both minima pass the gradient to their first argument there)
+        const float dwdm = inv0 < 1.f ? -3.f * inv0 * inv0 * inv0 * inv0 * k : 0.f;
+        const float sy1 = dwdm * (float)(gy1 / (double)total), sy2 = dwdm * (float)(gy2 / (double)total);
+        const float sx1 = dwdm * (float)(gx1 / (double)total), sx2 = dwdm * (float)(gx2 / (double)total);
+        // box -> positions: y1 = max(0, min(r0, r1) - win) / Hin, y2 = min(Hin, max(r0, r1) + win) / Hin (x alike)
+        const float ay1 = (fminf(r0, r1) - win > 0.f) ? sy1 / Hf : 0.f, ay2 = (fmaxf(r0, r1) + win < Hf) ? sy2 / Hf : 0.f;
+        const float ax1 = (fminf(c0, c1) - win > 0.f) ? sx1 / Wf : 0.f, ax2 = (fmaxf(c0, c1) + win < Wf) ? sx2 / Wf : 0.f;
+        const float rmin0 = r0 < r1 ? 1.f : (r0 > r1 ? 0.f : 0.5f), cmin0 = c0 < c1 ? 1.f : (c0 > c1 ? 0.f : 0.5f);
+        float* g = a.wt_w + ne + 4 * e;
+        g[0] = ay1 * rmin0 + ay2 * (1.f - rmin0);            // d w / d r0 (r0 is the max exactly where it is not the min)
+        g[1] = ax1 * cmin0 + ax2 * (1.f - cmin0);            // d w / d c0
+        g[2] = ay1 * (1.f - rmin0) + ay2 * rmin0;            // d w / d r1
+        g[3] = ax1 * (1.f - cmin0) + ax2 * cmin0;            // d w / d c1
     }
 }
 
-// K1c: temporal clique loss + d/dt (single workgroup): || (relu(D - wt_max) + wt_max) * w ||_F * scale
+// K1c: temporal clique loss + d/dt (single workgroup): || (relu(D - wt_max) + wt_max) * w ||_F * scale, with the gradient through
+// the distances D AND through the flow weights w (boxes of the crop: see K1b)
 __global__ __launch_bounds__(256) void loss_temporal(LossArgs a) {
     __shared__ double red[8];
     const int ne = (a.nt - 1) * a.nj;
@@ -177,8 +206,18 @@ __global__ __launch_bounds__(256) void loss_temporal(LossArgs a) {
         const float dr = (a.t_all[2 * ((n + 1) * a.nj + j)] - a.t_all[2 * (n * a.nj + j)]) * a.stride;
         const float dc = (a.t_all[2 * ((n + 1) * a.nj + j) + 1] - a.t_all[2 * (n * a.nj + j) + 1]) * a.stride;
         const float D = sqrtf(dr * dr + dc * dc);
-        if (!(D > a.wt_max) || D <= 0.f) continue;
         const float w = a.wt_w[e];
+        const float gD = fmaxf(D - a.wt_max, 0.f) + a.wt_max;
+        // through the weight: dL/dw = C v / F * gD, positions = t * stride + stride / 2
+        const float dLdw = C * (gD * w) / F * gD * a.stride;
+        const float* gw = a.wt_w + ne + 4 * e;
+        if (dLdw != 0.f) {
+            if (gw[0] != 0.f) atomicAdd(&a.dLdt[2 * (n * a.nj + j)], dLdw * gw[0]);
+            if (gw[1] != 0.f) atomicAdd(&a.dLdt[2 * (n * a.nj + j) + 1], dLdw * gw[1]);
+            if (gw[2] != 0.f) atomicAdd(&a.dLdt[2 * ((n + 1) * a.nj + j)], dLdw * gw[2]);
+            if (gw[3] != 0.f) atomicAdd(&a.dLdt[2 * ((n + 1) * a.nj + j) + 1], dLdw * gw[3]);
+        }
+        if (!(D > a.wt_max) || D <= 0.f) continue;
         const float v = D * w;
         const float g = C * v / F * w / D * a.stride;        // dL/dD * dD/d(dr) = g * dr
         atomicAdd(&a.dLdt[2 * ((n + 1) * a.nj + j)], g * dr);

@@ -1043,6 +1043,10 @@ static int infer_impl(dgp_net* net, const uint8_t* frames, int32_t batch, void* 
     if (!net) return fail(DGP_ERR_INVALID, "dgp_infer: null net");
     if (!mu || !conf || !idx) return fail(DGP_ERR_INVALID, "dgp_infer: null output");
     if (gauss_len < 0 || gauss_len > 7) return fail(DGP_ERR_INVALID, "dgp_infer: gauss_len (0..7)");
+    // the soft-argmax keeps one joint's map in LDS (150 KB: 38 400 pixels of the 2 fh x 2 fw scoremap, e.g. frames up to 1920 x 1280);
+    // refuse before running the backbone rather than fail at the launch
+    if ((size_t)4 * net->fh * net->fw * sizeof(float) > 150 * 1024)
+        return fail(DGP_ERR_INVALID, "dgp_infer: scoremap exceeds LDS (soft-argmax holds a map of at most 38400 pixels); use dgp_forward + tiles or smaller frames");
     net->prof_in_infer = true;
     int rc = dgp_forward(net, frames, batch, workspace, workspace_bytes, scmap_out, nullptr, nullptr, stream);
     net->prof_in_infer = false;
@@ -1124,7 +1128,7 @@ static size_t loss_scratch_layout(const dgp_loss_desc* d, size_t off[8]) {
     off[4] = take(nm * 4);        // kind
     off[5] = take(nm * 4);        // stats
     off[6] = take(8 * 4);         // norm
-    off[7] = take(nm * 4);        // temporal weights
+    off[7] = take(nm * 5 * 4);    // temporal weights [nm] + their derivatives by the four marker coordinates [nm][4]
     return o;
 }
 

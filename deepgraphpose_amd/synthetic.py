@@ -16,7 +16,7 @@ from typing import Dict
 
 import numpy as np
 
-from .arch import resnet_units
+from .arch import BN_EPS as BN_EPS_, resnet_units
 
 
 def _conv(rng, kh, kw, cin, cout, gain=2.0):
@@ -56,6 +56,64 @@ def make_weights(depth: int = 50, nj: int = 4, with_locref: bool = False,
     w["pose/part_pred/block4/biases"] = (0.01 * rng.standard_normal(nj)).astype(np.float32)
     if with_locref:
         w["pose/locref_pred/block4/weights"] = (head_std * rng.standard_normal((3, 3, 2 * nj, 2048))).astype(np.float32)
+        w["pose/locref_pred/block4/biases"] = (0.01 * rng.standard_normal(2 * nj)).astype(np.float32)
+    return w
+
+
+def make_stress_weights(depth: int = 50, nj: int = 4, with_locref: bool = False, seed: int = 0, head_std: float = 0.05,
+                        dead_frac: float = 0.05, n_outliers: int = 3) -> Dict[str, np.ndarray]:
+    """Weights with the statistics of a TRAINED network instead of make_weights' near-identity BatchNorm -- what the H2 activation
+    format (one power-of-two scale per tensor) and the per-tensor weight scales have to survive:
+      * the folded BN scale gamma * rsqrt(var + eps) of a layer's channels is log-uniform over [2^-8, 2^4], var log-uniform over
+        [1e-3, 1e2];
+      * the output magnitude of a layer's channels is log-uniform over [2^-6, 2^2] (weight columns compensate the BN scale, so a
+        panel's columns differ by up to 2^20);
+      * `dead_frac` of the channels are dead (gamma 0, beta < 0: zero after the ReLU) and `n_outliers` channels per layer are
+        100 x larger than their layer's typical channel.
+    The network stays finite: the pre-BN variance of a channel matches the variance its BN divides by."""
+    rng = np.random.default_rng(seed)
+    name = "resnet_v1_%d" % depth
+    w: Dict[str, np.ndarray] = {}
+
+    def layer(prefix, kh, kw, cin, cout, in_ms, gain=2.0, relu_after=True, damp=1.0):
+        """conv + BN whose output channel c has standard deviation ~ a[c]; returns E[x^2] of the (post-ReLU) output per channel"""
+        a = damp * 2.0 ** rng.uniform(-6, 2, cout)
+        if n_outliers:
+            a[rng.choice(cout, min(n_outliers, cout), replace=False)] *= 100.0
+        s = 2.0 ** rng.uniform(-8, 4, cout)                         # folded BN scale
+        var = 10.0 ** rng.uniform(-3, 2, cout)
+        base = rng.standard_normal((kh, kw, cin, cout)) * np.sqrt(gain / (kh * kw * cin))
+        pre_std = (a / s)                                           # what the conv must deliver so that BN scales it to a
+        wconv = base * (pre_std / np.sqrt(max(float(np.mean(in_ms)), 1e-30) * gain / 2.0))[None, None, None, :]
+        gamma = s * np.sqrt(var + BN_EPS_)
+        beta = 0.1 * a * rng.standard_normal(cout)
+        mean = 0.1 * pre_std * rng.standard_normal(cout)
+        dead = rng.random(cout) < dead_frac
+        gamma[dead] = 0.0
+        beta[dead] = -0.1 * a[dead]
+        w[prefix + "/weights"] = wconv.astype(np.float32)
+        w[prefix + "/BatchNorm/gamma"] = gamma.astype(np.float32)
+        w[prefix + "/BatchNorm/beta"] = beta.astype(np.float32)
+        w[prefix + "/BatchNorm/moving_mean"] = mean.astype(np.float32)
+        w[prefix + "/BatchNorm/moving_variance"] = var.astype(np.float32)
+        ms = np.where(dead, 0.0, a * a * (0.5 if relu_after else 1.0) + beta * beta)
+        return ms
+
+    x_ms = layer(name + "/conv1", 7, 7, 3, 64, np.full(3, 70.0 ** 2))
+    for u in resnet_units(depth):
+        sc_ms = x_ms
+        if u.has_shortcut_conv:
+            sc_ms = layer(u.scope + "/shortcut", 1, 1, u.depth_in, u.depth, x_ms, gain=1.0, relu_after=False)
+        r1 = layer(u.scope + "/conv1", 1, 1, u.depth_in, u.depth_bottleneck, x_ms)
+        r2 = layer(u.scope + "/conv2", 3, 3, u.depth_bottleneck, u.depth_bottleneck, r1)
+        r3 = layer(u.scope + "/conv3", 1, 1, u.depth_bottleneck, u.depth, r2, gain=1.0, relu_after=False, damp=0.5)
+        x_ms = 0.5 * (sc_ms + r3)                                   # relu(shortcut + residual), roughly
+    # heads: input magnitudes vary by channel (and the 100 x outlier channels dominate the sums); scale so that logits are O(10)
+    hs = 0.1 * head_std / np.sqrt(max(float(np.mean(x_ms)), 1e-30))
+    w["pose/part_pred/block4/weights"] = (hs * rng.standard_normal((3, 3, nj, 2048))).astype(np.float32)
+    w["pose/part_pred/block4/biases"] = (0.01 * rng.standard_normal(nj)).astype(np.float32)
+    if with_locref:
+        w["pose/locref_pred/block4/weights"] = (hs * rng.standard_normal((3, 3, 2 * nj, 2048))).astype(np.float32)
         w["pose/locref_pred/block4/biases"] = (0.01 * rng.standard_normal(2 * nj)).astype(np.float32)
     return w
 

@@ -156,7 +156,11 @@ int  dgp_loss_scratch_bytes(const dgp_loss_desc* d, size_t* out_bytes);
  * visible_in_targets indexes rows of `targets`; S0 [nl,nj], ws / ws_max [nl].
  * Outputs: dpred, dlocref (same shapes as the predictions), mu [nt*nj,2],
  * losses[8] = {visible_loss_pred, hidden_loss_pred, visible_loss_locref, ws_loss, total_loss, total_loss_visible,
- *             wt_loss, 0}. */
+ *             wt_loss, 0}.
+ * Temporal clique (use_wt; fitdgp.py:1079-1124): wt_loss = || (relu(D - wt_max) + wt_max) * w ||_F * scale with D the pixel distance of
+ * a marker between consecutive frames and w the flow weight min(1 / mean flow, 1)^3 * wt_batch / H / W over the +-10 px box of the two
+ * positions (bilinear crop_and_resize mean of vector_field).  The backward pass differentiates D AND w: the boxes are functions of the
+ * (hidden, soft-arg-max) targets and TF's crop_and_resize has a gradient with respect to its boxes -- the weight is not a stop-gradient. */
 int  dgp_loss_fwd_bwd(const dgp_loss_desc* d, const float* pred, const float* locref_pred, const float* targets,
                       const float* locref_map, const float* locref_mask, const int32_t* visible_marker,
                       const int32_t* hidden_marker, const int32_t* visible_in_targets, const float* S0,

@@ -232,8 +232,14 @@ def dgp_loss(pred, locref_pred, batch: dict, cfg: dict):
         vf = np.asarray(batch["vector_field"], dtype=np.float64)
         mask = np.asarray(batch.get("wt_batch_mask", np.ones(nt - 1)), dtype=np.float64)
         wt_batch = np.ones(nt - 1) * cfg["wt"] * mask
-        w = temporal_flow_weights(P_t.detach().numpy().astype(np.float64), vf, wt_batch, H, W)   # constant in backward
-        v = (F.relu(dif - cfg["wt_max"]) + cfg["wt_max"]) * torch.as_tensor(w).to(dt)
+        # the crop boxes are functions of the (differentiable) targets and tf.image.crop_and_resize has a gradient with respect to
+        # its boxes (python/ops/image_grad.py _CropAndResizeGrad -> CropAndResizeGradBoxes), so the weight is differentiated too;
+        # cfg["wt_weight_grad"] = False gives the weight as a constant (stop-gradient), for comparison
+        if cfg.get("wt_weight_grad", True):
+            w = temporal_flow_weights_torch(P_t.to(torch.float64), vf, wt_batch, H, W).to(dt)
+        else:
+            w = torch.as_tensor(temporal_flow_weights(P_t.detach().numpy().astype(np.float64), vf, wt_batch, H, W)).to(dt)
+        v = (F.relu(dif - cfg["wt_max"]) + cfg["wt_max"]) * w
         loss["wt_loss"] = torch.sqrt((v ** 2).sum()) * n_vis_total / n_v_eff / (n_vis_total + n_hid_total) / cfg["wn_visible"]
         total = total + loss["wt_loss"]
     loss["total_loss"] = total
@@ -281,6 +287,44 @@ def temporal_flow_weights(P_t: np.ndarray, vector_field: np.ndarray, wt_batch: n
             inv = min(np.exp(np.log(inv) * 3), 1.0)
             w[t, j] = inv * wt_batch[t] / H / W
     return w
+
+
+def temporal_flow_weights_torch(P_t, vector_field: np.ndarray, wt_batch: np.ndarray, H: int, W: int, window=10.0):
+    """temporal_flow_weights with the autograd path TF has (fitdgp.py:1085-1118): P_t [nt, nj, 2] torch float64 (graph attached).
+    crop_and_resize_op.cc: a sample at in_y = y1 (Hin - 1) + i (y2 - y1) (crop height = image height), bilinear between floor and
+    ceil rows; CropAndResizeGradBoxes differentiates the LERP FRACTIONS with respect to the box (the integer corner indices are
+    constants), which is what autograd does on `iy - floor(iy)` below.  reduce_min / reduce_max of the two positions share a tie's
+    gradient evenly (math_grad.py _MinOrMaxGrad); maximum(0, v) / minimum(n, v) pass the gradient to v where v is strictly inside."""
+    ntm1, nj = P_t.shape[0] - 1, P_t.shape[1]
+    Hin, Win = vector_field.shape[1:]
+    img_all = torch.as_tensor(np.asarray(vector_field, dtype=np.float64))
+    rows = []
+    for t in range(ntm1):
+        row = []
+        for j in range(nj):
+            pair_r = torch.stack([P_t[t, j, 0], P_t[t + 1, j, 0]])
+            pair_c = torch.stack([P_t[t, j, 1], P_t[t + 1, j, 1]])
+            y1 = torch.clamp(torch.amin(pair_r) - window, min=0.0) / Hin
+            y2 = torch.clamp(torch.amax(pair_r) + window, max=float(Hin)) / Hin
+            x1 = torch.clamp(torch.amin(pair_c) - window, min=0.0) / Win
+            x2 = torch.clamp(torch.amax(pair_c) + window, max=float(Win)) / Win
+            img = img_all[t]
+            iy = y1 * (Hin - 1) + torch.arange(Hin, dtype=torch.float64) * (y2 - y1) if Hin > 1 else (0.5 * (y1 + y2) * (Hin - 1)).reshape(1)
+            ix = x1 * (Win - 1) + torch.arange(Win, dtype=torch.float64) * (x2 - x1) if Win > 1 else (0.5 * (x1 + x2) * (Win - 1)).reshape(1)
+            vy = ((iy >= 0) & (iy <= Hin - 1)).to(torch.float64)
+            vx = ((ix >= 0) & (ix <= Win - 1)).to(torch.float64)
+            iyc, ixc = torch.clamp(iy, 0, Hin - 1), torch.clamp(ix, 0, Win - 1)
+            ty, by = torch.floor(iyc).long(), torch.ceil(iyc).long()
+            lx, rx = torch.floor(ixc).long(), torch.ceil(ixc).long()
+            fy, fx = (iy - ty.to(torch.float64))[:, None], (ix - lx.to(torch.float64))[None, :]       # differentiable fractions
+            top = img[ty][:, lx] + (img[ty][:, rx] - img[ty][:, lx]) * fx
+            bot = img[by][:, lx] + (img[by][:, rx] - img[by][:, lx]) * fx
+            m = ((top + (bot - top) * fy) * (vy[:, None] * vx[None, :])).sum() / (Hin * Win)
+            inv = torch.clamp(1.0 / (m + 1e-10), max=1.0)
+            inv = torch.clamp(torch.exp(torch.log(inv) * 3), max=1.0)
+            row.append(inv * float(wt_batch[t]) / H / W)
+        rows.append(torch.stack(row))
+    return torch.stack(rows)
 
 
 # ------------------------------------------------------------------ DLC step-0 loss (N2)

@@ -320,6 +320,24 @@ def test_run_dgp_demo_test_mode_end_to_end(lib_built, tmp_path):
     assert "Running DGP with labeled frames only" in r.stdout and "Predict with DGP" in r.stdout
 
 
+def test_run_dgp_demo_at_the_reaching_frame_size(lib_built, tmp_path):
+    """BASELINE configs[0] at its real shape: a synthetic project with the Reaching demo's geometry -- 832 x 747 frames, 5 bodyparts
+    (config.yaml:6-11) -- through `run_dgp_demo.py --test`: the fit steps train at 747 x 832 (scoremaps 94 x 104), estimate_pose
+    writes [T, 3 x 5] labels."""
+    from _project import make_project
+    proj, frames, wts = make_project(tmp_path, nj=5, n_frames=24, hw=(747, 832), labeled=(2, 9, 15, 21))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "demo", "run_dgp_demo.py"), "--dlcpath", proj, "--dlcsnapshot",
+                        "snapshot-step0-final--0", "--batch_size", "4", "--test"], env=_child_env(), cwd=str(tmp_path), capture_output=True,
+                       text=True, timeout=2400)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    csv = os.path.join(proj, "videos_pred", "clip_labeled.csv")
+    rows = open(csv).read().strip().split("\n")
+    assert len(rows) == 3 + frames.shape[0] and len(rows[3].split(",")) == 1 + 3 * 5
+    vals = np.array([[float(v) for v in row.split(",")[1:]] for row in rows[3:]])
+    assert np.isfinite(vals).all()
+    assert (vals[:, 0::3] >= 0).all() and (vals[:, 0::3] <= 832).all() and (vals[:, 1::3] >= 0).all() and (vals[:, 1::3] <= 747).all()
+
+
 def test_evaluate_dgp_soft_argmax_locref_readout(lib_built, tmp_path):
     """evaluate_dgp(loc_ref=True, loc_ref_calc='dgp') (eval.py:752-786): runs on the synthetic project and its per-frame read-out
     equals the restated numpy of the reference on the oracle's maps."""

@@ -202,3 +202,29 @@ def test_argmax_2d_threshold_branch_independent_restatement():
                 rows, cols = np.mgrid[0:9, 0:8]
                 np.testing.assert_allclose(mu[b, c], [(st * rows).sum(), (st * cols).sum()], rtol=1e-12)
         assert (pm == 0).sum() > 0
+
+
+def test_temporal_flow_weight_autograd_matches_finite_differences():
+    """The temporal clique's flow weight (fitdgp.py:1085-1118) as a differentiable function of the marker positions: values equal the
+    numpy restatement; the gradient (TF: CropAndResizeGradBoxes through min / max / the frame clamps / min(., 1)^3) matches central
+    differences and vanishes where the mean flow in the box is <= 1."""
+    import torch
+    from oracle import dgp_train_oracle as T
+    rng = np.random.default_rng(0)
+    nt, nj, Hin, Win = 4, 3, 48, 64
+    yy, xx = np.mgrid[0:Hin, 0:Win]
+    vf = np.stack([np.abs(np.sin(xx / 9.0 + t) * np.cos(yy / 7.0)) * sc for t, sc in zip(range(nt - 1), (0.3, 2.5, 4.0))])
+    P = torch.tensor(rng.uniform(5, 40, (nt, nj, 2)), dtype=torch.float64, requires_grad=True)
+    wb = np.array([50.0, 50.0, 50.0])
+    w = T.temporal_flow_weights_torch(P, vf, wb, 6, 8)
+    np.testing.assert_allclose(w.detach().numpy(), T.temporal_flow_weights(P.detach().numpy(), vf, wb, 6, 8), rtol=0, atol=1e-14)
+    w.sum().backward()
+    g = P.grad.numpy()
+    assert np.all(g[0] == 0)                          # frame 0 only touches pair 0, whose mean flow is < 1: weight clamped at 1
+    assert np.abs(g[1:]).max() > 1e-3
+    eps = 1e-5
+    for (t, j, k) in ((2, 1, 0), (1, 2, 1), (3, 0, 0)):
+        Pp = P.detach().clone().numpy(); Pm = Pp.copy()
+        Pp[t, j, k] += eps; Pm[t, j, k] -= eps
+        fd = (T.temporal_flow_weights(Pp, vf, wb, 6, 8).sum() - T.temporal_flow_weights(Pm, vf, wb, 6, 8).sum()) / (2 * eps)
+        assert abs(fd - g[t, j, k]) < 1e-6 * max(1.0, abs(fd)), (t, j, k, fd, g[t, j, k])

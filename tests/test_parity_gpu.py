@@ -248,6 +248,57 @@ def test_infer_640x480_r50_matches_oracle(eng):
     assert np.abs(conf.cpu().numpy() - ref["likelihoods"]).max() < 1e-4
 
 
+def test_demo_frame_size_747x832_five_joints_matches_oracle(eng):
+    """BASELINE configs[0]'s shape on the HIP path: the Reaching demo's frames are 832 x 747 with 5 bodyparts
+    (data/Reaching-Mackenzie-2018-08-30/config.yaml:6-11).  747 x 832 -> 374 x 416 -> 187 x 208 -> 94 x 104 -> 47 x 52: every stride-2
+    stage halves an ODD size somewhere, so each SAME / conv2d_same padding asymmetry (pad 0 before / 1 after, explicit pad before the
+    strided 3 x 3) is exercised at once.  Both heads, one frame, vs the oracle."""
+    from oracle import dgp_oracle as O
+    from deepgraphpose_amd.synthetic import make_weights, make_frames
+    H, W, nj = 747, 832, 5
+    wts = make_weights(50, nj, True, seed=11, head_std=0.05)
+    frames = make_frames(1, H, W, nj, seed=12)
+    net = eng.DGPNet(50, nj, H, W, max_batch=1, with_locref=True)
+    net.load_weights(wts)
+    assert (net.out_h, net.out_w, net.feat_h, net.feat_w) == (94, 104, 47, 52)
+    ft = torch.from_numpy(frames).cuda()
+    scmap, locref, feats = net.forward(ft, want_locref=True, want_features=True)
+    f_ref = O.resnet_features(frames, wts, 50)
+    s_ref, l_ref = O.pose_heads(f_ref, wts, True)
+    assert feats.shape == f_ref.shape and scmap.shape == s_ref.shape == (1, 94, 104, nj) and locref.shape == l_ref.shape
+    assert _rel_err(feats.cpu().numpy(), f_ref) < 1e-4
+    assert _rel_err(scmap.cpu().numpy(), s_ref) < 1e-4
+    assert _rel_err(locref.cpu().numpy(), l_ref) < 1e-4
+    mu, conf, idx = net.infer(ft, gamma=1.0, gauss_len=1)
+    ref = O.infer(frames, wts, 50, STRIDE, 1.0, 1)
+    assert np.abs(mu.cpu().numpy() - ref["mu"]).max() * STRIDE < PX_TOL
+    assert np.array_equal(idx.cpu().numpy(), ref["idx"])
+
+
+def test_maps_larger_than_the_lds_are_refused_with_a_message(eng):
+    """dgp_soft_argmax keeps one joint's map in LDS (150 KB = 38 400 pixels), dgp_loss_fwd_bwd two (19 200): larger maps return
+    DGP_ERR_INVALID with a message naming the limit instead of failing at the launch; dgp_infer checks before running the backbone."""
+    from deepgraphpose_amd import _lib
+    big = torch.zeros((1, 200, 200, 2), device="cuda")             # 40 000 pixels
+    with pytest.raises(_lib.DgpError, match="exceeds LDS"):
+        eng.soft_argmax(big, 1.0, 1)
+    ok = torch.zeros((1, 192, 200, 2), device="cuda")              # 38 400: the largest map that fits
+    ok[0, 7, 9, :] = 60.0                                          # (a peak that outweighs the 38 399 other pixels of the softmax)
+    mu, conf, idx = eng.soft_argmax(ok, 1.0, 1)[:3]
+    assert idx[0, 0].tolist() == [7, 9]
+    from deepgraphpose_amd.loss import DGPHyper, dgp_loss_fwd_bwd
+    nt, H, W, nj = 2, 120, 170, 2                                   # 20 400 pixels > 19 200
+    batch = dict(targets=np.zeros((1, nj, 2)), locref_map=np.zeros((nt, H, W, 2 * nj), np.float32),
+                 locref_mask=np.zeros((nt, H, W, 2 * nj), np.float32), visible_marker=np.array([0, 1], np.int32),
+                 hidden_marker=np.array([2, 3], np.int32), visible_marker_in_targets=np.array([0, 1], np.int32), nt=nt)
+    with pytest.raises(_lib.DgpError, match="exceeds LDS"):
+        dgp_loss_fwd_bwd(torch.zeros((nt, H, W, nj), device="cuda"), torch.zeros((nt, H, W, 2 * nj), device="cuda"), batch, DGPHyper(),
+                         np.zeros((0, nj)), np.zeros(0), np.zeros(0), 10.0, 2.0)
+    net = eng.DGPNet(50, 2, 1600, 1600, max_batch=1)               # scoremap 200 x 200
+    with pytest.raises(_lib.DgpError, match="scoremap exceeds LDS"):
+        net.infer(torch.zeros((1, 1600, 1600, 3), dtype=torch.uint8, device="cuda"))
+
+
 # ---------------------------------------------------------------------------- golden vectors from the reference
 def test_hip_kernels_reproduce_reference_vectors(eng):
     """A4 / A6 outputs of the reference's own numpy code (tests/golden/make_golden.py) from the HIP kernels."""

@@ -215,7 +215,8 @@ def test_fit_dgp_drivers_end_to_end(lib_built, tmp_path):
 
 
 def test_temporal_clique_matches_oracle(lib_built):
-    """B8 (wt > 0): temporal graph-smoothness term on top of the other terms, flow-weighted, vs the autograd oracle."""
+    """B8 (wt > 0): temporal graph-smoothness term on top of the other terms, flow-weighted, vs the autograd oracle -- including
+    the gradient through the flow weights (fitdgp.py:1091-1113: the boxes of tf.image.crop_and_resize are functions of the targets)."""
     from deepgraphpose_amd.loss import dgp_loss_fwd_bwd, DGPHyper
     from oracle import dgp_train_oracle as T
     nt, H, W, nj, nvf = 6, 12, 16, 3, 2
@@ -249,6 +250,15 @@ def test_temporal_clique_matches_oracle(lib_built):
         assert abs(losses["total_loss"] - float(L["total_loss"].detach())) < 1e-4 * abs(float(L["total_loss"].detach()))
         gp = pt.grad.numpy()
         assert np.abs(dpred.cpu().numpy() - gp).max() <= 3e-4 * np.abs(gp).max()
+        # the gradient THROUGH the flow weights (the crop boxes follow the differentiable targets; TF's crop_and_resize has a box
+        # gradient) is part of it: with the weight held constant the oracle's gradient is measurably different
+        pt2 = torch.tensor(pred, dtype=torch.float64, requires_grad=True)
+        lt2 = torch.tensor(loc, dtype=torch.float64, requires_grad=True)
+        L2 = T.dgp_loss(pt2, lt2, batch, dict(cfg, wt_weight_grad=False))
+        L2["total_loss"].backward()
+        assert abs(float(L2["wt_loss"].detach()) - float(L["wt_loss"].detach())) < 1e-12
+        gap = np.abs(pt2.grad.numpy() - gp).max()
+        assert gap > 30 * np.abs(dpred.cpu().numpy() - gp).max(), gap
 
 
 def _dlc_targets(rng, H, W, nj, scale=1.0):
