@@ -42,6 +42,12 @@ typedef __attribute__((address_space(3))) void lds_void;
 __device__ __forceinline__ floatx4 mma16(const uint4& a, const uint4& b, floatx4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
 }
+__device__ __forceinline__ uint4 ld16nt(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {      // streamed once: evict-first
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 2));
+}
+__device__ __forceinline__ void st16nt(__amdgpu_buffer_rsrc_t r, const uint4& v, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, soff, 2);
+}
 __device__ __forceinline__ uint4 ld16(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
     // voffset carries the per-lane offset (OOB for rows past M: the hardware range check zero-fills / drops), soffset the
     // wave-uniform part -- the SGPR offset takes no part in the range check, so OOB stays OOB whatever is added here
@@ -51,6 +57,30 @@ __device__ __forceinline__ void st16(__amdgpu_buffer_rsrc_t r, const uint4& v, u
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, soff, 0);
 }
 
+// residual cells of chunk jp (32 channels of X) for the wave's RB row blocks -> res; chain_prefetch: the first PD - 1 chunks of a tile
+template <int RES, int RB>
+__device__ __forceinline__ void chain_fetch_res(const ChainArgs& p, uint4 (&res)[RB][2], const unsigned (&roff)[RB],
+                                                const __amdgpu_buffer_rsrc_t rs_s2, int jp) {
+    if constexpr (RES != 0) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            if (p.nt & 1) {
+                res[rb][0] = ld16nt(rs_s2, roff[rb], jp * 128);
+                res[rb][1] = ld16nt(rs_s2, roff[rb], jp * 128 + 16);
+            } else {
+                res[rb][0] = ld16(rs_s2, roff[rb], jp * 128);
+                res[rb][1] = ld16(rs_s2, roff[rb], jp * 128 + 16);
+            }
+        }
+    }
+}
+template <int RES, int RB, int PD>
+__device__ __forceinline__ void chain_prefetch(const ChainArgs& p, uint4 (&res)[PD][RB][2], const unsigned (&roff)[RB],
+                                               const __amdgpu_buffer_rsrc_t rs_s2) {
+#pragma unroll
+    for (int u = 0; u < PD - 1; ++u) chain_fetch_res<RES, RB>(p, res[u], roff, rs_s2, u);
+}
+
 // conv3 (+ shortcut, ReLU) -> X' -> conv1 -> R1' for the RB row blocks of one wave, one weight chunk per 32 channels of X'
 // (the ring protocol is the caller's: `slot` is the chunk to read first, one barrier per chunk).  ph / pl: the B-operand fragments
 // (pixel lane & 15, k-group lane >> 4) of conv3's K-steps -- R2 first, then the K-concatenated source.
@@ -58,7 +88,8 @@ template <int C, int C1, int CIN2, int RES, int RB, int NS, int PD, int CHUNK, i
 __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring, int& slot, const uint4 (&ph)[RB][(C + CIN2) / 32],
                                            const uint4 (&pl)[RB][(C + CIN2) / 32], const unsigned (&xoff)[RB], const unsigned (&roff)[RB],
                                            const unsigned (&r1off)[RB], const __amdgpu_buffer_rsrc_t rs_s2, const __amdgpu_buffer_rsrc_t rs_xo,
-                                           const __amdgpu_buffer_rsrc_t rs_r1, float& amax_x, float& amax_r1, const int lane) {
+                                           const __amdgpu_buffer_rsrc_t rs_r1, float& amax_x, float& amax_r1, const int lane,
+                                           uint4 (&res)[PD][RB][2]) {
     constexpr int C4 = 4 * C, KS1 = (C + CIN2) / 32, NJP = C4 / 32, NCB = C1 / 16;
     constexpr int F1 = KS1 * 4, F2 = NCB * 2;
     static_assert(WR >= 2 && WR % 2 == 0, "weight fragments in flight: pairs share the ring");
@@ -69,18 +100,8 @@ __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) a2[rb][cb] = floatx4{0.f, 0.f, 0.f, 0.f};
-    uint4 res[PD][RB][2];
-    auto fetch_res = [&](int jp, int buf) {
-        if constexpr (RES != 0) {
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-                res[buf][rb][0] = ld16(rs_s2, roff[rb], jp * 128);
-                res[buf][rb][1] = ld16(rs_s2, roff[rb], jp * 128 + 16);
-            }
-        }
-    };
-#pragma unroll
-    for (int u = 0; u < PD - 1; ++u) fetch_res(u, u);
+    // (the caller has issued the residual loads of chunks 0 .. PD - 2 into res[0 .. PD - 2]: chain_prefetch)
+    auto fetch_res = [&](int jp, int buf) { chain_fetch_res<RES, RB>(p, res[buf], roff, rs_s2, jp); };
     for (int jp0 = 0; jp0 < NJP; jp0 += PD) {
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
@@ -134,8 +155,13 @@ __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring
                     o[k] = fmaxf(o[k], 0.f);
                 }
                 h2_pack8(o, p.xout_scale, xh[rb], xl[rb]);
-                st16(rs_xo, xh[rb], xoff[rb], jp * 128);
-                st16(rs_xo, xl[rb], xoff[rb], jp * 128 + 16);
+                if (p.nt & 2) {
+                    st16nt(rs_xo, xh[rb], xoff[rb], jp * 128);
+                    st16nt(rs_xo, xl[rb], xoff[rb], jp * 128 + 16);
+                } else {
+                    st16(rs_xo, xh[rb], xoff[rb], jp * 128);
+                    st16(rs_xo, xl[rb], xoff[rb], jp * 128 + 16);
+                }
                 if (xoff[rb] != OOB) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) amax_x = fmaxf(amax_x, o[k]);
@@ -295,7 +321,9 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void chain_kernel(const ChainArgs
                 for (int s = 0; s < KSB; ++s) { ph[rb][KSA + s] = ld16(rs_s2, boff, s * 128); pl[rb][KSA + s] = ld16(rs_s2, boff, s * 128 + 16); }
             }
         }
-        chain_tail<C, C1, CIN2, RES, RB, NS, PD, CHUNK, WR>(p, ring, slot, ph, pl, xoff, roff, r1off, rs_s2, rs_xo, rs_r1, amax_x, amax_r1, lane);
+        uint4 res[PD][RB][2];
+        chain_prefetch<RES, RB, PD>(p, res, roff, rs_s2);
+        chain_tail<C, C1, CIN2, RES, RB, NS, PD, CHUNK, WR>(p, ring, slot, ph, pl, xoff, roff, r1off, rs_s2, rs_xo, rs_r1, amax_x, amax_r1, lane, res);
     }
     // both tensors are post-ReLU: max = max |.|
     if (p.xout_absmax) track_absmax(p.xout_absmax, amax_x, lane, (int)(blockIdx.x * 8u + (unsigned)wave));
@@ -327,7 +355,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void unit_kernel(const ChainArgs 
     static_assert(C == 64, "one pixel of R1 = 16 slots of 16 bytes (the bank swizzle)");
     constexpr int NHI = (HPIX * PIXB + 1023) / 1024;               // DMA instructions per halo tile (4 pixels each; the last may run past
     constexpr int HALO_BYTES = NHI * 1024;                         // the tile: those lanes are out of range and write zeros into the pad)
-    static_assert(NLW == 1 || NLW == 2, "one or two loader waves");
+    static_assert(NLW == 1 || NLW == 2 || NLW == 4, "one, two or four loader waves");
     constexpr int C4 = 4 * C, KS1 = (C + CIN2) / 32, NJP = C4 / 32, NCB = C1 / 16;
     constexpr int NFJ = KS1 * 4 + NCB * 2 + 1;                      // fragments of a chain chunk
     constexpr int KS2 = C / 32, NCB2 = C / 16, NF2 = KS2 * NCB2 * 2 + 1;      // conv2: fragments per tap + the affine fragment
@@ -387,11 +415,12 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void unit_kernel(const ChainArgs 
             return was_conv2;
         };
         auto wait_all_but_newest = [&](bool conv2_chunk) {             // everything older than the chunk just issued has landed
+            // (wave lw issued ceil or floor of the chunk's fragments / NLW: the first `fragments % NLW` waves one more)
             if (conv2_chunk) {
-                if (lw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N2_0) : "memory");
+                if (lw < NF2 % NLW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N2_0) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N2_1) : "memory");
             } else {
-                if (lw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ_0) : "memory");
+                if (lw < NFJ % NLW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ_0) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ_1) : "memory");
             }
         };
@@ -440,7 +469,11 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void unit_kernel(const ChainArgs 
 #pragma unroll
             for (int s = 0; s < CIN2 / 32; ++s) { ph[0][KS2 + s] = ld16(rs_s2, boff, s * 128); pl[0][KS2 + s] = ld16(rs_s2, boff, s * 128 + 16); }
         }
-        // ---- conv2: 9 taps x KS2 K-steps, A... the pixel fragment comes from the halo tile (shifted by the tap), weights from the ring
+        // the residual of the first pointwise chunks is requested NOW: conv2 below touches no global memory, so HBM would sit idle
+        // for nine steps and the pointwise stage would start by waiting for it
+        uint4 res[PD][1][2];
+        chain_prefetch<RES, 1, PD>(p, res, roff, rs_s2);
+        // ---- conv2: 9 taps x KS2 K-steps, the pixel fragment comes from the halo tile (shifted by the tap), weights from the ring
         floatx4 acc[NCB2];
 #pragma unroll
         for (int cb = 0; cb < NCB2; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -507,7 +540,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void unit_kernel(const ChainArgs 
                 for (int k = 0; k < 8; ++k) amax_r2 = fmaxf(amax_r2, o[k]);
             }
         }
-        chain_tail<C, C1, CIN2, RES, 1, NS, PD, CHUNK, WR>(p, ring, slot, ph, pl, xoff, roff, r1off, rs_s2, rs_xo, rs_r1, amax_x, amax_r1, lane);
+        chain_tail<C, C1, CIN2, RES, 1, NS, PD, CHUNK, WR>(p, ring, slot, ph, pl, xoff, roff, r1off, rs_s2, rs_xo, rs_r1, amax_x, amax_r1, lane, res);
     }
     if (p.xout_absmax) track_absmax(p.xout_absmax, amax_x, lane, (int)(blockIdx.x * 8u + (unsigned)wave));
     if (p.r1_absmax) track_absmax(p.r1_absmax, amax_r1, lane, (int)(blockIdx.x * 8u + (unsigned)wave) + 97);
@@ -573,6 +606,8 @@ hipError_t launch_chain_t(const ChainArgs& a0, hipStream_t s) {
         attr_done[dev] = true;
     }
     ChainArgs a = a0;
+    static const int nt_env = getenv("DGP_CHAIN_NT") ? atoi(getenv("DGP_CHAIN_NT")) : 0;      // bit 0: residual loads, bit 1: X' stores non-temporal
+    a.nt = nt_env;
     constexpr int TILE = 16 * RB * NCW;
     a.ntiles = (a.M + TILE - 1) / TILE;
     int ncu = 256;
@@ -604,6 +639,8 @@ hipError_t launch_unit_t(const ChainArgs& a0, int N, hipStream_t s) {
         attr_done[dev] = true;
     }
     ChainArgs a = a0;
+    static const int nt_env = getenv("DGP_CHAIN_NT") ? atoi(getenv("DGP_CHAIN_NT")) : 0;
+    a.nt = nt_env;
     a.TY = (a.H + NCW - 1) / NCW; a.TX = (a.W + 15) / 16;
     a.ntiles = N * a.TY * a.TX;
     int ncu = 256;
@@ -634,12 +671,15 @@ bool unit_supported(int C, int C1, int CIN2, int res) {
 hipError_t launch_unit(const ChainArgs& a, int N, int C, int C1, int CIN2, int res, hipStream_t s) {
     static const int cfg = getenv("DGP_UNIT_CFG") ? atoi(getenv("DGP_UNIT_CFG")) : 0;      // tuning: tile rows / loader waves
     if (C == 64 && C1 == 64 && CIN2 == 0 && res == 1) {
-        if (cfg == 1) return launch_unit_t<64, 64, 0, 1, 10, 2, 2, 2>(a, N, s);
+        // (measured on the batch-32 640x480 shape, ms per launch: 8 rows + 2 loader waves 0.41-0.42; 10 rows 0.42-0.43; 8 rows + 4 loader
+        //  waves 0.42-0.43 -- the weight stream is not the pace; 4 rows + 1 loader, two workgroups per CU 0.56-0.67: 4.5 KB of weight
+        //  fragments per pixel; four residual buffers (three chunks ahead, requested before conv2) 0.57: spills at the 168-register cap)
+        if (cfg == 1) return launch_unit_t<64, 64, 0, 1, 8, 4, 2, 4>(a, N, s);
         if (cfg == 2) return launch_unit_t<64, 64, 0, 1, 10, 2, 2, 4>(a, N, s);
         return launch_unit_t<64, 64, 0, 1, 8, 2, 2, 4>(a, N, s);
     }
     if (C == 64 && C1 == 64 && CIN2 == 64 && res == 0) {
-        if (cfg == 1) return launch_unit_t<64, 64, 64, 0, 10, 2, 2, 4>(a, N, s);
+        if (cfg == 1) return launch_unit_t<64, 64, 64, 0, 8, 4, 2, 8>(a, N, s);
         if (cfg == 2) return launch_unit_t<64, 64, 64, 0, 10, 2, 2, 8>(a, N, s);
         return launch_unit_t<64, 64, 64, 0, 8, 2, 2, 8>(a, N, s);
     }

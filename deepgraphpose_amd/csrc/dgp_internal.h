@@ -41,6 +41,7 @@ struct ConvArgs {
     float* slab;
     unsigned slab_bytes;
     int n_main, tail_ksplit;
+    int epi_nt;                // H2 epilogue: non-temporal residual loads and output stores
     const float* in2;
     const float* in2_absmax;
     unsigned in2_bytes;
@@ -157,6 +158,7 @@ struct ChainArgs {
     int H, W, TY, TX;         // frame size (stride 1: output = input grid), tiles per frame
     float post0, r2_scale;    // 1 / (R1 scale x conv2 weight scale); scale R2's fragments are split with
     float* r2_absmax;
+    int nt;                   // bit 0: residual loads, bit 1: X' stores with the non-temporal (evict-first) policy
 };
 bool chain_supported(int C, int C1, int CIN2, int res);          // res: 0 K-concatenated shortcut, 1 identity, 2 subsample of a stride-2 unit
 int  chain_frags_per_chunk(int C, int C1, int CIN2);

@@ -889,8 +889,14 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
                     const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
                     roff = (unsigned)(((n * p.res_H + ho * p.res_s) * p.res_W + wo * p.res_s) * p.Cout + co8) << 2;
                 }
-                rres[slot][u][0] = __builtin_bit_cast(uint4, buf_load16(rs_res, roff));
-                rres[slot][u][1] = __builtin_bit_cast(uint4, buf_load16(rs_res, roff == OOB ? OOB : roff + 16u));
+                const unsigned roff1 = roff == OOB ? OOB : roff + 16u;
+                if (p.epi_nt & 1) { // streamed once: keep it from evicting the operand rows the other column tiles still need
+                    rres[slot][u][0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)roff, 0, 2));
+                    rres[slot][u][1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)roff1, 0, 2));
+                } else {
+                    rres[slot][u][0] = __builtin_bit_cast(uint4, buf_load16(rs_res, roff));
+                    rres[slot][u][1] = __builtin_bit_cast(uint4, buf_load16(rs_res, roff1));
+                }
             }
         }
     };
@@ -930,8 +936,14 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
             }
             uint4 hi, lo;
             h2_pack8(o, p.out_scale, hi, lo);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), rs_out, (int)ooff[slot][u], 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), rs_out, (int)(ooff[slot][u] == OOB ? OOB : ooff[slot][u] + 16u), 0, 0);
+            const unsigned ooff1 = ooff[slot][u] == OOB ? OOB : ooff[slot][u] + 16u;
+            if (p.epi_nt & 2) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), rs_out, (int)ooff[slot][u], 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), rs_out, (int)ooff1, 0, 2);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), rs_out, (int)ooff[slot][u], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), rs_out, (int)ooff1, 0, 0);
+            }
             if (ooff[slot][u] != OOB) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(o[k]));
@@ -1813,6 +1825,14 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     if (NT == 2 && ((!a.in_absmax && !a.in_fmt) || !a.w_absmax)) return hipErrorInvalidValue;      // fp16 split needs both ranges (H2 input carries its scale)
     if ((a.in_fmt || a.out_fmt) && !(NT == 2 && BK == 32 && CW == 4 && a.wh3 && (a.Cout % 8) == 0 && (a.Cin % 8) == 0 && !a.up && !a.stem && !a.mask))
         return hipErrorInvalidValue;                                                 // H2 tensors: fp16-split cell kernels only
+    // non-temporal residual loads / output stores in the H2 epilogue (A/B switch DGP_EPI_NT; 0: off, 1: every layer, 2 (default): only
+    // layers with >= 8 column tiles (N >= 1024: conv3 of block3 / block4), 3 / 4: their loads / stores only).  There the 128 KB a tile
+    // streams through the epilogue evict the A rows the other column tiles of the row block still read: PMC FETCH_SIZE 1061 MB per
+    // launch against 393 MB of operands on block4's conv3.  Measured (same box, ms per launch, nt 0 / 2): block3 conv3 0.105 -> 0.088,
+    // the conv1 that re-reads the tensor 0.070 -> 0.076, block4 conv3 0.268 -> 0.253; everywhere (1) loses: a small output written nt
+    // (R2: 39 MB) is no longer cache-resident for its consumer
+    static const int epi_nt_env = getenv("DGP_EPI_NT") ? atoi(getenv("DGP_EPI_NT")) : 2;
+    a.epi_nt = epi_nt_env == 1 ? 3 : (a.CoutP / BN >= 8 ? (epi_nt_env == 2 ? 3 : epi_nt_env == 3 ? 1 : epi_nt_env == 4 ? 2 : 0) : 0);   // bit 0: loads, bit 1: stores
     static const int tap_minor = getenv("DGP_TAP_MINOR") ? atoi(getenv("DGP_TAP_MINOR")) : 1;
     a.tap_minor = (tap_minor && !a.stem && a.ntaps > 1 && a.nk * 32 == a.ntaps * a.Cin) ? 1 : 0;
     const size_t smem_loop = (size_t)2 * (NP * KG * (BM + (BK == 32 ? 4 : 8)) + NP * KG * (BN + 4)) * 16;
