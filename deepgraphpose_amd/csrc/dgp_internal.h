@@ -42,6 +42,7 @@ struct ConvArgs {
     unsigned slab_bytes;
     int n_main, tail_ksplit;
     int epi_nt;                // H2 epilogue: non-temporal residual loads and output stores
+    int st_gn, st_mc, st_mb;   // supertile order of the grid (0: plain): column tiles per group, row tiles per chunk, row tiles per XCD band
     const float* in2;
     const float* in2_absmax;
     unsigned in2_bytes;

@@ -1015,6 +1015,20 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
         tail_slot = (int)blockIdx.x - p.n_main;
         tile = p.n_main + tail_slot / p.tail_ksplit;
         part = tail_slot % p.tail_ksplit;
+    } else if (p.st_gn > 0) {
+        // Supertile order (wide layers whose weight panel is larger than an XCD's L2, block4's conv3): XCD x = blockIdx & 7 owns a band
+        // of st_mb row tiles and walks it in supertiles of st_mc row tiles x st_gn column tiles, so that the ~64 tiles in flight on an
+        // XCD share ONE chunk of A rows (st_mc x 128 rows) and 1-2 groups of weight columns that fit the L2 together -- in the plain
+        // order they span all column tiles of 4 row tiles and the whole panel streams through the L2 for every 4 row tiles.
+        const int b = blockIdx.x, xcd = b & 7, loc = b >> 3;
+        const int per_chunk = p.st_mc * p.ntiles;
+        const int c = loc / per_chunk, r = loc - c * per_chunk;
+        const int left = p.st_mb - c * p.st_mc, mc = left < p.st_mc ? left : p.st_mc;       // row tiles of this (maybe last, shorter) chunk
+        const int per_group = mc * p.st_gn;
+        const int cg = r / per_group, r2 = r - cg * per_group;
+        const int mt_ = xcd * p.st_mb + c * p.st_mc + r2 / p.st_gn;
+        if (mt_ >= p.mtiles) return;                 // (the last band is padded to whole row tiles: nothing to do, before any barrier)
+        tile = mt_ * p.ntiles + cg * p.st_gn + r2 % p.st_gn;
     } else {
         const int nwg = p.tail_ksplit > 1 ? p.n_main : (int)gridDim.x, b = blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, loc = b >> 3;
@@ -1933,6 +1947,19 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     if (!dbg_buf) (void)hipMalloc(&dbg_buf, 10 * 8 * 65536);
     a.dbg = nwg <= 65536 ? dbg_buf : nullptr;
 #endif
+    // supertile order (see the kernel): H2 engine, 128-wide tiles, >= 8 column tiles and a weight panel that cannot stay in an XCD's L2
+    a.st_gn = 0;
+    {
+        static const int st_env = getenv("DGP_SUPERTILE") ? atoi(getenv("DGP_SUPERTILE")) : 1;       // A/B switch; > 1: force the row-chunk size
+        const long long panel_bytes = (long long)a.nk * 32 * a.CoutP * 4;
+        if (st_env && a.in_fmt && a.out_fmt && a.tail_ksplit <= 1 && BN == 128 && a.ntiles >= 8 && panel_bytes > (3LL << 20) && a.mtiles >= 64) {
+            const long long per_ntile = (long long)a.nk * 32 * BN * 4;
+            int gn = 1;
+            while (gn * 2 <= a.ntiles && (long long)(gn * 2) * per_ntile <= (3LL << 19) && a.ntiles % (gn * 2) == 0) gn *= 2;      // <= 1.5 MB of weight cells per group
+            a.st_gn = gn; a.st_mc = st_env > 1 ? st_env : 8; a.st_mb = (a.mtiles + 7) / 8;
+            nwg = 8LL * a.st_mb * a.ntiles;
+        }
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * (CW + 4)), smem, s, a);
     if (a.tail_ksplit > 1) {
         const int ntail = (int)((long long)a.mtiles * a.ntiles - a.n_main);
