@@ -449,6 +449,31 @@ def test_pipeline_two_engines_equal_single_engine(lib_built):
     assert np.array_equal(i1, i0) and np.abs(m1 - m0).max() * 8.0 < PX_TOL
 
 
+def test_pipeline_resyncs_engines_after_a_private_recalibration(lib_built):
+    """EvalSession shares engine 0 with the pipeline: a synchronous forward on it that overflows re-calibrates THAT engine alone
+    (new scales, +3 bits).  The next submit notices (scale_epoch), gives every engine the widest headroom and re-calibrates all of them
+    on one batch -- which engine a batch lands on again does not change a bit of its result."""
+    from deepgraphpose_amd.engine import DGPPipeline
+    from deepgraphpose_amd.synthetic import make_frames, make_weights
+    nj, B = 3, 4
+    wts = make_weights(50, nj, False, seed=33, head_std=0.05)
+    ft = torch.from_numpy(make_frames(2 * B, 64, 96, nj, seed=34)).cuda()
+    pipe = DGPPipeline(50, nj, 64, 96, max_batch=B, n_streams=2)
+    pipe.load_weights(wts)
+    out = torch.zeros((4, B, nj, 5), device="cuda")
+    pipe.submit(ft[:B].contiguous(), out[0]); pipe.submit(ft[B:].contiguous(), out[1])
+    pipe.join(); torch.cuda.synchronize()
+    assert pipe.range_status() == (False, 1)
+    pipe.nets[0].widen()                                   # what DGPNet.infer(check_range=True) does to the shared engine on an overflow
+    pipe.nets[0].infer(ft[B:].contiguous())                # ... and it re-calibrates on ITS batch: engine 0 now has other scales
+    assert [n.widen_count for n in pipe.nets] == [1, 0]
+    pipe.submit(ft[:B].contiguous(), out[2]); pipe.submit(ft[:B].contiguous(), out[3])       # the same batch on both engines
+    pipe.join(); torch.cuda.synchronize()
+    assert [n.widen_count for n in pipe.nets] == [1, 1]
+    assert [n.range_status()[1] for n in pipe.nets] == [3, 2]      # engine 0: load + private + resync; engine 1: load + resync
+    assert torch.equal(out[2], out[3])
+
+
 def test_pipeline_overflow_widens_every_engine(lib_built):
     """DGPPipeline.range_status: scales calibrated on a near-empty batch overflow on real frames on whichever engine gets them; the
     status call reports it, gives EVERY engine the wider headroom, and the next submit re-calibrates all of them on its batch -- after
