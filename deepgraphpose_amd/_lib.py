@@ -88,6 +88,7 @@ SYMBOLS = {
     "dgp_net_recalibrate": (C.c_int, [_vp]),
     "dgp_net_widen": (C.c_int, [_vp]),
     "dgp_conv2d_wgrad": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dgp_conv2d_wgrad_shadow": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgp_conv2d_dgrad_scratch_bytes": (_sz, [C.POINTER(DgpConvDesc)]),
     "dgp_conv2d_dgrad": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
     "dgp_motion_energy": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, _vp, _vp]),

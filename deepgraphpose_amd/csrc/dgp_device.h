@@ -6,6 +6,7 @@
 namespace dgp {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
     // raw buffer load: an offset >= num_records returns zeros (hardware range check), which is
@@ -55,6 +56,26 @@ __device__ __forceinline__ float pow2_scale_for(const float* absmax, int lane, c
     int se = 127 + 14 - (be - 127);
     se = se < 1 ? 1 : (se > 254 ? 254 : se);
     return __uint_as_float((unsigned)se << 23);
+}
+
+// Predicted-range fp16 copies (ConvArgs::shadow).  The copy of a tensor is written while its range is still being measured, so its
+// scale comes from the range the tensor had one training step earlier: max = m 2^E maps to [2^10, 2^11), five bits below the fp16
+// overflow.  0: no usable previous range (first step, all-zero or non-finite tensor) -- no copy.
+__device__ __forceinline__ float shadow_scale_for(const float* prev, int lane) {
+    if (!prev) return 0.f;
+    const unsigned mb = __float_as_uint(read_absmax(prev, lane));
+    const int be = (int)((mb >> 23) & 0xFF);
+    if (be == 0 || be == 0xFF) return 0.f;
+    const int se = 127 + 10 - (be - 127);
+    if (se < 1 || se > 254) return 0.f;
+    return __uint_as_float((unsigned)se << 23);
+}
+// A copy written with `scale` is usable when this step's measured maximum stayed inside [2^4, 65000) after scaling: no overflow,
+// and the largest values keep both fp16 pieces normal (22 bits).  NaN compares false: not usable.
+__device__ __forceinline__ bool shadow_usable(float scale, const float* cur, int lane) {
+    if (!(scale > 0.f) || !cur) return false;
+    const float v = read_absmax(cur, lane) * scale;
+    return v >= 16.f && v < 65000.f;
 }
 
 __device__ __forceinline__ void split2_f16(const float4 v, const float s, uint2& ph, uint2& pl) {

@@ -65,6 +65,12 @@ struct ConvArgs {
     float in_scale;           // in (and in2) cells hold x * in_scale
     float out_scale;          // cells written hold out * out_scale
     float res_inv_scale;      // residual value = (hi + lo) * res_inv_scale
+    // Training step: an optional second copy of the fp32 output as fp16 high / low cells in the H2 layout (the weight-gradient
+    // kernel's LDS-DMA operand).  Its power-of-two scale is PREDICTED from the range slots the same tensor had one step earlier
+    // (shadow_scale_for, dgp_device.h); the consumer checks this step's range against it and falls back to the fp32 tensor when
+    // the prediction failed, so a copy written with a stale scale is never read.  No previous range: no copy is written.
+    float*       shadow;
+    const float* shadow_prev;
 };
 
 constexpr int ABSMAX_SLOTS = 256;

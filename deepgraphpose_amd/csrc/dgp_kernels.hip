@@ -413,6 +413,10 @@ __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[T
     const __amdgpu_buffer_rsrc_t rs_res =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.in), 0, p.res ? (int)p.res_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+    // fp16 high / low copy of the output (ConvArgs::shadow): this lane's 4 channels are half of an 8-channel cell
+    const float sh_scale = p.shadow ? shadow_scale_for(p.shadow_prev, lane) : 0.f;
+    const __amdgpu_buffer_rsrc_t rs_sh =
+        __builtin_amdgcn_make_buffer_rsrc(p.shadow ? p.shadow : p.out, 0, sh_scale > 0.f ? (int)p.out_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_mask =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.mask ? p.mask : p.in), 0, p.mask ? (int)p.out_bytes : 0, 0x00020000);
     const int my_c4 = lane % C4;
@@ -504,6 +508,13 @@ __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[T
                 o.z = rmask[u].z > 0.f ? o.z : 0.f; o.w = rmask[u].w > 0.f ? o.w : 0.f;
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)ooff[slot][u], 0, 0);
+            if (sh_scale > 0.f) {
+                uint2 sh, sl;
+                split2_f16(o, sh_scale, sh, sl);
+                const unsigned so = (ooff[slot][u] & ~31u) + ((ooff[slot][u] & 16u) >> 1);      // cell base + this half's 8 bytes
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), rs_sh, (int)so, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), rs_sh, (int)(so + 16u), 0, 0);
+            }
             if (ooff[slot][u] != OOB) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
     }
@@ -1734,6 +1745,7 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const ConvArgs p) {
     const int per_tile = BM * C4;
     const int ntail = (int)gridDim.y;
     const int HoWo = p.Ho * p.Wo;
+    const float sh_scale = p.shadow ? shadow_scale_for(p.shadow_prev, lane) : 0.f;
     float amax = 0.f;
     for (int tt = blockIdx.y; tt < ntail; tt += gridDim.y) {
         const int tile = p.n_main + tt, mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
@@ -1768,6 +1780,13 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const ConvArgs p) {
                 o.x = g.x > 0.f ? o.x : 0.f; o.y = g.y > 0.f ? o.y : 0.f; o.z = g.z > 0.f ? o.z : 0.f; o.w = g.w > 0.f ? o.w : 0.f;
             }
             *reinterpret_cast<float4*>(p.out + (long long)m * p.Cout + co) = o;
+            if (sh_scale > 0.f) {
+                uint2 sh, sl;
+                split2_f16(o, sh_scale, sh, sl);
+                char* cell = reinterpret_cast<char*>(p.shadow + (long long)m * p.Cout + (co & ~7)) + ((co & 4) ? 8 : 0);
+                *reinterpret_cast<uint2*>(cell) = sh;
+                *reinterpret_cast<uint2*>(cell + 16) = sl;
+            }
             amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
     }

@@ -7,6 +7,7 @@
 // the net is built with is_training=False, PET/nnet/pose_net.py:52 -- head weights/biases),
 // clip_by_global_norm(10), MomentumOptimizer(0.9).
 #include "dgp_engine.h"
+#include "dgp_device.h"
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -16,7 +17,6 @@ using namespace dgp;
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned OOBT = 0xFFFFFFF0u;
 
 __device__ __forceinline__ float4 bload16(__amdgpu_buffer_rsrc_t r, unsigned off) {
@@ -250,10 +250,14 @@ struct WgradArgs {
     int KW, stride, dil, pad_t, pad_l, ntaps, kchunks;
     int M, m_per_block;
     unsigned x_bytes, dy_bytes;
+    // wgrad_dma only: the operands' fp16 high / low copies (ConvArgs::shadow, same geometry and byte extents as x / dy) and the range
+    // slots that decide whether they may be read: previous step (the scale they were written with) and this step (what they hold)
+    const void* xs; const void* dys;
+    const float *x_prev, *x_cur, *dy_prev, *dy_cur;
 };
 
 template <int T>      // tile = 64T (k) x 64T (co); 4 waves as 2 x 2, wave tile 32T x 32T
-__global__ __launch_bounds__(256) void wgrad_f32(const WgradArgs p) {
+__device__ __forceinline__ void wgrad_f32_body(const WgradArgs& p) {
     constexpr int BR = 64 * T;               // tile extent (both dims)
     constexpr int CH = BR / 4;               // 16-byte chunks per tile row
     constexpr int NLD = 32 * CH / 256;       // staged chunks per thread per operand (T=1: 2, T=2: 4)
@@ -370,6 +374,9 @@ __global__ __launch_bounds__(256) void wgrad_f32(const WgradArgs p) {
             }
     }
 }
+
+template <int T>
+__global__ __launch_bounds__(256) void wgrad_f32(const WgradArgs p) { wgrad_f32_body<T>(p); }
 
 // ------------------------------------------------------------------------------------------------
 // Weight gradient on the 16-bit matrix pipe (fp16 high/low split, 3 MFMAs per fp32-class product; the split and the range
@@ -902,6 +909,269 @@ __global__ __launch_bounds__(256) void wgrad_h3p(const WgradArgs p, const WgradR
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad_dma: the 128 x 128 weight-gradient tile with BOTH operands arriving as fp16 high / low cells by LDS-DMA.
+// wgrad_h3p's per-step demand was four units at 30-45 % each: 8 staging loads + their address walk, the
+// fp16 split of 32 values, 16 ds_write_b64, 32 transposed reads and 24 MFMAs per thread.  Here the producers of x and dY have
+// already written the split values (ConvArgs::shadow: the H2 cell layout, [pixel][8 channels: 16 B high | 16 B low]), so a step is
+// 4 DMA instructions (no VGPR round trip, no VALU, no ds_write), the same transposed reads and the same MFMAs.
+//   LDS        4 stages of 16 pixels x [A | B] x 512 B (per pixel row: 16 high chunks, then 16 low chunks; chunk slot XOR-swizzled by
+//              f(row) on the SOURCE side -- the DMA destination is lane-linear -- exactly wgrad_h3p's conflict-free image at twice
+//              the row pitch).  64 KB: two workgroups per CU.
+//   step u     every wave: 4 DMA instructions (2 x 1 KB of A rows, 2 x 1 KB of B rows) of step u + 4 into stage u & 3 (read out during
+//              step u - 1); 12 MFMAs (v_mfma_f32_32x32x16_f16, 3 per product) on the fragments of step u, between them the 16
+//              transposed reads of step u + 1 from stage (u + 1) & 3; s_waitcnt vmcnt(8) (own loads of step u + 2 have landed);
+//              one barrier.  Three steps (48 KB per workgroup) are in flight.
+//   validity   the copies were written with scales predicted from the previous step's ranges; every workgroup checks this step's
+//              ranges against them (shadow_usable) and, where the prediction failed (first step, a jump of more than 2^5 up or 2^7 down),
+//              runs the fp32-MFMA tile on the fp32 tensors instead (same grid, same LDS size) -- slower, never wrong.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void wgrad_dma(const WgradArgs p) {
+    constexpr unsigned ROW = 512u, OPB = 16u * ROW, STG = 2u * OPB;      // pixel row, one operand of a stage (8 KB), a stage (16 KB)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), half = lane >> 5, l31 = lane & 31;
+    const float sx = shadow_scale_for(p.x_prev, lane), sy = shadow_scale_for(p.dy_prev, lane);
+    if (!(shadow_usable(sx, p.x_cur, lane) && shadow_usable(sy, p.dy_cur, lane))) {
+        wgrad_f32_body<2>(p);
+        return;
+    }
+    const int wm = wave >> 1, wn = wave & 1;
+    const int q0c = blockIdx.x * 16;               // first 8-channel cell of this k-tile
+    const int n0 = blockIdx.y * 128;
+    const int m_lo = blockIdx.z * p.m_per_block;
+    const int m_hi = min(p.M, m_lo + p.m_per_block);
+    if (m_hi <= m_lo) return;
+    const int nsub = (((m_hi - m_lo + 15) >> 4) + 3) & ~3;      // 16-pixel steps, rounded up to the unroll (rows past m_hi read as zeros)
+    const bool pointwise = p.ntaps == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && p.H == p.Ho && p.W == p.Wo;
+    const unsigned x_lim = pointwise ? (unsigned)min((long long)p.x_bytes, (long long)m_hi * p.Cin * 4) : p.x_bytes;
+    const unsigned dy_lim = (unsigned)min((long long)p.dy_bytes, (long long)m_hi * p.Cdy * 4);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.xs), 0, (int)x_lim, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dys), 0, (int)dy_lim, 0x00020000);
+    const float post = 1.f / (sx * sy);
+
+    // ---- DMA lane map.  Instruction e (0, 1) of this wave fills stage rows R_e, R_e + 1 with R_e = 4 (2 (wave >> 1) + e) + 2 (wave & 1):
+    // lanes 0-31 the first row, 32-63 the second; slot = lane & 31 -> plane (high / low) = slot >> 4, chunk position cs = slot & 15,
+    // which holds logical cell cs ^ f(row), f(row) = ((row & 3) << 2) | ((row >> 2) & 3).  e only flips bit 0 of f: the two cells of a
+    // lane are neighbours (same tap), its two pixel rows are 4 apart.
+    const int slot = lane & 31, plane = slot >> 4, cs_ = slot & 15;
+    const int f0 = (((2 * (wave & 1) + half) << 2) | (2 * (wave >> 1)));
+    const int row0 = 4 * (2 * (wave >> 1)) + 2 * (wave & 1) + half;              // stage-local pixel row of instruction 0 (instruction 1: + 4)
+    const int lc8 = p.log2cin4 - 1;                                              // log2(Cin / 8)
+    const int kcells = p.kchunks >> 1;
+    int cellA[2], cellB[2];
+    bool qok[2], cok[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int c = cs_ ^ f0 ^ e;
+        cellA[e] = q0c + c; cellB[e] = c;
+        qok[e] = cellA[e] < kcells && (cellA[e] >> lc8) < p.ntaps;
+        cok[e] = n0 + 8 * c < p.Cdy;
+    }
+    const int tap = cellA[0] >> lc8;               // (cells c, c ^ 1 lie in the same tap: Cin / 8 is even)
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int dh = kh * p.dil - p.pad_t, dw = kw * p.dil - p.pad_l;
+    const int HoWo = p.Ho * p.Wo;
+    const int cmask = (1 << lc8) - 1;
+    unsigned offa[2], offb[2];
+    int whi[2], wwi[2], mleft[2];
+    const unsigned stepb = 16u * (unsigned)p.Cdy * 4u, stepa_pw = 16u * (unsigned)p.Cin * 4u;
+    const int hlim = p.Ho * p.stride + dh, wlim = p.Wo * p.stride + dw;
+    const unsigned d_px = (unsigned)(16 * p.stride * p.Cin * 4);
+    const unsigned d_row = (unsigned)((p.stride * p.W - p.Wo * p.stride) * p.Cin * 4);
+    const unsigned d_img = (unsigned)((p.H * p.W - p.Ho * p.stride * p.W) * p.Cin * 4);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int m = m_lo + row0 + 4 * e;
+        const unsigned cha = (unsigned)(((cellA[e] & cmask) * 8) * 4 + 16 * plane);
+        offb[e] = cok[e] ? ((unsigned)(m * p.Cdy + n0 + 8 * cellB[e]) << 2) + 16u * plane : OOBT;
+        if (pointwise) {
+            offa[e] = qok[e] ? (unsigned)(m * p.Cin) * 4u + cha : OOBT;
+            whi[e] = wwi[e] = mleft[e] = 0;
+        } else {
+            const int n = m / HoWo, rem = m - n * HoWo;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            whi[e] = ho * p.stride + dh;
+            wwi[e] = wo * p.stride + dw;
+            offa[e] = (unsigned)(((n * p.H + whi[e]) * p.W + wwi[e]) * p.Cin) * 4u + cha;
+            mleft[e] = m_hi - m;
+        }
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    char* const dst0 = smem + (unsigned)__builtin_amdgcn_readfirstlane((4 * (2 * (wave >> 1)) + 2 * (wave & 1)) * (int)ROW);
+    // the four DMA instructions of one step into stage ST (A e = 0, A e = 1, B e = 0, B e = 1), then the walkers move on by 16 pixels
+    auto dma_a = [&](char* stage, int e) {
+        unsigned off;
+        if (pointwise) {
+            off = offa[e];
+            if (qok[e]) offa[e] += stepa_pw;
+        } else {
+            const bool ok = qok[e] && mleft[e] > 0 && (unsigned)whi[e] < (unsigned)p.H && (unsigned)wwi[e] < (unsigned)p.W;
+            off = ok ? offa[e] : OOBT;
+            mleft[e] -= 16;
+            wwi[e] += 16 * p.stride;
+            offa[e] += d_px;
+            while (wwi[e] >= wlim) {
+                wwi[e] -= p.Wo * p.stride;
+                whi[e] += p.stride;
+                offa[e] += d_row;
+                if (whi[e] >= hlim) { whi[e] -= p.Ho * p.stride; offa[e] += d_img; }
+            }
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void*)(stage + e * (4 * ROW)), 16, (int)off, 0, 0, 0);
+    };
+    auto dma_b = [&](char* stage, int e) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_void*)(stage + OPB + e * (4 * ROW)), 16, (int)offb[e], 0, 0, 0);
+        if (cok[e]) offb[e] += stepb;
+    };
+
+    // transposed-read bases [operand][block b][pixel half h] (wgrad_h3p's map at the 512-byte row pitch)
+    const int g16 = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    const int f_lane = (qq << 2) | (2 * (g16 >> 1));
+    const unsigned rrow = (unsigned)(size_t)smem + ROW * (unsigned)(8 * (g16 >> 1) + qq) + 8u * (pp & 1);
+    unsigned rbase[2][2][2];
+#pragma unroll
+    for (int op = 0; op < 2; ++op) {
+        const int L = (8 * (op == 0 ? wm : wn) + 2 * (g16 & 1) + (pp >> 1)) ^ f_lane;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) rbase[op][b][h] = rrow + 16u * (unsigned)(L ^ (4 * b) ^ h);
+    }
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    WgFrag F0[2][2], F1[2][2];          // [operand][block]
+
+    // column sums of dY (d beta), workgroups of the first k-tile only: thread t owns stage row t >> 4, chunk position t & 15
+    const bool do_colsum = p.colsum != nullptr && blockIdx.x == 0;
+    float cs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const unsigned cs_off = OPB + ROW * (unsigned)(t >> 4) + 16u * (unsigned)(t & 15);
+    auto colsum_stage = [&](const char* stage) {
+        const half8 h = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(stage + cs_off));
+        const half8 l = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(stage + cs_off + 256));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cs8[k] += (float)h[k] + (float)l[k];
+    };
+
+#define WD_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define WD_READ2(F, ST, R)                                                                                           \
+    do {                                                                                                             \
+        constexpr int op_ = ((R) >> 2) & 1, b_ = ((R) >> 1) & 1, pc_ = (R) & 1;                                      \
+        constexpr unsigned o_ = (ST) * STG + op_ * OPB + pc_ * 256u;                                                 \
+        F[op_][b_].v[pc_][0] = trr<o_>(rbase[op_][b_][0]);                                                           \
+        F[op_][b_].v[pc_][1] = trr<o_ + 4u * ROW>(rbase[op_][b_][1]);                                                \
+    } while (0)
+#define WD_MMA(F, G)                                                                                                 \
+    do {                                                                                                             \
+        constexpr int blk_ = (G) & 3, i_ = blk_ >> 1, j_ = blk_ & 1, term_ = (G) >> 2;                               \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wg_op(F[0][i_], term_ == 0 ? 1 : 0),                    \
+                                                             wg_op(F[1][j_], term_ == 1 ? 1 : 0), acc[i_][j_], 0, 0, 0); \
+    } while (0)
+
+    // prologue: steps 0..3 in flight, steps 0 and 1 landed, fragments of step 0
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        char* st = dst0 + k * STG;
+        dma_a(st, 0); dma_a(st, 1); dma_b(st, 0); dma_b(st, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    WD_READ2(F0, 0, 0); WD_READ2(F0, 0, 1); WD_READ2(F0, 0, 2); WD_READ2(F0, 0, 3);
+    WD_READ2(F0, 0, 4); WD_READ2(F0, 0, 5); WD_READ2(F0, 0, 6); WD_READ2(F0, 0, 7);
+    if (do_colsum) colsum_stage(smem);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // stage 0 has been read out: step 4 may land in it
+    WD_FENCE();
+
+    // one step on the fragments F (step u, u & 3 == S): DMA of step u + 4 into stage S, fragments of step u + 1 from stage S + 1 into Fn
+#define WD_STEP(S, F, Fn)                                                                                            \
+    do {                                                                                                             \
+        constexpr int NS_ = ((S) + 1) & 3;                                                                           \
+        char* st_ = dst0 + (S) * STG;                                                                                \
+        dma_a(st_, 0); WD_FENCE();                                                                                   \
+        WD_MMA(F, 0);  WD_FENCE(); WD_READ2(Fn, NS_, 0); WD_FENCE();                                                 \
+        dma_a(st_, 1); WD_FENCE();                                                                                   \
+        WD_MMA(F, 1);  WD_FENCE(); WD_READ2(Fn, NS_, 1); WD_FENCE();                                                 \
+        dma_b(st_, 0); WD_FENCE();                                                                                   \
+        WD_MMA(F, 2);  WD_FENCE(); WD_READ2(Fn, NS_, 2); WD_FENCE();                                                 \
+        dma_b(st_, 1); WD_FENCE();                                                                                   \
+        WD_MMA(F, 3);  WD_FENCE(); WD_READ2(Fn, NS_, 3); WD_FENCE();                                                 \
+        WD_MMA(F, 4);  WD_FENCE(); WD_READ2(Fn, NS_, 4); WD_FENCE();                                                 \
+        WD_MMA(F, 5);  WD_FENCE(); WD_READ2(Fn, NS_, 5); WD_FENCE();                                                 \
+        WD_MMA(F, 6);  WD_FENCE(); WD_READ2(Fn, NS_, 6); WD_FENCE();                                                 \
+        WD_MMA(F, 7);  WD_FENCE(); WD_READ2(Fn, NS_, 7); WD_FENCE();                                                 \
+        WD_MMA(F, 8);  WD_FENCE();                                                                                   \
+        if (do_colsum) colsum_stage(smem + NS_ * STG);                                                               \
+        WD_FENCE();                                                                                                  \
+        WD_MMA(F, 9);  WD_FENCE();                                                                                   \
+        WD_MMA(F, 10); WD_FENCE();                                                                                   \
+        WD_MMA(F, 11); WD_FENCE();                                                                                   \
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                                  \
+        __builtin_amdgcn_s_barrier();                                                                                \
+        WD_FENCE();                                                                                                  \
+    } while (0)
+
+    for (int u = 0; u < nsub; u += 4) {
+        WD_STEP(0, F0, F1);
+        WD_STEP(1, F1, F0);
+        WD_STEP(2, F0, F1);
+        WD_STEP(3, F1, F0);
+    }
+#undef WD_STEP
+#undef WD_MMA
+#undef WD_READ2
+#undef WD_FENCE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the loads past the end (zeros) still write LDS
+
+    if (do_colsum) {
+        // (the colsum of steps nsub.. read zeros; step 0 was added in the prologue)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);       // [16 rows][128 columns]
+        const int r = t >> 4, c = (t & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[r * 128 + 8 * c + k] = cs8[k];
+        __syncthreads();
+        if (t < 128 && n0 + t < p.Cdy) {
+            float v = 0.f;
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) v += red[r2 * 128 + t];
+            atomicAdd(p.colsum + n0 + t, v / sy);
+        }
+    }
+    // C/D layout: col = lane&31 (co), row = (r&3) + 8*(r>>2) + 4*half (k)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = n0 + wn * 64 + 32 * j + l31;
+        if (co >= p.Cdy) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = q0c * 8 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (k < p.kchunks * 4) atomicAdd(p.dw + (long long)k * p.Cdy + co, acc[i][j][r] * post);
+            }
+    }
+}
+
+// fp32 [n][C] -> fp16 high / low cells with the scale shadow_scale_for predicts from `prev` (layer-level entry point only: inside the
+// training step the producers' epilogues write the copies)
+__global__ __launch_bounds__(256) void f32_to_shadow_kernel(const float4* __restrict__ x, long long n8, const float* __restrict__ prev,
+                                                            uint4* __restrict__ out) {
+    const float s = shadow_scale_for(prev, threadIdx.x & 63);
+    if (!(s > 0.f)) return;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < n8; g += (long long)gridDim.x * 256) {
+        const float4 a = x[2 * g], b = x[2 * g + 1];
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint4 hi, lo;
+        h2_pack8(v, s, hi, lo);
+        out[2 * g] = hi; out[2 * g + 1] = lo;
+    }
+}
+
 // dW = scale * dWraw (HWIO, real Cin) and dot[co] += sum_k W[k][co] * dWraw[k][co]   (grid: k-chunks x co-tiles of 64)
 __global__ __launch_bounds__(256) void scale_dw_dot_kernel(const float* __restrict__ dwraw, const float* __restrict__ w,
                                                            const float* __restrict__ scale, int taps, int cin, int cin_real,
@@ -1205,6 +1475,7 @@ struct TLayer {
 struct TPlanFwd;
 struct RangeCtx {
     float* pool = nullptr;            // RANGE_POOL slot arrays of ABSMAX_SLOTS floats
+    float* prev = nullptr;            // the pool as the previous pass of the same kind (forward / backward) left it: scales of the fp16 copies
     int next = 0, limit = 0;
     std::map<const void*, const float*> of;     // tensor / panel pointer -> its slot array
     // second forward chain (frames [n1, B)): its own slot arrays, CHAIN2_OFF arrays above the first chain's and taken in the same
@@ -1230,6 +1501,11 @@ struct TrainCtx {
     size_t ev_next = 0;
     std::multimap<const void*, hipEvent_t> readers;
     bool overlap = false;                        // set for the duration of a backward pass
+    // fp16 high / low copies of retained activations and gradient buffers (ConvArgs::shadow), operands of wgrad_dma:
+    // tensor base -> copy base (from the plan, per pass); tensor base -> previous-step range slots of the launch that WROTE the copy
+    // in this pass (absent: no copy of the current contents exists)
+    std::unordered_map<const void*, float*> shadow_base;
+    std::unordered_map<const void*, const float*> shadow_prev;
     ~TrainCtx() {
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         if (s2) (void)hipStreamDestroy(s2);
@@ -1256,6 +1532,7 @@ struct dgp_trainer {
     double* d_sumsq = nullptr;
     float* d_gnorm = nullptr;
     float* d_rng_pool = nullptr;      // activation / gradient range slots (RANGE_POOL arrays), zeroed per pass
+    float* d_rng_prev = nullptr;      // ... as the previous step left them (copied before the zeroing)
     float* d_wrng = nullptr;          // weight-panel range slots: [2 * n_layers] (forward panels, data-gradient panels), per sync
     void* d_pack_table = nullptr;     // PackDesc of every non-head layer (pack_all_kernel), built at the first sync
     int n_pack = 0;
@@ -1264,7 +1541,7 @@ struct dgp_trainer {
     void* d_fin_table = nullptr;      // FinDesc of every non-head layer (deferred weight-gradient finalisation), per batch size
     int n_fin = 0, fin_B = -1, fin_h = -1, fin_w = -1;
     ~dgp_trainer() {
-        for (void* q : {(void*)d_rng_pool, (void*)d_wrng, d_pack_table, d_fin_table, d_h3_table}) if (q) (void)hipFree(q);
+        for (void* q : {(void*)d_rng_pool, (void*)d_rng_prev, (void*)d_wrng, d_pack_table, d_fin_table, d_h3_table}) if (q) (void)hipFree(q);
         for (auto& t : tl) { if (t.d_wT) (void)hipFree(t.d_wT); if (t.d_wTh3) (void)hipFree(t.d_wTh3); }
         for (void* p : {(void*)params, (void*)grads, (void*)mom, (void*)stats, (void*)d_sumsq, (void*)d_gnorm})
             if (p) (void)hipFree(p);
@@ -1285,8 +1562,14 @@ struct TPlan {
     // per-layer weight-gradient scratch (non-head layers): [colsum | dot][dWraw], one contiguous region zeroed once per backward pass
     std::vector<size_t> cs_l, dw_l;
     size_t dwall = 0, dwall_bytes = 0;
+    // fp16 high / low copies (ConvArgs::shadow) of the tensors the 128 x 128 weight-gradient tiles read; 0: none
+    std::vector<size_t> sh_r1, sh_r2, sh_xo;
+    size_t sh_g0 = 0, sh_g1 = 0, sh_dr1 = 0, sh_dr2 = 0, sh_dr1_b = 0, sh_dr2_b = 0;
     size_t total;
 };
+
+// A/B switch (DGP_WGRAD_DMA=0: no copies, wgrad_h3p as before)
+static const bool g_wgrad_dma = !(getenv("DGP_WGRAD_DMA") && atoi(getenv("DGP_WGRAD_DMA")) == 0);
 
 size_t al(size_t x) { return (x + 255) / 256 * 256; }
 
@@ -1341,6 +1624,21 @@ TPlan make_tplan(const dgp_trainer* tr, int B) {
         p.dw_l[li] = take((size_t)l.KH * l.KW * l.Cin * l.Cout);
     }
     p.dwall_bytes = o - p.dwall;
+    p.sh_r1.assign(net->units.size(), 0); p.sh_r2.assign(net->units.size(), 0); p.sh_xo.assign(net->units.size(), 0);
+    if (g_wgrad_dma) {
+        int hh = net->hp, ww = net->wp;
+        for (size_t ui = 0; ui < net->units.size(); ++ui) {
+            const Unit& u = net->units[ui];
+            const int ho = (hh + u.stride - 1) / u.stride, wo = (ww + u.stride - 1) / u.stride;
+            // a copy pays where a 128 x 128 tile reads it: r1 feeds conv2 (K = 9 C1, Cdy = C1), r2 feeds conv3, xo the next unit's conv1 / shortcut
+            if (u.depth_bn >= 128) p.sh_r1[ui] = take((size_t)B * hh * ww * u.depth_bn);
+            if (u.depth_bn >= 128) p.sh_r2[ui] = take((size_t)B * ho * wo * u.depth_bn);
+            if (ui + 1 < net->units.size() && net->units[ui + 1].depth_bn >= 128) p.sh_xo[ui] = take((size_t)B * ho * wo * u.depth);
+            hh = ho; ww = wo;
+        }
+        p.sh_g0 = take(xmax); p.sh_g1 = take(xmax);
+        p.sh_dr1 = take(r1max); p.sh_dr2 = take(r2max); p.sh_dr1_b = take(r1max); p.sh_dr2_b = take(r2max);
+    }
     p.total = o;
     return p;
 }
@@ -1395,7 +1693,15 @@ static void range_pass_begin(dgp_trainer* tr, hipStream_t s, bool backward) {
     g_ctx->rng.chain2 = false;
     if (!backward) { g_ctx->rng.of.clear(); g_ctx->rng.of2.clear(); g_ctx->rng.next = 0; g_ctx->rng.next2 = 0; g_ctx->rng.limit = RANGE_FWD; }
     else { g_ctx->rng.next = 2 * RANGE_FWD; g_ctx->rng.limit = RANGE_POOL; }
+    g_ctx->rng.prev = tr->d_rng_prev;
+    if (!backward) g_ctx->shadow_prev.clear();
     if (!g_ctx->rng.on) return;
+    // what this kind of pass measured one step ago predicts the scales of this pass's fp16 copies (chain 2's own slots are not needed:
+    // after the merge chain 1's hold the maxima of the whole tensors)
+    if (g_wgrad_dma && tr->d_rng_prev)
+        (void)hipMemcpyAsync(reinterpret_cast<char*>(tr->d_rng_prev) + (backward ? fwd_bytes : 0),
+                             reinterpret_cast<char*>(tr->d_rng_pool) + (backward ? fwd_bytes : 0),
+                             backward ? bwd_bytes : fwd_bytes / 2, hipMemcpyDeviceToDevice, s);
     (void)hipMemsetAsync(reinterpret_cast<char*>(tr->d_rng_pool) + (backward ? fwd_bytes : 0), 0, backward ? bwd_bytes : fwd_bytes, s);
     if (backward) return;
     const size_t nl = tr->net->layers.size();
@@ -1405,6 +1711,16 @@ static void range_pass_begin(dgp_trainer* tr, hipStream_t s, bool backward) {
     }
 }
 
+
+// previous-step slots of the tensor that takes `slot` in this pass (the passes take their slots in the same order every step)
+static const float* range_prev_of(const float* slot) {
+    if (!slot || !g_ctx || !g_ctx->rng.pool || !g_ctx->rng.prev) return nullptr;
+    long long idx = (slot - g_ctx->rng.pool) / ABSMAX_SLOTS;
+    if (idx < 0 || idx >= RANGE_POOL) return nullptr;
+    if (idx >= RANGE_FWD && idx < 2 * RANGE_FWD) idx -= RANGE_FWD;      // chain 2 writes its frames of the same copy with the same scale
+    return g_ctx->rng.prev + idx * ABSMAX_SLOTS;
+}
+static thread_local bool g_shadow_want = true;      // backward pass: only gradients that a 128 x 128 weight-gradient tile will read
 
 // weight panel -> the same panel pre-split into fp16 cells (filled by dgp_trainer_sync_weights): with the cells and both ranges the
 // conv runs on the compute-side-split / LDS-DMA kernels of the inference engine
@@ -1447,12 +1763,28 @@ hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, 
         a.out_absmax = range_take();
         range_set(out_key ? out_key : out, a.out_absmax);
     }
-    return launch_conv(a, pick_tile(a.M, coutP, nk * BK, a.in_absmax && a.w_absmax), s);
+    const int tile = pick_tile(a.M, coutP, nk * BK, a.in_absmax && a.w_absmax);
+    if (g_ctx && out_mode == 0) {
+        // fp16 copy of the output for wgrad_dma: kernels that end in ls_epilogue / tail_fixup_kernel write it
+        const void* key = out_key ? out_key : (const void*)out;
+        const auto sb = g_ctx->shadow_base.find(key);
+        const float* prev = range_prev_of(a.out_absmax);
+        if (sb != g_ctx->shadow_base.end() && g_shadow_want && prev && (tile == TILE_128x128_H3K32 || tile == TILE_128x64_H3) &&
+            a.in_absmax && a.w_absmax && Cin >= 32 && Cout % 8 == 0) {
+            a.shadow = sb->second + (out - static_cast<const float*>(key));
+            a.shadow_prev = prev;
+            g_ctx->shadow_prev[key] = prev;
+        } else {
+            g_ctx->shadow_prev.erase(key);
+        }
+    }
+    return launch_conv(a, tile, s);
 }
 
 hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const float* dy, int Ho, int Wo, int Cdy, int KH,
                         int KW, int stride, int dil, int pad_t, int pad_l, float* dwraw, float* colsum, hipStream_t s,
-                        bool zeroed = false, const float* rx_given = nullptr, const float* rdy_given = nullptr) {
+                        bool zeroed = false, const float* rx_given = nullptr, const float* rdy_given = nullptr,
+                        const void* xs = nullptr, const float* x_prev = nullptr, const void* dys = nullptr, const float* dy_prev = nullptr) {
     WgradArgs a{};
     a.x = x; a.dy = dy; a.dw = dwraw; a.colsum = colsum; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.log2cin4 = ilog2(Cin / 4);
     a.Ho = Ho; a.Wo = Wo; a.Cdy = Cdy; a.KW = KW; a.stride = stride; a.dil = dil; a.pad_t = pad_t; a.pad_l = pad_l;
@@ -1483,15 +1815,28 @@ hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const floa
     static const int wgs_target = getenv("DGP_WGRAD_WGS") ? atoi(getenv("DGP_WGRAD_WGS")) : 512;
     static const int wgs_small = getenv("DGP_WGRAD_WGS_SMALL") ? atoi(getenv("DGP_WGRAD_WGS_SMALL")) : 1024;      // 64 x 64 tiles: 1024 (16.7 vs 16.9 ms at 512)
     int split = std::max(1, (big ? wgs_target : wgs_small) / (kt * nt));
-    int mpb = ((a.M + split - 1) / split + 31) / 32 * 32;
+    int mpb = ((a.M + split - 1) / split + 63) / 64 * 64;      // (64: wgrad_dma walks 16-pixel steps unrolled by four)
     if (mpb < 256) mpb = 256;
     split = (a.M + mpb - 1) / mpb;
     a.m_per_block = mpb;
-    static bool attr_dev[16][3] = {};
+    static bool attr_dev[16][4] = {};
     auto& attr = attr_dev[dgp_device_slot()];
     static const bool h3_env = !(getenv("DGP_WGRAD_F16") && atoi(getenv("DGP_WGRAD_F16")) == 0);       // A/B switch
     const float* rx = rx_given ? rx_given : range_of(x);
     const float* rdy = rdy_given ? rdy_given : range_of(dy);
+    // both operands also exist as fp16 high / low copies written by their producers: LDS-DMA tile (falls back per workgroup to the
+    // fp32-MFMA tile when this step's ranges left the copies' predicted scales)
+    if (big && h3_env && g_wgrad_dma && rx && rdy && xs && dys && x_prev && dy_prev && Cin % 16 == 0 && Cdy % 8 == 0 &&
+        (double)a.x_bytes + 80.0 * Cin * 4 < 4294967000.0 && (double)a.dy_bytes + 80.0 * Cdy * 4 < 4294967000.0) {
+        if (!attr[3]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            if (e != hipSuccess) return e;
+            attr[3] = true;
+        }
+        a.xs = xs; a.dys = dys; a.x_prev = x_prev; a.x_cur = rx; a.dy_prev = dy_prev; a.dy_cur = rdy;
+        hipLaunchKernelGGL(wgrad_dma, dim3(kt, nt, split), dim3(256), 64 * 1024, s, a);
+        return hipGetLastError();
+    }
     if (big && h3_env && rx && rdy && Cin % 4 == 0) {      // both operand ranges known: 16-bit matrix pipe
         if (!attr[2]) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -1600,6 +1945,9 @@ int dgp_trainer_create(dgp_net* net, dgp_trainer** out) {
     }
     (void)hipMemset(tr->params, 0, nb); (void)hipMemset(tr->grads, 0, nb); (void)hipMemset(tr->mom, 0, nb);
     if (hipMalloc(&tr->d_rng_pool, (size_t)RANGE_POOL * ABSMAX_SLOTS * sizeof(float)) != hipSuccess ||
+        hipMalloc(&tr->d_rng_prev, (size_t)RANGE_POOL * ABSMAX_SLOTS * sizeof(float)) != hipSuccess ||
+        hipMemset(tr->d_rng_pool, 0, (size_t)RANGE_POOL * ABSMAX_SLOTS * sizeof(float)) != hipSuccess ||
+        hipMemset(tr->d_rng_prev, 0, (size_t)RANGE_POOL * ABSMAX_SLOTS * sizeof(float)) != hipSuccess ||
         hipMalloc(&tr->d_wrng, (size_t)2 * net->layers.size() * ABSMAX_SLOTS * sizeof(float)) != hipSuccess) {
         delete tr;
         return fail(DGP_ERR_HIP, "dgp_trainer_create: hipMalloc failed");
@@ -1775,6 +2123,13 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     auto F = [&](size_t off) { return (float*)(ws + off); };
     g_ctx->tail_slab = F(pl.tail);
     range_pass_begin(tr, s, false);
+    g_ctx->shadow_base.clear();
+    g_shadow_want = true;
+    for (size_t ui = 0; ui < net->units.size(); ++ui) {
+        if (pl.sh_r1[ui]) g_ctx->shadow_base[F(pl.r1[ui])] = F(pl.sh_r1[ui]);
+        if (pl.sh_r2[ui]) g_ctx->shadow_base[F(pl.r2[ui])] = F(pl.sh_r2[ui]);
+        if (pl.sh_xo[ui]) g_ctx->shadow_base[F(pl.xo[ui])] = F(pl.sh_xo[ui]);
+    }
     const dgp_net_desc& d = net->desc;
     const int B = nt;
     // The forward pass as TWO chains of frames (DGP_FWD_CHAINS=1: one): frames [0, n1) on the caller's stream, [n1, B) on the trainer's
@@ -1941,9 +2296,19 @@ static int layer_param_grads(dgp_trainer* tr, size_t li, const float* x, int N, 
             TRY_HIP(hipStreamWaitEvent(g_ctx->s2, ready, 0));
             ws_ = g_ctx->s2;
         }
+        const void *xs = nullptr, *dys = nullptr;
+        const float *xp = nullptr, *dyp = nullptr;
+        {
+            const auto px = g_ctx->shadow_prev.find(x), py = g_ctx->shadow_prev.find(dy);
+            const auto bx = g_ctx->shadow_base.find(x), by = g_ctx->shadow_base.find(dy);
+            if (px != g_ctx->shadow_prev.end() && py != g_ctx->shadow_prev.end() && bx != g_ctx->shadow_base.end() && by != g_ctx->shadow_base.end()) {
+                xs = bx->second; xp = px->second; dys = by->second; dyp = py->second;
+            }
+        }
         TRY_HIP(wgrad_launch(x, N, H, W, l.Cin, dy, Ho, Wo, l.Cout, l.KH, l.KW, stride, l.rate, pad_t, pad_l,
                              reinterpret_cast<float*>(g_ctx->defer_ws + ((const TPlan*)g_ctx->defer_plan)->dw_l[li]),
-                             reinterpret_cast<float*>(g_ctx->defer_ws + ((const TPlan*)g_ctx->defer_plan)->cs_l[li]), ws_, true));
+                             reinterpret_cast<float*>(g_ctx->defer_ws + ((const TPlan*)g_ctx->defer_plan)->cs_l[li]), ws_, true,
+                             nullptr, nullptr, xs, xp, dys, dyp));
         if (done) {
             TRY_HIP(hipEventRecord(done, g_ctx->s2));
             g_ctx->readers.emplace((const void*)dy, done);
@@ -1974,6 +2339,11 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
     auto F = [&](size_t off) { return (float*)(ws + off); };
     g_ctx->tail_slab = F(pl.tail);
     range_pass_begin(tr, s, true);
+    if (pl.sh_g0) {
+        const size_t gb[6][2] = {{pl.g0, pl.sh_g0}, {pl.g1, pl.sh_g1}, {pl.dr1, pl.sh_dr1}, {pl.dr2, pl.sh_dr2}, {pl.dr1_b, pl.sh_dr1_b}, {pl.dr2_b, pl.sh_dr2_b}};
+        for (const auto& q : gb) { g_ctx->shadow_base[F(q[0])] = F(q[1]); g_ctx->shadow_prev.erase(F(q[0])); }
+    }
+    struct WantReset { ~WantReset() { g_shadow_want = true; } } want_reset;
     const dgp_net_desc& d = net->desc;
     const int B = nt, nj = d.num_joints;
     const int nu = (int)net->units.size();
@@ -2101,6 +2471,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         rc = layer_param_grads(tr, u.c3, F(pl.r2[ui]), B, ho, wo, Gout, ho, wo, 1, 0, 0, dwraw, colsum, s);
         if (rc) return rc;
         TRY_HIP(before_write(DR2));
+        g_shadow_want = u.depth_bn >= 128;       // dR2 -> conv2's weight gradient (9 C1 x C1)
         TRY_HIP(conv_launch(l3, t3.d_wT, t3.nkT, t3.cinP, Gout, B, ho, wo, l3.Cout, 0, 0, ho, wo, l3.Cin, 1, 0, nullptr, nullptr,
                             nullptr, 0, 0, 0, F(pl.r2[ui]), false, 0, 0, DR2, s));
         // conv2: params, then dR1 = convT(dR2) gated by R1 > 0
@@ -2109,6 +2480,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         if (rc) return rc;
         const int keff = 2 * u.rate + 1;
         TRY_HIP(before_write(DR1));
+        g_shadow_want = u.depth_bn >= 128 && u.depth_in >= 128;      // dR1 -> conv1's weight gradient (Cin x C1)
         TRY_HIP(conv_launch(l2, t2.d_wT, t2.nkT, t2.cinP, DR2, B, ho, wo, l2.Cout, keff - 1 - pb_h, keff - 1 - pb_w, h, w,
                             l2.Cin, 1, u.stride > 1 ? u.stride : 0, nullptr, nullptr, nullptr, 0, 0, 0, F(pl.r1[ui]), false, 0, 0,
                             DR1, s));
@@ -2122,6 +2494,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
             rc = layer_param_grads(tr, u.sc, xin, B, h, w, Gout, ho, wo, u.stride, 0, 0, dwraw, colsum, s);
             if (rc) return rc;
             TRY_HIP(before_write(DXA));
+            g_shadow_want = false;                // (dXa is only added to the next data gradient)
             TRY_HIP(conv_launch(ls, ts.d_wT, ts.nkT, ts.cinP, Gout, B, ho, wo, ls.Cout, 0, 0, h, w, ls.Cin, 1,
                                 u.stride > 1 ? u.stride : 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, false, 0, 0, DXA, s));
             dxa = DXA; dxa_h = h; dxa_w = w;
@@ -2132,6 +2505,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         rc = layer_param_grads(tr, u.c1, xin, B, h, w, DR1, h, w, 1, 0, 0, dwraw, colsum, s);
         if (rc) return rc;
         TRY_HIP(before_write(Gin));              // (the G of two units ago: its conv3 / shortcut weight gradients)
+        g_shadow_want = ui > 0 && net->units[ui - 1].depth_bn >= 128;      // G of unit ui - 1 -> its conv3 / shortcut weight gradients
         TRY_HIP(conv_launch(l1, t1.d_wT, t1.nkT, t1.cinP, DR1, B, h, w, l1.Cout, 0, 0, h, w, l1.Cin, 1, 0, nullptr, nullptr,
                             dxa, dxa_mode, dxa_h, dxa_w, xin, false, 0, 0, Gin, s));
         cur ^= 1;
@@ -2205,6 +2579,33 @@ int dgp_conv2d_wgrad(const dgp_conv_desc* d, const float* x, const float* dy, co
     hipError_t e = wgrad_launch(x, d->N, d->H, d->W, d->Cin, dy, d->Ho, d->Wo, d->Cout, d->KH, d->KW, d->stride, d->rate, d->pad_t,
                                 d->pad_l, dw_raw, colsum, (hipStream_t)stream, false, x_absmax, dy_absmax);
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_conv2d_wgrad: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
+/* dgp_conv2d_wgrad through the LDS-DMA tile (wgrad_dma): x and dy are first copied into fp16 high / low cells with the scales that
+ * x_prev / dy_prev (range slots "of the previous step") predict, as the producers' epilogues do inside the training step; the kernel
+ * checks x_absmax / dy_absmax (this step's ranges) against them and runs the fp32-MFMA tile on x / dy where the copies are unusable.
+ * scratch: 4 * (numel(x) + numel(dy)) device bytes. */
+int dgp_conv2d_wgrad_shadow(const dgp_conv_desc* d, const float* x, const float* dy, const float* x_absmax, const float* dy_absmax,
+                            const float* x_prev, const float* dy_prev, void* scratch, float* dw_raw, float* colsum, void* stream) {
+    g_ctx = nullptr;
+    if (!d || !x || !dy || !dw_raw || !scratch || !x_absmax || !dy_absmax || !x_prev || !dy_prev)
+        return fail(DGP_ERR_INVALID, "dgp_conv2d_wgrad_shadow: null argument");
+    if (d->Cin < 16 || (d->Cin & 15) || ((d->Cin / 4) & (d->Cin / 4 - 1)) || (d->Cout & 7) || d->Cout < 128 || d->KH * d->KW * d->Cin < 128)
+        return fail(DGP_ERR_INVALID, "dgp_conv2d_wgrad_shadow: Cin must be 16 * 2^k, Cout a multiple of 8, and the tile 128 x 128 (K, Cout >= 128)");
+    if ((double)d->N * d->H * d->W * d->Cin * 4 > 4200000000.0 || (double)d->N * d->Ho * d->Wo * d->Cout * 4 > 4200000000.0)
+        return fail(DGP_ERR_INVALID, "dgp_conv2d_wgrad_shadow: tensor exceeds 4 GiB");
+    hipStream_t s = (hipStream_t)stream;
+    const long long nx = (long long)d->N * d->H * d->W * d->Cin, ny = (long long)d->N * d->Ho * d->Wo * d->Cout;
+    float* xs = (float*)scratch;
+    float* dys = xs + nx;
+    hipLaunchKernelGGL(f32_to_shadow_kernel, dim3(grid_for(nx / 8)), dim3(256), 0, s, reinterpret_cast<const float4*>(x), nx / 8, x_prev,
+                       reinterpret_cast<uint4*>(xs));
+    hipLaunchKernelGGL(f32_to_shadow_kernel, dim3(grid_for(ny / 8)), dim3(256), 0, s, reinterpret_cast<const float4*>(dy), ny / 8, dy_prev,
+                       reinterpret_cast<uint4*>(dys));
+    hipError_t e = wgrad_launch(x, d->N, d->H, d->W, d->Cin, dy, d->Ho, d->Wo, d->Cout, d->KH, d->KW, d->stride, d->rate, d->pad_t,
+                                d->pad_l, dw_raw, colsum, s, false, x_absmax, dy_absmax, xs, x_prev, dys, dy_prev);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_conv2d_wgrad_shadow: ") + hipGetErrorString(e));
     return DGP_OK;
 }
 

@@ -476,6 +476,30 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int = 1,
     return dw, cs[:Cout]
 
 
+def conv2d_wgrad_shadow(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int = 1, rate: int = 1, pad_t: int = 0, pad_l: int = 0,
+                        prev_ratio: Tuple[float, float] = (1.0, 1.0)):
+    """conv2d_wgrad through the training step's LDS-DMA tile: both operands are copied into fp16 high / low cells with the scales a
+    "previous step" whose maxima were prev_ratio times this step's would predict (1.0: the steady state; 2^-6 or 2^8: the prediction
+    fails and the kernel computes the tile from the fp32 tensors; 0: no previous range at all, the first step)."""
+    lib = _lib.load()
+    _need_cuda(x, torch.float32, "x")
+    _need_cuda(dy, torch.float32, "dy")
+    dev = x.device
+    N, H, W, Cin = x.shape
+    _, Ho, Wo, Cout = dy.shape
+    d = _conv_desc(x.shape, (ksize, ksize, Cin, Cout), stride, rate, pad_t, pad_l, (Ho, Wo))
+    dw = torch.empty((ksize, ksize, Cin, Cout), dtype=torch.float32, device=dev)
+    cs = torch.empty(2 * Cout, dtype=torch.float32, device=dev)
+    rng = torch.zeros((2, ABSMAX_SLOTS), dtype=torch.float32, device=dev)
+    _lib.check(lib.dgp_tensor_absmax(_ptr(x), x.numel(), _ptr(rng[0]), _stream(dev)), "dgp_tensor_absmax")
+    _lib.check(lib.dgp_tensor_absmax(_ptr(dy), dy.numel(), _ptr(rng[1]), _stream(dev)), "dgp_tensor_absmax")
+    prev = torch.stack([rng[0] * float(prev_ratio[0]), rng[1] * float(prev_ratio[1])]).contiguous()
+    scratch = torch.empty(x.numel() + dy.numel(), dtype=torch.float32, device=dev)
+    _lib.check(lib.dgp_conv2d_wgrad_shadow(C.byref(d), _ptr(x), _ptr(dy), _ptr(rng[0]), _ptr(rng[1]), _ptr(prev[0]), _ptr(prev[1]),
+                                           _ptr(scratch), _ptr(dw), _ptr(cs), _stream(dev)), "dgp_conv2d_wgrad_shadow")
+    return dw, cs[:Cout]
+
+
 def conv2d_dgrad(dy: torch.Tensor, w_hwio: torch.Tensor, x_hw: Tuple[int, int], stride: int = 1, rate: int = 1, pad_t: int = 0,
                  pad_l: int = 0, scale: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
                  dx_add: Optional[torch.Tensor] = None, add_mode: int = 1, ranged: bool = True) -> torch.Tensor:

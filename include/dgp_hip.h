@@ -250,6 +250,16 @@ int  dgp_conv2d_ranged(const dgp_conv_desc* d, const float* x, const float* pack
  *                      (add_mode -2, the subsample shortcut).  scratch: dgp_conv2d_dgrad_scratch_bytes(d) device bytes. */
 int    dgp_conv2d_wgrad(const dgp_conv_desc* d, const float* x, const float* dy, const float* x_absmax, const float* dy_absmax,
                         float* dw_raw, float* colsum, void* stream);
+/* dgp_conv2d_wgrad on the LDS-DMA tile of the training step (csrc/dgp_train.hip, wgrad_dma).  Inside dgp_train_backward both operands
+ * of a 128 x 128 weight-gradient tile also exist as fp16 high / low cells (the H2 layout below), written by their producers' epilogues
+ * with a power-of-two scale PREDICTED from the range the same tensor had one step earlier (max -> [2^10, 2^11)); the kernel moves the
+ * cells by LDS-DMA (no split arithmetic, no register staging) and checks this step's ranges against the predicted scales: outside
+ * [2^4, 65000) after scaling -- first step, a jump of more than 2^5 -- the workgroup computes its tile from the fp32 tensors on the
+ * fp32 matrix pipe instead.  This entry point makes the copies itself from x / dy and the given "previous" ranges, so that the tile
+ * and both of its paths can be checked layer by layer.  scratch: 4 * (numel(x) + numel(dy)) device bytes; x_absmax / dy_absmax /
+ * x_prev / dy_prev: DGP_ABSMAX_SLOTS floats each; Cin = 16 * 2^k, Cout % 8 == 0, KH * KW * Cin >= 128, Cout >= 128. */
+int    dgp_conv2d_wgrad_shadow(const dgp_conv_desc* d, const float* x, const float* dy, const float* x_absmax, const float* dy_absmax,
+                               const float* x_prev, const float* dy_prev, void* scratch, float* dw_raw, float* colsum, void* stream);
 size_t dgp_conv2d_dgrad_scratch_bytes(const dgp_conv_desc* d);
 int    dgp_conv2d_dgrad(const dgp_conv_desc* d, const float* dy, const float* w_hwio, const float* scale, const float* mask,
                         const float* dx_add, int32_t add_mode, float* dx, void* scratch, int32_t ranged, void* stream);

@@ -76,6 +76,53 @@ def test_wgrad_layer_matches_float64(lib_built, case, ranged):
     assert float((cs.double() - cref).abs().max() / (cref.abs().max() + 1e-30)) < REL_TOL
 
 
+# the LDS-DMA tile of the training step (wgrad_dma): 128 x 128 layers only
+DMA_CASES = [c for c in WGRAD_CASES if c[4] >= 128 and c[3] * c[5] * c[5] >= 128] + [
+    (11, 30, 40, 256, 1024, 1, 1, 1),       # block3 conv3
+    (11, 60, 80, 128, 512, 1, 1, 1),        # block2 conv3 (one k-tile)
+    (3, 13, 17, 64, 136, 3, 1, 1),          # ragged everything: Wo < 16 (several row wraps per step), Cout % 128 != 0, M % 16 != 0, two taps per k-tile
+    (2, 9, 11, 32, 128, 3, 2, 1),           # stride 2, four taps per k-tile, K = 288 (the last k-tile is part empty)
+]
+
+
+@pytest.mark.parametrize("ratio", [(1.0, 1.0), (0.4, 3.0), (2.0 ** -6, 1.0), (1.0, 2.0 ** 8), (0.0, 1.0)])
+@pytest.mark.parametrize("case", DMA_CASES)
+def test_wgrad_dma_tile_matches_float64(lib_built, case, ratio):
+    """Both operands as fp16 high / low copies with predicted scales.  ratio = (previous / current maximum) of (x, dy): inside the
+    usable window the LDS-DMA path runs, outside it (or with no previous range) the fp32-MFMA path of the same kernel -- same tolerance."""
+    from deepgraphpose_amd import engine
+    N, H, W, Cin, Cout, k, stride, rate = case
+    if ratio != (1.0, 1.0) and case not in (DMA_CASES[0], DMA_CASES[-2]):
+        pytest.skip("failed-prediction paths: one large and one ragged shape")
+    g = torch.Generator(device="cuda").manual_seed(hash(case) % (2 ** 31))
+    pad_t, Ho = _same_pads(H, k, stride, rate)
+    pad_l, Wo = _same_pads(W, k, stride, rate)
+    x = torch.relu(torch.randn((N, H, W, Cin), generator=g, device="cuda"))
+    dy = torch.randn((N, Ho, Wo, Cout), generator=g, device="cuda") * 1e-3
+    dy[torch.rand((N, Ho, Wo, Cout), generator=g, device="cuda") < 0.4] = 0.0
+    dw, cs = engine.conv2d_wgrad_shadow(x, dy, k, stride, rate, pad_t, pad_l, prev_ratio=ratio)
+    cols = _im2col64(x.double(), k, stride, rate, pad_t, pad_l, Ho, Wo)
+    ref = (cols.t() @ dy.double().reshape(-1, Cout)).reshape(k, k, Cin, Cout)
+    err = float((dw.double() - ref).abs().max() / ref.abs().max())
+    assert err < REL_TOL, (case, ratio, err)
+    cref = dy.double().reshape(-1, Cout).sum(0)
+    assert float((cs.double() - cref).abs().max() / (cref.abs().max() + 1e-30)) < REL_TOL
+
+
+def test_wgrad_dma_tile_small_values_keep_their_bits(lib_built):
+    """A tensor whose bulk sits 2^-12 below its maximum (one outlier sets the scale): the copies' low pieces go subnormal there, the
+    products still carry >= 18 bits and the sum over 13 200 pixels stays inside the layer tolerance."""
+    from deepgraphpose_amd import engine
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.relu(torch.randn((11, 30, 40, 256), generator=g, device="cuda")) * 2.0 ** -12
+    x[0, 0, 0, 0] = 3.0
+    dy = torch.randn((11, 30, 40, 256), generator=g, device="cuda") * 1e-7
+    dy[3, 4, 5, 6] = 2e-4
+    dw, _ = engine.conv2d_wgrad_shadow(x, dy, 1)
+    ref = (x.double().reshape(-1, 256).t() @ dy.double().reshape(-1, 256)).reshape(1, 1, 256, 256)
+    assert float((dw.double() - ref).abs().max() / ref.abs().max()) < REL_TOL
+
+
 def _dgrad_ref(dy, w, H, W, stride, rate, pad_t, pad_l):
     """float64: dx[n, h, w, ci] = sum over taps / co of dy[n, ho, wo, co] * w[kh, kw, ci, co] with h = ho*s + kh*r - pad."""
     N, Ho, Wo, Cout = dy.shape
