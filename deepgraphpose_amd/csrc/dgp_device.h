@@ -78,6 +78,13 @@ __device__ __forceinline__ bool shadow_usable(float scale, const float* cur, int
     return v >= 16.f && v < 65000.f;
 }
 
+// scales of H2 tensors inside a kernel: the host-known float, or the prediction from the previous step's range slots (ConvArgs::*_scale_dev)
+__device__ __forceinline__ float h2_in_scale(const ConvArgs& p, int lane) { return p.in_scale_dev ? shadow_scale_for(p.in_scale_dev, lane) : p.in_scale; }
+__device__ __forceinline__ float h2_out_scale(const ConvArgs& p, int lane) { return p.out_scale_dev ? shadow_scale_for(p.out_scale_dev, lane) : p.out_scale; }
+__device__ __forceinline__ float h2_res_inv_scale(const ConvArgs& p, int lane) {
+    return p.res_scale_dev ? 1.f / shadow_scale_for(p.res_scale_dev, lane) : p.res_inv_scale;
+}
+
 __device__ __forceinline__ void split2_f16(const float4 v, const float s, uint2& ph, uint2& pl) {
 #if defined(DGP_SPLIT_PK)
     const float2v x01 = {v.x * s, v.y * s}, x23 = {v.z * s, v.w * s};
@@ -120,6 +127,16 @@ __device__ __forceinline__ void h2_unpack8(const uint4 hi, const uint4 lo, float
     const half8 h = __builtin_bit_cast(half8, hi), l = __builtin_bit_cast(half8, lo);
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = ((float)h[k] + (float)l[k]) * inv_scale;      // hi + lo is exact in fp32 (22 bits)
+}
+
+// ReLU gate read from an H2 tensor: 4 channels' high halves (h) and low halves (l); the stored value hi + lo is > 0 exactly when
+// hi > 0, or hi == 0 and lo > 0.  Returned as 4 floats that compare > 0 like the value.
+__device__ __forceinline__ float h2_half_bits(unsigned v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)v); }
+__device__ __forceinline__ float4 h2_gate4(const u32x2 h, const u32x2 l) {
+    // (written on the 16-bit patterns: a bit_cast of h.y to a two-half vector was compiled as a second read of h.x)
+    const unsigned h0 = h[0], h1 = h[1], l0 = l[0], l1 = l[1];
+    return make_float4(h2_half_bits(h0 & 0xFFFFu) + h2_half_bits(l0 & 0xFFFFu), h2_half_bits(h0 >> 16) + h2_half_bits(l0 >> 16),
+                       h2_half_bits(h1 & 0xFFFFu) + h2_half_bits(l1 & 0xFFFFu), h2_half_bits(h1 >> 16) + h2_half_bits(l1 >> 16));
 }
 
 }  // namespace dgp

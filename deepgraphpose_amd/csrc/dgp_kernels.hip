@@ -401,6 +401,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_f32(const C
 // barriers: the loader waves are gone).  acc -> scale/bias/residual/ReLU/mask -> 16-byte stores.
 // M16: the caller's accumulators are the 2 x 8 blocks of v_mfma_f32_16x16x32 and it has staged them into the wave's LDS tile itself
 // (block (i, j) register r of lane l = row 16 i + 4 (l >> 4) + r, column 16 j + (l & 15)); `acc` is not read
+#ifndef DGP_SHADOW_AUX
+#define DGP_SHADOW_AUX 0
+#endif
 template <int TM, int TN, int WN, bool M16 = false>
 __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[TM][TN], char* smem, int wave, int lane,
                                             int m0, int n0, int wave_m0, int wave_n0, float post = 1.f) {
@@ -491,7 +494,15 @@ __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[T
         float4 rmask[VC];          // ReLU gate of the training step's data-gradient convs: not pipelined (keeps the forward lean)
         if (p.mask) {
 #pragma unroll
-            for (int u = 0; u < VC; ++u) rmask[u] = buf_load16(rs_mask, ooff[slot][u]);
+            for (int u = 0; u < VC; ++u) {
+                if (p.mask_fmt) {      // H2 gate tensor: this lane's 4 channels are 8 bytes of the cell's high chunk and 8 of its low chunk
+                    const unsigned mo = (ooff[slot][u] & ~31u) + ((ooff[slot][u] & 16u) >> 1);
+                    // (bit_cast: the builtin's result converts to a vector by splatting its low dword)
+                    const u32x2 mh = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_mask, (int)mo, 0, 0));
+                    const u32x2 ml = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_mask, (int)(mo + 16u), 0, 0));
+                    rmask[u] = h2_gate4(mh, ml);
+                } else rmask[u] = buf_load16(rs_mask, ooff[slot][u]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < VC; ++u) {
@@ -512,8 +523,9 @@ __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[T
                 uint2 sh, sl;
                 split2_f16(o, sh_scale, sh, sl);
                 const unsigned so = (ooff[slot][u] & ~31u) + ((ooff[slot][u] & 16u) >> 1);      // cell base + this half's 8 bytes
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), rs_sh, (int)so, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), rs_sh, (int)(so + 16u), 0, 0);
+                // (DGP_SHADOW_AUX=2, non-temporal stores, measured no better: the gradient copies are read back within a few launches)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), rs_sh, (int)so, 0, DGP_SHADOW_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), rs_sh, (int)(so + 16u), 0, DGP_SHADOW_AUX);
             }
             if (ooff[slot][u] != OOB) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
@@ -881,6 +893,7 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
         const float4 a = *reinterpret_cast<const float4*>(p.bias + co8), b = *reinterpret_cast<const float4*>(p.bias + co8 + 4);
         bi[0] = a.x; bi[1] = a.y; bi[2] = a.z; bi[3] = a.w; bi[4] = b.x; bi[5] = b.y; bi[6] = b.z; bi[7] = b.w;
     }
+    const float out_scale = h2_out_scale(p, lane), res_inv_scale = p.res_fmt ? h2_res_inv_scale(p, lane) : 1.f;
     float amax = 0.f;
     unsigned ooff[2][VC];
     uint4 rres[2][VC][2];
@@ -934,7 +947,7 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
             float o[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
             float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (p.res) {
-                if (p.res_fmt) h2_unpack8(rres[slot][u][0], rres[slot][u][1], p.res_inv_scale, r);
+                if (p.res_fmt) h2_unpack8(rres[slot][u][0], rres[slot][u][1], res_inv_scale, r);
                 else {
                     const float4 r0 = __builtin_bit_cast(float4, rres[slot][u][0]), r1 = __builtin_bit_cast(float4, rres[slot][u][1]);
                     r[0] = r0.x; r[1] = r0.y; r[2] = r0.z; r[3] = r0.w; r[4] = r1.x; r[5] = r1.y; r[6] = r1.z; r[7] = r1.w;
@@ -946,7 +959,7 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
                 if (p.relu) o[k] = fmaxf(o[k], 0.f);
             }
             uint4 hi, lo;
-            h2_pack8(o, p.out_scale, hi, lo);
+            h2_pack8(o, out_scale, hi, lo);
             const unsigned ooff1 = ooff[slot][u] == OOB ? OOB : ooff[slot][u] + 16u;
             if (p.epi_nt & 2) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), rs_out, (int)ooff[slot][u], 0, 2);
@@ -1378,7 +1391,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const float scA_c = (CS && !AH2) ? pow2_scale_for(p.in_absmax, lane, p.in2_absmax) : 1.f;       // operand scale of the compute-side split
     // exact power of two that undoes the fp16 operand scales; read now, while this wave waits for the first tile anyway
-    const float post = (NT == 2 && part < 0) ? 1.f / ((AH2 ? p.in_scale : pow2_scale_for(p.in_absmax, lane, p.in2_absmax)) * pow2_scale_for(p.w_absmax, lane)) : 1.f;
+    const float post = (NT == 2 && part < 0) ? 1.f / ((AH2 ? h2_in_scale(p, lane) : pow2_scale_for(p.in_absmax, lane, p.in2_absmax)) * pow2_scale_for(p.w_absmax, lane)) : 1.f;
 #ifdef DGP_DIAG
     unsigned long long e0, e1, e2, e3, acc_mf = 0, acc_ba = 0;
     DIAG_STAMP(e0);
@@ -1740,7 +1753,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
 template <int BM, int BN, bool F16>
 __global__ __launch_bounds__(256) void tail_fixup_kernel(const ConvArgs p) {
     const int lane = threadIdx.x & 63;
-    const float post = F16 ? 1.f / ((p.in_fmt ? p.in_scale : pow2_scale_for(p.in_absmax, lane, p.in2_absmax)) * pow2_scale_for(p.w_absmax, lane)) : 1.f;
+    const float post = F16 ? 1.f / ((p.in_fmt ? h2_in_scale(p, lane) : pow2_scale_for(p.in_absmax, lane, p.in2_absmax)) * pow2_scale_for(p.w_absmax, lane)) : 1.f;
     constexpr int C4 = BN / 4;
     const int per_tile = BM * C4;
     const int ntail = (int)gridDim.y;
@@ -1776,7 +1789,12 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const ConvArgs p) {
             o.x = a.x * sc.x + bi.x + rr.x; o.y = a.y * sc.y + bi.y + rr.y; o.z = a.z * sc.z + bi.z + rr.z; o.w = a.w * sc.w + bi.w + rr.w;
             if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
             if (p.mask) {
-                const float4 g = *reinterpret_cast<const float4*>(p.mask + (long long)m * p.Cout + co);
+                float4 g;
+                if (p.mask_fmt) {
+                    const char* cell = reinterpret_cast<const char*>(p.mask + (long long)m * p.Cout + (co & ~7)) + ((co & 4) ? 8 : 0);
+                    const uint2 mh = *reinterpret_cast<const uint2*>(cell), ml = *reinterpret_cast<const uint2*>(cell + 16);
+                    g = h2_gate4(u32x2{mh.x, mh.y}, u32x2{ml.x, ml.y});
+                } else g = *reinterpret_cast<const float4*>(p.mask + (long long)m * p.Cout + co);
                 o.x = g.x > 0.f ? o.x : 0.f; o.y = g.y > 0.f ? o.y : 0.f; o.z = g.z > 0.f ? o.z : 0.f; o.w = g.w > 0.f ? o.w : 0.f;
             }
             *reinterpret_cast<float4*>(p.out + (long long)m * p.Cout + co) = o;
@@ -1797,11 +1815,12 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const ConvArgs p) {
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void tail_fixup_h2_kernel(const ConvArgs p) {
     const int lane = threadIdx.x & 63;
-    const float post = 1.f / ((p.in_fmt ? p.in_scale : pow2_scale_for(p.in_absmax, lane, p.in2_absmax)) * pow2_scale_for(p.w_absmax, lane));
+    const float post = 1.f / ((p.in_fmt ? h2_in_scale(p, lane) : pow2_scale_for(p.in_absmax, lane, p.in2_absmax)) * pow2_scale_for(p.w_absmax, lane));
     constexpr int C8 = BN / 8;
     const int per_tile = BM * C8;
     const int ntail = (int)gridDim.y;
     const int HoWo = p.Ho * p.Wo;
+    const float out_scale = h2_out_scale(p, lane), res_inv_scale = p.res_fmt ? h2_res_inv_scale(p, lane) : 1.f;
     float amax = 0.f;
     for (int tt = blockIdx.y; tt < ntail; tt += gridDim.y) {
         const int tile = p.n_main + tt, mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
@@ -1829,7 +1848,7 @@ __global__ __launch_bounds__(256) void tail_fixup_h2_kernel(const ConvArgs p) {
                     roff = (((long long)n * p.res_H + ho * p.res_s) * p.res_W + wo * p.res_s) * p.Cout + co;
                 }
                 const uint4 r0 = *reinterpret_cast<const uint4*>(p.res + roff), r1 = *reinterpret_cast<const uint4*>(p.res + roff + 4);
-                if (p.res_fmt) h2_unpack8(r0, r1, p.res_inv_scale, r);
+                if (p.res_fmt) h2_unpack8(r0, r1, res_inv_scale, r);
                 else {
                     const float4 f0 = __builtin_bit_cast(float4, r0), f1 = __builtin_bit_cast(float4, r1);
                     r[0] = f0.x; r[1] = f0.y; r[2] = f0.z; r[3] = f0.w; r[4] = f1.x; r[5] = f1.y; r[6] = f1.z; r[7] = f1.w;
@@ -1843,7 +1862,7 @@ __global__ __launch_bounds__(256) void tail_fixup_h2_kernel(const ConvArgs p) {
                 amax = fmaxf(amax, fabsf(o[k]));
             }
             uint4 hi, lo;
-            h2_pack8(o, p.out_scale, hi, lo);
+            h2_pack8(o, out_scale, hi, lo);
             uint4* dst = reinterpret_cast<uint4*>(p.out + (long long)m * p.Cout + co);
             dst[0] = hi; dst[1] = lo;
         }

@@ -9,6 +9,7 @@
 #include "dgp_engine.h"
 #include "dgp_device.h"
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <map>
 
@@ -254,6 +255,7 @@ struct WgradArgs {
     // slots that decide whether they may be read: previous step (the scale they were written with) and this step (what they hold)
     const void* xs; const void* dys;
     const float *x_prev, *x_cur, *dy_prev, *dy_cur;
+    int* fail_flag;       // x is an H2-only tensor (no fp32 twin, x == nullptr): unusable copies raise this flag instead of falling back
 };
 
 template <int T>      // tile = 64T (k) x 64T (co); 4 waves as 2 x 2, wave tile 32T x 32T
@@ -932,7 +934,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma(const WgradArgs p) {
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), half = lane >> 5, l31 = lane & 31;
     const float sx = shadow_scale_for(p.x_prev, lane), sy = shadow_scale_for(p.dy_prev, lane);
     if (!(shadow_usable(sx, p.x_cur, lane) && shadow_usable(sy, p.dy_cur, lane))) {
-        wgrad_f32_body<2>(p);
+        if (p.x && p.dy) wgrad_f32_body<2>(p);
+        else if (p.fail_flag && threadIdx.x == 0) atomicOr(p.fail_flag, 1);       // the host repeats the step on fp32 tensors
         return;
     }
     const int wm = wave >> 1, wn = wave & 1;
@@ -1169,6 +1172,32 @@ __global__ __launch_bounds__(256) void f32_to_shadow_kernel(const float4* __rest
         uint4 hi, lo;
         h2_pack8(v, s, hi, lo);
         out[2 * g] = hi; out[2 * g + 1] = lo;
+    }
+}
+
+// H2 tensors with predicted scales (ConvArgs::*_scale_dev): after the pass, every such tensor's measured range must lie inside the
+// window its predicted scale covers, else flag |= 1 and the host repeats the step on fp32 tensors.  One wave per listed slot.
+struct H2CheckList { int n; short idx[254]; };
+__global__ __launch_bounds__(64) void h2_pred_check_kernel(const H2CheckList list, const float* __restrict__ pool,
+                                                           const float* __restrict__ prev, int* __restrict__ flag) {
+    const int k = blockIdx.x;
+    if (k >= list.n) return;
+    const int lane = threadIdx.x;
+    const float* pv = prev + (size_t)list.idx[k] * ABSMAX_SLOTS;
+    const float* cu = pool + (size_t)list.idx[k] * ABSMAX_SLOTS;
+    if (!shadow_usable(shadow_scale_for(pv, lane), cu, lane) && lane == 0) atomicOr(flag, 1);
+}
+
+// H2 cells with a predicted scale -> fp32 (the heads' weight gradient and gate read the block4 features as fp32)
+__global__ __launch_bounds__(256) void h2_to_f32_pred_kernel(const uint4* __restrict__ x, long long n8, const float* __restrict__ prev,
+                                                             float4* __restrict__ out) {
+    const float s = shadow_scale_for(prev, threadIdx.x & 63);
+    const float inv = s > 0.f ? 1.f / s : 0.f;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < n8; g += (long long)gridDim.x * 256) {
+        float v[8];
+        h2_unpack8(x[2 * g], x[2 * g + 1], inv, v);
+        out[2 * g] = make_float4(v[0], v[1], v[2], v[3]);
+        out[2 * g + 1] = make_float4(v[4], v[5], v[6], v[7]);
     }
 }
 
@@ -1506,6 +1535,7 @@ struct TrainCtx {
     // in this pass (absent: no copy of the current contents exists)
     std::unordered_map<const void*, float*> shadow_base;
     std::unordered_map<const void*, const float*> shadow_prev;
+    std::vector<int> h2_slots;                   // range slots of the tensors written as H2 with predicted scales in this pass
     ~TrainCtx() {
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         if (s2) (void)hipStreamDestroy(s2);
@@ -1533,6 +1563,9 @@ struct dgp_trainer {
     float* d_gnorm = nullptr;
     float* d_rng_pool = nullptr;      // activation / gradient range slots (RANGE_POOL arrays), zeroed per pass
     float* d_rng_prev = nullptr;      // ... as the previous step left them (copied before the zeroing)
+    int* d_fast_flag = nullptr;       // != 0: an H2 tensor of the last fast pass left its predicted range (the step must be repeated)
+    bool fast_next = false;           // dgp_trainer_fast_mode: the next forward pass keeps blocks 2-4 as H2 tensors with predicted scales
+    bool fwd_fast = false;            // what the last forward pass did (the backward pass reads its tensors accordingly)
     float* d_wrng = nullptr;          // weight-panel range slots: [2 * n_layers] (forward panels, data-gradient panels), per sync
     void* d_pack_table = nullptr;     // PackDesc of every non-head layer (pack_all_kernel), built at the first sync
     int n_pack = 0;
@@ -1541,7 +1574,7 @@ struct dgp_trainer {
     void* d_fin_table = nullptr;      // FinDesc of every non-head layer (deferred weight-gradient finalisation), per batch size
     int n_fin = 0, fin_B = -1, fin_h = -1, fin_w = -1;
     ~dgp_trainer() {
-        for (void* q : {(void*)d_rng_pool, (void*)d_rng_prev, (void*)d_wrng, d_pack_table, d_fin_table, d_h3_table}) if (q) (void)hipFree(q);
+        for (void* q : {(void*)d_rng_pool, (void*)d_rng_prev, (void*)d_fast_flag, (void*)d_wrng, d_pack_table, d_fin_table, d_h3_table}) if (q) (void)hipFree(q);
         for (auto& t : tl) { if (t.d_wT) (void)hipFree(t.d_wT); if (t.d_wTh3) (void)hipFree(t.d_wTh3); }
         for (void* p : {(void*)params, (void*)grads, (void*)mom, (void*)stats, (void*)d_sumsq, (void*)d_gnorm})
             if (p) (void)hipFree(p);
@@ -1565,6 +1598,7 @@ struct TPlan {
     // fp16 high / low copies (ConvArgs::shadow) of the tensors the 128 x 128 weight-gradient tiles read; 0: none
     std::vector<size_t> sh_r1, sh_r2, sh_xo;
     size_t sh_g0 = 0, sh_g1 = 0, sh_dr1 = 0, sh_dr2 = 0, sh_dr1_b = 0, sh_dr2_b = 0;
+    size_t feat32 = 0;           // fast pass: fp32 copy of the block4 features for the heads' backward
     size_t total;
 };
 
@@ -1638,6 +1672,7 @@ TPlan make_tplan(const dgp_trainer* tr, int B) {
         }
         p.sh_g0 = take(xmax); p.sh_g1 = take(xmax);
         p.sh_dr1 = take(r1max); p.sh_dr2 = take(r2max); p.sh_dr1_b = take(r1max); p.sh_dr2_b = take(r2max);
+        p.feat32 = take((size_t)B * h * w * net->units.back().depth);
     }
     p.total = o;
     return p;
@@ -1721,6 +1756,10 @@ static const float* range_prev_of(const float* slot) {
     return g_ctx->rng.prev + idx * ABSMAX_SLOTS;
 }
 static thread_local bool g_shadow_want = true;      // backward pass: only gradients that a 128 x 128 weight-gradient tile will read
+// fast pass: formats of the NEXT conv_launch (consumed by it).  An H2 tensor's scale is the one predicted from the previous step's slots
+// of the tensor named by the launch's in_key / out_key / res_key.
+struct H2Launch { int in_fmt = 0, out_fmt = 0, res_fmt = 0, mask_fmt = 0; const void* res_key = nullptr; };
+static thread_local H2Launch g_h2;
 
 // weight panel -> the same panel pre-split into fp16 cells (filled by dgp_trainer_sync_weights): with the cells and both ranges the
 // conv runs on the compute-side-split / LDS-DMA kernels of the inference engine
@@ -1752,8 +1791,18 @@ hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, 
     a.res_bytes = res ? (unsigned)((size_t)N * res_H * res_W * Cout * 4) : 0u;
     a.w_bytes = (unsigned)((size_t)nk * 8 * coutP * 16);
     a.slab = g_ctx->tail_slab; a.slab_bytes = g_ctx->tail_slab ? (unsigned)(TAIL_SLAB_FLOATS * sizeof(float)) : 0u;
+    const H2Launch h2 = g_h2;
+    g_h2 = H2Launch();
     const float* rin = range_of(in_key ? in_key : in);
     const float* rw = range_of(wpk);
+    a.mask_fmt = h2.mask_fmt;
+    if (h2.in_fmt || h2.out_fmt || h2.res_fmt) {
+        if (!(rin && rw && out_mode == 0 && h2.in_fmt && h2.out_fmt)) return hipErrorInvalidValue;
+        a.in_fmt = 1; a.out_fmt = 1; a.res_fmt = h2.res_fmt;
+        a.in_scale_dev = range_prev_of(rin);
+        if (h2.res_fmt) a.res_scale_dev = range_prev_of(range_of(h2.res_key));
+        if (!a.in_scale_dev || (h2.res_fmt && !a.res_scale_dev)) return hipErrorInvalidValue;
+    }
     if (rin && rw && out_mode == 0) {
         a.in_absmax = rin; a.w_absmax = rw;
         const auto c = g_ctx->cells.find(wpk);
@@ -1764,7 +1813,16 @@ hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, 
         range_set(out_key ? out_key : out, a.out_absmax);
     }
     const int tile = pick_tile(a.M, coutP, nk * BK, a.in_absmax && a.w_absmax);
-    if (g_ctx && out_mode == 0) {
+    if (a.out_fmt) {
+        // the output IS the fp16 high / low tensor: later weight-gradient launches read it in place
+        const void* key = out_key ? out_key : (const void*)out;
+        a.out_scale_dev = range_prev_of(a.out_absmax);
+        if (!a.out_scale_dev || !a.wh3) return hipErrorInvalidValue;
+        g_ctx->shadow_base[key] = const_cast<float*>(static_cast<const float*>(key));
+        g_ctx->shadow_prev[key] = a.out_scale_dev;
+        const int idx = (int)((a.out_scale_dev - g_ctx->rng.prev) / ABSMAX_SLOTS);
+        if (std::find(g_ctx->h2_slots.begin(), g_ctx->h2_slots.end(), idx) == g_ctx->h2_slots.end()) g_ctx->h2_slots.push_back(idx);
+    } else if (g_ctx && out_mode == 0) {
         // fp16 copy of the output for wgrad_dma: kernels that end in ls_epilogue / tail_fixup_kernel write it
         const void* key = out_key ? out_key : (const void*)out;
         const auto sb = g_ctx->shadow_base.find(key);
@@ -1784,7 +1842,10 @@ hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, 
 hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const float* dy, int Ho, int Wo, int Cdy, int KH,
                         int KW, int stride, int dil, int pad_t, int pad_l, float* dwraw, float* colsum, hipStream_t s,
                         bool zeroed = false, const float* rx_given = nullptr, const float* rdy_given = nullptr,
-                        const void* xs = nullptr, const float* x_prev = nullptr, const void* dys = nullptr, const float* dy_prev = nullptr) {
+                        const void* xs = nullptr, const float* x_prev = nullptr, const void* dys = nullptr, const float* dy_prev = nullptr,
+                        int* x_h2_only_flag = nullptr) {
+    // x_h2_only_flag: x exists only as H2 cells (xs; fast pass) -- the LDS-DMA tile is the only kernel that can read it, and copies that
+    // left their predicted range raise the flag instead of falling back
     WgradArgs a{};
     a.x = x; a.dy = dy; a.dw = dwraw; a.colsum = colsum; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.log2cin4 = ilog2(Cin / 4);
     a.Ho = Ho; a.Wo = Wo; a.Cdy = Cdy; a.KW = KW; a.stride = stride; a.dil = dil; a.pad_t = pad_t; a.pad_l = pad_l;
@@ -1834,9 +1895,11 @@ hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const floa
             attr[3] = true;
         }
         a.xs = xs; a.dys = dys; a.x_prev = x_prev; a.x_cur = rx; a.dy_prev = dy_prev; a.dy_cur = rdy;
+        if (x_h2_only_flag) { a.x = nullptr; a.fail_flag = x_h2_only_flag; }
         hipLaunchKernelGGL(wgrad_dma, dim3(kt, nt, split), dim3(256), 64 * 1024, s, a);
         return hipGetLastError();
     }
+    if (x_h2_only_flag) return hipErrorInvalidValue;       // (no other kernel reads H2 cells)
     if (big && h3_env && rx && rdy && Cin % 4 == 0) {      // both operand ranges known: 16-bit matrix pipe
         if (!attr[2]) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -1946,6 +2009,7 @@ int dgp_trainer_create(dgp_net* net, dgp_trainer** out) {
     (void)hipMemset(tr->params, 0, nb); (void)hipMemset(tr->grads, 0, nb); (void)hipMemset(tr->mom, 0, nb);
     if (hipMalloc(&tr->d_rng_pool, (size_t)RANGE_POOL * ABSMAX_SLOTS * sizeof(float)) != hipSuccess ||
         hipMalloc(&tr->d_rng_prev, (size_t)RANGE_POOL * ABSMAX_SLOTS * sizeof(float)) != hipSuccess ||
+        hipMalloc(&tr->d_fast_flag, sizeof(int)) != hipSuccess || hipMemset(tr->d_fast_flag, 0, sizeof(int)) != hipSuccess ||
         hipMemset(tr->d_rng_pool, 0, (size_t)RANGE_POOL * ABSMAX_SLOTS * sizeof(float)) != hipSuccess ||
         hipMemset(tr->d_rng_prev, 0, (size_t)RANGE_POOL * ABSMAX_SLOTS * sizeof(float)) != hipSuccess ||
         hipMalloc(&tr->d_wrng, (size_t)2 * net->layers.size() * ABSMAX_SLOTS * sizeof(float)) != hipSuccess) {
@@ -2124,8 +2188,22 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     g_ctx->tail_slab = F(pl.tail);
     range_pass_begin(tr, s, false);
     g_ctx->shadow_base.clear();
+    g_ctx->h2_slots.clear();
     g_shadow_want = true;
+    g_h2 = H2Launch();
+    // Fast pass (dgp_trainer_fast_mode; the host asks for it once a pass of the same shapes has left its ranges behind): from the first
+    // unit with a 128-channel bottleneck on (block2) every retained activation is an H2 tensor -- fp16 high / low cells with a scale
+    // predicted from the previous step's range, no fp32 twin -- so these convs run the inference engine's cell kernels (no split in the
+    // K loop, no second copy written) and the weight gradients read them in place.  ub: first such unit; its input is the fp16 copy
+    // (ConvArgs::shadow) of block1's output.
+    size_t ub = net->units.size();
+    for (size_t ui = 1; ui < net->units.size(); ++ui)
+        if (net->units[ui].depth_bn >= 128 && pl.sh_xo[ui - 1]) { ub = ui; break; }
+    const bool fast = tr->fast_next && g_wgrad_dma && g_train_cells && g_ctx->rng.on && ub < net->units.size() && pl.feat32;
+    tr->fwd_fast = fast;
+    if (fast) TRY_HIP(hipMemsetAsync(tr->d_fast_flag, 0, sizeof(int), s));
     for (size_t ui = 0; ui < net->units.size(); ++ui) {
+        if (fast && ui >= ub) continue;              // (H2 tensors register themselves as they are written)
         if (pl.sh_r1[ui]) g_ctx->shadow_base[F(pl.r1[ui])] = F(pl.sh_r1[ui]);
         if (pl.sh_r2[ui]) g_ctx->shadow_base[F(pl.r2[ui])] = F(pl.sh_r2[ui]);
         if (pl.sh_xo[ui]) g_ctx->shadow_base[F(pl.xo[ui])] = F(pl.sh_xo[ui]);
@@ -2195,26 +2273,39 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
         const Unit& u = net->units[ui];
         const int ho = (hh + u.stride - 1) / u.stride, wo = (ww + u.stride - 1) / u.stride;
         const size_t pin = (size_t)hh * ww, pout = (size_t)ho * wo;
-        const float* x = at(c.x_off, pin * c.x_c);
+        const bool h2u = fast && ui >= ub;             // this unit's tensors are H2
+        // (the first H2 unit reads the fp16 copy of its fp32 input; ranges and scales go by the tensor's own name, F(c.x_off))
+        const float* x = (h2u && ui == ub) ? at(pl.sh_xo[ui - 1], pin * c.x_c) : at(c.x_off, pin * c.x_c);
         const float* res = x;
+        const void* res_key = F(c.x_off);
         int res_s = u.stride, res_H = hh, res_W = ww;
+        auto h2_next = [&](bool with_res) {
+            if (!h2u) return;
+            g_h2.in_fmt = 1; g_h2.out_fmt = 1;
+            if (with_res) { g_h2.res_fmt = 1; g_h2.res_key = res_key; }
+        };
         if (u.sc >= 0) {
             const ConvLayer& l = net->layers[u.sc];
+            h2_next(false);
             TRY_HIP(conv_launch(l, l.d_w, l.nk, l.CoutP, x, nB, hh, ww, l.Cin, 0, 0, ho, wo, l.Cout, u.stride, 0, l.d_scale,
                                 l.d_bias, nullptr, 0, 0, 0, nullptr, false, 0, 0, at(pl.sc[ui], pout * u.depth), cs, F(c.x_off),
                                 F(pl.sc[ui])));
             res = at(pl.sc[ui], pout * u.depth); res_s = 1; res_H = ho; res_W = wo;
+            res_key = F(pl.sc[ui]);
         }
         const ConvLayer& l1 = net->layers[u.c1];
+        h2_next(false);
         TRY_HIP(conv_launch(l1, l1.d_w, l1.nk, l1.CoutP, x, nB, hh, ww, l1.Cin, 0, 0, hh, ww, l1.Cout, 1, 0, l1.d_scale,
                             l1.d_bias, nullptr, 0, 0, 0, nullptr, true, 0, 0, at(pl.r1[ui], pin * u.depth_bn), cs, F(c.x_off),
                             F(pl.r1[ui])));
         const ConvLayer& l2 = net->layers[u.c2];
         const int pb_h = pad_before_for(hh, 3, u.stride, u.rate, true), pb_w = pad_before_for(ww, 3, u.stride, u.rate, true);
+        h2_next(false);
         TRY_HIP(conv_launch(l2, l2.d_w, l2.nk, l2.CoutP, at(pl.r1[ui], pin * u.depth_bn), nB, hh, ww, l2.Cin, pb_h, pb_w, ho, wo,
                             l2.Cout, u.stride, 0, l2.d_scale, l2.d_bias, nullptr, 0, 0, 0, nullptr, true, 0, 0,
                             at(pl.r2[ui], pout * u.depth_bn), cs, F(pl.r1[ui]), F(pl.r2[ui])));
         const ConvLayer& l3 = net->layers[u.c3];
+        h2_next(true);
         TRY_HIP(conv_launch(l3, l3.d_w, l3.nk, l3.CoutP, at(pl.r2[ui], pout * u.depth_bn), nB, ho, wo, l3.Cin, 0, 0, ho, wo, l3.Cout,
                             1, 0, l3.d_scale, l3.d_bias, res, res_s, res_H, res_W, nullptr, true, 0, 0,
                             at(pl.xo[ui], pout * u.depth), cs, F(pl.r2[ui]), F(pl.xo[ui])));
@@ -2252,12 +2343,14 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     auto head_forward = [&](const ConvLayer& hd, int li, int njt, float* out) -> hipError_t {
         const float* rin = range_of(xin);
         const float* rw = tr->d_wrng ? tr->d_wrng + (size_t)li * ABSMAX_SLOTS : nullptr;
+        if (fast && !(head_pw && rin && rw && hd.d_wh3_pw && tr->d_h3_table)) return hipErrorInvalidValue;       // (H2 features: cell kernels only)
         if (!(head_pw && g_ctx->rng.on && rin && rw && hd.d_wh3_pw && tr->d_h3_table))
             return conv_launch(hd, hd.d_w, hd.nk, hd.CoutP, xin, B, h, w, hd.Cin, 1, 1, h, w, hd.Cout, 1, 0, nullptr, hd.d_bias,
                                nullptr, 0, 0, 0, nullptr, false, 1, njt, out, s);
         float* T = F(pl.g0);                       // gradient scratch: free during the forward pass
         ConvArgs a{};
         a.in = xin; a.wpk = hd.d_w_pw; a.wh3 = hd.d_wh3_pw; a.out = T; a.in_absmax = rin; a.w_absmax = rw;
+        if (fast) { a.in_fmt = 1; a.in_scale_dev = range_prev_of(rin); if (!a.in_scale_dev) return hipErrorInvalidValue; }
         a.slab = g_ctx->tail_slab; a.slab_bytes = g_ctx->tail_slab ? (unsigned)(TAIL_SLAB_FLOATS * sizeof(float)) : 0u;
         a.N = B; a.H = h; a.W = w; a.Cin = hd.Cin; a.log2cin4 = ilog2(hd.Cin / 4);
         a.Ho = h; a.Wo = w; a.Cout = hd.coutp_pw; a.CoutP = hd.coutp_pw;
@@ -2270,6 +2363,25 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     };
     TRY_HIP(head_forward(net->layers[net->head_part], net->head_part, d.num_joints, F(pl.scmap)));
     TRY_HIP(head_forward(net->layers[net->head_locref], net->head_locref, 2 * d.num_joints, F(pl.locref)));
+    if (fast) {
+        // every H2 tensor of this pass against its predicted scale (the scoremaps are garbage when one failed: the host repeats the step)
+        H2CheckList cl{};
+        if (g_ctx->h2_slots.size() > sizeof(cl.idx) / sizeof(cl.idx[0])) return fail(DGP_ERR_STATE, "fast pass: too many H2 tensors");
+        {   // ... and the fp16 copy of block1's output that the first H2 unit read
+            const float* pv = range_prev_of(range_of(F(pl.xo[ub - 1])));
+            if (!pv) return fail(DGP_ERR_STATE, "fast pass: the first H2 unit's input has no range");
+            g_ctx->h2_slots.push_back((int)((pv - g_ctx->rng.prev) / ABSMAX_SLOTS));
+        }
+        cl.n = (int)g_ctx->h2_slots.size();
+        for (int k = 0; k < cl.n; ++k) cl.idx[k] = (short)g_ctx->h2_slots[k];
+        hipLaunchKernelGGL(h2_pred_check_kernel, dim3(cl.n), dim3(64), 0, s, cl, g_ctx->rng.pool, g_ctx->rng.prev, tr->d_fast_flag);
+        // fp32 copy of the features for the heads' backward
+        const float* rfeat = range_of(xin);
+        const long long n8 = (long long)B * h * w * net->units.back().depth / 8;
+        hipLaunchKernelGGL(h2_to_f32_pred_kernel, dim3(grid_for(n8)), dim3(256), 0, s, reinterpret_cast<const uint4*>(xin), n8,
+                           range_prev_of(rfeat), reinterpret_cast<float4*>(F(pl.feat32)));
+        TRY_HIP(hipGetLastError());
+    }
     if (scmap) *scmap = F(pl.scmap);
     if (locref) *locref = F(pl.locref);
     return DGP_OK;
@@ -2305,10 +2417,13 @@ static int layer_param_grads(dgp_trainer* tr, size_t li, const float* x, int N, 
                 xs = bx->second; xp = px->second; dys = by->second; dyp = py->second;
             }
         }
+        int* h2_only = (xs && xs == (const void*)x) ? tr->d_fast_flag : nullptr;       // fast pass: the activation has no fp32 twin
+        if (!h2_only && tr->fwd_fast && g_ctx->shadow_base.count(x) && g_ctx->shadow_base[x] == x)
+            return fail(DGP_ERR_STATE, "weight gradient of an H2-only activation without a usable gradient copy");
         TRY_HIP(wgrad_launch(x, N, H, W, l.Cin, dy, Ho, Wo, l.Cout, l.KH, l.KW, stride, l.rate, pad_t, pad_l,
                              reinterpret_cast<float*>(g_ctx->defer_ws + ((const TPlan*)g_ctx->defer_plan)->dw_l[li]),
                              reinterpret_cast<float*>(g_ctx->defer_ws + ((const TPlan*)g_ctx->defer_plan)->cs_l[li]), ws_, true,
-                             nullptr, nullptr, xs, xp, dys, dyp));
+                             nullptr, nullptr, xs, xp, dys, dyp, h2_only));
         if (done) {
             TRY_HIP(hipEventRecord(done, g_ctx->s2));
             g_ctx->readers.emplace((const void*)dy, done);
@@ -2404,8 +2519,15 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
     int cur = 0;
     int rc;
 
+    // fast pass (dgp_train_forward): the activations of units >= ub are H2 tensors -- gates read them as such, weight gradients read
+    // them in place, and the heads use the fp32 copy of the features the forward pass left in feat32
+    const bool fast = tr->fwd_fast;
+    int ub = nu;
+    for (int ui = 1; ui < nu; ++ui)
+        if (net->units[ui].depth_bn >= 128 && pl.sh_xo[ui - 1]) { ub = ui; break; }
+    g_h2 = H2Launch();
     // ---- heads: gather phases, parameter grads, data grad into G[cur] (gated by the last unit's ReLU)
-    const float* feat = F(pl.xo[nu - 1]);
+    const float* feat = fast ? F(pl.feat32) : F(pl.xo[nu - 1]);
     {
         const size_t heads[2] = {(size_t)net->head_part, (size_t)net->head_locref};
         const float* dsrc[2] = {dscmap, dlocref};
@@ -2437,6 +2559,17 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         }
     }
 
+    if (fast) {
+        // the heads' data gradient came from a kernel that writes no fp16 copy, and the last unit's conv3 weight gradient can only read
+        // its H2 activation through the LDS-DMA tile: make the copy here
+        const float* pv = range_prev_of(range_of(G[cur]));
+        const auto sb = g_ctx->shadow_base.find(G[cur]);
+        if (!pv || sb == g_ctx->shadow_base.end()) return fail(DGP_ERR_STATE, "fast pass: no range for the heads' data gradient");
+        const long long n8 = (long long)B * fh * fw * net->units[nu - 1].depth / 8;
+        hipLaunchKernelGGL(f32_to_shadow_kernel, dim3(grid_for(n8)), dim3(256), 0, s, reinterpret_cast<const float4*>(G[cur]), n8, pv,
+                           reinterpret_cast<uint4*>(sb->second));
+        g_ctx->shadow_prev[G[cur]] = pv;
+    }
     // ---- bottleneck units, last to first.  G[cur] = d loss / d (unit output), already gated by its ReLU.
     int stop_after = -1;
     if (const char* e = getenv("DGP_BWD_STOP")) stop_after = atoi(e);      // debugging aid: leave G of an inner unit in place
@@ -2472,6 +2605,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         if (rc) return rc;
         TRY_HIP(before_write(DR2));
         g_shadow_want = u.depth_bn >= 128;       // dR2 -> conv2's weight gradient (9 C1 x C1)
+        g_h2.mask_fmt = (fast && ui >= ub) ? 1 : 0;
         TRY_HIP(conv_launch(l3, t3.d_wT, t3.nkT, t3.cinP, Gout, B, ho, wo, l3.Cout, 0, 0, ho, wo, l3.Cin, 1, 0, nullptr, nullptr,
                             nullptr, 0, 0, 0, F(pl.r2[ui]), false, 0, 0, DR2, s));
         // conv2: params, then dR1 = convT(dR2) gated by R1 > 0
@@ -2481,6 +2615,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         const int keff = 2 * u.rate + 1;
         TRY_HIP(before_write(DR1));
         g_shadow_want = u.depth_bn >= 128 && u.depth_in >= 128;      // dR1 -> conv1's weight gradient (Cin x C1)
+        g_h2.mask_fmt = (fast && ui >= ub) ? 1 : 0;
         TRY_HIP(conv_launch(l2, t2.d_wT, t2.nkT, t2.cinP, DR2, B, ho, wo, l2.Cout, keff - 1 - pb_h, keff - 1 - pb_w, h, w,
                             l2.Cin, 1, u.stride > 1 ? u.stride : 0, nullptr, nullptr, nullptr, 0, 0, 0, F(pl.r1[ui]), false, 0, 0,
                             DR1, s));
@@ -2506,6 +2641,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         if (rc) return rc;
         TRY_HIP(before_write(Gin));              // (the G of two units ago: its conv3 / shortcut weight gradients)
         g_shadow_want = ui > 0 && net->units[ui - 1].depth_bn >= 128;      // G of unit ui - 1 -> its conv3 / shortcut weight gradients
+        g_h2.mask_fmt = (fast && ui > ub) ? 1 : 0;                           // (unit ub's input is block1's fp32 output)
         TRY_HIP(conv_launch(l1, t1.d_wT, t1.nkT, t1.cinP, DR1, B, h, w, l1.Cout, 0, 0, h, w, l1.Cin, 1, 0, nullptr, nullptr,
                             dxa, dxa_mode, dxa_h, dxa_w, xin, false, 0, 0, Gin, s));
         cur ^= 1;
@@ -2564,6 +2700,29 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
     return DGP_OK;
 }
 
+/* Fast pass of the training step.  enable != 0: the NEXT dgp_train_forward keeps the retained activations of blocks 2-4 as H2 tensors
+ * whose scales are predicted from the ranges the previous pass left behind (call it only after a pass of the same frame count and
+ * size; the first pass after dgp_trainer_create, a weight upload or a shape change must be a plain one).  dgp_train_backward follows
+ * what the forward did.  dgp_trainer_fast_status: call after the step's work has completed on the stream (it synchronises the
+ * device); *failed != 0: a tensor left its predicted range, scoremaps and gradients of that step are NOT valid -- run the step again
+ * with enable = 0 before using either. */
+int dgp_trainer_fast_mode(dgp_trainer* tr, int32_t enable) {
+    if (!tr) return fail(DGP_ERR_INVALID, "dgp_trainer_fast_mode: null");
+    tr->fast_next = enable != 0;
+    return DGP_OK;
+}
+int dgp_trainer_fast_status(dgp_trainer* tr, int32_t* was_fast, int32_t* failed) {
+    if (!tr || !failed) return fail(DGP_ERR_INVALID, "dgp_trainer_fast_status: null");
+    int f = 0;
+    if (tr->fwd_fast) {
+        TRY_HIP(hipDeviceSynchronize());
+        TRY_HIP(hipMemcpy(&f, tr->d_fast_flag, sizeof(int), hipMemcpyDeviceToHost));
+    }
+    if (was_fast) *was_fast = tr->fwd_fast ? 1 : 0;
+    *failed = f;
+    return DGP_OK;
+}
+
 /* ---- single-layer backward entry points (layer-level parity tests at the real shapes; the trainer calls the same launchers) ---- */
 
 /* dWraw[(tap, ci)][co] = sum_m x[m + tap][ci] * dy[m][co] (HWIO order, Cin rows per tap), colsum[co] = sum_m dy[m][co].
@@ -2613,7 +2772,8 @@ int dgp_conv2d_wgrad_shadow(const dgp_conv_desc* d, const float* x, const float*
  * w_hwio: device HWIO weights; scale: [Cout] device or NULL; mask: [N,H,W,Cin] (gate: mask > 0) or NULL; dx_add: gradient of the
  * shortcut branch or NULL, on dx's grid (add_mode 1) or on the 2x coarser grid (add_mode -2: the subsample shortcut).
  * scratch: >= dgp_conv2d_dgrad_scratch_bytes(d) device bytes (data-gradient panel, its fp16 cells, range slots).
- * ranged != 0: measure max |dy| and run the fp16-split kernels (what the trainer does); 0: bf16x6 split. */
+ * ranged bit 0: measure max |dy| and run the fp16-split kernels (what the trainer does), else the bf16x6 split; bit 1: `mask` is an H2
+ * tensor (dgp_f32_to_h2 of the activation, any scale) as in the fast pass of the training step -- fp16-split kernels only. */
 size_t dgp_conv2d_dgrad_scratch_bytes(const dgp_conv_desc* d) {
     if (!d) return 0;
     const size_t panel = (size_t)nk_for(d->KH, d->KW, d->Cout) * 8 * coutp_for(d->Cin) * 16;
@@ -2624,6 +2784,7 @@ int dgp_conv2d_dgrad(const dgp_conv_desc* d, const float* dy, const float* w_hwi
                      const float* dx_add, int32_t add_mode, float* dx, void* scratch, int32_t ranged, void* stream) {
     g_ctx = nullptr;
     if (!d || !dy || !w_hwio || !dx || !scratch) return fail(DGP_ERR_INVALID, "dgp_conv2d_dgrad: null argument");
+    if ((ranged & 2) && (!(ranged & 1) || !mask || (d->Cin & 7))) return fail(DGP_ERR_INVALID, "dgp_conv2d_dgrad: an H2 gate needs ranged bit 0, a mask and Cin % 8 == 0");
     if ((d->Cout & 31) || (d->Cin & 3)) return fail(DGP_ERR_INVALID, "dgp_conv2d_dgrad: Cout % 32, Cin % 4");
     hipStream_t s = (hipStream_t)stream;
     const int taps = d->KH * d->KW, nkT = nk_for(d->KH, d->KW, d->Cout), cinP = coutp_for(d->Cin);
@@ -2657,7 +2818,8 @@ int dgp_conv2d_dgrad(const dgp_conv_desc* d, const float* dy, const float* w_hwi
     a.out_bytes = (unsigned)((size_t)a.M * d->Cin * 4);
     a.res_bytes = dx_add ? (unsigned)((size_t)d->N * a.res_H * a.res_W * d->Cin * 4) : 0u;
     a.w_bytes = (unsigned)panel_bytes;
-    if (ranged) {
+    a.mask_fmt = (ranged & 2) ? 1 : 0;          // the gate tensor is H2 (fast pass of the training step): gate = stored value > 0
+    if (ranged & 1) {
         TRY_HIP(launch_absmax(dy, (long long)d->N * d->Ho * d->Wo * d->Cout, rng, s));
         TRY_HIP(launch_pack_h3(panel, nkT, cinP, rng + ABSMAX_SLOTS, cells, s));
         a.in_absmax = rng; a.w_absmax = rng + ABSMAX_SLOTS; a.wh3 = cells; a.wh3_bytes = a.w_bytes;

@@ -502,8 +502,9 @@ def conv2d_wgrad_shadow(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: i
 
 def conv2d_dgrad(dy: torch.Tensor, w_hwio: torch.Tensor, x_hw: Tuple[int, int], stride: int = 1, rate: int = 1, pad_t: int = 0,
                  pad_l: int = 0, scale: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
-                 dx_add: Optional[torch.Tensor] = None, add_mode: int = 1, ranged: bool = True) -> torch.Tensor:
-    """Data gradient of one conv layer through the trainer's kernels: dy [N,Ho,Wo,Cout], w [k,k,Cin,Cout] (device) -> dx [N,H,W,Cin]."""
+                 dx_add: Optional[torch.Tensor] = None, add_mode: int = 1, ranged: bool = True, mask_h2: bool = False) -> torch.Tensor:
+    """Data gradient of one conv layer through the trainer's kernels: dy [N,Ho,Wo,Cout], w [k,k,Cin,Cout] (device) -> dx [N,H,W,Cin].
+    mask_h2: hand the gate tensor over as H2 cells (the fast pass of the training step keeps its activations that way)."""
     lib = _lib.load()
     _need_cuda(dy, torch.float32, "dy")
     _need_cuda(w_hwio, torch.float32, "w_hwio")
@@ -514,8 +515,12 @@ def conv2d_dgrad(dy: torch.Tensor, w_hwio: torch.Tensor, x_hw: Tuple[int, int], 
     d = _conv_desc((N, H, W, Cin), w_hwio.shape, stride, rate, pad_t, pad_l, (Ho, Wo))
     dx = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dev)
     scratch = torch.empty(lib.dgp_conv2d_dgrad_scratch_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
+    flags = int(bool(ranged))
+    if mask_h2 and mask is not None:
+        mask = f32_to_h2(mask.contiguous(), h2_exp_for(float(mask.abs().max())))
+        flags |= 2
     _lib.check(lib.dgp_conv2d_dgrad(C.byref(d), _ptr(dy), _ptr(w_hwio), _ptr(scale), _ptr(mask), _ptr(dx_add), add_mode, _ptr(dx),
-                                    _ptr(scratch), int(ranged), _stream(dev)), "dgp_conv2d_dgrad")
+                                    _ptr(scratch), flags, _stream(dev)), "dgp_conv2d_dgrad")
     return dx
 
 

@@ -3,6 +3,7 @@ of fit_dgp / fit_dgp_labeledonly (DGP/models/fitdgp.py:818, :505)."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -52,6 +53,7 @@ class Trainer:
             self._shapes[k] = a.shape
             _lib.check(self.lib.dgp_trainer_upload(self._t, 3 if st else 0, off, a.ctypes.data_as(C.c_void_p), size))
         self.sync()
+        self._fast_key = None        # new weights, new ranges: the next pass is a plain one
 
     def _download(self, which: int) -> Dict[str, np.ndarray]:
         out = {}
@@ -87,6 +89,7 @@ class Trainer:
     def set_input_size(self, in_h: int, in_w: int):
         self.net.set_input_size(in_h, in_w)
         self._ws_nt = 0
+        self._fast_key = None
 
     def _forward(self, frames: torch.Tensor):
         nt = frames.shape[0]
@@ -102,7 +105,38 @@ class Trainer:
         nj, oh, ow = self.net.nj, self.net.out_h, self.net.out_w
         return wsb, _view(sc.value, (nt, oh, ow, nj), self.device), _view(lr.value, (nt, oh, ow, 2 * nj), self.device)
 
-    def forward_backward_dlc(self, frames: torch.Tensor, part_score_targets, locref_targets, locref_mask,
+    # ---- fast pass (csrc/dgp_train.hip, dgp_trainer_fast_mode): once a pass of the same shapes has left its ranges behind, the
+    # retained activations of blocks 2-4 are kept as fp16 high / low tensors with PREDICTED scales.  A step whose tensors left the
+    # predicted ranges reports it (one flag, read at the step's own synchronisation) and is repeated here as a plain pass before
+    # anything uses its gradients -- callers never see an invalid step.
+    def _fast_begin(self, nt: int) -> bool:
+        key = (nt, self.net.in_h, self.net.in_w)
+        # (opt-in: at 11 frames the forward convs of blocks 2-4 are grids of 52-208 tiles, paced by one tile's latency rather than by
+        #  operand traffic, and the fast pass measured 12.95-13.09 against 13.01-13.16 ms per step -- DESIGN.md section 6a')
+        fast = getattr(self, "_fast_key", None) == key and os.environ.get("DGP_TRAIN_H2", "0") == "1"
+        _lib.check(self.lib.dgp_trainer_fast_mode(self._t, 1 if fast else 0), "dgp_trainer_fast_mode")
+        return fast
+
+    def _fast_end(self, nt: int, fast: bool) -> bool:
+        """True: the pass is valid.  False: it was a fast pass that failed -- run it again (the next _fast_begin is a plain pass)."""
+        if fast:
+            was, failed = C.c_int32(), C.c_int32()
+            _lib.check(self.lib.dgp_trainer_fast_status(self._t, C.byref(was), C.byref(failed)), "dgp_trainer_fast_status")
+            if failed.value:
+                self._fast_key = None
+                self.fast_redos = getattr(self, "fast_redos", 0) + 1
+                return False
+        self._fast_key = (nt, self.net.in_h, self.net.in_w)
+        return True
+
+    def forward_backward_dlc(self, *args, **kwargs):
+        while True:
+            fast = self._fast_begin(args[0].shape[0])
+            out = self._forward_backward_dlc(*args, **kwargs)
+            if self._fast_end(args[0].shape[0], fast):
+                return out
+
+    def _forward_backward_dlc(self, frames: torch.Tensor, part_score_targets, locref_targets, locref_mask,
                              part_score_weights=None, locref_loss_weight: float = 0.05, locref_huber_loss: bool = True,
                              location_refinement: bool = True):
         """One DLC step-0 loss + gradients (pose_net.train, pose_net.py:159-190): frames uint8 [nt,H,W,3] on device,
@@ -128,9 +162,16 @@ class Trainer:
         l = losses.cpu().numpy()
         return {"part_loss": float(l[0]), "locref_loss": float(l[1]), "total_loss": float(l[2])}
 
-    def forward_backward(self, frames: torch.Tensor, batch: dict, hyper: DGPHyper, S0, ws, ws_max, n_frames_total,
-                         n_visible_frames_total, labeled_only: bool = False):
+    def forward_backward(self, frames: torch.Tensor, *args, **kwargs):
         """frames uint8 [nt,H,W,3] on device.  Fills the gradient buffer; returns the loss dict."""
+        while True:
+            fast = self._fast_begin(frames.shape[0])
+            out = self._forward_backward(frames, *args, **kwargs)
+            if self._fast_end(frames.shape[0], fast):
+                return out
+
+    def _forward_backward(self, frames: torch.Tensor, batch: dict, hyper: DGPHyper, S0, ws, ws_max, n_frames_total,
+                          n_visible_frames_total, labeled_only: bool = False):
         from .loss import dgp_loss_launch, dgp_loss_prepare, losses_to_dict
         frames = frames.contiguous()
         nt = frames.shape[0]

@@ -207,6 +207,17 @@ int    dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t w
                           const float* dlocref, void* stream);
 int    dgp_sgd_momentum_clip(dgp_trainer* tr, float lr, float momentum, float clip_norm, float* gnorm_host_or_null,
                              void* stream);
+/* Fast pass of the training step (no reference counterpart; the step's results are the same fp32-class numbers either way).
+ * dgp_trainer_fast_mode(tr, 1): the NEXT dgp_train_forward keeps the retained activations of blocks 2-4 as H2 tensors (fp16 high / low
+ * cells, no fp32 twin) whose power-of-two scales are PREDICTED from the ranges the same tensors had in the previous pass (max -> [2^10,
+ * 2^11): five bits of headroom), so its convs run the inference engine's cell kernels and the weight gradients read the activations in
+ * place by LDS-DMA; dgp_train_backward follows what the forward did.  Ask for it only after a pass with the same frame count and
+ * input size (plain or fast) -- never for the first pass after dgp_trainer_create, a weight upload or a shape change.
+ * dgp_trainer_fast_status (synchronises the device): *failed != 0 -- a tensor left its predicted range (a jump of more than 2^5 up or
+ * 2^7 down within one step); scoremaps, losses and gradients of that step are NOT valid: run it again with fast_mode(tr, 0) before
+ * using any of them.  deepgraphpose_amd/train.py (Trainer.forward_backward) does exactly that. */
+int    dgp_trainer_fast_mode(dgp_trainer* tr, int32_t enable);
+int    dgp_trainer_fast_status(dgp_trainer* tr, int32_t* was_fast, int32_t* failed);
 
 /* ---- single-layer entry points (used by the parity tests and by fit_dgp later) ---- */
 

@@ -153,11 +153,14 @@ DGRAD_CASES = [
 ]
 
 
-@pytest.mark.parametrize("ranged", [True, False])
+@pytest.mark.parametrize("ranged", [True, False, "h2gate"])
 @pytest.mark.parametrize("case", DGRAD_CASES)
 def test_dgrad_layer_matches_float64(lib_built, case, ranged):
+    """ranged "h2gate": the ReLU gate tensor arrives as H2 cells (fast pass of the training step)."""
     from deepgraphpose_amd import engine
     N, H, W, Cin, Cout, k, stride, rate, add_mode = case
+    mask_h2 = ranged == "h2gate"
+    ranged = bool(ranged)
     g = torch.Generator(device="cuda").manual_seed(hash(case) % (2 ** 31))
     pad_t, Ho = _same_pads(H, k, stride, rate)
     pad_l, Wo = _same_pads(W, k, stride, rate)
@@ -172,7 +175,7 @@ def test_dgrad_layer_matches_float64(lib_built, case, ranged):
     elif add_mode == -2:
         add = torch.randn((N, (H + 1) // 2, (W + 1) // 2, Cin), generator=g, device="cuda") * 1e-3
     dx = engine.conv2d_dgrad(dy, w, (H, W), stride, rate, pad_t, pad_l, scale=scale, mask=mask, dx_add=add,
-                             add_mode=add_mode if add is not None else 1, ranged=ranged)
+                             add_mode=add_mode if add is not None else 1, ranged=ranged, mask_h2=mask_h2)
     ref = _dgrad_ref(dy.double(), (w * scale).double(), H, W, stride, rate, pad_t, pad_l)
     if add_mode == 1:
         ref = ref + add.double()

@@ -131,6 +131,67 @@ def test_full_backward_matches_autograd(lib_built):
     assert np.sqrt(tot_err / tot_ref) < 3e-3
 
 
+def test_fast_pass_matches_autograd_and_recovers_from_a_failed_prediction(lib_built, monkeypatch):
+    """DGP_TRAIN_H2=1: from the second pass on, blocks 2-4 keep their activations as H2 tensors with scales predicted from the previous
+    pass (dgp_trainer_fast_mode).  (a) the fast pass meets the plain pass's tolerances against the fp64 oracle; (b) when the ranges jump
+    by more than the predicted scales cover (here: new weights 64 x larger in the stem, smuggled in behind the trainer's back), the
+    step reports it and is repeated as a plain pass before anything is returned."""
+    from deepgraphpose_amd.train import Trainer
+    from deepgraphpose_amd.loss import DGPHyper
+    monkeypatch.setenv("DGP_TRAIN_H2", "1")
+    batch, S0, wts, frames, ws, ws_max = _train_case(3)
+    hy = DGPHyper(gm2=1, gm3=3)
+    n_tot, n_vis = 300.0, 25.0
+    tr = Trainer(50, 3, 64, 96, max_frames=3)
+    tr.load_weights(wts)
+    ft = torch.from_numpy(frames).cuda()
+
+    def check(wts_now):
+        P, L = _oracle_grads(wts_now, frames, batch, S0, ws, ws_max, hy, n_tot, n_vis, dtype=torch.float64)
+        g = tr.get_grads()
+        rel, tot_ref, tot_err = {}, 0.0, 0.0
+        for k, t in P.items():
+            if not t.requires_grad:
+                continue
+            ref = t.grad.numpy()
+            d = g[k].reshape(ref.shape) - ref
+            rel[k] = np.linalg.norm(d.ravel()) / (np.linalg.norm(ref.ravel()) + 1e-30)
+            tot_ref += float((ref ** 2).sum())
+            tot_err += float((d ** 2).sum())
+        strict = {k: v for k, v in rel.items() if "block4" in k or k.startswith("pose/")}
+        assert max(strict.values()) < 2e-5, sorted(strict.items(), key=lambda kv: -kv[1])[:4]
+        assert max(rel.values()) < 1e-2, sorted(rel.items(), key=lambda kv: -kv[1])[:4]
+        assert np.sqrt(tot_err / tot_ref) < 3e-3
+        return L
+
+    tr.forward_backward(ft, batch, hy, S0, ws, ws_max, n_tot, n_vis)                 # plain pass: leaves the ranges behind
+    was, failed = __import__("ctypes").c_int32(), __import__("ctypes").c_int32()
+    tr.lib.dgp_trainer_fast_status(tr._t, was, failed)
+    assert was.value == 0
+    losses = tr.forward_backward(ft, batch, hy, S0, ws, ws_max, n_tot, n_vis)        # fast pass
+    tr.lib.dgp_trainer_fast_status(tr._t, was, failed)
+    assert was.value == 1 and failed.value == 0 and getattr(tr, "fast_redos", 0) == 0
+    L = check(wts)
+    assert abs(losses["total_loss"] - float(L["total_loss"].detach())) < 1e-4 * max(1, abs(float(L["total_loss"].detach())))
+    # (b) a 64-fold jump of every activation range: upload the new stem scale without telling the Python wrapper
+    w2 = dict(wts)
+    w2["resnet_v1_50/conv1/BatchNorm/gamma"] = wts["resnet_v1_50/conv1/BatchNorm/gamma"] * 64.0
+    w2["resnet_v1_50/conv1/BatchNorm/beta"] = wts["resnet_v1_50/conv1/BatchNorm/beta"] * 64.0
+    key = tr._fast_key
+    tr.load_weights(w2)
+    tr._fast_key = key                                                                # pretend nothing happened: the next pass goes fast
+    losses = tr.forward_backward(ft, batch, hy, S0, ws, ws_max, n_tot, n_vis)
+    assert tr.fast_redos == 1                                                         # ... fails its range check and is repeated
+    tr.lib.dgp_trainer_fast_status(tr._t, was, failed)
+    assert was.value == 0
+    L = check(w2)
+    assert abs(losses["total_loss"] - float(L["total_loss"].detach())) < 1e-4 * max(1, abs(float(L["total_loss"].detach())))
+    tr.forward_backward(ft, batch, hy, S0, ws, ws_max, n_tot, n_vis)                 # and the pass after that is fast again
+    tr.lib.dgp_trainer_fast_status(tr._t, was, failed)
+    assert was.value == 1 and failed.value == 0 and tr.fast_redos == 1
+    check(w2)
+
+
 def test_flat_gradient_view_matches_named_gradients(lib_built):
     """N4 plumbing: the flat device view that the RCCL all-reduce averages is the same memory get_grads() downloads."""
     from deepgraphpose_amd.train import Trainer
