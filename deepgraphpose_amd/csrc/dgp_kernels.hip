@@ -995,8 +995,14 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
 //   ConvArgs::in_fmt): chunk 2 kg of a row IS the high cell of k-group kg and chunk 2 kg + 1 the low cell, so the loaders are
 //   unchanged (same addresses, same bytes) and the compute waves drop the split -- ds_read + MFMA only.
 //   OH2 (AH2 kernels): the output tensor is H2 too (ls_epilogue_h2); false: fp32 output (the heads' pointwise GEMM).
-template <int BM, int BN, int NT, int BK, int CW, bool PB = false, int MODE = 0, bool CS = false, bool DMA = false, bool AH2 = false, bool OH2 = false>
+//   DEEP (DMA kernels, 128 columns): five A stages and four B stages (144 KB, one workgroup per CU) instead of three and two -- four / three
+//   K-steps of lookahead instead of two / one.  For grids of at most one tile per CU (the training step's 11-frame batches in blocks
+//   3 / 4, small inference batches): there a CU holds one workgroup and nothing else hides the L2 round trip of the weight cells.
+//   Measured per launch, one stream (rocprofv3, 11 frames): 208 tiles pointwise K = 1024 44.7 -> 40.3 us, 3x3 67.6 -> 63.7 us; with more
+//   than one tile per CU the 80-KB kernels' second resident workgroup is worth more (416 tiles: 88 -> 111 us), so those keep them.
+template <int BM, int BN, int NT, int BK, int CW, bool PB = false, int MODE = 0, bool CS = false, bool DMA = false, bool AH2 = false, bool OH2 = false, bool DEEP = false>
 __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2) ? 4 : 2)) void conv_igemm_split_ls(const ConvArgs p) {
+    static_assert(!DEEP || (DMA && BN == 128), "deep ring: LDS-DMA kernels with 128 columns");
     static_assert(!AH2 || CS, "pre-split A operand: compute-side-split kernels only");
     static_assert(!OH2 || AH2, "H2 output: kernels with H2 input only (the stem writes fp32, the pool converts)");
     // compute waves: 2 x (CW / 2) over the tile; with the compute-side split 4 x 1 (each wave owns 32 rows and ALL columns, so no
@@ -1016,7 +1022,8 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
     constexpr int LDB = DMA ? BN : BN + 4;
     constexpr int LDAF = BM + 1;                   // CS: fp32 image [chunk][row][4 floats], one pad slot per chunk plane
     constexpr int A_CELLS = DMA ? BM * CH : (CS ? CH * LDAF : NP * KG * LDA), B_CELLS = NP * KG * LDB;     // 16-byte cells per buffer
-    constexpr int NSA = DMA ? 3 : 2;               // A stages
+    constexpr int NSA = DEEP ? 5 : (DMA ? 3 : 2);  // A stages
+    constexpr int NSB = DEEP ? 4 : 2;              // B stages
     static_assert(!DMA || (CS && MODE != 0 && (BN == 128 || BN == 64) && BM == 128 && CW == 4), "LDS-DMA loaders: CS kernels, plain or pointwise walk, 128 rows");
     static_assert(!CS || (PB && NT == 2 && BK == 32), "compute-side split: fp16 path, pre-split weights, BK 32");
     constexpr int LDC = WN + 4;
@@ -1140,9 +1147,14 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             // one loop, one issue site per operand (the walkers stay in SGPRs): iteration `it` issues B(it + 1) and A(it + 2), waits
             // until everything but A(it + 2) has landed and meets the compute waves at barrier it + 1
             static_assert(AROWS == 4 && (BSLOTS == 4 || BSLOTS == 2), "counted waits below: vmcnt(4) = everything but the newest A stage (4 instructions)");
+            // LA / LB: K-steps of lookahead of the A / B issue sites (LA = LB + 1: a step's A rows are issued one iteration before its
+            // weight cells, so everything issued after B(it + 1) is the A rows of steps it + 2 .. it + LA and the cells of it + 2 .. it + LB)
+            constexpr int LA = NSA - 1, LB = NSB - 1;
+            static_assert(LA == LB + 1, "the counted waits assume that a step's A rows are issued one iteration before its cells");
+            static_assert(!DEEP || BSLOTS == 4, "deep ring: counted waits for 4 + 4 instructions per step");
             int sa = 0, sb = 0;
-            for (int it = -2; it < nks; ++it) {
-                if (it >= -1 && it + 1 < nks) {
+            for (int it = -LA; it < nks; ++it) {
+                if (it + LB >= 0 && it + LB < nks) {
                     const unsigned kbase = (unsigned)DGP_RFL((int)((unsigned)(b_tap * p.tap_rows + (b_ch >> 2)) * b_row_bytes));
                     const unsigned kgbase = (kbase >> 1) * 2u;
                     char* dst = smB + sb * (B_CELLS * 16) + b_dst0;
@@ -1157,9 +1169,9 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
                         if (b_ch >= p.Cin) { b_ch = 0; ++b_tap; }
                     }
                     b_tap = DGP_RFL(b_tap); b_ch = DGP_RFL(b_ch);
-                    sb ^= 1;
+                    sb = sb == NSB - 1 ? 0 : sb + 1;
                 }
-                const bool moreA = it + 2 < nks;
+                const bool moreA = it + LA < nks;
                 if (moreA) {
                     const int dh = DGP_RFL(a_kh * p.dil), dw = DGP_RFL(a_kw * p.dil);
                     const int doff = DGP_RFL(((dh * p.W + dw) * p.Cin + a_ch) * 4);
@@ -1196,11 +1208,27 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
                         }
                     }
                     a_tap = DGP_RFL(a_tap); a_kw = DGP_RFL(a_kw); a_kh = DGP_RFL(a_kh); a_ch = DGP_RFL(a_ch);
-                    sa = sa == 2 ? 0 : sa + 1;
+                    sa = sa == NSA - 1 ? 0 : sa + 1;
                 }
                 if (it >= -1) {
-                    if (moreA) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if constexpr (!DEEP) {
+                        if (moreA) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    } else {
+                        // step it + 1 must have landed; what may stay in flight was issued after its cells: the A rows of steps
+                        // it + 2 .. min(it + LA, nks - 1) and the cells of steps it + 2 .. min(it + LB, nks - 1), 4 instructions each
+                        const int last = nks - 1;
+                        int nA = (it + LA < last ? it + LA : last) - (it + 1), nB = (it + LB < last ? it + LB : last) - (it + 1);
+                        nA = nA < 0 ? 0 : nA; nB = nB < 0 ? 0 : nB;
+                        switch (nA + nB) {
+                            case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+                            case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+                            case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+                            case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                            case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                        }
+                    }
                     __builtin_amdgcn_s_barrier();
                 }
             }
@@ -1432,7 +1460,8 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
         int sa_c = 0;
         const uint4* A = a_lane;
         const uint4* B = sB + wave_n0 + l15 + g * LDB;
-        int da = A_CELLS, db = B_CELLS;            // to the other buffer and back
+        int da = A_CELLS, db = B_CELLS;            // to the other buffer and back (deep ring: to the next stage, wrapping)
+        int sb_c = 0; (void)sb_c;
         uint4 ra[2][2], ah[2], al[2], bq[4];
         auto mma = [](const uint4& x, const uint4& y, floatx4 cc) {
             return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), cc, 0, 0, 0);
@@ -1473,9 +1502,9 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
                 c[0][j] = mma(ah[0], bh, c[0][j]); c[1][j] = mma(ah[1], bh, c[1][j]);
             }
             __syncthreads();
-            if constexpr (DMA) { sa_c = sa_c == 2 ? 0 : sa_c + 1; a_cur = a_row0 + (unsigned)(sa_c * (A_CELLS * 16)); }
+            if constexpr (DMA) { sa_c = sa_c == NSA - 1 ? 0 : sa_c + 1; a_cur = a_row0 + (unsigned)(sa_c * (A_CELLS * 16)); }
             else { A += da; da = -da; }
-            B += db; db = -db;
+            if constexpr (NSB == 2) { B += db; db = -db; } else { B += db; if (++sb_c == NSB) { sb_c = 0; B -= NSB * B_CELLS; } }
         }
 #else
         DGP_RA(0); DGP_RA(1);
@@ -1490,9 +1519,9 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
                 DGP_MM(4); DGP_FENCE();
                 DGP_MM(5); DGP_FENCE();
                 __syncthreads();
-                if constexpr (DMA) { sa_c = sa_c == 2 ? 0 : sa_c + 1; a_cur = a_row0 + (unsigned)(sa_c * (A_CELLS * 16)); }
+                if constexpr (DMA) { sa_c = sa_c == NSA - 1 ? 0 : sa_c + 1; a_cur = a_row0 + (unsigned)(sa_c * (A_CELLS * 16)); }
                 else { A += da; da = -da; }
-                B += db; db = -db;
+                if constexpr (NSB == 2) { B += db; db = -db; } else { B += db; if (++sb_c == NSB) { sb_c = 0; B -= NSB * B_CELLS; } }
                 const bool more2 = ks + 1 < nks;
                 if (more2) { DGP_RA(0); DGP_RA(1); DGP_RB(0); DGP_RB(1); }
                 DGP_FENCE();
@@ -1514,9 +1543,9 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
 #ifdef DGP_DIAG
             acc_mf += e2 - e1; acc_ba += e3 - e2; e1 = e3;
 #endif
-            if constexpr (DMA) { sa_c = sa_c == 2 ? 0 : sa_c + 1; a_cur = a_row0 + (unsigned)(sa_c * (A_CELLS * 16)); }
+            if constexpr (DMA) { sa_c = sa_c == NSA - 1 ? 0 : sa_c + 1; a_cur = a_row0 + (unsigned)(sa_c * (A_CELLS * 16)); }
             else { A += da; da = -da; }
-            B += db; db = -db;
+            if constexpr (NSB == 2) { B += db; db = -db; } else { B += db; if (++sb_c == NSB) { sb_c = 0; B -= NSB * B_CELLS; } }
             const bool more = ks + 1 < nks;
             if (more) { DGP_RA(0); DGP_RA(1); DGP_RB(0); DGP_RB(1); }
             DGP_FENCE();
@@ -1602,7 +1631,8 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
         DGP_FENCE();
         const uint4* A = a_lane;
         const uint4* B = b_lane;
-        int da = A_CELLS, db = B_CELLS;            // to the other buffer and back
+        int da = A_CELLS, db = B_CELLS;            // to the other buffer and back (deep ring: to the next stage, wrapping)
+        int sb_c = 0; (void)sb_c;
         for (int ks = 0; ks < nks; ++ks) {
             constexpr int S0 = 0, S1 = 1, S2 = 2;
             DGP_SPLIT_HALF(0, 0);
@@ -1643,9 +1673,9 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
 #ifdef DGP_DIAG
             acc_mf += e2 - e1; acc_ba += e3 - e2; e1 = e3;
 #endif
-            if constexpr (DMA) { sa_c = sa_c == 2 ? 0 : sa_c + 1; a_cur = a_row0 + (unsigned)(sa_c * (A_CELLS * 16)); }
+            if constexpr (DMA) { sa_c = sa_c == NSA - 1 ? 0 : sa_c + 1; a_cur = a_row0 + (unsigned)(sa_c * (A_CELLS * 16)); }
             else { A += da; da = -da; }
-            B += db; db = -db;
+            if constexpr (NSB == 2) { B += db; db = -db; } else { B += db; if (++sb_c == NSB) { sb_c = 0; B -= NSB * B_CELLS; } }
             const bool more = ks + 1 < nks;
             if (more) {
                 DGP_RA(A, 0);
@@ -1918,10 +1948,24 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     constexpr bool CAN_DMA = CAN_CS && BM == 128 && (BN == 128 || BN == 64);
     static const int dma_env = getenv("DGP_DMA") ? atoi(getenv("DGP_DMA")) : 1;
     const bool dma = CAN_DMA && cs && mode != 0 && dma_env;
+    // deep DMA ring (see the kernel) for grids of at most one tile per CU; A/B switch DGP_DEEP_RING=0, =2: every DMA launch
+    constexpr bool CAN_DEEP = CAN_DMA && BN == 128;
+    static const int deep_env = getenv("DGP_DEEP_RING") ? atoi(getenv("DGP_DEEP_RING")) : 1;
+    bool deep = false;
     if (dma) {
         kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 2, CAN_DMA, CAN_DMA>
                          : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 1, CAN_DMA, CAN_DMA>;
         smem = (size_t)(3 * BM * 8 + 2 * NP * KG * BN) * 16;           // 3 A stages + 2 B stages = 80 KB
+        static int n_cu_d = 0;
+        if (!n_cu_d) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu_d, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu_d <= 0) n_cu_d = 256; }
+        const long long ntile = (long long)((a.M + BM - 1) / BM) * ((a.CoutP + BN - 1) / BN);
+        deep = CAN_DEEP && deep_env && (deep_env == 2 || ntile <= (long long)n_cu_d) && a.nk >= 6;
+        if (deep) {
+            if constexpr (CAN_DEEP)
+                kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, 2, CAN_DEEP, CAN_DEEP, false, false, CAN_DEEP>
+                                 : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, 1, CAN_DEEP, CAN_DEEP, false, false, CAN_DEEP>;
+            smem = (size_t)(5 * BM * 8 + 4 * NP * KG * BN) * 16;       // 5 A stages + 4 B stages = 144 KB
+        }
         if (smem < smem_epi) smem = smem_epi;
     }
     if (a.in_fmt) {        // H2 input: the same kernels without the split (AH2); H2 output: epilogue variant (OH2)
@@ -1932,6 +1976,9 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
                     if constexpr (CAN_DMA)
                         kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 2, CAN_DMA, CAN_DMA, CAN_DMA, CAN_DMA>
                                          : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 1, CAN_DMA, CAN_DMA, CAN_DMA, CAN_DMA>;
+                    if constexpr (CAN_DEEP)
+                        if (deep) kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, 2, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP>
+                                                   : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, 1, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP>;
                 } else {
                     kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 2, CAN_CS, false, CAN_CS, CAN_CS>
                          : mode == 1 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 1, CAN_CS, false, CAN_CS, CAN_CS>
@@ -1941,17 +1988,18 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
                 if (mode != 2) return hipErrorInvalidValue;
                 if (dma) {
                     if constexpr (CAN_DMA) kern = conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 2, CAN_DMA, CAN_DMA, CAN_DMA, false>;
+                    if constexpr (CAN_DEEP) if (deep) kern = conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, 2, CAN_DEEP, CAN_DEEP, CAN_DEEP, false, CAN_DEEP>;
                 } else kern = conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 2, CAN_CS, false, CAN_CS, false>;
             }
         }
     } else if (a.out_fmt) return hipErrorInvalidValue;
-    static bool attr_done_dev[16][3][4][3] = {};
+    static bool attr_done_dev[16][3][5][3] = {};
     auto& attr_done = attr_done_dev[dgp_device_slot()];
-    if (!attr_done[a.in_fmt ? (a.out_fmt ? 2 : 1) : 0][dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode]) {
+    if (!attr_done[a.in_fmt ? (a.out_fmt ? 2 : 1) : 0][deep ? 4 : dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_done[a.in_fmt ? (a.out_fmt ? 2 : 1) : 0][dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode] = true;
+        attr_done[a.in_fmt ? (a.out_fmt ? 2 : 1) : 0][deep ? 4 : dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode] = true;
     }
     long long nwg = (long long)a.mtiles * a.ntiles;
     // Grid tail: with `slots` workgroups resident, the last tiles % slots tiles run on a mostly idle chip.  Split their K range
