@@ -520,12 +520,16 @@ __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[T
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)ooff[slot][u], 0, 0);
             if (sh_scale > 0.f) {
+                // this lane holds 4 of a cell's 8 channels: trade halves with the neighbour (quad_perm 1,0,3,2) so that the even lane
+                // stores the whole high chunk and the odd lane the whole low chunk -- one 16-byte store per lane, whole cells per pair
                 uint2 sh, sl;
                 split2_f16(o, sh_scale, sh, sl);
-                const unsigned so = (ooff[slot][u] & ~31u) + ((ooff[slot][u] & 16u) >> 1);      // cell base + this half's 8 bytes
-                // (DGP_SHADOW_AUX=2, non-temporal stores, measured no better: the gradient copies are read back within a few launches)
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), rs_sh, (int)so, 0, DGP_SHADOW_AUX);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), rs_sh, (int)(so + 16u), 0, DGP_SHADOW_AUX);
+                const bool odd = my_c4 & 1;
+                const unsigned g0 = odd ? sh.x : sl.x, g1 = odd ? sh.y : sl.y;
+                const unsigned r0 = (unsigned)__builtin_amdgcn_mov_dpp((int)g0, 0xB1, 0xF, 0xF, true);
+                const unsigned r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)g1, 0xB1, 0xF, 0xF, true);
+                const u32x4 cell = odd ? u32x4{r0, r1, sl.x, sl.y} : u32x4{sh.x, sh.y, r0, r1};
+                __builtin_amdgcn_raw_buffer_store_b128(cell, rs_sh, (int)((ooff[slot][u] & ~31u) + (odd ? 16u : 0u)), 0, DGP_SHADOW_AUX);
             }
             if (ooff[slot][u] != OOB) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
