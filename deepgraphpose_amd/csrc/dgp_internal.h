@@ -79,6 +79,7 @@ struct ConvArgs {
     const float* out_scale_dev;
     const float* res_scale_dev;
     int mask_fmt;             // 1: the ReLU gate tensor (mask) is H2: gate = stored value > 0
+    int hi_only;              // H2 kernels with 128-column tiles: the 16-bit tier (DGP_CONV_MODE=f16) -- one MFMA per product, high cells only
 };
 
 constexpr int ABSMAX_SLOTS = 256;

@@ -1004,14 +1004,25 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
 //   3 / 4, small inference batches): there a CU holds one workgroup and nothing else hides the L2 round trip of the weight cells.
 //   Measured per launch, one stream (rocprofv3, 11 frames): 208 tiles pointwise K = 1024 44.7 -> 40.3 us, 3x3 67.6 -> 63.7 us; with more
 //   than one tile per CU the 80-KB kernels' second resident workgroup is worth more (416 tiles: 88 -> 111 us), so those keep them.
-template <int BM, int BN, int NT, int BK, int CW, bool PB = false, int MODE = 0, bool CS = false, bool DMA = false, bool AH2 = false, bool OH2 = false, bool DEEP = false>
-__global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2) ? 4 : 2)) void conv_igemm_split_ls(const ConvArgs p) {
-    static_assert(!DEEP || (DMA && BN == 128), "deep ring: LDS-DMA kernels with 128 columns");
+//   T16 (AH2 DMA kernels; DGP_CONV_MODE=f16, the reported 16-bit tier): one MFMA per product -- high cell x high cell -- instead of
+//   three; the low cells still travel (same tensors, same LDS images) but are neither read from LDS nor multiplied.  11-bit operands:
+//   NOT inside the 1e-3 px gate (bench.py reports what it measures), a third of the matrix work.
+//   BM = 256, CW = 8 (the "tall" tile, H2 DMA kernels): eight compute waves of 32 rows x 128 columns each -- the same inner loop -- on
+//   ONE B stage: two co-resident 128-row workgroups fetch the same 16 KB of weight cells per K-step twice, a 256-row workgroup once
+//   (48 instead of 64 KB of L2 -> LDS traffic per CU and K-step).  That path, ~70 GB/s per CU (MI355X_MICROARCH.md, rows served
+//   from the XCD's L2), co-limits the deep-K layers: with a THIRD of the MFMAs (the 16-bit tier) block4's 3x3 conv only went
+//   0.39 -> 0.275 ms.  Measured (one stream, batch 32): block4 3x3 0.389 -> 0.442 ms, block4 conv1 0.195 -> 0.216 ms -- SLOWER: the eight
+//   compute waves of the one 135-KB workgroup per CU meet at one barrier per K-step, where two independent 128-row workgroups drift
+//   apart and fill each other's stalls.  Kept as an opt-in (DGP_TALL=1; DGP_TALL=2 forces it wherever it applies: the parity test).
+template <int BM, int BN, int NT, int BK, int CW, bool PB = false, int MODE = 0, bool CS = false, bool DMA = false, bool AH2 = false, bool OH2 = false, bool DEEP = false, bool T16 = false>
+__global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK == 16 || NT == 2) ? 4 : 2)) void conv_igemm_split_ls(const ConvArgs p) {
+    static_assert(!DEEP || (DMA && BN == 128 && BM == 128), "deep ring: LDS-DMA kernels with 128 x 128 tiles");
+    static_assert(!T16 || (AH2 && DMA && !DEEP), "16-bit tier: H2 input, LDS-DMA kernels");
     static_assert(!AH2 || CS, "pre-split A operand: compute-side-split kernels only");
     static_assert(!OH2 || AH2, "H2 output: kernels with H2 input only (the stem writes fp32, the pool converts)");
     // compute waves: 2 x (CW / 2) over the tile; with the compute-side split 4 x 1 (each wave owns 32 rows and ALL columns, so no
     // two waves split the same A rows -- half the split arithmetic for 25 % more B fragment reads)
-    constexpr int WAVES_M = (CS && CW == 4) ? 4 : 2;
+    constexpr int WAVES_M = (CS && CW == 4) ? 4 : (CS && CW == 8 && BM == 256) ? 8 : 2;
     constexpr int WAVES_N = CW / WAVES_M;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -1028,7 +1039,8 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
     constexpr int A_CELLS = DMA ? BM * CH : (CS ? CH * LDAF : NP * KG * LDA), B_CELLS = NP * KG * LDB;     // 16-byte cells per buffer
     constexpr int NSA = DEEP ? 5 : (DMA ? 3 : 2);  // A stages
     constexpr int NSB = DEEP ? 4 : 2;              // B stages
-    static_assert(!DMA || (CS && MODE != 0 && (BN == 128 || BN == 64) && BM == 128 && CW == 4), "LDS-DMA loaders: CS kernels, plain or pointwise walk, 128 rows");
+    static_assert(!DMA || (CS && MODE != 0 && (BN == 128 || BN == 64) && ((BM == 128 && CW == 4) || (BM == 256 && CW == 8 && BN == 128))),
+                  "LDS-DMA loaders: CS kernels, plain or pointwise walk, 128 rows (4 compute waves) or 256 rows (8)");
     static_assert(!CS || (PB && NT == 2 && BK == 32), "compute-side split: fp16 path, pre-split weights, BK 32");
     constexpr int LDC = WN + 4;
     static_assert(NT == 2 || NT == 3 || NT == 6, "6 / 3 bf16 products, or NT = 2: fp16 high/low pair (3 products)");
@@ -1150,7 +1162,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             char* smB = smem + NSA * A_CELLS * 16;
             // one loop, one issue site per operand (the walkers stay in SGPRs): iteration `it` issues B(it + 1) and A(it + 2), waits
             // until everything but A(it + 2) has landed and meets the compute waves at barrier it + 1
-            static_assert(AROWS == 4 && (BSLOTS == 4 || BSLOTS == 2), "counted waits below: vmcnt(4) = everything but the newest A stage (4 instructions)");
+            static_assert((AROWS == 4 || (AROWS == 8 && !DEEP)) && (BSLOTS == 4 || BSLOTS == 2), "counted waits below: vmcnt(AROWS) = everything but the newest A stage");
             // LA / LB: K-steps of lookahead of the A / B issue sites (LA = LB + 1: a step's A rows are issued one iteration before its
             // weight cells, so everything issued after B(it + 1) is the A rows of steps it + 2 .. it + LA and the cells of it + 2 .. it + LB)
             constexpr int LA = NSA - 1, LB = NSB - 1;
@@ -1216,7 +1228,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
                 }
                 if (it >= -1) {
                     if constexpr (!DEEP) {
-                        if (moreA) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        if (moreA) { if constexpr (AROWS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     } else {
                         // step it + 1 must have landed; what may stay in flight was issued after its cells: the A rows of steps
@@ -1475,7 +1487,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
             ra[I][0] = *reinterpret_cast<const uint4*>(smem + a_cur + (I) * 2048);                                 \
             ra[I][1] = *reinterpret_cast<const uint4*>(smem + (a_cur ^ 16u) + (I) * 2048);                         \
         } else { ra[I][0] = A[16 * (I)]; ra[I][1] = A[LDAF + 16 * (I)]; } } while (0)
-#define DGP_RB(F) do { bq[(F) & 3] = B[((((F) & 1) ? 0 : 1) * KG) * LDB + 16 * (((F) % NF) >> 1)]; } while (0)
+#define DGP_RB(F) do { if constexpr (!T16 || ((F) & 1)) bq[(F) & 3] = B[((((F) & 1) ? 0 : 1) * KG) * LDB + 16 * (((F) % NF) >> 1)]; } while (0)
 #if defined(DGP_X) && DGP_X == 1      // timing-only stand-in: the A operand as if it arrived pre-split (no split arithmetic)
 #define DGP_SPLIT(I) do { ah[I] = ra[I][0]; al[I] = ra[I][1]; } while (0)
 #else
@@ -1486,7 +1498,8 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : ((BK == 16 || NT == 2)
         ah[I] = make_uint4(h0_.x, h0_.y, h1_.x, h1_.y); al[I] = make_uint4(l0_.x, l0_.y, l1_.x, l1_.y); } while (0)
 #endif
 #define DGP_MM(F) do { constexpr int j_ = (F) >> 1;                                                                \
-        if (((F) & 1) == 0) { c[0][j_] = mma(ah[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(ah[1], bq[(F) & 3], c[1][j_]); }    \
+        if constexpr (T16) { if ((F) & 1) { c[0][j_] = mma(ah[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(ah[1], bq[(F) & 3], c[1][j_]); } } \
+        else if (((F) & 1) == 0) { c[0][j_] = mma(ah[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(ah[1], bq[(F) & 3], c[1][j_]); }    \
         else { c[0][j_] = mma(al[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(al[1], bq[(F) & 3], c[1][j_]);         \
                c[0][j_] = mma(ah[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(ah[1], bq[(F) & 3], c[1][j_]); } } while (0)
 #define DGP_STEP(F) do { DGP_MM(F); DGP_FENCE(); DGP_RB((F) + 4); DGP_FENCE(); } while (0)
@@ -1963,7 +1976,7 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
         static int n_cu_d = 0;
         if (!n_cu_d) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu_d, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu_d <= 0) n_cu_d = 256; }
         const long long ntile = (long long)((a.M + BM - 1) / BM) * ((a.CoutP + BN - 1) / BN);
-        deep = CAN_DEEP && deep_env && (deep_env == 2 || ntile <= (long long)n_cu_d) && a.nk >= 6;
+        deep = CAN_DEEP && deep_env && (deep_env == 2 || ntile <= (long long)n_cu_d) && a.nk >= 6 && !(a.hi_only && a.in_fmt && a.out_fmt);
         if (deep) {
             if constexpr (CAN_DEEP)
                 kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, 2, CAN_DEEP, CAN_DEEP, false, false, CAN_DEEP>
@@ -1980,9 +1993,13 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
                     if constexpr (CAN_DMA)
                         kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 2, CAN_DMA, CAN_DMA, CAN_DMA, CAN_DMA>
                                          : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 1, CAN_DMA, CAN_DMA, CAN_DMA, CAN_DMA>;
-                    if constexpr (CAN_DEEP)
+                    if constexpr (CAN_DEEP) {
                         if (deep) kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, 2, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP>
                                                    : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, 1, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP>;
+                        else if (a.hi_only)       // 16-bit tier (128-column tiles; the 64-column layers keep three products)
+                            kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, 2, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP, false, CAN_DEEP>
+                                             : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, 1, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP, false, CAN_DEEP>;
+                    }
                 } else {
                     kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 2, CAN_CS, false, CAN_CS, CAN_CS>
                          : mode == 1 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 1, CAN_CS, false, CAN_CS, CAN_CS>
@@ -1997,13 +2014,13 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
             }
         }
     } else if (a.out_fmt) return hipErrorInvalidValue;
-    static bool attr_done_dev[16][3][5][3] = {};
+    static bool attr_done_dev[16][3][6][3] = {};
     auto& attr_done = attr_done_dev[dgp_device_slot()];
-    if (!attr_done[a.in_fmt ? (a.out_fmt ? 2 : 1) : 0][deep ? 4 : dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode]) {
+    if (!attr_done[a.in_fmt ? (a.out_fmt ? 2 : 1) : 0][(a.hi_only && dma && a.in_fmt && a.out_fmt && BN == 128 && !deep) ? 5 : deep ? 4 : dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_done[a.in_fmt ? (a.out_fmt ? 2 : 1) : 0][deep ? 4 : dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode] = true;
+        attr_done[a.in_fmt ? (a.out_fmt ? 2 : 1) : 0][(a.hi_only && dma && a.in_fmt && a.out_fmt && BN == 128 && !deep) ? 5 : deep ? 4 : dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode] = true;
     }
     long long nwg = (long long)a.mtiles * a.ntiles;
     // Grid tail: with `slots` workgroups resident, the last tiles % slots tiles run on a mostly idle chip.  Split their K range
@@ -2081,6 +2098,44 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// The 256 x 128 tile of the H2 engine (see conv_igemm_split_ls): deep-K layers only.
+static bool conv_tall_eligible(const ConvArgs& a) {
+    static const int tall_env = getenv("DGP_TALL") ? atoi(getenv("DGP_TALL")) : 0;              // opt-in (measured slower, see the kernel)
+    static const int min_nk = getenv("DGP_TALL_MINK") ? atoi(getenv("DGP_TALL_MINK")) : 48;      // K-steps from which the epilogue is small change
+    if (!tall_env || !a.in_fmt || !a.out_fmt || !a.wh3 || a.hi_only || a.in2 || a.up || a.stem || a.mask || a.out_mode != 0) return false;
+    if (a.CoutP % 128 != 0 || (a.Cout % 8) || (a.Cin % 32)) return false;
+    if (tall_env == 2) return true;                // (tests: every shape the kernel can take)
+    const long long tiles = (long long)((a.M + 255) / 256) * (a.CoutP / 128);
+    return a.nk >= min_nk && tiles >= 512;         // long K loops, at least two rounds of one workgroup per CU
+}
+
+static hipError_t launch_conv_tall(ConvArgs a, hipStream_t s) {
+    constexpr int BM = 256, BN = 128, NT = 2, BK = 32, CW = 8, NP = 2, KG = 4;
+    static const int tap_minor = getenv("DGP_TAP_MINOR") ? atoi(getenv("DGP_TAP_MINOR")) : 1;
+    a.tap_minor = (tap_minor && a.ntaps > 1 && a.nk * 32 == a.ntaps * a.Cin) ? 1 : 0;
+    a.mtiles = (a.M + BM - 1) / BM;
+    a.ntiles = a.CoutP / BN;
+    if (a.tap_rows == 0) a.tap_rows = a.Cin >> 2;
+    a.epi_nt = 0; a.tail_ksplit = 0; a.st_gn = 0;
+    const bool pointwise = a.ntaps == 1 && a.stride == 1 && a.pad_t == 0 && a.pad_l == 0 && a.H == a.Ho && a.W == a.Wo;
+    const int mode = (pointwise && (unsigned long long)a.M * a.Cin * 4ull == a.in_bytes && a.in_bytes < 4200000000u) ? 2 : 1;
+    auto kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, true, 2, true, true, true, true>
+                          : conv_igemm_split_ls<BM, BN, NT, BK, CW, true, 1, true, true, true, true>;
+    size_t smem = (size_t)(3 * BM * 8 + 2 * NP * KG * BN) * 16;                // 3 A stages + 2 B stages = 128 KB
+    const size_t smem_epi = (size_t)CW * 32 * (BN + 4) * 4;                    // 135 KB: the eight wave tiles of the epilogue
+    if (smem < smem_epi) smem = smem_epi;
+    static bool attr_dev[16][3] = {};
+    bool& attr = attr_dev[dgp_device_slot()][mode];
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    a.n_main = a.mtiles * a.ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(64 * (CW + 4)), smem, s, a);
+    return hipGetLastError();
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool WIDE>
 static hipError_t launch_conv_t(ConvArgs a, hipStream_t s) {
     size_t smem = (size_t)(2 * 8 * (BM + 1) + 2 * 8 * BN) * 16;
@@ -2146,6 +2201,7 @@ int pick_tile(int M, int CoutP, int K, bool have_absmax) {
     // rule 2 (DGP_CONV_MODE=f32): fp32 MFMA everywhere (bitwise fmaf chains)
     static const int rule = getenv("DGP_TILE_RULE") ? atoi(getenv("DGP_TILE_RULE"))
                             : !getenv("DGP_CONV_MODE") ? 4
+                            : !strcmp(getenv("DGP_CONV_MODE"), "f16") ? 4
                             : !strcmp(getenv("DGP_CONV_MODE"), "f32") ? 2
                             : !strcmp(getenv("DGP_CONV_MODE"), "bf16x6") ? 3 : 4;
     if (rule >= 4 && have_absmax) {
@@ -2184,7 +2240,7 @@ const char* conv_kernel_name(const ConvArgs& a, int tile_cfg) {
             case TILE_128x128_S6K16W8: return "split6_128x128_k16w8";
             case TILE_128x128_H3K16:   return "splith3_128x128_k16";
             case TILE_128x128_H3K16W8: return "splith3_128x128_k16w8";
-            case TILE_128x128_H3K32:   return "splith3_128x128_k32";
+            case TILE_128x128_H3K32:   return conv_tall_eligible(a) ? "splith3_256x128_k32" : "splith3_128x128_k32";
             case TILE_128x64_H3:       return "splith3_128x64_k32";
             case TILE_128x128_S6:    return "split6_128x128_k32";
             case TILE_128x64_S6:     return "split6_128x64_k32";
@@ -2220,7 +2276,9 @@ hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s) {
         case TILE_128x128_S6K16W8: return a.out_mode == 0 ? launch_conv_split<128, 128, 6, 16, 8>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
         case TILE_128x128_H3K16:   return a.out_mode == 0 ? launch_conv_split<128, 128, 2, 16>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
         case TILE_128x128_H3K16W8: return a.out_mode == 0 ? launch_conv_split<128, 128, 2, 16, 8>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
-        case TILE_128x128_H3K32:   return a.out_mode == 0 ? launch_conv_split<128, 128, 2, 32>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
+        case TILE_128x128_H3K32:
+            if (conv_tall_eligible(a)) return launch_conv_tall(a, s);
+            return a.out_mode == 0 ? launch_conv_split<128, 128, 2, 32>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
         case TILE_128x64_H3:       return a.out_mode == 0 ? launch_conv_split<128, 64, 2, 32>(a, s) : launch_conv_t<128, 64, 2, 2, true>(a, s);
         case TILE_128x64_S6:  return a.out_mode == 0 ? launch_conv_split<128, 64, 6, 32>(a, s) : launch_conv_t<128, 64, 2, 2, true>(a, s);
         default:          return launch_conv_t<128, 128, 2, 2, true>(a, s);

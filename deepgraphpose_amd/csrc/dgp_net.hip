@@ -547,7 +547,15 @@ double conv_flops_of(const ConvLayer& l, int M, bool is_head) {
 // H2 formats / scale exponents of a launch's tensors (all zero: fp32 everywhere)
 struct H2Spec { int in_fmt = 0, in_exp = 0, out_fmt = 0, out_exp = 0, res_fmt = 0, res_exp = 0; };
 
+// DGP_CONV_MODE=f16: the reported 16-bit tier -- the H2 engine as it is (layer by layer), the 128-column conv kernels multiplying the high
+// cells only (one MFMA per product instead of three).  Not inside the 1e-3 px gate; bench.py runs it in a child and reports what it measures.
+static bool tier16_mode() {
+    static const bool on = getenv("DGP_CONV_MODE") && !strcmp(getenv("DGP_CONV_MODE"), "f16");
+    return on;
+}
+
 void apply_h2(ConvArgs& a, const H2Spec& h) {
+    a.hi_only = (tier16_mode() && h.in_fmt && h.out_fmt) ? 1 : 0;
     a.in_fmt = h.in_fmt; a.out_fmt = h.out_fmt; a.res_fmt = h.res_fmt;
     a.in_scale = ldexpf(1.f, h.in_exp); a.out_scale = ldexpf(1.f, h.out_exp); a.res_inv_scale = ldexpf(1.f, -h.res_exp);
 }
@@ -787,7 +795,7 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     // fp16 high / low cells with a calibrated per-tensor scale, so the conv kernels' K loops are ds_read + MFMA only (DGP_H2=0: fp32
     // activations, split in the consumers' K loops -- also what the other DGP_CONV_MODEs and a trainer-owned net use).
     static const bool h2_env = !(getenv("DGP_H2") && atoi(getenv("DGP_H2")) == 0);
-    static const bool f16_mode = !getenv("DGP_CONV_MODE") || !strcmp(getenv("DGP_CONV_MODE"), "f16x3");
+    static const bool f16_mode = !getenv("DGP_CONV_MODE") || !strcmp(getenv("DGP_CONV_MODE"), "f16x3") || tier16_mode();
     static const bool head_pw = !(getenv("DGP_HEAD_PW") && atoi(getenv("DGP_HEAD_PW")) == 0);      // A/B switch
     static const bool fuse_env = !(getenv("DGP_FUSE_SHORTCUT") && atoi(getenv("DGP_FUSE_SHORTCUT")) == 0);      // A/B switch
     static const bool f32_mode = getenv("DGP_CONV_MODE") && !strcmp(getenv("DGP_CONV_MODE"), "f32");
@@ -870,7 +878,7 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     // conv3(k) + conv1(k + 1) as one launch (DGP_CHAIN=0: layer by layer).  Calibration runs layer by layer (it needs every tensor's
     // range before the next layer runs) and is followed by a second, chained pass, so results never depend on which pass produced them
     static const bool chain_env = !(getenv("DGP_CHAIN") && atoi(getenv("DGP_CHAIN")) == 0);
-    const bool chain_on = h2 && !calib && chain_env && net->chains.size() == net->units.size();
+    const bool chain_on = h2 && !calib && chain_env && !tier16_mode() && net->chains.size() == net->units.size();
     static const bool unit_env = !(getenv("DGP_UNIT") && atoi(getenv("DGP_UNIT")) == 0);      // conv2 inside the chain launch (block1)
     bool r1_ready = false;                            // R1 of this unit came out of the previous unit's chain launch
     float *Ra = R1, *Rb = R2;
@@ -1001,7 +1009,7 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
         e = launch_h2_range_check(net->d_amax, net->d_exps, (int)net->layers.size(), net->d_flag, s);
         if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("range check: ") + hipGetErrorString(e));
     }
-    if (calib && chain_env) return dgp_forward(net, frames, batch, workspace, workspace_bytes, scmap, locref, features, stream);   // the chained pass
+    if (calib && chain_env && !tier16_mode()) return dgp_forward(net, frames, batch, workspace, workspace_bytes, scmap, locref, features, stream);   // the chained pass
     if (net->prof_on && net->prof_used < net->prof_slots && !net->prof_in_infer) ++net->prof_used;
     return DGP_OK;
 }
