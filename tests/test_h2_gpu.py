@@ -46,8 +46,8 @@ H2_CONV_CASES = [
     (2, 10, 12, 512, 1024, 1, 1, 1, 3, True),      # conv3 of a strided unit: residual subsampled from the 2x finer grid
     (1, 30, 40, 2048, 128, 1, 1, 1, 0, False),     # the head's pointwise GEMM: H2 in, fp32 out
     (32, 30, 40, 1024, 256, 1, 1, 1, 0, True),     # batch-32 block3 conv1: 600 tiles -> grid-tail K-split + tail_fixup_h2
-    (32, 30, 40, 512, 512, 3, 1, 2, 2, True),      # batch-32 block4 conv2 (+ an H2 residual): deep K, 600 tall tiles -> the 256 x 128 kernel
-    (11, 30, 40, 2048, 512, 1, 1, 1, 0, True),     # block4 conv1 at 11 frames: 52 x 4 tall tiles would be too few -> 128 x 128 (deep ring)
+    (32, 30, 40, 512, 512, 3, 1, 2, 2, True),      # batch-32 block4 conv2 (+ an H2 residual): the deepest K loop at its real size
+    (11, 30, 40, 2048, 512, 1, 1, 1, 0, True),     # block4 conv1 at 11 frames: 416 tiles, K = 2048
 ]
 
 
@@ -197,7 +197,7 @@ def test_tail_split_fixup_on_h2_tensors_in_a_child_process(lib_built):
 
 
 def test_tall_tile_on_every_shape_it_can_take_in_a_child_process(lib_built):
-    """The 256 x 128 tile (eight compute waves on one B stage) runs by default only for deep-K layers with >= 512 tiles; DGP_TALL=2 forces it
+    """The 256 x 128 tile (eight compute waves on one B stage) is an opt-in (DGP_TALL=1: deep-K layers with >= 512 tiles); DGP_TALL=2 forces it
     wherever the kernel applies: pointwise and 3x3 loaders, dilation, stride 2, H2 / fp32 / strided residuals, ragged last row tile."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
