@@ -184,6 +184,41 @@ def test_h2_network_is_deterministic_and_close_to_fp32_activation_path(lib_built
     assert np.abs(a.cpu().numpy() - sc32).max() <= 2e-5 * np.abs(sc32).max()
 
 
+def test_reported_16_bit_tier_is_an_11_bit_version_of_the_same_network(lib_built, tmp_path):
+    """DGP_CONV_MODE=f16 (bench.py's `tier_f16`): the H2 engine with ONE MFMA per product on the high fp16 cells in the 128-column conv
+    kernels.  Not a parity tier -- the test pins what it is: the same network to 11-bit operand accuracy (scoremap within 2e-2 of its
+    range, far outside the parity tier's 2e-5 and far inside "wrong"), the same arg-max cells, coordinates within 0.25 px."""
+    import os, subprocess, sys
+    from deepgraphpose_amd.engine import DGPNet
+    from deepgraphpose_amd.synthetic import make_frames, make_weights
+    nj = 4
+    wts = make_weights(50, nj, False, seed=5, head_std=0.05)
+    frames = make_frames(6, 256, 320, nj, seed=6)              # 16 x 20 feature maps: the 128 x 128 kernels run from block2 on
+    net = DGPNet(50, nj, 256, 320, max_batch=8)
+    net.load_weights(wts)
+    ft = torch.from_numpy(frames).cuda()
+    a = net.forward(ft).cpu().numpy()
+    mu_a, _, idx_a = net.infer(ft)
+    np.save(tmp_path / "frames.npy", frames)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, torch, sys\n"
+            "from deepgraphpose_amd.engine import DGPNet\n"
+            "from deepgraphpose_amd.synthetic import make_weights\n"
+            "net = DGPNet(50, 4, 256, 320, max_batch=8); net.load_weights(make_weights(50, 4, False, seed=5, head_std=0.05))\n"
+            "ft = torch.from_numpy(np.load(sys.argv[1])).cuda()\n"
+            "sc = net.forward(ft).cpu().numpy(); mu, _, idx = net.infer(ft)\n"
+            "np.savez(sys.argv[2], sc=sc, mu=mu.cpu().numpy(), idx=idx.cpu().numpy())\n")
+    env = dict(os.environ, DGP_CONV_MODE="f16", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "frames.npy"), str(tmp_path / "t16.npz")], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    t = np.load(tmp_path / "t16.npz")
+    rel = np.abs(a - t["sc"]).max() / np.abs(a).max()
+    assert 2e-5 < rel < 2e-2, rel                               # the mode is active, and it is the same network
+    assert np.array_equal(idx_a.cpu().numpy(), t["idx"])
+    assert np.abs(mu_a.cpu().numpy() - t["mu"]).max() * 8.0 < 0.25
+
+
 def test_tail_split_fixup_on_h2_tensors_in_a_child_process(lib_built):
     """The K-split of the grid tail is off by default for H2 launches (measured slower); DGP_TAIL_SPLIT=2 forces it.  The batch-32
     block3 shape (600 tiles: 88 tail tiles split 4 ways + tail_fixup_h2_kernel) then has to give the same parity."""
