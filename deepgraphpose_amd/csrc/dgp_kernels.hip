@@ -2630,9 +2630,12 @@ __device__ __forceinline__ double wave_sum(double v) {
 // Layer by layer the root block moves 1.8 GB per 32-frame step (centred fp32 frame out and in, the 64-channel conv1 map out and
 // in) for 46 GFLOP; fused it reads the uint8 frames (29 MB) and writes the pool output (157 MB).
 //   tile      5 x 16 pool pixels <- 11 x 33 conv1 pixels (363 GEMM rows, 23 blocks of 16: three per wave) <- 27 x 72 input pixels
-//   phase 1   all 512 threads: input pixels -> centred, scaled by 2^6 (|x| < 152: no overflow, static), split into fp16 high / low,
-//             two LDS planes of 8 bytes per pixel (R, G, B, 0): a GEMM row's k-group (2 adjacent pixels) is ONE 16-byte read per plane
-//   phase 2   GEMM M = 368, N = 64, K = 7 kernel rows x (8 pixels x 4 channels) on v_mfma_f32_16x16x32_f16, 3 MFMAs per product; the
+//   phase 1   all 512 threads: input pixels -> (x - round(mean_c), 1) as fp16 -- exact small integers, so there is NO low plane: the
+//             fractional part of the mean rides on the fourth channel (1 inside the frame, 0 in the padding), whose weight is
+//             sum_c (round(mean_c) - mean_c) w_c (built with the row panel, dgp_net.hip).  One LDS plane of 8 bytes per pixel: a GEMM
+//             row's k-group (2 adjacent pixels) is ONE 16-byte read
+//   phase 2   GEMM M = 368, N = 64, K = 7 kernel rows x (8 pixels x 4 channels) on v_mfma_f32_16x16x32_f16, 2 MFMAs per product
+//             (a x w_low, a x w_high; round 2: 3, with a centred fp32 input split into two planes); the
 //             whole weight panel (57 KB of pre-split cells, the stem row panel of the layer kernels) stays in LDS for the kernel's
 //             lifetime; a wave owns 2-3 row blocks and all 4 column blocks
 //   phase 3   BN + ReLU, conv1 pixels outside the map := 0 (never win: ReLU outputs are >= 0 and every window holds a real pixel),
@@ -2645,7 +2648,7 @@ struct StemPoolArgs {
     const uint4* wcells;              // [7 kernel rows][4 k-groups][2 planes][64][8 halves]  (launch_pack_h3 of the stem row panel)
     const float* w_absmax;            // its range slots
     const float* bn_scale; const float* bn_bias;
-    float mean0, mean1, mean2, out_scale;
+    float mean0, mean1, mean2, out_scale;   // mean: round(mean_pixel[c]) (the fraction is in the fourth channel's weights)
     float* out;                       // H2 [B, HP, WP, 64]
     float* out_absmax;
     int B, H, W, H1, W1, HP, WP, pbh, pbw, tiles_h, tiles_w, ntiles;
@@ -2662,12 +2665,11 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
     uint4* sW = reinterpret_cast<uint4*>(smem);
     char* sU = smem + WCELLS * 16;
     uint2* sHi = reinterpret_cast<uint2*>(sU);                     // [IR][IC]
-    uint2* sLo = sHi + IR * IC;
     float* sC = reinterpret_cast<float*>(sU);                      // [NRB * 16][LDC]   (aliases the planes)
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, g = lane >> 4;
     for (int i = t; i < WCELLS; i += 512) sW[i] = p.wcells[i];
-    const float post = 1.f / (64.f * pow2_scale_for(p.w_absmax, lane));
+    const float post = 1.f / pow2_scale_for(p.w_absmax, lane);
     const int nrb = wave < NRB - 16 ? 3 : 2;                       // row blocks wave, wave + 8, wave + 16 (23 blocks: 3 each, wave 7: 2)
     float sc4[4][1], bi4[4][1];
 #pragma unroll
@@ -2703,13 +2705,12 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
             if (q < IR * IC) {
                 const int r = q / IC, c = q - r * IC;
                 const int gr = ir0 + r, gc = ic0 + c;
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                half2v x01 = {(_Float16)0.f, (_Float16)0.f}, x23 = x01;
                 if ((unsigned)gr < (unsigned)p.H && (unsigned)gc < (unsigned)p.W) {
-                    x.x = (float)pix[u][0] - p.mean0; x.y = (float)pix[u][1] - p.mean1; x.z = (float)pix[u][2] - p.mean2;
+                    x01 = half2v{(_Float16)((float)pix[u][0] - p.mean0), (_Float16)((float)pix[u][1] - p.mean1)};
+                    x23 = half2v{(_Float16)((float)pix[u][2] - p.mean2), (_Float16)1.f};
                 }
-                uint2 h, l;
-                split2_f16(x, 64.f, h, l);
-                sHi[q] = h; sLo[q] = l;
+                sHi[q] = make_uint2(__builtin_bit_cast(unsigned, x01), __builtin_bit_cast(unsigned, x23));
             }
         }
         __syncthreads();
@@ -2740,11 +2741,9 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
             for (int i = 0; i < 3; ++i) {
                 if (i < nrb) {
                     const uint4 ah = *reinterpret_cast<const uint4*>(sHi + abase[i] + kh * IC);
-                    const uint4 al = *reinterpret_cast<const uint4*>(sLo + abase[i] + kh * IC);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah), __builtin_bit_cast(half8, bl[j]), acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, al), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
                     }
                 }
@@ -2804,7 +2803,7 @@ hipError_t launch_stem_pool_fused(const unsigned char* frames, int B, int H, int
                                   float* out, float* out_absmax, hipStream_t s) {
     StemPoolArgs a{};
     a.frames = frames; a.wcells = reinterpret_cast<const uint4*>(wcells); a.w_absmax = w_absmax; a.bn_scale = bn_scale; a.bn_bias = bn_bias;
-    a.mean0 = m0; a.mean1 = m1; a.mean2 = m2; a.out_scale = out_scale; a.out = out; a.out_absmax = out_absmax;
+    a.mean0 = roundf(m0); a.mean1 = roundf(m1); a.mean2 = roundf(m2); a.out_scale = out_scale; a.out = out; a.out_absmax = out_absmax;
     a.B = B; a.H = H; a.W = W; a.H1 = (H + 1) / 2; a.W1 = (W + 1) / 2;
     a.HP = (a.H1 + 1) / 2; a.WP = (a.W1 + 1) / 2;
     const int pth = ((a.HP - 1) * 2 + 3 - a.H1) > 0 ? ((a.HP - 1) * 2 + 3 - a.H1) : 0;

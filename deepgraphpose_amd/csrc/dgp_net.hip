@@ -388,10 +388,19 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
             // left edge (one contiguous 128-byte read per output pixel and kernel row); pixel 7 has zero weights
             std::vector<float> rows((size_t)7 * 8 * l.CoutP * 4, 0.f), host((size_t)l.nk * 8 * l.CoutP * 4);
             HIP_TRY(hipMemcpy(host.data(), l.d_w, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+            // Channel slot 3 (a zero in every input the layer kernels see) carries, for the fused root kernel, the part of the mean
+            // subtraction that is not an integer: x - mean_c = (x - round(mean_c)) + d_c with d_c = round(mean_c) - mean_c, and
+            // sum_c d_c w[tap][c][co] is a weight of a fourth input channel that is 1 on every pixel inside the frame.  The kernel then
+            // multiplies exact small integers (one fp16 plane, two MFMAs per product instead of three).
+            float dmean[3];
+            for (int c = 0; c < 3; ++c) dmean[c] = roundf(net->desc.mean_pixel[c]) - net->desc.mean_pixel[c];
             for (int kh = 0; kh < 7; ++kh)
-                for (int kw = 0; kw < 7; ++kw)        // generic panel row = tap (Cin = 4: one row of 4 k-values per tap)
-                    memcpy(&rows[((size_t)(kh * 8 + kw)) * l.CoutP * 4], &host[((size_t)(kh * 7 + kw)) * l.CoutP * 4],
-                           (size_t)l.CoutP * 4 * sizeof(float));
+                for (int kw = 0; kw < 7; ++kw) {      // generic panel row = tap (Cin = 4: one row of 4 k-values per tap)
+                    float* dst = &rows[((size_t)(kh * 8 + kw)) * l.CoutP * 4];
+                    memcpy(dst, &host[((size_t)(kh * 7 + kw)) * l.CoutP * 4], (size_t)l.CoutP * 4 * sizeof(float));
+                    for (int co = 0; co < l.CoutP; ++co)
+                        dst[co * 4 + 3] = dmean[0] * dst[co * 4] + dmean[1] * dst[co * 4 + 1] + dmean[2] * dst[co * 4 + 2];
+                }
             if (!l.d_w_rows) HIP_TRY(hipMalloc(&l.d_w_rows, rows.size() * sizeof(float)));
             HIP_TRY(hipMemcpy(l.d_w_rows, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
             if (!l.d_wh3) HIP_TRY(hipMalloc(&l.d_wh3, rows.size() * sizeof(float)));
