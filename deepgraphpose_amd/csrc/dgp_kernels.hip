@@ -1176,6 +1176,9 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK
                     char* dst = smB + sb * (B_CELLS * 16) + b_dst0;
 #pragma unroll
                     for (int i = 0; i < BSLOTS; ++i)
+#if defined(DGP_FEEDX) && (DGP_FEEDX & 2)
+                        if (it < 0)
+#endif
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (lds_void*)(dst + i * (PB_KG_STEP * LDB * 16)), 16, (int)pb_goff0,
                                                                  (int)kgbase + i * pb_gstride, 0, 0);
                     if (p.tap_minor) {
@@ -1197,6 +1200,9 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK
                         const int d2 = DGP_RFL((a_ch - p.cin_split) * 4);
 #pragma unroll
                         for (int i = 0; i < AROWS; ++i) {
+#if defined(DGP_FEEDX) && (DGP_FEEDX & 1)
+                            if (it < 0)
+#endif
                             if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in2, (lds_void*)(dst + i * (32 * 128)), 16,
                                                                                  (int)(rowbase2 + (unsigned)(d2 + i * rstride2)), 0, 0, 0);
                             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(dst + i * (32 * 128)), 16,
@@ -1208,6 +1214,9 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK
                         for (int i = 0; i < AROWS; ++i) {
                             const int hi = hi0[i] + dh, wi = wi0[i] + dw;
                             const bool ok = tapok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+#if defined(DGP_FEEDX) && (DGP_FEEDX & 1)
+                            if (it < 0)
+#endif
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(dst + i * (32 * 128)), 16,
                                                                      (int)(ok ? (unsigned)(rowoff[i] + doff) : OOB), 0, 0, 0);
                         }
