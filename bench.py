@@ -92,8 +92,41 @@ def spawn_workers(args) -> None:
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    # rank 0's stdout is drained by a thread; this loop polls EVERY child: the first one that exits non-zero (OOM, RCCL init failure, bad
+    # LOCAL_RANK) takes the others down with it instead of leaving rank 0 inside a collective until a watchdog fires (or for ever),
+    # and an overall deadline bounds the run.  Children are terminated / killed by PID, never re-exec'd.
+    import threading
+    buf = []
+    rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    deadline = time.monotonic() + float(os.environ.get("DGP_BENCH_TIMEOUT", 3600))
+    failed = None
+    while True:
+        rcs = [q.poll() for q in procs]
+        if all(c is not None for c in rcs):
+            break
+        bad = [i for i, c in enumerate(rcs) if c not in (None, 0)]
+        if bad or time.monotonic() > deadline:
+            failed = "rank %d exited with code %d" % (bad[0], rcs[bad[0]]) if bad else "timeout"
+            for q in procs:
+                if q.poll() is None:
+                    q.terminate()
+            t_end = time.monotonic() + 10.0
+            for q in procs:
+                try:
+                    q.wait(timeout=max(0.1, t_end - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    q.kill()
+                    q.wait()
+            rcs = [q.returncode for q in procs]
+            break
+        time.sleep(0.05)
+    rd.join(timeout=5.0)
+    out0 = buf[0] if buf else ""
+    if failed:
+        print("bench.py: %s; the other workers were stopped" % failed, file=sys.stderr, flush=True)
+        first_bad = next((c for c in rcs if c not in (0, None) and c > 0), 1)
+        raise SystemExit(first_bad)
     line = None
     for ln in (out0 or "").splitlines():
         if ln.startswith("{"):
@@ -200,6 +233,8 @@ def main():
     from deepgraphpose_amd.synthetic import make_frames, make_weights
     import torch.distributed as dist
 
+    if os.environ.get("DGP_BENCH_FAULT_RANK") == os.environ.get("RANK", "0"):      # tests: a worker that dies before it joins the group
+        raise SystemExit(7)
     rank, local_rank, world = ddist.init_from_env("nccl")
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
@@ -451,7 +486,6 @@ def main():
 
     if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
         from oracle import dgp_oracle as O      # checker / baseline only
-        ncmp = 8
         nthreads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
         torch.set_num_threads(nthreads)
         O.infer(ring[0][:1].cpu().numpy(), wts, 50, STRIDE, 1.0, 1)             # warm-up
@@ -468,11 +502,23 @@ def main():
         ref = O.infer(f32, wts, 50, STRIDE, 1.0, 1)
         c3 = time.perf_counter()
         fps1, fps32 = n1 / (c1 - c0), f32.shape[0] / (c3 - c2)
-        m, c, ix = net.infer(ring[0][:ncmp].contiguous(), 1.0, 1)
-        m = m.cpu().numpy().astype(np.float64)
-        ex = m[:, :, 1] * STRIDE + 0.5 * STRIDE - ref["x"][:ncmp]
-        ey = m[:, :, 0] * STRIDE + 0.5 * STRIDE - ref["y"][:ncmp]
-        err = np.sqrt(ex ** 2 + ey ** 2)
+        # checked: the trajectory the TIMED REGION wrote -- global batch 0 = ring[0] is traj[0:B] (an instrumented step, alone on one
+        # stream), global batch RING = ring[0] again is traj[RING B:(RING + 1) B] (dealt to the two engines, two batches in flight) --
+        # all B frames of each against the oracle on the same frames (records: row, col, likelihood fp32 + (iy, ix) int32 bit patterns)
+        def _timed_vs_oracle(first):
+            rec = traj[first:first + B].cpu().numpy()
+            ex_ = rec[:, :, 1].astype(np.float64) * STRIDE + 0.5 * STRIDE - ref["x"]
+            ey_ = rec[:, :, 0].astype(np.float64) * STRIDE + 0.5 * STRIDE - ref["y"]
+            ix_ = np.ascontiguousarray(rec[:, :, 3:5]).view(np.int32)
+            return np.sqrt(ex_ ** 2 + ey_ ** 2), bool(np.array_equal(ix_, ref["idx"])), float(np.abs(rec[:, :, 2] - ref["likelihoods"]).max())
+        assert g0 == 0
+        err, idx_ok, lik_d = _timed_vs_oracle(0)
+        checked = ["timed step 0 (one stream)"]
+        if K > RING:
+            err2, idx_ok2, lik_d2 = _timed_vs_oracle(RING * B)
+            err, idx_ok, lik_d = np.concatenate([err, err2]), idx_ok and idx_ok2, max(lik_d, lik_d2)
+            checked.append("timed step %d (two batches in flight)" % RING)
+        ncmp = err.shape[0]
         out["cpu_baseline"] = {
             "value": round(max(fps1, fps32), 3), "unit": "frames/s", "cores": nthreads, "kind": "port",
             "batch1_frames_per_s": round(fps1, 3), "batch32_frames_per_s": round(fps32, 3),
@@ -484,8 +530,11 @@ def main():
         }
         out["accuracy_vs_oracle"] = {
             "px_rmse": float(np.sqrt((err ** 2).mean())), "px_max": float(err.max()), "frames": ncmp,
-            "idx_bit_exact": bool(np.array_equal(ix.cpu().numpy(), ref["idx"][:ncmp])),
+            "idx_bit_exact": idx_ok, "likelihood_max_abs_diff": lik_d,
+            "what": "the packed trajectory written inside the timed region (" + " + ".join(checked) + "), every frame of the batch, vs the "
+                    "CPU oracle on the same frames",
         }
+        assert idx_ok and float(err.max()) < 1e-3, "timed trajectory outside the parity gate"
     if world == 1 and not args.no_strict_f32:
         # the IEEE-fp32 tier beside the fp32-class one, timed in THIS run: a fresh child process (the conv mode is read once per
         # process) runs the same workload on the fp32 MFMA kernels for a few steps

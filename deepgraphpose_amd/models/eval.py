@@ -128,7 +128,7 @@ def setup_dgp_eval_graph(dlc_cfg, dgp_model_file, loc_ref=False, gauss_len=1, ga
 
 
 # counters of the last estimate_pose call (tests, soak runs): chunks processed and chunks re-run after a range overflow
-RUN_STATS = {"chunks": 0, "chunk_reruns": 0}
+RUN_STATS = {"chunks": 0, "chunk_reruns": 0, "strict_passes": 0}
 
 
 def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle=1, save_pose=True, save_str="",
@@ -226,9 +226,16 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
         # The frames of a CHUNK of batches stay on the device until the chunk's range check has come back clean: a chunk whose
         # activations outgrew the calibrated H2 scales is re-run from HBM, without decoding anything again (DGP_EVAL_CHUNK_BATCHES,
         # default 64 batches, capped at 4 GB of frames)
+        # -- never more batches than the shard holds, and at most DGP_EVAL_CHUNK_BYTES (default 1 GiB) of frames: 34 batches of 32 at
+        # 640 x 480, 24 batches of 16 at 1280 x 720, next to the engines' workspaces.  Every term is the same on every rank (the chunk
+        # rounds below are collective), so nothing here may depend on a rank's free memory.
         batch_bytes = batch_size * hh * ww * 3
-        chunk_batches = max(1, min(int(os.environ.get("DGP_EVAL_CHUNK_BATCHES", "64")), int(4e9 // max(batch_bytes, 1)) or 1))
+        per_rank_batches = max(1, -(-(-(-n_frames // world)) // batch_size))
+        chunk_cap = int(float(os.environ.get("DGP_EVAL_CHUNK_BYTES", str(1 << 30))) // max(batch_bytes, 1)) or 1
+        chunk_batches = max(1, min(int(os.environ.get("DGP_EVAL_CHUNK_BATCHES", "64")), chunk_cap, per_rank_batches))
         dchunk = torch.empty((chunk_batches, batch_size, hh, ww, 3), dtype=torch.uint8, device=dev)
+        strict = os.environ.get("DGP_EVAL_STRICT", "0") == "1"
+        stale = False                             # an earlier chunk holds results of narrower scales than the video ended with
         cal_batch = None                          # the batch every engine (and every rank) calibrates its activation scales on
         if world > 1 and hasattr(video_clip, "frame_at"):
             # every rank calibrates the activation scales on the video's FIRST batch (not on its own shard's), so the frozen scales --
@@ -329,7 +336,9 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
                 if not overflow:
                     net.widen()                   # follow the rank that overflowed: same headroom everywhere
                 net.calibrate(cal_batch, sess.gamma, sess.gauss_len)
-                if overflow:
+                if rnd > 0:
+                    stale = True                  # chunks [0, rnd) were computed with the narrower scales (valid, but other bits)
+                if overflow or strict:            # strict: every rank re-runs this chunk on the new scales, not only the one that overflowed
                     print("activation ranges outgrew the calibrated scales: re-calibrated, re-running frames %d-%d of %s"
                           % (lo + entries[0][2] if entries else lo, lo + start, video_file), flush=True)
                     RUN_STATS["chunk_reruns"] += 1
@@ -351,10 +360,19 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
             mu_t, lik_t, _ = ddist.unpack_keypoints(traj[:start])
             markers[:start] = mu_t.cpu().numpy()
             likelihoods[:start] = lik_t.cpu().numpy()
+        return stale
 
+    # Bit-identity of a sharded run with a single-process run holds as long as no chunk overflows (or only the first one does).  After an
+    # overflow in a LATER chunk the earlier chunks keep the (valid) results of the narrower scales, which a run that started with the
+    # wide scales would not reproduce bit for bit.  DGP_EVAL_STRICT=1 restores the guarantee at the cost of a second pass over the video:
+    # the engines keep the widened headroom and everything is computed again on those scales (the decision is collective).
     net_used = None
-    RUN_STATS["chunks"] = RUN_STATS["chunk_reruns"] = 0
-    _infer_once(video_clip)
+    RUN_STATS["chunks"] = RUN_STATS["chunk_reruns"] = RUN_STATS["strict_passes"] = 0
+    for _pass in range(4):
+        if not (_infer_once(video_clip) and os.environ.get("DGP_EVAL_STRICT", "0") == "1"):
+            break
+        RUN_STATS["strict_passes"] += 1
+        print("DGP_EVAL_STRICT: scales were widened after the first chunk; computing %s again on the final scales" % video_file, flush=True)
     sess.close()
     video_clip.close()
 

@@ -50,6 +50,11 @@ def _to_nchw(x: np.ndarray) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(x)).permute(0, 3, 1, 2)
 
 
+def _t(a: np.ndarray, like: torch.Tensor) -> torch.Tensor:
+    """numpy parameter -> torch tensor of the activation's dtype (fp32: no change; fp64 anchor: exact widening of the fp32 values)"""
+    return torch.from_numpy(np.ascontiguousarray(a)).to(like.dtype)
+
+
 def _to_nhwc(t: torch.Tensor) -> np.ndarray:
     return t.permute(0, 2, 3, 1).contiguous().numpy()
 
@@ -59,7 +64,7 @@ def conv2d(x: torch.Tensor, w_hwio: np.ndarray, stride: int = 1, rate: int = 1,
     """slim.conv2d without bias/BN/activation on an NCHW torch tensor.
     TF conv2d is a cross-correlation (no kernel flip), weights HWIO."""
     kh, kw = w_hwio.shape[:2]
-    w = torch.from_numpy(np.ascontiguousarray(w_hwio)).permute(3, 2, 0, 1).contiguous()
+    w = _t(w_hwio, x).permute(3, 2, 0, 1).contiguous()
     if padding == "SAME":
         _, pt, pb = tf_same_pads(x.shape[2], kh, stride, rate)
         _, pl, pr = tf_same_pads(x.shape[3], kw, stride, rate)
@@ -84,10 +89,10 @@ def conv2d_same(x: torch.Tensor, w_hwio: np.ndarray, stride: int, rate: int = 1)
 def batch_norm(x: torch.Tensor, wts: Dict[str, np.ndarray], scope: str) -> torch.Tensor:
     """slim.batch_norm, is_training=False (PET/nnet/pose_net.py:52): moving stats,
     scale=True, eps 1e-5, evaluated as (x-mean) * (gamma * rsqrt(var+eps)) + beta."""
-    g = torch.from_numpy(wts[scope + "/BatchNorm/gamma"])
-    b = torch.from_numpy(wts[scope + "/BatchNorm/beta"])
-    m = torch.from_numpy(wts[scope + "/BatchNorm/moving_mean"])
-    v = torch.from_numpy(wts[scope + "/BatchNorm/moving_variance"])
+    g = _t(wts[scope + "/BatchNorm/gamma"], x)
+    b = _t(wts[scope + "/BatchNorm/beta"], x)
+    m = _t(wts[scope + "/BatchNorm/moving_mean"], x)
+    v = _t(wts[scope + "/BatchNorm/moving_variance"], x)
     inv = g * torch.rsqrt(v + BN_EPS)
     return (x - m[None, :, None, None]) * inv[None, :, None, None] + b[None, :, None, None]
 
@@ -109,13 +114,15 @@ def subsample(x: torch.Tensor, factor: int) -> torch.Tensor:
 # A1: backbone
 # ----------------------------------------------------------------------------
 def resnet_features(frames_u8: np.ndarray, wts: Dict[str, np.ndarray], depth: int = 50,
-                    return_endpoints: bool = False):
+                    return_endpoints: bool = False, dtype=np.float32):
     """PoseNet.extract_features (PET/nnet/pose_net.py:36-54): (x - mean_pixel) ->
-    slim resnet_v1_{depth}(global_pool=False, output_stride=16, is_training=False)."""
+    slim resnet_v1_{depth}(global_pool=False, output_stride=16, is_training=False).
+    dtype=np.float64: the ACCURACY ANCHOR -- the same fp32 parameters and the same graph evaluated in double precision (what every
+    fp32 evaluation order, TF's included, approximates); the reference itself runs fp32."""
     from oracle.resnet_plan import units as resnet_units   # the oracle's OWN restatement of slim's plan
     name = "resnet_v1_%d" % depth
     x = frames_u8.astype(np.float32) - np.asarray(MEAN_PIXEL, dtype=np.float32)[None, None, None, :]
-    x = _to_nchw(x).contiguous(memory_format=torch.channels_last)
+    x = _to_nchw(x.astype(dtype)).contiguous(memory_format=torch.channels_last)
     ends = {}
     with torch.no_grad():
         net = conv2d_same(x, wts[name + "/conv1/weights"], stride=2)
@@ -159,14 +166,15 @@ def conv2d_transpose_same(x_nhwc: np.ndarray, w: np.ndarray, b: Optional[np.ndar
     oh, ow = h * stride, wd * stride
     _, pt, _ = tf_same_pads(oh, kh, stride)
     _, pl, _ = tf_same_pads(ow, kw, stride)
-    wt = torch.from_numpy(np.ascontiguousarray(w)).permute(3, 2, 0, 1).contiguous()  # [Cin,Cout,kh,kw]
+    xt = _to_nchw(x_nhwc)
+    wt = _t(w, xt).permute(3, 2, 0, 1).contiguous()  # [Cin,Cout,kh,kw]
     with torch.no_grad():
-        full = F.conv_transpose2d(_to_nchw(x_nhwc), wt, stride=stride)   # (H-1)*s + k
+        full = F.conv_transpose2d(xt, wt, stride=stride)   # (H-1)*s + k
         y = full[:, :, pt:pt + oh, pl:pl + ow]
         if y.shape[2] < oh or y.shape[3] < ow:    # only when k < stride
             y = F.pad(y, (0, ow - y.shape[3], 0, oh - y.shape[2]))
         if b is not None:
-            y = y + torch.from_numpy(b)[None, :, None, None]
+            y = y + _t(b, xt)[None, :, None, None]
     return _to_nhwc(y)
 
 
@@ -282,12 +290,14 @@ def sigmoid_f32(x: np.ndarray) -> np.ndarray:
 # A0: whole inference step (one sess.run + host read-out, batched)
 # ----------------------------------------------------------------------------
 def infer(frames_u8: np.ndarray, wts: Dict[str, np.ndarray], depth: int = 50,
-          stride: float = 8.0, gamma: float = 1.0, gauss_len: int = 1):
+          stride: float = 8.0, gamma: float = 1.0, gauss_len: int = 1, dtype=np.float32):
     """estimate_pose hot loop (DGP/models/eval.py:306-357) over a batch of frames.
-    Returns dict(x, y, likelihoods [T,nj] float64; mu [T,nj,2] f32; idx [T,nj,2]; scmap)."""
-    feats = resnet_features(frames_u8, wts, depth)
+    Returns dict(x, y, likelihoods [T,nj] float64; mu [T,nj,2] f32; idx [T,nj,2]; scmap).
+    dtype=np.float64: the accuracy anchor (see resnet_features) -- backbone, heads and soft-argmax in double precision (mu is then
+    float64); the tolerance tests measure every fp32 evaluation, the CPU oracle's own included, against it."""
+    feats = resnet_features(frames_u8, wts, depth, dtype=dtype)
     scmap, _ = pose_heads(feats, wts, False)
-    mu, _ = argmax_2d_from_cm(scmap, gamma, gauss_len)
+    mu, _ = argmax_2d_from_cm(scmap, gamma, gauss_len, dtype=dtype)
     t, nj = mu.shape[:2]
     idx = np.zeros((t, nj, 2), dtype=np.int64)
     lik = np.zeros((t, nj))

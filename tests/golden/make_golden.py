@@ -209,6 +209,30 @@ def main():
         tgt.append(1)
     g["tg_n"] = len(tgt)
 
+    # ---------------- A4 again, with mu = the soft-argmax OF the scoremap (round 4): the GPU kernel computes its own mu, so these cases
+    # let its window indices / likelihoods be compared with the reference's lines directly.  mu comes from this repository's oracle
+    # (argmax_2d_from_cm is TF code in the reference and cannot run); the eval.py loop body that turns (scmap, mu) into (idx, lik) is
+    # the reference's own.  Own generator: the arrays above stay byte-identical.
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from oracle import dgp_oracle as O
+    rng2 = np.random.default_rng(20261003)
+    lm = [(60, 80, 4, 1), (47, 52, 5, 1), (24, 32, 3, 2), (90, 160, 20, 1)]
+    g["likmu_n"] = len(lm)
+    for i, (h, w, c, gl) in enumerate(lm):
+        while True:                                              # redraw until no coordinate sits within 1e-3 of an integer (the window
+            s = (rng2.standard_normal((1, h, w, c)) * 1.5).astype(np.float32)      # would then depend on the last bits of mu)
+            yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+            for j in range(c):                                   # one or two blobs per map: mu between them, windows off the peak too
+                for _ in range(1 + (j % 2)):
+                    py, px = rng2.uniform(2, h - 3), rng2.uniform(2, w - 3)
+                    s[0, :, :, j] += (12.0 * np.exp(-((yy - py) ** 2 + (xx - px) ** 2) / (2 * rng2.uniform(0.8, 2.5) ** 2))).astype(np.float32)
+            mu, _ = O.argmax_2d_from_cm(s, 1.0, gl)
+            if np.abs(mu - np.round(mu)).min() > 1e-3:
+                break
+        idx, lik = likelihood_from_eval_py(s, mu)
+        g["likmu%d_scmap" % i], g["likmu%d_mu" % i], g["likmu%d_idx" % i], g["likmu%d_lik" % i] = s[0], mu[0], idx, lik
+        g["likmu%d_gauss_len" % i] = gl
+
     np.savez_compressed(OUT, **g)
     print("wrote", OUT, "%.1f KiB" % (os.path.getsize(OUT) / 1024), len(g), "arrays")
 

@@ -374,9 +374,22 @@ def test_estimate_pose_reruns_only_the_chunk_that_overflowed(lib_built, tmp_path
     monkeypatch.setenv("DGP_EVAL_CHUNK_BATCHES", "2")                 # chunks of 2 batches of 4 frames: the real frames start in chunk 2
     out = E.estimate_pose(str(proj / "config.yaml"), snap, str(tmp_path / "mixed.npy"), str(tmp_path / "pred_mixed"), shuffle=1,
                           batch_size=4)
-    assert E.RUN_STATS["chunks"] == 5 and E.RUN_STATS["chunk_reruns"] == 1, E.RUN_STATS
+    assert E.RUN_STATS["chunks"] == 5 and E.RUN_STATS["chunk_reruns"] == 1 and E.RUN_STATS["strict_passes"] == 0, E.RUN_STATS
     ref = O.infer(frames, wts, 50, 8.0, 1.0, 1)
     assert np.abs(out["x"] - ref["x"]).max() < 1e-3 and np.abs(out["y"] - ref["y"]).max() < 1e-3
+    # DGP_EVAL_STRICT=1: chunks 0-1 were computed on the narrower scales, so the video is computed again on the final ones -- and is
+    # then bit-identical to a run whose ONE chunk holds the whole video (overflow in chunk 0: everything re-run on the wide scales)
+    monkeypatch.setenv("DGP_EVAL_STRICT", "1")
+    strict = E.estimate_pose(str(proj / "config.yaml"), snap, str(tmp_path / "mixed.npy"), str(tmp_path / "pred_strict"), shuffle=1,
+                             batch_size=4)
+    assert E.RUN_STATS["strict_passes"] == 1 and E.RUN_STATS["chunk_reruns"] == 1, E.RUN_STATS
+    monkeypatch.setenv("DGP_EVAL_CHUNK_BATCHES", "64")
+    whole = E.estimate_pose(str(proj / "config.yaml"), snap, str(tmp_path / "mixed.npy"), str(tmp_path / "pred_whole"), shuffle=1,
+                            batch_size=4)
+    assert E.RUN_STATS["chunks"] == 1 and E.RUN_STATS["chunk_reruns"] == 1 and E.RUN_STATS["strict_passes"] == 0, E.RUN_STATS
+    for k in ("x", "y", "likelihoods"):
+        assert np.array_equal(strict[k], whole[k]), k
+    assert np.abs(strict["x"] - ref["x"]).max() < 1e-3 and np.abs(strict["y"] - ref["y"]).max() < 1e-3
 
 
 def test_estimate_pose_edge_cases_vs_oracle(lib_built, tmp_path):

@@ -281,30 +281,92 @@ def _stress_case(hw, seed, B=2, nj=4):
     return wts, frames
 
 
-@pytest.mark.parametrize("hw,seed,px_gate", [((96, 128), 1, 1e-3), ((96, 128), 2, 1e-3), ((480, 640), 3, 5e-3)])
-def test_trained_like_bn_statistics_keep_the_parity_gate(lib_built, hw, seed, px_gate):
+def _px_gate(err_oracle32_vs_fp64):
+    """The round-4 criterion: a HIP tier may sit as far from the fp64 anchor as 1.5 x the CPU-fp32 oracle itself does, and never needs
+    to be closer than the reference's 1e-3 px."""
+    return max(1e-3, 1.5 * err_oracle32_vs_fp64)
+
+
+@pytest.mark.parametrize("hw,seed", [((96, 128), 1), ((96, 128), 2), ((480, 640), 3), ((480, 640), 4), ((480, 640), 5), ((480, 640), 7)])
+def test_trained_like_bn_statistics_keep_the_parity_gate(lib_built, hw, seed):
     """The H2 format on weights that look like a trained network: folded BN scales spread over 2^-8 .. 2^4 per layer, channel
     magnitudes over 2^-6 .. 2^2 with 100 x outliers, 5 % dead channels, weight-panel columns differing by up to 2^20.  Likelihood
-    indices bit-exact, likelihoods within 1e-4, scoremap within 4e-5 relative, no range overflow after ONE calibration.
-    Coordinates: within the reference's 1e-3 px at 96 x 128.  At 640 x 480 this regime is ill-conditioned for ANY fp32 arithmetic
-    with another summation order: the IEEE-fp32 MFMA kernels (DGP_CONV_MODE=f32, bitwise fmaf chains) differ from the CPU oracle by
-    0.85e-3 .. 1.65e-3 px on these cases, the 22-bit-operand paths (H2, DGP_H2=0, bf16x6) by 2.2e-3 .. 4.9e-3 (scripts/stress_modes.py
-    prints the table) -- three to four times the fp32 kernels' error, the ratio 2 missing operand bits predict.  Gate there: 5e-3 px."""
+    indices bit-exact, likelihoods within 1e-4, no range overflow after ONE calibration.
+    Coordinates, anchored to FLOAT64 (oracle.infer(dtype=float64): the same graph and fp32 parameters in double precision).  In this
+    regime the logits are broad (std 3 over the whole map), so the soft-argmax coordinate amplifies every rounding of the 50 layers
+    in front of it: the CPU-fp32 oracle ITSELF is 0.8e-3 .. 5.7e-3 px from float64 at 640 x 480 (1.7e-4 at 96 x 128), i.e. two fp32
+    evaluations of this network differ by more than the reference's 1e-3 px whatever computes them.  The gate is therefore relative:
+    err_vs_fp64(HIP default) <= max(1e-3 px, 1.5 x err_vs_fp64(CPU-fp32 oracle)); and on the scoremap, where the error is not amplified,
+    the engine must be at least as close to float64 as the fp32 oracle is (x 1.25).  Measured (scripts/stress_modes.py, seeds 3 / 4 / 5 /
+    7): HIP default 6.3e-3 / 0.52e-3 / 0.55e-3 / 1.8e-3 px against the oracle's 5.7e-3 / 0.76e-3 / 2.6e-3 / 1.9e-3; scoremap 3.4 .. 6.5e-6
+    relative against 5.2e-6 .. 1.26e-5."""
     from deepgraphpose_amd.engine import DGPNet
     from oracle import dgp_oracle as O
     wts, frames = _stress_case(hw, seed)
     ref = O.infer(frames, wts, 50, 8.0, 1.0, 1)
+    r64 = O.infer(frames, wts, 50, 8.0, 1.0, 1, dtype=np.float64)
     assert np.isfinite(ref["scmap"]).all() and 1.0 < ref["scmap"].std() < 10.0
     net = DGPNet(50, 4, hw[0], hw[1], max_batch=frames.shape[0])
     net.load_weights(wts)
     sc = torch.empty((frames.shape[0], net.out_h, net.out_w, 4), device="cuda")
     mu, conf, idx = net.infer(torch.from_numpy(frames).cuda(), scmap_out=sc)
     assert net.range_status() == (False, 1)
-    err = np.abs(mu.cpu().numpy() - ref["mu"]).max() * 8.0
-    assert err < px_gate, err
+    mu = mu.cpu().numpy().astype(np.float64)
+    sc = sc.cpu().numpy().astype(np.float64)
+    err_oracle = np.abs(ref["mu"] - r64["mu"]).max() * 8.0
+    err_hip = np.abs(mu - r64["mu"]).max() * 8.0
+    print("px vs fp64: HIP default %.3g, CPU-fp32 oracle %.3g; HIP vs oracle %.3g" % (err_hip, err_oracle, np.abs(mu - ref["mu"]).max() * 8.0))
+    assert err_hip <= _px_gate(err_oracle), (err_hip, err_oracle)
+    if hw == (96, 128):                      # well inside the reference's tolerance at the small size, against the fp32 oracle too
+        assert np.abs(mu - ref["mu"]).max() * 8.0 < 1e-3
+    s_scale = np.abs(r64["scmap"]).max()
+    sc_hip, sc_oracle = np.abs(sc - r64["scmap"]).max() / s_scale, np.abs(ref["scmap"] - r64["scmap"]).max() / s_scale
+    assert sc_hip <= max(1.25 * sc_oracle, 4e-6), (sc_hip, sc_oracle)
     assert np.array_equal(idx.cpu().numpy(), ref["idx"])
+    assert np.array_equal(ref["idx"], r64["idx"])
     assert np.abs(conf.cpu().numpy() - ref["likelihoods"]).max() < 1e-4
-    assert np.abs(sc.cpu().numpy() - ref["scmap"]).max() <= 4e-5 * np.abs(ref["scmap"]).max()
+
+
+def test_three_distances_from_the_fp64_anchor(lib_built, tmp_path):
+    """The three numbers of the round-3 review at the headline shape (640 x 480, stress seed 3): |HIP default - fp64|,
+    |HIP DGP_CONV_MODE=f32 - fp64| (IEEE-fp32 MFMA kernels, a child process: the mode is read once) and |CPU-fp32 oracle - fp64|.
+    Both HIP tiers must meet the same relative gate; the fp16-split default must not be worse than the strict-fp32 tier by more
+    than 2 x on the scoremap (measured: it is closer to float64 than the strict tier, 6.5e-6 against 1.2e-5)."""
+    import os
+    import subprocess
+    import sys
+    from deepgraphpose_amd.engine import DGPNet
+    from oracle import dgp_oracle as O
+    hw = (480, 640)
+    wts, frames = _stress_case(hw, 3)
+    ref = O.infer(frames, wts, 50, 8.0, 1.0, 1)
+    r64 = O.infer(frames, wts, 50, 8.0, 1.0, 1, dtype=np.float64)
+    np.savez(tmp_path / "case.npz", frames=frames, **wts)
+    code = r"""
+import sys, numpy as np, torch
+from deepgraphpose_amd.engine import DGPNet
+d = dict(np.load(sys.argv[1]))
+frames = d.pop("frames")
+net = DGPNet(50, 4, frames.shape[1], frames.shape[2], max_batch=frames.shape[0]); net.load_weights(d)
+sc = torch.empty((frames.shape[0], net.out_h, net.out_w, 4), device="cuda")
+mu, conf, idx = net.infer(torch.from_numpy(frames).cuda(), scmap_out=sc)
+np.savez(sys.argv[2], mu=mu.cpu().numpy(), idx=idx.cpu().numpy(), sc=sc.cpu().numpy())
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for tier, env in (("default", {}), ("f32", {"DGP_CONV_MODE": "f32"})):
+        subprocess.check_call([sys.executable, "-c", code, str(tmp_path / "case.npz"), str(tmp_path / (tier + ".npz"))],
+                              env=dict(os.environ, PYTHONPATH=root, **env), cwd=root)
+        out[tier] = np.load(tmp_path / (tier + ".npz"))
+    err_oracle = np.abs(ref["mu"] - r64["mu"]).max() * 8.0
+    errs = {t: np.abs(o["mu"].astype(np.float64) - r64["mu"]).max() * 8.0 for t, o in out.items()}
+    scs = {t: np.abs(o["sc"].astype(np.float64) - r64["scmap"]).max() / np.abs(r64["scmap"]).max() for t, o in out.items()}
+    print("px vs fp64: HIP default %.3g, HIP f32 %.3g, CPU-fp32 oracle %.3g; scoremap rel %.3g / %.3g" % (
+        errs["default"], errs["f32"], err_oracle, scs["default"], scs["f32"]))
+    for t in out:
+        assert errs[t] <= _px_gate(err_oracle), (t, errs[t], err_oracle)
+        assert np.array_equal(out[t]["idx"], r64["idx"])
+    assert scs["default"] <= 2.0 * scs["f32"]
 
 
 def test_trained_like_bn_statistics_on_fp32_activations(lib_built, tmp_path):

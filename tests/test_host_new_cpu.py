@@ -174,3 +174,24 @@ def test_prefetched_keeps_order_propagates_errors_and_stops(monkeypatch):
     gen.close()                                   # consumer walks away: the producer must stop, not build 1000 items
     time.sleep(0.2)
     assert count[0] < 20
+
+
+def test_bench_spawner_stops_the_other_workers_when_one_dies():
+    """`python bench.py --gpus 2` (its own spawner): rank 1 exits with code 7 before joining the process group; rank 0 would wait in the
+    rendezvous for ever.  The parent polls every child, stops rank 0 and exits with rank 1's code -- no GPU involved (the workers never
+    get as far as the device)."""
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DGP_BENCH_FAULT_RANK="1", DGP_DIST_BACKEND="gloo", PYTHONPATH=root)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--no-cpu-baseline"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 7, (r.returncode, r.stderr[-500:])
+    assert "rank 1 exited with code 7" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert time.monotonic() - t0 < 200

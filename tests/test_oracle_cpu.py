@@ -32,6 +32,13 @@ def test_likelihood_window_matches_reference_vectors():
         idx, lik = O.likelihood_window(GOLD["lik%d_scmap" % i], GOLD["lik%d_mu" % i])
         np.testing.assert_array_equal(idx, GOLD["lik%d_idx" % i])
         np.testing.assert_array_equal(lik, GOLD["lik%d_lik" % i])
+    for i in range(int(GOLD["likmu_n"])):           # mu = the scoremap's own soft-argmax (round 4; the GPU test uses these directly)
+        s = GOLD["likmu%d_scmap" % i]
+        mu, _ = O.argmax_2d_from_cm(s[None], 1.0, int(GOLD["likmu%d_gauss_len" % i]))
+        np.testing.assert_array_equal(mu[0], GOLD["likmu%d_mu" % i])
+        idx, lik = O.likelihood_window(s, mu[0])
+        np.testing.assert_array_equal(idx, GOLD["likmu%d_idx" % i])
+        np.testing.assert_array_equal(lik, GOLD["likmu%d_lik" % i])
 
 
 # ------------------------------------------------------------------ known answers (TF semantics)

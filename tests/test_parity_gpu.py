@@ -318,15 +318,31 @@ def test_hip_kernels_reproduce_reference_vectors(eng):
         ref = g["app%d_pose" % i]
         np.testing.assert_array_equal(pose[:, :2], ref[:, :2])          # integer index + fp32 offset: exact
         np.testing.assert_allclose(pose[:, 2], ref[:, 2], atol=2e-7)
+    from oracle import dgp_oracle as O
     for i in range(int(g["lik_n"])):
+        # fixtures whose mu is a random point, not the scoremap's soft-argmax: the kernel computes its OWN mu, so the fixture's
+        # (idx, lik) apply only where that mu falls into the fixture's window (same floor / ceil); otherwise the kernel is checked
+        # against the oracle's restatement of the same lines (pinned to these fixtures in tests/test_oracle_cpu.py)
         s, mu_ref = g["lik%d_scmap" % i], g["lik%d_mu" % i]
-        # drive the kernel's window with the fixture's mu by building a scoremap whose soft-argmax we do not need:
-        # the kernel computes its own mu, so compare through the oracle-equivalent path instead
-        from oracle import dgp_oracle as O
         mu, conf, idx = eng.soft_argmax(torch.from_numpy(s[None]).cuda(), 1.0, 1)
-        iref, lref = O.likelihood_window(s, mu[0].cpu().numpy())
-        assert np.array_equal(idx[0].cpu().numpy(), iref)
-        np.testing.assert_allclose(conf[0].cpu().numpy(), lref, atol=2e-7)
+        mu, conf, idx = mu[0].cpu().numpy(), conf[0].cpu().numpy(), idx[0].cpu().numpy()
+        iref, lref = O.likelihood_window(s, mu)
+        assert np.array_equal(idx, iref)
+        np.testing.assert_allclose(conf, lref, atol=2e-7)
+        same = np.all((np.floor(mu) == np.floor(mu_ref)) & (np.ceil(mu) == np.ceil(mu_ref)), axis=1)
+        assert np.array_equal(idx[same], g["lik%d_idx" % i][same])
+        np.testing.assert_allclose(conf[same], g["lik%d_lik" % i][same], atol=2e-7)
+    # round 4: fixtures whose mu IS the soft-argmax of their scoremap -> the kernel's own (mu, idx, likelihood) against the
+    # outputs of the reference's eval.py:329-343 lines DIRECTLY, every joint of every case (no oracle in between)
+    n_direct = 0
+    for i in range(int(g["likmu_n"])):
+        s, mu_ref = g["likmu%d_scmap" % i], g["likmu%d_mu" % i]
+        mu, conf, idx = eng.soft_argmax(torch.from_numpy(s[None]).cuda(), 1.0, int(g["likmu%d_gauss_len" % i]))
+        np.testing.assert_allclose(mu[0].cpu().numpy(), mu_ref, atol=1e-3 / 8.0)             # 1e-3 px at stride 8
+        np.testing.assert_array_equal(idx[0].cpu().numpy(), g["likmu%d_idx" % i])
+        np.testing.assert_allclose(conf[0].cpu().numpy(), g["likmu%d_lik" % i], atol=2e-7)
+        n_direct += mu_ref.shape[0]
+    assert n_direct >= 32
 
 
 def test_estimate_pose_end_to_end(eng, tmp_path):
