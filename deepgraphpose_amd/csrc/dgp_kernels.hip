@@ -1014,8 +1014,36 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
 //   0.39 -> 0.275 ms.  Measured (one stream, batch 32): block4 3x3 0.389 -> 0.442 ms, block4 conv1 0.195 -> 0.216 ms -- SLOWER: the eight
 //   compute waves of the one 135-KB workgroup per CU meet at one barrier per K-step, where two independent 128-row workgroups drift
 //   apart and fill each other's stalls.  Kept as an opt-in (DGP_TALL=1; DGP_TALL=2 forces it wherever it applies: the parity test).
+//   MODE 3 (round 4; H2 DMA kernels, 3x3 / stride 1 / any dilation: the "halo walk").  With MODE 1 the A rows of a 3x3 conv cross the
+//   L2 -> LDS path NINE times, once per tap (16 KB per K-step and workgroup, as much as the weight cells).  On a stride-1 conv the tap
+//   (kh, kw) of output pixel m reads input pixel m + d ((kh - 1) W + (kw - 1)) of the FLATTENED [N H W] pixel list -- a constant
+//   shift -- so one channel chunk's nine taps read nine shifted 128-pixel windows of ONE strip of S = 128 + 2 d (W + 1) consecutive
+//   pixels.  The loaders stream those strips, chunk after chunk, ONCE through a ring of HALO_C pixels x 128 B in LDS (37 KB instead of
+//   9 x 16 KB per chunk at W = 40, d = 2); the ring position of (chunk c, strip pixel j) is (c S8 + j) mod HALO_C, S8 = S rounded up
+//   to 8.  What the per-tap zero padding did in MODE 1 (the loader sent out-of-image taps to an out-of-range offset) moves to the
+//   compute waves: a lane knows, as a 9-bit mask per row block, which taps of its pixel fall outside the image (or belong to the
+//   neighbouring row / frame the flattened shift wraps into) and reads a zero cell instead.  Ring bookkeeping, all wave-uniform: step
+//   s = (c, t) reads stream pixels [lo(s), lo(s) + 128), lo = c S8 + d (kh W + kw), non-decreasing in s, so after barrier #s every
+//   pixel below lo(s) is dead and the loaders may write up to lo(s) + HALO_C; they keep >= 2 K-steps (and a smooth S8 / 9 pixels per
+//   step) ahead, counted vmcnt waits as in the DMA loaders.  Capacity rule: the largest jump between consecutive steps,
+//   max(d (W - 2), 128 + pad) + 128 <= HALO_C - 8 (launcher).  LDS image of an 8-pixel group (one DMA instruction, 1 KiB): cell
+//   index (b2 b0 | q | b1) for pixel q, chunk (b2 b1 b0): ds_read_b128's 16-lane groups pair row sets {0-3, 12-15} and {4-11} of two
+//   k-groups whose chunks differ in bit 1 -- with (q, b1) as the low four bits of the cell index every such group covers the 16
+//   slots of a bank row exactly once for ANY ring offset (the (row >> 1) & 7 XOR image of MODE 1 / 2 is 2-way on these reads), and
+//   the low cell of a k-group is +256 B from its high cell (an instruction offset, no XOR).
+//   Who computes the addresses: the compute waves are issue-bound (a first version that walked the ring and tested the masks in the
+//   compute waves -- 17 VALU + 20 SALU per K-step -- cut the bank conflicts by 73 % and the loads by 37 % and was 8 % SLOWER), so the
+//   loader waves do: two of them write, two steps ahead, a table of 128 cell addresses (row's ring cell for k-group 0, or the zero
+//   cells for a masked tap) and a compute lane reads its two entries with one ds_read_b64 and adds its k-group's constant.
+constexpr int HALO_C = 360;                       // ring capacity in pixels (multiple of 8)
+constexpr int HALO_ZERO = HALO_C * 128;           // 1 KiB of zeros: what masked taps read (k-group constants up to 528, low cell at +256)
+constexpr int HALO_TBL = HALO_ZERO + 1024;        // three stages of the address table: [wave][row & 15][row block] x 4 B = 512 B each (step s: stage s % 3;
+                                                  // written two steps ahead, read one step ahead: the stage being written is never one being read)
+constexpr int HALO_B0 = HALO_TBL + 2048;          // two stages of weight cells behind it: 49 152 + 32 768 = 80 KB, two workgroups per CU
+static_assert(HALO_B0 == 49152, "80 KB per workgroup");
 template <int BM, int BN, int NT, int BK, int CW, bool PB = false, int MODE = 0, bool CS = false, bool DMA = false, bool AH2 = false, bool OH2 = false, bool DEEP = false, bool T16 = false>
 __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK == 16 || NT == 2) ? 4 : 2)) void conv_igemm_split_ls(const ConvArgs p) {
+    static_assert(MODE != 3 || (DMA && AH2 && OH2 && BM == 128 && BN == 128 && CW == 4 && !DEEP && !T16), "halo walk: H2 tensors, LDS-DMA, 128 x 128 tiles");
     static_assert(!DEEP || (DMA && BN == 128 && BM == 128), "deep ring: LDS-DMA kernels with 128 x 128 tiles");
     static_assert(!T16 || (AH2 && DMA && !DEEP), "16-bit tier: H2 input, LDS-DMA kernels");
     static_assert(!AH2 || CS, "pre-split A operand: compute-side-split kernels only");
@@ -1052,7 +1080,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* sA = reinterpret_cast<uint4*>(smem);       // [2][NP][KG][LDA]
-    uint4* sB = sA + NSA * A_CELLS;                   // [2][NP][KG][LDB]
+    uint4* sB = MODE == 3 ? reinterpret_cast<uint4*>(smem + HALO_B0) : sA + NSA * A_CELLS;                   // [2][NP][KG][LDB]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1151,6 +1179,143 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK
             w_kh = w_tap / p.KW; w_kw = w_tap % p.KW;
         }
         float scA = 1.f, scW = 1.f;           // fp16 operand scales: read AFTER the first operand loads are in flight (below)
+        if constexpr (MODE == 3) {
+            typedef __attribute__((address_space(3))) void lds_void;
+            const int lw = wave - CW;
+            // Roles.  EVERY loader wave first issues its four one-KiB pieces of the next step's weight cells -- the cost of a step's
+            // loader side is (pieces per wave) x ~115 cycles of issue + one L2 round trip, and only the weight cells have a single step
+            // of lookahead, so they go first and four per wave is the minimum (measured: 5 / 5 / 6 pieces on three waves put the loaders
+            // 170 cycles behind the compute waves).  What follows runs under that round trip: waves 0 and 1 write the address table (one
+            // entry per lane, own two-variable walker), wave 3 keeps the ring's books and issues the ~4 strip pieces of a step, wave 2
+            // nothing.  Wave 3 waits with a counted vmcnt (this iteration's strip pieces stay in flight), the others for everything.
+            const int d = DGP_RFL(p.dil), Wd = DGP_RFL(p.W);
+            const int S8 = DGP_RFL((128 + 2 * d * (Wd + 1) + 7) & ~7), GS = S8 >> 3;
+            const int d_kh = DGP_RFL(d * (Wd - 2)), d_ch = DGP_RFL(S8 - 2 * d * (Wd + 1));
+            const unsigned b_dst0 = (unsigned)DGP_RFL(pb_cell0 * 16);
+            char* smB = smem + HALO_B0;
+            int b_ch = 0, b_tap = 0, sb = 0;
+            auto issue_cells = [&]() {                                   // weight cells of the next step (tap-minor walk)
+                const unsigned kbase = (unsigned)DGP_RFL((int)((unsigned)(b_tap * p.tap_rows + (b_ch >> 2)) * b_row_bytes));
+                const unsigned kgbase = (kbase >> 1) * 2u;
+                char* dst = smB + sb * (B_CELLS * 16) + b_dst0;
+#pragma unroll
+                for (int i = 0; i < BSLOTS; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (lds_void*)(dst + i * (PB_KG_STEP * LDB * 16)), 16, (int)pb_goff0,
+                                                             (int)kgbase + i * pb_gstride, 0, 0);
+                if (++b_tap == 9) { b_tap = 0; b_ch += BK; }
+                sb ^= 1;
+            };
+            if (lw < 3) {
+                // table entry e = [wave w][l15][row block i] <-> tile row 32 w + 16 i + l15; this lane's entry: e = t (waves 0, 1)
+                const int te = t & 127, trow = (te >> 5) * 32 + (te & 1) * 16 + ((te >> 1) & 15);
+                unsigned tmask = 0;                                      // bit tp: tap tp of this row's pixel lies inside the image
+                if (lw < 2) {
+                    const int m = m0 + trow;
+                    if (m < p.M) {
+                        const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+#pragma unroll
+                        for (int tp = 0; tp < 9; ++tp) {
+                            const int hi = ho + (tp / 3 - 1) * d, wi = wo + (tp % 3 - 1) * d;
+                            if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) tmask |= 1u << tp;
+                        }
+                    }
+                }
+                int wt = 0, wr = 0, ws = 0, tb_st = 0;                   // tap, ring position, index and table stage of the step whose table is written next
+                auto write_table = [&]() {
+                    unsigned u = (unsigned)(wr + trow);
+                    u = u < u - (unsigned)HALO_C ? u : u - (unsigned)HALO_C;                  // min_u32(u, u - C): ring wrap
+                    const unsigned a = (u << 5) + (u >> 3) * 768u;                            // (u >> 3) 1024 + (u & 7) 32
+                    *reinterpret_cast<unsigned*>(smem + HALO_TBL + tb_st * 512 + te * 4) = ((tmask >> wt) & 1u) ? a : (unsigned)HALO_ZERO;
+                    const int dl = wt == 8 ? d_ch : ((wt == 2 || wt == 5) ? d_kh : d);
+                    wr += dl;
+                    wr = wr >= HALO_C ? wr - HALO_C : wr;
+                    wt = wt == 8 ? 0 : wt + 1;
+                    tb_st = tb_st == 2 ? 0 : tb_st + 1;
+                    ++ws;
+                };
+                if (lw < 2) { write_table(); if (nks > 1) write_table(); }                    // steps 0 and 1, before barrier #0
+                for (int it = -1; it < nks; ++it) {
+                    if (it + 1 < nks) issue_cells();                     // step it + 1
+                    if (lw < 2 && it >= 0 && ws < nks) write_table();    // step it + 2: read by the compute waves behind barrier it + 1
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                return;
+            }
+            // ---- wave 3: the ring
+            const int total_g = DGP_RFL((p.Cin >> 5) * GS);
+            const int q0 = m0 - d * (Wd + 1);                            // input pixel of strip position 0 (may be negative: out of range -> zeros)
+            // this lane's cell of an 8-pixel group: lane = (b2 << 5) | (b0 << 4) | (q << 1) | b1 fetches chunk (b2 b1 b0) of pixel q
+            const int lq = (lane >> 1) & 7, lch = ((lane >> 5) << 2) | ((lane & 1) << 1) | ((lane >> 4) & 1);
+            const unsigned a_lane = (unsigned)(lq * p.Cin * 4 + lch * 16);
+            int G = 0, g_c = 0, g_j = 0, Gr = 0;                         // next stream group, its chunk, its index inside the chunk, its ring group
+            auto issue_group = [&]() {
+                const unsigned voff = (unsigned)((q0 + 8 * g_j) * p.Cin * 4 + g_c * 128) + a_lane;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(smem + Gr * 1024), 16, (int)voff, 0, 0, 0);
+                ++G;
+                if (++g_j == GS) { g_j = 0; ++g_c; }
+                if (++Gr == HALO_C / 8) Gr = 0;
+            };
+            // lo(s) of steps it, it + 1, it + 2 (negative steps count as step 0, steps past the end as the last one) as a three-deep queue
+            // fed by the tap deltas -- no divisions in the loop; the smooth pacing target advances by ~S8 / 9 pixels per step
+            const int pace = DGP_RFL((S8 * 7282 + 65535) >> 16);
+            int l0 = 0, l1 = 0, l2 = 0, wl = 0, wt = 0, ws = 0;          // queue; walker: lo, tap and index of the newest step generated
+            int smooth = 4 * pace;
+#ifdef DGP_DIAG
+            unsigned long long h0, h1, h2, h3, hs_is = 0, hs_wt = 0, hs_ba = 0;
+#endif
+            for (int it = -2; it < nks; ++it) {
+                DIAG_STAMP(h0);
+                if (it + 1 >= 0 && it + 1 < nks) issue_cells();          // weight cells of step it + 1 first
+                if (it > -2) {                                           // ring bookkeeping
+                    if (ws + 1 < nks) {
+                        wl += wt == 8 ? d_ch : ((wt == 2 || wt == 5) ? d_kh : d);
+                        wt = wt == 8 ? 0 : wt + 1;
+                        ++ws;
+                    }
+                    l0 = l1; l1 = l2; l2 = wl;
+                }
+                const int alw_g = (l0 + HALO_C) >> 3;                    // every pixel below lo(it) is dead (see above)
+                int tgt = l2 + 128;                                      // hi(it + 2)
+                smooth += pace;
+                if (smooth > tgt) tgt = smooth;
+                int end_g = (tgt + 7) >> 3;
+                end_g = end_g < alw_g ? end_g : alw_g;
+                end_g = end_g < total_g ? end_g : total_g;
+                const int need_g = (it + 1 >= 0 && it + 1 < nks) ? (l1 + 128 + 7) >> 3 : 0;      // must have landed at barrier it + 1
+                while (G < end_g && G < need_g) issue_group();           // (normally empty: issued as lookahead earlier)
+                int n_far = end_g - G;
+                n_far = n_far < 0 ? 0 : n_far;
+                while (G < end_g) issue_group();
+                DIAG_STAMP(h1);
+                if (it >= -1) {
+                    switch (n_far) {                                     // everything but this iteration's lookahead pieces has landed
+                        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                    }
+                    DIAG_STAMP(h2);
+                    __builtin_amdgcn_s_barrier();
+                    DIAG_STAMP(h3);
+#ifdef DGP_DIAG
+                    if (it >= 0) { hs_is += h1 - h0; hs_wt += h2 - h1; hs_ba += h3 - h2; }
+#endif
+                }
+            }
+#ifdef DGP_DIAG
+            if (p.dbg && lane == 0) {
+                unsigned long long* dd = p.dbg + 10ull * blockIdx.x;
+                dd[3] = hs_wt; dd[5] = hs_is; dd[6] = hs_ba;
+            }
+#endif
+            return;
+        }
         if constexpr (DMA) {
             typedef __attribute__((address_space(3))) void lds_void;
             const int lw = wave - CW;                                    // loader wave 0..3: rows 8 lw + 32 i of instruction i
@@ -1449,6 +1614,9 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK
     unsigned long long e0, e1, e2, e3, acc_mf = 0, acc_ba = 0;
     DIAG_STAMP(e0);
 #endif
+    if constexpr (MODE == 3) {        // the zero cells masked taps read (before barrier #0)
+        if (threadIdx.x < 64) *reinterpret_cast<uint4*>(smem + HALO_ZERO + 16 * threadIdx.x) = make_uint4(0u, 0u, 0u, 0u);
+    }
     __syncthreads();
 #ifdef DGP_DIAG
     DIAG_STAMP(e1);
@@ -1463,7 +1631,94 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK
 #endif
     static_assert(!DMA || (TM == 1 && (TN == 4 || TN == 2)), "DMA image is read by the pipelined loop only");
     static_assert(!(DMA && AH2) || M16, "pre-split A + DMA image: 16x16x32 loop only");
-    if constexpr (M16) {
+    if constexpr (MODE == 3) {
+        // The 16x16x32 loop of the branch below on the pixel ring: same fragment ring, same barrier placement; the A cells of the NEXT
+        // step come from the loaders' address table (one ds_read_b64 behind the previous barrier + this lane's k-group constant).
+        typedef float floatx4 __attribute__((ext_vector_type(4)));
+        const int l15 = lane & 15, g = lane >> 4;
+        constexpr int NJ = 8, NF = 16;
+        floatx4 c[2][NJ];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) c[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        const unsigned lane_c = (unsigned)((g >> 1) * 512 + (g & 1) * 16);       // k-group g: chunk 2 g = (b2 b1 0) -> cell (b2 0 | q | b1)
+        const char* tbl = smem + HALO_TBL + (wave * 32 + l15 * 2) * 4;           // this lane's two entries of a table stage
+        int tst = 0;                                                             // stage of the table to read next
+        u32x2 tq;
+        unsigned a_adr[2];
+        const uint4* B = sB + wave_n0 + l15 + g * LDB;
+        int db = B_CELLS;
+        uint4 ra[2][2], ah[2], al[2], bq[4];
+        auto mma = [](const uint4& x, const uint4& y, floatx4 cc) {
+            return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), cc, 0, 0, 0);
+        };
+        // (barrier #0 above: step 0's pixels and cells have landed, the zero cells and the tables of steps 0 and 1 are written)
+        tq = *reinterpret_cast<const u32x2*>(tbl);
+        a_adr[0] = tq[0] + lane_c; a_adr[1] = tq[1] + lane_c;
+        tq = *reinterpret_cast<const u32x2*>(tbl + 512);
+        tst = 2;                                            // (next: the table of step 2)
+#define DGP_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define DGP_RA(I) do { ra[I][0] = *reinterpret_cast<const uint4*>(smem + a_adr[I]);                                 \
+                       ra[I][1] = *reinterpret_cast<const uint4*>(smem + a_adr[I] + 256); } while (0)
+#define DGP_RB(F) do { bq[(F) & 3] = B[((((F) & 1) ? 0 : 1) * KG) * LDB + 16 * (((F) % NF) >> 1)]; } while (0)
+#define DGP_MM(F) do { constexpr int j_ = (F) >> 1;                                                                \
+        if (((F) & 1) == 0) { c[0][j_] = mma(ah[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(ah[1], bq[(F) & 3], c[1][j_]); }    \
+        else { c[0][j_] = mma(al[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(al[1], bq[(F) & 3], c[1][j_]);         \
+               c[0][j_] = mma(ah[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(ah[1], bq[(F) & 3], c[1][j_]); } } while (0)
+#define DGP_STEP(F) do { DGP_MM(F); DGP_FENCE(); DGP_RB((F) + 4); DGP_FENCE(); } while (0)
+        DGP_RA(0); DGP_RA(1);
+        DGP_RB(0); DGP_RB(1); DGP_RB(2); DGP_RB(3);
+        DGP_FENCE();
+        for (int ks = 0; ks < nks; ++ks) {
+            ah[0] = ra[0][0]; al[0] = ra[0][1]; ah[1] = ra[1][0]; al[1] = ra[1][1];
+            DGP_FENCE();
+            a_adr[0] = tq[0] + lane_c; a_adr[1] = tq[1] + lane_c;      // the next step's A cells (table read behind the previous barrier)
+            DGP_FENCE();
+            DGP_STEP(0); DGP_STEP(1); DGP_STEP(2); DGP_STEP(3);
+            DGP_STEP(4); DGP_STEP(5);
+            DGP_STEP(6); DGP_STEP(7); DGP_STEP(8); DGP_STEP(9); DGP_STEP(10); DGP_STEP(11);
+            DGP_MM(12); DGP_FENCE();
+            DGP_MM(13); DGP_FENCE();
+            DIAG_STAMP(e2);
+            __syncthreads();
+            DIAG_STAMP(e3);
+#ifdef DGP_DIAG
+            acc_mf += e2 - e1; acc_ba += e3 - e2; e1 = e3;
+#endif
+            B += db; db = -db;
+            const bool more = ks + 1 < nks;
+            if (more) {
+                DGP_RA(0); DGP_RA(1); DGP_RB(0); DGP_RB(1);
+                tq = *reinterpret_cast<const u32x2*>(tbl + tst * 512);      // table of step ks + 2 (written before this barrier)
+                tst = tst == 2 ? 0 : tst + 1;
+            }
+            DGP_FENCE();
+            DGP_MM(14); DGP_FENCE();
+            if (more) DGP_RB(2);
+            DGP_FENCE();
+            DGP_MM(15); DGP_FENCE();
+            if (more) DGP_RB(3);
+            DGP_FENCE();
+        }
+#undef DGP_FENCE
+#undef DGP_RA
+#undef DGP_RB
+#undef DGP_MM
+#undef DGP_STEP
+        {
+            constexpr int LDCW = WN + 4;
+            float* sCw = reinterpret_cast<float*>(smem) + wave * (32 * LDCW);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sCw[(16 * i + 4 * g + r) * LDCW + 16 * j + l15] = c[i][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    } else if constexpr (M16) {
         // One K-step = one MFMA depth (32).  Per step a wave splits its 2 x 16 rows (A: two fp32 chunks per lane and row block ->
         // a_hi / a_lo), and walks 16 B fragments f = (column block j = f / 2, plane: low first) through a ring of four register
         // quads, three fragments ahead of the MFMAs: low plane -> a_hi b_lo for both row blocks, high plane -> a_lo b_hi, a_hi b_hi.
@@ -1957,6 +2212,14 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     const int mode = (pointwise && (unsigned long long)a.M * (a.in2 ? a.cin_split : a.Cin) * 4ull == a.in_bytes &&
                       (!a.in2 || (unsigned long long)a.M * (a.Cin - a.cin_split) * 4ull == a.in2_bytes) && a.in_bytes < 4200000000u)
                          ? 2 : ((a.up || a.in2 || a.stem) ? 0 : 1);
+    // halo walk (MODE 3, see the kernel): 3x3 / stride 1 convs of the H2 engine on 128 x 128 tiles whose tap shifts fit the pixel ring.
+    // A/B switch DGP_HALO=0
+    static const int halo_env = getenv("DGP_HALO") ? atoi(getenv("DGP_HALO")) : 1;
+    const bool halo = halo_env && BM == 128 && BN == 128 && CW == 4 && NT == 2 && BK == 32 && mode == 1 && a.in_fmt && a.out_fmt && a.wh3 && !a.hi_only &&
+                      a.KH == 3 && a.KW == 3 && a.ntaps == 9 && a.stride == 1 && a.dil >= 1 && a.pad_t == a.dil && a.pad_l == a.dil && a.H == a.Ho &&
+                      a.W == a.Wo && a.W >= 2 && (a.Cin % 32) == 0 && a.nk * 32 == 9 * a.Cin && a.tap_rows == (a.Cin >> 2) && !a.in_scale_dev &&
+                      (unsigned long long)a.M * a.Cin * 4ull == a.in_bytes && a.in_bytes < 4000000000u &&
+                      a.dil * (a.W - 2) + 128 <= HALO_C - 8 && (unsigned long long)a.dil * (a.W + 1) * a.Cin * 4ull < 200000000ull;
     constexpr bool CAN_PB = NT == 2 && CW == 4;
     if (!(CAN_PB && a.wh3)) a.wh3 = nullptr;
     auto kern = conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 0>;
@@ -1977,7 +2240,7 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     // deep DMA ring (see the kernel) for grids of at most one tile per CU; A/B switch DGP_DEEP_RING=0, =2: every DMA launch
     constexpr bool CAN_DEEP = CAN_DMA && BN == 128;
     static const int deep_env = getenv("DGP_DEEP_RING") ? atoi(getenv("DGP_DEEP_RING")) : 1;
-    bool deep = false;
+    bool deep = false, use_halo = false;
     if (dma) {
         kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 2, CAN_DMA, CAN_DMA>
                          : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 1, CAN_DMA, CAN_DMA>;
@@ -2003,6 +2266,14 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
                         kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 2, CAN_DMA, CAN_DMA, CAN_DMA, CAN_DMA>
                                          : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 1, CAN_DMA, CAN_DMA, CAN_DMA, CAN_DMA>;
                     if constexpr (CAN_DEEP) {
+                        if (halo && !deep) {
+                            kern = conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, CAN_DEEP ? 3 : 1, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP>;
+                            smem = (size_t)HALO_B0 + 2 * (size_t)(NP * KG * BN) * 16;
+                            if (smem < smem_epi) smem = smem_epi;
+                            use_halo = true;
+                        }
+                    }
+                    if constexpr (CAN_DEEP) {
                         if (deep) kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, 2, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP>
                                                    : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, 1, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP>;
                         else if (a.hi_only)       // 16-bit tier (128-column tiles; the 64-column layers keep three products)
@@ -2023,13 +2294,14 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
             }
         }
     } else if (a.out_fmt) return hipErrorInvalidValue;
-    static bool attr_done_dev[16][3][6][3] = {};
+    static bool attr_done_dev[16][3][6][4] = {};
     auto& attr_done = attr_done_dev[dgp_device_slot()];
-    if (!attr_done[a.in_fmt ? (a.out_fmt ? 2 : 1) : 0][(a.hi_only && dma && a.in_fmt && a.out_fmt && BN == 128 && !deep) ? 5 : deep ? 4 : dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode]) {
+    const int mode_slot = use_halo ? 3 : mode;
+    if (!attr_done[a.in_fmt ? (a.out_fmt ? 2 : 1) : 0][(a.hi_only && dma && a.in_fmt && a.out_fmt && BN == 128 && !deep) ? 5 : deep ? 4 : dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode_slot]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_done[a.in_fmt ? (a.out_fmt ? 2 : 1) : 0][(a.hi_only && dma && a.in_fmt && a.out_fmt && BN == 128 && !deep) ? 5 : deep ? 4 : dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode] = true;
+        attr_done[a.in_fmt ? (a.out_fmt ? 2 : 1) : 0][(a.hi_only && dma && a.in_fmt && a.out_fmt && BN == 128 && !deep) ? 5 : deep ? 4 : dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode_slot] = true;
     }
     long long nwg = (long long)a.mtiles * a.ntiles;
     // Grid tail: with `slots` workgroups resident, the last tiles % slots tiles run on a mostly idle chip.  Split their K range
@@ -2038,7 +2310,7 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     static const int tail_env = getenv("DGP_TAIL_SPLIT") ? atoi(getenv("DGP_TAIL_SPLIT")) : 1;      // A/B switch
     // (H2 tensors: with the split gone from the K loop the K-split of the tail + its fix-up launch no longer pays -- same-box A/B,
     //  block3 conv1 -7..-24 %, block4 conv1 -12 %, block4 conv2 -5 % without it, +2.5 % end to end -- so tail_env == 2 is needed to force it)
-    if (tail_env && (!a.in_fmt || tail_env == 2) && a.slab && CW == 4 && BN == 128) {      // (128 x 64 tiles fit three per CU and gain nothing)
+    if (tail_env && (!a.in_fmt || tail_env == 2) && a.slab && CW == 4 && BN == 128 && !use_halo) {      // (128 x 64 tiles fit three per CU and gain nothing)
         static int n_cu = 0;
         if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
         const long long slots = 2LL * n_cu;            // two workgroups of these kernels fit a CU

@@ -48,6 +48,15 @@ H2_CONV_CASES = [
     (32, 30, 40, 1024, 256, 1, 1, 1, 0, True),     # batch-32 block3 conv1: 600 tiles -> grid-tail K-split + tail_fixup_h2
     (32, 30, 40, 512, 512, 3, 1, 2, 2, True),      # batch-32 block4 conv2 (+ an H2 residual): the deepest K loop at its real size
     (11, 30, 40, 2048, 512, 1, 1, 1, 0, True),     # block4 conv1 at 11 frames: 416 tiles, K = 2048
+    # round 4, the halo walk (MODE 3 of the dominant kernel: 3x3 / stride 1 on a pixel ring in LDS, taps masked by the compute waves)
+    (3, 7, 9, 128, 128, 3, 1, 1, 0, True),         # case12: frames smaller than a tile -- a 128-pixel window spans three frames; ragged last tile
+    (2, 30, 40, 256, 256, 3, 1, 1, 0, True),       # case13: block3 conv2
+    (1, 60, 80, 128, 128, 3, 1, 1, 2, True),       # case14: block2 conv2 (+ an H2 residual)
+    (1, 20, 118, 128, 128, 3, 1, 2, 0, True),      # case15: d (W - 2) + 128 = HALO_C - 8: the widest row the ring takes
+    (1, 9, 200, 128, 128, 3, 1, 2, 0, True),       # case16: wider than that -> the per-tap loaders (MODE 1)
+    (1, 45, 80, 512, 512, 3, 1, 2, 0, True),       # case17: block4 conv2 of the 1280 x 720 network
+    (2, 5, 2, 128, 128, 3, 1, 1, 0, True),         # case18: two pixels per row (every tap but the centre column masked somewhere)
+    (1, 33, 47, 128, 256, 3, 1, 3, 0, True),       # case19: dilation 3, odd sizes
 ]
 
 
@@ -229,6 +238,18 @@ def test_tail_split_fixup_on_h2_tensors_in_a_child_process(lib_built):
                         "test_conv_on_h2_tensors_matches_float64 and (case9 or case5)"], env=env, cwd=root, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
+
+
+def test_per_tap_loaders_of_the_3x3_layers_in_a_child_process(lib_built):
+    """DGP_HALO=0: the 3x3 / stride-1 layers on the per-tap LDS-DMA loaders (MODE 1) they used before the halo walk became the
+    default -- still the path of rows too wide for the pixel ring, of the 16-bit tier and of the A/B switch."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DGP_HALO="0", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_h2_gpu.py"), "-q", "-m", "gpu", "-k",
+                        "test_conv_on_h2_tensors_matches_float64 and (case4 or case5 or case12 or case13 or case19)"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "5 passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
 
 
 def test_tall_tile_on_every_shape_it_can_take_in_a_child_process(lib_built):
