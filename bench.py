@@ -217,7 +217,9 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --steps batches per GPU; strong: --total-batches batches in all, rank r runs its contiguous share")
     ap.add_argument("--total-batches", type=int, default=1024, help="strong scaling: batches of the one fixed stream (1024 x 32 = 32768 frames)")
-    ap.add_argument("--no-strict-f32", action="store_true", help="skip the DGP_CONV_MODE=f32 child run (IEEE fp32 MFMA tier) after the timed region")
+    ap.add_argument("--no-strict-f32", action="store_true", help="skip the child-process legs after the timed region: DGP_CONV_MODE=f32 (IEEE fp32 MFMA tier), the 16-bit tier and the training step")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the training-step child run (BASELINE configs[3]) after the timed region")
+    ap.add_argument("--train-steps", type=int, default=30, help="timed steps of the training-step child run")
     ap.add_argument("--strict-f32-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.strict_f32_child:
@@ -354,14 +356,16 @@ def main():
     range_overflow, n_calib = pipe.range_status()         # a forward that outgrew the calibrated activation scales would be invalid
     assert not range_overflow, "activation ranges outgrew the calibrated scales during the run"
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    elapsed_min = elapsed.clone()
     if use_pg:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
+        dist.all_reduce(elapsed_min, op=dist.ReduceOp.MIN)
+    elapsed, elapsed_min = float(elapsed.item()), float(elapsed_min.item())
     assert full.shape[0] == world * n_local
-    # every rank ran the same ring: global batch g must reproduce batch g % RING (computed by rank 0 when K >= RING) bit for bit --
+    # every rank ran the same ring: global batch g must reproduce batch g % RING (its first occurrence: rank 0's when K >= RING) bit for bit --
     # the gathered N-rank trajectory equals what one rank computes for the same frames
     shard_check = None
-    if K >= RING:
+    if world * K > RING:
         fb = full.view(world * K, B, NJ, 5)
         same = all(torch.equal(fb[gb], fb[gb % RING]) for gb in range(RING, world * K))
         same_idx = all(torch.equal(fb[gb][..., 3:], fb[gb % RING][..., 3:]) for gb in range(RING, world * K))
@@ -481,6 +485,9 @@ def main():
         "streams": {"n": len(pipe.nets), "note": "batches are dealt in turn to n engines on n HIP streams (engine.DGPPipeline); the "
                     "`steps_profiled` instrumented steps run alone on one stream, the other timed steps overlap pairwise"},
         "range_overflow": bool(range_overflow),
+        # imbalance between the ranks: `value` divides by the slowest rank's time (both include the barriers and the all-gather)
+        "rank_elapsed_s": {"max": round(elapsed, 6), "min": round(elapsed_min, 6), "imbalance": round(elapsed / max(elapsed_min, 1e-12) - 1.0, 4)},
+        "frames_per_s": round(fps, 2),
         "activation_format": "H2 (fp16 high/low cells, calibrated per-tensor scales; include/dgp_hip.h)" if n_calib else "fp32",
     }
 
@@ -557,6 +564,30 @@ def main():
                 out[key] = json.loads(ln[-1]) if cp.returncode == 0 and ln else {"error": (cp.stderr or cp.stdout)[-300:]}
             except Exception as e:      # noqa: BLE001 -- the main line must still be printed
                 out[key] = {"error": repr(e)[:300]}
+    if world == 1 and not args.no_train_step and not args.no_strict_f32:
+        # BASELINE configs[3] next to the headline number, driver-timed: the semi-supervised fit_dgp step (1 labeled + 10 unlabeled 640 x 480
+        # frames, gm2 = 1, gm3 = 3, skeleton clique; forward + loss + backward + clip + momentum) -- the call that replaces
+        # sess.run([loss, train_op]) (DGP/models/fitdgp.py:801-818) -- in a fresh child process (scripts/bench_train.py), never a re-exec
+        import subprocess
+        env = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "DGP_CONV_MODE"):
+            env.pop(k, None)
+        try:
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_train.py"), str(args.train_steps)], env=env, capture_output=True,
+                                text=True, timeout=600)
+            ln = [q for q in cp.stdout.splitlines() if q.startswith("{")]
+            if cp.returncode == 0 and ln:
+                t = json.loads(ln[-1])
+                out["train_step"] = {"ms_per_step": t["ms_per_step"], "steps": args.train_steps, "frames_per_step": t["nt"], "frames_per_s": t["frames_per_s"],
+                                     "frac": t["roofline"]["frac"], "achieved_tflops": t["roofline"]["achieved"], "peak_tflops": t["roofline"]["peak"],
+                                     "algorithmic_gflop_per_step": t["roofline"]["algorithmic_gflop_per_step"], "loss": t["loss"],
+                                     "workload": "BASELINE configs[3]: fit_dgp step, ResNet-50 640x480, 1 labeled + 10 unlabeled frames, 4 keypoints, "
+                                                 "fp32-class arithmetic (not bf16), 2 warm-up steps then `steps` timed ones",
+                                     "frac_basis": "3 x forward conv FLOPs (forward + data-gradient + weight-gradient convolutions) / step time / (2500 / 3 TFLOP/s)"}
+            else:
+                out["train_step"] = {"error": (cp.stderr or cp.stdout)[-300:]}
+        except Exception as e:      # noqa: BLE001 -- the main line must still be printed
+            out["train_step"] = {"error": repr(e)[:300]}
     print(json.dumps(out), flush=True)
     if use_pg:
         dist.destroy_process_group()

@@ -39,6 +39,7 @@ class DgpConvDesc(C.Structure):
 _vp, _i32, _f32, _sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
 SYMBOLS = {
     "dgp_version": (C.c_int, []),
+    "dgp_tuning_build": (C.c_int, []),
     "dgp_crc32c": (C.c_uint32, [C.c_void_p, C.c_size_t, C.c_uint32]),
     "dgp_last_error": (C.c_char_p, []),
     "dgp_net_create": (C.c_int, [C.POINTER(DgpNetDesc), C.POINTER(_vp)]),

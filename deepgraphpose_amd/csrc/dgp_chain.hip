@@ -601,12 +601,12 @@ hipError_t launch_chain_t(const ChainArgs& a0, hipStream_t s) {
         int occ = 0;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * (NCW + NLW), LDS);
         if (e != hipSuccess) return e;
-        static const int force = getenv("DGP_CHAIN_WGS") ? atoi(getenv("DGP_CHAIN_WGS")) : 0;      // tuning: resident workgroups per CU
+        static const int force = dgp_tune("DGP_CHAIN_WGS", 0);      // tuning: resident workgroups per CU
         wgs_per_cu[dev] = force > 0 ? force : (occ < 1 ? 1 : occ);
         attr_done[dev] = true;
     }
     ChainArgs a = a0;
-    static const int nt_env = getenv("DGP_CHAIN_NT") ? atoi(getenv("DGP_CHAIN_NT")) : 0;      // bit 0: residual loads, bit 1: X' stores non-temporal
+    static const int nt_env = dgp_tune("DGP_CHAIN_NT", 0);      // bit 0: residual loads, bit 1: X' stores non-temporal
     a.nt = nt_env;
     constexpr int TILE = 16 * RB * NCW;
     a.ntiles = (a.M + TILE - 1) / TILE;
@@ -634,12 +634,12 @@ hipError_t launch_unit_t(const ChainArgs& a0, int N, hipStream_t s) {
         int occ = 0;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * (NCW + NLW), LDS);
         if (e != hipSuccess) return e;
-        static const int force = getenv("DGP_CHAIN_WGS") ? atoi(getenv("DGP_CHAIN_WGS")) : 0;
+        static const int force = dgp_tune("DGP_CHAIN_WGS", 0);
         wgs_per_cu[dev] = force > 0 ? force : (occ < 1 ? 1 : occ);
         attr_done[dev] = true;
     }
     ChainArgs a = a0;
-    static const int nt_env = getenv("DGP_CHAIN_NT") ? atoi(getenv("DGP_CHAIN_NT")) : 0;
+    static const int nt_env = dgp_tune("DGP_CHAIN_NT", 0);
     a.nt = nt_env;
     a.TY = (a.H + NCW - 1) / NCW; a.TX = (a.W + 15) / 16;
     a.ntiles = N * a.TY * a.TX;
@@ -669,7 +669,7 @@ bool unit_supported(int C, int C1, int CIN2, int res) {
 }
 
 hipError_t launch_unit(const ChainArgs& a, int N, int C, int C1, int CIN2, int res, hipStream_t s) {
-    static const int cfg = getenv("DGP_UNIT_CFG") ? atoi(getenv("DGP_UNIT_CFG")) : 0;      // tuning: tile rows / loader waves
+    static const int cfg = dgp_tune("DGP_UNIT_CFG", 0);      // tuning: tile rows / loader waves
     if (C == 64 && C1 == 64 && CIN2 == 0 && res == 1) {
         // (measured on the batch-32 640x480 shape, ms per launch: 8 rows + 2 loader waves 0.41-0.42; 10 rows 0.42-0.43; 8 rows + 4 loader
         //  waves 0.42-0.43 -- the weight stream is not the pace; 4 rows + 1 loader, two workgroups per CU 0.56-0.67: 4.5 KB of weight
@@ -696,7 +696,7 @@ const char* chain_kernel_name(int C, int C1, int CIN2, int res) {
 }
 
 hipError_t launch_chain(const ChainArgs& a, int C, int C1, int CIN2, int res, hipStream_t s) {
-    static const int cfg = getenv("DGP_CHAIN_CFG") ? atoi(getenv("DGP_CHAIN_CFG")) : 0;      // tuning: alternative workgroup shapes
+    static const int cfg = dgp_tune("DGP_CHAIN_CFG", 0);      // tuning: alternative workgroup shapes
     //                                                                        C   C1  CIN2 RES RB NCW NLW PD
     if (C == 64 && C1 == 64 && CIN2 == 0 && res == 1) {
         if (cfg == 1) return launch_chain_t<64, 64, 0, 1, 2, 5, 1, 4>(a, s);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 namespace dgp {
 
@@ -187,6 +188,26 @@ hipError_t launch_unit(const ChainArgs& a, int N, int C, int C1, int CIN2, int r
 // fp32 fragments -> fp16 high / low fragment pairs.  src per chunk: (f1_pairs + f2_pairs) x [64 lanes][8 floats], then the affine
 // fragment [64 floats... 256 floats]; out per chunk: 2 (f1_pairs + f2_pairs) + 1 KiB-fragments
 hipError_t launch_chain_pack(const float* src, int n_chunks, int f1_pairs, int f2_pairs, float s1, float s2, void* out, hipStream_t s);
+
+// Run-time switches of the native code, two classes (README "Switches"):
+//  * dgp_env(): the shipped ones -- the precision tiers (DGP_CONV_MODE, DGP_H2) and the A/B switches between paths that all ship
+//    and that the tests exercise (<= 20 in all); read from the environment once per process;
+//  * dgp_tune(): knobs of measured-and-settled choices and the opt-ins that measured SLOWER (the 256-row tile DGP_TALL, the C = 256
+//    chain instance DGP_CHAIN_WIDE, the trainer's fast pass, the non-pipelined weight-gradient tile).  The product binary compiles
+//    the default in; they read the environment only in a tuning build (DGP_BUILD_FLAGS=-DDGP_TUNING python -m deepgraphpose_amd.build),
+//    which is also the only build that carries the kernels behind the opt-ins.
+inline int dgp_env(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+inline int dgp_tune(const char* name, int dflt) {
+#ifdef DGP_TUNING
+    return dgp_env(name, dflt);
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 
 // hipFuncSetAttribute applies to the CURRENT device: the "done once" flags of the launchers are kept per device
 inline int dgp_device_slot() { int d = 0; (void)hipGetDevice(&d); return d & 15; }

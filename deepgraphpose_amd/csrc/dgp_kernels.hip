@@ -2194,9 +2194,9 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     // launch against 393 MB of operands on block4's conv3.  Measured (same box, ms per launch, nt 0 / 2): block3 conv3 0.105 -> 0.088,
     // the conv1 that re-reads the tensor 0.070 -> 0.076, block4 conv3 0.268 -> 0.253; everywhere (1) loses: a small output written nt
     // (R2: 39 MB) is no longer cache-resident for its consumer
-    static const int epi_nt_env = getenv("DGP_EPI_NT") ? atoi(getenv("DGP_EPI_NT")) : 2;
+    static const int epi_nt_env = dgp_env("DGP_EPI_NT", 2);
     a.epi_nt = epi_nt_env == 1 ? 3 : (a.CoutP / BN >= 8 ? (epi_nt_env == 2 ? 3 : epi_nt_env == 3 ? 1 : epi_nt_env == 4 ? 2 : 0) : 0);   // bit 0: loads, bit 1: stores
-    static const int tap_minor = getenv("DGP_TAP_MINOR") ? atoi(getenv("DGP_TAP_MINOR")) : 1;
+    static const int tap_minor = dgp_tune("DGP_TAP_MINOR", 1);
     a.tap_minor = (tap_minor && !a.stem && a.ntaps > 1 && a.nk * 32 == a.ntaps * a.Cin) ? 1 : 0;
     const size_t smem_loop = (size_t)2 * (NP * KG * (BM + (BK == 32 ? 4 : 8)) + NP * KG * (BN + 4)) * 16;
     const size_t smem_epi = (size_t)CW * 32 * (BN + 4) * 4;        // (upper bound: 4 x 1 compute-wave layout of the CS kernels)
@@ -2214,7 +2214,7 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
                          ? 2 : ((a.up || a.in2 || a.stem) ? 0 : 1);
     // halo walk (MODE 3, see the kernel): 3x3 / stride 1 convs of the H2 engine on 128 x 128 tiles whose tap shifts fit the pixel ring.
     // A/B switch DGP_HALO=0
-    static const int halo_env = getenv("DGP_HALO") ? atoi(getenv("DGP_HALO")) : 1;
+    static const int halo_env = dgp_env("DGP_HALO", 1);
     const bool halo = halo_env && BM == 128 && BN == 128 && CW == 4 && NT == 2 && BK == 32 && mode == 1 && a.in_fmt && a.out_fmt && a.wh3 && !a.hi_only &&
                       a.KH == 3 && a.KW == 3 && a.ntaps == 9 && a.stride == 1 && a.dil >= 1 && a.pad_t == a.dil && a.pad_l == a.dil && a.H == a.Ho &&
                       a.W == a.Wo && a.W >= 2 && (a.Cin % 32) == 0 && a.nk * 32 == 9 * a.Cin && a.tap_rows == (a.Cin >> 2) && !a.in_scale_dev &&
@@ -2227,7 +2227,7 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
                     : mode == 1 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_PB, 1> : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_PB, 0>;
     constexpr bool CAN_CS = CAN_PB && BK == 32;
     // 2 (default): every fp16 kernel with pre-split weights; 1: 128 x 128 tiles only; 0: loaders split (A/B switch)
-    static const int cs_env = getenv("DGP_COMPUTE_SPLIT") ? atoi(getenv("DGP_COMPUTE_SPLIT")) : 2;
+    static const int cs_env = dgp_env("DGP_COMPUTE_SPLIT", 2);
     const bool cs = CAN_CS && a.wh3 && (cs_env >= 2 || (cs_env == 1 && BN == 128));
     if (cs) kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 2, CAN_CS>
                  : mode == 1 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 1, CAN_CS> : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 0, CAN_CS>;
@@ -2235,11 +2235,11 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
               : mode == 1 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 1> : conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 0>;
     // LDS-DMA loaders (A/B switch DGP_DMA=0): 128 x 128 CS kernels with the plain or the pointwise walk
     constexpr bool CAN_DMA = CAN_CS && BM == 128 && (BN == 128 || BN == 64);
-    static const int dma_env = getenv("DGP_DMA") ? atoi(getenv("DGP_DMA")) : 1;
+    static const int dma_env = dgp_env("DGP_DMA", 1);
     const bool dma = CAN_DMA && cs && mode != 0 && dma_env;
     // deep DMA ring (see the kernel) for grids of at most one tile per CU; A/B switch DGP_DEEP_RING=0, =2: every DMA launch
     constexpr bool CAN_DEEP = CAN_DMA && BN == 128;
-    static const int deep_env = getenv("DGP_DEEP_RING") ? atoi(getenv("DGP_DEEP_RING")) : 1;
+    static const int deep_env = dgp_tune("DGP_DEEP_RING", 1);
     bool deep = false, use_halo = false;
     if (dma) {
         kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 2, CAN_DMA, CAN_DMA>
@@ -2307,7 +2307,7 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     // Grid tail: with `slots` workgroups resident, the last tiles % slots tiles run on a mostly idle chip.  Split their K range
     // over up to 4 blocks each (raw slabs + a fixup pass that sums them in fixed order: deterministic) so the last round is full.
     a.tail_ksplit = 0; a.n_main = (int)nwg;
-    static const int tail_env = getenv("DGP_TAIL_SPLIT") ? atoi(getenv("DGP_TAIL_SPLIT")) : 1;      // A/B switch
+    static const int tail_env = dgp_env("DGP_TAIL_SPLIT", 1);      // A/B switch
     // (H2 tensors: with the split gone from the K loop the K-split of the tail + its fix-up launch no longer pays -- same-box A/B,
     //  block3 conv1 -7..-24 %, block4 conv1 -12 %, block4 conv2 -5 % without it, +2.5 % end to end -- so tail_env == 2 is needed to force it)
     if (tail_env && (!a.in_fmt || tail_env == 2) && a.slab && CW == 4 && BN == 128 && !use_halo) {      // (128 x 64 tiles fit three per CU and gain nothing)
@@ -2338,7 +2338,7 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     // supertile order (see the kernel): H2 engine, 128-wide tiles, >= 8 column tiles and a weight panel that cannot stay in an XCD's L2
     a.st_gn = 0;
     {
-        static const int st_env = getenv("DGP_SUPERTILE") ? atoi(getenv("DGP_SUPERTILE")) : 1;       // A/B switch; > 1: force the row-chunk size
+        static const int st_env = dgp_tune("DGP_SUPERTILE", 1);       // A/B switch; > 1: force the row-chunk size
         const long long panel_bytes = (long long)a.nk * 32 * a.CoutP * 4;
         if (st_env && a.in_fmt && a.out_fmt && a.tail_ksplit <= 1 && BN == 128 && a.ntiles >= 8 && panel_bytes > (3LL << 20) && a.mtiles >= 64) {
             const long long per_ntile = (long long)a.nk * 32 * BN * 4;
@@ -2381,18 +2381,27 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
 
 // The 256 x 128 tile of the H2 engine (see conv_igemm_split_ls): deep-K layers only.
 static bool conv_tall_eligible(const ConvArgs& a) {
-    static const int tall_env = getenv("DGP_TALL") ? atoi(getenv("DGP_TALL")) : 0;              // opt-in (measured slower, see the kernel)
-    static const int min_nk = getenv("DGP_TALL_MINK") ? atoi(getenv("DGP_TALL_MINK")) : 48;      // K-steps from which the epilogue is small change
+#ifndef DGP_TUNING
+    (void)a;
+    return false;                                   // (the 256-row instances are compiled into tuning builds only)
+#else
+    static const int tall_env = dgp_tune("DGP_TALL", 0);              // opt-in (measured slower, see the kernel)
+    static const int min_nk = dgp_tune("DGP_TALL_MINK", 48);      // K-steps from which the epilogue is small change
     if (!tall_env || !a.in_fmt || !a.out_fmt || !a.wh3 || a.hi_only || a.in2 || a.up || a.stem || a.mask || a.out_mode != 0) return false;
     if (a.CoutP % 128 != 0 || (a.Cout % 8) || (a.Cin % 32)) return false;
     if (tall_env == 2) return true;                // (tests: every shape the kernel can take)
     const long long tiles = (long long)((a.M + 255) / 256) * (a.CoutP / 128);
     return a.nk >= min_nk && tiles >= 512;         // long K loops, at least two rounds of one workgroup per CU
+#endif
 }
 
 static hipError_t launch_conv_tall(ConvArgs a, hipStream_t s) {
+#ifndef DGP_TUNING
+    (void)a; (void)s;
+    return hipErrorInvalidValue;
+#else
     constexpr int BM = 256, BN = 128, NT = 2, BK = 32, CW = 8, NP = 2, KG = 4;
-    static const int tap_minor = getenv("DGP_TAP_MINOR") ? atoi(getenv("DGP_TAP_MINOR")) : 1;
+    static const int tap_minor = dgp_tune("DGP_TAP_MINOR", 1);
     a.tap_minor = (tap_minor && a.ntaps > 1 && a.nk * 32 == a.ntaps * a.Cin) ? 1 : 0;
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = a.CoutP / BN;
@@ -2415,6 +2424,7 @@ static hipError_t launch_conv_tall(ConvArgs a, hipStream_t s) {
     a.n_main = a.mtiles * a.ntiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(64 * (CW + 4)), smem, s, a);
     return hipGetLastError();
+#endif
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool WIDE>
@@ -2480,7 +2490,7 @@ int pick_tile(int M, int CoutP, int K, bool have_absmax) {
     //         product), bf16-split elsewhere;
     // rule 3 (DGP_CONV_MODE=bf16x6): bf16-split kernels (6 bf16 MFMAs per product, no range requirement);
     // rule 2 (DGP_CONV_MODE=f32): fp32 MFMA everywhere (bitwise fmaf chains)
-    static const int rule = getenv("DGP_TILE_RULE") ? atoi(getenv("DGP_TILE_RULE"))
+    static const int rule = dgp_tune("DGP_TILE_RULE", 0) ? dgp_tune("DGP_TILE_RULE", 0)
                             : !getenv("DGP_CONV_MODE") ? 4
                             : !strcmp(getenv("DGP_CONV_MODE"), "f16") ? 4
                             : !strcmp(getenv("DGP_CONV_MODE"), "f32") ? 2

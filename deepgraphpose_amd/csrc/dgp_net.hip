@@ -192,6 +192,13 @@ uint32_t dgp_crc32c(const void* data, size_t n, uint32_t crc) {
     return ~crc;
 }
 const char* dgp_last_error(void) { return g_err.c_str(); }
+int dgp_tuning_build(void) {
+#ifdef DGP_TUNING
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 int dgp_net_create(const dgp_net_desc* d, dgp_net** out) {
     if (!d || !out) return fail(DGP_ERR_INVALID, "dgp_net_create: null argument");
@@ -456,7 +463,7 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
         const int C = l3.Cin, C1 = l1.Cout;
         // block3 (C = 256): the kernel instance exists and is tested, but with 65-KiB weight chunks per 80 pixels it is paced by the
         // weight stream (0.18 ms per pair against 0.17 layer by layer on the batch-32 shapes): off unless DGP_CHAIN_WIDE=1
-        static const bool wide_env = getenv("DGP_CHAIN_WIDE") && atoi(getenv("DGP_CHAIN_WIDE")) != 0;
+        static const bool wide_env = (dgp_tune("DGP_CHAIN_WIDE", 0) != 0);
         if (C > 128 && !wide_env) continue;
         const ConvLayer& l2 = net->layers[u.c2];
         const bool c2_plain = l2.KH == 3 && l2.stride == 1 && l2.rate == 1 && l2.Cin == C && l2.Cout == C;      // conv2 the unit kernel can take
@@ -597,13 +604,13 @@ int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, in
         a.in_bytes = (unsigned)inb; a.out_bytes = (unsigned)outb; a.res_bytes = (unsigned)resb;
         a.w_bytes = (unsigned)((size_t)l.nk * 8 * l.CoutP * 16);
     }
-    static const bool stem_rows = !(getenv("DGP_STEM_ROWS") && atoi(getenv("DGP_STEM_ROWS")) == 0);        // A/B switch
+    static const bool stem_rows = (dgp_env("DGP_STEM_ROWS", 1) != 0);        // A/B switch
     static const bool f32_mode = getenv("DGP_CONV_MODE") && !strcmp(getenv("DGP_CONV_MODE"), "f32");
     if (li == net->conv1 && l.d_w_rows && net->wmax_valid && stem_rows && !f32_mode && l.CoutP % 64 == 0) {
         a.stem = 1; a.tap_rows = 8; a.KH = 7; a.KW = 1; a.ntaps = 7; a.nk = 7; a.wpk = l.d_w_rows;
         a.w_bytes = (unsigned)((size_t)7 * 8 * l.CoutP * 16);
     }
-    static const bool use_cells = !(getenv("DGP_PRESPLIT_WEIGHTS") && atoi(getenv("DGP_PRESPLIT_WEIGHTS")) == 0);   // A/B switch
+    static const bool use_cells = (dgp_env("DGP_PRESPLIT_WEIGHTS", 1) != 0);   // A/B switch
     if (use_cells && ranged && l.d_wh3 && (li != net->conv1 || a.stem)) { a.wh3 = l.d_wh3; a.wh3_bytes = a.w_bytes; }
     const int tile_cfg = pick_tile(a.M, a.CoutP, a.nk * BK, ranged && a.w_absmax);
     ProfScope ps(net, s, "conv:" + l.scope + "|" + conv_kernel_name(a, tile_cfg), conv_flops_of(l, a.M, out_mode == 1));
@@ -803,12 +810,12 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     // ---- activation format of this forward.  H2 (default): every tensor from the pool output to the block4 features lives in HBM as
     // fp16 high / low cells with a calibrated per-tensor scale, so the conv kernels' K loops are ds_read + MFMA only (DGP_H2=0: fp32
     // activations, split in the consumers' K loops -- also what the other DGP_CONV_MODEs and a trainer-owned net use).
-    static const bool h2_env = !(getenv("DGP_H2") && atoi(getenv("DGP_H2")) == 0);
+    static const bool h2_env = (dgp_env("DGP_H2", 1) != 0);
     static const bool f16_mode = !getenv("DGP_CONV_MODE") || !strcmp(getenv("DGP_CONV_MODE"), "f16x3") || tier16_mode();
-    static const bool head_pw = !(getenv("DGP_HEAD_PW") && atoi(getenv("DGP_HEAD_PW")) == 0);      // A/B switch
-    static const bool fuse_env = !(getenv("DGP_FUSE_SHORTCUT") && atoi(getenv("DGP_FUSE_SHORTCUT")) == 0);      // A/B switch
+    static const bool head_pw = (dgp_env("DGP_HEAD_PW", 1) != 0);      // A/B switch
+    static const bool fuse_env = (dgp_env("DGP_FUSE_SHORTCUT", 1) != 0);      // A/B switch
     static const bool f32_mode = getenv("DGP_CONV_MODE") && !strcmp(getenv("DGP_CONV_MODE"), "f32");
-    static const bool cells_env = !(getenv("DGP_PRESPLIT_WEIGHTS") && atoi(getenv("DGP_PRESPLIT_WEIGHTS")) == 0);
+    static const bool cells_env = (dgp_env("DGP_PRESPLIT_WEIGHTS", 1) != 0);
     const bool h2 = h2_env && cells_env && f16_mode && head_pw && net->wmax_valid && net->d_exps && net->layers[net->head_part].d_wh3_pw &&
                     (net->head_locref < 0 || net->layers[net->head_locref].d_wh3_pw) && net->act_exp.size() == net->layers.size();
     const bool calib = h2 && !net->h2_calibrated;
@@ -848,7 +855,7 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     };
     // ---- root block.  H2 engine: ONE kernel from the uint8 frame to the pool output's cells (stem_pool_fused_kernel);
     // otherwise preprocess -> conv1 -> max-pool as three launches
-    static const bool stem_fused_env = !(getenv("DGP_STEM_FUSED") && atoi(getenv("DGP_STEM_FUSED")) == 0);
+    static const bool stem_fused_env = (dgp_env("DGP_STEM_FUSED", 1) != 0);
     const ConvLayer& lstem = net->layers[net->conv1];
     const bool stem_fused = h2 && stem_fused_env && lstem.d_wh3 && lstem.d_w_rows && lstem.CoutP == 64 && lstem.d_scale && lstem.d_bias;
     if (stem_fused) {
@@ -886,9 +893,9 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     const int pool_exp = h2 ? net->act_exp[net->conv1] : 0;
     // conv3(k) + conv1(k + 1) as one launch (DGP_CHAIN=0: layer by layer).  Calibration runs layer by layer (it needs every tensor's
     // range before the next layer runs) and is followed by a second, chained pass, so results never depend on which pass produced them
-    static const bool chain_env = !(getenv("DGP_CHAIN") && atoi(getenv("DGP_CHAIN")) == 0);
+    static const bool chain_env = (dgp_env("DGP_CHAIN", 1) != 0);
     const bool chain_on = h2 && !calib && chain_env && !tier16_mode() && net->chains.size() == net->units.size();
-    static const bool unit_env = !(getenv("DGP_UNIT") && atoi(getenv("DGP_UNIT")) == 0);      // conv2 inside the chain launch (block1)
+    static const bool unit_env = (dgp_env("DGP_UNIT", 1) != 0);      // conv2 inside the chain launch (block1)
     bool r1_ready = false;                            // R1 of this unit came out of the previous unit's chain launch
     float *Ra = R1, *Rb = R2;
     int cur = 0, h = net->hp, w = net->wp;
@@ -1277,7 +1284,7 @@ int dgp_conv2d_ranged(const dgp_conv_desc* d, const float* x, const float* packe
     a.in_absmax = x_absmax; a.w_absmax = w_absmax; a.out_absmax = y_absmax;
     // DGP_CONV2D_CELLS=1 (tests, tuning): split the panel into fp16 cells per call (grow-only scratch, stream-ordered) so that a single
     // layer runs on the engine's compute-side-split / LDS-DMA kernels; the network packs its cells once at load instead
-    static const bool cells_env = getenv("DGP_CONV2D_CELLS") && atoi(getenv("DGP_CONV2D_CELLS")) != 0;
+    static const bool cells_env = (dgp_env("DGP_CONV2D_CELLS", 0) != 0);
     if (cells_env && x_absmax && w_absmax && d->Cin >= 32) {
         static void* cells = nullptr;
         static size_t cells_bytes = 0;

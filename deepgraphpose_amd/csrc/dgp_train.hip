@@ -1603,7 +1603,7 @@ struct TPlan {
 };
 
 // A/B switch (DGP_WGRAD_DMA=0: no copies, wgrad_h3p as before)
-static const bool g_wgrad_dma = !(getenv("DGP_WGRAD_DMA") && atoi(getenv("DGP_WGRAD_DMA")) == 0);
+static const bool g_wgrad_dma = (dgp_env("DGP_WGRAD_DMA", 1) != 0);
 
 size_t al(size_t x) { return (x + 255) / 256 * 256; }
 
@@ -1719,7 +1719,7 @@ static void range_set(const void* p, const float* slot) {
 // Start of a forward or a backward pass.  Forward: everything fresh (first half of the pool).  Backward: the forward tensors'
 // ranges stay (weight gradients read the retained activations), gradient tensors take slots from the second half.
 static void range_pass_begin(dgp_trainer* tr, hipStream_t s, bool backward) {
-    static const bool enabled = !(getenv("DGP_TRAIN_F16") && atoi(getenv("DGP_TRAIN_F16")) == 0) &&
+    static const bool enabled = (dgp_tune("DGP_TRAIN_F16", 1) != 0) &&
                                 !(getenv("DGP_CONV_MODE") && strcmp(getenv("DGP_CONV_MODE"), "f16x3") != 0);
     g_ctx->rng.on = enabled && tr->d_rng_pool && tr->d_wrng;
     g_ctx->rng.pool = tr->d_rng_pool;
@@ -1766,7 +1766,7 @@ static thread_local H2Launch g_h2;
 // Default on (DGP_TRAIN_CELLS=0: the trainer's convs split their weights in the loaders): the cells of all panels are rebuilt by ONE
 // launch per sync (pack_h3_all_kernel), after which forward and data-gradient convs run the engine's compute-side-split / LDS-DMA /
 // 16x16x32 kernels: 17.0 -> 16.2 ms per step.  (With one pack launch per layer and panel the packing cost what the kernels saved.)
-static const bool g_train_cells = !(getenv("DGP_TRAIN_CELLS") && atoi(getenv("DGP_TRAIN_CELLS")) == 0);
+static const bool g_train_cells = (dgp_tune("DGP_TRAIN_CELLS", 1) != 0);
 
 hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, const float* in, int N, int H, int W,
                        int Cin, int pad_t, int pad_l, int Ho, int Wo, int Cout, int stride, int up, const float* scale,
@@ -1873,8 +1873,8 @@ hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const floa
     // workgroups per launch: ONE round of resident workgroups (2 per CU).  Every workgroup adds its whole 128 x 128 tile to dW with
     // float atomics, so more pixel slices mean more atomic traffic, fewer leave CUs idle: 1536 -> 18.4 ms per step, 1024 -> 17.8,
     // 640 -> 18.2, 512 -> 16.7, 384 -> 17.2, 256 -> 18.1 (DGP_WGRAD_WGS)
-    static const int wgs_target = getenv("DGP_WGRAD_WGS") ? atoi(getenv("DGP_WGRAD_WGS")) : 512;
-    static const int wgs_small = getenv("DGP_WGRAD_WGS_SMALL") ? atoi(getenv("DGP_WGRAD_WGS_SMALL")) : 1024;      // 64 x 64 tiles: 1024 (16.7 vs 16.9 ms at 512)
+    static const int wgs_target = dgp_tune("DGP_WGRAD_WGS", 512);
+    static const int wgs_small = dgp_tune("DGP_WGRAD_WGS_SMALL", 1024);      // 64 x 64 tiles: 1024 (16.7 vs 16.9 ms at 512)
     int split = std::max(1, (big ? wgs_target : wgs_small) / (kt * nt));
     int mpb = ((a.M + split - 1) / split + 63) / 64 * 64;      // (64: wgrad_dma walks 16-pixel steps unrolled by four)
     if (mpb < 256) mpb = 256;
@@ -1882,13 +1882,15 @@ hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const floa
     a.m_per_block = mpb;
     static bool attr_dev[16][4] = {};
     auto& attr = attr_dev[dgp_device_slot()];
-    static const bool h3_env = !(getenv("DGP_WGRAD_F16") && atoi(getenv("DGP_WGRAD_F16")) == 0);       // A/B switch
+    static const bool h3_env = (dgp_tune("DGP_WGRAD_F16", 1) != 0);       // A/B switch
     const float* rx = rx_given ? rx_given : range_of(x);
     const float* rdy = rdy_given ? rdy_given : range_of(dy);
     // both operands also exist as fp16 high / low copies written by their producers: LDS-DMA tile (falls back per workgroup to the
     // fp32-MFMA tile when this step's ranges left the copies' predicted scales)
-    if (big && h3_env && g_wgrad_dma && rx && rdy && xs && dys && x_prev && dy_prev && Cin % 16 == 0 && Cdy % 8 == 0 &&
-        (double)a.x_bytes + 80.0 * Cin * 4 < 4294967000.0 && (double)a.dy_bytes + 80.0 * Cdy * 4 < 4294967000.0) {
+    // (guards: the kernel's offset walkers run up to 15 (row0) + 63 (sub-steps rounded up to four) + 64 (four prefetched steps) = 142
+    //  pixel rows past the tensor's end, and its channel masks need Cin / 8 to be a power of two)
+    if (big && h3_env && g_wgrad_dma && rx && rdy && xs && dys && x_prev && dy_prev && Cin % 16 == 0 && ((Cin / 8) & (Cin / 8 - 1)) == 0 && Cdy % 8 == 0 &&
+        (double)a.x_bytes + 160.0 * Cin * 4 < 4294967000.0 && (double)a.dy_bytes + 160.0 * Cdy * 4 < 4294967000.0) {
         if (!attr[3]) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
             if (e != hipSuccess) return e;
@@ -1907,7 +1909,7 @@ hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const floa
             attr[2] = true;
         }
         WgradRanges rg{rx, rdy};
-        static const bool pipe_env = !(getenv("DGP_WGRAD_PIPE") && atoi(getenv("DGP_WGRAD_PIPE")) == 0);      // A/B switch
+        static const bool pipe_env = (dgp_tune("DGP_WGRAD_PIPE", 1) != 0);      // A/B switch
         if (pipe_env) {
             if (!attr[0]) {
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3p), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -2063,7 +2065,7 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
     const size_t nl_all = net->layers.size();
     if (tr->d_wrng) TRY_HIP(hipMemsetAsync(tr->d_wrng, 0, 2 * nl_all * ABSMAX_SLOTS * sizeof(float), s));
     // one launch for the panels / folded BN of all non-head layers (DGP_PACK_MERGED=0: one launch per layer and job, as before)
-    static const bool merged_env = !(getenv("DGP_PACK_MERGED") && atoi(getenv("DGP_PACK_MERGED")) == 0);
+    static const bool merged_env = (dgp_tune("DGP_PACK_MERGED", 1) != 0);
     const bool merged = merged_env;
     for (size_t li = 0; li < net->layers.size(); ++li) {
         ConvLayer& l = net->layers[li];
@@ -2214,8 +2216,8 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     // second stream.  At 11 frames the grids of block3 / block4 cover half of the chip, and two independent chains drift apart so that
     // one chain's small or tail-heavy layers run under the other's.  Both chains write frame ranges of the SAME activation tensors
     // (the backward pass sees one batch) and max into the same range slots.
-    static const bool side_env = !(getenv("DGP_WGRAD_OVERLAP") && atoi(getenv("DGP_WGRAD_OVERLAP")) == 0);
-    static const int chains_env = getenv("DGP_FWD_CHAINS") ? atoi(getenv("DGP_FWD_CHAINS")) : 2;
+    static const bool side_env = (dgp_env("DGP_WGRAD_OVERLAP", 1) != 0);
+    static const int chains_env = dgp_env("DGP_FWD_CHAINS", 2);
     if (side_env && !g_ctx->s2) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -2225,7 +2227,7 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     const bool two = side_env && g_ctx->s2 && chains_env >= 2 && B >= 4;
     const int n1 = two ? (B + 1) / 2 : B;
     const ConvLayer& c1 = net->layers[net->conv1];
-    static const bool pool_idx = !(getenv("DGP_POOL_IDX") && atoi(getenv("DGP_POOL_IDX")) == 0);       // A/B switch (0: re-scan in backward)
+    static const bool pool_idx = (dgp_tune("DGP_POOL_IDX", 1) != 0);       // A/B switch (0: re-scan in backward)
     if (two) {
         hipEvent_t ready = g_ctx->take_event();
         if (!ready) return fail(DGP_ERR_HIP, "forward chains: hipEventCreate failed");
@@ -2339,7 +2341,7 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     }
     // heads: pointwise GEMM on the cell kernels + gather of the four taps (as the inference engine) when the feature map's range
     // and the pointwise cells exist, else the 2x2-conv form on the fp32 kernel
-    static const bool head_pw = !(getenv("DGP_HEAD_PW") && atoi(getenv("DGP_HEAD_PW")) == 0);
+    static const bool head_pw = (dgp_env("DGP_HEAD_PW", 1) != 0);
     auto head_forward = [&](const ConvLayer& hd, int li, int njt, float* out) -> hipError_t {
         const float* rin = range_of(xin);
         const float* rw = tr->d_wrng ? tr->d_wrng + (size_t)li * ABSMAX_SLOTS : nullptr;
@@ -2462,18 +2464,18 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
     const dgp_net_desc& d = net->desc;
     const int B = nt, nj = d.num_joints;
     const int nu = (int)net->units.size();
-    static const bool defer_env = !(getenv("DGP_WGRAD_DEFER") && atoi(getenv("DGP_WGRAD_DEFER")) == 0);
+    static const bool defer_env = (dgp_tune("DGP_WGRAD_DEFER", 1) != 0);
     g_ctx->defer_plan = defer_env ? &pl : nullptr;
     g_ctx->defer_ws = ws;
     if (defer_env) TRY_HIP(hipMemsetAsync(ws + pl.dwall, 0, pl.dwall_bytes, s));
     // weight gradients on their own stream beside the data-gradient chain (DGP_WGRAD_OVERLAP=0: one stream, A/B)
-    static const bool overlap_env = !(getenv("DGP_WGRAD_OVERLAP") && atoi(getenv("DGP_WGRAD_OVERLAP")) == 0);
+    static const bool overlap_env = (dgp_env("DGP_WGRAD_OVERLAP", 1) != 0);
     TrainCtx* const ctx = g_ctx;
     if (defer_env && overlap_env) {
         if (!ctx->s2) {
             int lo = 0, hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);         // lo: numerically greatest = least urgent
-            static const int prio_mode = getenv("DGP_WGRAD_PRIO") ? atoi(getenv("DGP_WGRAD_PRIO")) : 0;      // 0 least urgent, 1 default, 2 most urgent
+            static const int prio_mode = dgp_tune("DGP_WGRAD_PRIO", 0);      // 0 least urgent, 1 default, 2 most urgent
             TRY_HIP(hipStreamCreateWithPriority(&ctx->s2, hipStreamNonBlocking, prio_mode == 0 ? lo : prio_mode == 2 ? hi : 0));
         }
         ctx->overlap = true;
@@ -2572,7 +2574,9 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
     }
     // ---- bottleneck units, last to first.  G[cur] = d loss / d (unit output), already gated by its ReLU.
     int stop_after = -1;
-    if (const char* e = getenv("DGP_BWD_STOP")) stop_after = atoi(e);      // debugging aid: leave G of an inner unit in place
+#ifdef DGP_TUNING
+    if (const char* e = getenv("DGP_BWD_STOP")) stop_after = atoi(e);      // debugging aid (tuning builds): leave G of an inner unit in place
+#endif
     for (int ui = nu - 1; ui >= 0; --ui) {
         if (stop_after >= 0 && (nu - 1 - ui) >= stop_after) {
             if (const char* e2 = getenv("DGP_BWD_DUMP")) {
@@ -2651,7 +2655,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         int pth = (net->hp - 1) * 2 + 3 - net->h1; if (pth < 0) pth = 0;
         int ptw = (net->wp - 1) * 2 + 3 - net->w1; if (ptw < 0) ptw = 0;
         const long long tot = (long long)B * net->h1 * net->w1 * 16;
-        static const bool pool_idx = !(getenv("DGP_POOL_IDX") && atoi(getenv("DGP_POOL_IDX")) == 0);
+        static const bool pool_idx = (dgp_tune("DGP_POOL_IDX", 1) != 0);
         if (pool_idx)
             hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(grid_for(tot)), dim3(256), 0, s, F(pl.c1), G[cur],
                                reinterpret_cast<const uchar4*>(ws + pl.pidx), B, net->h1, net->w1, 64, net->hp, net->wp, pth / 2, ptw / 2,
@@ -2708,6 +2712,10 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
  * with enable = 0 before using either. */
 int dgp_trainer_fast_mode(dgp_trainer* tr, int32_t enable) {
     if (!tr) return fail(DGP_ERR_INVALID, "dgp_trainer_fast_mode: null");
+#ifndef DGP_TUNING
+    // measured no faster than the plain pass: an opt-in of tuning builds only
+    if (enable) return fail(DGP_ERR_INVALID, "dgp_trainer_fast_mode: the fast pass is enabled in -DDGP_TUNING builds only");
+#endif
     tr->fast_next = enable != 0;
     return DGP_OK;
 }

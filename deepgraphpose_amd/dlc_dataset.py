@@ -145,6 +145,23 @@ class PoseDataset:
             if self.is_valid_size(item.im_size, scale):
                 return self.make_batch(item, scale, mirror)
 
+    def skip_batch(self):
+        """Advance every random stream exactly as next_batch() would -- sample index, mirror flag, scale jitter with its
+        size-rejection loop, the crop decision and its five draws -- WITHOUT reading, scaling or cropping the image and without
+        building target maps.  Data-parallel fit_dlc: rank r trains on sample it * W + r of the common sequence and skips the
+        other W - 1 samples of an iteration, so its host work per step stays that of one sample."""
+        cfg = self.cfg
+        while True:
+            imidx, mirror = self.next_training_sample()
+            item = self.data[imidx]
+            scale = self.get_scale()
+            if self.is_valid_size(item.im_size, scale):
+                break
+        if self.has_gt and cfg.crop and np.random.rand() < cfg.cropratio and np.asarray(item.joints).shape[1] > 0:
+            np.random.randint(np.asarray(item.joints).shape[1])
+            for key in ("rightwidth", "leftwidth", "topheight", "bottomheight"):      # crop_image's draws, in its order
+                np.random.randint(cfg[key])
+
     def make_batch(self, item, scale, mirror):
         """-> dict(inputs uint8 [1,H,W,3], part_score_targets / part_score_weights [1,h,w,nj],
         locref_targets / locref_mask [1,h,w,2nj], data_item)."""

@@ -405,10 +405,11 @@ def fit_dlc(snapshot, dlcpath, shuffle=1, step=0, saveiters=1000, displayiters=1
 
     def next_sample(_i):                      # W samples per optimiser step: rank r trains on sample it * W + r of the common sequence
         batch = None
-        for r in range(world):
-            b = dataset.next_batch()
+        for r in range(world):                # the other ranks' samples only advance the random streams (no image read, no target maps)
             if r == rank:
-                batch = b
+                batch = dataset.next_batch()
+            else:
+                dataset.skip_batch()
         return batch
 
     max_iter = max(1, max_iter // world) if world > 1 else max_iter

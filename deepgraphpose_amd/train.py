@@ -113,7 +113,8 @@ class Trainer:
         key = (nt, self.net.in_h, self.net.in_w)
         # (opt-in: at 11 frames the forward convs of blocks 2-4 are grids of 52-208 tiles, paced by one tile's latency rather than by
         #  operand traffic, and the fast pass measured 12.95-13.09 against 13.01-13.16 ms per step -- DESIGN.md section 6a')
-        fast = getattr(self, "_fast_key", None) == key and os.environ.get("DGP_TRAIN_H2", "0") == "1"
+        fast = (getattr(self, "_fast_key", None) == key and os.environ.get("DGP_TRAIN_H2", "0") == "1"
+                and bool(self.lib.dgp_tuning_build()))          # (an opt-in of -DDGP_TUNING builds: include/dgp_hip.h)
         _lib.check(self.lib.dgp_trainer_fast_mode(self._t, 1 if fast else 0), "dgp_trainer_fast_mode")
         return fast
 

@@ -64,6 +64,9 @@ typedef struct dgp_tensor_view {
 } dgp_tensor_view;
 
 int          dgp_version(void);
+/* 1 when the library was built with -DDGP_TUNING (tuning knobs read from the environment, the opt-in kernels that measured slower
+ * compiled in), 0 for the product build.  No reference counterpart (build introspection for the tests). */
+int          dgp_tuning_build(void);
 /* Host-only helper: CRC-32C (Castagnoli) of a byte range, continuing from `crc` (0 to start).  Used for the
  * per-tensor checksums of TF tensor bundles that tf.train.Saver writes/verifies (DGP/models/fitdgp.py:149-171). */
 uint32_t     dgp_crc32c(const void* data, size_t n, uint32_t crc);

@@ -1,8 +1,10 @@
 #!/bin/bash
 # kernel-level durations of scripts/bench_wgrad_layers.py (rocprofv3 kernel trace): the copies and memsets are separate kernels there
-cd /tmp && export TMPDIR=/tmp
-rm -rf $GRAFT_REPO_ROOT/gpurun_out/wgl && mkdir -p $GRAFT_REPO_ROOT/gpurun_out/wgl
-cd $GRAFT_REPO_ROOT
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export TMPDIR=/tmp
+rm -rf "$ROOT/gpurun_out/wgl" && mkdir -p "$ROOT/gpurun_out/wgl"
+cd "$ROOT"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/wgl -o wgl -- python3 scripts/bench_wgrad_layers.py > gpurun_out/wgl/out.txt 2>&1
 python3 - <<'PY'
 import csv, glob, collections

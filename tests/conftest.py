@@ -17,3 +17,13 @@ def lib_built():
     """Make sure libdgp_hip.so exists (hipcc cross-compiles without a GPU)."""
     from deepgraphpose_amd import build
     return build.build(verbose=False)
+
+
+@pytest.fixture(scope="session")
+def tuning_build(lib_built):
+    """Tests of the opt-in paths that measured slower (256-row tile, the trainer's fast pass): they exist only in a library built with
+    DGP_BUILD_FLAGS=-DDGP_TUNING; the product build skips them."""
+    from deepgraphpose_amd import _lib
+    if not _lib.load().dgp_tuning_build():
+        pytest.skip("opt-in path of -DDGP_TUNING builds (DGP_BUILD_FLAGS=-DDGP_TUNING python -m deepgraphpose_amd.build)")
+    return True

@@ -251,7 +251,9 @@ def test_bench_through_its_own_spawner(lib_built):
     """`python bench.py --gpus N` with no launcher around it spawns its N workers itself (the parent never touches the GPU) and relays
     rank 0's line.  Here N = 1 through the spawner (DGP_BENCH_FORCE_SPAWN=1): RCCL group of one rank, the strict-fp32 child run included."""
     d = _run_bench(["--gpus", "1", "--steps", "6", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--sustain-seconds", "0.3",
-                    "--prewarm-seconds", "0.2"], DGP_BENCH_FORCE_SPAWN=1)
+                    "--prewarm-seconds", "0.2", "--train-steps", "3"], DGP_BENCH_FORCE_SPAWN=1)
+    ts = d["train_step"]                                    # BASELINE configs[3], timed by a fresh child of the same run
+    assert "error" not in ts and 0 < ts["ms_per_step"] < 200 and ts["frames_per_step"] == 11 and 0 < ts["frac"] < 1 and np.isfinite(ts["loss"]["total_loss"])
     assert "spawned 1 worker" in d["launcher"] and d["n_gpus"] == 1 and d["steps"] == 6 and d["value"] > 0
     assert d["roofline"]["frac"] > 0 and d["shard_check"]["indices_identical"]
     sf = d["strict_f32"]
@@ -270,6 +272,20 @@ def test_bench_strong_scaling_two_ranks_through_the_spawner(lib_built):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 4 and d["config"]["total_frames"] == 64
     assert d["shard_check"]["batches_compared"] == 4 and d["shard_check"]["indices_identical"]
     assert "spawned 2 worker" in d["launcher"] and "strict_f32" not in d
+
+
+def test_bench_strong_scaling_eight_ranks_through_the_spawner(lib_built):
+    """The command the README quotes for an 8-GPU node -- `python bench.py --gpus 8 --scaling strong` -- through bench.py's own spawner with all
+    eight ranks on the one GPU of this box (gloo control plane, DGP_BENCH_VISIBLE_GPUS=1): eight shards of one fixed stream, one gather,
+    every batch identical to rank 0's ring, per-rank elapsed times reported."""
+    d = _run_bench(["--gpus", "8", "--scaling", "strong", "--total-batches", "8", "--warmup", "1", "--batch", "4", "--no-cpu-baseline",
+                    "--sustain-seconds", "0.1", "--prewarm-seconds", "0.1", "--streams", "1"], DGP_DIST_BACKEND="gloo", DGP_BENCH_VISIBLE_GPUS=1)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["steps"] == 1 and d["config"]["total_frames"] == 32
+    assert "spawned 8 worker" in d["launcher"]
+    assert d["shard_check"]["batches_compared"] == 4 and d["shard_check"]["indices_identical"]       # ranks 4-7 against ranks 0-3
+    assert d["frames_per_s"] == d["value"] > 0
+    re = d["rank_elapsed_s"]
+    assert re["max"] >= re["min"] > 0 and re["imbalance"] >= 0
 
 
 def test_shard_ranges_reassemble_bit_exactly(lib_built):

@@ -252,7 +252,7 @@ def test_per_tap_loaders_of_the_3x3_layers_in_a_child_process(lib_built):
     assert r.returncode == 0 and "5 passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
 
 
-def test_tall_tile_on_every_shape_it_can_take_in_a_child_process(lib_built):
+def test_tall_tile_on_every_shape_it_can_take_in_a_child_process(lib_built, tuning_build):
     """The 256 x 128 tile (eight compute waves on one B stage) is an opt-in (DGP_TALL=1: deep-K layers with >= 512 tiles); DGP_TALL=2 forces it
     wherever the kernel applies: pointwise and 3x3 loaders, dilation, stride 2, H2 / fp32 / strided residuals, ragged last row tile."""
     import os, subprocess, sys

@@ -253,6 +253,34 @@ def test_frame_sharding_allgather_gloo_world2(T):
         np.testing.assert_array_equal(i[:, 2, 1], np.full(T, 2))
 
 
+@pytest.mark.parametrize("T", [13, 5])
+def test_frame_sharding_allgather_gloo_world8(T):
+    """Eight ranks, T % 8 != 0: ceil(T / 8) frames per rank, a short last shard (T = 13: ranks 6 holds one frame, rank 7 none) or several
+    EMPTY shards (T = 5: ranks 5-7) -- every rank still ends with the whole frame-ordered trajectory."""
+    import torch.multiprocessing as mp
+    from deepgraphpose_amd import dist as dd
+    assert [dd.shard_range(13, r, 8) for r in range(8)] == [(0, 2), (2, 4), (4, 6), (6, 8), (8, 10), (10, 12), (12, 13), (13, 13)]
+    assert [dd.shard_range(5, r, 8) for r in range(8)] == [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 5), (5, 5), (5, 5)]
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 8, port, T, q)) for r in range(8)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=240) for _ in ps]
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(8))
+    for rank, m, c, i in res:
+        fr = np.arange(T, dtype=np.float32)
+        assert m.shape == (T, 3, 2)
+        np.testing.assert_array_equal(m[:, 0, 0], fr + 0.25)
+        np.testing.assert_array_equal(m[:, 2, 1], fr * 2)
+        np.testing.assert_array_equal(c[:, 1], fr / 100)
+        np.testing.assert_array_equal(i[:, 0, 0], np.arange(T))
+        np.testing.assert_array_equal(i[:, 2, 1], np.full(T, 2))
+
+
 def _grad_worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
@@ -298,6 +326,22 @@ def test_dlc_pose_dataset_samples(tmp_path):
         np.random.seed(seed); random.seed(seed)
         ds = PoseDataset(cfg)
         return [ds.next_batch() for _ in range(n)]
+
+    # skip_batch() consumes exactly the draws of next_batch(): rank 1 of a 3-rank job sees samples 1, 4, 7 of the common sequence
+    np.random.seed(5); random.seed(5)
+    ds = PoseDataset(cfg)
+    seq = [ds.next_batch() for _ in range(9)]
+    np.random.seed(5); random.seed(5)
+    ds = PoseDataset(cfg)
+    for it in range(3):
+        got = None
+        for r in range(3):
+            if r == 1:
+                got = ds.next_batch()
+            else:
+                ds.skip_batch()
+        np.testing.assert_array_equal(got["inputs"], seq[3 * it + 1]["inputs"])
+        np.testing.assert_array_equal(got["locref_targets"], seq[3 * it + 1]["locref_targets"])
     a, b = run(4, 9), run(4, 9)
     sizes = set()
     for x, y in zip(a, b):

@@ -131,7 +131,20 @@ def test_full_backward_matches_autograd(lib_built):
     assert np.sqrt(tot_err / tot_ref) < 3e-3
 
 
-def test_fast_pass_matches_autograd_and_recovers_from_a_failed_prediction(lib_built, monkeypatch):
+def test_product_build_refuses_the_opt_in_fast_pass(lib_built):
+    """The fast pass measured no faster than the plain pass and lives in -DDGP_TUNING builds only: the product library says so instead
+    of silently running something else."""
+    from deepgraphpose_amd import _lib
+    from deepgraphpose_amd.train import Trainer
+    lib = _lib.load()
+    if lib.dgp_tuning_build():
+        pytest.skip("tuning build: the fast pass is available")
+    tr = Trainer(50, 3, 64, 96, max_frames=3)
+    assert lib.dgp_trainer_fast_mode(tr._t, 0) == 0
+    assert lib.dgp_trainer_fast_mode(tr._t, 1) == -1 and b"DGP_TUNING" in lib.dgp_last_error()       # DGP_ERR_INVALID
+
+
+def test_fast_pass_matches_autograd_and_recovers_from_a_failed_prediction(lib_built, tuning_build, monkeypatch):
     """DGP_TRAIN_H2=1: from the second pass on, blocks 2-4 keep their activations as H2 tensors with scales predicted from the previous
     pass (dgp_trainer_fast_mode).  (a) the fast pass meets the plain pass's tolerances against the fp64 oracle; (b) when the ranges jump
     by more than the predicted scales cover (here: new weights 64 x larger in the stem, smuggled in behind the trainer's back), the
