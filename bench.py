@@ -218,6 +218,7 @@ def main():
                     help="weak: --steps batches per GPU; strong: --total-batches batches in all, rank r runs its contiguous share")
     ap.add_argument("--total-batches", type=int, default=1024, help="strong scaling: batches of the one fixed stream (1024 x 32 = 32768 frames)")
     ap.add_argument("--no-strict-f32", action="store_true", help="skip the child-process legs after the timed region: DGP_CONV_MODE=f32 (IEEE fp32 MFMA tier), the 16-bit tier and the training step")
+    ap.add_argument("--no-r101", action="store_true", help="skip the ResNet-101 1280x720 child run (BASELINE configs[4] per-GPU shape)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-step child run (BASELINE configs[3]) after the timed region")
     ap.add_argument("--train-steps", type=int, default=30, help="timed steps of the training-step child run")
     ap.add_argument("--strict-f32-child", action="store_true", help=argparse.SUPPRESS)
@@ -430,7 +431,7 @@ def main():
     # HBM traffic of the dominant kernel, per launch, from the committed rocprofv3 PMC passes of this same command
     # (scripts/profile.sh -> profiles/traffic_r1.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate
     # passes); null when no profile of this kernel has been taken.
-    tj = next((q for q in (os.path.join(ROOT, "profiles", "traffic_r%d.json" % r) for r in (3, 2, 1)) if os.path.exists(q)), "")
+    tj = next((q for q in (os.path.join(ROOT, "profiles", "traffic_r%d.json" % r) for r in (4, 3, 2, 1)) if os.path.exists(q)), "")
     if os.path.exists(tj):
         try:
             tr = json.load(open(tj))
@@ -564,6 +565,19 @@ def main():
                 out[key] = json.loads(ln[-1]) if cp.returncode == 0 and ln else {"error": (cp.stderr or cp.stdout)[-300:]}
             except Exception as e:      # noqa: BLE001 -- the main line must still be printed
                 out[key] = {"error": repr(e)[:300]}
+    if world == 1 and not args.no_strict_f32 and not args.no_r101:
+        # BASELINE configs[4]'s per-GPU shape (ResNet-101, 1280 x 720, 20 keypoints) in a fresh child process: block3 has 23 units there
+        import subprocess
+        env = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "DGP_CONV_MODE"):
+            env.pop(k, None)
+        try:
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_r101.py"), "16", "--json"], env=env, capture_output=True, text=True,
+                                timeout=600)
+            ln = [q for q in cp.stdout.splitlines() if q.startswith("{")]
+            out["r101_1280x720"] = json.loads(ln[-1]) if cp.returncode == 0 and ln else {"error": (cp.stderr or cp.stdout)[-300:]}
+        except Exception as e:      # noqa: BLE001
+            out["r101_1280x720"] = {"error": repr(e)[:300]}
     if world == 1 and not args.no_train_step and not args.no_strict_f32:
         # BASELINE configs[3] next to the headline number, driver-timed: the semi-supervised fit_dgp step (1 labeled + 10 unlabeled 640 x 480
         # frames, gm2 = 1, gm3 = 3, skeleton clique; forward + loss + backward + clip + momentum) -- the call that replaces

@@ -25,6 +25,11 @@ dt = (time.perf_counter() - t0) / K
 gf = 2.0 * conv_macs_per_frame(H, W, 101, NJ, False) / 1e9
 print("ResNet-101 %dx%d nj=%d batch %d: %.2f ms/step, %.1f frames/s, %.1f TFLOP/s of algorithmic conv FLOPs (%.1f GFLOP/frame)"
       % (W, H, NJ, B, dt * 1e3, B / dt, gf * B / dt / 1e3, gf), flush=True)
+if "--json" in sys.argv:
+    import json
+    print(json.dumps({"frames_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "batch": B, "steps": K, "conv_tflops": round(gf * B / dt / 1e3, 1),
+                      "frac_of_its_peak": round(gf * B / dt / 1e3 / (2500.0 / 3.0), 4), "algorithmic_gflop_per_frame": round(gf, 1),
+                      "workload": "BASELINE configs[4], per-GPU shape: ResNet-101, 1280x720, 20 keypoints, one stream"}), flush=True)
 if "--parity" in sys.argv:
     from oracle import dgp_oracle as O
     ref = O.infer(frames[:1], wts, 101, 8.0, 1.0, 1)
