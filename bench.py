@@ -220,7 +220,7 @@ def main():
     ap.add_argument("--no-strict-f32", action="store_true", help="skip the child-process legs after the timed region: DGP_CONV_MODE=f32 (IEEE fp32 MFMA tier), the 16-bit tier and the training step")
     ap.add_argument("--no-r101", action="store_true", help="skip the ResNet-101 1280x720 child run (BASELINE configs[4] per-GPU shape)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-step child run (BASELINE configs[3]) after the timed region")
-    ap.add_argument("--train-steps", type=int, default=30, help="timed steps of the training-step child run")
+    ap.add_argument("--train-steps", type=int, default=60, help="timed steps of the training-step child run")
     ap.add_argument("--strict-f32-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.strict_f32_child:
@@ -587,7 +587,7 @@ def main():
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "DGP_CONV_MODE"):
             env.pop(k, None)
         try:
-            cp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_train.py"), str(args.train_steps)], env=env, capture_output=True,
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_train.py"), str(args.train_steps), "8"], env=env, capture_output=True,
                                 text=True, timeout=600)
             ln = [q for q in cp.stdout.splitlines() if q.startswith("{")]
             if cp.returncode == 0 and ln:
@@ -596,7 +596,7 @@ def main():
                                      "frac": t["roofline"]["frac"], "achieved_tflops": t["roofline"]["achieved"], "peak_tflops": t["roofline"]["peak"],
                                      "algorithmic_gflop_per_step": t["roofline"]["algorithmic_gflop_per_step"], "loss": t["loss"],
                                      "workload": "BASELINE configs[3]: fit_dgp step, ResNet-50 640x480, 1 labeled + 10 unlabeled frames, 4 keypoints, "
-                                                 "fp32-class arithmetic (not bf16), 2 warm-up steps then `steps` timed ones",
+                                                 "fp32-class arithmetic (not bf16), 8 warm-up steps then `steps` timed ones",
                                      "frac_basis": "3 x forward conv FLOPs (forward + data-gradient + weight-gradient convolutions) / step time / (2500 / 3 TFLOP/s)"}
             else:
                 out["train_step"] = {"error": (cp.stderr or cp.stdout)[-300:]}

@@ -12,6 +12,7 @@ from deepgraphpose_amd.synthetic import make_frames, make_weights
 
 H, W, NJ, NT = 480, 640, 4, 11
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+warm = int(sys.argv[2]) if len(sys.argv) > 2 else 2        # (the first pass has no predicted scales yet: its weight gradients run the fp32 tile)
 rng = np.random.default_rng(0)
 wts = make_weights(50, NJ, True, seed=0, head_std=0.05)
 frames = torch.from_numpy(make_frames(NT, H, W, NJ, seed=0)).cuda()
@@ -26,7 +27,7 @@ hy = DGPHyper(gm2=1, gm3=3)
 tr = Trainer(50, NJ, H, W, max_frames=NT)
 tr.load_weights(wts)
 ws, ws_max = np.full(3, 10.0), np.full(3, 200.0)
-for _ in range(2):
+for _ in range(warm):
     losses = tr.step(frames, batch, hy, S0, ws, ws_max, 2000.0, 50.0)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
