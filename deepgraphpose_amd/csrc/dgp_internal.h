@@ -111,6 +111,7 @@ hipError_t launch_preprocess(const uint8_t* f, long long npix, float m0, float m
                              float* out, hipStream_t s);
 hipError_t launch_motion_energy(const uint8_t* frames, long long frame_bytes, int n_frames, const uint8_t* prev_frame,
                                 unsigned long long* sums, hipStream_t s);
+constexpr size_t SOFT_ARGMAX_LDS_LIMIT = 150 * 1024;      // bytes of one joint's map the LDS variant holds (38 400 cells); larger maps stream
 hipError_t launch_soft_argmax(const float* scmap, int B, int H, int W, int C, float gamma,
                               int gauss_len, float* mu, float* conf, int* idx, float* pmap,
                               hipStream_t s, int record_stride = 0);

@@ -3125,6 +3125,11 @@ hipError_t launch_stem_pool_fused(const unsigned char* frames, int B, int H, int
 //   arg-max of e^x/(e^x+1) on the RAW logits.        (DGP/models/eval.py:331-343)
 // The map lives in LDS (H*W floats); sums are carried in fp64.
 // ------------------------------------------------------------------------------------
+// LARGE (round 4): maps that do not fit the LDS (the reference's placeholders are [None, None, None, nj], DGP/models/fitdgp.py:1130-1142:
+// any size).  The softmax values are then not cached but RECOMPUTED from global memory wherever the blur reads them -- the same
+// expressions on the same inputs, so every output is bit-identical to what the LDS variant would give; (2 r + 1)^2 exps per cell
+// instead of one, a fallback for frames beyond ~1920 x 1280, not a fast path.
+template <bool LARGE>
 __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restrict__ scmap, int H, int W, int C,
                                                           float gamma, int glen, float* __restrict__ mu,
                                                           float* __restrict__ conf, int* __restrict__ idx,
@@ -3158,7 +3163,7 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
     float mx = -INFINITY;
     for (int i = t; i < HW; i += 256) {
         const float v = src[(long long)i * C] * gamma;
-        sp[i] = v;
+        if (!LARGE) sp[i] = v;
         mx = fmaxf(mx, v);
     }
     mx = wave_max(mx);
@@ -3168,8 +3173,8 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
 
     double se = 0.0;
     for (int i = t; i < HW; i += 256) {
-        const float e = expf(sp[i] - mx);
-        sp[i] = e;
+        const float e = expf((LARGE ? src[(long long)i * C] * gamma : sp[i]) - mx);
+        if (!LARGE) sp[i] = e;
         se += (double)e;
     }
     se = wave_sum(se);
@@ -3177,8 +3182,11 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
     __syncthreads();
     const float denom = (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
     __syncthreads();
-    for (int i = t; i < HW; i += 256) sp[i] = sp[i] / denom;    // tf.nn.softmax output
+    if (!LARGE) {
+        for (int i = t; i < HW; i += 256) sp[i] = sp[i] / denom;    // tf.nn.softmax output
+    }
     __syncthreads();
+    auto P = [&](int i) -> float { return LARGE ? expf(src[(long long)i * C] * gamma - mx) / denom : sp[i]; };
 
     // blur (zero padded) + moments
     double s0 = 0.0, sh = 0.0, sw = 0.0;
@@ -3192,7 +3200,7 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
             for (int bb = -r; bb <= r; ++bb) {
                 const int ww = w + bb;
                 if ((unsigned)ww >= (unsigned)W) continue;
-                acc += (ga * gk[bb + r]) * sp[hh * W + ww];
+                acc += (ga * gk[bb + r]) * P(hh * W + ww);
             }
         }
         s0 += (double)acc;
@@ -3246,15 +3254,20 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
 hipError_t launch_soft_argmax(const float* scmap, int B, int H, int W, int C, float gamma, int gauss_len,
                               float* mu, float* conf, int* idx, float* pmap, hipStream_t s, int record_stride) {
     const size_t smem = (size_t)H * W * sizeof(float);
+    if (smem > SOFT_ARGMAX_LDS_LIMIT) {            // the map does not fit the LDS: streaming variant (same arithmetic)
+        hipLaunchKernelGGL(soft_argmax_kernel<true>, dim3((unsigned)(B * C)), dim3(256), 0, s, scmap, H, W, C, gamma, gauss_len, mu, conf, idx,
+                           pmap, record_stride);
+        return hipGetLastError();
+    }
     static size_t attr_set_dev[16] = {};
     size_t& attr_set = attr_set_dev[dgp_device_slot()];
     if (smem > 64 * 1024 && smem > attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(soft_argmax_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(soft_argmax_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr_set = smem;
     }
-    hipLaunchKernelGGL(soft_argmax_kernel, dim3((unsigned)(B * C)), dim3(256), smem, s, scmap, H, W, C, gamma,
+    hipLaunchKernelGGL(soft_argmax_kernel<false>, dim3((unsigned)(B * C)), dim3(256), smem, s, scmap, H, W, C, gamma,
                        gauss_len, mu, conf, idx, pmap, record_stride);
     return hipGetLastError();
 }

@@ -132,8 +132,8 @@ int build_chain_plan(ChainPlan& pl, int C, int C1, int CIN2, int res, const floa
 
 namespace {
 
-void pack_panels(const float* hwio, int KH, int KW, int Cin, int Cout, float* packed) {
-    const int cin4 = Cin / 4, CoutP = coutp_for(Cout), nk = nk_for(KH, KW, Cin);
+void pack_panels(const float* hwio, int KH, int KW, int Cin, int Cout, float* packed, int coutp = 0) {
+    const int cin4 = Cin / 4, CoutP = coutp ? coutp : coutp_for(Cout), nk = nk_for(KH, KW, Cin);
     const size_t total = (size_t)nk * 8 * CoutP * 4;
     memset(packed, 0, total * sizeof(float));
     const int nchunks = KH * KW * cin4;
@@ -361,10 +361,10 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
             for (int tap = 0; tap < 4; ++tap)
                 for (int ci = 0; ci < 2048; ++ci)
                     memcpy(&wpw[(size_t)ci * cpw + (size_t)tap * l.Cout], &hwio[((size_t)tap * 2048 + ci) * l.Cout], l.Cout * sizeof(float));
-            l.coutp_pw = coutp_for(cpw);
+            l.coutp_pw = coutp_for(cpw) < 64 ? 64 : coutp_for(cpw);      // (the H2 cell kernels start at 64-column tiles: one or two joints pad to 64)
             const size_t npw = (size_t)nk_for(1, 1, 2048) * 8 * l.coutp_pw * 4;
             std::vector<float> ppw(npw);
-            pack_panels(wpw.data(), 1, 1, 2048, cpw, ppw.data());
+            pack_panels(wpw.data(), 1, 1, 2048, cpw, ppw.data(), l.coutp_pw);
             if (!l.d_w_pw) HIP_TRY(hipMalloc(&l.d_w_pw, npw * sizeof(float)));
             if (!l.d_wh3_pw) HIP_TRY(hipMalloc(&l.d_wh3_pw, npw * sizeof(float)));
             HIP_TRY(hipMemcpy(l.d_w_pw, ppw.data(), npw * sizeof(float), hipMemcpyHostToDevice));
@@ -1035,7 +1035,6 @@ int dgp_soft_argmax(const float* scmap, int32_t B, int32_t H, int32_t W, int32_t
     if (!scmap || !mu || !conf || !idx) return fail(DGP_ERR_INVALID, "dgp_soft_argmax: null argument");
     if (B < 0 || H < 1 || W < 1 || C < 1 || gauss_len < 0 || gauss_len > 7)
         return fail(DGP_ERR_INVALID, "dgp_soft_argmax: bad shape / gauss_len (0..7)");
-    if ((size_t)H * W * sizeof(float) > 150 * 1024) return fail(DGP_ERR_INVALID, "dgp_soft_argmax: map exceeds LDS");
     if (B == 0) return DGP_OK;
     hipError_t e = launch_soft_argmax(scmap, B, H, W, C, gamma, gauss_len, mu, conf, idx, pmap, (hipStream_t)stream);
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("soft_argmax: ") + hipGetErrorString(e));
@@ -1067,10 +1066,7 @@ static int infer_impl(dgp_net* net, const uint8_t* frames, int32_t batch, void* 
     if (!net) return fail(DGP_ERR_INVALID, "dgp_infer: null net");
     if (!mu || !conf || !idx) return fail(DGP_ERR_INVALID, "dgp_infer: null output");
     if (gauss_len < 0 || gauss_len > 7) return fail(DGP_ERR_INVALID, "dgp_infer: gauss_len (0..7)");
-    // the soft-argmax keeps one joint's map in LDS (150 KB: 38 400 pixels of the 2 fh x 2 fw scoremap, e.g. frames up to 1920 x 1280);
-    // refuse before running the backbone rather than fail at the launch
-    if ((size_t)4 * net->fh * net->fw * sizeof(float) > 150 * 1024)
-        return fail(DGP_ERR_INVALID, "dgp_infer: scoremap exceeds LDS (soft-argmax holds a map of at most 38400 pixels); use dgp_forward + tiles or smaller frames");
+    // (the soft-argmax keeps one joint's map in LDS up to 38 400 cells -- frames up to ~1920 x 1280 -- and streams larger ones: launch_soft_argmax)
     net->prof_in_infer = true;
     int rc = dgp_forward(net, frames, batch, workspace, workspace_bytes, scmap_out, nullptr, nullptr, stream);
     net->prof_in_infer = false;

@@ -93,7 +93,9 @@ int  dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* works
 
 /* DGP soft-argmax + likelihood window.
  * scmap [B,H,W,C] fp32 -> mu [B,C,2] (row, col) fp32, conf [B,C] fp32 (sigmoid of the raw
- * logit at the window arg-max), idx [B,C,2] int32 (row, col), pmap optional [B,H,W,C]. */
+ * logit at the window arg-max), idx [B,C,2] int32 (row, col), pmap optional [B,H,W,C].
+ * Any H x W (the reference's placeholders are [None, None, None, nj]): maps up to 38 400 cells are held in LDS, larger ones
+ * stream from global memory with the same arithmetic. */
 int  dgp_soft_argmax(const float* scmap, int32_t B, int32_t H, int32_t W, int32_t C,
                      float gamma, int32_t gauss_len, float* mu, float* conf, int32_t* idx,
                      float* pmap, void* stream);
