@@ -1,0 +1,38 @@
+"""Random whole-net configurations (frame size, bodyparts, batch, locref) against the CPU oracle.  Usage: python scripts/fuzz_net.py [n] [seed]"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deepgraphpose_amd.engine import DGPNet
+from deepgraphpose_amd.synthetic import make_frames, make_weights
+from oracle import dgp_oracle as O
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for k in range(n):
+    H, W = int(rng.integers(33, 420)), int(rng.integers(33, 420))
+    nj, B, loc = int(rng.integers(1, 9)), int(rng.integers(1, 6)), bool(rng.integers(0, 2))
+    depth = 101 if rng.random() < 0.15 else 50
+    wts = make_weights(depth, nj, loc, seed=int(rng.integers(1 << 20)), head_std=0.05)
+    frames = make_frames(B, H, W, nj, seed=int(rng.integers(1 << 20)))
+    try:
+        net = DGPNet(depth, nj, H, W, max_batch=B, with_locref=loc)
+        net.load_weights(wts)
+        ft = torch.from_numpy(frames).cuda()
+        out = net.forward(ft, want_locref=loc)
+        out = out if isinstance(out, (tuple, list)) else (out,)
+        sc = out[0].cpu().numpy(); lr = out[1].cpu().numpy() if loc else None
+        assert sc.shape == (B, net.out_h, net.out_w, nj)
+        mu, conf, idx = net.infer(ft)
+        ref = O.infer(frames, wts, depth, 8.0, 1.0, 1)
+        s_ref, l_ref = O.pose_heads(ref["features"], wts, loc)
+        e_sc = np.abs(sc - s_ref).max() / max(np.abs(s_ref).max(), 1e-30)
+        e_lr = np.abs(lr - l_ref).max() / max(np.abs(l_ref).max(), 1e-30) if loc else 0.0
+        e_mu = np.abs(mu.cpu().numpy() - ref["mu"]).max() * 8.0
+        ok = e_sc < 1e-4 and e_lr < 1e-4 and e_mu < 1e-3 and np.array_equal(idx.cpu().numpy(), ref["idx"]) and not net.range_status()[0]
+    except Exception as e:      # noqa: BLE001
+        ok, e_sc, e_lr, e_mu = False, -1, -1, -1
+        print("   exception:", repr(e)[:200])
+    bad += not ok
+    print("%s  R%d %3d x %3d nj %d B %d locref %d   scmap %.2g locref %.2g px %.2g" % ("ok " if ok else "BAD", depth, H, W, nj, B, loc, e_sc, e_lr, e_mu), flush=True)
+print("failures:", bad)
+sys.exit(1 if bad else 0)
