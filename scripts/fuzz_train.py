@@ -1,0 +1,55 @@
+"""Random training-step configurations (frame size, frames, bodyparts, visible frames, loss variant) against the fp64 autograd oracle.
+Usage: python scripts/fuzz_train.py [n] [seed]"""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_train_gpu import _make_loss_case, _oracle_grads
+from deepgraphpose_amd.arch import scoremap_hw
+from deepgraphpose_amd.loss import DGPHyper
+from deepgraphpose_amd.synthetic import make_frames, make_weights
+from deepgraphpose_amd.train import Trainer
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for k in range(n):
+    hw = (int(rng.integers(48, 161)), int(rng.integers(48, 161)))
+    nt, nj = int(rng.integers(2, 6)), int(rng.integers(1, 7))
+    nvf = int(rng.integers(0, nt + 1))
+    gm2, gm3 = [(0, 0), (1, 3), (2, 3), (1, 0)][int(rng.integers(0, 4))]
+    H, W = scoremap_hw(*hw)
+    seed = int(rng.integers(1 << 20))
+    r2 = np.random.default_rng(seed)
+    nl = 0 if nj < 2 else int(r2.integers(0, 4))
+    batch, S0 = _make_loss_case(r2, nt, H, W, nj, nvf, 0.2 if nvf else 0.0, nl)
+    wts = make_weights(50, nj, True, seed=seed, head_std=0.05)
+    frames = make_frames(nt, hw[0], hw[1], nj, seed=seed)
+    ws, ws_max = r2.uniform(5, 20, nl), r2.uniform(10, 40, nl)
+    hy = DGPHyper(gm2=gm2, gm3=gm3)
+    try:
+        P, L = _oracle_grads(wts, frames, batch, S0, ws, ws_max, hy, 300.0, 25.0, dtype=torch.float64)
+        tr = Trainer(50, nj, hw[0], hw[1], max_frames=nt)
+        tr.load_weights(wts)
+        losses = tr.forward_backward(torch.from_numpy(frames).cuda(), batch, hy, S0, ws, ws_max, 300.0, 25.0)
+        g = tr.get_grads()
+        Lt = float(L["total_loss"].detach())
+        e_loss = abs(losses["total_loss"] - Lt) / max(1.0, abs(Lt))
+        tot_ref = tot_err = 0.0
+        head = 0.0
+        for name, t in P.items():
+            if not t.requires_grad or t.grad is None:
+                continue
+            ref = t.grad.numpy(); d = g[name].reshape(ref.shape) - ref
+            tot_ref += float((ref ** 2).sum()); tot_err += float((d ** 2).sum())
+            if name.startswith("pose/"):
+                head = max(head, np.linalg.norm(d.ravel()) / (np.linalg.norm(ref.ravel()) + 1e-30))
+        e_g = np.sqrt(tot_err / max(tot_ref, 1e-300))
+        ok = e_loss < 1e-4 and e_g < 1e-2 and head < 1e-4
+    except Exception as e:      # noqa: BLE001
+        ok, e_loss, e_g, head = False, -1, -1, -1
+        print("   exception:", repr(e)[:300])
+    bad += not ok
+    print("%s  %3d x %3d nt %d nj %d visible %d nl %d gm2 %d gm3 %d   loss %.2g  grad L2 %.2g  heads %.2g" % ("ok " if ok else "BAD", hw[0], hw[1], nt, nj, nvf, nl, gm2, gm3,
+          e_loss, e_g, head), flush=True)
+print("failures:", bad)
+sys.exit(1 if bad else 0)
