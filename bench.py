@@ -318,8 +318,8 @@ def main():
     # hipEvent pairs around every launch of the FIRST `prof_steps` steps of the timed region (106 event records per step cost ~4 % of a
     # step; the remaining steps run uninstrumented).  Per-kernel durations -> the roofline object.
     prof_steps = min(K, args.profile_steps)
-    if prof_steps > 1 and prof_steps * 6 > K:      # short runs: at most a sixth of the timed steps carries the instrumentation
-        prof_steps = max(1, K // 6)
+    if prof_steps > 1 and prof_steps * 10 > K:     # short runs: at most a tenth of the timed steps carries the instrumentation
+        prof_steps = max(1, K // 10)
     net.profile_begin(max(prof_steps, 1))
     barrier()
     torch.cuda.synchronize(dev)
