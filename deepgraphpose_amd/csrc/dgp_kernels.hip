@@ -2219,7 +2219,10 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
                       a.KH == 3 && a.KW == 3 && a.ntaps == 9 && a.stride == 1 && a.dil >= 1 && a.pad_t == a.dil && a.pad_l == a.dil && a.H == a.Ho &&
                       a.W == a.Wo && a.W >= 2 && (a.Cin % 32) == 0 && a.nk * 32 == 9 * a.Cin && a.tap_rows == (a.Cin >> 2) && !a.in_scale_dev &&
                       (unsigned long long)a.M * a.Cin * 4ull == a.in_bytes && a.in_bytes < 4000000000u &&
-                      a.dil * (a.W - 2) + 128 <= HALO_C - 8 && (unsigned long long)a.dil * (a.W + 1) * a.Cin * 4ull < 200000000ull;
+                      a.dil * (a.W - 2) + 128 <= HALO_C - 8 && (unsigned long long)a.dil * (a.W + 1) * a.Cin * 4ull < 200000000ull &&
+                      // a strip longer than the ring still works (the ring slides), but the loaders can then never run a chunk ahead and
+                      // the walk measured 0.4 % behind the per-tap loaders (ResNet-101 1280 x 720: W = 80 at dilation 2); DGP_HALO=2 forces it
+                      (halo_env >= 2 || 128 + 2 * a.dil * (a.W + 1) <= HALO_C);
     constexpr bool CAN_PB = NT == 2 && CW == 4;
     if (!(CAN_PB && a.wh3)) a.wh3 = nullptr;
     auto kern = conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 0>;

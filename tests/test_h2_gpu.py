@@ -240,6 +240,18 @@ def test_tail_split_fixup_on_h2_tensors_in_a_child_process(lib_built):
     assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
 
 
+def test_halo_walk_on_strips_longer_than_the_ring_in_a_child_process(lib_built):
+    """DGP_HALO=2 forces the halo walk wherever the ring's capacity rule allows, i.e. also where ONE strip (128 + 2 d (W + 1) pixels) is
+    longer than the 360-pixel ring and the ring slides inside a channel chunk (by default those shapes keep the per-tap loaders)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DGP_HALO="2", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_h2_gpu.py"), "-q", "-m", "gpu", "-k",
+                        "test_conv_on_h2_tensors_matches_float64 and (case15 or case17 or case19)"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "3 passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
+
+
 def test_per_tap_loaders_of_the_3x3_layers_in_a_child_process(lib_built):
     """DGP_HALO=0: the 3x3 / stride-1 layers on the per-tap LDS-DMA loaders (MODE 1) they used before the halo walk became the
     default -- still the path of rows too wide for the pixel ring, of the 16-bit tier and of the A/B switch."""
