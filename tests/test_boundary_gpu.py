@@ -163,25 +163,26 @@ dist.destroy_process_group()
     assert os.path.isfile(tmp_path / "pred_dist" / "clip_labeled.csv")
 
 
-def test_estimate_pose_two_ranks_on_one_gpu_equal_single_process(lib_built, tmp_path):
-    """The sharded product path with W = 2 for real: two processes (RANK 0 / 1, both on cuda:0, control plane on gloo via
-    DGP_DIST_BACKEND because RCCL refuses two ranks on one device) run estimate_pose on the same video.  Rank 1's shard starts in
-    the middle (frame_at seek), both calibrate on the video's first batch, the gather reassembles [T, nj], rank 0 alone exports --
-    and the result equals the single-process run bit for bit."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_estimate_pose_two_ranks_on_one_gpu_equal_single_process(lib_built, tmp_path, world):
+    """The sharded product path with W = 2 and W = 8 for real: W processes (all on cuda:0, control plane on gloo via DGP_DIST_BACKEND
+    because RCCL refuses two ranks on one device) run estimate_pose on the same video.  Every shard but the first starts in the middle
+    (frame_at seek), all calibrate on the video's first batch, the gather reassembles [T, nj], rank 0 alone exports -- and the result
+    equals the single-process run bit for bit.  T = 23: with eight ranks the shards are 3, 3, ..., 2 frames (T % 8 != 0, batch_size 4)."""
     proj, snap, frames, wts = _tiny_project(tmp_path, T=23)
     code = r'''
 import json, os, sys, numpy as np
 from deepgraphpose_amd.models import eval as E
 out = E.estimate_pose(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], shuffle=1, batch_size=4)
 import torch.distributed as dist
-assert dist.is_initialized() and dist.get_world_size() == 2 and dist.get_backend() == "gloo"
+assert dist.is_initialized() and dist.get_world_size() == int(os.environ["WORLD_SIZE"]) and dist.get_backend() == "gloo"
 np.savez(sys.argv[5] + os.environ["RANK"] + ".npz", **out)
 dist.barrier()
 dist.destroy_process_group()
 '''
     procs = []
-    for rank in (0, 1):
-        env = _child_env(RANK=rank, WORLD_SIZE=2, LOCAL_RANK=0, MASTER_ADDR="127.0.0.1", MASTER_PORT=29631, DGP_DIST_BACKEND="gloo")
+    for rank in range(world):
+        env = _child_env(RANK=rank, WORLD_SIZE=world, LOCAL_RANK=0, MASTER_ADDR="127.0.0.1", MASTER_PORT=29631 + world, DGP_DIST_BACKEND="gloo")
         procs.append(subprocess.Popen([sys.executable, "-c", code, str(proj / "config.yaml"), snap, str(tmp_path / "clip.npy"),
                                        str(tmp_path / "pred_w2"), str(tmp_path / "out_rank")], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -198,7 +199,7 @@ dist.destroy_process_group()
     from deepgraphpose_amd.models import eval as E
     ref = E.estimate_pose(str(proj / "config.yaml"), snap, str(tmp_path / "clip.npy"), str(tmp_path / "pred_w1"), shuffle=1,
                           batch_size=4)
-    for rank in (0, 1):
+    for rank in range(world):
         got = np.load(str(tmp_path / "out_rank") + "%d.npz" % rank)
         for k in ("x", "y", "likelihoods"):
             assert got[k].shape == (23, 3) and np.array_equal(got[k], ref[k]), (rank, k)
