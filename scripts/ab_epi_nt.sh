@@ -1,4 +1,8 @@
-cd $GRAFT_REPO_ROOT
+#!/bin/bash
+# A/B of the epilogue's non-temporal policy (DGP_EPI_NT: 2 default, 3 loads only, 4 stores only, 0 off) on one box, one stream.
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$ROOT"; mkdir -p gpurun_out/r4
 for v in 2 3 4 0 2 3; do
   DGP_EPI_NT=$v python bench.py --steps 12 --warmup 3 --no-cpu-baseline --sustain-seconds 0 --streams 1 --profile-steps 10 --no-strict-f32 --layer-table gpurun_out/r4/lt_nt$v.tsv 2>/dev/null | python3 -c "
 import sys, json
