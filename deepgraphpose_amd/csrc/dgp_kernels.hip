@@ -2346,7 +2346,8 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
         if (st_env && a.in_fmt && a.out_fmt && a.tail_ksplit <= 1 && BN == 128 && a.ntiles >= 8 && panel_bytes > (3LL << 20) && a.mtiles >= 64) {
             const long long per_ntile = (long long)a.nk * 32 * BN * 4;
             int gn = 1;
-            while (gn * 2 <= a.ntiles && (long long)(gn * 2) * per_ntile <= (3LL << 19) && a.ntiles % (gn * 2) == 0) gn *= 2;      // <= 1.5 MB of weight cells per group
+            static const long long st_cap = (long long)dgp_tune("DGP_ST_CAP_KB", 1536) << 10;
+            while (gn * 2 <= a.ntiles && (long long)(gn * 2) * per_ntile <= st_cap && a.ntiles % (gn * 2) == 0) gn *= 2;      // <= 1.5 MB of weight cells per group
             a.st_gn = gn; a.st_mc = st_env > 1 ? st_env : 8; a.st_mb = (a.mtiles + 7) / 8;
             nwg = 8LL * a.st_mb * a.ntiles;
         }
