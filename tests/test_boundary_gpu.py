@@ -355,6 +355,48 @@ def test_run_dgp_demo_at_the_reaching_frame_size(lib_built, tmp_path):
     assert (vals[:, 0::3] >= 0).all() and (vals[:, 0::3] <= 832).all() and (vals[:, 1::3] >= 0).all() and (vals[:, 1::3] <= 747).all()
 
 
+def test_strict_two_ranks_stay_bit_identical_after_a_late_overflow(lib_built, tmp_path):
+    """DGP_EVAL_STRICT=1 in a sharded run: the first chunk of EACH shard is flat (the scales calibrated on the video's first batch are far too
+    small, and nothing overflows in round 0), the real frames begin in every rank's second chunk, so both ranks overflow LATE.  The ranks
+    decide together, widen together, re-run that chunk, and -- strict -- compute the whole video again on the final scales: the gathered
+    result equals, bit for bit, a single-process run whose one chunk holds the whole video (everything on the wide scales)."""
+    from deepgraphpose_amd.models import eval as E
+    from deepgraphpose_amd.synthetic import make_frames
+    proj, snap, _, wts = _tiny_project(tmp_path)
+    frames = make_frames(40, 96, 128, 3, seed=77)                                      # T = 40: shards of 20 frames, chunks of 8
+    for lo in (0, 20):                                                                 # the FIRST chunk of each shard is flat
+        frames[lo:lo + 8, ..., 0], frames[lo:lo + 8, ..., 1], frames[lo:lo + 8, ..., 2] = 124, 117, 104
+    np.save(tmp_path / "mixed.npy", frames)
+    code = r'''
+import os, sys, numpy as np
+from deepgraphpose_amd.models import eval as E
+out = E.estimate_pose(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], shuffle=1, batch_size=4)
+np.savez(sys.argv[5] + os.environ["RANK"] + ".npz", strict_passes=E.RUN_STATS["strict_passes"], **out)
+import torch.distributed as dist
+dist.barrier(); dist.destroy_process_group()
+'''
+    procs = []
+    for rank in range(2):
+        env = _child_env(RANK=rank, WORLD_SIZE=2, LOCAL_RANK=0, MASTER_ADDR="127.0.0.1", MASTER_PORT=29671, DGP_DIST_BACKEND="gloo",
+                         DGP_EVAL_STRICT=1, DGP_EVAL_CHUNK_BATCHES=2)
+        procs.append(subprocess.Popen([sys.executable, "-c", code, str(proj / "config.yaml"), snap, str(tmp_path / "mixed.npy"),
+                                       str(tmp_path / "pred_strict2"), str(tmp_path / "strict_rank")], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for pr in procs:
+        so, se = pr.communicate(timeout=900)
+        assert pr.returncode == 0, se[-2000:]
+    os.environ["DGP_EVAL_CHUNK_BATCHES"] = "64"
+    try:
+        whole = E.estimate_pose(str(proj / "config.yaml"), snap, str(tmp_path / "mixed.npy"), str(tmp_path / "pred_whole2"), shuffle=1, batch_size=4)
+    finally:
+        del os.environ["DGP_EVAL_CHUNK_BATCHES"]
+    for rank in range(2):
+        got = np.load(str(tmp_path / "strict_rank") + "%d.npz" % rank)
+        assert int(got["strict_passes"]) == 1
+        for k in ("x", "y", "likelihoods"):
+            assert got[k].shape == (40, 3) and np.array_equal(got[k], whole[k]), (rank, k)
+
+
 def test_evaluate_dgp_soft_argmax_locref_readout(lib_built, tmp_path):
     """evaluate_dgp(loc_ref=True, loc_ref_calc='dgp') (eval.py:752-786): runs on the synthetic project and its per-frame read-out
     equals the restated numpy of the reference on the oracle's maps."""
