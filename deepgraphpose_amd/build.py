@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libdgp_hip.so")
-SOURCES = ["dgp_kernels.hip", "dgp_chain.hip", "dgp_loss.hip", "dgp_net.hip", "dgp_train.hip"]
+SOURCES = ["dgp_kernels.hip", "dgp_ops.hip", "dgp_chain.hip", "dgp_loss.hip", "dgp_net.hip", "dgp_train.hip"]
 HEADERS = ["dgp_internal.h", "dgp_device.h", "dgp_engine.h", os.path.join("..", "..", "include", "dgp_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 
@@ -82,7 +82,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             f.write(want)
         return obj
 
-    jobs = max(1, min(len(SOURCES), int(os.environ.get("DGP_BUILD_JOBS", "5"))))
+    jobs = max(1, min(len(SOURCES), int(os.environ.get("DGP_BUILD_JOBS", "6"))))
     with ThreadPoolExecutor(jobs) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs
