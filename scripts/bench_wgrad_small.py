@@ -17,7 +17,12 @@ for name, N, H, W, Cin, Cout, k, stride, rate, ohw in CASES:
     x = torch.relu(torch.randn((N, H, W, Cin), device=dev)); dy = torch.randn((N, ohw[0], ohw[1], Cout), device=dev) * 1e-3
     d = _conv_desc(x.shape, (k, k, Cin, Cout), stride, rate, pad, pad, ohw)
     dw = torch.empty((k, k, Cin, Cout), device=dev); cs = torch.empty(2 * Cout, device=dev)
-    run = lambda: lib.dgp_conv2d_wgrad(C.byref(d), _ptr(x), _ptr(dy), None, None, _ptr(dw), _ptr(cs), _stream(dev))
+    rng = torch.zeros((2, 256), device=dev)
+    ranged = "--ranged" in sys.argv          # hand the operand ranges over, as the training step does (16-bit tiles may be chosen)
+    if ranged:
+        lib.dgp_tensor_absmax(_ptr(x), x.numel(), _ptr(rng[0]), _stream(dev)); lib.dgp_tensor_absmax(_ptr(dy), dy.numel(), _ptr(rng[1]), _stream(dev))
+    run = lambda: lib.dgp_conv2d_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(rng[0]) if ranged else None, _ptr(rng[1]) if ranged else None,
+                                       _ptr(dw), _ptr(cs), _stream(dev))
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
