@@ -217,7 +217,8 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --steps batches per GPU; strong: --total-batches batches in all, rank r runs its contiguous share")
     ap.add_argument("--total-batches", type=int, default=1024, help="strong scaling: batches of the one fixed stream (1024 x 32 = 32768 frames)")
-    ap.add_argument("--no-strict-f32", action="store_true", help="skip the child-process legs after the timed region: DGP_CONV_MODE=f32 (IEEE fp32 MFMA tier), the 16-bit tier and the training step")
+    ap.add_argument("--no-strict-f32", action="store_true", help="skip the child-process legs after the timed region: DGP_CONV_MODE=f32 (IEEE fp32 MFMA tier), the 16-bit tier, ResNet-101 1280x720, the training step and the PCIe-inclusive estimate_pose run")
+    ap.add_argument("--no-host-pipeline", action="store_true", help="skip the PCIe-inclusive estimate_pose child run (4096 host frames)")
     ap.add_argument("--no-r101", action="store_true", help="skip the ResNet-101 1280x720 child run (BASELINE configs[4] per-GPU shape)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-step child run (BASELINE configs[3]) after the timed region")
     ap.add_argument("--train-steps", type=int, default=60, help="timed steps of the training-step child run")
@@ -602,6 +603,20 @@ def main():
                 out["train_step"] = {"error": (cp.stderr or cp.stdout)[-300:]}
         except Exception as e:      # noqa: BLE001 -- the main line must still be printed
             out["train_step"] = {"error": repr(e)[:300]}
+    if world == 1 and not args.no_host_pipeline and not args.no_strict_f32:
+        # the PCIe-inclusive rate of the boundary that takes HOST frames (A0 estimate_pose: decode thread -> pinned ring -> copy stream -> engines
+        # -> one D2H), in a fresh child process; reported beside `value`, never as it
+        import subprocess
+        env = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "DGP_CONV_MODE"):
+            env.pop(k, None)
+        try:
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_pipeline.py"), "4096", "--json"], env=env, capture_output=True,
+                                text=True, timeout=300)
+            ln = [q for q in cp.stdout.splitlines() if q.startswith("{")]
+            out["host_pipeline"] = json.loads(ln[-1]) if cp.returncode == 0 and ln else {"error": (cp.stderr or cp.stdout)[-300:]}
+        except Exception as e:      # noqa: BLE001 -- the main line must still be printed
+            out["host_pipeline"] = {"error": repr(e)[:300]}
     print(json.dumps(out), flush=True)
     if use_pg:
         dist.destroy_process_group()

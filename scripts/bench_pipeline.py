@@ -8,7 +8,7 @@ from deepgraphpose_amd import weights_io
 from deepgraphpose_amd.models import eval as E
 from deepgraphpose_amd.synthetic import make_weights, make_frames
 
-T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+T = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1024
 tmp = tempfile.mkdtemp()
 proj = os.path.join(tmp, "proj"); train = os.path.join(proj, "dlc-models", "iteration-0", "DemoOct2-trainset95shuffle1", "train")
 os.makedirs(train)
@@ -22,4 +22,9 @@ E.estimate_pose(os.path.join(proj, "config.yaml"), snap, frames[:64], os.path.jo
 t0 = time.perf_counter()
 out = E.estimate_pose(os.path.join(proj, "config.yaml"), snap, frames, os.path.join(tmp, "pred"), save_pose=False, batch_size=32)
 dt = time.perf_counter() - t0
+if "--json" in sys.argv:
+    import json
+    print(json.dumps({"frames_per_s": round(T / dt, 1), "frames": T, "seconds": round(dt, 3), "batch": 32,
+                      "workload": "estimate_pose on a host array of %d 640x480x3 u8 frames (ResNet-50, 4 keypoints): engine set-up, decode thread, pinned "
+                                  "staging, H2D on a copy stream, two engines, one D2H of the trajectory -- PCIe-inclusive, never `value`" % T}), flush=True)
 print("estimate_pose on %d host frames (640x480x3 u8): %.1f frames/s incl. engine setup, pinned staging, H2D and the final D2H" % (T, T / dt))
