@@ -13,6 +13,7 @@ third-party territory (moviepy) and only used when installed.
 from __future__ import annotations
 
 import os
+import time
 from os.path import join
 from pathlib import Path
 from typing import Dict, Optional
@@ -128,7 +129,7 @@ def setup_dgp_eval_graph(dlc_cfg, dgp_model_file, loc_ref=False, gauss_len=1, ga
 
 
 # counters of the last estimate_pose call (tests, soak runs): chunks processed and chunks re-run after a range overflow
-RUN_STATS = {"chunks": 0, "chunk_reruns": 0, "strict_passes": 0}
+RUN_STATS = {"chunks": 0, "chunk_reruns": 0, "strict_passes": 0, "stage_s": 0.0, "wait_frames_s": 0.0, "wait_h2d_s": 0.0, "drain_s": 0.0}
 
 
 def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle=1, save_pose=True, save_str="",
@@ -265,7 +266,9 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
                         if nb <= 0:
                             break
                         slot = free_slots.get()
+                        t_ = time.perf_counter()
                         np.copyto(pinned[slot][:nb].numpy(), chunk[:nb])
+                        RUN_STATS["stage_s"] += time.perf_counter() - t_
                         ready.put((slot, nb))
                         done += nb
                     ready.put(None)
@@ -299,7 +302,9 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
         for rnd in range(n_rounds):
             entries = []                          # (slot in dchunk, frames, offset in traj) of this chunk
             while len(entries) < chunk_batches and not finished:
+                t_ = time.perf_counter()
                 item = ready.get()
+                RUN_STATS["wait_frames_s"] += time.perf_counter() - t_
                 if item is None:
                     finished = True
                     break
@@ -318,15 +323,19 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
                 net.submit(dchunk[k][:nb], traj[start:start + nb], sess.gamma, sess.gauss_len)
                 entries.append((k, nb, start))
                 start += nb
+                t_ = time.perf_counter()
                 copied.synchronize()              # the pinned buffer is free again once its H2D copy has completed
+                RUN_STATS["wait_h2d_s"] += time.perf_counter() - t_
                 free_slots.put(slot)
             # H2 activation scales (include/dgp_hip.h): a batch that outgrew the scales calibrated on the first batch invalidates the
             # results since the last clean check, i.e. THIS chunk's.  All ranks decide together; every engine of every rank then
             # re-calibrates on the calibration batch with 3 more bits of headroom (same scales everywhere again) and the ranks whose
             # chunk overflowed re-run it from the frames still resident in HBM.
             for attempt in range(5):
+                t_ = time.perf_counter()
                 net.join()
                 torch.cuda.synchronize(dev)
+                RUN_STATS["drain_s"] += time.perf_counter() - t_
                 overflow = bool(net.range_status()[0])
                 anywhere = ddist.any_rank(overflow, device="cuda:%d" % sess.device)
                 if not anywhere:
@@ -368,6 +377,9 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
     # the engines keep the widened headroom and everything is computed again on those scales (the decision is collective).
     net_used = None
     RUN_STATS["chunks"] = RUN_STATS["chunk_reruns"] = RUN_STATS["strict_passes"] = 0
+    # where the host side of the call spent its time: staging copies of in-memory frames (producer thread), the consumer waiting for a
+    # decoded batch / for an H2D copy / for the engines at a chunk boundary
+    RUN_STATS["stage_s"] = RUN_STATS["wait_frames_s"] = RUN_STATS["wait_h2d_s"] = RUN_STATS["drain_s"] = 0.0
     for _pass in range(4):
         if not (_infer_once(video_clip) and os.environ.get("DGP_EVAL_STRICT", "0") == "1"):
             break

@@ -19,12 +19,15 @@ snap = weights_io.save_weights(os.path.join(train, "snapshot-step2-final--0"), m
 base = make_frames(16, 480, 640, 4, seed=0)
 frames = np.concatenate([base] * (T // 16))
 E.estimate_pose(os.path.join(proj, "config.yaml"), snap, frames[:64], os.path.join(tmp, "warm"), save_pose=False, batch_size=32)
+import torch
+torch.cuda.synchronize()
 t0 = time.perf_counter()
 out = E.estimate_pose(os.path.join(proj, "config.yaml"), snap, frames, os.path.join(tmp, "pred"), save_pose=False, batch_size=32)
 dt = time.perf_counter() - t0
 if "--json" in sys.argv:
     import json
     print(json.dumps({"frames_per_s": round(T / dt, 1), "frames": T, "seconds": round(dt, 3), "batch": 32,
+                      "host_seconds": {k: round(float(v), 3) for k, v in E.RUN_STATS.items() if k.endswith("_s")},
                       "workload": "estimate_pose on a host array of %d 640x480x3 u8 frames (ResNet-50, 4 keypoints): engine set-up, decode thread, pinned "
                                   "staging, H2D on a copy stream, two engines, one D2H of the trajectory -- PCIe-inclusive, never `value`" % T}), flush=True)
 print("estimate_pose on %d host frames (640x480x3 u8): %.1f frames/s incl. engine setup, pinned staging, H2D and the final D2H" % (T, T / dt))
