@@ -356,7 +356,8 @@ def main():
         barrier()
 
     range_overflow, n_calib = pipe.range_status()         # a forward that outgrew the calibrated activation scales would be invalid
-    assert not range_overflow, "activation ranges outgrew the calibrated scales during the run"
+    assert not range_overflow or os.environ.get("DGP_BENCH_ALLOW_OVERFLOW") == "1", \
+        "activation ranges outgrew the calibrated scales during the run"      # (the override: timing-only ablation builds, scripts/ablate_unit.sh)
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     elapsed_min = elapsed.clone()
     if use_pg:

@@ -57,10 +57,35 @@ __device__ __forceinline__ void st16(__amdgpu_buffer_rsrc_t r, const uint4& v, u
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, soff, 0);
 }
 
+#ifdef DGP_DIAG
+// diagnostic build only (scripts/diag_unit.sh): s_memtime stamps of compute wave 0 and loader wave 0 of every workgroup, summed over the grid.
+// The stamps fence the schedule and drain the LDS queue: read SHARES, not totals.
+//   [0] conv2 tap work  [1] conv2 tap barrier  [2] conv2 epilogue  [3] tile prologue  [4] conv3 MFMAs  [5] conv3 epilogue  [6] conv1 MFMAs
+//   [7] chunk barrier   [8] conv1 epilogue     [9] tiles           [10] tile loop     [12] loader issue in conv2 steps, [11] in pointwise steps
+//   [13] loader vmcnt wait [14] loader barrier [15] loader steps
+__device__ unsigned long long g_unit_diag[16];
+#define UD_STAMP(x)                                                                     \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+    } while (0)
+#define UD_PARAM , unsigned long long (&ud)[12]
+#define UD_ARG , ud
+#else
+#define UD_STAMP(x)
+#define UD_PARAM
+#define UD_ARG
+#endif
+
 // residual cells of chunk jp (32 channels of X) for the wave's RB row blocks -> res; chain_prefetch: the first PD - 1 chunks of a tile
 template <int RES, int RB>
 __device__ __forceinline__ void chain_fetch_res(const ChainArgs& p, uint4 (&res)[RB][2], const unsigned (&roff)[RB],
                                                 const __amdgpu_buffer_rsrc_t rs_s2, int jp) {
+#if defined(DGP_UX) && (DGP_UX & 1)      // timing-only ablation (scripts/diag_unit.sh): no residual loads
+    for (int rb = 0; rb < RB; ++rb) { res[rb][0] = make_uint4(0, 0, 0, 0); res[rb][1] = make_uint4(0, 0, 0, 0); }
+    return;
+#endif
     if constexpr (RES != 0) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
@@ -89,7 +114,10 @@ __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring
                                            const uint4 (&pl)[RB][(C + CIN2) / 32], const unsigned (&xoff)[RB], const unsigned (&roff)[RB],
                                            const unsigned (&r1off)[RB], const __amdgpu_buffer_rsrc_t rs_s2, const __amdgpu_buffer_rsrc_t rs_xo,
                                            const __amdgpu_buffer_rsrc_t rs_r1, float& amax_x, float& amax_r1, const int lane,
-                                           uint4 (&res)[PD][RB][2]) {
+                                           uint4 (&res)[PD][RB][2] UD_PARAM) {
+#ifdef DGP_DIAG
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+#endif
     constexpr int C4 = 4 * C, KS1 = (C + CIN2) / 32, NJP = C4 / 32, NCB = C1 / 16;
     constexpr int F1 = KS1 * 4, F2 = NCB * 2;
     static_assert(WR >= 2 && WR % 2 == 0, "weight fragments in flight: pairs share the ring");
@@ -107,6 +135,7 @@ __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring
         for (int u = 0; u < PD; ++u) {
             const int jp = jp0 + u;
             if (jp + PD - 1 < NJP) fetch_res(jp + PD - 1, (u + PD - 1) % PD);
+            UD_STAMP(c0);
             const uint4* Wc = ring + slot * (CHUNK / 16);          // the chunk; W: this lane's 16 bytes of fragment 0
             const uint4* W = Wc + lane;
             // ---- conv3 for channels [32 jp, 32 jp + 32): two 16-channel blocks, transposed product (weights = A operand)
@@ -139,6 +168,7 @@ __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring
                 }
             // ---- epilogue of conv3 = operand of conv1: BN affine (x the power of two that undoes the operand scales), shortcut,
             // ReLU, range, split
+            UD_STAMP(c1);
             const float4 sa = __builtin_bit_cast(float4, Wc[(F1 + F2) * 64 + 2 * g]), sb = __builtin_bit_cast(float4, Wc[(F1 + F2) * 64 + 2 * g + 1]);
             const float4 ba = __builtin_bit_cast(float4, Wc[(F1 + F2) * 64 + 8 + 2 * g]), bb = __builtin_bit_cast(float4, Wc[(F1 + F2) * 64 + 8 + 2 * g + 1]);
             const float sc[8] = {sa.x * p.post1, sa.y * p.post1, sa.z * p.post1, sa.w * p.post1,
@@ -155,12 +185,18 @@ __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring
                     o[k] = fmaxf(o[k], 0.f);
                 }
                 h2_pack8(o, p.xout_scale, xh[rb], xl[rb]);
+#if defined(DGP_UX) && (DGP_UX & 2)      // timing-only ablation: no X' stores
+                if (p.nt == 77) {
+#else
                 if (p.nt & 2) {
+#endif
                     st16nt(rs_xo, xh[rb], xoff[rb], jp * 128);
                     st16nt(rs_xo, xl[rb], xoff[rb], jp * 128 + 16);
                 } else {
+#if !(defined(DGP_UX) && (DGP_UX & 2))
                     st16(rs_xo, xh[rb], xoff[rb], jp * 128);
                     st16(rs_xo, xl[rb], xoff[rb], jp * 128 + 16);
+#endif
                 }
                 if (xoff[rb] != OOB) {
 #pragma unroll
@@ -168,6 +204,7 @@ __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring
                 }
             }
             // ---- conv1 of the next unit: K-step jp, all C1 columns
+            UD_STAMP(c2);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
@@ -185,12 +222,18 @@ __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring
                 __builtin_amdgcn_sched_barrier(0);
             }
             slot = slot + 1 == NS ? 0 : slot + 1;
+            UD_STAMP(c3);
             // (not __syncthreads(): its fences would drain the residual prefetch and the stores; the ring only needs this
             // wave's LDS reads of the slot to have completed)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                          // B(it): this slot may be refilled
+            UD_STAMP(c4);
+#ifdef DGP_DIAG
+            ud[4] += c1 - c0; ud[5] += c2 - c1; ud[6] += c3 - c2; ud[7] += c4 - c3;
+#endif
         }
     }
+    UD_STAMP(c0);
     // ---- epilogue of conv1: BN affine, ReLU, range, split, store R1' (block pair q = 32 channels, 8 per lane)
 #pragma unroll
     for (int q = 0; q < NCB / 2; ++q) {
@@ -214,6 +257,10 @@ __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring
             }
         }
     }
+    UD_STAMP(c1);
+#ifdef DGP_DIAG
+    ud[8] += c1 - c0;
+#endif
 }
 
 // C     channels of R2 (conv3's K), C4 = 4 C channels of X'
@@ -323,7 +370,16 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void chain_kernel(const ChainArgs
         }
         uint4 res[PD][RB][2];
         chain_prefetch<RES, RB, PD>(p, res, roff, rs_s2);
-        chain_tail<C, C1, CIN2, RES, RB, NS, PD, CHUNK, WR>(p, ring, slot, ph, pl, xoff, roff, r1off, rs_s2, rs_xo, rs_r1, amax_x, amax_r1, lane, res);
+#ifdef DGP_DIAG
+        unsigned long long ud[12] = {0};
+#endif
+        chain_tail<C, C1, CIN2, RES, RB, NS, PD, CHUNK, WR>(p, ring, slot, ph, pl, xoff, roff, r1off, rs_s2, rs_xo, rs_r1, amax_x, amax_r1, lane, res UD_ARG);
+#ifdef DGP_DIAG
+        if (wave == 0 && lane == 0) {
+            for (int i = 4; i < 9; ++i) atomicAdd(&g_unit_diag[i], ud[i]);
+            atomicAdd(&g_unit_diag[9], 1ull);
+        }
+#endif
     }
     // both tensors are post-ReLU: max = max |.|
     if (p.xout_absmax) track_absmax(p.xout_absmax, amax_x, lane, (int)(blockIdx.x * 8u + (unsigned)wave));
@@ -347,21 +403,30 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void chain_kernel(const ChainArgs
 // Weights: 9 chunks for conv2 (one tap each: [ks][cb][plane] fragments + conv2's BN affine) followed by the chain's chunks, through
 // the same ring; 9 + 8 barriers per tile.
 // Tiles are dealt so that workgroups on one XCD (blockIdx & 7) work on neighbouring tiles: halo rows are re-read from that L2.
-template <int C, int C1, int CIN2, int RES, int NCW, int NLW, int PD, int WR>
-__global__ __launch_bounds__(64 * (NCW + NLW)) void unit_kernel(const ChainArgs p) {
+template <int C, int C1, int CIN2, int RES, int NCW, int NLW, int PD, int WR, int HWV = 1>
+__global__ __launch_bounds__(64 * (NCW + NLW + HWV)) void unit_kernel(const ChainArgs p) {
+    // NLW weight-loader waves + HWV (0 / 1) halo wave.  Round 4: with the halo pieces in the weight loaders' queues (HWV = 0) the weight
+    // stream waits behind them -- a wave's vector-memory operations return in order, the halo pieces come from HBM / the Infinity Cache,
+    // the weight chunks from L2: a timing-only build without the halo DMA ran unit_c64_n64_sc 21 % faster, unit_c64_n64_id 7 %
+    // (scripts/ablate_unit.sh).  The halo wave gets a part of that back where the launch is not HBM-bound (launch_unit).
     constexpr int NS = 3;
     constexpr int TH = NCW, TW = 16, HW = TW + 2, HPIX = (TH + 2) * HW;
     constexpr int PIXB = C * 4;
     static_assert(C == 64, "one pixel of R1 = 16 slots of 16 bytes (the bank swizzle)");
     constexpr int NHI = (HPIX * PIXB + 1023) / 1024;               // DMA instructions per halo tile (4 pixels each; the last may run past
     constexpr int HALO_BYTES = NHI * 1024;                         // the tile: those lanes are out of range and write zeros into the pad)
-    static_assert(NLW == 1 || NLW == 2 || NLW == 4, "one, two or four loader waves");
+    static_assert(NLW == 1 || NLW == 2 || NLW == 4, "one, two or four weight-loader waves");
+    static_assert(HWV == 0 || HWV == 1, "at most one halo wave");
+    constexpr int NHW = HWV ? 1 : NLW;                              // waves that share a halo tile's instructions
     constexpr int C4 = 4 * C, KS1 = (C + CIN2) / 32, NJP = C4 / 32, NCB = C1 / 16;
     constexpr int NFJ = KS1 * 4 + NCB * 2 + 1;                      // fragments of a chain chunk
     constexpr int KS2 = C / 32, NCB2 = C / 16, NF2 = KS2 * NCB2 * 2 + 1;      // conv2: fragments per tap + the affine fragment
     constexpr int NFMAX = NFJ > NF2 ? NFJ : NF2, CHUNK = NFMAX * 1024;
     constexpr int STEPS = 9 + NJP;
-    constexpr int HPP = (NHI + NJP - 1) / NJP;                      // halo instructions issued per pointwise step
+    // halo instructions issued per pointwise step; the halo wave is done one step before the tile ends, so that its wait at the tile's
+    // last barrier finds the pieces landed instead of exposing their latency to every wave
+    constexpr int HSTEPS = HWV ? NJP - 1 : NJP;
+    constexpr int HPP = (NHI + HSTEPS - 1) / HSTEPS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* halo = smem;
     char* ringb = smem + HALO_BYTES;
@@ -374,14 +439,15 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void unit_kernel(const ChainArgs 
     const int tpf = p.TY * p.TX;
 
     if (wave >= NCW) {
-        // ================================ loader waves: halo tiles + weight chunks ================================
-        // wave lw copies the fragments / halo instructions i with i % NLW == lw
-        const int lw = wave - NCW;
-        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wfrag), 0, (int)p.w_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.r1in), 0, (int)p.r1in_bytes, 0x00020000);
-        auto halo_issue = [&](int tile, int i0, int i1) {
+        // ================================ loader waves: weight chunks (+ halo tiles) ================================
+        // Weight wave lw copies the fragments i with i % NLW == lw; lw is a compile-time constant inside (which fragments a wave copies
+        // and how many is then straight-line code: with a run-time lw every LDS-DMA instruction sat behind its own conditional branch,
+        // ~200 cycles per instruction instead of ~70).
+        // halo instructions [i0, i1) of a tile, every NHW-th from hl on
+        auto halo_issue = [&](int tile, int i0, int i1, int hl) {
+            const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.r1in), 0, (int)p.r1in_bytes, 0x00020000);
             const int f = tile / tpf, rem = tile - f * tpf, ty = rem / p.TX, tx = rem - ty * p.TX;
-            for (int i = i0 + lw; i < i1; i += NLW) {
+            for (int i = i0 + hl; i < i1; i += NHW) {
                 const int hp = 4 * i + (lane >> 4);
                 const int hy = (hp * 57) >> 10, hx = hp - HW * hy;                 // hp / 18 (exact for hp < 400)
                 const int gy = ty * TH - 1 + hy, gx = tx * TW - 1 + hx;
@@ -390,24 +456,53 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void unit_kernel(const ChainArgs 
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(halo + i * 1024), 16, (int)off, 0, 0, 0);
             }
         };
+        // the pointwise stage of a tile no longer reads the halo buffer (every wave passed barrier 8): the next tile's is fetched then
+        auto halo_step = [&](int cur_st, int tile, int hl) {
+#if !(defined(DGP_UX) && (DGP_UX & 32))     // (timing-only ablation: no halo tiles after the first)
+            if (cur_st >= 9 && tile + G < p.ntiles) {
+                const int i0 = (cur_st - 9) * HPP, i1 = i0 + HPP < NHI ? i0 + HPP : NHI;
+                halo_issue(tile + G, i0, i1, hl);
+            }
+#endif
+        };
+        const int lw_rt = wave - NCW;
+        if (HWV && lw_rt == NLW) {
+            // ---- the halo wave: nothing but halo pieces in its queue; they must have landed at a tile's last barrier
+            if (total > 0) halo_issue(vwg, 0, NHI, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                              // B(-1): the first halo tile has landed
+            int cur_st = 0, tile = vwg;
+            for (int it = 0; it < total; ++it) {
+                halo_step(cur_st, tile, 0);
+                if (cur_st == STEPS - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                          // B(it)
+                if (++cur_st == STEPS) { cur_st = 0; tile += G; }
+            }
+            return;
+        }
+        auto loader = [&](auto lw_c) {
+        constexpr int lw = decltype(lw_c)::value;
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wfrag), 0, (int)p.w_bytes, 0x00020000);
         int st = 0, slot = 0;                                          // step and ring slot of the NEXT chunk to issue
         // instructions of THIS wave per chunk: compile-time counts for the counted waits
-        constexpr int N2_0 = (NF2 + NLW - 1) / NLW, N2_1 = NF2 / NLW, NJ_0 = (NFJ + NLW - 1) / NLW, NJ_1 = NFJ / NLW;
+        // (wave lw issues ceil or floor of the chunk's fragments / NLW: the first `fragments % NLW` waves one more)
+        constexpr int N2 = lw < NF2 % NLW ? (NF2 + NLW - 1) / NLW : NF2 / NLW, NJ = lw < NFJ % NLW ? (NFJ + NLW - 1) / NLW : NFJ / NLW;
         auto issue = [&]() {
             char* dst = ringb + slot * CHUNK;
+#if defined(DGP_UX) && (DGP_UX & 4)      // timing-only ablation: every workgroup walks the chunks in its own rotation (results are garbage)
+            const int st2 = (st + (int)blockIdx.x) % 9, stj = (st - 9 + (int)blockIdx.x) % NJP;
+#else
+            const int st2 = st, stj = st - 9;
+#endif
             if (st < 9) {
 #pragma unroll
-                for (int k = 0; k < N2_0; ++k) {
-                    const int i = lw + k * NLW;
-                    if (i < NF2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + i * 1024), 16, lane * 16, st * (NF2 * 1024) + i * 1024, 0, 0);
-                }
+                for (int k = 0; k < N2; ++k)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + (lw + k * NLW) * 1024), 16, lane * 16, st2 * (NF2 * 1024) + (lw + k * NLW) * 1024, 0, 0);
             } else {
 #pragma unroll
-                for (int k = 0; k < NJ_0; ++k) {
-                    const int i = lw + k * NLW;
-                    if (i < NFJ) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + i * 1024), 16, lane * 16,
-                                                                          9 * (NF2 * 1024) + (st - 9) * (NFJ * 1024) + i * 1024, 0, 0);
-                }
+                for (int k = 0; k < NJ; ++k)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + (lw + k * NLW) * 1024), 16, lane * 16,
+                                                             9 * (NF2 * 1024) + stj * (NFJ * 1024) + (lw + k * NLW) * 1024, 0, 0);
             }
             const bool was_conv2 = st < 9;
             st = st + 1 == STEPS ? 0 : st + 1;
@@ -415,33 +510,52 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void unit_kernel(const ChainArgs 
             return was_conv2;
         };
         auto wait_all_but_newest = [&](bool conv2_chunk) {             // everything older than the chunk just issued has landed
-            // (wave lw issued ceil or floor of the chunk's fragments / NLW: the first `fragments % NLW` waves one more)
-            if (conv2_chunk) {
-                if (lw < NF2 % NLW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N2_0) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N2_1) : "memory");
-            } else {
-                if (lw < NFJ % NLW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ_0) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ_1) : "memory");
-            }
+            if (conv2_chunk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N2) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ) : "memory");
         };
         if (total > 0) {
-            halo_issue(vwg, 0, NHI);
+            if (!HWV) halo_issue(vwg, 0, NHI, lw);
             issue();
             wait_all_but_newest(issue());                              // (STEPS >= 2: both are conv2 chunks)
         }
-        __builtin_amdgcn_s_barrier();                                  // B(-1): the first halo tile and chunk 0 have landed
+        __builtin_amdgcn_s_barrier();                                  // B(-1): (the first halo tile and) chunk 0 have landed
         int cur_st = 0, tile = vwg;
+#ifdef DGP_DIAG
+        unsigned long long l0 = 0, l1 = 0, l2 = 0, l3 = 0, ul[3] = {0, 0, 0}, ul3 = 0;
+#endif
         for (int it = 0; it < total; ++it) {
-            // the pointwise stage of this tile no longer reads the halo buffer (every wave passed barrier 8): fetch the next tile's
-            if (cur_st >= 9 && tile + G < p.ntiles) {
-                const int i0 = (cur_st - 9) * HPP, i1 = i0 + HPP < NHI ? i0 + HPP : NHI;
-                halo_issue(tile + G, i0, i1);
-            }
+            UD_STAMP(l0);
+            if (!HWV) halo_step(cur_st, tile, lw);                     // (older than the chunk issued below: landed when its wait returns)
+#ifdef DGP_DIAG
+            bool c2_ = false;
+            if (it + 2 < total) c2_ = issue();
+            UD_STAMP(l1);
+            if (it + 2 < total) wait_all_but_newest(c2_);
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            UD_STAMP(l2);
+#else
             if (it + 2 < total) wait_all_but_newest(issue());
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             __builtin_amdgcn_s_barrier();                              // B(it)
+            UD_STAMP(l3);
+#ifdef DGP_DIAG
+            if (cur_st < 9) ul[0] += l1 - l0; else ul3 += l1 - l0;
+            ul[1] += l2 - l1; ul[2] += l3 - l2;
+#endif
             if (++cur_st == STEPS) { cur_st = 0; tile += G; }
         }
+#ifdef DGP_DIAG
+        if (lw == 0 && lane == 0) {
+            atomicAdd(&g_unit_diag[12], ul[0]); atomicAdd(&g_unit_diag[13], ul[1]); atomicAdd(&g_unit_diag[14], ul[2]); atomicAdd(&g_unit_diag[11], ul3);
+            atomicAdd(&g_unit_diag[15], (unsigned long long)total);
+        }
+#endif
+        };
+        if (lw_rt == 0) loader(std::integral_constant<int, 0>());
+        else if (NLW > 1 && lw_rt == 1) loader(std::integral_constant<int, (NLW > 1 ? 1 : 0)>());
+        else if (NLW > 2 && lw_rt == 2) loader(std::integral_constant<int, (NLW > 2 ? 2 : 0)>());
+        else if (NLW > 3) loader(std::integral_constant<int, (NLW > 3 ? 3 : 0)>());
         return;
     }
 
@@ -454,7 +568,12 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void unit_kernel(const ChainArgs 
     int slot = 0;
     float amax_x = 0.f, amax_r1 = 0.f, amax_r2 = 0.f;
     __builtin_amdgcn_s_barrier();                                      // B(-1)
+#ifdef DGP_DIAG
+    unsigned long long ud[12] = {0}, u0 = 0, u1 = 0, u2 = 0, ubeg = 0, uend = 0;
+    UD_STAMP(ubeg);
+#endif
     for (int tile = vwg; tile < p.ntiles; tile += G) {
+        UD_STAMP(u0);
         const int f = tile / tpf, rem = tile - f * tpf, ty = rem / p.TX, tx = rem - ty * p.TX;
         const int y = ty * TH + wave, x = tx * TW + l15;
         const bool ok = y < p.H && x < p.W;
@@ -478,8 +597,13 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void unit_kernel(const ChainArgs 
 #pragma unroll
         for (int cb = 0; cb < NCB2; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
         uint4 aff[KS2][4];
+        UD_STAMP(u1);
+#ifdef DGP_DIAG
+        ud[3] += u1 - u0;
+#endif
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
+            UD_STAMP(u0);
             const uint4* Wc = ring + slot * (CHUNK / 16);
             const uint4* W = Wc + lane;
             const int hp = (wave + t / 3) * HW + l15 + t % 3;
@@ -495,8 +619,13 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void unit_kernel(const ChainArgs 
             }
             constexpr int NW2 = KS2 * NCB2 * 2;
             uint4 wq[WR];
+#if defined(DGP_UX) && (DGP_UX & 8)      // timing-only ablation: the weight fragments are not read from LDS
+#define UX_W(i) make_uint4(lane, i, slot, t)
+#else
+#define UX_W(i) W[(i) * 64]
+#endif
 #pragma unroll
-            for (int f = 0; f < WR && f < NW2; ++f) wq[f] = W[f * 64];
+            for (int f = 0; f < WR && f < NW2; ++f) wq[f] = UX_W(f);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < KS2; ++ks) {
@@ -504,15 +633,20 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void unit_kernel(const ChainArgs 
                 for (int cb = 0; cb < NCB2; ++cb) {
                     const int f0 = (ks * NCB2 + cb) * 2;
                     const uint4 wh = wq[f0 % WR], wl = wq[(f0 + 1) % WR];
+#if defined(DGP_UX) && (DGP_UX & 16)     // timing-only ablation: no MFMAs
+                    acc[cb][0] += __builtin_bit_cast(float, wh.x ^ wl.y ^ ah[ks].x ^ al[ks].y);
+#else
                     acc[cb] = mma16(wl, ah[ks], acc[cb]);
                     acc[cb] = mma16(wh, al[ks], acc[cb]);
                     acc[cb] = mma16(wh, ah[ks], acc[cb]);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
-                    if (f0 + WR < NW2) wq[f0 % WR] = W[(f0 + WR) * 64];
-                    if (f0 + 1 + WR < NW2) wq[(f0 + 1) % WR] = W[(f0 + 1 + WR) * 64];
+                    if (f0 + WR < NW2) wq[f0 % WR] = UX_W(f0 + WR);
+                    if (f0 + 1 + WR < NW2) wq[(f0 + 1) % WR] = UX_W(f0 + 1 + WR);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#undef UX_W
             if (t == 8) {                                              // conv2's BN affine rides in the last tap's chunk
 #pragma unroll
                 for (int q = 0; q < KS2; ++q) {
@@ -521,9 +655,15 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void unit_kernel(const ChainArgs 
                 }
             }
             slot = slot + 1 == NS ? 0 : slot + 1;
+            UD_STAMP(u1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            UD_STAMP(u2);
+#ifdef DGP_DIAG
+            ud[0] += u1 - u0; ud[1] += u2 - u1;
+#endif
         }
+        UD_STAMP(u0);
         // ---- epilogue of conv2 = operand of conv3: BN affine, ReLU, range, split with R2's scale
 #pragma unroll
         for (int q = 0; q < KS2; ++q) {
@@ -540,8 +680,18 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void unit_kernel(const ChainArgs 
                 for (int k = 0; k < 8; ++k) amax_r2 = fmaxf(amax_r2, o[k]);
             }
         }
-        chain_tail<C, C1, CIN2, RES, 1, NS, PD, CHUNK, WR>(p, ring, slot, ph, pl, xoff, roff, r1off, rs_s2, rs_xo, rs_r1, amax_x, amax_r1, lane, res);
+        UD_STAMP(u1);
+#ifdef DGP_DIAG
+        ud[2] += u1 - u0; ud[9] += 1;
+#endif
+        chain_tail<C, C1, CIN2, RES, 1, NS, PD, CHUNK, WR>(p, ring, slot, ph, pl, xoff, roff, r1off, rs_s2, rs_xo, rs_r1, amax_x, amax_r1, lane, res UD_ARG);
     }
+#ifdef DGP_DIAG
+    UD_STAMP(uend);
+    ud[10] = uend - ubeg;
+    if (wave == 0 && lane == 0)
+        for (int i = 0; i < 11; ++i) atomicAdd(&g_unit_diag[i], ud[i]);
+#endif
     if (p.xout_absmax) track_absmax(p.xout_absmax, amax_x, lane, (int)(blockIdx.x * 8u + (unsigned)wave));
     if (p.r1_absmax) track_absmax(p.r1_absmax, amax_r1, lane, (int)(blockIdx.x * 8u + (unsigned)wave) + 97);
     if (p.r2_absmax) track_absmax(p.r2_absmax, amax_r2, lane, (int)(blockIdx.x * 8u + (unsigned)wave) + 41);
@@ -615,16 +765,30 @@ hipError_t launch_chain_t(const ChainArgs& a0, hipStream_t s) {
     int grid = ncu * wgs_per_cu[dev];
     if (grid > a.ntiles) grid = a.ntiles;
     if (grid < 1) return hipSuccess;
+#ifdef DGP_DIAG
+    unsigned long long hz[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_unit_diag), hz, sizeof(hz));
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * (NCW + NLW)), LDS, s, a);
+#ifdef DGP_DIAG
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(hz, HIP_SYMBOL(g_unit_diag), sizeof(hz));
+    const double nt = (double)hz[9] > 0 ? (double)hz[9] : 1.0, ns = (double)hz[15] > 0 ? (double)hz[15] : 1.0;
+    printf("[diag chain C %d C1 %d CIN2 %d] grid %d tiles %d (%.1f per workgroup) | compute wave 0, cycles per TILE: prologue %.0f | conv2: 9 x (work %.0f + barrier %.0f) "
+           "epilogue %.0f | chain: %d x (conv3 %.0f + epilogue %.0f + conv1 %.0f + barrier %.0f) conv1 epilogue %.0f | tile loop %.0f per tile | "
+           "loader wave 0, cycles per STEP: issue %.0f (conv2 steps) / %.0f (pointwise steps), vmcnt wait %.0f, barrier %.0f\n", C, C1, CIN2, grid, a.ntiles, (double)a.ntiles / grid,
+           hz[3] / nt, hz[0] / nt / 9.0, hz[1] / nt / 9.0, hz[2] / nt, 4 * C / 32, hz[4] / nt / (4 * C / 32), hz[5] / nt / (4 * C / 32), hz[6] / nt / (4 * C / 32),
+           hz[7] / nt / (4 * C / 32), hz[8] / nt, hz[10] * (double)grid / nt / grid, hz[12] / (ns * 9.0 / (9.0 + 4 * C / 32)), hz[11] / (ns * (4 * C / 32) / (9.0 + 4 * C / 32)), hz[13] / ns, hz[14] / ns);
+#endif
     return hipGetLastError();
 }
 
-template <int C, int C1, int CIN2, int RES, int NCW, int NLW, int PD, int WR = 4>
+template <int C, int C1, int CIN2, int RES, int NCW, int NLW, int PD, int WR = 4, int HWV = 1>
 hipError_t launch_unit_t(const ChainArgs& a0, int N, hipStream_t s) {
     constexpr int NFJ = (C + CIN2) / 32 * 4 + C1 / 16 * 2 + 1, NF2 = (C / 32) * (C / 16) * 2 + 1, NFMAX = NFJ > NF2 ? NFJ : NF2;
     constexpr int LDS = ((NCW + 2) * 18 * C * 4 + 1023) / 1024 * 1024 + 3 * NFMAX * 1024;
     static_assert(LDS <= 160 * 1024, "halo tile + ring do not fit the LDS");
-    auto kern = unit_kernel<C, C1, CIN2, RES, NCW, NLW, PD, WR>;
+    auto kern = unit_kernel<C, C1, CIN2, RES, NCW, NLW, PD, WR, HWV>;
     static bool attr_done[16] = {};
     static int wgs_per_cu[16] = {};
     const int dev = dgp_device_slot();
@@ -632,7 +796,7 @@ hipError_t launch_unit_t(const ChainArgs& a0, int N, hipStream_t s) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         int occ = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * (NCW + NLW), LDS);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * (NCW + NLW + HWV), LDS);
         if (e != hipSuccess) return e;
         static const int force = dgp_tune("DGP_CHAIN_WGS", 0);
         wgs_per_cu[dev] = force > 0 ? force : (occ < 1 ? 1 : occ);
@@ -648,7 +812,21 @@ hipError_t launch_unit_t(const ChainArgs& a0, int N, hipStream_t s) {
     int grid = ncu * wgs_per_cu[dev];
     if (grid > a.ntiles) grid = a.ntiles;
     if (grid < 1) return hipSuccess;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * (NCW + NLW)), LDS, s, a);
+#ifdef DGP_DIAG
+    unsigned long long hz[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_unit_diag), hz, sizeof(hz));
+#endif
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * (NCW + NLW + HWV)), LDS, s, a);
+#ifdef DGP_DIAG
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(hz, HIP_SYMBOL(g_unit_diag), sizeof(hz));
+    const double nt = (double)hz[9] > 0 ? (double)hz[9] : 1.0, ns = (double)hz[15] > 0 ? (double)hz[15] : 1.0;
+    printf("[diag unit  C %d C1 %d CIN2 %d] grid %d tiles %d (%.1f per workgroup) | compute wave 0, cycles per TILE: prologue %.0f | conv2: 9 x (work %.0f + barrier %.0f) "
+           "epilogue %.0f | chain: %d x (conv3 %.0f + epilogue %.0f + conv1 %.0f + barrier %.0f) conv1 epilogue %.0f | tile loop %.0f per tile | "
+           "loader wave 0, cycles per STEP: issue %.0f (conv2 steps) / %.0f (pointwise steps), vmcnt wait %.0f, barrier %.0f\n", C, C1, CIN2, grid, a.ntiles, (double)a.ntiles / grid,
+           hz[3] / nt, hz[0] / nt / 9.0, hz[1] / nt / 9.0, hz[2] / nt, 4 * C / 32, hz[4] / nt / (4 * C / 32), hz[5] / nt / (4 * C / 32), hz[6] / nt / (4 * C / 32),
+           hz[7] / nt / (4 * C / 32), hz[8] / nt, hz[10] * (double)grid / nt / grid, hz[12] / (ns * 9.0 / (9.0 + 4 * C / 32)), hz[11] / (ns * (4 * C / 32) / (9.0 + 4 * C / 32)), hz[13] / ns, hz[14] / ns);
+#endif
     return hipGetLastError();
 }
 
@@ -674,14 +852,18 @@ hipError_t launch_unit(const ChainArgs& a, int N, int C, int C1, int CIN2, int r
         // (measured on the batch-32 640x480 shape, ms per launch: 8 rows + 2 loader waves 0.41-0.42; 10 rows 0.42-0.43; 8 rows + 4 loader
         //  waves 0.42-0.43 -- the weight stream is not the pace; 4 rows + 1 loader, two workgroups per CU 0.56-0.67: 4.5 KB of weight
         //  fragments per pixel; four residual buffers (three chunks ahead, requested before conv2) 0.57: spills at the 168-register cap)
-        if (cfg == 1) return launch_unit_t<64, 64, 0, 1, 8, 4, 2, 4>(a, N, s);
-        if (cfg == 2) return launch_unit_t<64, 64, 0, 1, 10, 2, 2, 4>(a, N, s);
-        return launch_unit_t<64, 64, 0, 1, 8, 2, 2, 4>(a, N, s);
+        if (cfg == 1) return launch_unit_t<64, 64, 0, 1, 8, 4, 2, 4, 0>(a, N, s);          // (12 waves: a 13th would cap the registers at 128)
+        if (cfg == 2) return launch_unit_t<64, 64, 0, 1, 10, 2, 2, 4, 0>(a, N, s);
+        if (cfg == 3) return launch_unit_t<64, 64, 0, 1, 8, 2, 2, 4, 1>(a, N, s);          // with the halo wave
+        // (identity units move 1.57 GB per launch at 3.6-3.7 TB/s: the halo wave measured -2 % on one box, +1 / +1.5 % on two others)
+        return launch_unit_t<64, 64, 0, 1, 8, 2, 2, 4, 0>(a, N, s);
     }
     if (C == 64 && C1 == 64 && CIN2 == 64 && res == 0) {
-        if (cfg == 1) return launch_unit_t<64, 64, 64, 0, 8, 4, 2, 8>(a, N, s);
-        if (cfg == 2) return launch_unit_t<64, 64, 64, 0, 10, 2, 2, 8>(a, N, s);
-        return launch_unit_t<64, 64, 64, 0, 8, 2, 2, 8>(a, N, s);
+        if (cfg == 1) return launch_unit_t<64, 64, 64, 0, 8, 4, 2, 8, 0>(a, N, s);
+        if (cfg == 2) return launch_unit_t<64, 64, 64, 0, 10, 2, 2, 8, 0>(a, N, s);
+        if (cfg == 3) return launch_unit_t<64, 64, 64, 0, 8, 2, 2, 8, 0>(a, N, s);          // no halo wave: the halo pieces in the weight loaders' queues
+        // (halo wave: 0.402 / 0.402 -> 0.367 / 0.378 ms alternating on one box, 0.406-0.417 -> 0.391-0.411 on two others)
+        return launch_unit_t<64, 64, 64, 0, 8, 2, 2, 8, 1>(a, N, s);
     }
     return hipErrorInvalidValue;
 }
@@ -702,20 +884,27 @@ hipError_t launch_chain(const ChainArgs& a, int C, int C1, int CIN2, int res, hi
         if (cfg == 1) return launch_chain_t<64, 64, 0, 1, 2, 5, 1, 4>(a, s);
         if (cfg == 2) return launch_chain_t<64, 64, 0, 1, 2, 4, 1, 2>(a, s);
         if (cfg == 3) return launch_chain_t<64, 64, 0, 1, 1, 11, 1, 4>(a, s);
+        if (cfg == 4) return launch_chain_t<64, 64, 0, 1, 1, 8, 2, 4>(a, s);          // more loader waves (4 / 5: two / four)
+        if (cfg == 5) return launch_chain_t<64, 64, 0, 1, 1, 8, 4, 4>(a, s);
         return launch_chain_t<64, 64, 0, 1, 1, 8, 1, 4>(a, s);
     }
     if (C == 64 && C1 == 64 && CIN2 == 64 && res == 0) {
         if (cfg == 1) return launch_chain_t<64, 64, 64, 0, 2, 5, 1, 2>(a, s);
+        if (cfg == 4) return launch_chain_t<64, 64, 64, 0, 1, 8, 2, 2>(a, s);
+        if (cfg == 5) return launch_chain_t<64, 64, 64, 0, 1, 8, 4, 2>(a, s);
         return launch_chain_t<64, 64, 64, 0, 1, 8, 1, 2>(a, s);
     }
     if (C == 64 && C1 == 128 && CIN2 == 0 && res == 2) {
         if (cfg == 1) return launch_chain_t<64, 128, 0, 2, 2, 5, 1, 4>(a, s);
+        if (cfg == 4) return launch_chain_t<64, 128, 0, 2, 1, 8, 2, 4>(a, s);
+        if (cfg == 5) return launch_chain_t<64, 128, 0, 2, 1, 8, 4, 4>(a, s);
         return launch_chain_t<64, 128, 0, 2, 1, 8, 1, 4>(a, s);
     }
     if (C == 128 && C1 == 128 && CIN2 == 0 && res == 1) {
         if (cfg == 1) return launch_chain_t<128, 128, 0, 1, 1, 8, 2, 4, 3, 4>(a, s);
         if (cfg == 2) return launch_chain_t<128, 128, 0, 1, 1, 8, 2, 2, 3, 8>(a, s);
         if (cfg == 3) return launch_chain_t<128, 128, 0, 1, 1, 6, 2, 2, 3, 8>(a, s);
+        if (cfg == 4 || cfg == 5) return launch_chain_t<128, 128, 0, 1, 1, 8, 4, 2, 3, 4>(a, s);
         return launch_chain_t<128, 128, 0, 1, 1, 8, 2, 2, 3, 4>(a, s);
     }
     if (C == 128 && C1 == 256 && CIN2 == 0 && res == 2) {
