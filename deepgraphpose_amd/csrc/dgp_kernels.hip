@@ -1359,17 +1359,19 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK
                     const int doff = DGP_RFL(((dh * p.W + dw) * p.Cin + a_ch) * 4);
                     char* dst = smA + sa * (A_CELLS * 16) + a_dst0;
                     if (MODE == 2) {
+                        // (source, base and stride are chosen ONCE per step, by selects: with the choice inside the loop every LDS-DMA
+                        //  instruction sat behind its own branch -- the cost the unit kernel's loader showed, DESIGN section 6a'')
                         const bool second = p.in2 && a_ch >= p.cin_split;
                         const int d2 = DGP_RFL((a_ch - p.cin_split) * 4);
+                        const __amdgpu_buffer_rsrc_t rs_a = second ? rs_in2 : rs_in;
+                        const unsigned base_a = second ? rowbase2 + (unsigned)d2 : rowbase + (unsigned)doff;
+                        const int stride_a = second ? rstride2 : rstride;
 #pragma unroll
                         for (int i = 0; i < AROWS; ++i) {
 #if defined(DGP_FEEDX) && (DGP_FEEDX & 1)
                             if (it < 0)
 #endif
-                            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in2, (lds_void*)(dst + i * (32 * 128)), 16,
-                                                                                 (int)(rowbase2 + (unsigned)(d2 + i * rstride2)), 0, 0, 0);
-                            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(dst + i * (32 * 128)), 16,
-                                                                          (int)(rowbase + (unsigned)(doff + i * rstride)), 0, 0, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(dst + i * (32 * 128)), 16, (int)(base_a + (unsigned)(i * stride_a)), 0, 0, 0);
                         }
                     } else {
                         const bool tapok = DGP_RFL(a_tap) < p.ntaps;
