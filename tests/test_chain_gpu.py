@@ -196,3 +196,21 @@ np.savez(sys.argv[1], sc=sc.cpu().numpy(), mu=mu.cpu().numpy(), idx=idx.cpu().nu
     assert np.array_equal(a["idx"], b["idx"])
     assert np.abs(a["mu"] - b["mu"]).max() * 8.0 < 2e-4            # px; both within 1e-3 of the oracle (test_parity_gpu.py)
     assert np.abs(a["sc"] - b["sc"]).max() <= 2e-5 * np.abs(b["sc"]).max()
+
+
+def test_other_workgroup_shapes_of_the_fused_kernels_in_child_processes(lib_built, tuning_build):
+    """The unit / chain kernels have alternative workgroup shapes behind tuning knobs (DGP_UNIT_CFG: four weight-loader waves, ten-row tiles,
+    the halo wave swapped between the two unit instances; DGP_CHAIN_CFG: row blocks per wave, loader waves, ring depth).  The arithmetic per
+    pixel does not depend on the shape: the layer tests of this file must pass unchanged under each of them (tuning builds only)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for var, values in (("DGP_UNIT_CFG", ("1", "2", "3")), ("DGP_CHAIN_CFG", ("1", "4", "5"))):
+        for v in values:
+            env = dict(os.environ, PYTHONPATH=root)
+            env[var] = v
+            r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_chain_gpu.py"), "-q", "-m", "gpu", "-k",
+                                "test_chain_matches_float64 or test_unit_kernel_matches_float64"], env=env, cwd=root,
+                               capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, (var, v, r.stdout[-1500:] + r.stderr[-500:])
