@@ -426,7 +426,11 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
             pix[u][0] = px[0]; pix[u][1] = px[1]; pix[u][2] = px[2];
         }
     };
-    if ((int)blockIdx.x < p.ntiles) fetch(blockIdx.x);
+#ifndef DGP_SX
+#define DGP_SX 0      // timing-only ablations of the phases (scripts/ablate_stem.sh; results are garbage): 1 no input fetch, 2 no phase 1,
+#endif                // 4 no MFMAs, 8 no phase-3 tile store, 16 no pooling reads, 32 no global stores
+    if (!(DGP_SX & 1) && (int)blockIdx.x < p.ntiles) fetch(blockIdx.x);
+    if (DGP_SX & 1) for (int u = 0; u < NPX; ++u) { pix[u][0] = t; pix[u][1] = u; pix[u][2] = lane; }
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int n = tile / (p.tiles_h * p.tiles_w), rem = tile - n * (p.tiles_h * p.tiles_w);
         const int ph0 = (rem / p.tiles_w) * PH, pw0 = (rem % p.tiles_w) * PW;
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
 #pragma unroll
         for (int u = 0; u < NPX; ++u) {
             const int q = t + 512 * u;
-            if (q < IR * IC) {
+            if (!(DGP_SX & 2) && q < IR * IC) {
                 const int r = q / IC, c = q - r * IC;
                 const int gr = ir0 + r, gc = ic0 + c;
                 half2v x01 = {(_Float16)0.f, (_Float16)0.f}, x23 = x01;
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
             }
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < p.ntiles) fetch(tile + gridDim.x);
+        if (!(DGP_SX & 1) && tile + (int)gridDim.x < p.ntiles) fetch(tile + gridDim.x);
         // ---- phase 2: GEMM
         floatx4 acc[3][4];
 #pragma unroll
@@ -477,6 +481,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
                     const uint4 ah = *reinterpret_cast<const uint4*>(sHi + abase[i] + kh * IC);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
+                        if (DGP_SX & 4) { acc[i][j][0] += __builtin_bit_cast(float, ah.x ^ bl[j].y ^ bh[j].z); continue; }
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah), __builtin_bit_cast(half8, bl[j]), acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
                     }
@@ -496,6 +501,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float v = fmaxf(acc[i][j][r] * sc4[j][0] + bi4[j][0], 0.f);
+                        if (DGP_SX & 8) { amax = fmaxf(amax, v); continue; }
                         sC[m * LDC + 16 * j + l15] = ok ? v : 0.f;
                     }
                 }
@@ -514,6 +520,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
 #pragma unroll
                 for (int b = 0; b < 3; ++b) {
                     const float* src = sC + ((2 * ph + a) * SC + 2 * pw + b) * LDC + 8 * cg;
+                    if (DGP_SX & 16) { v[0] = fmaxf(v[0], (float)(a + b + q)); continue; }
                     const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
                     v[0] = fmaxf(v[0], x0.x); v[1] = fmaxf(v[1], x0.y); v[2] = fmaxf(v[2], x0.z); v[3] = fmaxf(v[3], x0.w);
                     v[4] = fmaxf(v[4], x1.x); v[5] = fmaxf(v[5], x1.y); v[6] = fmaxf(v[6], x1.z); v[7] = fmaxf(v[7], x1.w);
@@ -522,7 +529,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
                 uint4 hi, lo;
                 h2_pack8(v, p.out_scale, hi, lo);
                 uint4* dst = reinterpret_cast<uint4*>(p.out + ((((size_t)n * p.HP + ph0 + ph) * p.WP + pw0 + pw) * 64 + 8 * cg));
-                dst[0] = hi; dst[1] = lo;
+                if (!(DGP_SX & 32)) { dst[0] = hi; dst[1] = lo; } else amax = fmaxf(amax, __builtin_bit_cast(float, hi.x ^ lo.y));
 #pragma unroll
                 for (int k = 0; k < 8; ++k) amax = fmaxf(amax, v[k]);
             }
