@@ -218,7 +218,8 @@ def main():
                     help="weak: --steps batches per GPU; strong: --total-batches batches in all, rank r runs its contiguous share")
     ap.add_argument("--total-batches", type=int, default=1024, help="strong scaling: batches of the one fixed stream (1024 x 32 = 32768 frames)")
     ap.add_argument("--no-strict-f32", action="store_true", help="skip the child-process legs after the timed region: DGP_CONV_MODE=f32 (IEEE fp32 MFMA tier), the 16-bit tier, ResNet-101 1280x720, the training step and the PCIe-inclusive estimate_pose run")
-    ap.add_argument("--no-host-pipeline", action="store_true", help="skip the PCIe-inclusive estimate_pose child run (4096 host frames)")
+    ap.add_argument("--no-host-pipeline", action="store_true", help="skip the PCIe-inclusive estimate_pose child run")
+    ap.add_argument("--host-frames", type=int, default=4096, help="host frames of the PCIe-inclusive estimate_pose child run (a multiple of 16)")
     ap.add_argument("--no-r101", action="store_true", help="skip the ResNet-101 1280x720 child run (BASELINE configs[4] per-GPU shape)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-step child run (BASELINE configs[3]) after the timed region")
     ap.add_argument("--train-steps", type=int, default=60, help="timed steps of the training-step child run")
@@ -612,7 +613,7 @@ def main():
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "DGP_CONV_MODE"):
             env.pop(k, None)
         try:
-            cp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_pipeline.py"), "4096", "--json"], env=env, capture_output=True,
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_pipeline.py"), str(args.host_frames), "--json"], env=env, capture_output=True,
                                 text=True, timeout=300)
             ln = [q for q in cp.stdout.splitlines() if q.startswith("{")]
             out["host_pipeline"] = json.loads(ln[-1]) if cp.returncode == 0 and ln else {"error": (cp.stderr or cp.stdout)[-300:]}

@@ -252,7 +252,9 @@ def test_bench_through_its_own_spawner(lib_built):
     """`python bench.py --gpus N` with no launcher around it spawns its N workers itself (the parent never touches the GPU) and relays
     rank 0's line.  Here N = 1 through the spawner (DGP_BENCH_FORCE_SPAWN=1): RCCL group of one rank, the strict-fp32 child run included."""
     d = _run_bench(["--gpus", "1", "--steps", "6", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--sustain-seconds", "0.3",
-                    "--prewarm-seconds", "0.2", "--train-steps", "3", "--no-r101"], DGP_BENCH_FORCE_SPAWN=1)
+                    "--prewarm-seconds", "0.2", "--train-steps", "3", "--no-r101", "--host-frames", "128"], DGP_BENCH_FORCE_SPAWN=1)
+    hp = d["host_pipeline"]                                 # the PCIe-inclusive estimate_pose leg, also a fresh child
+    assert "error" not in hp and hp["frames"] == 128 and hp["frames_per_s"] > 0 and hp["host_seconds"]["drain_s"] >= 0
     ts = d["train_step"]                                    # BASELINE configs[3], timed by a fresh child of the same run
     assert "error" not in ts and 0 < ts["ms_per_step"] < 200 and ts["frames_per_step"] == 11 and 0 < ts["frac"] < 1 and np.isfinite(ts["loss"]["total_loss"])
     assert "spawned 1 worker" in d["launcher"] and d["n_gpus"] == 1 and d["steps"] == 6 and d["value"] > 0
