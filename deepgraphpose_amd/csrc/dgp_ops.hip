@@ -783,7 +783,10 @@ hipError_t launch_hard_argmax(const float* scmap, const float* locref, int B, in
 // strided passes over H W values (the map is a column of the [B,H,W,C] tensor: stride C).
 __global__ __launch_bounds__(256) void pmap_threshold_kernel(float* __restrict__ pmap, int H, int W, int C, float th,
                                                              float* __restrict__ mu) {
-    __shared__ float red[3][4];
+    // The sums run in double: a relative error d of the normaliser moves mu by d x mu, and 200 fp32 additions per thread on a 250 x 250 map
+    // left mu 1.3-2.1e-3 px from float64 (scripts/fuzz_readout.py); the stored map and mu stay fp32 like the reference's.
+    __shared__ float red[4];
+    __shared__ double redd[3][4];
     const int c = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     float* p = pmap + (size_t)b * H * W * C + c;
     const int n = H * W;
@@ -791,33 +794,32 @@ __global__ __launch_bounds__(256) void pmap_threshold_kernel(float* __restrict__
     for (int i = t; i < n; i += 256) m = fmaxf(m, p[(size_t)i * C]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if (lane == 0) red[0][wave] = m;
+    if (lane == 0) red[wave] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     const float cut = m * th;
-    float s = 0.f;
-    for (int i = t; i < n; i += 256) { const float v = p[(size_t)i * C]; s += v < cut ? 0.f : v; }
+    double sd = 0.0;
+    for (int i = t; i < n; i += 256) { const float v = p[(size_t)i * C]; sd += v < cut ? 0.0 : (double)v; }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    for (int o = 32; o > 0; o >>= 1) sd += __shfl_xor(sd, o, 64);
+    if (lane == 0) redd[0][wave] = sd;
     __syncthreads();
-    if (lane == 0) red[0][wave] = s;
-    __syncthreads();
-    s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    float sh = 0.f, sw = 0.f;
+    const float s = (float)((redd[0][0] + redd[0][1]) + (redd[0][2] + redd[0][3]));
+    double sh = 0.0, sw = 0.0;
     for (int i = t; i < n; i += 256) {
         const float v = p[(size_t)i * C];
         const float q = (v < cut ? 0.f : v) / s;           // (+ 1e-100 in the reference: 0 in fp32; an all-zero map gives NaN there too)
         p[(size_t)i * C] = q;
         const int h = i / W, w = i - h * W;
-        sh += q * (float)h; sw += q * (float)w;
+        sh += (double)q * (double)h; sw += (double)q * (double)w;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { sh += __shfl_xor(sh, o, 64); sw += __shfl_xor(sw, o, 64); }
-    if (lane == 0) { red[1][wave] = sh; red[2][wave] = sw; }
+    if (lane == 0) { redd[1][wave] = sh; redd[2][wave] = sw; }
     __syncthreads();
     if (t == 0) {
-        mu[((size_t)b * C + c) * 2 + 0] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-        mu[((size_t)b * C + c) * 2 + 1] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+        mu[((size_t)b * C + c) * 2 + 0] = (float)((redd[1][0] + redd[1][1]) + (redd[1][2] + redd[1][3]));
+        mu[((size_t)b * C + c) * 2 + 1] = (float)((redd[2][0] + redd[2][1]) + (redd[2][2] + redd[2][3]));
     }
 }
 

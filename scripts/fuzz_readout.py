@@ -50,9 +50,16 @@ for it in range(n):
     mu_t = engine.pmap_threshold(torch.from_numpy(pmap.copy()).cuda(), th).cpu().numpy()
     mu_t64, _ = O.argmax_2d_from_cm(s, gamma, gl, dtype=np.float64, th=th)
     mu_t32, _ = O.argmax_2d_from_cm(s, gamma, gl, th=th)
-    # (a cell within rounding of th x max may fall on either side of the threshold: accept either the fp32 or the fp64 oracle's answer)
-    et = min(float(np.abs(mu_t - mu_t64).max()), float(np.abs(mu_t - mu_t32).max())) * 8.0
-    ok = ok and (et < max(1e-3, slack) or mode == 1)
+    # thresholding is discontinuous: a cell within rounding of th x max may fall on either side.  Judge only the (frame, joint) maps whose
+    # closest cell keeps a relative margin of 1e-5 from the threshold in float64 (the kernel's pmap is within ~1e-7 relative of it)
+    _, pm64 = O.argmax_2d_from_cm(s, gamma, gl, dtype=np.float64)
+    thr = pm64.max(axis=(1, 2), keepdims=True) * th
+    margin = (np.abs(pm64 - thr) / np.maximum(thr, 1e-300)).min(axis=(1, 2))              # [B, C]
+    clear = margin > 1e-5
+    d64 = np.abs(mu_t - mu_t64).max(axis=2) * 8.0                                         # [B, C] px
+    et = float(np.where(clear, d64, 0.0).max())
+    nborder = int((~clear).sum())
+    ok = ok and et < max(1e-3, slack)
     hi, hp, _ = engine.hard_argmax(t)
     for b in range(B):
         sig = O.sigmoid_f32(s[b])
@@ -62,7 +69,7 @@ for it in range(n):
         same = np.array_equal(hi[b].cpu().numpy(), loc_ref) or float(s[b].max()) > 15.0
         ok = ok and same
     fails += 0 if ok else 1
-    print("%s  %3d x %3d  C %2d B %d gamma %6.2f gl %d mode %d  mu vs fp64 %.1e px (fp32 oracle %.1e)  pmap %.1e  th %.2f: %.1e px"
-          % ("ok  " if ok else "FAIL", H, W, C, B, gamma, gl, mode, e64, e32, ep, th, et), flush=True)
+    print("%s  %3d x %3d  C %2d B %d gamma %6.2f gl %d mode %d  mu vs fp64 %.1e px (fp32 oracle %.1e)  pmap %.1e  th %.2f: %.1e px (%d borderline maps skipped)"
+          % ("ok  " if ok else "FAIL", H, W, C, B, gamma, gl, mode, e64, e32, ep, th, et, nborder), flush=True)
 print("failures: %d" % fails)
 sys.exit(1 if fails else 0)

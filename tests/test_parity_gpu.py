@@ -179,6 +179,27 @@ def test_soft_argmax_known_answers(eng):
         assert abs(mu[0, 0, 1].item() - exp1(c, W)) < 1e-5
 
 
+def test_threshold_branch_on_large_maps_stays_within_the_gate(eng):
+    """argmax_2d_from_cm's th branch on maps of ~50 000 cells (flat, and noisy with a broad softmax): a relative error d of the
+    normaliser moves mu by d x mu, so the kernel sums in double -- with fp32 sums it was 1.3-2.1e-3 px from float64 here
+    (found by scripts/fuzz_readout.py)."""
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(5)
+    for (H, W, C, gamma, gl, th, flat) in ((211, 254, 3, 10.45, 2, 0.30, True), (254, 222, 2, 2.63, 4, 0.13, True), (230, 240, 2, 1.0, 3, 0.45, False)):
+        s = np.zeros((1, H, W, C), dtype=np.float32)
+        if not flat:            # one strong peak per map far from the centre: the cells that survive the cut are the blur's taps around it
+            s += (0.05 * rng.standard_normal(s.shape)).astype(np.float32)
+            s[0, 201, 17, 0] += 14.0
+            s[0, 9, 222, 1] += 14.0
+        mu, conf, idx, pmap = eng.soft_argmax(torch.from_numpy(s).cuda(), gamma, gl, want_pmap=True)
+        mu_t = eng.pmap_threshold(pmap.clone(), th).cpu().numpy()
+        mu64, pm64 = O.argmax_2d_from_cm(s, gamma, gl, dtype=np.float64, th=th)
+        _, pm = O.argmax_2d_from_cm(s, gamma, gl, dtype=np.float64)
+        thr = pm.max(axis=(1, 2), keepdims=True) * th
+        assert (np.abs(pm - thr) / thr).min() > 1e-5            # no cell sits on the threshold: the comparison is well defined
+        assert np.abs(mu_t - mu64).max() * STRIDE < 2e-4, (H, W, float(np.abs(mu_t - mu64).max() * STRIDE))
+
+
 def test_likelihood_tie_takes_first(eng):
     s = np.zeros((1, 6, 6, 1), dtype=np.float32)          # flat map: mu = centre 2.5, window 2x2, all tied
     mu, conf, idx = eng.soft_argmax(torch.from_numpy(s).cuda(), 1.0, 1)
