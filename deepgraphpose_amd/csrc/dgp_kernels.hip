@@ -2290,6 +2290,7 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
                 }
             } else {           // fp32 output: pointwise GEMMs only (the heads, layer tests)
                 if (mode != 2) return hipErrorInvalidValue;
+                if (a.res && a.res_fmt) return hipErrorInvalidValue;      // (its epilogue adds an fp32 residual: H2 cells would be read as floats)
                 if (dma) {
                     if constexpr (CAN_DMA) kern = conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 2, CAN_DMA, CAN_DMA, CAN_DMA, false>;
                     if constexpr (CAN_DEEP) if (deep) kern = conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, 2, CAN_DEEP, CAN_DEEP, CAN_DEEP, false, CAN_DEEP>;

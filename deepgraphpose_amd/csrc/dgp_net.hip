@@ -1321,6 +1321,8 @@ int dgp_conv2d_h2(const dgp_conv_desc* d, const void* x_h2, int32_t x_exp, const
     if (d->Cin < 32 || (d->Cin & 7) || ((d->Cin / 4) & (d->Cin / 4 - 1)) || (d->Cout & 7))
         return fail(DGP_ERR_INVALID, "dgp_conv2d_h2: Cin must be 4 * 2^k >= 32, Cout a multiple of 8");
     if (d->res_stride > 0 && !residual) return fail(DGP_ERR_INVALID, "dgp_conv2d_h2: residual missing");
+    if (d->res_stride > 0 && res_is_h2 && !y_is_h2)
+        return fail(DGP_ERR_INVALID, "dgp_conv2d_h2: an H2 residual needs an H2 output (the fp32-output epilogue adds fp32 residuals only)");
     ConvArgs a{};
     a.in = (const float*)x_h2; a.wpk = packed_w; a.scale = scale; a.bias = bias; a.res = d->res_stride > 0 ? (const float*)residual : nullptr;
     a.out = (float*)y; a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.log2cin4 = ilog2(d->Cin / 4);

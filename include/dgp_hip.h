@@ -292,7 +292,9 @@ int    dgp_conv2d_dgrad(const dgp_conv_desc* d, const float* dy, const float* w_
 int  dgp_f32_to_h2(const float* x, size_t n_floats, int32_t scale_exp, void* out, void* stream);
 int  dgp_h2_to_f32(const void* x, size_t n_floats, int32_t scale_exp, float* out, void* stream);
 /* dgp_conv2d on H2 tensors: x (H2, exponent x_exp) -> y (H2 with y_exp, or fp32 when y_is_h2 == 0); residual fp32 or H2.
- * w_absmax: range slots of packed_w (dgp_tensor_absmax); cells_scratch: >= dgp_packed_weight_floats(...) * 4 device bytes. */
+ * w_absmax: range slots of packed_w (dgp_tensor_absmax); cells_scratch: >= dgp_packed_weight_floats(...) * 4 device bytes.
+ * fp32 output exists for 1x1 / stride-1 layers only (the heads' pointwise GEMM) and takes an fp32 residual; every other combination
+ * with y_is_h2 == 0, and an H2 residual with an fp32 output, returns DGP_ERR_INVALID. */
 int  dgp_conv2d_h2(const dgp_conv_desc* d, const void* x_h2, int32_t x_exp, const float* packed_w, const float* w_absmax,
                    const float* scale, const float* bias, const void* residual, int32_t res_is_h2, int32_t res_exp, void* y,
                    int32_t y_is_h2, int32_t y_exp, float* y_absmax, void* cells_scratch, void* stream);

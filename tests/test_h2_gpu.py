@@ -428,3 +428,20 @@ np.savez(sys.argv[2], mu=mu.cpu().numpy(), idx=idx.cpu().numpy())
     out = np.load(tmp_path / "out.npz")
     assert np.abs(out["mu"] - ref["mu"]).max() * 8.0 < 1e-3
     assert np.array_equal(out["idx"], ref["idx"])
+
+
+def test_h2_residual_with_an_fp32_output_is_rejected(lib_built):
+    """The fp32-output epilogue (the heads' pointwise GEMM) adds fp32 residuals only; with an H2 residual it used to read the cells as
+    floats and return garbage (found by scripts/fuzz_conv_h2.py).  The combination is DGP_ERR_INVALID now; the fp32 residual still works."""
+    from deepgraphpose_amd import _lib, engine
+    rng = np.random.default_rng(3)
+    x = torch.relu(torch.randn((2, 9, 11, 64), device="cuda"))
+    res = torch.randn((2, 9, 11, 128), device="cuda")
+    w = (rng.standard_normal((1, 1, 64, 128)) / 8.0).astype(np.float32)
+    xe = engine.h2_exp_for(float(x.abs().max())); xh = engine.f32_to_h2(x, xe)
+    re_ = engine.h2_exp_for(float(res.abs().max())); rh = engine.f32_to_h2(res, re_)
+    with pytest.raises(_lib.DgpError, match="H2 residual needs an H2 output"):
+        engine.conv2d_h2(xh, xe, w, residual=rh, res_stride=1, res_is_h2=True, res_exp=re_, y_is_h2=False)
+    y, _ = engine.conv2d_h2(xh, xe, w, residual=res, res_stride=1, res_is_h2=False, y_is_h2=False)
+    ref = torch.einsum("nhwc,co->nhwo", engine.h2_to_f32(xh, xe).double(), torch.from_numpy(w[0, 0]).double().cuda()) + res.double()
+    assert float((y.double() - ref).abs().max() / ref.abs().max()) < 2e-5
