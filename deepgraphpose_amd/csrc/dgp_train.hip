@@ -2792,7 +2792,9 @@ int dgp_conv2d_dgrad(const dgp_conv_desc* d, const float* dy, const float* w_hwi
                      const float* dx_add, int32_t add_mode, float* dx, void* scratch, int32_t ranged, void* stream) {
     g_ctx = nullptr;
     if (!d || !dy || !w_hwio || !dx || !scratch) return fail(DGP_ERR_INVALID, "dgp_conv2d_dgrad: null argument");
-    if ((ranged & 2) && (!(ranged & 1) || !mask || (d->Cin & 7))) return fail(DGP_ERR_INVALID, "dgp_conv2d_dgrad: an H2 gate needs ranged bit 0, a mask and Cin % 8 == 0");
+    // (Cin < 64: dx goes through the 32-column fp32 tile, which reads the gate as fp32 -- garbage with H2 cells; found by scripts/fuzz_backward_layers.py)
+    if ((ranged & 2) && (!(ranged & 1) || !mask || (d->Cin & 7) || d->Cin < 64))
+        return fail(DGP_ERR_INVALID, "dgp_conv2d_dgrad: an H2 gate needs ranged bit 0, a mask and Cin % 8 == 0, Cin >= 64");
     if ((d->Cout & 31) || (d->Cin & 3)) return fail(DGP_ERR_INVALID, "dgp_conv2d_dgrad: Cout % 32, Cin % 4");
     hipStream_t s = (hipStream_t)stream;
     const int taps = d->KH * d->KW, nkT = nk_for(d->KH, d->KW, d->Cout), cinP = coutp_for(d->Cin);

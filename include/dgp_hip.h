@@ -263,7 +263,8 @@ int  dgp_conv2d_ranged(const dgp_conv_desc* d, const float* x, const float* pack
  *                      (DGP_ABSMAX_SLOTS floats each) and a tile of 128 x 128 the fp16-split kernel runs, else fp32 MFMA.
  *   dgp_conv2d_dgrad : dx = gate(convT(dy; w * scale) + dx_add); w_hwio device HWIO weights; scale [Cout] or NULL; mask [N,H,W,Cin]
  *                      or NULL (gate: mask > 0); dx_add NULL, or a gradient on dx's grid (add_mode 1) or on the 2x coarser grid
- *                      (add_mode -2, the subsample shortcut).  scratch: dgp_conv2d_dgrad_scratch_bytes(d) device bytes. */
+ *                      (add_mode -2, the subsample shortcut).  scratch: dgp_conv2d_dgrad_scratch_bytes(d) device bytes.
+ *                      Cout % 32 == 0, Cin % 4 == 0; ranged bit 1 (the gate is an H2 tensor): bit 0, a mask, Cin % 8 == 0 and Cin >= 64. */
 int    dgp_conv2d_wgrad(const dgp_conv_desc* d, const float* x, const float* dy, const float* x_absmax, const float* dy_absmax,
                         float* dw_raw, float* colsum, void* stream);
 /* dgp_conv2d_wgrad on the LDS-DMA tile of the training step (csrc/dgp_train.hip, wgrad_dma).  Inside dgp_train_backward both operands

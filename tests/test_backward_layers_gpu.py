@@ -399,3 +399,18 @@ def test_full_size_backward_is_stable_across_repeats(lib_built):
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-800:])
     worst = float(r.stdout.strip().splitlines()[-1].split("first pass")[1].split()[0])
     assert worst < 1e-5, r.stdout[-400:]
+
+
+def test_dgrad_rejects_an_h2_gate_on_fewer_than_64_channels(lib_built):
+    """dx with 32 channels goes through the 32-column fp32 tile, which reads the gate as fp32: with H2 cells the result was garbage
+    (found by scripts/fuzz_backward_layers.py; the network has no such layer).  DGP_ERR_INVALID now; the fp32 gate works."""
+    from deepgraphpose_amd import _lib, engine
+    g = torch.Generator(device="cuda").manual_seed(5)
+    dy = torch.randn((2, 7, 9, 64), generator=g, device="cuda") * 1e-3
+    w = torch.randn((1, 1, 32, 64), generator=g, device="cuda") / 6.0
+    mask = torch.relu(torch.randn((2, 7, 9, 32), generator=g, device="cuda"))
+    with pytest.raises(_lib.DgpError, match="Cin >= 64"):
+        engine.conv2d_dgrad(dy, w, (7, 9), mask=mask, ranged=True, mask_h2=True)
+    dx = engine.conv2d_dgrad(dy, w, (7, 9), mask=mask, ranged=True, mask_h2=False)
+    ref = torch.where(mask > 0, _dgrad_ref(dy.double(), w.double(), 7, 9, 1, 1, 0, 0), torch.zeros((2, 7, 9, 32), dtype=torch.float64, device="cuda"))
+    assert float((dx.double() - ref).abs().max() / ref.abs().max()) < REL_TOL
