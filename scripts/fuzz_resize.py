@@ -1,0 +1,44 @@
+"""One engine through a random sequence of frame sizes and batch sizes (dgp_net_set_input_size; DLC's step-0 loader changes the size every
+iteration): parity with the oracle at every stop, sizes above and below the size the net was created with, returning to earlier sizes, frames of
+very different brightness between stops (the activation scales must be re-calibrated, not reused).  Usage: python scripts/fuzz_resize.py [n] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from deepgraphpose_amd import engine
+from deepgraphpose_amd.synthetic import make_frames, make_weights
+from oracle import dgp_oracle as O
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for it in range(n):
+    nj = int(rng.integers(1, 6)); depth = 101 if rng.integers(0, 6) == 0 else 50
+    wts = make_weights(depth, nj, False, seed=int(rng.integers(0, 1000)), head_std=0.05)
+    h0, w0, B = int(rng.integers(48, 140)), int(rng.integers(48, 160)), int(rng.integers(1, 5))
+    net = engine.DGPNet(depth, nj, h0, w0, max_batch=B)
+    net.load_weights(wts)
+    sizes = [(h0, w0)]
+    for stop in range(7):
+        if stop and rng.integers(0, 3) == 0:
+            h, w = sizes[int(rng.integers(0, len(sizes)))]                   # back to an earlier size
+        else:
+            h, w = int(rng.integers(40, 150)), int(rng.integers(40, 170))
+        sizes.append((h, w))
+        net.set_input_size(h, w)
+        b = int(rng.integers(1, B + 1))
+        fr = make_frames(b, h, w, nj, seed=int(rng.integers(0, 1000)))
+        kind = int(rng.integers(0, 4))
+        if kind == 1:
+            fr = (fr // 8).astype(np.uint8)                                   # a dark clip after a bright one
+        elif kind == 2:
+            fr = np.clip(fr.astype(np.int32) * 2 + 60, 0, 255).astype(np.uint8)
+        mu, conf, idx = net.infer(torch.from_numpy(fr).cuda(), 1.0, 1)
+        if net.range_status()[0]:                                             # the documented protocol: an overflowed forward is re-run
+            mu, conf, idx = net.infer(torch.from_numpy(fr).cuda(), 1.0, 1)
+            assert not net.range_status()[0]
+        ref = O.infer(fr, wts, depth, 8.0, 1.0, 1)
+        d = float(np.abs(mu.cpu().numpy() - ref["mu"]).max() * 8.0)
+        ok = d < 1e-3 and np.array_equal(idx.cpu().numpy(), ref["idx"]) and float(np.abs(conf.cpu().numpy() - ref["likelihoods"]).max()) < 1e-4
+        bad += not ok
+        print("%s net %d (R%d nj %d, created %d x %d, max batch %d) stop %d: %3d x %3d batch %d kind %d   %.1e px" % ("ok  " if ok else "BAD ", it, depth, nj, h0, w0, B, stop, h, w, b, kind, d), flush=True)
+print("failures:", bad)
+sys.exit(1 if bad else 0)
