@@ -17,6 +17,7 @@ run fuzz_conv_f32 $((200 * K)) $SEED           # fp32-activation tiles, max-pool
 run fuzz_backward_layers $((100 * K)) $SEED    # weight-gradient tiles, data gradient
 run fuzz_train $((14 * K)) $SEED               # whole DGP training steps vs fp64 autograd
 run fuzz_dlc                                   # DLC (step-0) training steps
+mv "$OUT/fuzz_dlc.log" "$OUT/fuzz_dlc_single.log"; run fuzz_dlc --sequence     # ... one trainer through five frame sizes in a row
 run fuzz_motion $((150 * K)) $SEED             # motion-energy scan, whole and chunked
 echo "fuzz_all: $([ $rc -eq 0 ] && echo clean || echo FAILURES)"
 exit $rc
