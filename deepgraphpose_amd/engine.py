@@ -140,19 +140,20 @@ class DGPNet:
         B = frames.shape[0]
         if tuple(frames.shape[1:]) != (self.in_h, self.in_w, 3):
             raise _lib.DgpError("frames must be [B,%d,%d,3], got %s" % (self.in_h, self.in_w, tuple(frames.shape)))
-        ws = self.workspace(B)
         scmap = torch.empty((B, self.out_h, self.out_w, self.nj), dtype=torch.float32, device=self.device)
         locref = torch.empty((B, self.out_h, self.out_w, 2 * self.nj), dtype=torch.float32,
                              device=self.device) if want_locref else None
         feats = torch.empty((B, self.feat_h, self.feat_w, 2048), dtype=torch.float32,
                             device=self.device) if want_features else None
-        for attempt in range(5):
+        ws = self.workspace(B) if B else None
+        for attempt in range(5 if B else 0):           # (an empty batch -- e.g. the empty shard of a short video -- gives empty outputs, like sess.run)
             _lib.check(self.lib.dgp_forward(self._h, _ptr(frames), B, _ptr(ws), ws.numel(), _ptr(scmap), _ptr(locref),
                                             _ptr(feats), _stream(self.device)), "dgp_forward")
             if not check_range or not self.range_status()[0]:
                 break
         else:
-            raise _lib.DgpError("dgp_forward: activation ranges still overflow after 4 re-calibrations (non-finite weights or input?)")
+            if B:
+                raise _lib.DgpError("dgp_forward: activation ranges still overflow after 4 re-calibrations (non-finite weights or input?)")
         out = [scmap]
         if want_locref:
             out.append(locref)
@@ -171,13 +172,15 @@ class DGPNet:
         B = frames.shape[0]
         if tuple(frames.shape[1:]) != (self.in_h, self.in_w, 3):
             raise _lib.DgpError("frames must be [B,%d,%d,3], got %s" % (self.in_h, self.in_w, tuple(frames.shape)))
-        ws = self.workspace(B)
         if out is None:
             mu = torch.empty((B, self.nj, 2), dtype=torch.float32, device=self.device)
             conf = torch.empty((B, self.nj), dtype=torch.float32, device=self.device)
             idx = torch.empty((B, self.nj, 2), dtype=torch.int32, device=self.device)
         else:
             mu, conf, idx = out
+        if B == 0:                                      # an empty batch gives empty outputs, like sess.run
+            return mu, conf, idx
+        ws = self.workspace(B)
         for attempt in range(5):
             _lib.check(self.lib.dgp_infer(self._h, _ptr(frames), B, _ptr(ws), ws.numel(), float(gamma), int(gauss_len),
                                           _ptr(mu), _ptr(conf), _ptr(idx), _ptr(scmap_out), _stream(self.device)),
@@ -356,6 +359,8 @@ def soft_argmax(scmap: torch.Tensor, gamma: float = 1.0, gauss_len: int = 2, wan
     conf = torch.empty((B, Cn), dtype=torch.float32, device=dev)
     idx = torch.empty((B, Cn, 2), dtype=torch.int32, device=dev)
     pmap = torch.empty_like(scmap) if want_pmap else None
+    if B * Cn == 0 and H > 0 and W > 0:                 # no frames or no joints: empty outputs
+        return (mu, conf, idx, pmap) if want_pmap else (mu, conf, idx)
     _lib.check(lib.dgp_soft_argmax(_ptr(scmap), B, H, W, Cn, float(gamma), int(gauss_len), _ptr(mu), _ptr(conf),
                                    _ptr(idx), _ptr(pmap), _stream(dev)), "dgp_soft_argmax")
     return (mu, conf, idx, pmap) if want_pmap else (mu, conf, idx)
@@ -370,6 +375,8 @@ def pmap_threshold(pmap: torch.Tensor, th: float) -> torch.Tensor:
         raise _lib.DgpError("pmap must be a contiguous rank-4 tensor [B,H,W,C]")
     B, H, W, Cn = pmap.shape
     mu = torch.empty((B, Cn, 2), dtype=torch.float32, device=pmap.device)
+    if B * Cn == 0 and H > 0 and W > 0:
+        return mu
     _lib.check(lib.dgp_pmap_threshold(_ptr(pmap), B, H, W, Cn, float(th), _ptr(mu), _stream(pmap.device)), "dgp_pmap_threshold")
     return mu
 
@@ -387,6 +394,8 @@ def hard_argmax(scmap: torch.Tensor, locref: Optional[torch.Tensor] = None):
     idx = torch.empty((B, Cn, 2), dtype=torch.int32, device=dev)
     prob = torch.empty((B, Cn), dtype=torch.float32, device=dev)
     offs = torch.empty((B, Cn, 2), dtype=torch.float32, device=dev)
+    if B * Cn == 0 and H > 0 and W > 0:
+        return idx, prob, offs
     _lib.check(lib.dgp_hard_argmax(_ptr(scmap), _ptr(locref), B, H, W, Cn, _ptr(idx), _ptr(prob), _ptr(offs),
                                    _stream(dev)), "dgp_hard_argmax")
     return idx, prob, offs

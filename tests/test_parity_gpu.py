@@ -200,6 +200,22 @@ def test_threshold_branch_on_large_maps_stays_within_the_gate(eng):
         assert np.abs(mu_t - mu64).max() * STRIDE < 2e-4, (H, W, float(np.abs(mu_t - mu64).max() * STRIDE))
 
 
+def test_empty_batches_give_empty_outputs(eng):
+    """No frames (the empty shard of a short video) or no joints: well-defined empty results, like sess.run on an empty feed --
+    not an error about a null pointer (scripts/probe_edges.py walks the other degenerate arguments)."""
+    from deepgraphpose_amd.synthetic import make_weights
+    z = torch.zeros((0, 8, 8, 3), dtype=torch.float32, device="cuda")
+    mu, conf, idx = eng.soft_argmax(z)
+    assert mu.shape == (0, 3, 2) and conf.shape == (0, 3) and idx.shape == (0, 3, 2)
+    assert eng.soft_argmax(torch.zeros((2, 8, 8, 0), device="cuda"))[0].shape == (2, 0, 2)
+    assert eng.hard_argmax(z)[0].shape == (0, 3, 2) and eng.pmap_threshold(z, 0.5).shape == (0, 3, 2)
+    net = eng.DGPNet(50, 3, 64, 96, max_batch=2)
+    net.load_weights(make_weights(50, 3, False, seed=1, head_std=0.05))
+    e = torch.zeros((0, 64, 96, 3), dtype=torch.uint8, device="cuda")
+    assert net.infer(e)[0].shape == (0, 3, 2) and net.forward(e).shape == (0, 8, 12, 3)
+    assert eng.motion_energy(torch.zeros((0, 8, 8, 3), dtype=torch.uint8, device="cuda")).shape == (0,)
+
+
 def test_likelihood_tie_takes_first(eng):
     s = np.zeros((1, 6, 6, 1), dtype=np.float32)          # flat map: mu = centre 2.5, window 2x2, all tied
     mu, conf, idx = eng.soft_argmax(torch.from_numpy(s).cuda(), 1.0, 1)
