@@ -333,7 +333,7 @@ def write_v2(prefix: str, tensors: Dict[str, np.ndarray]):
     off = 0
     with open(prefix + ".data-00000-of-00001", "wb") as data:
         for name in sorted(tensors):
-            a = np.ascontiguousarray(tensors[name], dtype="<f4")
+            a = np.asarray(tensors[name], dtype="<f4", order="C")       # (not ascontiguousarray: it turns a scalar into shape (1,))
             raw = a.tobytes()
             entry = _pb_int(1, DT_FLOAT) + _pb_bytes(2, _encode_shape(a.shape))
             if off:
@@ -347,12 +347,12 @@ def write_v2(prefix: str, tensors: Dict[str, np.ndarray]):
 
 # ------------------------------------------------------------------------------------------- V1 tensor-slice files
 def _parse_tensor_proto(buf: bytes) -> np.ndarray:
-    dtype, shape, content, floats = 0, (), None, []
+    dtype, shape, content, floats, have_shape = 0, (), None, [], False
     for fn, wt, v in _pb_fields(buf):
         if fn == 1:
             dtype = v
         elif fn == 2:
-            shape = _parse_shape(v)
+            shape, have_shape = _parse_shape(v), True
         elif fn == 4:
             content = v
         elif fn == 5:                                 # float_val: packed (wt 2) or single fixed32 (wt 5)
@@ -362,7 +362,12 @@ def _parse_tensor_proto(buf: bytes) -> np.ndarray:
     if content is not None:
         return np.frombuffer(content, dtype="<f4").reshape(shape).copy()
     a = np.concatenate(floats) if floats else np.zeros(0, dtype=np.float32)
-    return a.reshape(shape).copy() if shape else a
+    if not have_shape:
+        return a
+    n = int(np.prod(shape, dtype=np.int64))               # (an empty shape is a scalar: one element)
+    if 0 < a.size < n:                                    # TensorProto: a short float_val repeats its last value
+        a = np.concatenate([a, np.full(n - a.size, a[-1], dtype=np.float32)])
+    return a.reshape(shape).copy()
 
 
 def read_v1(path: str) -> Dict[str, np.ndarray]:
@@ -398,7 +403,7 @@ def write_v1(path: str, tensors: Dict[str, np.ndarray]):
                            _pb_bytes(4, full))
     tw.add(b"", _pb_bytes(1, metas))
     for i, name in enumerate(sorted(tensors)):
-        a = np.ascontiguousarray(tensors[name], dtype="<f4")
+        a = np.asarray(tensors[name], dtype="<f4", order="C")
         full = b"".join(_pb_bytes(1, b"") for _ in a.shape)
         tp = _pb_int(1, DT_FLOAT) + _pb_bytes(2, _encode_shape(a.shape)) + _pb_bytes(5, a.tobytes())
         key = b"\x00" + name.encode() + b"\x00\x01" + bytes([len(a.shape)]) + b"\x00" * i      # ordered & unique; readers ignore it
@@ -407,8 +412,23 @@ def write_v1(path: str, tensors: Dict[str, np.ndarray]):
 
 
 # ------------------------------------------------------------------------------------------- front door
+def _is_table(path: str) -> bool:
+    """Does the file end in the SSTable footer magic (V1 checkpoint files and V2 .index files do)?"""
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, os.SEEK_END)
+            if f.tell() < 48:
+                return False
+            f.seek(-8, os.SEEK_END)
+            return struct.unpack("<Q", f.read(8))[0] == TABLE_MAGIC
+    except OSError:
+        return False
+
+
 def is_tf_checkpoint(path: str) -> bool:
-    return os.path.isfile(path + ".index") or (os.path.isfile(path) and path.endswith(".ckpt"))
+    """A V2 prefix (<path>.index exists) or a V1 file -- recognised by the table magic, whatever it is called (DLC's resnet_v1_50.ckpt, a
+    snapshot-N file without suffix); an .npz snapshot is not one."""
+    return os.path.isfile(path + ".index") or (os.path.isfile(path) and _is_table(path))
 
 
 def load_checkpoint(path: str) -> Dict[str, np.ndarray]:

@@ -232,3 +232,26 @@ def test_v2_reader_rejects_truncated_and_corrupt_files(tmp_path):
     open(prefix + ".data-00000-of-00001", "wb").write(bytes(flipped))
     with pytest.raises(ValueError, match="checksum"):
         tfc.read_v2(prefix, verify=True)
+
+
+def test_scalars_keep_rank_zero_and_v1_files_are_recognised_by_content(tmp_path):
+    """Found by scripts/fuzz_tf_checkpoint.py: both writers turned a rank-0 variable into shape (1,) (np.ascontiguousarray promotes 0-d arrays), the V1
+    parser returned the flat array for an EMPTY shape field (a scalar) as if the field were missing, and a V1 file was only recognised when its name
+    ended in .ckpt.  Also TensorProto's rule that a short float_val repeats its last value."""
+    from deepgraphpose_amd import tf_checkpoint as tfc
+    tensors = {"a/scalar": np.float32(2.5), "a/vec": np.arange(3, dtype=np.float32), "a/empty": np.zeros((0, 4), np.float32)}
+    v2 = str(tmp_path / "model.ckpt-7")
+    tfc.write_v2(v2, tensors)
+    v1 = str(tmp_path / "snapshot_without_suffix")
+    tfc.write_v1(v1, tensors)
+    for got in (tfc.read_v2(v2, verify=True), tfc.read_v1(v1), tfc.load_checkpoint(v1)):
+        assert got["a/scalar"].shape == () and float(got["a/scalar"]) == 2.5
+        assert got["a/vec"].shape == (3,) and got["a/empty"].shape == (0, 4)
+    assert tfc.is_tf_checkpoint(v1) and tfc.is_tf_checkpoint(v2)
+    npz = str(tmp_path / "weights.npz")
+    np.savez(npz, **{k.replace("/", "__"): v for k, v in tensors.items()})
+    assert not tfc.is_tf_checkpoint(npz) and not tfc.is_tf_checkpoint(str(tmp_path / "missing"))
+    # a TensorProto whose float_val holds ONE value for a [2, 3] tensor (TF stores constant tensors that way)
+    proto = tfc._pb_int(1, tfc.DT_FLOAT) + tfc._pb_bytes(2, tfc._encode_shape((2, 3))) + tfc._pb_bytes(5, np.float32(7.0).tobytes())
+    t = tfc._parse_tensor_proto(proto)
+    assert t.shape == (2, 3) and (t == 7.0).all()
