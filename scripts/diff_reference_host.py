@@ -17,8 +17,14 @@ ds = G.load(os.path.join(REF, "deepgraphpose/dataset.py"), "ref_dataset")
 pdd = G.load(os.path.join(REF, "DeepLabCut/deeplabcut/pose_estimation_tensorflow/dataset/pose_defaultdataset.py"), "ref_pose_defaultdataset")
 predict = G.load(os.path.join(REF, "DeepLabCut/deeplabcut/pose_estimation_tensorflow/nnet/predict.py"), "ref_predict")
 from deepgraphpose_amd import dataset as D
+from deepgraphpose_amd import config as K
 from deepgraphpose_amd.models import fitdgp_util as F
+from deepgraphpose_amd.models.fitdgp import _limb_statistics
 from oracle import dgp_oracle as O
+import make_reaching_golden as GR
+FIT = os.path.join(REF, "deepgraphpose/models/fitdgp.py")
+S0_LINES = GR.cut(FIT, "bodyparts = cfg['bodyparts']", "S0[s, skj] = -1")                                   # fitdgp.py:607-617
+LIMB_LINES = GR.cut(FIT, "joint_locs = [d.labels for d in data_batcher.datasets]", "limb_full) + 1e-20) * dgp_cfg.ws")   # :875-892
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -107,6 +113,31 @@ for it in range(n):
             check("coord2map", same(lt_r.astype(np.float64), lt_o) and same(lm_r.astype(np.uint8), lm_o.astype(np.uint8)), (thr, njt, size))
     except Exception as e:      # noqa: BLE001
         check("locref targets raised", False, repr(e)[:160])
+    # ---- skeleton matrix and limb statistics: the reference's own lines (fitdgp.py:607-617, :875-892), exec'd as the golden generator does
+    njs = int(rng.integers(2, 9))
+    parts = ["part%d" % i for i in range(njs)]
+    pairs = [tuple(rng.choice(njs, 2, replace=False)) for _ in range(int(rng.integers(1, 8)))]
+    proj = dict(bodyparts=parts, skeleton=[[parts[a], parts[b]] for a, b in pairs])
+    try:
+        ns_ = dict(np=np, cfg=proj); exec(S0_LINES, ns_)
+        S0r = np.asarray(ns_["S0"], dtype=np.float64)
+        S0o = np.asarray(K.skeleton_matrix(proj), dtype=np.float64)
+        check("skeleton_matrix", same(S0r, S0o), (njs, pairs))
+        labels = []
+        for dset in range(int(rng.integers(1, 4))):
+            lab = rng.uniform(0, 60, size=(int(rng.integers(1, 30)), njs, 2))
+            lab[rng.random(lab.shape[:2]) < rng.uniform(0, 0.5)] = np.nan
+            labels.append(lab)
+        ws_c, wsmax_c, stride_c = float(rng.choice([1.0, 1000.0, 3.5])), float(rng.choice([1.2, 2.0])), float(rng.choice([8.0, 4.0]))
+        AD = GR.AttrDict
+        ns_ = dict(np=np, data_batcher=AD(datasets=[AD(labels=l) for l in labels]), nj=njs, S0=S0r, dgp_cfg=AD(stride=stride_c, ws=ws_c, ws_max=wsmax_c))
+        with np.errstate(all="ignore"):
+            exec(LIMB_LINES, ns_)
+            ws_o, wsmax_o = _limb_statistics(labels, S0r, stride_c, ws_c, wsmax_c)
+        close = lambda a, b: np.allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), rtol=1e-12, atol=0, equal_nan=True)
+        check("limb statistics", close(ns_["ws"], ws_o) and close(ns_["ws_max"], wsmax_o), (njs, len(labels), np.asarray(ns_["ws"])[:3], np.asarray(ws_o)[:3]))
+    except Exception as e:      # noqa: BLE001
+        check("limb statistics raised", False, repr(e)[:160])
     # ---- DLC hard arg-max (the oracle's restatement against the reference's function)
     h, w, c = int(rng.integers(1, 40)), int(rng.integers(1, 50)), int(rng.integers(1, 8))
     logits = (rng.standard_normal((h, w, c)) * rng.uniform(0.5, 20)).astype(np.float32)
