@@ -24,6 +24,7 @@ from oracle import dgp_oracle as O
 import make_reaching_golden as GR
 FIT = os.path.join(REF, "deepgraphpose/models/fitdgp.py")
 S0_LINES = GR.cut(FIT, "bodyparts = cfg['bodyparts']", "S0[s, skj] = -1")                                   # fitdgp.py:607-617
+EXPORT_LINES = GR.cut(os.path.join(REF, "deepgraphpose/models/eval.py"), "def export_pose_like_dlc(labels, scorer, joints_names, save_file):", "def evaluate_dgp(", include_last=False)
 LIMB_LINES = GR.cut(FIT, "joint_locs = [d.labels for d in data_batcher.datasets]", "limb_full) + 1e-20) * dgp_cfg.ws")   # :875-892
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
@@ -138,6 +139,35 @@ for it in range(n):
         check("limb statistics", close(ns_["ws"], ws_o) and close(ns_["ws_max"], wsmax_o), (njs, len(labels), np.asarray(ns_["ws"])[:3], np.asarray(ws_o)[:3]))
     except Exception as e:      # noqa: BLE001
         check("limb statistics raised", False, repr(e)[:160])
+    # ---- A5: the DLC export (eval.py:621-653), the reference's function text exec'd; to_hdf needs pytables, which neither side has here
+    if it % 5 == 0:
+        import pandas as pd, tempfile
+        from deepgraphpose_amd.models import eval as E
+        nfr, nlab = int(rng.integers(0, 40)), int(rng.integers(1, 9))
+        lab = {k: rng.standard_normal((nfr, nlab)) * 10.0 ** rng.integers(-3, 5) for k in ("x", "y", "likelihoods")}
+        if nfr:
+            lab["x"][rng.integers(0, nfr), 0] = np.nan
+        names = ["part %d/%s" % (i, "ab_c"[i % 4:]) for i in range(nlab)]      # (no commas: the reference's genfromtxt loader cannot read quoted fields)
+        td = tempfile.mkdtemp()
+        ns_ = dict(np=np, os=os); exec(EXPORT_LINES, ns_)
+        hdf = pd.DataFrame.to_hdf
+        try:
+            pd.DataFrame.to_hdf = lambda self, *a, **k: None
+            ns_["export_pose_like_dlc"](lab, "snapshot-5", names, os.path.join(td, "ref"))
+        finally:
+            pd.DataFrame.to_hdf = hdf
+        E.export_pose_like_dlc(lab, "snapshot-5", names, os.path.join(td, "ours"))
+        a, b = open(os.path.join(td, "ref.csv")).read(), open(os.path.join(td, "ours.csv")).read()
+        check("export_pose_like_dlc csv", a == b, (nfr, nlab))
+        if nfr:             # (a NaN is an empty csv field, which the reference's loader cannot convert: both sides must then fail alike)
+            res = []
+            for fn, path in ((ns_["load_pose_from_dlc_to_dict"], "ref.csv"), (E.load_pose_from_dlc_to_dict, "ours.csv")):
+                try: res.append(fn(os.path.join(td, path)))
+                except Exception as e: res.append(type(e).__name__)     # noqa: BLE001,E701
+            if isinstance(res[0], str) or isinstance(res[1], str):
+                check("load_pose_from_dlc_to_dict", res[0] == res[1], (res[0] if isinstance(res[0], str) else "ok", res[1] if isinstance(res[1], str) else "ok"))
+            else:
+                check("load_pose_from_dlc_to_dict", all(same(res[0][k], res[1][k]) for k in ("x", "y", "likelihoods")))
     # ---- DLC hard arg-max (the oracle's restatement against the reference's function)
     h, w, c = int(rng.integers(1, 40)), int(rng.integers(1, 50)), int(rng.integers(1, 8))
     logits = (rng.standard_normal((h, w, c)) * rng.uniform(0.5, 20)).astype(np.float32)
