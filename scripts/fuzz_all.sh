@@ -16,6 +16,7 @@ run fuzz_fused $((120 * K)) $SEED              # chain / unit kernels
 run fuzz_conv_f32 $((200 * K)) $SEED           # fp32-activation tiles, max-pool, H2 converters
 run fuzz_backward_layers $((100 * K)) $SEED    # weight-gradient tiles, data gradient
 run fuzz_train $((14 * K)) $SEED               # whole DGP training steps vs fp64 autograd
+mv "$OUT/fuzz_train.log" "$OUT/fuzz_train_single.log"; run fuzz_train $((12 * K)) $SEED --sequence     # ... one trainer through four different steps in a row
 run fuzz_dlc                                   # DLC (step-0) training steps
 mv "$OUT/fuzz_dlc.log" "$OUT/fuzz_dlc_single.log"; run fuzz_dlc --sequence     # ... one trainer through five frame sizes in a row
 run fuzz_motion $((150 * K)) $SEED             # motion-energy scan, whole and chunked

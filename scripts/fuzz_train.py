@@ -1,5 +1,7 @@
 """Random training-step configurations (frame size, frames, bodyparts, visible frames, loss variant) against the fp64 autograd oracle.
-Usage: python scripts/fuzz_train.py [n] [seed]"""
+Usage: python scripts/fuzz_train.py [n] [seed] [--sequence]
+--sequence: ONE trainer per (frame size, bodyparts, skeleton) taken through four steps in a row with different frame counts, visible frames, loss
+variants and brightness -- the trainer predicts a step's tensor scales from the previous step's ranges, so nothing stale may survive a change."""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,27 +11,41 @@ from deepgraphpose_amd.arch import scoremap_hw
 from deepgraphpose_amd.loss import DGPHyper
 from deepgraphpose_amd.synthetic import make_frames, make_weights
 from deepgraphpose_amd.train import Trainer
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+SEQ = "--sequence" in sys.argv
+n = int(args[0]) if len(args) > 0 else 10
+rng = np.random.default_rng(int(args[1]) if len(args) > 1 else 0)
 bad = 0
+tr = None
 for k in range(n):
-    hw = (int(rng.integers(48, 161)), int(rng.integers(48, 161)))
-    nt, nj = int(rng.integers(2, 6)), int(rng.integers(1, 7))
+    if not SEQ or k % 4 == 0:
+        hw = (int(rng.integers(48, 161)), int(rng.integers(48, 161)))
+        nt_max, nj = int(rng.integers(2, 6)), int(rng.integers(1, 7))
+        seed = int(rng.integers(1 << 20))
+        wts = make_weights(50, nj, True, seed=seed, head_std=0.05)
+        nl = 0 if nj < 2 else int(np.random.default_rng(seed).integers(0, 4))
+        tr = None
+    nt = nt_max if not SEQ else int(rng.integers(1, nt_max + 1))
     nvf = int(rng.integers(0, nt + 1))
     gm2, gm3 = [(0, 0), (1, 3), (2, 3), (1, 0)][int(rng.integers(0, 4))]
     H, W = scoremap_hw(*hw)
-    seed = int(rng.integers(1 << 20))
+    seed = int(rng.integers(1 << 20)) if SEQ else seed
     r2 = np.random.default_rng(seed)
-    nl = 0 if nj < 2 else int(r2.integers(0, 4))
+    if not SEQ:
+        nl = 0 if nj < 2 else int(r2.integers(0, 4))
     batch, S0 = _make_loss_case(r2, nt, H, W, nj, nvf, 0.2 if nvf else 0.0, nl)
-    wts = make_weights(50, nj, True, seed=seed, head_std=0.05)
     frames = make_frames(nt, hw[0], hw[1], nj, seed=seed)
+    if SEQ and k % 4 == 1:
+        frames = (frames // 7).astype(np.uint8)                      # a dark clip after a bright one
+    elif SEQ and k % 4 == 3:
+        frames = np.clip(frames.astype(np.int32) * 3, 0, 255).astype(np.uint8)
     ws, ws_max = r2.uniform(5, 20, nl), r2.uniform(10, 40, nl)
     hy = DGPHyper(gm2=gm2, gm3=gm3)
     try:
         P, L = _oracle_grads(wts, frames, batch, S0, ws, ws_max, hy, 300.0, 25.0, dtype=torch.float64)
-        tr = Trainer(50, nj, hw[0], hw[1], max_frames=nt)
-        tr.load_weights(wts)
+        if tr is None:
+            tr = Trainer(50, nj, hw[0], hw[1], max_frames=nt_max)
+            tr.load_weights(wts)
         losses = tr.forward_backward(torch.from_numpy(frames).cuda(), batch, hy, S0, ws, ws_max, 300.0, 25.0)
         g = tr.get_grads()
         Lt = float(L["total_loss"].detach())
