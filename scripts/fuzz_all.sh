@@ -9,6 +9,7 @@ run() { name=$1; shift; timeout 3000 python "scripts/$name.py" "$@" > "$OUT/$nam
 run fuzz_net $((40 * K)) $SEED                 # whole networks (size, bodyparts, batch, locref, depth) vs the oracle
 run fuzz_estimate_pose $((12 * K)) $SEED       # the A0 entry point: batch sizes, chunk rounds, ragged tails
 run fuzz_resize $((4 * K)) $SEED                # one engine through sequences of frame sizes, batch sizes and brightness
+run fuzz_pipeline $((6 * K)) $SEED              # DGPPipeline submit patterns vs one engine, bit for bit
 run fuzz_readout $((150 * K)) $SEED            # soft-argmax, likelihood window, th branch, hard arg-max
 run fuzz_conv_h2 $((200 * K)) $SEED            # every loader of the cell kernels
 run fuzz_halo $((100 * K)) $SEED               # the halo walk and its fall-backs
