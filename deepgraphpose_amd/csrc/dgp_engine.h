@@ -70,6 +70,7 @@ void free_chain_plan(ChainPlan& pl);
 constexpr size_t TAIL_SLAB_FLOATS = (size_t)512 * 128 * 128;      // K-split slabs of a conv grid's tail: <= 512 slices of a 128 x 128 tile (32 MB)
 
 int coutp_for(int cout);
+int head_pw_coutp(int cpw);
 int nk_for(int kh, int kw, int cin);
 void tf_same(int n, int k, int s, int d, int* out, int* pad_before);
 int pad_before_for(int n, int k, int stride, int rate, bool conv2d_same_explicit);

@@ -21,6 +21,9 @@ int coutp_for(int cout) {
     if (cout <= 64) return 64;
     return round_up(cout, 128);
 }
+// padded width of a head's pointwise panel (columns = (tap, phase, joint)): the H2 cell kernels start at 64-column tiles, so one or two
+// joints (16 / 32 columns) pad to 64.  ONE rule for dgp_net_load_weights and dgp_trainer_sync_weights: they share l.d_w_pw / l.d_wh3_pw.
+int head_pw_coutp(int cpw) { const int c = coutp_for(cpw); return c < 64 ? 64 : c; }
 int nk_for(int kh, int kw, int cin) { return (kh * kw * (cin / 4) + 7) / 8; }
 
 void tf_same(int n, int k, int s, int d, int* out, int* pad_before) {
@@ -361,7 +364,7 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
             for (int tap = 0; tap < 4; ++tap)
                 for (int ci = 0; ci < 2048; ++ci)
                     memcpy(&wpw[(size_t)ci * cpw + (size_t)tap * l.Cout], &hwio[((size_t)tap * 2048 + ci) * l.Cout], l.Cout * sizeof(float));
-            l.coutp_pw = coutp_for(cpw) < 64 ? 64 : coutp_for(cpw);      // (the H2 cell kernels start at 64-column tiles: one or two joints pad to 64)
+            l.coutp_pw = head_pw_coutp(cpw);
             const size_t npw = (size_t)nk_for(1, 1, 2048) * 8 * l.coutp_pw * 4;
             std::vector<float> ppw(npw);
             pack_panels(wpw.data(), 1, 1, 2048, cpw, ppw.data(), l.coutp_pw);

@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
 
     float mx = -INFINITY;
     for (int i = t; i < HW; i += 256) {
-        const float v = src[(long long)i * C] * gamma;
+        const float v = __fmul_rn(src[(long long)i * C], gamma);     // rounded product in BOTH variants (no fma contraction below)
         if (!LARGE) sp[i] = v;
         mx = fmaxf(mx, v);
     }
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
 
     double se = 0.0;
     for (int i = t; i < HW; i += 256) {
-        const float e = expf((LARGE ? src[(long long)i * C] * gamma : sp[i]) - mx);
+        const float e = expf((LARGE ? __fmul_rn(src[(long long)i * C], gamma) : sp[i]) - mx);
         if (!LARGE) sp[i] = e;
         se += (double)e;
     }
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
         for (int i = t; i < HW; i += 256) sp[i] = sp[i] / denom;    // tf.nn.softmax output
     }
     __syncthreads();
-    auto P = [&](int i) -> float { return LARGE ? expf(src[(long long)i * C] * gamma - mx) / denom : sp[i]; };
+    auto P = [&](int i) -> float { return LARGE ? expf(__fmul_rn(src[(long long)i * C], gamma) - mx) / denom : sp[i]; };
 
     // blur (zero padded) + moments
     double s0 = 0.0, sh = 0.0, sw = 0.0;
@@ -704,7 +704,8 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
 hipError_t launch_soft_argmax(const float* scmap, int B, int H, int W, int C, float gamma, int gauss_len,
                               float* mu, float* conf, int* idx, float* pmap, hipStream_t s, int record_stride) {
     const size_t smem = (size_t)H * W * sizeof(float);
-    if (smem > SOFT_ARGMAX_LDS_LIMIT) {            // the map does not fit the LDS: streaming variant (same arithmetic)
+    const char* force = getenv("DGP_SOFTARGMAX_STREAM");      // tests: the streaming variant on a map the LDS variant also takes (read per call)
+    if (smem > SOFT_ARGMAX_LDS_LIMIT || (force && atoi(force) != 0)) {      // the map does not fit the LDS: streaming variant (same arithmetic, bit-identical)
         hipLaunchKernelGGL(soft_argmax_kernel<true>, dim3((unsigned)(B * C)), dim3(256), 0, s, scmap, H, W, C, gamma, gauss_len, mu, conf, idx,
                            pmap, record_stride);
         return hipGetLastError();

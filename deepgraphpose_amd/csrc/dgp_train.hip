@@ -2084,7 +2084,7 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
             const int njt = l.Cout / 4;
             hipLaunchKernelGGL(pack_head_fwd_kernel, dim3(grid_for(tot)), dim3(256), 0, s, w, njt, l.Cin, l.CoutP, l.nk * 8, l.d_w);
             if (g_train_cells && merged && rng_f) {      // pointwise form of the same head for the forward pass (cells built below)
-                l.coutp_pw = coutp_for(16 * njt);
+                l.coutp_pw = head_pw_coutp(16 * njt);      // same width as dgp_net_load_weights gives the shared buffers
                 const size_t npw = (size_t)nk_for(1, 1, l.Cin) * 8 * l.coutp_pw * 4;
                 if (!l.d_w_pw) TRY_HIP(hipMalloc(&l.d_w_pw, npw * sizeof(float)));
                 if (!l.d_wh3_pw) TRY_HIP(hipMalloc(&l.d_wh3_pw, npw * sizeof(float)));

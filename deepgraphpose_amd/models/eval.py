@@ -115,7 +115,9 @@ class EvalSession:
 def setup_dgp_eval_graph(dlc_cfg, dgp_model_file, loc_ref=False, gauss_len=1, gamma=1):
     """-> (sess, mu_n, softmax_tensor, scmap, locref, inputs), as eval.py:147-214.
 
-    `dgp_model_file` is a snapshot written by this package (.npz / .safetensors with TF variable names);
+    `dgp_model_file` is what Saver.restore takes (eval.py:194-211): the prefix of a TF V2 bundle (`<prefix>.index` +
+    `.data-*`, written by the reference or by this package's fit drivers), a V1 `.ckpt` file, or an .npz / .safetensors
+    file with TF variable names; optimiser slots and non-float variables (global_step) in a checkpoint are skipped;
     a missing file raises FileNotFoundError, a net_type that does not match the snapshot raises
     KeyError (the reference relies on exactly that failure to fall back from resnet_50 to resnet_101)."""
     from .. import weights_io

@@ -6,7 +6,10 @@
   fit_dlc(snapshot, dlcpath, ...)               DGP/models/fitdgp.py:53-254    (step 0: DLC baseline trainer)
 
 One iteration = `Trainer.step` (deepgraphpose_amd/train.py) = the reference's sess.run([loss, train_op]).
-Snapshots are `<train dir>/snapshot-step{k}-{it}.npz` and `snapshot-step{k}-final--0.npz` (TF variable names).
+Snapshots are what the reference's tf.train.Saver leaves in the train folder (fitdgp.py:239-245, 535-540, 832-839):
+TensorFlow V2 bundles `snapshot-step{k}--{it}.{index,data-00000-of-00001}`, `snapshot-step{k}--0.*` and
+`snapshot-step{k}-final--0.*` plus the `checkpoint` state file, written without TensorFlow (weights_io.Saver,
+tf_checkpoint.py); DGP_SNAPSHOT_FORMAT=npz writes `.npz` files of the same names instead.
 Host-side hooks: augmentation of the labeled frames (`aug`; deepgraphpose_amd/augment.py: imgaug's pipeline when imgaug is
 installed, the numpy / scipy restatement of the same seven augmenters otherwise) and the cv2 Farneback
 optical flow feeding the temporal clique (`wt > 0`; raises ImportError without OpenCV -- the loss term itself is a HIP kernel).
@@ -204,20 +207,19 @@ def _locref_targets(joint_loc, nt, vis_within, nx_out, ny_out, nj, dgp_cfg):
     return lmap, lmask
 
 
-def _save(trainer, prefix, step, it, final, debug=""):
-    from .. import weights_io
-    import os
+def _save(saver, trainer, prefix, step, it, final, debug=""):
+    """The reference's three Saver.save calls (fitdgp.py:535-540, 832-839): `<prefix>-step{k}-` at global_step it and 0, and
+    `<prefix>-step{k}-final-` at 0 after the last iteration."""
     if _is_dp():
         import torch.distributed as dist
         if dist.get_rank() != 0:                 # every rank holds the same weights: one writer
             return
     w = trainer.get_weights()
-    base = prefix + "-step" + str(step) + debug
-    fmt = os.environ.get("DGP_SNAPSHOT_FORMAT", "npz")          # "tf": V2 bundles a tf.train.Saver can restore
-    weights_io.save_weights(base + "-" + str(it), w, fmt=fmt)
-    weights_io.save_weights(base + "--0", w, fmt=fmt)
+    model_name = prefix + "-step" + str(step) + debug + "-"
+    saver.save(w, model_name, global_step=it)
+    saver.save(w, model_name, global_step=0)
     if final:
-        weights_io.save_weights(base + "-final--0", w, fmt=fmt)
+        saver.save(w, prefix + "-step" + str(step) + debug + "-final-", global_step=0)
 
 
 def _augment(dgp_cfg):
@@ -358,7 +360,7 @@ def fit_dlc(snapshot, dlcpath, shuffle=1, step=0, saveiters=1000, displayiters=1
     dlc_cfg.global_scale = 0.8
     dlc_cfg.multi_step = [[0.001, 10000], [0.005, 430000], [0.002, 730000], [0.001, 1030000]]
     final = dlc_cfg.snapshot_prefix + "-step0-final--0"
-    if any(os.path.isfile(final + ext) for ext in (".index", ".npz", ".safetensors")):
+    if weights_io.exists(final):
         print(final, "  exists! The original DLC has already been run.", flush=True)
         return None
     if "snapshot" in snapshot:
@@ -396,6 +398,7 @@ def fit_dlc(snapshot, dlcpath, shuffle=1, step=0, saveiters=1000, displayiters=1
     print("Save_iters overwritten as", save_iters, flush=True)
     print("Max_iters overwritten as", max_iter, flush=True)
 
+    saver = weights_io.Saver(max_to_keep=5)                       # fitdgp.py:150-152
     lr_gen = LearningRate(dlc_cfg)
     stats_path = Path(pose_config_yaml).with_name("learning_stats.csv")
     lrf = open(str(stats_path) if rank == 0 else os.devnull, "w")
@@ -438,12 +441,11 @@ def fit_dlc(snapshot, dlcpath, shuffle=1, step=0, saveiters=1000, displayiters=1
             print("iteration: {} loss: {} scmap loss: {} locref loss: {} lr: {}".format(*vals), flush=True)
             lrf.write("iteration: {}, loss: {}, scmap loss: {}, locref loss: {}, lr: {}\n".format(*vals))
             lrf.flush()
-        if rank == 0 and ((it % save_iters == 0 and it != 0) or it == max_iter):
-            fmt = os.environ.get("DGP_SNAPSHOT_FORMAT", "npz")
+        if rank == 0 and ((it % save_iters == 0 and it != 0) or it == max_iter):      # fitdgp.py:237-245
             w = trainer.get_weights()
-            weights_io.save_weights(dlc_cfg.snapshot_prefix + "-step" + str(step) + "--" + str(it), w, fmt=fmt)
+            saver.save(w, dlc_cfg.snapshot_prefix + "-step" + str(step) + "-", global_step=it)
             if it == max_iter:
-                weights_io.save_weights(dlc_cfg.snapshot_prefix + "-step" + str(step) + "-final--0", w, fmt=fmt)
+                saver.save(w, dlc_cfg.snapshot_prefix + "-step" + str(step) + "-final-", global_step=0)
     print("Finish training {} iterations\n".format(it), flush=True)
     lrf.close()
     return None
@@ -458,8 +460,9 @@ def fit_dgp_labeledonly(snapshot, dlcpath, shuffle=1, step=1, saveiters=1000, di
     dgp_cfg = data_batcher.dlc_config
     dgp_cfg.update(ws=0, ws_max=1.2, wt=0, wt_max=0, wn_visible=1, wn_hidden=0, gamma=1, gauss_len=1, lengthscale=1,
                    max_to_keep=5, batch_size=1, n_times_all_frames=100, lr=0.005, gm2=0, gm3=0, aug=aug)
-    final = dgp_cfg.snapshot_prefix + "-step1-final--0.npz"
-    if os.path.isfile(final):
+    from .. import weights_io
+    final = dgp_cfg.snapshot_prefix + "-step1-final--0"
+    if weights_io.exists(final):
         print(final, "  exists! DGP with labeled frames has already been run.", flush=True)
         return None
     data_batcher.create_batches_from_resnet_output(0, ns_jump=None, step=1, ns=ns, nc=nc, n_max_frames=n_max_frames)
@@ -472,6 +475,7 @@ def fit_dgp_labeledonly(snapshot, dlcpath, shuffle=1, step=1, saveiters=1000, di
     learning_rate = Placeholder("learning_rate")
     train_op = loss.graph.minimize(total_loss_visible, learning_rate)          # fitdgp.py:412-418
     sess = TrainSession(trainer, loss.graph)
+    saver = weights_io.Saver(max_to_keep=dgp_cfg.max_to_keep)     # fitdgp.py:401, 696
     uploader = _FrameUploader(trainer.device) if int(os.environ.get("DGP_FIT_PREFETCH", "2")) > 0 else None
     nepoch = int(np.min([int(data_batcher.n_visible_frames_total * dgp_cfg.n_times_all_frames), maxiters]))
     table = np.array([(i, vv) for i, v in enumerate(visible_frame_total) for vv in v]).reshape(-1, 2)
@@ -508,7 +512,7 @@ def fit_dgp_labeledonly(snapshot, dlcpath, shuffle=1, step=1, saveiters=1000, di
             print("dataset_i: ", dataset_i, " visible_frame_batch_i: ", [frame_i], flush=True)
             print(" running time: ", time.time() - t0, "\n loss: ", loss_eval, flush=True)
         if (it % saveiters == 0) or (it + 1) == maxiters:
-            _save(trainer, dgp_cfg.snapshot_prefix, step, it, (it + 1) == maxiters)
+            _save(saver, trainer, dgp_cfg.snapshot_prefix, step, it, (it + 1) == maxiters)
     print("Finished training {} iterations\n".format(it), flush=True)
     print("\n\n TOTAL TIME ELAPSED: ", time.time() - t_start)
     return None
@@ -524,8 +528,9 @@ def fit_dgp(snapshot, dlcpath, batch_size=10, shuffle=1, step=2, saveiters=1000,
     dgp_cfg = data_batcher.dlc_config
     dgp_cfg.update(ws=1000, ws_max=1.2, wt=wt, wt_max=0, wn_visible=5, wn_hidden=3, gamma=1, gauss_len=1, lengthscale=1,
                    max_to_keep=5, batch_size=batch_size, n_times_all_frames=nepoch, lr=0.005, gm2=gm2, gm3=gm3, aug=aug)
-    final = dgp_cfg.snapshot_prefix + "-step{}{}-final--0.npz".format(step, debug)
-    if os.path.isfile(final):
+    from .. import weights_io
+    final = dgp_cfg.snapshot_prefix + "-step{}{}-final--0".format(step, debug)
+    if weights_io.exists(final):
         print(final, "  exists! DGP has already been run.", flush=True)
         return None
     data_batcher.create_batches_from_resnet_output(0, ns_jump=None, step=1, ns=ns, nc=nc, n_max_frames=n_max_frames)
@@ -543,6 +548,7 @@ def fit_dgp(snapshot, dlcpath, batch_size=10, shuffle=1, step=2, saveiters=1000,
     learning_rate = Placeholder("learning_rate")
     train_op = loss.graph.minimize(total_loss, learning_rate)                  # fitdgp.py:708-713
     sess = TrainSession(trainer, loss.graph)
+    saver = weights_io.Saver(max_to_keep=dgp_cfg.max_to_keep)     # fitdgp.py:401, 696
     uploader = _FrameUploader(trainer.device) if int(os.environ.get("DGP_FIT_PREFETCH", "2")) > 0 else None
     batch_ind_all = gen_batch(visible_frame_total, hidden_frame_total, all_frame_total, dgp_cfg, maxiters)
     save_iters = max(int(saveiters / dgp_cfg.batch_size), 1)
@@ -593,7 +599,7 @@ def fit_dgp(snapshot, dlcpath, batch_size=10, shuffle=1, step=2, saveiters=1000,
             print("\n running time: ", time.time() - t0, flush=True)
             print("\n loss: ", loss_eval, flush=True)
         if (it % save_iters == 0) or (it + 1) == maxiters:
-            _save(trainer, dgp_cfg.snapshot_prefix, step, it, (it + 1) == maxiters, debug)
+            _save(saver, trainer, dgp_cfg.snapshot_prefix, step, it, (it + 1) == maxiters, debug)
     print("Finished {} iterations\n".format(it), flush=True)
     print("\n\n TOTAL TIME ELAPSED: ", time.time() - t_start)
     return None

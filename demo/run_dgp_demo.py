@@ -14,7 +14,7 @@ for the run and restore them afterwards; they apply to the Reaching demo project
 data/Reaching-Mackenzie-2018-08-30, relative to the working directory like in the reference).  Videos are taken from
 <proj>/videos_dgp/ or the project's video_sets; real videos need moviepy, directories of frames and .npy stacks work without a
 decoder, and a missing video whose labeled frames exist under labeled-data/<name>/ runs on those frames as a pseudo-video.
-Snapshots are .npz files keyed by TF variable names (or TF bundles, DGP_SNAPSHOT_FORMAT=tf).
+Snapshots are TensorFlow V2 bundles keyed by TF variable names, as the reference's Saver writes them (.npz with DGP_SNAPSHOT_FORMAT=npz).
 """
 import argparse
 import os

@@ -330,7 +330,8 @@ def test_run_dgp_demo_test_mode_end_to_end(lib_built, tmp_path):
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
     train = os.path.join(proj, "dlc-models", "iteration-0", "DemoOct2-trainset95shuffle1", "train")
     for step in (1, 2):
-        assert os.path.isfile(os.path.join(train, "snapshot-step%d-final--0.npz" % step))
+        assert os.path.isfile(os.path.join(train, "snapshot-step%d-final--0.index" % step))          # TF V2 bundles, like the reference's Saver
+        assert os.path.isfile(os.path.join(train, "snapshot-step%d-final--0.data-00000-of-00001" % step))
     csv = os.path.join(proj, "videos_pred", "clip_labeled.csv")
     assert os.path.isfile(csv)
     rows = open(csv).read().strip().split("\n")

@@ -142,9 +142,13 @@ def test_weights_io_and_errors(tmp_path):
     from deepgraphpose_amd import weights_io as Wio
     from deepgraphpose_amd.synthetic import make_weights
     w = make_weights(50, 2, False, seed=1)
-    p = Wio.save_weights(str(tmp_path / "snapshot-step2-final--0"), w)
+    p = Wio.save_weights(str(tmp_path / "snapshot-step2-final--0"), w)          # default: the reference's on-disk format (TF V2 bundle)
+    assert os.path.isfile(p + ".index") and os.path.isfile(p + ".data-00000-of-00001") and Wio.exists(p)
     back = Wio.load_weights(str(tmp_path / "snapshot-step2-final--0"))
-    assert set(back) == set(w) and Wio.net_depth(back) == 50 and p.endswith(".npz")
+    assert set(back) == set(w) and Wio.net_depth(back) == 50
+    q = Wio.save_weights(str(tmp_path / "opt-out"), w, fmt="npz")
+    assert q.endswith(".npz") and set(Wio.load_weights(str(tmp_path / "opt-out"))) == set(w) and Wio.exists(str(tmp_path / "opt-out"))
+    assert not Wio.exists(str(tmp_path / "missing"))
     np.testing.assert_array_equal(back["pose/part_pred/block4/weights"], w["pose/part_pred/block4/weights"])
     with pytest.raises(FileNotFoundError):
         Wio.load_weights(str(tmp_path / "missing"))

@@ -315,6 +315,25 @@ def test_demo_frame_size_747x832_five_joints_matches_oracle(eng):
     assert np.array_equal(idx.cpu().numpy(), ref["idx"])
 
 
+def test_streaming_soft_argmax_is_bit_identical_to_the_lds_variant(eng):
+    """Both instances of soft_argmax_kernel on the SAME maps (DGP_SOFTARGMAX_STREAM=1 forces the streaming one where the LDS one also fits):
+    every output -- mu, likelihood, window index, pmap -- must be equal bit for bit, gamma != 1 included (the product s * gamma is rounded
+    before the subtraction in both: __fmul_rn, no fma contraction), so a result cannot flip at the 38 400-cell boundary."""
+    import os
+    rng = np.random.default_rng(17)
+    for (B, H, W, C, gl, gamma) in ((2, 60, 80, 4, 1, 1.0), (1, 192, 200, 2, 1, 0.37), (2, 33, 47, 5, 2, 2.5), (1, 1, 7, 1, 1, 1.3)):
+        s = _peaky_scmap(rng, B, H, W, C) * np.float32(1.7)
+        t = torch.from_numpy(s).cuda()
+        lds = [x.clone() for x in eng.soft_argmax(t, gamma, gl, want_pmap=True)]
+        os.environ["DGP_SOFTARGMAX_STREAM"] = "1"
+        try:
+            stream = eng.soft_argmax(t, gamma, gl, want_pmap=True)
+        finally:
+            del os.environ["DGP_SOFTARGMAX_STREAM"]
+        for a, b, name in zip(lds, stream, ("mu", "conf", "idx", "pmap")):
+            assert torch.equal(a, b), (name, (B, H, W, C, gl, gamma))
+
+
 def test_maps_larger_than_the_lds_stream_from_global_memory(eng):
     """The reference's scoremap placeholders have no size limit ([None, None, None, nj], DGP/models/fitdgp.py:1130-1142).  dgp_soft_argmax keeps
     one joint's map in LDS up to 150 KB = 38 400 cells and STREAMS larger ones (softmax values recomputed from global memory where the blur

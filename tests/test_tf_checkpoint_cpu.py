@@ -79,97 +79,35 @@ def test_not_a_checkpoint(tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-# Known-answer files assembled BY HAND from the published formats (leveldb table_format.md; tensorflow/core/protobuf/
-# tensor_bundle.proto; tensorflow/core/lib/hash/crc32c.h for the mask) with code that shares nothing with tf_checkpoint's writer:
-# own varints, own bitwise CRC-32C, explicit struct packing.  The reader must return the tensors these bytes describe.
+# Known-answer files assembled BY HAND from the published formats by tests/_kat_ckpt.py, code that shares nothing with
+# tf_checkpoint's writer or reader: own varints, own CRC-32C, own snappy emitter, explicit struct packing.  The reader must return
+# the tensors these bytes describe, and the independent reader there must return what the product's writer wrote.
 # ---------------------------------------------------------------------------------------------------------------------------
-def _kat_varint(v):
-    out = bytearray()
-    while True:
-        b = v & 0x7F
-        v >>= 7
-        out.append(b | (0x80 if v else 0))
-        if not v:
-            return bytes(out)
+import _kat_ckpt as kat
 
-
-def _kat_crc32c(data):
-    crc = 0xFFFFFFFF
-    for byte in data:
-        crc ^= byte
-        for _ in range(8):
-            crc = (crc >> 1) ^ (0x82F63B78 if crc & 1 else 0)       # Castagnoli polynomial, reflected
-    return crc ^ 0xFFFFFFFF
-
-
-def _kat_mask(crc):
-    return ((((crc >> 15) | (crc << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
-
-
-def _kat_block(entries, restart_every=16, snappy=False):
-    """leveldb block: prefix-compressed entries, restart array, [type byte][masked crc32c of contents + type]."""
-    body, restarts, last = bytearray(), [], b""
-    for i, (k, v) in enumerate(entries):
-        shared = 0
-        if i % restart_every == 0:
-            restarts.append(len(body))
-        else:
-            while shared < min(len(k), len(last)) and k[shared] == last[shared]:
-                shared += 1
-        body += _kat_varint(shared) + _kat_varint(len(k) - shared) + _kat_varint(len(v)) + k[shared:] + v
-        last = k
-    for r in restarts or [0]:
-        body += struct.pack("<I", r)
-    body += struct.pack("<I", len(restarts) or 1)
-    ctype = 0
-    if snappy:      # snappy stream of literals only (tag = (len - 1) << 2 for len <= 60, else tag 60 << 2 + one length byte)
-        raw, comp, pos = bytes(body), bytearray(_kat_varint(len(body))), 0
-        while pos < len(raw):
-            n = min(200, len(raw) - pos)
-            comp += bytes([(n - 1) << 2]) if n <= 60 else bytes([60 << 2, n - 1])
-            comp += raw[pos:pos + n]
-            pos += n
-        body, ctype = comp, 1
-    trailer = bytes([ctype]) + struct.pack("<I", _kat_mask(_kat_crc32c(bytes(body) + bytes([ctype]))))
-    return bytes(body), trailer
+_kat_crc32c, _kat_mask = kat.crc32c_bitwise, kat.mask
 
 
 def _kat_bundle(tmp_path, name, tensors, snappy=False, two_blocks=False):
-    """Write <name>.index / <name>.data-00000-of-00001 for {variable: float32 array} without tf_checkpoint's writer."""
-    data, entries = bytearray(), []
-    header = bytes([0x08, 0x01, 0x10, 0x00, 0x1A, 0x02, 0x08, 0x01])      # BundleHeaderProto{num_shards: 1, LITTLE, version{producer: 1}}
-    entries.append((b"", header))
-    for key in sorted(tensors):
-        a = np.asarray(tensors[key], dtype="<f4")                     # (ascontiguousarray would turn a scalar into shape (1,))
-        raw = a.tobytes()
-        shape = b"".join(bytes([0x12]) + _kat_varint(len(d)) + d for d in (bytes([0x08]) + _kat_varint(s) for s in a.shape))
-        val = bytes([0x08, 0x01])                                         # dtype: DT_FLOAT
-        val += bytes([0x12]) + _kat_varint(len(shape)) + shape            # shape: TensorShapeProto{dim{size}...}
-        if len(data):
-            val += bytes([0x20]) + _kat_varint(len(data))                 # offset (shard_id 0 and offset 0 are proto defaults: omitted)
-        val += bytes([0x28]) + _kat_varint(len(raw))                      # size
-        val += bytes([0x35]) + struct.pack("<I", _kat_mask(_kat_crc32c(raw)))     # crc32c: fixed32
-        entries.append((key.encode(), val))
-        data += raw
-    groups = [entries[:2], entries[2:]] if two_blocks and len(entries) > 2 else [entries]
-    out, index = bytearray(), []
-    for g in groups:
-        body, trailer = _kat_block(g, restart_every=2, snappy=snappy)
-        index.append((g[-1][0] + b"\x00", len(out), len(body)))            # any separator key >= the block's last key
-        out += body + trailer
-    mbody, mtrailer = _kat_block([])
-    moff = len(out)
-    out += mbody + mtrailer
-    ibody, itrailer = _kat_block([(k, _kat_varint(o) + _kat_varint(s)) for k, o, s in index])
-    ioff = len(out)
-    out += ibody + itrailer
-    footer = _kat_varint(moff) + _kat_varint(len(mbody)) + _kat_varint(ioff) + _kat_varint(len(ibody))
-    footer += b"\x00" * (40 - len(footer)) + bytes.fromhex("57fb808b247547db")          # kTableMagicNumber, little endian
-    out += footer
     prefix = str(tmp_path / name)
-    open(prefix + ".index", "wb").write(bytes(out))
-    open(prefix + ".data-00000-of-00001", "wb").write(bytes(data))
+    first = len(sorted(tensors)[0]) + 40          # closes the first data block behind the header + first entry
+    kat.bundle(prefix, tensors, compress=snappy, block_bytes=first if two_blocks else 1 << 30)
     return prefix
+
+
+def test_kat_crc_and_snappy_helpers_are_sound():
+    """The independent assembler's own pieces: the lane-folded CRC equals the bitwise loop, and its snappy stream (literals + overlapping
+    copies) decodes to the input."""
+    rng = np.random.RandomState(0)
+    for n in (1 << 14, 70001, 300000):
+        data = rng.randint(0, 256, size=n, dtype=np.uint8).tobytes()
+        assert kat.crc32c(data) == kat.crc32c_bitwise(data)
+    assert kat.crc32c(b"123456789") == 0xE3069283
+    raw = np.concatenate([np.zeros(40, np.float32), np.ones(70, np.float32), rng.randn(33).astype(np.float32)]).tobytes() + b"xy"
+    comp = kat.snappy(raw)
+    assert len(comp) < len(raw) // 2 and tfc._snappy_decompress(comp) == raw      # runs became copies
+    big = rng.randint(0, 256, size=200000, dtype=np.uint8).tobytes()
+    assert tfc._snappy_decompress(kat.snappy(big)) == big
 
 
 @pytest.mark.parametrize("snappy,two_blocks", [(False, False), (True, False), (False, True)])
@@ -255,3 +193,77 @@ def test_scalars_keep_rank_zero_and_v1_files_are_recognised_by_content(tmp_path)
     proto = tfc._pb_int(1, tfc.DT_FLOAT) + tfc._pb_bytes(2, tfc._encode_shape((2, 3))) + tfc._pb_bytes(5, np.float32(7.0).tobytes())
     t = tfc._parse_tensor_proto(proto)
     assert t.shape == (2, 3) and (t == 7.0).all()
+
+
+def _saver_like_variables(rng):
+    """What tf.train.Saver() puts into a DLC / DGP snapshot when it is built after the optimiser (fit_dlc: fitdgp.py:150-152): every
+    model variable, a `<var>/Momentum` slot per trainable, and the int64 `global_step`."""
+    model = {"resnet_v1_50/conv1/weights": rng.randn(7, 7, 3, 64).astype(np.float32),
+             "resnet_v1_50/conv1/BatchNorm/gamma": np.ones(64, np.float32),
+             "resnet_v1_50/conv1/BatchNorm/beta": np.zeros(64, np.float32),
+             "resnet_v1_50/conv1/BatchNorm/moving_mean": rng.randn(64).astype(np.float32),
+             "resnet_v1_50/conv1/BatchNorm/moving_variance": rng.rand(64).astype(np.float32) + 0.5,
+             "pose/part_pred/block4/weights": rng.randn(3, 3, 4, 8).astype(np.float32),
+             "pose/part_pred/block4/biases": rng.randn(4).astype(np.float32)}
+    extra = {k + "/Momentum": rng.randn(*v.shape).astype(np.float32) for k, v in model.items() if "moving_" not in k}
+    extra["global_step"] = np.array(1030000, dtype=np.int64)
+    return model, extra
+
+
+@pytest.mark.parametrize("compress", [False, True])
+def test_v2_bundle_with_momentum_slots_and_global_step(tmp_path, compress):
+    """A Saver-written snapshot holds optimiser slots and an int64 global_step next to the model: they are skipped, not rejected."""
+    model, extra = _saver_like_variables(np.random.RandomState(8))
+    prefix = str(tmp_path / "snapshot-step0-final--0")
+    n_blocks = kat.bundle(prefix, {**model, **extra}, compress=compress, block_bytes=200)
+    assert n_blocks >= 3
+    raw = tfc.read_v2(prefix, verify=True)
+    assert "global_step" not in raw and "pose/part_pred/block4/weights/Momentum" in raw        # non-float skipped by the bundle reader
+    back = weights_io.load_weights(prefix)
+    assert sorted(back) == sorted(model)
+    for k, v in model.items():
+        assert back[k].dtype == np.float32 and np.array_equal(back[k], v), k
+
+
+@pytest.mark.parametrize("compress", [True, False])
+def test_v1_reader_on_hand_assembled_checkpoint(tmp_path, compress):
+    """slim's ImageNet resnet_v1_50.ckpt is a V1 tensor-slice file: snappy blocks, float_val payloads, ordered-code keys, and it holds
+    variables the pose network does not have (logits, mean_rgb, global_step)."""
+    rng = np.random.RandomState(9)
+    model, extra = _saver_like_variables(rng)
+    model = {k: v for k, v in model.items() if k.startswith("resnet_v1_50")}
+    model["resnet_v1_50/logits/biases"] = np.zeros(1000, np.float32)
+    model["resnet_v1_50/mean_rgb"] = np.array([123.68, 116.78, 103.94], np.float32)
+    path = str(tmp_path / "resnet_v1_50.ckpt")
+    n_blocks = kat.v1_file(path, {**model, "global_step": np.array(7, dtype=np.int64)}, compress=compress, block_bytes=2000)
+    assert n_blocks >= 3
+    assert tfc.is_tf_checkpoint(path)
+    back = weights_io.load_weights(path)
+    assert sorted(back) == sorted(model)
+    for k, v in model.items():
+        assert back[k].shape == v.shape and np.array_equal(back[k], v), k
+    raw = bytearray(open(path, "rb").read())
+    raw[len(raw) // 3] ^= 0x10                                                   # inside a data block: its checksum must notice
+    open(path, "wb").write(bytes(raw))
+    with pytest.raises(ValueError):
+        tfc.read_v1(path)
+
+
+def test_product_writer_is_read_by_the_independent_reader(tmp_path):
+    """The other direction: what write_v2 / weights_io.Saver put on disk, parsed by tests/_kat_ckpt.read_bundle (own table walk, own
+    proto decoding, every block and tensor checksum verified with its own CRC)."""
+    w = synthetic.make_weights(50, 3, True, seed=4)
+    small = {k: v for k, v in w.items() if v.size <= 70000}              # the bitwise / lane CRC of the test reader: keep it to seconds
+    small["pose/scalar"] = np.float32(0.25).reshape(())
+    saver = weights_io.Saver(max_to_keep=2, fmt="tf")
+    paths = [saver.save(small, str(tmp_path / "snapshot-step2-"), global_step=g) for g in (5, 0, 10)]
+    assert paths[0].endswith("snapshot-step2--5") and paths[1].endswith("snapshot-step2--0")
+    assert not os.path.exists(paths[0] + ".index") and not os.path.exists(paths[0] + ".data-00000-of-00001")      # max_to_keep
+    assert weights_io.latest_checkpoint(str(tmp_path)) == paths[2]
+    state = open(tmp_path / "checkpoint").read().splitlines()
+    assert state == ['model_checkpoint_path: "snapshot-step2--10"', 'all_model_checkpoint_paths: "snapshot-step2--0"',
+                     'all_model_checkpoint_paths: "snapshot-step2--10"']
+    back = kat.read_bundle(paths[2])
+    assert sorted(back) == sorted(small)
+    for k, v in small.items():
+        assert back[k].shape == np.asarray(v).shape and np.array_equal(back[k], v), k

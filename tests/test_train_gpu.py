@@ -265,13 +265,14 @@ def test_fit_dgp_drivers_end_to_end(lib_built, tmp_path):
     np.random.seed(0); random.seed(0)
     fit_dgp_labeledonly("snapshot-step0-final--0", proj, shuffle=1, step=1, maxiters=4, displayiters=1, aug=False)
     snap1, cfg_path = get_snapshot_path("snapshot-step1-final--0", proj, shuffle=1)
-    assert os.path.isfile(snap1 + ".npz")
+    assert os.path.isfile(snap1 + ".index") and os.path.isfile(snap1 + ".data-00000-of-00001")
     w1 = weights_io.load_weights(snap1)
     assert np.abs(w1["pose/part_pred/block4/weights"] - wts["pose/part_pred/block4/weights"]).max() > 0
     fit_dgp("snapshot-step1-final--0", proj, batch_size=4, shuffle=1, step=2, maxiters=3, displayiters=1, gm2=1, gm3=3,
             aug=False, n_max_frames=30, ns=3)
     snap2, _ = get_snapshot_path("snapshot-step2-final--0", proj, shuffle=1)
-    assert os.path.isfile(snap2 + ".npz")
+    assert os.path.isfile(snap2 + ".index") and os.path.isfile(snap2 + ".data-00000-of-00001")
+    assert weights_io.latest_checkpoint(os.path.dirname(snap2)) == snap2          # the Saver's `checkpoint` state file
     w2 = weights_io.load_weights(snap2)
     assert all(np.isfinite(v).all() for v in w2.values())
     # second call is a no-op (skip-if-exists guard, fitdgp.py:656-660)
@@ -280,6 +281,21 @@ def test_fit_dgp_drivers_end_to_end(lib_built, tmp_path):
                            shuffle=1, batch_size=8)
     assert labels["x"].shape == (40, 3) and np.isfinite(labels["x"]).all()
     assert os.path.isfile(os.path.join(proj, "videos_pred", "clip_labeled.csv"))
+    # N1 (a): the trajectory estimate_pose computed FROM THE TF BUNDLE fit_dgp wrote equals the oracle's on the tensors an independent
+    # reader (tests/_kat_ckpt.py: own table walk, own CRC) finds in that bundle -- coordinates within 1e-3 px, window indices bit-exact
+    import _kat_ckpt as kat
+    from oracle import dgp_oracle as O
+    disk = kat.read_bundle(snap2)
+    assert sorted(disk) == sorted(w2) and all(np.array_equal(disk[k], w2[k]) for k in w2)
+    ref = O.infer(frames, disk, 50, 8.0, 1.0, 1)
+    assert np.abs(labels["x"] - ref["x"]).max() < 1e-3 and np.abs(labels["y"] - ref["y"]).max() < 1e-3
+    assert np.abs(labels["likelihoods"] - ref["likelihoods"]).max() < 1e-5
+    from deepgraphpose_amd import engine
+    import torch
+    net = engine.DGPNet(50, 3, 64, 96, max_batch=8, device=0)
+    net.load_weights(weights_io.load_weights(snap2))
+    _, _, idx = net.infer(torch.from_numpy(frames[:8]).cuda(), 1.0, 1)
+    assert np.array_equal(idx.cpu().numpy(), ref["idx"][:8])
     # evaluate_dgp (eval.py:656): RMSE table over the labeled images, both read-out paths
     from deepgraphpose_amd.models.eval import evaluate_dgp
     for lr in (True, False):
@@ -433,22 +449,40 @@ def test_fit_dlc_driver(lib_built, tmp_path):
     from deepgraphpose_amd.models.fitdgp_util import get_snapshot_path
     proj, frames, wts = make_project(tmp_path, hw=(96, 128))
     snap0, _ = get_snapshot_path("snapshot-step0-final--0", proj, shuffle=1)
-    os.remove(snap0 + ".npz")                                   # make_project seeds one; step 0 must create it
+    for ext in (".index", ".data-00000-of-00001"):
+        os.remove(snap0 + ext)                                  # make_project seeds one; step 0 must create it
     pre = tmp_path / "pretrained"
     pre.mkdir()
+    # N1 (b): the ImageNet checkpoint is a V1 tensor-slice file assembled by the INDEPENDENT code of tests/_kat_ckpt.py (snappy blocks,
+    # one data block per large tensor, ordered-code keys) and holds what slim's resnet_v1_50.ckpt holds beside the backbone: the
+    # classifier, mean_rgb and an int64 global_step.  fit_dlc restores the backbone only (fitdgp.py:139-142) and creates fresh heads.
+    import _kat_ckpt as kat
     backbone = {k: v for k, v in wts.items() if k.startswith("resnet_v1_50")}
+    backbone["resnet_v1_50/logits/weights"] = np.zeros((1, 1, 2048, 1000), dtype=np.float32)
     backbone["resnet_v1_50/logits/biases"] = np.zeros(1000, dtype=np.float32)
-    tf_checkpoint.write_v1(str(pre / "resnet_v1_50.ckpt"), backbone)
+    backbone["resnet_v1_50/mean_rgb"] = np.array([123.68, 116.78, 103.94], dtype=np.float32)
+    backbone["global_step"] = np.array(0, dtype=np.int64)
+    backbone["pose/part_pred/block4/weights"] = np.full((3, 3, 3, 2048), 7.0, dtype=np.float32)     # must NOT be restored
+    n_blocks = kat.v1_file(str(pre / "resnet_v1_50.ckpt"), backbone, compress=True, block_bytes=256 << 10)
+    assert n_blocks >= 2
+    restored = weights_io.load_weights(str(pre / "resnet_v1_50.ckpt"))
+    assert "global_step" not in restored and all(np.array_equal(restored[k], v) for k, v in wts.items() if k.startswith("resnet_v1_50"))
     os.environ["DGP_PRETRAINED_DIR"] = str(pre)
     try:
         np.random.seed(0); random.seed(0)
         fit_dlc("resnet_v1_50.ckpt", proj, shuffle=1, step=0, saveiters=3, displayiters=2, maxiters=5)
     finally:
         del os.environ["DGP_PRETRAINED_DIR"]
-    assert os.path.isfile(snap0 + ".npz") and os.path.isfile(os.path.join(os.path.dirname(snap0), "snapshot-step0--3.npz"))
+    assert os.path.isfile(snap0 + ".index") and os.path.isfile(os.path.join(os.path.dirname(snap0), "snapshot-step0--3.index"))
     w0 = weights_io.load_weights(snap0)
     assert all(np.isfinite(v).all() for v in w0.values())
     assert np.abs(w0["resnet_v1_50/conv1/weights"] - wts["resnet_v1_50/conv1/weights"]).max() > 0
+    # backbone restored from the V1 file (five momentum steps of lr <= 0.005 move a weight by far less than its scale) ...
+    k3 = "resnet_v1_50/block3/unit_2/bottleneck_v1/conv2/weights"
+    assert np.abs(w0[k3] - wts[k3]).max() < 0.05 * np.abs(wts[k3]).max()
+    # ... heads fresh (glorot-uniform, |w| <= sqrt(3 / ((27 + 18432) / 2)) = 0.018; the file's 7.0s were not restored), both heads present
+    assert np.abs(w0["pose/part_pred/block4/weights"]).max() < 0.1 and w0["pose/locref_pred/block4/weights"].shape == (3, 3, 6, 2048)
+    assert sorted(k for k in w0 if "logits" in k or "mean_rgb" in k or k == "global_step") == []
     stats = open(os.path.join(os.path.dirname(snap0), "learning_stats.csv")).read().strip().splitlines()
     assert len(stats) == 2 and stats[0].startswith("iteration: 2, loss: total loss ")
     assert fit_dlc("resnet_v1_50.ckpt", proj, maxiters=5) is None            # skip-if-exists guard (fitdgp.py:113-117)
@@ -566,9 +600,70 @@ print("rank", os.environ["RANK"], "done")
     for pr, (so, se) in zip(procs, outs):
         assert pr.returncode == 0, (so[-500:], se[-2000:])
     snap2, _ = get_snapshot_path("snapshot-step2-final--0", proj, shuffle=1)
-    assert os.path.isfile(snap2 + ".npz")
+    assert os.path.isfile(snap2 + ".index")
     w2 = weights_io.load_weights(snap2)
     assert all(np.isfinite(v).all() for v in w2.values())
     assert np.abs(w2["pose/part_pred/block4/weights"] - wts["pose/part_pred/block4/weights"]).max() > 0
     # 6 schedule entries over 2 ranks = 3 optimiser steps: the iteration snapshot rank 0 wrote is the third
-    assert os.path.isfile(snap2.replace("-final--0", "-3") + ".npz") or os.path.isfile(snap2.replace("-final--0", "-2") + ".npz")
+    assert os.path.isfile(snap2.replace("-final--0", "--3") + ".index") or os.path.isfile(snap2.replace("-final--0", "--2") + ".index")
+
+
+def test_estimate_from_a_saver_bundle_with_slots_and_global_step(lib_built, tmp_path):
+    """N1 (c): a snapshot as tf.train.Saver() writes it after the optimiser exists -- every model variable, `<var>/Momentum` slots and
+    the int64 `global_step` -- assembled by the independent code of tests/_kat_ckpt.py (snappy index blocks).  The extra variables
+    are skipped, not rejected, and the engine loaded from that prefix matches the oracle on the same model variables."""
+    import _kat_ckpt as kat
+    from deepgraphpose_amd import engine, synthetic, weights_io
+    from deepgraphpose_amd.models.eval import setup_dgp_eval_graph
+    from oracle import dgp_oracle as O
+    nj, B, h, w = 3, 4, 96, 128
+    wts = synthetic.make_weights(50, nj, True, seed=21, head_std=0.05)
+    rng = np.random.default_rng(0)
+    extra = {k + "/Momentum": rng.standard_normal(v.shape).astype(np.float32) for k, v in wts.items()
+             if "moving_" not in k and v.size < 300000}
+    extra["global_step"] = np.array(200000, dtype=np.int64)
+    extra["beta1_power"] = np.float32(0.9).reshape(())                  # a float scalar no layer owns (Adam leaves such behind)
+    prefix = str(tmp_path / "snapshot-step0-final--0")
+    assert kat.bundle(prefix, {**wts, **extra}, compress=True, block_bytes=4096) >= 3
+    loaded = weights_io.load_weights(prefix)
+    assert not any(k.endswith("/Momentum") or k == "global_step" for k in loaded)
+    frames = synthetic.make_frames(B, h, w, nj, seed=5)
+    from types import SimpleNamespace
+    cfg = dict(net_type="resnet_50", num_joints=nj)
+    dlc_cfg = SimpleNamespace(**cfg, get=lambda k, d=None: cfg.get(k, d))
+    sess, mu_n, _, scmap, _, inputs = setup_dgp_eval_graph(dlc_cfg, prefix)          # Saver.restore(sess, prefix), eval.py:194-211
+    mu, sc = sess.run([mu_n, scmap], feed_dict={inputs: frames})
+    ref = O.infer(frames, wts, 50, 8.0, 1.0, 1)
+    assert np.abs(np.asarray(mu) - ref["mu"]).max() * 8.0 < 1e-3
+    assert np.abs(np.asarray(sc) - ref["scmap"]).max() < 1e-4 * np.abs(ref["scmap"]).max()
+    net = engine.DGPNet(50, nj, h, w, max_batch=B, device=0)
+    net.load_weights(loaded)
+    _, _, idx = net.infer(torch.from_numpy(frames).cuda(), 1.0, 1)
+    assert np.array_equal(idx.cpu().numpy(), ref["idx"])
+
+
+@pytest.mark.parametrize("nj", [1, 2])
+def test_trainer_sync_then_net_load_weights_share_one_head_panel_width(lib_built, nj):
+    """The heads' pointwise panel buffers (l.d_w_pw / l.d_wh3_pw) are shared by dgp_trainer_sync_weights and dgp_net_load_weights and are
+    allocated by whichever runs first: both must size them with the same rule (head_pw_coutp: one or two joints pad to 64 columns).
+    Before the fix a trainer sync (32 columns) followed by net.load_weights (64) wrote 512 KB into a 256-KB buffer."""
+    from deepgraphpose_amd import synthetic
+    from deepgraphpose_amd.train import Trainer
+    from oracle import dgp_oracle as O
+    h, w = 64, 96
+    wts = synthetic.make_weights(50, nj, True, seed=31, head_std=0.05)
+    frames = synthetic.make_frames(2, h, w, nj, seed=1)
+    tr = Trainer(50, nj, h, w, max_frames=2)
+    tr.load_weights(wts)                          # uploads + dgp_trainer_sync_weights: allocates the shared panels
+    tr.sync()
+    tr.net.load_weights(wts)                      # the public path the advisor named: dgp_net_load_weights on the trainer's net
+    ft = torch.from_numpy(frames).cuda()
+    mu, conf, idx = tr.net.infer(ft, 1.0, 1)
+    torch.cuda.synchronize()
+    ref = O.infer(frames, wts, 50, 8.0, 1.0, 1)
+    assert np.abs(mu.cpu().numpy() - ref["mu"]).max() * 8.0 < 1e-3
+    assert np.array_equal(idx.cpu().numpy(), ref["idx"])
+    tr.sync()                                     # and back: the trainer's pack kernels write the same buffers again
+    sc = tr._forward(ft)[1]
+    torch.cuda.synchronize()
+    assert np.abs(sc.cpu().numpy() - ref["scmap"]).max() < 1e-4 * np.abs(ref["scmap"]).max()
