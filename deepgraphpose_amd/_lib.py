@@ -83,6 +83,11 @@ SYMBOLS = {
     "dgp_f32_to_h2": (C.c_int, [_vp, _sz, _i32, _vp, _vp]),
     "dgp_h2_to_f32": (C.c_int, [_vp, _sz, _i32, _vp, _vp]),
     "dgp_conv2d_h2": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "dgp_net_set_tier": (C.c_int, [_vp, _i32]),
+    "dgp_net_get_tier": (C.c_int, [_vp]),
+    "dgp_f32_to_h1": (C.c_int, [_vp, _sz, _i32, _vp, _vp]),
+    "dgp_h1_to_f32": (C.c_int, [_vp, _sz, _i32, _vp, _vp]),
+    "dgp_conv2d_h1": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "dgp_chain_h2": (C.c_int, [_i32] * 9 + [_vp, _i32, _vp, _i32] + [_vp] * 6 + [_vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     "dgp_unit_h2": (C.c_int, [_i32] * 7 + [_vp, _i32, _vp, _i32] + [_vp] * 3 + [_i32] + [_vp] * 6 + [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "dgp_net_range_status": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), _vp]),

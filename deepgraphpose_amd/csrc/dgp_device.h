@@ -129,6 +129,24 @@ __device__ __forceinline__ void h2_unpack8(const uint4 hi, const uint4 lo, float
     for (int k = 0; k < 8; ++k) v[k] = ((float)h[k] + (float)l[k]) * inv_scale;      // hi + lo is exact in fp32 (22 bits)
 }
 
+// ---- H1 activation format (the 16-bit tier): 8 consecutive channels of a pixel = ONE 16-byte cell of 8 halves holding
+// fp16(x * scale) -- bit for bit the HIGH cell of the H2 pair (same v_fma_mixlo/hi_f16 rounding), i.e. plain NHWC fp16 with a
+// per-tensor power-of-two scale.  Half the bytes of H2 / fp32 in HBM, L2 and LDS; 11 significant bits.
+__device__ __forceinline__ uint4 h1_pack8(const float (&v)[8], float scale) {
+    unsigned h[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h[k]) : "v"(scale), "v"(v[2 * k]));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h[k]) : "v"(scale), "v"(v[2 * k + 1]));
+    }
+    return make_uint4(h[0], h[1], h[2], h[3]);
+}
+__device__ __forceinline__ void h1_unpack8(const uint4 c, float inv_scale, float (&v)[8]) {
+    const half8 h = __builtin_bit_cast(half8, c);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (float)h[k] * inv_scale;
+}
+
 // ReLU gate read from an H2 tensor: 4 channels' high halves (h) and low halves (l); the stored value hi + lo is > 0 exactly when
 // hi > 0, or hi == 0 and lo > 0.  Returned as 4 floats that compare > 0 like the value.
 __device__ __forceinline__ float h2_half_bits(unsigned v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)v); }

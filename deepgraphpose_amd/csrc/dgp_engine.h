@@ -29,15 +29,18 @@ struct ConvLayer {
     bool has_bn = true, relu = false;
     float *d_w = nullptr, *d_scale = nullptr, *d_bias = nullptr;
     void* d_wh3 = nullptr;    // fp16 high/low cells of the panel (fp16-split kernels), built at load
+    void* d_wh1 = nullptr;    // 16-bit tier: high-only cells (launch_pack_h1), built at load for layers with K % 64 == 0
     // conv3 of a unit with a shortcut conv: both 1x1 convs as ONE K-concatenated GEMM [R2 | X] [W3 s3 ; Wsc ssc] + (b3 + bsc)
     float *d_w_fused = nullptr, *d_bias_fused = nullptr;
     void* d_wh3_fused = nullptr;
+    void* d_wh1_fused = nullptr;
     int nk_fused = 0, cin2 = 0;
     float* d_w_rows = nullptr;   // stem only: panel for the row walk [7 rows x 8 pixels][CoutP][4] (pixel 7 and channel 3 are zero)
     // heads only: the transposed conv as ONE pointwise GEMM [pixels x 2048] x [2048 x (4 taps x 4 phases x nj)] + a gather of the
     // <= 4 tap contributions per output pixel (reads the 2048-channel map once instead of four shifted times)
     float* d_w_pw = nullptr;
     void* d_wh3_pw = nullptr;
+    void* d_wh1_pw = nullptr;
     int coutp_pw = 0;
 };
 
@@ -85,6 +88,10 @@ struct dgp_net {
     std::vector<dgp::Unit> units;
     std::vector<dgp::ChainPlan> chains;       // chains[ui]: conv3 of unit ui + conv1 of unit ui + 1 (ok = false: layer by layer)
     bool loaded = false;
+    // precision tier (dgp_net_set_tier): 0 = parity tier (H2 cells, 22-bit operands as fp16 pairs, three MFMAs per product);
+    // 1 = 16-bit tier (H1 cells: 2-byte activations end to end, fp16 operands, one MFMA per product, fp32 accumulation / epilogues /
+    // heads / soft-argmax).  Scales, calibration and the range check are shared; switching tiers re-calibrates.
+    int tier = 0;
     // geometry
     int h1 = 0, w1 = 0, hp = 0, wp = 0, fh = 0, fw = 0;
     // operand ranges of the fp16-split conv kernels: ABSMAX_SLOTS floats per tensor.  d_wmax[li]: weight panel of
@@ -129,6 +136,7 @@ struct dgp_net {
             if (l.d_w_rows) (void)hipFree(l.d_w_rows);
             if (l.d_w_pw) (void)hipFree(l.d_w_pw);
             if (l.d_wh3_pw) (void)hipFree(l.d_wh3_pw);
+            for (void* q : {l.d_wh1, l.d_wh1_fused, l.d_wh1_pw}) if (q) (void)hipFree(q);
             for (void* q : {(void*)l.d_w_fused, (void*)l.d_bias_fused, l.d_wh3_fused}) if (q) (void)hipFree(q);
         }
         for (auto& c : chains) dgp::free_chain_plan(c);

@@ -61,7 +61,8 @@ struct ConvArgs {
     // [8 halves hi | 8 halves lo] = 32 bytes, the same footprint and the same addresses as 8 fp32 channels -- holding x * scale with
     // scale = 2^e chosen per tensor by the engine (calibrated, with headroom; host-known, so it travels as a kernel argument).
     // Consumers copy the cells straight into the MFMA operand image (no split arithmetic in the K loop); producers split once in
-    // the epilogue.  0 = fp32, 1 = H2.
+    // the epilogue.  0 = fp32, 1 = H2, 2 = H1 (the 16-bit tier: ONE 16-byte cell of 8 halves per 8 channels = the H2 pair's high cell,
+    // half the bytes; wh3 then points at high-only weight cells, launch_pack_h1; in with out 0 or 2, residual 2).
     int   in_fmt, out_fmt, res_fmt;
     float in_scale;           // in (and in2) cells hold x * in_scale
     float out_scale;          // cells written hold out * out_scale
@@ -80,7 +81,6 @@ struct ConvArgs {
     const float* out_scale_dev;
     const float* res_scale_dev;
     int mask_fmt;             // 1: the ReLU gate tensor (mask) is H2: gate = stored value > 0
-    int hi_only;              // H2 kernels with 128-column tiles: the 16-bit tier (DGP_CONV_MODE=f16) -- one MFMA per product, high cells only
 };
 
 constexpr int ABSMAX_SLOTS = 256;
@@ -91,6 +91,10 @@ hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s);
 int        pick_tile(int M, int CoutP, int K, bool have_absmax = false);
 // fp32 panel [nk*8][CoutP][4] -> fp16 cells [nk*4 k-groups][2 planes][CoutP][8 halves] in the LDS order of the fp16-split kernels
 hipError_t launch_pack_h3(const float* panel, int nk, int CoutP, const float* w_absmax, void* out, hipStream_t s);
+// fp32 panel -> H1 cells [nk*4 k-groups of 8 channels][CoutP][8 halves]: the high plane of launch_pack_h3's cells, compacted (16-bit tier)
+hipError_t launch_pack_h1(const float* panel, int nk, int CoutP, const float* w_absmax, void* out, hipStream_t s);
+hipError_t launch_f32_to_h1(const float* x, long long n_groups8, float scale, void* out, hipStream_t s);
+hipError_t launch_h1_to_f32(const void* x, long long n_groups8, float inv_scale, float* out, hipStream_t s);
 struct PackH3Desc { const float* panel; int nkg; int CoutP; const float* rng; void* out; };      // nkg = nk * 4 k-groups
 hipError_t launch_pack_h3_all(const PackH3Desc* table_dev, int n, hipStream_t s);
 hipError_t launch_absmax(const float* x, long long n, float* out_slots, hipStream_t s);   // slots = max(slots, max |x|)
@@ -106,7 +110,7 @@ hipError_t launch_h2_range_check(const float* amax_slots, const int* exps, int n
 // root block fused: uint8 frames -> conv1 (7x7/2) + BN + ReLU -> 3x3/2 max-pool -> H2 cells [B, HP, WP, 64] with scale out_scale
 hipError_t launch_stem_pool_fused(const unsigned char* frames, int B, int H, int W, const void* wcells, const float* w_absmax,
                                   const float* bn_scale, const float* bn_bias, float m0, float m1, float m2, float out_scale,
-                                  float* out, float* out_absmax, hipStream_t s);
+                                  float* out, float* out_absmax, hipStream_t s, int out_h1 = 0);
 hipError_t launch_preprocess(const uint8_t* f, long long npix, float m0, float m1, float m2,
                              float* out, hipStream_t s);
 hipError_t launch_motion_energy(const uint8_t* frames, long long frame_bytes, int n_frames, const uint8_t* prev_frame,

@@ -866,9 +866,12 @@ __device__ __forceinline__ void split3_bf16(const float4 v, uint2& p1, uint2& p2
 // a row -- two 16-byte reads of the staged tile, the residual's cell pair (H2 or fp32: the same 32 bytes at the same address),
 // scale / bias / residual / ReLU in fp32, max |out| tracking, ONE split with the tensor's scale and two 16-byte stores (32 contiguous
 // bytes per lane, 512 per row of a 128-column tile).  Chunks of two row groups are software-pipelined like ls_epilogue's.
-template <int TM, int TN, int WN, bool M16 = false>
+// O1: the output (and the residual, when there is one) is an H1 tensor -- ONE 16-byte cell of 8 halves per lane at HALF the byte offset
+// (the 16-bit tier; ConvArgs::out_fmt == 2).
+template <int TM, int TN, int WN, bool M16 = false, bool O1 = false>
 __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc)[TM][TN], char* smem, int wave, int lane,
                                                int m0, int n0, int wave_m0, int wave_n0, float post) {
+    constexpr int OSH = O1 ? 1 : 2;                // log2 bytes per channel of the output / residual tensors
     constexpr int LDC = WN + 4;
     constexpr int C8 = WN / 8;                     // lanes per row
     constexpr int RPI = 64 / C8;                   // rows per wave-instruction
@@ -906,22 +909,22 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
             const int row = my_r0 + (v0 + u) * RPI;
             const int m = m0 + wave_m0 + 32 * i + row;
             const bool ok = cok && m < p.M;
-            ooff[slot][u] = ok ? ((unsigned)(m * p.Cout + co8) << 2) : OOB;
+            ooff[slot][u] = ok ? ((unsigned)(m * p.Cout + co8) << OSH) : OOB;
             if (p.res) {
                 unsigned roff = OOB;
                 if (p.res_s == 1) {
                     roff = ooff[slot][u];
                 } else if (p.res_s > 1 && ok) {
                     const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                    roff = (unsigned)(((n * p.res_H + ho * p.res_s) * p.res_W + wo * p.res_s) * p.Cout + co8) << 2;
+                    roff = (unsigned)(((n * p.res_H + ho * p.res_s) * p.res_W + wo * p.res_s) * p.Cout + co8) << OSH;
                 }
                 const unsigned roff1 = roff == OOB ? OOB : roff + 16u;
                 if (p.epi_nt & 1) { // streamed once: keep it from evicting the operand rows the other column tiles still need
                     rres[slot][u][0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)roff, 0, 2));
-                    rres[slot][u][1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)roff1, 0, 2));
+                    if (!O1) rres[slot][u][1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)roff1, 0, 2));
                 } else {
                     rres[slot][u][0] = __builtin_bit_cast(uint4, buf_load16(rs_res, roff));
-                    rres[slot][u][1] = __builtin_bit_cast(uint4, buf_load16(rs_res, roff1));
+                    if (!O1) rres[slot][u][1] = __builtin_bit_cast(uint4, buf_load16(rs_res, roff1));
                 }
             }
         }
@@ -949,7 +952,8 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
             float o[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
             float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (p.res) {
-                if (p.res_fmt) h2_unpack8(rres[slot][u][0], rres[slot][u][1], res_inv_scale, r);
+                if (O1) h1_unpack8(rres[slot][u][0], res_inv_scale, r);
+                else if (p.res_fmt) h2_unpack8(rres[slot][u][0], rres[slot][u][1], res_inv_scale, r);
                 else {
                     const float4 r0 = __builtin_bit_cast(float4, rres[slot][u][0]), r1 = __builtin_bit_cast(float4, rres[slot][u][1]);
                     r[0] = r0.x; r[1] = r0.y; r[2] = r0.z; r[3] = r0.w; r[4] = r1.x; r[5] = r1.y; r[6] = r1.z; r[7] = r1.w;
@@ -960,6 +964,11 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
                 o[k] = o[k] * sc[k] + bi[k] + r[k];
                 if (p.relu) o[k] = fmaxf(o[k], 0.f);
             }
+            if constexpr (O1) {
+                const uint4 hc = h1_pack8(o, out_scale);
+                if (p.epi_nt & 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hc), rs_out, (int)ooff[slot][u], 0, 2);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hc), rs_out, (int)ooff[slot][u], 0, 0);
+            } else {
             uint4 hi, lo;
             h2_pack8(o, out_scale, hi, lo);
             const unsigned ooff1 = ooff[slot][u] == OOB ? OOB : ooff[slot][u] + 16u;
@@ -969,6 +978,7 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
             } else {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), rs_out, (int)ooff[slot][u], 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), rs_out, (int)ooff1, 0, 0);
+            }
             }
             if (ooff[slot][u] != OOB) {
 #pragma unroll
@@ -1002,9 +1012,13 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
 //   3 / 4, small inference batches): there a CU holds one workgroup and nothing else hides the L2 round trip of the weight cells.
 //   Measured per launch, one stream (rocprofv3, 11 frames): 208 tiles pointwise K = 1024 44.7 -> 40.3 us, 3x3 67.6 -> 63.7 us; with more
 //   than one tile per CU the 80-KB kernels' second resident workgroup is worth more (416 tiles: 88 -> 111 us), so those keep them.
-//   T16 (AH2 DMA kernels; DGP_CONV_MODE=f16, the reported 16-bit tier): one MFMA per product -- high cell x high cell -- instead of
-//   three; the low cells still travel (same tensors, same LDS images) but are neither read from LDS nor multiplied.  11-bit operands:
-//   NOT inside the 1e-3 px gate (bench.py reports what it measures), a third of the matrix work.
+//   H1 (AH2 DMA kernels, round 5; the 16-bit tier, dgp_net_set_tier(net, 1)): the A operand is an H1 tensor -- ONE 16-byte cell of 8
+//   halves per 8 channels, half the bytes of H2 -- and the weights are high cells only.  Everything that moves bytes is UNCHANGED: the
+//   launcher hands the kernel the tensor in 4-byte units (Cin / 2 "floats" per pixel), so a K-step's 128-byte line per pixel now holds 64
+//   channels, and the weight cells [k-group of 8 channels][column] have the addresses the [k-group of 16][plane] pairs had.  What was the
+//   (high, low) cell pair of k-group g is now the pair of k-groups (2 g, 2 g + 1): the compute waves issue a_even b_even + a_odd b_odd --
+//   TWO MFMAs per 64 channels where the parity tier issues three per 32 -- on the same LDS reads.  A third of the matrix work and half the
+//   operand bytes per FLOP; 11-bit operands: NOT inside the 1e-3 px gate (bench.py reports what it measures).  O1 = H1 output.
 //   BM = 256, CW = 8 (the "tall" tile, H2 DMA kernels): eight compute waves of 32 rows x 128 columns each -- the same inner loop -- on
 //   ONE B stage: two co-resident 128-row workgroups fetch the same 16 KB of weight cells per K-step twice, a 256-row workgroup once
 //   (48 instead of 64 KB of L2 -> LDS traffic per CU and K-step).  That path, ~70 GB/s per CU (MI355X_MICROARCH.md, rows served
@@ -1039,11 +1053,11 @@ constexpr int HALO_TBL = HALO_ZERO + 1024;        // three stages of the address
                                                   // written two steps ahead, read one step ahead: the stage being written is never one being read)
 constexpr int HALO_B0 = HALO_TBL + 2048;          // two stages of weight cells behind it: 49 152 + 32 768 = 80 KB, two workgroups per CU
 static_assert(HALO_B0 == 49152, "80 KB per workgroup");
-template <int BM, int BN, int NT, int BK, int CW, bool PB = false, int MODE = 0, bool CS = false, bool DMA = false, bool AH2 = false, bool OH2 = false, bool DEEP = false, bool T16 = false>
+template <int BM, int BN, int NT, int BK, int CW, bool PB = false, int MODE = 0, bool CS = false, bool DMA = false, bool AH2 = false, bool OH2 = false, bool DEEP = false, bool H1 = false>
 __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK == 16 || NT == 2) ? 4 : 2)) void conv_igemm_split_ls(const ConvArgs p) {
-    static_assert(MODE != 3 || (DMA && AH2 && OH2 && BM == 128 && BN == 128 && CW == 4 && !DEEP && !T16), "halo walk: H2 tensors, LDS-DMA, 128 x 128 tiles");
+    static_assert(MODE != 3 || (DMA && AH2 && OH2 && BM == 128 && BN == 128 && CW == 4 && !DEEP), "halo walk: H2 / H1 tensors, LDS-DMA, 128 x 128 tiles");
     static_assert(!DEEP || (DMA && BN == 128 && BM == 128), "deep ring: LDS-DMA kernels with 128 x 128 tiles");
-    static_assert(!T16 || (AH2 && DMA && !DEEP), "16-bit tier: H2 input, LDS-DMA kernels");
+    static_assert(!H1 || (AH2 && DMA && !DEEP && BM == 128), "16-bit tier: cell input, LDS-DMA kernels");
     static_assert(!AH2 || CS, "pre-split A operand: compute-side-split kernels only");
     static_assert(!OH2 || AH2, "H2 output: kernels with H2 input only (the stem writes fp32, the pool converts)");
     // compute waves: 2 x (CW / 2) over the tile; with the compute-side split 4 x 1 (each wave owns 32 rows and ALL columns, so no
@@ -1662,8 +1676,11 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK
 #define DGP_RA(I) do { ra[I][0] = *reinterpret_cast<const uint4*>(smem + a_adr[I]);                                 \
                        ra[I][1] = *reinterpret_cast<const uint4*>(smem + a_adr[I] + 256); } while (0)
 #define DGP_RB(F) do { bq[(F) & 3] = B[((((F) & 1) ? 0 : 1) * KG) * LDB + 16 * (((F) % NF) >> 1)]; } while (0)
+        // (H1: fragment F even = plane 1 = the odd k-groups' weights x the odd chunks `al`; F odd = plane 0 x the even chunks `ah`)
 #define DGP_MM(F) do { constexpr int j_ = (F) >> 1;                                                                \
-        if (((F) & 1) == 0) { c[0][j_] = mma(ah[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(ah[1], bq[(F) & 3], c[1][j_]); }    \
+        if constexpr (H1) { if (((F) & 1) == 0) { c[0][j_] = mma(al[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(al[1], bq[(F) & 3], c[1][j_]); } \
+                            else { c[0][j_] = mma(ah[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(ah[1], bq[(F) & 3], c[1][j_]); } }              \
+        else if (((F) & 1) == 0) { c[0][j_] = mma(ah[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(ah[1], bq[(F) & 3], c[1][j_]); }    \
         else { c[0][j_] = mma(al[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(al[1], bq[(F) & 3], c[1][j_]);         \
                c[0][j_] = mma(ah[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(ah[1], bq[(F) & 3], c[1][j_]); } } while (0)
 #define DGP_STEP(F) do { DGP_MM(F); DGP_FENCE(); DGP_RB((F) + 4); DGP_FENCE(); } while (0)
@@ -1751,7 +1768,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK
             ra[I][0] = *reinterpret_cast<const uint4*>(smem + a_cur + (I) * 2048);                                 \
             ra[I][1] = *reinterpret_cast<const uint4*>(smem + (a_cur ^ 16u) + (I) * 2048);                         \
         } else { ra[I][0] = A[16 * (I)]; ra[I][1] = A[LDAF + 16 * (I)]; } } while (0)
-#define DGP_RB(F) do { if constexpr (!T16 || ((F) & 1)) bq[(F) & 3] = B[((((F) & 1) ? 0 : 1) * KG) * LDB + 16 * (((F) % NF) >> 1)]; } while (0)
+#define DGP_RB(F) do { bq[(F) & 3] = B[((((F) & 1) ? 0 : 1) * KG) * LDB + 16 * (((F) % NF) >> 1)]; } while (0)
 #if defined(DGP_X) && DGP_X == 1      // timing-only stand-in: the A operand as if it arrived pre-split (no split arithmetic)
 #define DGP_SPLIT(I) do { ah[I] = ra[I][0]; al[I] = ra[I][1]; } while (0)
 #else
@@ -1762,7 +1779,8 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK
         ah[I] = make_uint4(h0_.x, h0_.y, h1_.x, h1_.y); al[I] = make_uint4(l0_.x, l0_.y, l1_.x, l1_.y); } while (0)
 #endif
 #define DGP_MM(F) do { constexpr int j_ = (F) >> 1;                                                                \
-        if constexpr (T16) { if ((F) & 1) { c[0][j_] = mma(ah[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(ah[1], bq[(F) & 3], c[1][j_]); } } \
+        if constexpr (H1) { if (((F) & 1) == 0) { c[0][j_] = mma(al[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(al[1], bq[(F) & 3], c[1][j_]); } \
+                            else { c[0][j_] = mma(ah[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(ah[1], bq[(F) & 3], c[1][j_]); } }              \
         else if (((F) & 1) == 0) { c[0][j_] = mma(ah[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(ah[1], bq[(F) & 3], c[1][j_]); }    \
         else { c[0][j_] = mma(al[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(al[1], bq[(F) & 3], c[1][j_]);         \
                c[0][j_] = mma(ah[0], bq[(F) & 3], c[0][j_]); c[1][j_] = mma(ah[1], bq[(F) & 3], c[1][j_]); } } while (0)
@@ -2049,7 +2067,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK
         ls_store_raw<TM, TN, WN, M16>(acc, smem, wave, lane, wave_m0, wave_n0, p.slab + (size_t)tail_slot * (BM * BN), BN);
         return;
     }
-    if constexpr (OH2) ls_epilogue_h2<TM, TN, WN, M16>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
+    if constexpr (OH2) ls_epilogue_h2<TM, TN, WN, M16, H1>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
     else ls_epilogue<TM, TN, WN, M16>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
 #ifdef DGP_DIAG
     DIAG_STAMP(e2);
@@ -2188,6 +2206,12 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     if (NT == 2 && ((!a.in_absmax && !a.in_fmt) || !a.w_absmax)) return hipErrorInvalidValue;      // fp16 split needs both ranges (H2 input carries its scale)
     if ((a.in_fmt || a.out_fmt) && !(NT == 2 && BK == 32 && CW == 4 && a.wh3 && (a.Cout % 8) == 0 && (a.Cin % 8) == 0 && !a.up && !a.stem && !a.mask))
         return hipErrorInvalidValue;                                                 // H2 tensors: fp16-split cell kernels only
+    // 16-bit tier (in_fmt 2: H1 cells, already in 4-byte units here -- launch_conv): H1 or fp32 output, H1 residual, no predicted scales
+    const bool h1 = a.in_fmt == 2;
+    if (h1 != (a.out_fmt == 2) && a.out_fmt != 0) return hipErrorInvalidValue;
+    if (a.out_fmt == 2 && !h1) return hipErrorInvalidValue;
+    if (a.res && (a.res_fmt == 2) != (a.out_fmt == 2)) return hipErrorInvalidValue;
+    if (h1 && (a.in_scale_dev || a.out_scale_dev || a.res_scale_dev || a.shadow)) return hipErrorInvalidValue;
     // non-temporal residual loads / output stores in the H2 epilogue (A/B switch DGP_EPI_NT; 0: off, 1: every layer, 2 (default): only
     // layers with >= 8 column tiles (N >= 1024: conv3 of block3 / block4), 3 / 4: their loads / stores only).  There the 128 KB a tile
     // streams through the epilogue evict the A rows the other column tiles of the row block still read: PMC FETCH_SIZE 1061 MB per
@@ -2215,7 +2239,7 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     // halo walk (MODE 3, see the kernel): 3x3 / stride 1 convs of the H2 engine on 128 x 128 tiles whose tap shifts fit the pixel ring.
     // A/B switch DGP_HALO=0
     static const int halo_env = dgp_env("DGP_HALO", 1);
-    const bool halo = halo_env && BM == 128 && BN == 128 && CW == 4 && NT == 2 && BK == 32 && mode == 1 && a.in_fmt && a.out_fmt && a.wh3 && !a.hi_only &&
+    const bool halo = halo_env && BM == 128 && BN == 128 && CW == 4 && NT == 2 && BK == 32 && mode == 1 && a.in_fmt && a.out_fmt && a.wh3 &&
                       a.KH == 3 && a.KW == 3 && a.ntaps == 9 && a.stride == 1 && a.dil >= 1 && a.pad_t == a.dil && a.pad_l == a.dil && a.H == a.Ho &&
                       a.W == a.Wo && a.W >= 2 && (a.Cin % 32) == 0 && a.nk * 32 == 9 * a.Cin && a.tap_rows == (a.Cin >> 2) && !a.in_scale_dev &&
                       (unsigned long long)a.M * a.Cin * 4ull == a.in_bytes && a.in_bytes < 4000000000u &&
@@ -2251,7 +2275,7 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
         static int n_cu_d = 0;
         if (!n_cu_d) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu_d, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu_d <= 0) n_cu_d = 256; }
         const long long ntile = (long long)((a.M + BM - 1) / BM) * ((a.CoutP + BN - 1) / BN);
-        deep = CAN_DEEP && deep_env && (deep_env == 2 || ntile <= (long long)n_cu_d) && a.nk >= 6 && !(a.hi_only && a.in_fmt && a.out_fmt);
+        deep = CAN_DEEP && deep_env && (deep_env == 2 || ntile <= (long long)n_cu_d) && a.nk >= 6 && !h1;
         if (deep) {
             if constexpr (CAN_DEEP)
                 kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, 2, CAN_DEEP, CAN_DEEP, false, false, CAN_DEEP>
@@ -2260,7 +2284,26 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
         }
         if (smem < smem_epi) smem = smem_epi;
     }
-    if (a.in_fmt) {        // H2 input: the same kernels without the split (AH2); H2 output: epilogue variant (OH2)
+    if (h1) {              // H1 input (16-bit tier): LDS-DMA kernels only; H1 output (O1 epilogue) or fp32 output (the heads' pointwise GEMM)
+        if (!cs || !dma) return hipErrorInvalidValue;
+        if constexpr (CAN_DMA) {
+            if (a.out_fmt) {
+                kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 2, CAN_DMA, CAN_DMA, CAN_DMA, CAN_DMA, false, CAN_DMA>
+                                 : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 1, CAN_DMA, CAN_DMA, CAN_DMA, CAN_DMA, false, CAN_DMA>;
+                if constexpr (CAN_DEEP) {
+                    if (halo) {
+                        kern = conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, CAN_DEEP ? 3 : 1, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP, false, CAN_DEEP>;
+                        smem = (size_t)HALO_B0 + 2 * (size_t)(NP * KG * BN) * 16;
+                        if (smem < smem_epi) smem = smem_epi;
+                        use_halo = true;
+                    }
+                }
+            } else {
+                if (mode != 2 || a.res) return hipErrorInvalidValue;
+                kern = conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DMA, 2, CAN_DMA, CAN_DMA, CAN_DMA, false, false, CAN_DMA>;
+            }
+        }
+    } else if (a.in_fmt) {        // H2 input: the same kernels without the split (AH2); H2 output: epilogue variant (OH2)
         if (!cs) return hipErrorInvalidValue;
         if constexpr (CAN_CS) {
             if (a.out_fmt) {
@@ -2279,9 +2322,6 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
                     if constexpr (CAN_DEEP) {
                         if (deep) kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, 2, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP>
                                                    : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, 1, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP>;
-                        else if (a.hi_only)       // 16-bit tier (128-column tiles; the 64-column layers keep three products)
-                            kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, 2, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP, false, CAN_DEEP>
-                                             : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_DEEP, 1, CAN_DEEP, CAN_DEEP, CAN_DEEP, CAN_DEEP, false, CAN_DEEP>;
                     }
                 } else {
                     kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 2, CAN_CS, false, CAN_CS, CAN_CS>
@@ -2298,14 +2338,15 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
             }
         }
     } else if (a.out_fmt) return hipErrorInvalidValue;
-    static bool attr_done_dev[16][3][6][4] = {};
+    static bool attr_done_dev[16][5][5][4] = {};
     auto& attr_done = attr_done_dev[dgp_device_slot()];
     const int mode_slot = use_halo ? 3 : mode;
-    if (!attr_done[a.in_fmt ? (a.out_fmt ? 2 : 1) : 0][(a.hi_only && dma && a.in_fmt && a.out_fmt && BN == 128 && !deep) ? 5 : deep ? 4 : dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode_slot]) {
+    const int fmt_slot = h1 ? (a.out_fmt ? 4 : 3) : a.in_fmt ? (a.out_fmt ? 2 : 1) : 0, path_slot = deep ? 4 : dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0);
+    if (!attr_done[fmt_slot][path_slot][mode_slot]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_done[a.in_fmt ? (a.out_fmt ? 2 : 1) : 0][(a.hi_only && dma && a.in_fmt && a.out_fmt && BN == 128 && !deep) ? 5 : deep ? 4 : dma ? 3 : cs ? 2 : (a.wh3 ? 1 : 0)][mode_slot] = true;
+        attr_done[fmt_slot][path_slot][mode_slot] = true;
     }
     long long nwg = (long long)a.mtiles * a.ntiles;
     // Grid tail: with `slots` workgroups resident, the last tiles % slots tiles run on a mostly idle chip.  Split their K range
@@ -2314,7 +2355,7 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     static const int tail_env = dgp_env("DGP_TAIL_SPLIT", 1);      // A/B switch
     // (H2 tensors: with the split gone from the K loop the K-split of the tail + its fix-up launch no longer pays -- same-box A/B,
     //  block3 conv1 -7..-24 %, block4 conv1 -12 %, block4 conv2 -5 % without it, +2.5 % end to end -- so tail_env == 2 is needed to force it)
-    if (tail_env && (!a.in_fmt || tail_env == 2) && a.slab && CW == 4 && BN == 128 && !use_halo) {      // (128 x 64 tiles fit three per CU and gain nothing)
+    if (tail_env && (!a.in_fmt || tail_env == 2) && !h1 && a.slab && CW == 4 && BN == 128 && !use_halo) {      // (128 x 64 tiles fit three per CU and gain nothing)
         static int n_cu = 0;
         if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
         const long long slots = 2LL * n_cu;            // two workgroups of these kernels fit a CU
@@ -2392,7 +2433,7 @@ static bool conv_tall_eligible(const ConvArgs& a) {
 #else
     static const int tall_env = dgp_tune("DGP_TALL", 0);              // opt-in (measured slower, see the kernel)
     static const int min_nk = dgp_tune("DGP_TALL_MINK", 48);      // K-steps from which the epilogue is small change
-    if (!tall_env || !a.in_fmt || !a.out_fmt || !a.wh3 || a.hi_only || a.in2 || a.up || a.stem || a.mask || a.out_mode != 0) return false;
+    if (!tall_env || a.in_fmt != 1 || a.out_fmt != 1 || !a.wh3 || a.in2 || a.up || a.stem || a.mask || a.out_mode != 0) return false;
     if (a.CoutP % 128 != 0 || (a.Cout % 8) || (a.Cin % 32)) return false;
     if (tall_env == 2) return true;                // (tests: every shape the kernel can take)
     const long long tiles = (long long)((a.M + 255) / 256) * (a.CoutP / 128);
@@ -2536,8 +2577,8 @@ const char* conv_kernel_name(const ConvArgs& a, int tile_cfg) {
             case TILE_128x128_S6K16W8: return "split6_128x128_k16w8";
             case TILE_128x128_H3K16:   return "splith3_128x128_k16";
             case TILE_128x128_H3K16W8: return "splith3_128x128_k16w8";
-            case TILE_128x128_H3K32:   return conv_tall_eligible(a) ? "splith3_256x128_k32" : "splith3_128x128_k32";
-            case TILE_128x64_H3:       return "splith3_128x64_k32";
+            case TILE_128x128_H3K32:   return a.in_fmt == 2 ? "h1_128x128_k64" : conv_tall_eligible(a) ? "splith3_256x128_k32" : "splith3_128x128_k32";
+            case TILE_128x64_H3:       return a.in_fmt == 2 ? "h1_128x64_k64" : "splith3_128x64_k32";
             case TILE_128x128_S6:    return "split6_128x128_k32";
             case TILE_128x64_S6:     return "split6_128x64_k32";
             case TILE_128x128_S3K16: return "split3_128x128_k16";
@@ -2548,7 +2589,23 @@ const char* conv_kernel_name(const ConvArgs& a, int tile_cfg) {
     return "f32";
 }
 
-hipError_t launch_conv(const ConvArgs& a, int tile_cfg, hipStream_t s) {
+// 16-bit tier: ConvArgs describe the layer in REAL channels and fp32-sized byte extents; the cell kernels address the H1 input in 4-byte
+// units (two halves each), so every quantity the loaders use is halved here, once: channels per pixel, K-steps, panel rows per tap,
+// second-source split, byte extents.  The GEMM's columns (Cout, CoutP) are not touched: the O1 epilogue halves its own byte offsets.
+static bool to_h1_units(ConvArgs& a) {
+    if ((a.Cin & 63) || (a.in2 && (a.cin_split & 63)) || (a.nk & 1) || a.up || a.stem || a.mask || !a.wh3) return false;
+    a.Cin >>= 1; a.cin_split >>= 1; a.nk >>= 1; a.tap_rows >>= 1;
+    a.log2cin4 = ilog2(a.Cin / 4);
+    a.in_bytes >>= 1; a.in2_bytes >>= 1; a.w_bytes >>= 1; a.wh3_bytes >>= 1;
+    if (a.out_fmt == 2) a.out_bytes >>= 1;
+    if (a.res && a.res_fmt == 2) a.res_bytes >>= 1;
+    return true;
+}
+
+hipError_t launch_conv(const ConvArgs& a_in, int tile_cfg, hipStream_t s) {
+    ConvArgs a = a_in;
+    if (a.in_fmt == 2 && !(a.out_mode == 0 && to_h1_units(a))) return hipErrorInvalidValue;
+    if (a.in_fmt != 2 && (a.out_fmt == 2 || a.res_fmt == 2)) return hipErrorInvalidValue;
     if (a.Cin < 32 && !a.stem) {       // generic per-lane tap path (stem / small test shapes)
         if (tile_cfg == TILE_128x32) return launch_conv_t<128, 32, 4, 1, false>(a, s);
         if (tile_cfg == TILE_128x128_W8 || tile_cfg == TILE_128x128_LS || tile_cfg == TILE_128x128_S6 ||

@@ -42,6 +42,14 @@ int pad_before_for(int n, int k, int stride, int rate, bool conv2d_same_explicit
     tf_same(n, k, stride, rate, &out, &pb);
     return pb;
 }
+// The 16-bit tier (dgp_net::tier == 1; DGP_CONV_MODE=f16 makes it the default of every net of the process): H1 cells -- 2-byte
+// activations -- from the pool output to the block4 features, high-only weight cells, one MFMA per product.  Not inside the 1e-3 px gate;
+// bench.py reports what it measures beside the parity tier.
+static bool tier16_env() {
+    static const bool on = getenv("DGP_CONV_MODE") && !strcmp(getenv("DGP_CONV_MODE"), "f16");
+    return on;
+}
+
 static int pow2_exp_for_max(float mx) {        // e with max * 2^e in [2^14, 2^15) -- the weight scale of the fp16 split (pow2_scale_for)
     if (!(mx > 0.f) || !std::isfinite(mx)) return 0;
     int ex; (void)frexpf(mx, &ex);             // mx = f 2^ex, f in [0.5, 1)
@@ -258,11 +266,20 @@ int dgp_net_create(const dgp_net_desc* d, dgp_net** out) {
     net->h1 = (d->in_h + 1) / 2; net->w1 = (d->in_w + 1) / 2;     // conv2d_same stride 2
     tf_same(net->h1, 3, 2, 1, &net->hp, &pb); tf_same(net->w1, 3, 2, 1, &net->wp, &pb);
     net->fh = (((net->hp + 1) / 2) + 1) / 2; net->fw = (((net->wp + 1) / 2) + 1) / 2;
+    net->tier = tier16_env() ? 1 : 0;
     *out = net;
     return DGP_OK;
 }
 
 void dgp_net_destroy(dgp_net* net) { delete net; }
+
+int dgp_net_set_tier(dgp_net* net, int32_t tier) {
+    if (!net) return fail(DGP_ERR_INVALID, "dgp_net_set_tier: null net");
+    if (tier != 0 && tier != 1) return fail(DGP_ERR_INVALID, "dgp_net_set_tier: tier must be 0 (parity) or 1 (16-bit)");
+    if (tier != net->tier) { net->tier = tier; net->h2_calibrated = false; }      // the next forward calibrates the scales on this tier's tensors
+    return DGP_OK;
+}
+int dgp_net_get_tier(const dgp_net* net) { return net ? net->tier : 0; }
 
 int dgp_net_set_input_size(dgp_net* net, int32_t in_h, int32_t in_w) {
     if (!net) return fail(DGP_ERR_INVALID, "dgp_net_set_input_size: null net");
@@ -421,11 +438,17 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
             float* wm = net->d_wmax + (nl + li) * ABSMAX_SLOTS;
             e = launch_absmax(l.d_w_pw, (long long)nkpw * 8 * l.coutp_pw * 4, wm, nullptr);
             if (e == hipSuccess) e = launch_pack_h3(l.d_w_pw, nkpw, l.coutp_pw, wm, l.d_wh3_pw, nullptr);
+            if (e == hipSuccess && !l.d_wh1_pw) e = hipMalloc(&l.d_wh1_pw, (size_t)nkpw * 8 * l.coutp_pw * 8);
+            if (e == hipSuccess) e = launch_pack_h1(l.d_w_pw, nkpw, l.coutp_pw, wm, l.d_wh1_pw, nullptr);
             if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("head pointwise panel: ") + hipGetErrorString(e));
         } else if (l.Cin >= 32 && l.CoutP % 64 == 0) {          // layers the fp16-split kernels can take: pre-split cells
             const size_t bytes = (size_t)l.nk * 8 * l.CoutP * 16;
             if (!l.d_wh3) HIP_TRY(hipMalloc(&l.d_wh3, bytes));
             e = launch_pack_h3(l.d_w, l.nk, l.CoutP, net->d_wmax + li * ABSMAX_SLOTS, l.d_wh3, nullptr);
+            if (e == hipSuccess && (l.Cin % 64) == 0 && (l.nk % 2) == 0) {      // 16-bit tier: a K-step is 64 channels
+                if (!l.d_wh1) e = hipMalloc(&l.d_wh1, bytes / 2);
+                if (e == hipSuccess) e = launch_pack_h1(l.d_w, l.nk, l.CoutP, net->d_wmax + li * ABSMAX_SLOTS, l.d_wh1, nullptr);
+            }
             if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("weight cells: ") + hipGetErrorString(e));
         }
     }
@@ -454,6 +477,10 @@ int dgp_net_load_weights(dgp_net* net, const dgp_tensor_view* tensors, int32_t n
         float* wm = net->d_wmax + (nl + (size_t)u.c3) * ABSMAX_SLOTS;
         hipError_t e = launch_absmax(l3.d_w_fused, (long long)nfl, wm, nullptr);
         if (e == hipSuccess) e = launch_pack_h3(l3.d_w_fused, l3.nk_fused, l3.CoutP, wm, l3.d_wh3_fused, nullptr);
+        if (e == hipSuccess && (c1 % 64) == 0 && (c2 % 64) == 0) {
+            if (!l3.d_wh1_fused) e = hipMalloc(&l3.d_wh1_fused, nfl * 2);
+            if (e == hipSuccess) e = launch_pack_h1(l3.d_w_fused, l3.nk_fused, l3.CoutP, wm, l3.d_wh1_fused, nullptr);
+        }
         if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("fused shortcut panel: ") + hipGetErrorString(e));
     }
     // conv3 of unit k (+ shortcut) and conv1 of unit k + 1 as one launch (dgp_chain.hip) wherever a kernel instance exists
@@ -566,15 +593,7 @@ double conv_flops_of(const ConvLayer& l, int M, bool is_head) {
 // H2 formats / scale exponents of a launch's tensors (all zero: fp32 everywhere)
 struct H2Spec { int in_fmt = 0, in_exp = 0, out_fmt = 0, out_exp = 0, res_fmt = 0, res_exp = 0; };
 
-// DGP_CONV_MODE=f16: the reported 16-bit tier -- the H2 engine as it is (layer by layer), the 128-column conv kernels multiplying the high
-// cells only (one MFMA per product instead of three).  Not inside the 1e-3 px gate; bench.py runs it in a child and reports what it measures.
-static bool tier16_mode() {
-    static const bool on = getenv("DGP_CONV_MODE") && !strcmp(getenv("DGP_CONV_MODE"), "f16");
-    return on;
-}
-
 void apply_h2(ConvArgs& a, const H2Spec& h) {
-    a.hi_only = (tier16_mode() && h.in_fmt && h.out_fmt) ? 1 : 0;
     a.in_fmt = h.in_fmt; a.out_fmt = h.out_fmt; a.res_fmt = h.res_fmt;
     a.in_scale = ldexpf(1.f, h.in_exp); a.out_scale = ldexpf(1.f, h.out_exp); a.res_inv_scale = ldexpf(1.f, -h.res_exp);
 }
@@ -615,6 +634,7 @@ int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, in
     }
     static const bool use_cells = (dgp_env("DGP_PRESPLIT_WEIGHTS", 1) != 0);   // A/B switch
     if (use_cells && ranged && l.d_wh3 && (li != net->conv1 || a.stem)) { a.wh3 = l.d_wh3; a.wh3_bytes = a.w_bytes; }
+    if (h2.in_fmt == 2) { a.wh3 = l.d_wh1; a.wh3_bytes = a.w_bytes; }       // (null: launch_conv refuses)
     const int tile_cfg = pick_tile(a.M, a.CoutP, a.nk * BK, ranged && a.w_absmax);
     ProfScope ps(net, s, "conv:" + l.scope + "|" + conv_kernel_name(a, tile_cfg), conv_flops_of(l, a.M, out_mode == 1));
     const long long out_n = (long long)N * 4 * Ho * Wo * dc_nj;
@@ -647,7 +667,7 @@ int run_head_pointwise(dgp_net* net, const ConvLayer& l, const float* feat, int 
     const int nl = (int)net->layers.size();
     ConvArgs a{};
     apply_h2(a, h2);
-    a.in = feat; a.wpk = l.d_w_pw; a.wh3 = l.d_wh3_pw; a.out = T;
+    a.in = feat; a.wpk = l.d_w_pw; a.wh3 = h2.in_fmt == 2 ? l.d_wh1_pw : l.d_wh3_pw; a.out = T;
     a.in_absmax = feat_absmax; a.w_absmax = net->d_wmax + (size_t)(nl + li) * ABSMAX_SLOTS;
     a.slab = net->tail_slab; a.slab_bytes = net->tail_slab_bytes;
     a.N = B; a.H = h; a.W = w; a.Cin = 2048; a.log2cin4 = ilog2(2048 / 4);
@@ -688,7 +708,7 @@ int run_conv_fused_shortcut(dgp_net* net, const Unit& u, const float* r2, const 
     a.w_bytes = (unsigned)((size_t)l.nk_fused * 8 * l.CoutP * 16);
     if ((r2_absmax && x_absmax) || h2.in_fmt) {
         a.in_absmax = r2_absmax; a.in2_absmax = x_absmax; a.w_absmax = net->wmax(nl + u.c3);
-        a.wh3 = l.d_wh3_fused; a.wh3_bytes = a.w_bytes;
+        a.wh3 = h2.in_fmt == 2 ? l.d_wh1_fused : l.d_wh3_fused; a.wh3_bytes = a.w_bytes;
     }
     a.out_absmax = net->amax(u.c3);
     a.slab = net->tail_slab; a.slab_bytes = net->tail_slab_bytes;
@@ -814,13 +834,23 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     // fp16 high / low cells with a calibrated per-tensor scale, so the conv kernels' K loops are ds_read + MFMA only (DGP_H2=0: fp32
     // activations, split in the consumers' K loops -- also what the other DGP_CONV_MODEs and a trainer-owned net use).
     static const bool h2_env = (dgp_env("DGP_H2", 1) != 0);
-    static const bool f16_mode = !getenv("DGP_CONV_MODE") || !strcmp(getenv("DGP_CONV_MODE"), "f16x3") || tier16_mode();
+    static const bool f16_mode = !getenv("DGP_CONV_MODE") || !strcmp(getenv("DGP_CONV_MODE"), "f16x3") || tier16_env();
+    const int tier = net->tier, FMT = tier ? 2 : 1;      // activation cells of this forward: H2 (parity tier) or H1 (16-bit tier)
     static const bool head_pw = (dgp_env("DGP_HEAD_PW", 1) != 0);      // A/B switch
     static const bool fuse_env = (dgp_env("DGP_FUSE_SHORTCUT", 1) != 0);      // A/B switch
     static const bool f32_mode = getenv("DGP_CONV_MODE") && !strcmp(getenv("DGP_CONV_MODE"), "f32");
     static const bool cells_env = (dgp_env("DGP_PRESPLIT_WEIGHTS", 1) != 0);
     const bool h2 = h2_env && cells_env && f16_mode && head_pw && net->wmax_valid && net->d_exps && net->layers[net->head_part].d_wh3_pw &&
                     (net->head_locref < 0 || net->layers[net->head_locref].d_wh3_pw) && net->act_exp.size() == net->layers.size();
+    if (tier) {            // the 16-bit tier has no fallback: say what is missing instead of silently running another tier
+        bool ok = h2 && net->layers[net->head_part].d_wh1_pw && (net->head_locref < 0 || net->layers[net->head_locref].d_wh1_pw);
+        for (const Unit& u : net->units) {
+            ok = ok && net->layers[u.c1].d_wh1 && net->layers[u.c2].d_wh1 && net->layers[u.c3].d_wh1 && (u.sc < 0 || net->layers[u.sc].d_wh1);
+            if (u.sc >= 0 && net->layers[u.c3].d_w_fused && !net->layers[u.c3].d_wh1_fused) ok = false;
+        }
+        if (!ok) return fail(DGP_ERR_STATE, "dgp_forward: the 16-bit tier needs the H2 engine's switches at their defaults (DGP_H2, DGP_PRESPLIT_WEIGHTS, "
+                                            "DGP_HEAD_PW, DGP_CONV_MODE unset or f16) and weights loaded by dgp_net_load_weights");
+    }
     const bool calib = h2 && !net->h2_calibrated;
     const int H2_HEAD = net->h2_head;             // bits of headroom between a calibrated maximum and the fp16 limit
     auto exp_for = [H2_HEAD](float mx) {          // scale exponent that puts mx into [2^(14 - H2_HEAD), 2^(15 - H2_HEAD))
@@ -860,13 +890,14 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     // otherwise preprocess -> conv1 -> max-pool as three launches
     static const bool stem_fused_env = (dgp_env("DGP_STEM_FUSED", 1) != 0);
     const ConvLayer& lstem = net->layers[net->conv1];
-    const bool stem_fused = h2 && stem_fused_env && lstem.d_wh3 && lstem.d_w_rows && lstem.CoutP == 64 && lstem.d_scale && lstem.d_bias;
+    const bool stem_fused = h2 && (stem_fused_env || tier) && lstem.d_wh3 && lstem.d_w_rows && lstem.CoutP == 64 && lstem.d_scale && lstem.d_bias;
+    if (tier && !stem_fused) return fail(DGP_ERR_STATE, "dgp_forward: the 16-bit tier needs the fused root block");
     if (stem_fused) {
         rc = layer(net->conv1, [&] {
             ProfScope ps(net, s, "conv:" + lstem.scope + "+pool|stem_pool_fused", conv_flops_of(lstem, B * net->h1 * net->w1, false));
             hipError_t e2 = launch_stem_pool_fused(frames, B, d.in_h, d.in_w, lstem.d_wh3, net->wmax(net->conv1), lstem.d_scale, lstem.d_bias,
                                                    d.mean_pixel[0], d.mean_pixel[1], d.mean_pixel[2],
-                                                   ldexpf(1.f, net->act_exp[net->conv1]), X[0], net->amax(net->conv1), s);
+                                                   ldexpf(1.f, net->act_exp[net->conv1]), X[0], net->amax(net->conv1), s, tier ? 1 : 0);
             return e2 == hipSuccess ? (int)DGP_OK : fail(DGP_ERR_HIP, std::string("stem + pool: ") + hipGetErrorString(e2));
         });
         if (rc) return rc;
@@ -897,7 +928,7 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     // conv3(k) + conv1(k + 1) as one launch (DGP_CHAIN=0: layer by layer).  Calibration runs layer by layer (it needs every tensor's
     // range before the next layer runs) and is followed by a second, chained pass, so results never depend on which pass produced them
     static const bool chain_env = (dgp_env("DGP_CHAIN", 1) != 0);
-    const bool chain_on = h2 && !calib && chain_env && !tier16_mode() && net->chains.size() == net->units.size();
+    const bool chain_on = h2 && !calib && chain_env && !tier && net->chains.size() == net->units.size();
     static const bool unit_env = (dgp_env("DGP_UNIT", 1) != 0);      // conv2 inside the chain launch (block1)
     bool r1_ready = false;                            // R1 of this unit came out of the previous unit's chain launch
     float *Ra = R1, *Rb = R2;
@@ -937,7 +968,7 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
             if (rc) return rc;
         } else {
             auto spec = [&](int in_exp, int out_li, int r_fmt = 0, int r_exp = 0) {
-                H2Spec q; q.in_fmt = 1; q.in_exp = in_exp; q.out_fmt = 1; q.out_exp = net->act_exp[out_li]; q.res_fmt = r_fmt; q.res_exp = r_exp;
+                H2Spec q; q.in_fmt = FMT; q.in_exp = in_exp; q.out_fmt = FMT; q.out_exp = net->act_exp[out_li]; q.res_fmt = r_fmt ? FMT : 0; q.res_exp = r_exp;
                 return q;
             };
             // Ra: this unit's conv1 output; Rb: its conv2 output (the chain writes the NEXT unit's conv1 output back into Ra; the unit
@@ -989,7 +1020,8 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     const float* feat = X[cur];
     if (features) {
         if (h2) {
-            e = launch_h2_to_f32(feat, (long long)B * h * w * 2048 / 8, ldexpf(1.f, -x_exp), features, s);
+            e = tier ? launch_h1_to_f32(feat, (long long)B * h * w * 2048 / 8, ldexpf(1.f, -x_exp), features, s)
+                     : launch_h2_to_f32(feat, (long long)B * h * w * 2048 / 8, ldexpf(1.f, -x_exp), features, s);
             if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("features: ") + hipGetErrorString(e));
         } else
             HIP_TRY(hipMemcpyAsync(features, feat, (size_t)B * h * w * 2048 * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -997,7 +1029,7 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     float* sm = scmap ? scmap : (float*)(ws + pl.off_scmap);
     float* slabs = (float*)(ws + pl.off_slabs);
     H2Spec hs;
-    if (h2) { hs.in_fmt = 1; hs.in_exp = x_exp; }
+    if (h2) { hs.in_fmt = FMT; hs.in_exp = x_exp; }
     const bool pw = h2 || (head_pw && f16_mode && net->wmax_valid && x_rng && net->layers[net->head_part].d_wh3_pw);
     if (pw) rc = run_head_pointwise(net, net->layers[net->head_part], feat, B, h, w, d.num_joints, sm, s, R1, x_rng, hs);
     else rc = run_conv(net, net->layers[net->head_part], feat, B, h, w, 1, 1, h, w, nullptr, 0, 0, 0, false, 1, d.num_joints,
@@ -1028,7 +1060,7 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
         e = launch_h2_range_check(net->d_amax, net->d_exps, (int)net->layers.size(), net->d_flag, s);
         if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("range check: ") + hipGetErrorString(e));
     }
-    if (calib && chain_env && !tier16_mode()) return dgp_forward(net, frames, batch, workspace, workspace_bytes, scmap, locref, features, stream);   // the chained pass
+    if (calib && chain_env && !tier) return dgp_forward(net, frames, batch, workspace, workspace_bytes, scmap, locref, features, stream);   // the chained pass
     if (net->prof_on && net->prof_used < net->prof_slots && !net->prof_in_infer) ++net->prof_used;
     return DGP_OK;
 }
@@ -1317,9 +1349,42 @@ int dgp_h2_to_f32(const void* x, size_t n_floats, int32_t scale_exp, float* out,
     return DGP_OK;
 }
 
+int dgp_f32_to_h1(const float* x, size_t n_floats, int32_t scale_exp, void* out, void* stream) {
+    if (!x || !out || (n_floats & 7)) return fail(DGP_ERR_INVALID, "dgp_f32_to_h1: null argument / length not a multiple of 8");
+    hipError_t e = launch_f32_to_h1(x, (long long)(n_floats / 8), ldexpf(1.f, scale_exp), out, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_f32_to_h1: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
+int dgp_h1_to_f32(const void* x, size_t n_floats, int32_t scale_exp, float* out, void* stream) {
+    if (!x || !out || (n_floats & 7)) return fail(DGP_ERR_INVALID, "dgp_h1_to_f32: null argument / length not a multiple of 8");
+    hipError_t e = launch_h1_to_f32(x, (long long)(n_floats / 8), ldexpf(1.f, -scale_exp), out, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_h1_to_f32: ") + hipGetErrorString(e));
+    return DGP_OK;
+}
+
+static int conv2d_cells(int fmt, const dgp_conv_desc* d, const void* x_h2, int32_t x_exp, const float* packed_w, const float* w_absmax,
+                        const float* scale, const float* bias, const void* residual, int32_t res_is_h2, int32_t res_exp, void* y,
+                        int32_t y_is_h2, int32_t y_exp, float* y_absmax, void* cells_scratch, void* stream);
+
 int dgp_conv2d_h2(const dgp_conv_desc* d, const void* x_h2, int32_t x_exp, const float* packed_w, const float* w_absmax,
                   const float* scale, const float* bias, const void* residual, int32_t res_is_h2, int32_t res_exp, void* y,
                   int32_t y_is_h2, int32_t y_exp, float* y_absmax, void* cells_scratch, void* stream) {
+    return conv2d_cells(1, d, x_h2, x_exp, packed_w, w_absmax, scale, bias, residual, res_is_h2, res_exp, y, y_is_h2, y_exp, y_absmax,
+                        cells_scratch, stream);
+}
+
+int dgp_conv2d_h1(const dgp_conv_desc* d, const void* x_h1, int32_t x_exp, const float* packed_w, const float* w_absmax,
+                  const float* scale, const float* bias, const void* residual_h1, int32_t res_exp, void* y,
+                  int32_t y_is_h1, int32_t y_exp, float* y_absmax, void* cells_scratch, void* stream) {
+    if (d && (d->Cin & 63)) return fail(DGP_ERR_INVALID, "dgp_conv2d_h1: Cin must be a multiple of 64 (a K-step is 64 channels)");
+    return conv2d_cells(2, d, x_h1, x_exp, packed_w, w_absmax, scale, bias, residual_h1, 1, res_exp, y, y_is_h1, y_exp, y_absmax,
+                        cells_scratch, stream);
+}
+
+static int conv2d_cells(int fmt, const dgp_conv_desc* d, const void* x_h2, int32_t x_exp, const float* packed_w, const float* w_absmax,
+                        const float* scale, const float* bias, const void* residual, int32_t res_is_h2, int32_t res_exp, void* y,
+                        int32_t y_is_h2, int32_t y_exp, float* y_absmax, void* cells_scratch, void* stream) {
     if (!d || !x_h2 || !packed_w || !w_absmax || !y || !cells_scratch) return fail(DGP_ERR_INVALID, "dgp_conv2d_h2: null argument");
     if (d->Cin < 32 || (d->Cin & 7) || ((d->Cin / 4) & (d->Cin / 4 - 1)) || (d->Cout & 7))
         return fail(DGP_ERR_INVALID, "dgp_conv2d_h2: Cin must be 4 * 2^k >= 32, Cout a multiple of 8");
@@ -1339,10 +1404,11 @@ int dgp_conv2d_h2(const dgp_conv_desc* d, const void* x_h2, int32_t x_exp, const
     if (inb > lim || outb > lim || resb > lim) return fail(DGP_ERR_INVALID, "dgp_conv2d_h2: tensor exceeds 4 GiB");
     a.in_bytes = (unsigned)inb; a.out_bytes = (unsigned)outb; a.res_bytes = (unsigned)resb;
     a.w_bytes = (unsigned)((size_t)a.nk * 8 * a.CoutP * 16);
-    H2Spec h; h.in_fmt = 1; h.in_exp = x_exp; h.out_fmt = y_is_h2 ? 1 : 0; h.out_exp = y_exp; h.res_fmt = res_is_h2 ? 1 : 0; h.res_exp = res_exp;
+    H2Spec h; h.in_fmt = fmt; h.in_exp = x_exp; h.out_fmt = y_is_h2 ? fmt : 0; h.out_exp = y_exp; h.res_fmt = (a.res && res_is_h2) ? fmt : 0; h.res_exp = res_exp;
     apply_h2(a, h);
     a.w_absmax = w_absmax; a.out_absmax = y_absmax;
-    hipError_t pe = launch_pack_h3(packed_w, a.nk, a.CoutP, w_absmax, cells_scratch, (hipStream_t)stream);
+    hipError_t pe = fmt == 2 ? launch_pack_h1(packed_w, a.nk, a.CoutP, w_absmax, cells_scratch, (hipStream_t)stream)
+                             : launch_pack_h3(packed_w, a.nk, a.CoutP, w_absmax, cells_scratch, (hipStream_t)stream);
     if (pe != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_conv2d_h2: pack cells: ") + hipGetErrorString(pe));
     a.wh3 = cells_scratch; a.wh3_bytes = a.w_bytes;
     hipError_t e = launch_conv(a, pick_tile(a.M, a.CoutP, a.nk * BK, true), (hipStream_t)stream);

@@ -44,6 +44,31 @@ hipError_t launch_pack_h3(const float* panel, int nk, int CoutP, const float* w_
     return hipGetLastError();
 }
 
+// fp32 weight panel -> H1 cells (the 16-bit tier): the HIGH halves only, [k-group of 8 channels][column][8 halves] -- the high plane of
+// pack_h3's cells, compacted; same power-of-two scale (max |w| -> [2^14, 2^15)): 2 bytes per weight where the H2 cells and the fp32
+// panel have 4.
+__global__ __launch_bounds__(256) void pack_h1_kernel(const float4* __restrict__ panel, int nkg, int CoutP,
+                                                      const float* __restrict__ w_absmax, uint4* __restrict__ out) {
+    const float s = pow2_scale_for(w_absmax, threadIdx.x & 63);
+    const long long total = (long long)nkg * CoutP;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int col = (int)(g % CoutP);
+        const long long kg = g / CoutP;
+        const float4 a = panel[(2 * kg) * CoutP + col], b = panel[(2 * kg + 1) * CoutP + col];
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        out[g] = h1_pack8(v, s);
+    }
+}
+
+hipError_t launch_pack_h1(const float* panel, int nk, int CoutP, const float* w_absmax, void* out, hipStream_t s) {
+    const long long total = (long long)nk * 4 * CoutP;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_h1_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(panel), nk * 4,
+                       CoutP, w_absmax, reinterpret_cast<uint4*>(out));
+    return hipGetLastError();
+}
+
 // pack_h3_kernel for a table of panels in one launch (the trainer re-splits every panel after each optimiser step)
 __global__ __launch_bounds__(256) void pack_h3_all_kernel(const PackH3Desc* __restrict__ table) {
     const PackH3Desc d = table[blockIdx.y];
@@ -205,6 +230,30 @@ __global__ __launch_bounds__(256) void h2_to_f32_kernel(const uint4* __restrict_
         h2_unpack8(x[2 * g], x[2 * g + 1], inv_scale, v);
         out[2 * g] = make_float4(v[0], v[1], v[2], v[3]); out[2 * g + 1] = make_float4(v[4], v[5], v[6], v[7]);
     }
+}
+__global__ __launch_bounds__(256) void f32_to_h1_kernel(const float4* __restrict__ x, long long ng, float scale, uint4* __restrict__ out) {
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < ng; g += (long long)gridDim.x * blockDim.x) {
+        const float4 a = x[2 * g], b = x[2 * g + 1];
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        out[g] = h1_pack8(v, scale);
+    }
+}
+__global__ __launch_bounds__(256) void h1_to_f32_kernel(const uint4* __restrict__ x, long long ng, float inv_scale, float4* __restrict__ out) {
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < ng; g += (long long)gridDim.x * blockDim.x) {
+        float v[8];
+        h1_unpack8(x[g], inv_scale, v);
+        out[2 * g] = make_float4(v[0], v[1], v[2], v[3]); out[2 * g + 1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+hipError_t launch_f32_to_h1(const float* x, long long ng, float scale, void* out, hipStream_t s) {
+    long long blocks = (ng + 255) / 256; if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(f32_to_h1_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x), ng, scale, reinterpret_cast<uint4*>(out));
+    return hipGetLastError();
+}
+hipError_t launch_h1_to_f32(const void* x, long long ng, float inv_scale, float* out, hipStream_t s) {
+    long long blocks = (ng + 255) / 256; if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(h1_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(x), ng, inv_scale, reinterpret_cast<float4*>(out));
+    return hipGetLastError();
 }
 hipError_t launch_f32_to_h2(const float* x, long long ng, float scale, void* out, hipStream_t s) {
     long long blocks = (ng + 255) / 256; if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
@@ -383,8 +432,9 @@ struct StemPoolArgs {
     const float* w_absmax;            // its range slots
     const float* bn_scale; const float* bn_bias;
     float mean0, mean1, mean2, out_scale;   // mean: round(mean_pixel[c]) (the fraction is in the fourth channel's weights)
-    float* out;                       // H2 [B, HP, WP, 64]
+    float* out;                       // H2 [B, HP, WP, 64] (out_h1: H1 cells, half the bytes)
     float* out_absmax;
+    int out_h1;
     int B, H, W, H1, W1, HP, WP, pbh, pbw, tiles_h, tiles_w, ntiles;
 };
 
@@ -528,8 +578,9 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
             if (ph0 + ph < p.HP && pw0 + pw < p.WP) {
                 uint4 hi, lo;
                 h2_pack8(v, p.out_scale, hi, lo);
-                uint4* dst = reinterpret_cast<uint4*>(p.out + ((((size_t)n * p.HP + ph0 + ph) * p.WP + pw0 + pw) * 64 + 8 * cg));
-                if (!(DGP_SX & 32)) { dst[0] = hi; dst[1] = lo; } else amax = fmaxf(amax, __builtin_bit_cast(float, hi.x ^ lo.y));
+                const size_t cell = (((size_t)n * p.HP + ph0 + ph) * p.WP + pw0 + pw) * 8 + cg;       // 8-channel group of the pool output
+                uint4* dst = reinterpret_cast<uint4*>(p.out) + (p.out_h1 ? cell : 2 * cell);
+                if (!(DGP_SX & 32)) { dst[0] = hi; if (!p.out_h1) dst[1] = lo; } else amax = fmaxf(amax, __builtin_bit_cast(float, hi.x ^ lo.y));
 #pragma unroll
                 for (int k = 0; k < 8; ++k) amax = fmaxf(amax, v[k]);
             }
@@ -541,8 +592,9 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
 
 hipError_t launch_stem_pool_fused(const unsigned char* frames, int B, int H, int W, const void* wcells, const float* w_absmax,
                                   const float* bn_scale, const float* bn_bias, float m0, float m1, float m2, float out_scale,
-                                  float* out, float* out_absmax, hipStream_t s) {
+                                  float* out, float* out_absmax, hipStream_t s, int out_h1) {
     StemPoolArgs a{};
+    a.out_h1 = out_h1;
     a.frames = frames; a.wcells = reinterpret_cast<const uint4*>(wcells); a.w_absmax = w_absmax; a.bn_scale = bn_scale; a.bn_bias = bn_bias;
     a.mean0 = roundf(m0); a.mean1 = roundf(m1); a.mean2 = roundf(m2); a.out_scale = out_scale; a.out = out; a.out_absmax = out_absmax;
     a.B = B; a.H = H; a.W = W; a.H1 = (H + 1) / 2; a.W1 = (W + 1) / 2;
@@ -610,9 +662,13 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
         for (int i = 0; i <= 2 * r; ++i) gk[i] = gk[i] / s;
     }
 
+    // gamma * s ROUNDED to fp32 in both variants: the LDS variant stores the product before it subtracts the maximum, so the streaming
+    // variant must not let hipcc (-ffp-contract=fast; __fmul_rn is a plain multiply in HIP) fuse product and subtraction into one fma.
+    // The empty asm makes the product opaque to the optimiser; it costs no instruction.
+    auto scaled = [&](int i) -> float { float v = src[(long long)i * C] * gamma; asm volatile("" : "+v"(v)); return v; };
     float mx = -INFINITY;
     for (int i = t; i < HW; i += 256) {
-        const float v = __fmul_rn(src[(long long)i * C], gamma);     // rounded product in BOTH variants (no fma contraction below)
+        const float v = scaled(i);
         if (!LARGE) sp[i] = v;
         mx = fmaxf(mx, v);
     }
@@ -623,7 +679,7 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
 
     double se = 0.0;
     for (int i = t; i < HW; i += 256) {
-        const float e = expf((LARGE ? __fmul_rn(src[(long long)i * C], gamma) : sp[i]) - mx);
+        const float e = expf((LARGE ? scaled(i) : sp[i]) - mx);
         if (!LARGE) sp[i] = e;
         se += (double)e;
     }
@@ -636,7 +692,7 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
         for (int i = t; i < HW; i += 256) sp[i] = sp[i] / denom;    // tf.nn.softmax output
     }
     __syncthreads();
-    auto P = [&](int i) -> float { return LARGE ? expf(__fmul_rn(src[(long long)i * C], gamma) - mx) / denom : sp[i]; };
+    auto P = [&](int i) -> float { return LARGE ? expf(scaled(i) - mx) / denom : sp[i]; };
 
     // blur (zero padded) + moments
     double s0 = 0.0, sh = 0.0, sw = 0.0;

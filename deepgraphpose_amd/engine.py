@@ -43,7 +43,10 @@ class DGPNet:
 
     def __init__(self, depth: int = 50, num_joints: int = 4, in_h: int = 480, in_w: int = 640,
                  max_batch: int = 32, with_locref: bool = False, device: int = 0,
-                 mean_pixel=MEAN_PIXEL, bn_eps: float = BN_EPS):
+                 mean_pixel=MEAN_PIXEL, bn_eps: float = BN_EPS, tier: Optional[str] = None):
+        """tier: None = the library's default (the parity tier, or the 16-bit tier under DGP_CONV_MODE=f16); "parity" / "f32x": fp32-class
+        arithmetic on H2 cells (the 1e-3 px / bit-exact-index gate); "f16": the 16-bit tier -- 2-byte H1 activation cells, one MFMA per
+        product (include/dgp_hip.h, dgp_net_set_tier): a reported tier with measured error, not a parity claim."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.DgpError("no HIP device visible: DGPNet needs an MI355X (there is no CPU fallback)")
@@ -65,6 +68,19 @@ class DGPNet:
         # the headroom was raised since load_weights, scale_epoch = bumped by everything that invalidates the calibrated scales
         self.widen_count = 0
         self.scale_epoch = 0
+        if tier is not None:
+            self.set_tier(tier)
+
+    TIERS = {"parity": 0, "f32x": 0, "f16": 1}
+
+    def set_tier(self, tier):
+        t = self.TIERS[tier] if isinstance(tier, str) else int(tier)
+        _lib.check(self.lib.dgp_net_set_tier(self._h, t), "dgp_net_set_tier")
+        self.scale_epoch += 1                   # the next forward calibrates again
+
+    @property
+    def tier(self) -> str:
+        return "f16" if self.lib.dgp_net_get_tier(self._h) == 1 else "parity"
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -245,13 +261,15 @@ class DGPPipeline:
 
     def __init__(self, depth: int = 50, num_joints: int = 4, in_h: int = 480, in_w: int = 640, max_batch: int = 32,
                  with_locref: bool = False, device: int = 0, n_streams: int = 2, mean_pixel=MEAN_PIXEL,
-                 first: Optional[DGPNet] = None):
-        """first: an existing engine of the same configuration to adopt as engine 0 (its weights stay loaded)."""
+                 first: Optional[DGPNet] = None, tier: Optional[str] = None):
+        """first: an existing engine of the same configuration to adopt as engine 0 (its weights stay loaded); tier: as DGPNet's."""
         if n_streams < 1:
             raise _lib.DgpError("n_streams must be >= 1")
         self.nets = [first] if first is not None else []
         while len(self.nets) < n_streams:
-            self.nets.append(DGPNet(depth, num_joints, in_h, in_w, max_batch, with_locref, device, mean_pixel))
+            self.nets.append(DGPNet(depth, num_joints, in_h, in_w, max_batch, with_locref, device, mean_pixel, tier=tier))
+        if tier is not None and first is not None and first.tier != self.nets[-1].tier:
+            first.set_tier(tier)
         self.device = self.nets[0].device
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
         self.nj, self.max_batch = num_joints, max_batch
@@ -586,6 +604,55 @@ def conv2d_h2(x_h2: torch.Tensor, x_exp: int, w_hwio: np.ndarray, stride: int = 
     _lib.check(lib.dgp_conv2d_h2(C.byref(d), _ptr(x_h2), int(x_exp), _ptr(wp), _ptr(rng[0]), _ptr(sc), _ptr(bi), _ptr(residual),
                                  int(res_is_h2), int(res_exp), _ptr(y), int(y_is_h2), int(y_exp), _ptr(rng[1]), _ptr(cells),
                                  _stream(dev)), "dgp_conv2d_h2")
+    return y, rng[1]
+
+
+def f32_to_h1(x: torch.Tensor, scale_exp: int) -> torch.Tensor:
+    """fp32 [..., C] (C % 8 == 0) -> H1 cells (the 16-bit tier's activation format: fp16(x * 2^exp), 16 bytes per 8 channels), returned
+    as a float16 tensor of x's shape -- the cells ARE plain NHWC fp16 with a per-tensor scale."""
+    _need_cuda(x, torch.float32, "x")
+    out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    _lib.check(_lib.load().dgp_f32_to_h1(_ptr(x), x.numel(), int(scale_exp), _ptr(out), _stream(x.device)), "dgp_f32_to_h1")
+    return out
+
+
+def h1_to_f32(x: torch.Tensor, scale_exp: int) -> torch.Tensor:
+    _need_cuda(x, torch.float16, "x")
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().dgp_h1_to_f32(_ptr(x), x.numel(), int(scale_exp), _ptr(out), _stream(x.device)), "dgp_h1_to_f32")
+    return out
+
+
+def conv2d_h1(x_h1: torch.Tensor, x_exp: int, w_hwio: np.ndarray, stride: int = 1, rate: int = 1, pad_t: int = 0, pad_l: int = 0,
+              out_hw: Optional[Tuple[int, int]] = None, scale=None, bias=None, residual: Optional[torch.Tensor] = None,
+              res_stride: int = 0, res_exp: int = 0, relu: bool = False, y_is_h1: bool = True, y_exp: int = 0):
+    """One conv layer on H1 tensors (float16 NHWC with power-of-two scales) through the 16-bit tier's cell kernels.
+    -> (y: float16 H1 cells or fp32, y_absmax_slots)."""
+    lib = _lib.load()
+    _need_cuda(x_h1, torch.float16, "x_h1")
+    N, H, W, Cin = x_h1.shape
+    kh, kw, cin2, cout = w_hwio.shape
+    assert cin2 == Cin
+    dev = x_h1.device
+    if out_hw is None:
+        keh, kew = (kh - 1) * rate + 1, (kw - 1) * rate + 1
+        out_hw = ((H + 2 * pad_t - keh) // stride + 1, (W + 2 * pad_l - kew) // stride + 1)
+    Ho, Wo = out_hw
+    wp = torch.from_numpy(pack_conv_weights(w_hwio)).to(dev)
+    sc = None if scale is None else torch.as_tensor(scale, dtype=torch.float32).contiguous().to(dev)
+    bi = None if bias is None else torch.as_tensor(bias, dtype=torch.float32).contiguous().to(dev)
+    y = torch.empty((N, Ho, Wo, cout), dtype=torch.float16 if y_is_h1 else torch.float32, device=dev)
+    if residual is not None:
+        _need_cuda(residual, torch.float16, "residual")
+    rh, rw = (residual.shape[1], residual.shape[2]) if residual is not None else (0, 0)
+    d = _lib.DgpConvDesc(N, H, W, Cin, cout, kh, kw, stride, rate, pad_t, pad_l, Ho, Wo, int(relu),
+                         res_stride if residual is not None else 0, rh, rw)
+    rng = torch.zeros((2, ABSMAX_SLOTS), dtype=torch.float32, device=dev)
+    _lib.check(lib.dgp_tensor_absmax(_ptr(wp), wp.numel(), _ptr(rng[0]), _stream(dev)), "dgp_tensor_absmax")
+    cells = torch.empty(wp.numel(), dtype=torch.float16, device=dev)
+    _lib.check(lib.dgp_conv2d_h1(C.byref(d), _ptr(x_h1), int(x_exp), _ptr(wp), _ptr(rng[0]), _ptr(sc), _ptr(bi), _ptr(residual),
+                                 int(res_exp), _ptr(y), int(y_is_h1), int(y_exp), _ptr(rng[1]), _ptr(cells), _stream(dev)),
+               "dgp_conv2d_h1")
     return y, rng[1]
 
 

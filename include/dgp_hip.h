@@ -299,6 +299,23 @@ int  dgp_h2_to_f32(const void* x, size_t n_floats, int32_t scale_exp, float* out
 int  dgp_conv2d_h2(const dgp_conv_desc* d, const void* x_h2, int32_t x_exp, const float* packed_w, const float* w_absmax,
                    const float* scale, const float* bias, const void* residual, int32_t res_is_h2, int32_t res_exp, void* y,
                    int32_t y_is_h2, int32_t y_exp, float* y_absmax, void* cells_scratch, void* stream);
+/* ---- "H1" activation format: the 16-bit tier.  dgp_net_set_tier(net, 1) makes dgp_forward / dgp_infer keep every tensor from the pool
+ * output to the block4 features as ONE 16-byte cell of 8 halves per pixel and 8 channels -- fp16(x * 2^exp), bit for bit the high cell
+ * of the H2 pair: plain NHWC fp16 with the same calibrated per-tensor scales -- and multiply them with fp16 weights on one MFMA per
+ * product (fp32 accumulation, fp32 epilogue arithmetic, fp32 heads and soft-argmax).  Half the activation bytes and a third of the
+ * matrix work of the parity tier (tier 0, the default); 11-bit operands, so NOT inside the 1e-3 px gate: a reported tier with measured
+ * error (bench.py `tier_f16`), never the parity claim.  No reference counterpart (the reference computes in fp32 on TF-1.x).
+ * Switching tiers re-calibrates on the next forward.  DGP_CONV_MODE=f16 in the environment makes tier 1 the default of new nets. */
+int  dgp_net_set_tier(dgp_net* net, int32_t tier);
+int  dgp_net_get_tier(const dgp_net* net);
+int  dgp_f32_to_h1(const float* x, size_t n_floats, int32_t scale_exp, void* out, void* stream);
+int  dgp_h1_to_f32(const void* x, size_t n_floats, int32_t scale_exp, float* out, void* stream);
+/* dgp_conv2d on H1 tensors (layer tests): x (H1, exponent x_exp; Cin % 64 == 0) -> y (H1 with y_exp, or fp32 when y_is_h1 == 0: 1x1 /
+ * stride-1 layers only, no residual); residual_h1: an H1 tensor on y's grid (d->res_stride) or NULL.  cells_scratch:
+ * >= dgp_packed_weight_floats(...) * 2 device bytes. */
+int  dgp_conv2d_h1(const dgp_conv_desc* d, const void* x_h1, int32_t x_exp, const float* packed_w, const float* w_absmax,
+                   const float* scale, const float* bias, const void* residual_h1, int32_t res_exp, void* y,
+                   int32_t y_is_h1, int32_t y_exp, float* y_absmax, void* cells_scratch, void* stream);
 /* The engine's chain kernel at layer level (tests): conv3 of a bottleneck unit + shortcut + ReLU (X', written once) and conv1 of the
  * NEXT unit (R1') in one launch; conv1 takes X' from the accumulator registers, so the 4C-wide tensor is not re-read.  Replaces two
  * slim.conv2d calls of consecutive `bottleneck` units (PET/nnet/pose_net.py:46-52 -> slim resnet_v1.bottleneck: conv3 without
