@@ -108,10 +108,10 @@ def conv_macs_per_frame(h: int, w: int, depth: int = 50, nj: int = 4,
     return macs
 
 
-def launch_algorithmic_bytes(name: str, h: int, w: int, depth: int = 50, batch: int = 1) -> float:
+def launch_algorithmic_bytes(name: str, h: int, w: int, depth: int = 50, batch: int = 1, elem_bytes: float = 4.0) -> float:
     """Algorithmic HBM bytes of ONE backbone launch of the engine, from its profile name ("conv:<scope>[+<scope>...]|<kernel>",
     dgp_net_profile_launch): every tensor that enters or leaves the launch once (4 bytes per value: H2 cells are as large as fp32)
-    plus the weights.  Tensors that stay inside a fused launch are not counted: the shortcut tensor of conv3+shortcut, X' between
+    plus the weights; elem_bytes = 2 for the 16-bit tier's H1 cells and fp16 weight cells.  Tensors that stay inside a fused launch are not counted: the shortcut tensor of conv3+shortcut, X' between
     conv3 and the next unit's conv1 (chain kernel: written once, not re-read), R2 between conv2 and conv3 (unit kernel).
     0.0 for names that are not backbone convs (stem, heads)."""
     body = name.split("|")[0]
@@ -119,7 +119,7 @@ def launch_algorithmic_bytes(name: str, h: int, w: int, depth: int = 50, batch: 
         return 0.0
     if body.endswith("/conv1+pool"):      # fused root block: uint8 frames in, pool output out, 7x7x3x64 weights
         h1, w1 = same_out(h, 2), same_out(w, 2)
-        return float(batch * h * w * 3 + 4 * batch * same_out(h1, 2) * same_out(w1, 2) * 64 + 4 * 7 * 7 * 3 * 64)
+        return float(batch * h * w * 3 + elem_bytes * batch * same_out(h1, 2) * same_out(w1, 2) * 64 + 4 * 7 * 7 * 3 * 64)
     toks = body[5:].split("+")
     units = {u.scope: (i, u) for i, u in enumerate(resnet_units(depth))}
     plan = resnet_units(depth)
@@ -169,7 +169,7 @@ def launch_algorithmic_bytes(name: str, h: int, w: int, depth: int = 50, batch: 
             total += u.depth_in * u.depth
             if (ui, "conv3") not in have:
                 total += pin * u.depth_in + pout * u.depth
-    return 4.0 * total
+    return elem_bytes * total
 
 
 def conv_algorithmic_bytes(h: int, w: int, depth: int = 50, batch: int = 1) -> dict:

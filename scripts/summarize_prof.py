@@ -16,7 +16,7 @@ def find(sub, pat):
 
 def short(n):
     n = n.replace("dgp::", "")
-    return n[:70]
+    return n[:112]
 
 
 st = find("trace", "*kernel_stats.csv")
@@ -24,7 +24,7 @@ if st:
     print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
     rows = list(csv.DictReader(open(st)))
     for r in rows[:12]:
-        print("%-72s calls %6s  total %10.3f ms  avg %9.3f us  %6s%%" % (
+        print("%-114s calls %6s  total %10.3f ms  avg %9.3f us  %6s%%" % (
             short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
             r["Percentage"]))
 

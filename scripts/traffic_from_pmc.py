@@ -46,6 +46,9 @@ for k in sorted(set(fetch) | set(write)):
     fpl, wpl = fb / max(nf.get(k, 0), 1), wb / max(nw.get(k, 0), 1)
     per_kernel[k] = {"launches_per_step": nf.get(k, 0) / steps_f, "hbm_bytes_per_launch": fpl + wpl,
                      "fetch_bytes_per_launch_corrected": fpl, "write_bytes_per_launch": wpl}
+    targs = k[k.index("<") + 1:k.rindex(">")].split(",") if "<" in k and k.startswith("conv_igemm_split_ls") else []
+    if len(targs) >= 13 and targs[12] == "true":      # template H1: the 16-bit tier's instances of the cell kernels
+        per_kernel[k]["h1"] = True
     tot_fetch += fb / steps_f
     tot_write += wb / steps_w
 res = {"conv_hbm_bytes_per_step": tot_fetch + tot_write, "fetch_bytes_per_step_corrected": tot_fetch,
