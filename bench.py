@@ -295,10 +295,11 @@ def tier_f16_child(args) -> None:
     torch.cuda.set_device(dev)
     B, K = args.batch, max(8, args.steps)
     wts = make_weights(50, NJ, False, seed=0, head_std=0.05)
-    pipe = engine.DGPPipeline(50, NJ, H, W, max_batch=B, device=0, n_streams=2, tier="f16")
+    NS = 1 if args.streams == 1 else 2              # (--streams 1: the rocprofv3 passes of scripts/profile.sh, every launch alone on the chip)
+    pipe = engine.DGPPipeline(50, NJ, H, W, max_batch=B, device=0, n_streams=NS, tier="f16")
     pipe.load_weights(wts)
     net = pipe.nets[0]
-    assert net.tier == "f16" and pipe.nets[1].tier == "f16"
+    assert all(n.tier == "f16" for n in pipe.nets)
     NB = 8                                          # ring[0..3] are the main run's batches (same seeds); 4 more for the 256-frame error figures
     base = make_frames(8, H, W, NJ, seed=100)
     g = torch.Generator().manual_seed(1234)
@@ -311,7 +312,7 @@ def tier_f16_child(args) -> None:
     scr = [torch.zeros((B, NJ, 5), dtype=torch.float32, device=dev) for _ in range(2)]
     pipe.calibrate(ring[0])
     p0 = time.perf_counter()
-    while time.perf_counter() - p0 < 1.0:
+    while time.perf_counter() - p0 < (1.0 if NS > 1 else 0.1):
         for i in range(8):
             pipe.submit(ring[i % NB], scr[i & 1], 1.0, 1)
         pipe.join()
@@ -341,7 +342,7 @@ def tier_f16_child(args) -> None:
     roofline, by_kernel = roofline_from_launches(launches, B, 2.0, [os.path.join(ROOT, "profiles", "traffic_r5_f16.json")])
     roofline["steps_profiled"] = n_prof
     fps2, fps1 = K * B / (t2 - t1), K * B / (t1 - t0)
-    res = {"frames_per_s": round(fps2, 1), "ms_per_step": round((t2 - t1) / K * 1e3, 3), "steps": K, "streams": 2,
+    res = {"frames_per_s": round(fps2, 1), "ms_per_step": round((t2 - t1) / K * 1e3, 3), "steps": K, "streams": NS,
            "one_stream": {"frames_per_s": round(fps1, 1), "ms_per_step": round((t1 - t0) / K * 1e3, 3)},
            "dtype": "f16", "sclk_mhz_under_load": sclk,
            "dtype_note": ("2-byte activations end to end (H1 cells = NHWC fp16 with calibrated per-tensor power-of-two scales), fp16 weight cells, ONE "

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 cd "$ROOT"
 BENCH="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --sustain-seconds 0 --prewarm-seconds 0 --profile-steps 10 --streams 1 --no-strict-f32"
 # second argument "f16": the 16-bit tier's child leg of bench.py (the same workload on H1 cells) instead of the parity tier's run
-if [ "${2:-}" = "f16" ]; then BENCH="python3 bench.py --tier-f16-child --steps 10 --no-cpu-baseline"; fi
+if [ "${2:-}" = "f16" ]; then BENCH="python3 bench.py --tier-f16-child --steps 10 --streams 1 --no-cpu-baseline"; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/bench_trace.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -- $BENCH > "$OUT/bench_pmc_mfma.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > "$OUT/bench_pmc_fetch.log" 2>&1
