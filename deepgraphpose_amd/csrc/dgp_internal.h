@@ -144,6 +144,7 @@ struct LossArgs {
     int use_wt, Hin, Win;
     float wt_max, temporal_scale;
 };
+constexpr size_t LOSS_LDS_LIMIT = 150 * 1024;      // bytes of the TWO per-marker maps loss_ce_backward<false> keeps in LDS (19 200 cells); larger maps stream
 hipError_t launch_loss(const LossArgs& a, hipStream_t s);
 
 struct DlcLossArgs {                      // DLC step-0 loss (sigmoid CE on binary disks + locref Huber)

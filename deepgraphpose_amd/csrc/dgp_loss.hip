@@ -9,7 +9,7 @@
 //   spatial clique ("skeleton graph smoothness")                               :1060-1076
 // and their gradient d total / d pred, d total / d locref_pred, including the path through the hidden
 // targets (Gaussian target + clique -> mu -> softmax).  Maps are tiny (<= 14 400 px), so every kernel is one
-// workgroup per marker map with LDS-resident probabilities and fp64 wave reductions.
+// workgroup per marker map with LDS-resident probabilities and fp64 wave reductions (larger maps stream: loss_ce_backward<true>).
 //
 //   temporal clique ("temporal graph smoothness", wt > 0)                     :1079-1124
 // The temporal term follows the reference's specification of intent (its TF code passes float crop sizes to
@@ -53,6 +53,19 @@ __device__ __forceinline__ float block_max(float v, double* red) {
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float ce_logits(float z, float x) {      // tf.nn.sigmoid_cross_entropy_with_logits
     return fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
+}
+
+// Out-of-line on purpose (loss_ce_backward): every call site executes the SAME instructions, so a value recomputed in a later pass is bit
+// for bit the value an earlier pass took the maximum of.
+__device__ __attribute__((noinline)) float loss_gauss_cell(float h, float w, float t0, float t1, float inv2l2) {
+    const float dh = h - t0, dw = w - t1;
+    return expf(-(dh * dh + dw * dw) * inv2l2);
+}
+__device__ __attribute__((noinline)) float loss_sigmoid_cell(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __attribute__((noinline)) float loss_softmax_cell(float x, float gamma, float mx) {      // exp(gamma x - max): the product is rounded first
+    float v = x * gamma;
+    asm volatile("" : "+v"(v));
+    return expf(v - mx);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(256) void loss_marker_stats(LossArgs a) {
     const int HW = a.H * a.W;
     const float* x = a.pred + (long long)n * HW * a.nj + cj;
     float qmax = -1.f;
-    for (int i = threadIdx.x; i < HW; i += 256) qmax = fmaxf(qmax, sigmoidf(x[(long long)i * a.nj]));
+    for (int i = threadIdx.x; i < HW; i += 256) qmax = fmaxf(qmax, loss_sigmoid_cell(x[(long long)i * a.nj]));
     qmax = block_max(qmax, red);
     if (threadIdx.x == 0) a.stats[m] = qmax;
 }
@@ -262,11 +275,17 @@ __global__ __launch_bounds__(256) void loss_normalisers(LossArgs a) {
 // K4: per-marker CE loss + d/dpred (direct) + d/dt, then (hidden markers) back through the soft-argmax.
 // G and sigmoid(x) are computed ONCE into LDS so that the "is this the max element" tests of the
 // reduce_max gradients (ties share the gradient evenly, like tf.reduce_max) are exact.
+// LARGE (round 5): maps beyond 19 200 cells do not fit two LDS arrays (the reference's placeholders are [None, None, None, nj],
+// DGP/models/fitdgp.py:1130-1142: any size).  G, sigmoid(x) and the softmax probabilities are then RECOMPUTED wherever they are read --
+// by the same out-of-line functions on the same inputs, so a recomputed value is bit for bit the value the first pass took the maximum
+// of and the equality tests stay exact; every output equals what the LDS variant gives (tests force both on one map).  A fallback for
+// frames beyond ~960 x 1280, not a fast path: (2 gauss_len + 1)^2 exps per cell in the blur.
 // ------------------------------------------------------------------------------------------------
+template <bool LARGE>
 __global__ __launch_bounds__(256) void loss_ce_backward(LossArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sG = reinterpret_cast<float*>(smem);      // H*W Gaussian bump (later: softmax probabilities)
-    float* sq = sG + a.H * a.W;                      // H*W sigmoid(x)
+    float* sq = sG + (LARGE ? 0 : a.H * a.W);        // H*W sigmoid(x)
     __shared__ double red[8];
     __shared__ float gk[16];
     const int m = blockIdx.x, n = m / a.nj, cj = m - n * a.nj;
@@ -287,19 +306,20 @@ __global__ __launch_bounds__(256) void loss_ce_backward(LossArgs a) {
     const bool scaled_logit = hidden && a.gm3 == 3;
     const float e20 = 1e-20f;
 
+    auto Gat = [&](int i) -> float { if (!LARGE) return sG[i]; const int h = i / a.W; return loss_gauss_cell((float)h, (float)(i - h * a.W), t0, t1, inv2l2); };
+    auto Qat = [&](int i) -> float { return LARGE ? loss_sigmoid_cell(x[(long long)i * a.nj]) : sq[i]; };
     float gmax = -1.f, c = -1.f;
     for (int i = threadIdx.x; i < HW; i += 256) {
         const int h = i / a.W, w = i - h * a.W;
-        const float dh = (float)h - t0, dw = (float)w - t1;
-        const float G = expf(-(dh * dh + dw * dw) * inv2l2);
-        const float q = sigmoidf(x[(long long)i * a.nj]);
-        sG[i] = G; sq[i] = q;
+        const float G = loss_gauss_cell((float)h, (float)w, t0, t1, inv2l2);
+        const float q = loss_sigmoid_cell(x[(long long)i * a.nj]);
+        if (!LARGE) { sG[i] = G; sq[i] = q; }
         gmax = fmaxf(gmax, G); c = fmaxf(c, q);
     }
     gmax = block_max(gmax, red);
     c = block_max(c, red);
     double ngd = 0, nqd = 0;
-    for (int i = threadIdx.x; i < HW; i += 256) { if (sG[i] == gmax) ngd += 1; if (sq[i] == c) nqd += 1; }
+    for (int i = threadIdx.x; i < HW; i += 256) { if (Gat(i) == gmax) ngd += 1; if (Qat(i) == c) nqd += 1; }
     const float ng = (float)block_sum(ngd, red), nq = (float)block_sum(nqd, red);
     const float gden = gmax + 1e-5f;
     const float A = !hidden ? a.norm[0] : (scaled_logit ? a.norm[2] * (1.f - c) : a.norm[1]);
@@ -308,7 +328,7 @@ __global__ __launch_bounds__(256) void loss_ce_backward(LossArgs a) {
     // pass 1: loss value, dL/dc, dL/dGmax accumulators
     double ce_sum = 0, dLdc = 0, dLdgmax = 0;
     for (int i = threadIdx.x; i < HW; i += 256) {
-        const float G = sG[i], g = G / gden, q = sq[i];
+        const float G = Gat(i), g = G / gden, q = Qat(i);
         const float xi = x[(long long)i * a.nj];
         const float z = scale_target ? g * c : g;
         float xe = xi, dxe_ds = 0.f;
@@ -338,7 +358,7 @@ __global__ __launch_bounds__(256) void loss_ce_backward(LossArgs a) {
     for (int i = threadIdx.x; i < HW; i += 256) {
         const int h = i / a.W, w = i - h * a.W;
         const float dh = (float)h - t0, dw = (float)w - t1;
-        const float G = sG[i], g = G / gden, q = sq[i];
+        const float G = Gat(i), g = G / gden, q = Qat(i);
         const float xi = x[(long long)i * a.nj];
         const float z = scale_target ? g * c : g;
         float xe = xi, dxe_ds = 0.f;
@@ -382,14 +402,15 @@ __global__ __launch_bounds__(256) void loss_ce_backward(LossArgs a) {
         for (int i = 0; i <= 2 * r; ++i) gk[i] /= sacc;
     }
     float mx = -INFINITY;
-    for (int i = threadIdx.x; i < HW; i += 256) { const float v = x[(long long)i * a.nj] * a.gamma; sp[i] = v; mx = fmaxf(mx, v); }
+    for (int i = threadIdx.x; i < HW; i += 256) { float v = x[(long long)i * a.nj] * a.gamma; asm volatile("" : "+v"(v)); mx = fmaxf(mx, v); }
     mx = block_max(mx, red);
     double se = 0;
-    for (int i = threadIdx.x; i < HW; i += 256) { const float e = expf(sp[i] - mx); sp[i] = e; se += (double)e; }
+    for (int i = threadIdx.x; i < HW; i += 256) { const float e = loss_softmax_cell(x[(long long)i * a.nj], a.gamma, mx); if (!LARGE) sp[i] = e; se += (double)e; }
     se = block_sum(se, red);
     const float den = (float)se;
-    for (int i = threadIdx.x; i < HW; i += 256) sp[i] /= den;
+    if (!LARGE) for (int i = threadIdx.x; i < HW; i += 256) sp[i] /= den;
     __syncthreads();
+    auto Pat = [&](int i) -> float { return LARGE ? loss_softmax_cell(x[(long long)i * a.nj], a.gamma, mx) / den : sp[i]; };
     double B = 0, Bh = 0, Bw = 0;
     for (int i = threadIdx.x; i < HW; i += 256) {
         const int h = i / a.W, w = i - h * a.W;
@@ -400,7 +421,7 @@ __global__ __launch_bounds__(256) void loss_ce_backward(LossArgs a) {
             for (int bb = -r; bb <= r; ++bb) {
                 const int ww = w + bb;
                 if ((unsigned)ww >= (unsigned)a.W) continue;
-                bsum += gk[aa + r] * gk[bb + r] * sp[hh * a.W + ww];
+                bsum += gk[aa + r] * gk[bb + r] * Pat(hh * a.W + ww);
             }
         }
         B += (double)bsum; Bh += (double)bsum * h; Bw += (double)bsum * w;
@@ -422,11 +443,11 @@ __global__ __launch_bounds__(256) void loss_ce_backward(LossArgs a) {
         return sacc;
     };
     double inner = 0;
-    for (int i = threadIdx.x; i < HW; i += 256) { const int h = i / a.W, w = i - h * a.W; inner += (double)(sp[i] * dLdp(h, w)); }
+    for (int i = threadIdx.x; i < HW; i += 256) { const int h = i / a.W, w = i - h * a.W; inner += (double)(Pat(i) * dLdp(h, w)); }
     inner = block_sum(inner, red);
     for (int i = threadIdx.x; i < HW; i += 256) {
         const int h = i / a.W, w = i - h * a.W;
-        dx[(long long)i * a.nj] += a.gamma * sp[i] * (dLdp(h, w) - (float)inner);
+        dx[(long long)i * a.nj] += a.gamma * Pat(i) * (dLdp(h, w) - (float)inner);
     }
 }
 
@@ -558,15 +579,20 @@ hipError_t launch_loss(const LossArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(loss_marker_stats, dim3(nm), dim3(256), 0, s, a);
     hipLaunchKernelGGL(loss_normalisers, dim3(1), dim3(256), 0, s, a);
     const size_t smem = (size_t)2 * a.H * a.W * sizeof(float);
-    static bool attr_dev[16] = {};
-    bool& attr = attr_dev[dgp_device_slot()];
-    if (!attr) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(loss_ce_backward),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e != hipSuccess) return e;
-        attr = true;
+    const char* force = getenv("DGP_LOSS_STREAM");            // tests: the streaming variant on a map the LDS variant also takes (read per call)
+    if (smem > LOSS_LDS_LIMIT || (force && atoi(force) != 0)) {
+        hipLaunchKernelGGL(loss_ce_backward<true>, dim3(nm), dim3(256), 0, s, a);
+    } else {
+        static bool attr_dev[16] = {};
+        bool& attr = attr_dev[dgp_device_slot()];
+        if (!attr) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(loss_ce_backward<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (e != hipSuccess) return e;
+            attr = true;
+        }
+        hipLaunchKernelGGL(loss_ce_backward<false>, dim3(nm), dim3(256), smem, s, a);
     }
-    hipLaunchKernelGGL(loss_ce_backward, dim3(nm), dim3(256), smem, s, a);
     if (a.n_v > 0) {
         hipLaunchKernelGGL(loss_locref_count, dim3(a.n_v), dim3(256), 0, s, a);
         hipLaunchKernelGGL(loss_locref_backward, dim3(a.n_v), dim3(256), 0, s, a);

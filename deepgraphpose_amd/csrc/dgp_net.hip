@@ -1207,7 +1207,6 @@ int dgp_loss_fwd_bwd(const dgp_loss_desc* d, const float* pred, const float* loc
         return fail(DGP_ERR_INVALID, "dgp_loss_fwd_bwd: gauss_len must be 1..7");
     if (!(d->gm2 == 0 || d->gm2 == 1 || d->gm2 == 2) || !(d->gm3 == 0 || d->gm3 == 3) || (d->gm3 == 3 && d->gm2 == 0))
         return fail(DGP_ERR_INVALID, "dgp_loss_fwd_bwd: Not implemented (gm2 in {0,1,2}, gm3 in {0,3}, gm3=3 needs gm2>0)");
-    if ((size_t)2 * d->H * d->W * sizeof(float) > 150 * 1024) return fail(DGP_ERR_INVALID, "dgp_loss_fwd_bwd: map exceeds LDS");
     if ((d->n_visible > 0 && (!visible_marker || !visible_in_targets || !targets || !locref_map || !locref_mask)) ||
         (d->n_hidden > 0 && !hidden_marker) || (d->nl > 0 && (!S0 || !ws || !ws_max)))
         return fail(DGP_ERR_INVALID, "dgp_loss_fwd_bwd: missing marker / target / skeleton arrays");

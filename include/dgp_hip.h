@@ -165,7 +165,9 @@ int  dgp_loss_scratch_bytes(const dgp_loss_desc* d, size_t* out_bytes);
  * Temporal clique (use_wt; fitdgp.py:1079-1124): wt_loss = || (relu(D - wt_max) + wt_max) * w ||_F * scale with D the pixel distance of
  * a marker between consecutive frames and w the flow weight min(1 / mean flow, 1)^3 * wt_batch / H / W over the +-10 px box of the two
  * positions (bilinear crop_and_resize mean of vector_field).  The backward pass differentiates D AND w: the boxes are functions of the
- * (hidden, soft-arg-max) targets and TF's crop_and_resize has a gradient with respect to its boxes -- the weight is not a stop-gradient. */
+ * (hidden, soft-arg-max) targets and TF's crop_and_resize has a gradient with respect to its boxes -- the weight is not a stop-gradient.
+ * Any H x W (the reference's placeholders are [None, None, None, nj], fitdgp.py:1130-1142): maps up to 19 200 cells keep their Gaussian
+ * target and sigmoid in LDS, larger ones recompute them where they are read -- same functions, bit-identical results. */
 int  dgp_loss_fwd_bwd(const dgp_loss_desc* d, const float* pred, const float* locref_pred, const float* targets,
                       const float* locref_map, const float* locref_mask, const int32_t* visible_marker,
                       const int32_t* hidden_marker, const int32_t* visible_in_targets, const float* S0,

@@ -337,8 +337,8 @@ def test_streaming_soft_argmax_is_bit_identical_to_the_lds_variant(eng):
 def test_maps_larger_than_the_lds_stream_from_global_memory(eng):
     """The reference's scoremap placeholders have no size limit ([None, None, None, nj], DGP/models/fitdgp.py:1130-1142).  dgp_soft_argmax keeps
     one joint's map in LDS up to 150 KB = 38 400 cells and STREAMS larger ones (softmax values recomputed from global memory where the blur
-    reads them: the same expressions, a fallback not a fast path); dgp_infer therefore takes frames of any size.  dgp_loss_fwd_bwd holds two
-    maps (19 200 cells) and still refuses larger ones with a message naming the limit."""
+    reads them: the same expressions, a fallback not a fast path); dgp_infer therefore takes frames of any size.  (dgp_loss_fwd_bwd streams
+    maps beyond its 19 200-cell LDS limit the same way since round 5: tests/test_train_gpu.py.)"""
     from deepgraphpose_amd import _lib
     from oracle import dgp_oracle as O
     rng = np.random.default_rng(5)
@@ -357,14 +357,6 @@ def test_maps_larger_than_the_lds_stream_from_global_memory(eng):
             iref, lref = O.likelihood_window(s[b], mu[b].cpu().numpy())
             assert np.array_equal(idx[b].cpu().numpy(), iref)
             np.testing.assert_allclose(conf[b].cpu().numpy(), lref, atol=2e-7)
-    from deepgraphpose_amd.loss import DGPHyper, dgp_loss_fwd_bwd
-    nt, H, W, nj = 2, 120, 170, 2                                   # 20 400 pixels > 19 200
-    batch = dict(targets=np.zeros((1, nj, 2)), locref_map=np.zeros((nt, H, W, 2 * nj), np.float32),
-                 locref_mask=np.zeros((nt, H, W, 2 * nj), np.float32), visible_marker=np.array([0, 1], np.int32),
-                 hidden_marker=np.array([2, 3], np.int32), visible_marker_in_targets=np.array([0, 1], np.int32), nt=nt)
-    with pytest.raises(_lib.DgpError, match="exceeds LDS"):
-        dgp_loss_fwd_bwd(torch.zeros((nt, H, W, nj), device="cuda"), torch.zeros((nt, H, W, 2 * nj), device="cuda"), batch, DGPHyper(),
-                         np.zeros((0, nj)), np.zeros(0), np.zeros(0), 10.0, 2.0)
 
 
 def test_infer_on_frames_whose_scoremap_exceeds_the_lds(eng):

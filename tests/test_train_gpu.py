@@ -71,6 +71,76 @@ def test_loss_forward_backward_matches_autograd(lib_built, gm2, gm3, shape):
     assert np.abs(dloc.cpu().numpy() - gl).max() <= 2e-5 * (np.abs(gl).max() + 1e-12) + 1e-10
 
 
+def _loss_case_with_peaks(rng, nt, H, W, nj, nvf, nl, gm2, gm3):
+    from deepgraphpose_amd.loss import DGPHyper
+    batch, S0 = _make_loss_case(rng, nt, H, W, nj, nvf, 0.2, nl)
+    pred = (rng.standard_normal((nt, H, W, nj)) * 2).astype(np.float32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for n in range(nt):
+        for j in range(nj):
+            cy, cx = rng.uniform(0, H - 1), rng.uniform(0, W - 1)
+            pred[n, :, :, j] += 6 * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / 6.0)
+    loc = rng.standard_normal((nt, H, W, 2 * nj)).astype(np.float32)
+    hy = DGPHyper(gm2=gm2, gm3=gm3)
+    ws, ws_max = rng.uniform(5, 20, S0.shape[0]), rng.uniform(10, 40, S0.shape[0])
+    cfg = dict(nj=nj, S0=S0, ws=ws, ws_max=ws_max, stride=8.0, gamma=hy.gamma, gauss_len=hy.gauss_len,
+               lengthscale=hy.lengthscale, gm2=gm2, gm3=gm3, wn_visible=hy.wn_visible, wn_hidden=hy.wn_hidden,
+               locref_loss_weight=hy.locref_loss_weight, locref_huber_loss=True, n_frames_total=500.0, n_visible_frames_total=37.0)
+    return batch, S0, pred, loc, hy, ws, ws_max, cfg
+
+
+@pytest.mark.parametrize("shape,gm2,gm3", [((3, 136, 240, 4, 1), 1, 3), ((2, 150, 200, 2, 1), 0, 0), ((2, 120, 170, 3, 1), 2, 3)])
+def test_loss_on_maps_beyond_the_lds_limit_matches_autograd(lib_built, shape, gm2, gm3):
+    """The reference's loss placeholders are [None, None, None, nj] (DGP/models/fitdgp.py:1130-1142): any scoremap size.  Beyond 19 200
+    cells (frames above ~960 x 1280; 136 x 240 is a 1080p frame) the two per-marker maps no longer fit the LDS and loss_ce_backward
+    streams: Gaussian target, sigmoid and softmax values recomputed where they are read.  Same bounds as the LDS-resident maps, against
+    the float64 autograd oracle: CE terms (gm2 / gm3), Gaussian targets through the hidden markers' soft-argmax, locref Huber, clique."""
+    from deepgraphpose_amd.loss import dgp_loss_fwd_bwd
+    from oracle import dgp_train_oracle as T
+    nt, H, W, nj, nvf = shape
+    assert 2 * H * W * 4 > 150 * 1024
+    rng = np.random.default_rng(H * 7 + W + gm2)
+    batch, S0, pred, loc, hy, ws, ws_max, cfg = _loss_case_with_peaks(rng, nt, H, W, nj, nvf, 2 if nj > 2 else (1 if nj == 2 else 0), gm2, gm3)
+    pt = torch.tensor(pred, dtype=torch.float64, requires_grad=True)
+    lt = torch.tensor(loc, dtype=torch.float64, requires_grad=True)
+    L = T.dgp_loss(pt, lt, batch, cfg)
+    L["total_loss"].backward()
+    losses, dpred, dloc, mu = dgp_loss_fwd_bwd(torch.from_numpy(pred).cuda(), torch.from_numpy(loc).cuda(), batch, hy, S0, ws, ws_max, 500.0, 37.0)
+    for k in ("visible_loss_pred", "hidden_loss_pred", "visible_loss_locref", "total_loss", "total_loss_visible"):
+        assert abs(losses[k] - float(L[k])) <= 2e-5 * max(1.0, abs(float(L[k]))), (k, losses[k], float(L[k]))
+    np.testing.assert_allclose(mu.cpu().numpy(), L["_mu"].detach().numpy(), atol=2e-5)
+    gp, gl = pt.grad.numpy(), lt.grad.numpy()
+    assert np.abs(dpred.cpu().numpy() - gp).max() <= 2e-4 * (np.abs(gp).max() + 1e-12) + 1e-9
+    assert np.abs(dloc.cpu().numpy() - gl).max() <= 2e-5 * (np.abs(gl).max() + 1e-12) + 1e-10
+
+
+@pytest.mark.parametrize("gm2,gm3", [(1, 3), (0, 0), (2, 0)])
+def test_streaming_loss_kernel_is_bit_identical_to_the_lds_variant(lib_built, gm2, gm3):
+    """Both instances of loss_ce_backward on the SAME maps (DGP_LOSS_STREAM=1 forces the streaming one): losses, gradients and mu equal bit
+    for bit -- the recomputed Gaussian / sigmoid / softmax values come from the same out-of-line functions, so the `== max` tests of the
+    reduce_max gradients see the same bits in both (a result cannot change at the 19 200-cell boundary)."""
+    import os
+    from deepgraphpose_amd.loss import dgp_loss_fwd_bwd
+    rng = np.random.default_rng(11 + gm2)
+    batch, S0, pred, loc, hy, ws, ws_max, _ = _loss_case_with_peaks(rng, 4, 60, 80, 4, 1, 2, gm2, gm3)
+    p, l = torch.from_numpy(pred).cuda(), torch.from_numpy(loc).cuda()
+
+    def run():
+        losses, dpred, dloc, mu = dgp_loss_fwd_bwd(p, l, batch, hy, S0, ws, ws_max, 500.0, 37.0)
+        torch.cuda.synchronize()
+        return losses, dpred.clone(), dloc.clone(), mu.clone()
+    a = run()
+    os.environ["DGP_LOSS_STREAM"] = "1"
+    try:
+        b = run()
+    finally:
+        del os.environ["DGP_LOSS_STREAM"]
+    # (the loss VALUES are sums of per-marker terms added with float atomics in whatever order the workgroups finish: compared to 1e-6)
+    for k in a[0]:
+        assert abs(a[0][k] - b[0][k]) <= 1e-6 * max(1.0, abs(a[0][k])), k
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+
+
 # ---------------------------------------------------------------------------------------------------------------
 def _train_case(seed, hw=(64, 96), nt=3, nj=3, nvf=1, depth=50):
     from deepgraphpose_amd.synthetic import make_weights, make_frames
