@@ -174,6 +174,8 @@ def spawn_workers(args) -> None:
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    if torch.cuda.device_count() < n and not os.environ.get("DGP_BENCH_VISIBLE_GPUS"):      # (device_count() does not initialise the GPU on this image)
+        raise SystemExit("bench.py: --gpus %d but only %d device(s) visible (set DGP_BENCH_VISIBLE_GPUS to share devices knowingly)" % (n, torch.cuda.device_count()))
     visible = int(os.environ.get("DGP_BENCH_VISIBLE_GPUS", n))      # tests: several ranks on one GPU (with DGP_DIST_BACKEND=gloo)
     procs = []
     for r in range(n):
@@ -416,12 +418,20 @@ def main():
 
     if os.environ.get("DGP_BENCH_FAULT_RANK") == os.environ.get("RANK", "0"):      # tests: a worker that dies before it joins the group
         raise SystemExit(7)
+    # one GPU per rank: refuse to put several ranks on one device by accident (a line measured that way is not an N-GPU line);
+    # DGP_BENCH_VISIBLE_GPUS=<n> is the explicit opt-in the one-GPU tests use (with DGP_DIST_BACKEND=gloo).  device_count() does not
+    # initialise the GPU on this image
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and not os.environ.get("DGP_BENCH_VISIBLE_GPUS"):
+        raise SystemExit("bench.py: --gpus %d but only %d device(s) visible (set DGP_BENCH_VISIBLE_GPUS to share devices knowingly)" % (args.gpus, n_dev))
     rank, local_rank, world = ddist.init_from_env("nccl")
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
                          % (args.gpus, world))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    numa = ddist.bind_to_gpu_numa_node(local_rank)      # before any helper thread exists: they inherit the mask
+    ident = dict(ddist.device_identity(local_rank), rank=rank, **numa)
 
     B, K, Wm = args.batch, args.steps, args.warmup
     if args.scaling == "strong":      # one fixed stream, independent of N: rank r runs batches [r TB / N, (r + 1) TB / N)
@@ -505,8 +515,11 @@ def main():
     for i in range(K):
         step(i, sequential=i < prof_steps)      # instrumented steps run alone (per-launch durations are not shared with a second batch)
     pipe.join()
+    torch.cuda.synchronize(dev)                         # (this rank's frames are done: what follows is the collective alone)
+    tg0 = time.perf_counter()
     full = ddist.gather_trajectory(traj, world * n_local)
     torch.cuda.synchronize(dev)
+    tg1 = time.perf_counter()
     barrier()
     t1 = time.perf_counter()
     n_prof, launches = net.profile_end()
@@ -542,6 +555,18 @@ def main():
         dist.all_reduce(elapsed_min, op=dist.ReduceOp.MIN)
     elapsed, elapsed_min = float(elapsed.item()), float(elapsed_min.item())
     assert full.shape[0] == world * n_local
+    # what RCCL saw, rank by rank, so that an N > 1 line can be verified by its reader: backend and world size as torch.distributed reports
+    # them, every rank's device (index, PCI address, uuid, NUMA node, CPUs it was bound to), its own frames/s, and the one collective
+    mine = dict(ident, frames_per_s=round(n_local / (t1 - t0), 2), elapsed_s=round(t1 - t0, 6), all_gather_ms=round((tg1 - tg0) * 1e3, 4))
+    per_rank = [mine]
+    if use_pg:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    collective = {"backend": dist.get_backend() if use_pg else None, "world_size": dist.get_world_size() if use_pg else 1,
+                  "initialized": bool(use_pg), "op": "all_gather_into_tensor of the packed keypoints, once per run, inside the timed region",
+                  "all_gather_bytes": int(world * (-(-world * n_local // world)) * NJ * 5 * 4),
+                  "all_gather_ms": {"rank0": round((tg1 - tg0) * 1e3, 4), "max": max(q["all_gather_ms"] for q in per_rank)},
+                  "distinct_devices": len({(q["pci"], q["uuid"]) for q in per_rank}), "ranks": per_rank}
     # every rank ran the same ring: global batch g must reproduce batch g % RING (its first occurrence: rank 0's when K >= RING) bit for bit --
     # the gathered N-rank trajectory equals what one rank computes for the same frames
     shard_check = None
@@ -603,6 +628,7 @@ def main():
         # imbalance between the ranks: `value` divides by the slowest rank's time (both include the barriers and the all-gather)
         "rank_elapsed_s": {"max": round(elapsed, 6), "min": round(elapsed_min, 6), "imbalance": round(elapsed / max(elapsed_min, 1e-12) - 1.0, 4)},
         "frames_per_s": round(fps, 2),
+        "collective": collective,
         "activation_format": "H2 (fp16 high/low cells, calibrated per-tensor scales; include/dgp_hip.h)" if n_calib else "fp32",
     }
 

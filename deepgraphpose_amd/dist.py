@@ -117,3 +117,54 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def parse_cpulist(text: str):
+    """'0-3,8,10-11' (sysfs cpulist syntax) -> sorted list of CPU numbers."""
+    cpus = set()
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            lo, hi = part.split("-", 1)
+            cpus.update(range(int(lo), int(hi) + 1))
+        else:
+            cpus.add(int(part))
+    return sorted(cpus)
+
+
+def device_identity(local_rank: int) -> dict:
+    """What a reader needs to verify which GPU a rank really ran on: torch's device index, the PCI address, the device uuid (when
+    torch exposes it) and the NUMA node sysfs reports for that PCI function (-1: unknown / single node)."""
+    pr = torch.cuda.get_device_properties(local_rank)
+    bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+    node = -1
+    try:
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+            node = int(f.read().strip())
+    except (OSError, ValueError):
+        pass
+    return {"index": int(local_rank), "name": pr.name, "pci": bdf, "uuid": str(getattr(pr, "uuid", "")), "numa_node": node}
+
+
+def bind_to_gpu_numa_node(local_rank: int) -> dict:
+    """Pin this process (and every thread it starts afterwards: decode / staging / prefetch threads inherit the mask) to the CPUs of the
+    NUMA node its GPU hangs off, so that with 8 ranks on one host the pinned staging buffers and the H2D copies of a rank stay on its
+    GPU's side of the machine.  No-op when sysfs has no answer (single node, containers without /sys) or DGP_NUMA_BIND=0.
+    -> {'numa_node', 'cpus_bound'} for the bench line."""
+    import os
+    ident = device_identity(local_rank)
+    out = {"numa_node": ident["numa_node"], "cpus_bound": None}
+    if os.environ.get("DGP_NUMA_BIND", "1") == "0" or ident["numa_node"] < 0 or not hasattr(os, "sched_setaffinity"):
+        return out
+    try:
+        with open("/sys/devices/system/node/node%d/cpulist" % ident["numa_node"]) as f:
+            cpus = set(parse_cpulist(f.read()))
+        allowed = cpus & set(os.sched_getaffinity(0))      # (never widen a mask a launcher / cgroup already narrowed)
+        if allowed:
+            os.sched_setaffinity(0, allowed)
+            out["cpus_bound"] = len(allowed)
+    except (OSError, ValueError):
+        pass
+    return out

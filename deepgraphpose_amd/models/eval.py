@@ -154,6 +154,8 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
     world = tdist.get_world_size() if tdist.is_initialized() else 1
     rank = tdist.get_rank() if tdist.is_initialized() else 0
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+    if world > 1:          # the decode / staging threads started below inherit the mask: each rank's host work stays on its GPU's NUMA node
+        ddist.bind_to_gpu_numa_node(local_rank)
 
     f = os.path.basename(str(video_file)).rsplit(".", 1)
     save_file = join(output_dir, f[0] + "_labeled%s" % save_str)

@@ -289,6 +289,26 @@ def test_bench_strong_scaling_eight_ranks_through_the_spawner(lib_built):
     assert d["frames_per_s"] == d["value"] > 0
     re = d["rank_elapsed_s"]
     assert re["max"] >= re["min"] > 0 and re["imbalance"] >= 0
+    # the line verifies itself: what torch.distributed saw, every rank's device and rate, the one collective
+    c = d["collective"]
+    assert c["backend"] == "gloo" and c["world_size"] == 8 and c["initialized"] and c["all_gather_bytes"] == 8 * 4 * 4 * 5 * 4
+    assert c["all_gather_ms"]["max"] >= c["all_gather_ms"]["rank0"] > 0
+    assert [q["rank"] for q in c["ranks"]] == list(range(8))
+    assert all(q["frames_per_s"] > 0 and q["elapsed_s"] > 0 and q["index"] == 0 and len(q["pci"]) == 12 and "numa_node" in q for q in c["ranks"])
+    assert c["distinct_devices"] == 1                          # eight ranks on ONE device here: a real 8-GPU line reads 8
+
+
+def test_bench_refuses_more_ranks_than_devices_unless_told(lib_built):
+    """`--gpus 2` on a one-GPU box is an error (several ranks on one device by accident would print a line that is not a 2-GPU line); the
+    explicit opt-in is DGP_BENCH_VISIBLE_GPUS."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than two devices")
+    env = _child_env()
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DGP_BENCH_VISIBLE_GPUS"):
+        env.pop(k, None)
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env, cwd=ROOT, capture_output=True, text=True,
+                        timeout=300)
+    assert cp.returncode != 0 and "device(s) visible" in (cp.stderr + cp.stdout)
 
 
 def test_shard_ranges_reassemble_bit_exactly(lib_built):

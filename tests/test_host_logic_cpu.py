@@ -381,3 +381,22 @@ def test_motion_energy_host_backend_equals_oracle_restatement():
     assert D.calculate_motion_energy(ArraySource(two), backend="host")[1] == 16.0
     with pytest.raises(ValueError):
         D.calculate_motion_energy(ArraySource(two), backend="numpy")
+
+
+def test_cpulist_parser_and_numa_binding_is_a_noop_without_sysfs(monkeypatch):
+    """dist.parse_cpulist reads sysfs' cpulist syntax; bind_to_gpu_numa_node never widens an affinity mask and does nothing when the GPU's
+    NUMA node is unknown (-1) or DGP_NUMA_BIND=0."""
+    from deepgraphpose_amd import dist as D
+    assert D.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert D.parse_cpulist("") == [] and D.parse_cpulist("5") == [5]
+    before = os.sched_getaffinity(0)
+    monkeypatch.setattr(D, "device_identity", lambda lr: {"index": lr, "name": "x", "pci": "0000:00:00.0", "uuid": "", "numa_node": -1})
+    assert D.bind_to_gpu_numa_node(0) == {"numa_node": -1, "cpus_bound": None}
+    monkeypatch.setattr(D, "device_identity", lambda lr: {"index": lr, "name": "x", "pci": "0000:00:00.0", "uuid": "", "numa_node": 0})
+    monkeypatch.setenv("DGP_NUMA_BIND", "0")
+    assert D.bind_to_gpu_numa_node(0)["cpus_bound"] is None
+    monkeypatch.delenv("DGP_NUMA_BIND")
+    got = D.bind_to_gpu_numa_node(0)                       # node 0 exists on this host or it does not: either way the mask never grows
+    assert os.sched_getaffinity(0) <= before
+    assert got["cpus_bound"] is None or got["cpus_bound"] == len(os.sched_getaffinity(0))
+    os.sched_setaffinity(0, before)
