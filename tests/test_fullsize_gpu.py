@@ -1,0 +1,71 @@
+"""Whole batches at BASELINE's full sizes against the CPU oracle.  The oracle's outputs are cached fixtures (tests/golden/fullsize_vectors.npz,
+written by tests/golden/make_fullsize_golden.py in the build container: minutes of fp32 CPU convolutions), so the GPU suite compares every
+frame without paying for them at run time.  The oracle is the checker; the product path is the HIP engine behind the C-ABI."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def G():
+    return np.load(os.path.join(HERE, "golden", "fullsize_vectors.npz"))
+
+
+def test_resnet101_1280x720_20_keypoints_all_16_frames_both_heads(lib_built, G):
+    """BASELINE configs[4]'s per-GPU shape: ResNet-101, 1280 x 720, 20 keypoints, a batch of 16 -- ALL frames, BOTH heads.  Soft-argmax
+    coordinates within 1e-3 px, window indices and likelihood cells bit-exact, scoremap and locref map (16 384 sampled positions each)
+    within 1e-4 of their range."""
+    from deepgraphpose_amd import engine
+    from deepgraphpose_amd.synthetic import make_frames, make_weights
+    wts = make_weights(101, 20, True, seed=41, head_std=0.05)
+    frames = torch.from_numpy(make_frames(16, 720, 1280, 20, seed=42)).cuda()
+    net = engine.DGPNet(101, 20, 720, 1280, max_batch=16, with_locref=True)
+    net.load_weights(wts)
+    sc, lr = net.forward(frames, want_locref=True)
+    mu, conf, idx = net.infer(frames, 1.0, 1)
+    torch.cuda.synchronize()
+    assert tuple(sc.shape) == (16, 90, 160, 20) and tuple(lr.shape) == (16, 90, 160, 40)
+    px = np.abs(mu.cpu().numpy() - G["r101_mu"]).max() * 8.0
+    assert px < 1e-3, px
+    assert np.array_equal(idx.cpu().numpy(), G["r101_idx"])
+    assert np.abs(conf.cpu().numpy() - G["r101_lik"]).max() < 1e-5
+    scn, lrn = sc.cpu().numpy().reshape(16, -1), lr.cpu().numpy().reshape(16, -1)
+    got_sc = np.take_along_axis(scn, G["r101_pos_sc"].astype(np.int64), 1)
+    got_lr = np.take_along_axis(lrn, G["r101_pos_lr"].astype(np.int64), 1)
+    assert np.abs(got_sc - G["r101_sc"]).max() < 1e-4 * float(G["r101_sc_max"])
+    assert np.abs(got_lr - G["r101_lr"]).max() < 1e-4 * float(G["r101_lr_max"])
+    assert abs(float(np.abs(scn).max()) - float(G["r101_sc_max"])) < 1e-4 * float(G["r101_sc_max"])
+
+
+def test_estimate_pose_on_the_reaching_projects_labeled_frames(lib_built, G, tmp_path):
+    """BASELINE configs[0] / [1] on REAL frames: the 55 labeled images of the reference's Reaching demo project (832 x 747; 15 of them are
+    640 x 470 crops that LabeledDirSource resizes) as the pseudo-video the demo falls back to when the .avi is missing, through
+    estimate_pose -- decode thread, pinned staging, two engines, csv export -- with a seeded snapshot stored as a TF bundle.  Every one of
+    the 246 pseudo-frames against the oracle's (x, y, likelihood, window index) of the labeled image it shows."""
+    import shutil
+    from _project import make_project
+    from deepgraphpose_amd import weights_io
+    from deepgraphpose_amd.models.eval import estimate_pose
+    from deepgraphpose_amd.models.fitdgp_util import get_snapshot_path
+    from deepgraphpose_amd.synthetic import make_weights
+    proj, _, _ = make_project(tmp_path, nj=5, hw=(64, 96))
+    dst = os.path.join(proj, "labeled-data", "reachingvideo1")
+    shutil.copytree(os.path.join(HERE, "golden", "reaching_frames"), dst)
+    snap, cfg_path = get_snapshot_path("snapshot-step2-final--0", proj, shuffle=1)
+    weights_io.save_weights(snap, make_weights(50, 5, True, seed=43, head_std=0.05))          # (TF V2 bundle: the default format)
+    labels = estimate_pose(str(cfg_path), snap, os.path.join(proj, "videos", "reachingvideo1.avi"), os.path.join(proj, "videos_pred"),
+                           shuffle=1, batch_size=16)
+    numbers = G["reach_numbers"]
+    T = int(numbers[-1]) + 1
+    assert labels["x"].shape == (T, 5) and T == 246
+    which = np.maximum(np.searchsorted(numbers, np.arange(T), side="right") - 1, 0)          # the labeled image frame t shows
+    assert np.abs(labels["x"] - G["reach_x"][which]).max() < 1e-3
+    assert np.abs(labels["y"] - G["reach_y"][which]).max() < 1e-3
+    assert np.abs(labels["likelihoods"] - G["reach_lik"][which]).max() < 1e-5
+    rows = open(os.path.join(proj, "videos_pred", "reachingvideo1_labeled.csv")).read().strip().split("\n")
+    assert len(rows) == 3 + T and rows[1].startswith("bodyparts,part0,part0,part0,part1")
