@@ -73,6 +73,7 @@ struct ConvArgs {
     // the prediction failed, so a copy written with a stale scale is never read.  No previous range: no copy is written.
     float*       shadow;
     const float* shadow_prev;
+    int          shadow_fmt;   // 0 / 1: H2 cells (fp16 high / low, the parity trainer's wgrad_dma operands); 2: H1 cells (high only: the 16-bit trainer)
     // Training step, H2 tensors with PREDICTED scales: where a pointer is set, the tensor's scale is not the host-known float above
     // but shadow_scale_for(pointer) -- the range slots the same tensor had one step earlier -- read on the device.  The host checks
     // after the pass that every such tensor stayed inside its predicted range (dgp_train.hip, h2_pred_check_kernel) and repeats the
@@ -80,7 +81,7 @@ struct ConvArgs {
     const float* in_scale_dev;
     const float* out_scale_dev;
     const float* res_scale_dev;
-    int mask_fmt;             // 1: the ReLU gate tensor (mask) is H2: gate = stored value > 0
+    int mask_fmt;             // 1: the ReLU gate tensor (mask) is H2: gate = stored value > 0; 2: H1 (stored half > 0)
 };
 
 constexpr int ABSMAX_SLOTS = 256;

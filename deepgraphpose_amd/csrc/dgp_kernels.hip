@@ -417,7 +417,7 @@ __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[T
     // fp16 high / low copy of the output (ConvArgs::shadow): this lane's 4 channels are half of an 8-channel cell
     const float sh_scale = p.shadow ? shadow_scale_for(p.shadow_prev, lane) : 0.f;
     const __amdgpu_buffer_rsrc_t rs_sh =
-        __builtin_amdgcn_make_buffer_rsrc(p.shadow ? p.shadow : p.out, 0, sh_scale > 0.f ? (int)p.out_bytes : 0, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(p.shadow ? p.shadow : p.out, 0, sh_scale > 0.f ? (int)(p.shadow_fmt == 2 ? p.out_bytes >> 1 : p.out_bytes) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_mask =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.mask ? p.mask : p.in), 0, p.mask ? (int)p.out_bytes : 0, 0x00020000);
     const int my_c4 = lane % C4;
@@ -493,7 +493,10 @@ __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[T
         if (p.mask) {
 #pragma unroll
             for (int u = 0; u < VC; ++u) {
-                if (p.mask_fmt) {      // H2 gate tensor: this lane's 4 channels are 8 bytes of the cell's high chunk and 8 of its low chunk
+                if (p.mask_fmt == 2) {      // H1 gate tensor: this lane's 4 channels are 8 bytes at half the fp32 offset
+                    const u32x2 mh = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_mask, (int)(ooff[slot][u] >> 1), 0, 0));
+                    rmask[u] = h2_gate4(mh, u32x2{0u, 0u});
+                } else if (p.mask_fmt) {      // H2 gate tensor: this lane's 4 channels are 8 bytes of the cell's high chunk and 8 of its low chunk
                     const unsigned mo = (ooff[slot][u] & ~31u) + ((ooff[slot][u] & 16u) >> 1);
                     // (bit_cast: the builtin's result converts to a vector by splatting its low dword)
                     const u32x2 mh = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_mask, (int)mo, 0, 0));
@@ -517,7 +520,12 @@ __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[T
                 o.z = rmask[u].z > 0.f ? o.z : 0.f; o.w = rmask[u].w > 0.f ? o.w : 0.f;
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)ooff[slot][u], 0, 0);
-            if (sh_scale > 0.f) {
+            if (sh_scale > 0.f && p.shadow_fmt == 2) {
+                // H1 copy (the 16-bit trainer): this lane's 4 channels are 8 bytes of the tensor at half the fp32 offset
+                uint2 sh, sl;
+                split2_f16(o, sh_scale, sh, sl);
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{sh.x, sh.y}, rs_sh, (int)(ooff[slot][u] >> 1), 0, DGP_SHADOW_AUX);
+            } else if (sh_scale > 0.f) {
                 // this lane holds 4 of a cell's 8 channels: trade halves with the neighbour (quad_perm 1,0,3,2) so that the even lane
                 // stores the whole high chunk and the odd lane the whole low chunk -- one 16-byte store per lane, whole cells per pair
                 uint2 sh, sl;
@@ -899,6 +907,9 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
         bi[0] = a.x; bi[1] = a.y; bi[2] = a.z; bi[3] = a.w; bi[4] = b.x; bi[5] = b.y; bi[6] = b.z; bi[7] = b.w;
     }
     const float out_scale = h2_out_scale(p, lane), res_inv_scale = p.res_fmt ? h2_res_inv_scale(p, lane) : 1.f;
+    // O1 only (the 16-bit trainer's data-gradient convs): ReLU gate read from an H1 tensor of the output's shape (gate = stored half > 0)
+    const __amdgpu_buffer_rsrc_t rs_mask =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((O1 && p.mask) ? p.mask : p.in), 0, (O1 && p.mask) ? (int)p.out_bytes : 0, 0x00020000);
     float amax = 0.f;
     unsigned ooff[2][VC];
     uint4 rres[2][VC][2];
@@ -914,6 +925,9 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
                 unsigned roff = OOB;
                 if (p.res_s == 1) {
                     roff = ooff[slot][u];
+                } else if (O1 && p.res_s == -2 && ok) {        // residual on the 2x coarser grid (gradient of a subsample shortcut)
+                    const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                    if (!((ho | wo) & 1)) roff = (unsigned)(((n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1)) * p.Cout + co8) << OSH;
                 } else if (p.res_s > 1 && ok) {
                     const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
                     roff = (unsigned)(((n * p.res_H + ho * p.res_s) * p.res_W + wo * p.res_s) * p.Cout + co8) << OSH;
@@ -965,6 +979,11 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
                 if (p.relu) o[k] = fmaxf(o[k], 0.f);
             }
             if constexpr (O1) {
+                if (p.mask) {          // d/dx of ReLU: pass the gradient where the saved (H1) activation is positive
+                    const half8 g = __builtin_bit_cast(half8, __builtin_bit_cast(uint4, buf_load16(rs_mask, ooff[slot][u])));
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] = (float)g[k] > 0.f ? o[k] : 0.f;
+                }
                 const uint4 hc = h1_pack8(o, out_scale);
                 if (p.epi_nt & 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hc), rs_out, (int)ooff[slot][u], 0, 2);
                 else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hc), rs_out, (int)ooff[slot][u], 0, 0);
@@ -2119,7 +2138,10 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const ConvArgs p) {
             if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
             if (p.mask) {
                 float4 g;
-                if (p.mask_fmt) {
+                if (p.mask_fmt == 2) {
+                    const uint2 mh = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(p.mask) + ((long long)m * p.Cout + co) * 2);
+                    g = h2_gate4(u32x2{mh.x, mh.y}, u32x2{0u, 0u});
+                } else if (p.mask_fmt) {
                     const char* cell = reinterpret_cast<const char*>(p.mask + (long long)m * p.Cout + (co & ~7)) + ((co & 4) ? 8 : 0);
                     const uint2 mh = *reinterpret_cast<const uint2*>(cell), ml = *reinterpret_cast<const uint2*>(cell + 16);
                     g = h2_gate4(u32x2{mh.x, mh.y}, u32x2{ml.x, ml.y});
@@ -2130,9 +2152,13 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const ConvArgs p) {
             if (sh_scale > 0.f) {
                 uint2 sh, sl;
                 split2_f16(o, sh_scale, sh, sl);
+                if (p.shadow_fmt == 2) {
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(p.shadow) + ((long long)m * p.Cout + co) * 2) = sh;
+                } else {
                 char* cell = reinterpret_cast<char*>(p.shadow + (long long)m * p.Cout + (co & ~7)) + ((co & 4) ? 8 : 0);
                 *reinterpret_cast<uint2*>(cell) = sh;
                 *reinterpret_cast<uint2*>(cell + 16) = sl;
+                }
             }
             amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
@@ -2204,14 +2230,16 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     constexpr int NP = NT == 6 ? 3 : 2;
     constexpr int KG = BK / 8;
     if (NT == 2 && ((!a.in_absmax && !a.in_fmt) || !a.w_absmax)) return hipErrorInvalidValue;      // fp16 split needs both ranges (H2 input carries its scale)
-    if ((a.in_fmt || a.out_fmt) && !(NT == 2 && BK == 32 && CW == 4 && a.wh3 && (a.Cout % 8) == 0 && (a.Cin % 8) == 0 && !a.up && !a.stem && !a.mask))
-        return hipErrorInvalidValue;                                                 // H2 tensors: fp16-split cell kernels only
+    if ((a.in_fmt || a.out_fmt) && !(NT == 2 && BK == 32 && CW == 4 && a.wh3 && (a.Cout % 8) == 0 && (a.Cin % 8) == 0 && !a.up && !a.stem &&
+                                     (!a.mask || (a.in_fmt == 2 && a.out_fmt == 2 && a.mask_fmt == 2))))
+        return hipErrorInvalidValue;                                                 // H2 tensors: fp16-split cell kernels only (an H1 gate: H1 -> H1 launches)
     // 16-bit tier (in_fmt 2: H1 cells, already in 4-byte units here -- launch_conv): H1 or fp32 output, H1 residual, no predicted scales
     const bool h1 = a.in_fmt == 2;
     if (h1 != (a.out_fmt == 2) && a.out_fmt != 0) return hipErrorInvalidValue;
     if (a.out_fmt == 2 && !h1) return hipErrorInvalidValue;
     if (a.res && (a.res_fmt == 2) != (a.out_fmt == 2)) return hipErrorInvalidValue;
-    if (h1 && (a.in_scale_dev || a.out_scale_dev || a.res_scale_dev || a.shadow)) return hipErrorInvalidValue;
+    if (h1 && a.shadow) return hipErrorInvalidValue;
+    if (a.res && a.res_s == -2 && !(h1 && a.out_fmt == 2)) { if (a.in_fmt) return hipErrorInvalidValue; }
     // non-temporal residual loads / output stores in the H2 epilogue (A/B switch DGP_EPI_NT; 0: off, 1: every layer, 2 (default): only
     // layers with >= 8 column tiles (N >= 1024: conv3 of block3 / block4), 3 / 4: their loads / stores only).  There the 128 KB a tile
     // streams through the epilogue evict the A rows the other column tiles of the row block still read: PMC FETCH_SIZE 1061 MB per
@@ -2593,7 +2621,7 @@ const char* conv_kernel_name(const ConvArgs& a, int tile_cfg) {
 // units (two halves each), so every quantity the loaders use is halved here, once: channels per pixel, K-steps, panel rows per tap,
 // second-source split, byte extents.  The GEMM's columns (Cout, CoutP) are not touched: the O1 epilogue halves its own byte offsets.
 static bool to_h1_units(ConvArgs& a) {
-    if ((a.Cin & 63) || (a.in2 && (a.cin_split & 63)) || (a.nk & 1) || a.up || a.stem || a.mask || !a.wh3) return false;
+    if ((a.Cin & 63) || (a.in2 && (a.cin_split & 63)) || (a.nk & 1) || a.up || a.stem || !a.wh3) return false;
     a.Cin >>= 1; a.cin_split >>= 1; a.nk >>= 1; a.tap_rows >>= 1;
     a.log2cin4 = ilog2(a.Cin / 4);
     a.in_bytes >>= 1; a.in2_bytes >>= 1; a.w_bytes >>= 1; a.wh3_bytes >>= 1;

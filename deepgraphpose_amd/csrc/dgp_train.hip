@@ -928,13 +928,20 @@ __global__ __launch_bounds__(256) void wgrad_h3p(const WgradArgs p, const WgradR
 //              ranges against them (shadow_usable) and, where the prediction failed (first step, a jump of more than 2^5 up or 2^7 down),
 //              runs the fp32-MFMA tile on the fp32 tensors instead (same grid, same LDS size) -- slower, never wrong.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void wgrad_dma(const WgradArgs p) {
-    constexpr unsigned ROW = 512u, OPB = 16u * ROW, STG = 2u * OPB;      // pixel row, one operand of a stage (8 KB), a stage (16 KB)
+// H1 (round 5, the 16-bit trainer): both operands are H1 tensors IN PLACE -- the retained activation and the gradient tensor themselves, plain
+// NHWC fp16 with predicted power-of-two scales, no copies and no fp32 twins.  A pixel row of a stage is 16 cells of 16 bytes (256 B), ONE
+// LDS-DMA instruction per operand, wave and step covers four pixel rows (lane >> 4) x 16 chunk positions (lane & 15), the transposed reads
+// are the high-piece reads of the H2 image at half the row pitch, and a step is 4 MFMAs (one per product) instead of 12.  A tensor that
+// left its predicted range raises fail_flag (the host repeats the step on the parity path): there is nothing to fall back to.
+template <bool H1>
+__device__ __forceinline__ void wgrad_dma_t(const WgradArgs& p) {
+    constexpr unsigned ROW = H1 ? 256u : 512u, OPB = 16u * ROW, STG = 2u * OPB;      // pixel row, one operand of a stage, a stage (H2: 16 KB)
+    constexpr unsigned EB = H1 ? 2u : 4u;         // bytes per channel of the operand tensors
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), half = lane >> 5, l31 = lane & 31;
     const float sx = shadow_scale_for(p.x_prev, lane), sy = shadow_scale_for(p.dy_prev, lane);
     if (!(shadow_usable(sx, p.x_cur, lane) && shadow_usable(sy, p.dy_cur, lane))) {
-        if (p.x && p.dy) wgrad_f32_body<2>(p);
+        if (!H1 && p.x && p.dy) wgrad_f32_body<2>(p);
         else if (p.fail_flag && threadIdx.x == 0) atomicOr(p.fail_flag, 1);       // the host repeats the step on fp32 tensors
         return;
     }
@@ -946,8 +953,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma(const WgradArgs p) {
     if (m_hi <= m_lo) return;
     const int nsub = (((m_hi - m_lo + 15) >> 4) + 3) & ~3;      // 16-pixel steps, rounded up to the unroll (rows past m_hi read as zeros)
     const bool pointwise = p.ntaps == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && p.H == p.Ho && p.W == p.Wo;
-    const unsigned x_lim = pointwise ? (unsigned)min((long long)p.x_bytes, (long long)m_hi * p.Cin * 4) : p.x_bytes;
-    const unsigned dy_lim = (unsigned)min((long long)p.dy_bytes, (long long)m_hi * p.Cdy * 4);
+    const unsigned xb = H1 ? p.x_bytes >> 1 : p.x_bytes, dyb = H1 ? p.dy_bytes >> 1 : p.dy_bytes;
+    const unsigned x_lim = pointwise ? (unsigned)min((long long)xb, (long long)m_hi * p.Cin * EB) : xb;
+    const unsigned dy_lim = (unsigned)min((long long)dyb, (long long)m_hi * p.Cdy * EB);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.xs), 0, (int)x_lim, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dys), 0, (int)dy_lim, 0x00020000);
     const float post = 1.f / (sx * sy);
@@ -956,9 +964,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma(const WgradArgs p) {
     // lanes 0-31 the first row, 32-63 the second; slot = lane & 31 -> plane (high / low) = slot >> 4, chunk position cs = slot & 15,
     // which holds logical cell cs ^ f(row), f(row) = ((row & 3) << 2) | ((row >> 2) & 3).  e only flips bit 0 of f: the two cells of a
     // lane are neighbours (same tap), its two pixel rows are 4 apart.
-    const int slot = lane & 31, plane = slot >> 4, cs_ = slot & 15;
-    const int f0 = (((2 * (wave & 1) + half) << 2) | (2 * (wave >> 1)));
-    const int row0 = 4 * (2 * (wave >> 1)) + 2 * (wave & 1) + half;              // stage-local pixel row of instruction 0 (instruction 1: + 4)
+    // (H1: one instruction per operand covers rows 4 wave + (lane >> 4), chunk position lane & 15; f(row) = ((lane >> 4) << 2) | wave; e = 0 only)
+    const int slot = lane & 31, plane = H1 ? 0 : slot >> 4, cs_ = H1 ? (lane & 15) : (slot & 15);
+    const int f0 = H1 ? (((lane >> 4) << 2) | wave) : (((2 * (wave & 1) + half) << 2) | (2 * (wave >> 1)));
+    const int row0 = H1 ? 4 * wave + (lane >> 4) : 4 * (2 * (wave >> 1)) + 2 * (wave & 1) + half;      // stage-local pixel row of instruction 0 (H2: instruction 1: + 4)
+    constexpr int NE = H1 ? 1 : 2;                // DMA instructions per operand, wave and step
     const int lc8 = p.log2cin4 - 1;                                              // log2(Cin / 8)
     const int kcells = p.kchunks >> 1;
     int cellA[2], cellB[2];
@@ -977,30 +987,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma(const WgradArgs p) {
     const int cmask = (1 << lc8) - 1;
     unsigned offa[2], offb[2];
     int whi[2], wwi[2], mleft[2];
-    const unsigned stepb = 16u * (unsigned)p.Cdy * 4u, stepa_pw = 16u * (unsigned)p.Cin * 4u;
+    const unsigned stepb = 16u * (unsigned)p.Cdy * EB, stepa_pw = 16u * (unsigned)p.Cin * EB;
     const int hlim = p.Ho * p.stride + dh, wlim = p.Wo * p.stride + dw;
-    const unsigned d_px = (unsigned)(16 * p.stride * p.Cin * 4);
-    const unsigned d_row = (unsigned)((p.stride * p.W - p.Wo * p.stride) * p.Cin * 4);
-    const unsigned d_img = (unsigned)((p.H * p.W - p.Ho * p.stride * p.W) * p.Cin * 4);
+    const unsigned d_px = (unsigned)(16 * p.stride * p.Cin) * EB;
+    const unsigned d_row = (unsigned)((p.stride * p.W - p.Wo * p.stride) * p.Cin) * EB;
+    const unsigned d_img = (unsigned)((p.H * p.W - p.Ho * p.stride * p.W) * p.Cin) * EB;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int m = m_lo + row0 + 4 * e;
-        const unsigned cha = (unsigned)(((cellA[e] & cmask) * 8) * 4 + 16 * plane);
-        offb[e] = cok[e] ? ((unsigned)(m * p.Cdy + n0 + 8 * cellB[e]) << 2) + 16u * plane : OOBT;
+        const unsigned cha = (unsigned)((cellA[e] & cmask) * 8) * EB + 16u * (unsigned)plane;
+        offb[e] = cok[e] ? (unsigned)(m * p.Cdy + n0 + 8 * cellB[e]) * EB + 16u * (unsigned)plane : OOBT;
         if (pointwise) {
-            offa[e] = qok[e] ? (unsigned)(m * p.Cin) * 4u + cha : OOBT;
+            offa[e] = qok[e] ? (unsigned)(m * p.Cin) * EB + cha : OOBT;
             whi[e] = wwi[e] = mleft[e] = 0;
         } else {
             const int n = m / HoWo, rem = m - n * HoWo;
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
             whi[e] = ho * p.stride + dh;
             wwi[e] = wo * p.stride + dw;
-            offa[e] = (unsigned)(((n * p.H + whi[e]) * p.W + wwi[e]) * p.Cin) * 4u + cha;
+            offa[e] = (unsigned)(((n * p.H + whi[e]) * p.W + wwi[e]) * p.Cin) * EB + cha;
             mleft[e] = m_hi - m;
         }
     }
     typedef __attribute__((address_space(3))) void lds_void;
-    char* const dst0 = smem + (unsigned)__builtin_amdgcn_readfirstlane((4 * (2 * (wave >> 1)) + 2 * (wave & 1)) * (int)ROW);
+    char* const dst0 = smem + (unsigned)__builtin_amdgcn_readfirstlane((H1 ? 4 * wave : 4 * (2 * (wave >> 1)) + 2 * (wave & 1)) * (int)ROW);
     // the four DMA instructions of one step into stage ST (A e = 0, A e = 1, B e = 0, B e = 1), then the walkers move on by 16 pixels
     auto dma_a = [&](char* stage, int e) {
         unsigned off;
@@ -1055,9 +1065,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma(const WgradArgs p) {
     const unsigned cs_off = OPB + ROW * (unsigned)(t >> 4) + 16u * (unsigned)(t & 15);
     auto colsum_stage = [&](const char* stage) {
         const half8 h = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(stage + cs_off));
+        if constexpr (H1) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cs8[k] += (float)h[k];
+        } else {
         const half8 l = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(stage + cs_off + 256));
 #pragma unroll
         for (int k = 0; k < 8; ++k) cs8[k] += (float)h[k] + (float)l[k];
+        }
     };
 
 #define WD_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -1079,12 +1094,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma(const WgradArgs p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         char* st = dst0 + k * STG;
-        dma_a(st, 0); dma_a(st, 1); dma_b(st, 0); dma_b(st, 1);
+        dma_a(st, 0); if constexpr (!H1) dma_a(st, 1);
+        dma_b(st, 0); if constexpr (!H1) dma_b(st, 1);
     }
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (H1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    WD_READ2(F0, 0, 0); WD_READ2(F0, 0, 1); WD_READ2(F0, 0, 2); WD_READ2(F0, 0, 3);
-    WD_READ2(F0, 0, 4); WD_READ2(F0, 0, 5); WD_READ2(F0, 0, 6); WD_READ2(F0, 0, 7);
+    WD_READ2(F0, 0, 0); WD_READ2(F0, 0, 2); WD_READ2(F0, 0, 4); WD_READ2(F0, 0, 6);
+    if constexpr (!H1) { WD_READ2(F0, 0, 1); WD_READ2(F0, 0, 3); WD_READ2(F0, 0, 5); WD_READ2(F0, 0, 7); }
     if (do_colsum) colsum_stage(smem);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // stage 0 has been read out: step 4 may land in it
@@ -1118,12 +1134,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma(const WgradArgs p) {
         WD_FENCE();                                                                                                  \
     } while (0)
 
+    // H1: the same step with half of everything but the barrier: 2 DMA instructions, the 4 high-piece read pairs, 4 MFMAs (high x high)
+#define WD_STEP1(S, F, Fn)                                                                                           \
+    do {                                                                                                             \
+        constexpr int NS_ = ((S) + 1) & 3;                                                                           \
+        char* st_ = dst0 + (S) * STG;                                                                                \
+        dma_a(st_, 0); WD_FENCE();                                                                                   \
+        WD_MMA(F, 8);  WD_FENCE(); WD_READ2(Fn, NS_, 0); WD_FENCE();                                                 \
+        dma_b(st_, 0); WD_FENCE();                                                                                   \
+        WD_MMA(F, 9);  WD_FENCE(); WD_READ2(Fn, NS_, 2); WD_FENCE();                                                 \
+        WD_MMA(F, 10); WD_FENCE(); WD_READ2(Fn, NS_, 4); WD_FENCE();                                                 \
+        WD_MMA(F, 11); WD_FENCE(); WD_READ2(Fn, NS_, 6); WD_FENCE();                                                 \
+        if (do_colsum) colsum_stage(smem + NS_ * STG);                                                               \
+        WD_FENCE();                                                                                                  \
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                                                  \
+        __builtin_amdgcn_s_barrier();                                                                                \
+        WD_FENCE();                                                                                                  \
+    } while (0)
     for (int u = 0; u < nsub; u += 4) {
+        if constexpr (H1) {
+            WD_STEP1(0, F0, F1);
+            WD_STEP1(1, F1, F0);
+            WD_STEP1(2, F0, F1);
+            WD_STEP1(3, F1, F0);
+        } else {
         WD_STEP(0, F0, F1);
         WD_STEP(1, F1, F0);
         WD_STEP(2, F0, F1);
         WD_STEP(3, F1, F0);
+        }
     }
+#undef WD_STEP1
 #undef WD_STEP
 #undef WD_MMA
 #undef WD_READ2
@@ -1159,6 +1200,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma(const WgradArgs p) {
             }
     }
 }
+
+__global__ __launch_bounds__(256, 2) void wgrad_dma(const WgradArgs p) { wgrad_dma_t<false>(p); }
+__global__ __launch_bounds__(256, 2) void wgrad_dma_h1(const WgradArgs p) { wgrad_dma_t<true>(p); }
 
 // fp32 [n][C] -> fp16 high / low cells with the scale shadow_scale_for predicts from `prev` (layer-level entry point only: inside the
 // training step the producers' epilogues write the copies)

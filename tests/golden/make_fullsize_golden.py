@@ -5,7 +5,9 @@ oracle at run time (minutes of fp32 CPU convolutions): run in the build containe
 
   r101_*   BASELINE configs[4]'s per-GPU shape: ResNet-101, 1280 x 720, 20 keypoints, both heads, a batch of 16 seeded frames
            (synthetic.make_weights(101, 20, True, seed 41), synthetic.make_frames(16, 720, 1280, 20, seed 42)): soft-argmax mu, window
-           indices, likelihoods of all 16 frames; the scoremap and the locref map sampled at 16 384 seeded positions each + their
+           indices, likelihoods of all 16 frames, and the same coordinates / indices from the oracle's graph evaluated in float64 (the anchor every fp32
+           evaluation order is measured against: with logits of standard deviation 5 on a 90 x 160 map the softmax is broad and two fp32
+           evaluations of this network differ by ~1e-3 px from each other); the scoremap and the locref map sampled at 16 384 seeded positions each + their
            maxima (the maps themselves are 18 / 37 MB)
   reach_*  BASELINE configs[1] / [0]: the 55 labeled frames of the reference's Reaching demo project (832 x 747, 15 of them 640 x 470 crops that
            frames.LabeledDirSource resizes) through ResNet-50 with seeded weights (make_weights(50, 5, True, seed 43)): x, y, likelihood,
@@ -34,7 +36,7 @@ def main():
     # ---- configs[4] per-GPU shape
     wts = make_weights(101, 20, True, seed=41, head_std=0.05)
     frames = make_frames(16, 720, 1280, 20, seed=42)
-    mu, idx, lik, sc_s, lr_s = [], [], [], [], []
+    mu, idx, lik, sc_s, lr_s, mu64, idx64 = [], [], [], [], [], [], []
     rng = np.random.default_rng(7)
     n_sc, n_lr = 90 * 160 * 20, 90 * 160 * 40
     pos_sc = rng.integers(0, n_sc, size=(16, 1024))
@@ -45,6 +47,8 @@ def main():
         sc, lr = O.pose_heads(r["features"], wts, True)
         assert np.array_equal(sc, r["scmap"])
         mu.append(r["mu"]); idx.append(r["idx"]); lik.append(r["likelihoods"])
+        r64 = O.infer(frames[i:i + 2], wts, 101, 8.0, 1.0, 1, dtype=np.float64)        # the accuracy anchor
+        mu64.append(r64["mu"]); idx64.append(r64["idx"])
         for k in range(2):
             sc_s.append(sc[k].reshape(-1)[pos_sc[i + k]]); lr_s.append(lr[k].reshape(-1)[pos_lr[i + k]])
         sc_max, lr_max = max(sc_max, float(np.abs(sc).max())), max(lr_max, float(np.abs(lr).max()))
@@ -52,7 +56,8 @@ def main():
     out.update(r101_mu=np.concatenate(mu).astype(np.float32), r101_idx=np.concatenate(idx).astype(np.int32),
                r101_lik=np.concatenate(lik).astype(np.float32), r101_pos_sc=pos_sc.astype(np.int32), r101_pos_lr=pos_lr.astype(np.int32),
                r101_sc=np.stack(sc_s).astype(np.float32), r101_lr=np.stack(lr_s).astype(np.float32),
-               r101_sc_max=np.float32(sc_max), r101_lr_max=np.float32(lr_max))
+               r101_sc_max=np.float32(sc_max), r101_lr_max=np.float32(lr_max),
+               r101_mu64=np.concatenate(mu64).astype(np.float64), r101_idx64=np.concatenate(idx64).astype(np.int32))
     # ---- the Reaching project's labeled frames
     dst = os.path.join(HERE, "reaching_frames")
     os.makedirs(dst, exist_ok=True)
