@@ -98,6 +98,7 @@ hipError_t launch_f32_to_h1(const float* x, long long n_groups8, float scale, vo
 hipError_t launch_h1_to_f32(const void* x, long long n_groups8, float inv_scale, float* out, hipStream_t s);
 struct PackH3Desc { const float* panel; int nkg; int CoutP; const float* rng; void* out; };      // nkg = nk * 4 k-groups
 hipError_t launch_pack_h3_all(const PackH3Desc* table_dev, int n, hipStream_t s);
+hipError_t launch_pack_h1_all(const PackH3Desc* table_dev, int n, hipStream_t s);      // same table layout, out = H1 cells (half the bytes)
 hipError_t launch_absmax(const float* x, long long n, float* out_slots, hipStream_t s);   // slots = max(slots, max |x|)
 const char* conv_kernel_name(const ConvArgs& a, int tile_cfg);
 hipError_t launch_reduce_slabs(const float* slabs, long long n, long long stride, int nsplit, float* out, hipStream_t s);

@@ -88,6 +88,29 @@ __global__ __launch_bounds__(256) void pack_h3_all_kernel(const PackH3Desc* __re
     }
 }
 
+// pack_h1_kernel for a table of panels in one launch (the 16-bit trainer re-packs every panel after each optimiser step)
+__global__ __launch_bounds__(256) void pack_h1_all_kernel(const PackH3Desc* __restrict__ table) {
+    const PackH3Desc d = table[blockIdx.y];
+    const long long total = (long long)d.nkg * d.CoutP;
+    if ((long long)blockIdx.x * blockDim.x >= total) return;
+    const float s = pow2_scale_for(d.rng, threadIdx.x & 63);
+    const float4* panel = reinterpret_cast<const float4*>(d.panel);
+    uint4* out = reinterpret_cast<uint4*>(d.out);
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int col = (int)(g % d.CoutP);
+        const long long kg = g / d.CoutP;
+        const float4 a = panel[(2 * kg) * d.CoutP + col], b = panel[(2 * kg + 1) * d.CoutP + col];
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        out[g] = h1_pack8(v, s);
+    }
+}
+
+hipError_t launch_pack_h1_all(const PackH3Desc* table_dev, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_h1_all_kernel, dim3(512, (unsigned)n), dim3(256), 0, s, table_dev);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_h3_all(const PackH3Desc* table_dev, int n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(pack_h3_all_kernel, dim3(512, (unsigned)n), dim3(256), 0, s, table_dev);

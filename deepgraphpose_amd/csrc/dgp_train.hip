@@ -1245,6 +1245,47 @@ __global__ __launch_bounds__(256) void h2_to_f32_pred_kernel(const uint4* __rest
     }
 }
 
+// 16-bit tier: H1 cells with a predicted scale -> fp32 (the block4 features for the heads' backward; the data gradient that leaves the
+// H1 units for block1).  gate != nullptr: an H1 tensor of the same shape, the output is zeroed where its half is not positive.
+__global__ __launch_bounds__(256) void h1_to_f32_pred_kernel(const uint4* __restrict__ x, long long n8, const float* __restrict__ prev,
+                                                             float4* __restrict__ out, const uint4* __restrict__ gate) {
+    const float s = shadow_scale_for(prev, threadIdx.x & 63);
+    const float inv = s > 0.f ? 1.f / s : 0.f;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < n8; g += (long long)gridDim.x * 256) {
+        float v[8];
+        h1_unpack8(x[g], inv, v);
+        if (gate) {
+            const half8 q = __builtin_bit_cast(half8, gate[g]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (float)q[k] > 0.f ? v[k] : 0.f;
+        }
+        out[2 * g] = make_float4(v[0], v[1], v[2], v[3]);
+        out[2 * g + 1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+// fp32 -> H1 cells with the scale predicted from `prev` (the heads' data gradient enters the H1 units)
+__global__ __launch_bounds__(256) void f32_to_h1_pred_kernel(const float4* __restrict__ x, long long n8, const float* __restrict__ prev,
+                                                             uint4* __restrict__ out) {
+    const float s = shadow_scale_for(prev, threadIdx.x & 63);
+    if (!(s > 0.f)) return;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < n8; g += (long long)gridDim.x * 256) {
+        const float4 a = x[2 * g], b = x[2 * g + 1];
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        out[g] = h1_pack8(v, s);
+    }
+}
+// zero-stuffed copy of an H1 gradient tensor [N, Ho, Wo, C] -> [N, 2 Ho, 2 Wo, C] (data at the even positions; `out` zeroed by the caller):
+// the data gradient of a stride-2 conv then is a plain stride-1 conv on the cell kernels (the gather form `up = 2` has no LDS-DMA loader)
+__global__ __launch_bounds__(256) void h1_zero_stuff_kernel(const uint4* __restrict__ x, int N, int Ho, int Wo, int C8, uint4* __restrict__ out) {
+    const long long total = (long long)N * Ho * Wo * C8;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const int c = (int)(g % C8);
+        const long long px = g / C8;
+        const int wo = (int)(px % Wo), ho = (int)((px / Wo) % Ho), n = (int)(px / ((long long)Wo * Ho));
+        out[(((long long)n * 2 * Ho + 2 * ho) * (2 * Wo) + 2 * wo) * C8 + c] = x[g];
+    }
+}
+
 // dW = scale * dWraw (HWIO, real Cin) and dot[co] += sum_k W[k][co] * dWraw[k][co]   (grid: k-chunks x co-tiles of 64)
 __global__ __launch_bounds__(256) void scale_dw_dot_kernel(const float* __restrict__ dwraw, const float* __restrict__ w,
                                                            const float* __restrict__ scale, int taps, int cin, int cin_real,
@@ -1540,6 +1581,7 @@ struct TLayer {
     int cin_real = 0;
     float* d_wT = nullptr;                            // data-gradient panels
     float* d_wTh3 = nullptr;                          // ... pre-split into fp16 high/low cells (launch_pack_h3), per sync
+    void* d_wTh1 = nullptr;                           // ... as high-only H1 cells (tier 1)
     int nkT = 0, cinP = 0, cpad = 0;                  // cpad: padded phase-major channel count (heads)
 };
 
@@ -1563,6 +1605,7 @@ struct TrainCtx {
     float* tail_slab = nullptr;                  // K-split slab of the running forward / backward pass (a region of the caller's workspace)
     RangeCtx rng;
     std::unordered_map<const float*, const float*> cells;      // weight panel -> the same panel pre-split into fp16 cells
+    std::unordered_map<const float*, const void*> cells1;      // ... -> its high-only H1 cells (16-bit tier, launch_pack_h1)
     const void* defer_plan = nullptr;            // TPlan of the running backward pass when weight-gradient finalisation is deferred
     char* defer_ws = nullptr;
     // Weight gradients on a second stream: the data-gradient chain is the critical path of the backward pass
@@ -1610,6 +1653,16 @@ struct dgp_trainer {
     int* d_fast_flag = nullptr;       // != 0: an H2 tensor of the last fast pass left its predicted range (the step must be repeated)
     bool fast_next = false;           // dgp_trainer_fast_mode: the next forward pass keeps blocks 2-4 as H2 tensors with predicted scales
     bool fwd_fast = false;            // what the last forward pass did (the backward pass reads its tensors accordingly)
+    // precision tier (dgp_trainer_set_tier): 0 = parity (fp32-class arithmetic, fp32 retained activations); 1 = 16-bit: once a pass of
+    // the same shapes has left its ranges behind, blocks 2-4 keep their retained activations AND their gradient tensors as H1 cells
+    // (2 bytes per channel, scales predicted from the previous step's ranges, no fp32 twins), forward / data-gradient convs run one MFMA
+    // per product on H1 operands and the weight gradients read both operands in place by LDS-DMA (wgrad_dma_h1).  fp32 master
+    // weights, momentum, gradient accumulation (float atomics into fp32 dW), loss, block1 / stem / heads.  A step whose tensors left
+    // their predicted ranges raises d_fast_flag and the host repeats it on the parity path.
+    int tier = 0;
+    int fwd_fmt = 0;                  // cell format of the last fast forward pass: 1 H2 (tuning builds' fast pass), 2 H1 (tier 1)
+    void* d_h1_table = nullptr;       // PackH3Desc of every panel whose H1 cells are rebuilt per sync (tier 1)
+    int n_h1 = 0;
     float* d_wrng = nullptr;          // weight-panel range slots: [2 * n_layers] (forward panels, data-gradient panels), per sync
     void* d_pack_table = nullptr;     // PackDesc of every non-head layer (pack_all_kernel), built at the first sync
     int n_pack = 0;
@@ -1618,8 +1671,8 @@ struct dgp_trainer {
     void* d_fin_table = nullptr;      // FinDesc of every non-head layer (deferred weight-gradient finalisation), per batch size
     int n_fin = 0, fin_B = -1, fin_h = -1, fin_w = -1;
     ~dgp_trainer() {
-        for (void* q : {(void*)d_rng_pool, (void*)d_rng_prev, (void*)d_fast_flag, (void*)d_wrng, d_pack_table, d_fin_table, d_h3_table}) if (q) (void)hipFree(q);
-        for (auto& t : tl) { if (t.d_wT) (void)hipFree(t.d_wT); if (t.d_wTh3) (void)hipFree(t.d_wTh3); }
+        for (void* q : {(void*)d_rng_pool, (void*)d_rng_prev, (void*)d_fast_flag, (void*)d_wrng, d_pack_table, d_fin_table, d_h3_table, d_h1_table}) if (q) (void)hipFree(q);
+        for (auto& t : tl) { if (t.d_wT) (void)hipFree(t.d_wT); if (t.d_wTh3) (void)hipFree(t.d_wTh3); if (t.d_wTh1) (void)hipFree(t.d_wTh1); }
         for (void* p : {(void*)params, (void*)grads, (void*)mom, (void*)stats, (void*)d_sumsq, (void*)d_gnorm})
             if (p) (void)hipFree(p);
     }
@@ -1804,6 +1857,7 @@ static thread_local bool g_shadow_want = true;      // backward pass: only gradi
 // of the tensor named by the launch's in_key / out_key / res_key.
 struct H2Launch { int in_fmt = 0, out_fmt = 0, res_fmt = 0, mask_fmt = 0; const void* res_key = nullptr; };
 static thread_local H2Launch g_h2;
+static thread_local int g_shadow_fmt = 1;            // format of the fp16 copies written in this pass: 1 H2 (high / low), 2 H1 (tier 1: high only)
 
 // weight panel -> the same panel pre-split into fp16 cells (filled by dgp_trainer_sync_weights): with the cells and both ranges the
 // conv runs on the compute-side-split / LDS-DMA kernels of the inference engine
@@ -1841,8 +1895,8 @@ hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, 
     const float* rw = range_of(wpk);
     a.mask_fmt = h2.mask_fmt;
     if (h2.in_fmt || h2.out_fmt || h2.res_fmt) {
-        if (!(rin && rw && out_mode == 0 && h2.in_fmt && h2.out_fmt)) return hipErrorInvalidValue;
-        a.in_fmt = 1; a.out_fmt = 1; a.res_fmt = h2.res_fmt;
+        if (!(rin && rw && out_mode == 0 && h2.in_fmt && h2.out_fmt == h2.in_fmt && (!h2.res_fmt || h2.res_fmt == h2.in_fmt))) return hipErrorInvalidValue;
+        a.in_fmt = h2.in_fmt; a.out_fmt = h2.out_fmt; a.res_fmt = h2.res_fmt;
         a.in_scale_dev = range_prev_of(rin);
         if (h2.res_fmt) a.res_scale_dev = range_prev_of(range_of(h2.res_key));
         if (!a.in_scale_dev || (h2.res_fmt && !a.res_scale_dev)) return hipErrorInvalidValue;
@@ -1851,6 +1905,10 @@ hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, 
         a.in_absmax = rin; a.w_absmax = rw;
         const auto c = g_ctx->cells.find(wpk);
         if (g_train_cells && c != g_ctx->cells.end()) { a.wh3 = c->second; a.wh3_bytes = a.w_bytes; }
+        if (a.in_fmt == 2) {                       // H1 operands: the panel's high-only cells (none: launch_conv refuses)
+            const auto c1 = g_ctx->cells1.find(wpk);
+            a.wh3 = c1 != g_ctx->cells1.end() ? c1->second : nullptr;
+        }
     }
     if (out_mode == 0) {
         a.out_absmax = range_take();
@@ -1873,7 +1931,9 @@ hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, 
         const float* prev = range_prev_of(a.out_absmax);
         if (sb != g_ctx->shadow_base.end() && g_shadow_want && prev && (tile == TILE_128x128_H3K32 || tile == TILE_128x64_H3) &&
             a.in_absmax && a.w_absmax && Cin >= 32 && Cout % 8 == 0) {
-            a.shadow = sb->second + (out - static_cast<const float*>(key));
+            a.shadow_fmt = g_shadow_fmt;
+            a.shadow = g_shadow_fmt == 2 ? reinterpret_cast<float*>(reinterpret_cast<char*>(sb->second) + (out - static_cast<const float*>(key)) * 2)
+                                         : sb->second + (out - static_cast<const float*>(key));
             a.shadow_prev = prev;
             g_ctx->shadow_prev[key] = prev;
         } else {
@@ -1887,7 +1947,7 @@ hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const floa
                         int KW, int stride, int dil, int pad_t, int pad_l, float* dwraw, float* colsum, hipStream_t s,
                         bool zeroed = false, const float* rx_given = nullptr, const float* rdy_given = nullptr,
                         const void* xs = nullptr, const float* x_prev = nullptr, const void* dys = nullptr, const float* dy_prev = nullptr,
-                        int* x_h2_only_flag = nullptr) {
+                        int* x_h2_only_flag = nullptr, bool h1 = false) {
     // x_h2_only_flag: x exists only as H2 cells (xs; fast pass) -- the LDS-DMA tile is the only kernel that can read it, and copies that
     // left their predicted range raise the flag instead of falling back
     WgradArgs a{};
@@ -1933,6 +1993,15 @@ hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const floa
     // fp32-MFMA tile when this step's ranges left the copies' predicted scales)
     // (guards: the kernel's offset walkers run up to 15 (row0) + 63 (sub-steps rounded up to four) + 64 (four prefetched steps) = 142
     //  pixel rows past the tensor's end, and its channel masks need Cin / 8 to be a power of two)
+    if (h1) {       // 16-bit tier: both operands are H1 tensors (xs, dys: in place or the H1 copy of a boundary tensor); no other kernel reads them
+        if (!(big && g_wgrad_dma && rx && rdy && xs && dys && x_prev && dy_prev && x_h2_only_flag && Cin % 16 == 0 && ((Cin / 8) & (Cin / 8 - 1)) == 0 &&
+              Cdy % 8 == 0 && (double)a.x_bytes + 160.0 * Cin * 4 < 4294967000.0 && (double)a.dy_bytes + 160.0 * Cdy * 4 < 4294967000.0))
+            return hipErrorInvalidValue;
+        a.xs = xs; a.dys = dys; a.x_prev = x_prev; a.x_cur = rx; a.dy_prev = dy_prev; a.dy_cur = rdy;
+        a.x = nullptr; a.dy = nullptr; a.fail_flag = x_h2_only_flag;
+        hipLaunchKernelGGL(wgrad_dma_h1, dim3(kt, nt, split), dim3(256), 32 * 1024, s, a);
+        return hipGetLastError();
+    }
     if (big && h3_env && g_wgrad_dma && rx && rdy && xs && dys && x_prev && dy_prev && Cin % 16 == 0 && ((Cin / 8) & (Cin / 8 - 1)) == 0 && Cdy % 8 == 0 &&
         (double)a.x_bytes + 160.0 * Cin * 4 < 4294967000.0 && (double)a.dy_bytes + 160.0 * Cdy * 4 < 4294967000.0) {
         if (!attr[3]) {
@@ -2212,6 +2281,37 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
                 TRY_HIP(hipMemcpy(tr->d_h3_table, tab.data(), tab.size() * sizeof(PackH3Desc), hipMemcpyHostToDevice));
             }
             TRY_HIP(launch_pack_h3_all(reinterpret_cast<const PackH3Desc*>(tr->d_h3_table), tr->n_h3, s));
+            if (tr->tier == 1) {              // 16-bit tier: the same panels as high-only H1 cells (K-steps of 64 channels: K % 64 == 0)
+                if (!tr->d_h1_table) {
+                    std::vector<PackH3Desc> tab;
+                    for (size_t li = 0; li < net->layers.size(); ++li) {
+                        if ((int)li == net->head_part || (int)li == net->head_locref) continue;
+                        ConvLayer& l = net->layers[li];
+                        TLayer& t = tr->tl[li];
+                        if (l.Cin >= 64 && (l.Cin % 64) == 0 && (l.nk % 2) == 0 && l.CoutP % 64 == 0) {
+                            if (!l.d_wh1) TRY_HIP(hipMalloc(&l.d_wh1, (size_t)l.nk * 8 * l.CoutP * 8));
+                            tab.push_back(PackH3Desc{l.d_w, l.nk * 4, l.CoutP, tr->d_wrng + li * ABSMAX_SLOTS, l.d_wh1});
+                            g_ctx->cells1[l.d_w] = l.d_wh1;
+                        }
+                        if (t.d_wT && l.Cout >= 64 && (l.Cout % 64) == 0 && (t.nkT % 2) == 0 && t.cinP % 64 == 0) {
+                            if (!t.d_wTh1) TRY_HIP(hipMalloc(&t.d_wTh1, (size_t)t.nkT * 8 * t.cinP * 8));
+                            tab.push_back(PackH3Desc{t.d_wT, t.nkT * 4, t.cinP, tr->d_wrng + (nl_all + li) * ABSMAX_SLOTS, t.d_wTh1});
+                            g_ctx->cells1[t.d_wT] = t.d_wTh1;
+                        }
+                    }
+                    for (int hd : {net->head_part, net->head_locref}) {
+                        ConvLayer& l = net->layers[hd];
+                        if (l.d_w_pw) {
+                            if (!l.d_wh1_pw) TRY_HIP(hipMalloc(&l.d_wh1_pw, (size_t)nk_for(1, 1, l.Cin) * 8 * l.coutp_pw * 8));
+                            tab.push_back(PackH3Desc{l.d_w_pw, nk_for(1, 1, l.Cin) * 4, l.coutp_pw, tr->d_wrng + (size_t)hd * ABSMAX_SLOTS, l.d_wh1_pw});
+                        }
+                    }
+                    tr->n_h1 = (int)tab.size();
+                    TRY_HIP(hipMalloc(&tr->d_h1_table, tab.size() * sizeof(PackH3Desc)));
+                    TRY_HIP(hipMemcpy(tr->d_h1_table, tab.data(), tab.size() * sizeof(PackH3Desc), hipMemcpyHostToDevice));
+                }
+                TRY_HIP(launch_pack_h1_all(reinterpret_cast<const PackH3Desc*>(tr->d_h1_table), tr->n_h1, s));
+            }
         }
     }
     TRY_HIP(hipGetLastError());
@@ -2245,8 +2345,12 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     size_t ub = net->units.size();
     for (size_t ui = 1; ui < net->units.size(); ++ui)
         if (net->units[ui].depth_bn >= 128 && pl.sh_xo[ui - 1]) { ub = ui; break; }
-    const bool fast = tr->fast_next && g_wgrad_dma && g_train_cells && g_ctx->rng.on && ub < net->units.size() && pl.feat32;
+    const bool fast = tr->fast_next && g_wgrad_dma && g_train_cells && g_ctx->rng.on && ub < net->units.size() && pl.feat32 &&
+                      (tr->tier != 1 || tr->d_h1_table);
+    const int FMT = tr->tier == 1 ? 2 : 1;       // cell format of this pass's H2 / H1 tensors
     tr->fwd_fast = fast;
+    tr->fwd_fmt = fast ? FMT : 0;
+    g_shadow_fmt = (fast && FMT == 2) ? 2 : 1;   // (the one copy a tier-1 forward pass writes: block1's output, read by the first H1 unit)
     if (fast) TRY_HIP(hipMemsetAsync(tr->d_fast_flag, 0, sizeof(int), s));
     for (size_t ui = 0; ui < net->units.size(); ++ui) {
         if (fast && ui >= ub) continue;              // (H2 tensors register themselves as they are written)
@@ -2321,40 +2425,45 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
         const size_t pin = (size_t)hh * ww, pout = (size_t)ho * wo;
         const bool h2u = fast && ui >= ub;             // this unit's tensors are H2
         // (the first H2 unit reads the fp16 copy of its fp32 input; ranges and scales go by the tensor's own name, F(c.x_off))
-        const float* x = (h2u && ui == ub) ? at(pl.sh_xo[ui - 1], pin * c.x_c) : at(c.x_off, pin * c.x_c);
+        // (frame offsets inside H1 tensors are half the fp32 ones: atf)
+        auto atf = [&](size_t off, size_t per_frame, bool cells1) {
+            return cells1 ? reinterpret_cast<float*>(reinterpret_cast<char*>(F(off)) + (size_t)n0 * per_frame * 2) : F(off) + (size_t)n0 * per_frame;
+        };
+        const bool h1u = h2u && FMT == 2;
+        const float* x = (h2u && ui == ub) ? atf(pl.sh_xo[ui - 1], pin * c.x_c, h1u) : atf(c.x_off, pin * c.x_c, h1u && ui > ub);
         const float* res = x;
         const void* res_key = F(c.x_off);
         int res_s = u.stride, res_H = hh, res_W = ww;
         auto h2_next = [&](bool with_res) {
             if (!h2u) return;
-            g_h2.in_fmt = 1; g_h2.out_fmt = 1;
-            if (with_res) { g_h2.res_fmt = 1; g_h2.res_key = res_key; }
+            g_h2.in_fmt = FMT; g_h2.out_fmt = FMT;
+            if (with_res) { g_h2.res_fmt = FMT; g_h2.res_key = res_key; }
         };
         if (u.sc >= 0) {
             const ConvLayer& l = net->layers[u.sc];
             h2_next(false);
             TRY_HIP(conv_launch(l, l.d_w, l.nk, l.CoutP, x, nB, hh, ww, l.Cin, 0, 0, ho, wo, l.Cout, u.stride, 0, l.d_scale,
-                                l.d_bias, nullptr, 0, 0, 0, nullptr, false, 0, 0, at(pl.sc[ui], pout * u.depth), cs, F(c.x_off),
+                                l.d_bias, nullptr, 0, 0, 0, nullptr, false, 0, 0, atf(pl.sc[ui], pout * u.depth, h1u), cs, F(c.x_off),
                                 F(pl.sc[ui])));
-            res = at(pl.sc[ui], pout * u.depth); res_s = 1; res_H = ho; res_W = wo;
+            res = atf(pl.sc[ui], pout * u.depth, h1u); res_s = 1; res_H = ho; res_W = wo;
             res_key = F(pl.sc[ui]);
         }
         const ConvLayer& l1 = net->layers[u.c1];
         h2_next(false);
         TRY_HIP(conv_launch(l1, l1.d_w, l1.nk, l1.CoutP, x, nB, hh, ww, l1.Cin, 0, 0, hh, ww, l1.Cout, 1, 0, l1.d_scale,
-                            l1.d_bias, nullptr, 0, 0, 0, nullptr, true, 0, 0, at(pl.r1[ui], pin * u.depth_bn), cs, F(c.x_off),
+                            l1.d_bias, nullptr, 0, 0, 0, nullptr, true, 0, 0, atf(pl.r1[ui], pin * u.depth_bn, h1u), cs, F(c.x_off),
                             F(pl.r1[ui])));
         const ConvLayer& l2 = net->layers[u.c2];
         const int pb_h = pad_before_for(hh, 3, u.stride, u.rate, true), pb_w = pad_before_for(ww, 3, u.stride, u.rate, true);
         h2_next(false);
-        TRY_HIP(conv_launch(l2, l2.d_w, l2.nk, l2.CoutP, at(pl.r1[ui], pin * u.depth_bn), nB, hh, ww, l2.Cin, pb_h, pb_w, ho, wo,
+        TRY_HIP(conv_launch(l2, l2.d_w, l2.nk, l2.CoutP, atf(pl.r1[ui], pin * u.depth_bn, h1u), nB, hh, ww, l2.Cin, pb_h, pb_w, ho, wo,
                             l2.Cout, u.stride, 0, l2.d_scale, l2.d_bias, nullptr, 0, 0, 0, nullptr, true, 0, 0,
-                            at(pl.r2[ui], pout * u.depth_bn), cs, F(pl.r1[ui]), F(pl.r2[ui])));
+                            atf(pl.r2[ui], pout * u.depth_bn, h1u), cs, F(pl.r1[ui]), F(pl.r2[ui])));
         const ConvLayer& l3 = net->layers[u.c3];
         h2_next(true);
-        TRY_HIP(conv_launch(l3, l3.d_w, l3.nk, l3.CoutP, at(pl.r2[ui], pout * u.depth_bn), nB, ho, wo, l3.Cin, 0, 0, ho, wo, l3.Cout,
+        TRY_HIP(conv_launch(l3, l3.d_w, l3.nk, l3.CoutP, atf(pl.r2[ui], pout * u.depth_bn, h1u), nB, ho, wo, l3.Cin, 0, 0, ho, wo, l3.Cout,
                             1, 0, l3.d_scale, l3.d_bias, res, res_s, res_H, res_W, nullptr, true, 0, 0,
-                            at(pl.xo[ui], pout * u.depth), cs, F(pl.r2[ui]), F(pl.xo[ui])));
+                            atf(pl.xo[ui], pout * u.depth, h1u), cs, F(pl.r2[ui]), F(pl.xo[ui])));
         c.x_off = pl.xo[ui]; c.x_c = u.depth; c.hh = ho; c.ww = wo;
         return DGP_OK;
     };
@@ -2389,14 +2498,18 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     auto head_forward = [&](const ConvLayer& hd, int li, int njt, float* out) -> hipError_t {
         const float* rin = range_of(xin);
         const float* rw = tr->d_wrng ? tr->d_wrng + (size_t)li * ABSMAX_SLOTS : nullptr;
-        if (fast && !(head_pw && rin && rw && hd.d_wh3_pw && tr->d_h3_table)) return hipErrorInvalidValue;       // (H2 features: cell kernels only)
+        if (fast && !(head_pw && rin && rw && hd.d_wh3_pw && tr->d_h3_table && (FMT == 1 || hd.d_wh1_pw))) return hipErrorInvalidValue;       // (H2 / H1 features: cell kernels only)
         if (!(head_pw && g_ctx->rng.on && rin && rw && hd.d_wh3_pw && tr->d_h3_table))
             return conv_launch(hd, hd.d_w, hd.nk, hd.CoutP, xin, B, h, w, hd.Cin, 1, 1, h, w, hd.Cout, 1, 0, nullptr, hd.d_bias,
                                nullptr, 0, 0, 0, nullptr, false, 1, njt, out, s);
         float* T = F(pl.g0);                       // gradient scratch: free during the forward pass
         ConvArgs a{};
         a.in = xin; a.wpk = hd.d_w_pw; a.wh3 = hd.d_wh3_pw; a.out = T; a.in_absmax = rin; a.w_absmax = rw;
-        if (fast) { a.in_fmt = 1; a.in_scale_dev = range_prev_of(rin); if (!a.in_scale_dev) return hipErrorInvalidValue; }
+        if (fast) {
+            a.in_fmt = FMT; a.in_scale_dev = range_prev_of(rin);
+            if (!a.in_scale_dev) return hipErrorInvalidValue;
+            if (FMT == 2) a.wh3 = hd.d_wh1_pw;
+        }
         a.slab = g_ctx->tail_slab; a.slab_bytes = g_ctx->tail_slab ? (unsigned)(TAIL_SLAB_FLOATS * sizeof(float)) : 0u;
         a.N = B; a.H = h; a.W = w; a.Cin = hd.Cin; a.log2cin4 = ilog2(hd.Cin / 4);
         a.Ho = h; a.Wo = w; a.Cout = hd.coutp_pw; a.CoutP = hd.coutp_pw;
@@ -2424,6 +2537,10 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
         // fp32 copy of the features for the heads' backward
         const float* rfeat = range_of(xin);
         const long long n8 = (long long)B * h * w * net->units.back().depth / 8;
+        if (FMT == 2)
+            hipLaunchKernelGGL(h1_to_f32_pred_kernel, dim3(grid_for(n8)), dim3(256), 0, s, reinterpret_cast<const uint4*>(xin), n8,
+                               range_prev_of(rfeat), reinterpret_cast<float4*>(F(pl.feat32)), (const uint4*)nullptr);
+        else
         hipLaunchKernelGGL(h2_to_f32_pred_kernel, dim3(grid_for(n8)), dim3(256), 0, s, reinterpret_cast<const uint4*>(xin), n8,
                            range_prev_of(rfeat), reinterpret_cast<float4*>(F(pl.feat32)));
         TRY_HIP(hipGetLastError());
@@ -2464,12 +2581,14 @@ static int layer_param_grads(dgp_trainer* tr, size_t li, const float* x, int N, 
             }
         }
         int* h2_only = (xs && xs == (const void*)x) ? tr->d_fast_flag : nullptr;       // fast pass: the activation has no fp32 twin
+        const bool h1 = tr->fwd_fast && tr->fwd_fmt == 2 && xs && dys;                 // 16-bit tier: both operands are H1 tensors
+        if (h1) h2_only = tr->d_fast_flag;
         if (!h2_only && tr->fwd_fast && g_ctx->shadow_base.count(x) && g_ctx->shadow_base[x] == x)
             return fail(DGP_ERR_STATE, "weight gradient of an H2-only activation without a usable gradient copy");
         TRY_HIP(wgrad_launch(x, N, H, W, l.Cin, dy, Ho, Wo, l.Cout, l.KH, l.KW, stride, l.rate, pad_t, pad_l,
                              reinterpret_cast<float*>(g_ctx->defer_ws + ((const TPlan*)g_ctx->defer_plan)->dw_l[li]),
                              reinterpret_cast<float*>(g_ctx->defer_ws + ((const TPlan*)g_ctx->defer_plan)->cs_l[li]), ws_, true,
-                             nullptr, nullptr, xs, xp, dys, dyp, h2_only));
+                             nullptr, nullptr, xs, xp, dys, dyp, h2_only, h1));
         if (done) {
             TRY_HIP(hipEventRecord(done, g_ctx->s2));
             g_ctx->readers.emplace((const void*)dy, done);
@@ -2568,10 +2687,27 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
     // fast pass (dgp_train_forward): the activations of units >= ub are H2 tensors -- gates read them as such, weight gradients read
     // them in place, and the heads use the fp32 copy of the features the forward pass left in feat32
     const bool fast = tr->fwd_fast;
+    const bool h1p = fast && tr->fwd_fmt == 2;          // 16-bit tier: the gradient tensors of units >= ub are H1-only as well
+    if (h1p && !defer_env) return fail(DGP_ERR_STATE, "the 16-bit tier needs the deferred weight-gradient finalisation (DGP_WGRAD_DEFER)");
     int ub = nu;
     for (int ui = 1; ui < nu; ++ui)
         if (net->units[ui].depth_bn >= 128 && pl.sh_xo[ui - 1]) { ub = ui; break; }
     g_h2 = H2Launch();
+    g_shadow_fmt = h1p ? 2 : 1;
+    if (h1p) g_ctx->h2_slots.clear();                   // this pass's H1 gradient tensors, checked against their predicted scales at its end
+    float* GH[2] = {F(pl.sh_g0), F(pl.sh_g1)};           // tier 1: G of the H1 units (the fp16-copy regions of the parity pass hold the tensors themselves)
+    // H1 tensor `t` takes the range slot / predicted scale of the launch that wrote `src` (a converted copy of it)
+    auto adopt_h1 = [&](const void* t, const void* src) -> int {
+        const float* slot = range_of(src);
+        const float* pv = range_prev_of(slot);
+        if (!slot || !pv) return fail(DGP_ERR_STATE, "16-bit tier: a gradient tensor has no predicted range");
+        range_set(t, slot);
+        g_ctx->shadow_base[t] = const_cast<float*>(static_cast<const float*>(t));
+        g_ctx->shadow_prev[t] = pv;
+        const int idx = (int)((pv - g_ctx->rng.prev) / ABSMAX_SLOTS);
+        if (std::find(g_ctx->h2_slots.begin(), g_ctx->h2_slots.end(), idx) == g_ctx->h2_slots.end()) g_ctx->h2_slots.push_back(idx);
+        return DGP_OK;
+    };
     // ---- heads: gather phases, parameter grads, data grad into G[cur] (gated by the last unit's ReLU)
     const float* feat = fast ? F(pl.feat32) : F(pl.xo[nu - 1]);
     {
@@ -2605,7 +2741,13 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         }
     }
 
-    if (fast) {
+    if (h1p) {
+        // the heads' data gradient (fp32, from the kernels of the parity path) enters the H1 units as an H1 tensor
+        if ((rc = adopt_h1(GH[cur], G[cur]))) return rc;
+        const long long n8 = (long long)B * fh * fw * net->units[nu - 1].depth / 8;
+        hipLaunchKernelGGL(f32_to_h1_pred_kernel, dim3(grid_for(n8)), dim3(256), 0, s, reinterpret_cast<const float4*>(G[cur]), n8,
+                           g_ctx->shadow_prev[GH[cur]], reinterpret_cast<uint4*>(GH[cur]));
+    } else if (fast) {
         // the heads' data gradient came from a kernel that writes no fp16 copy, and the last unit's conv3 weight gradient can only read
         // its H2 activation through the LDS-DMA tile: make the copy here
         const float* pv = range_prev_of(range_of(G[cur]));
@@ -2639,6 +2781,87 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         const Unit& u = net->units[ui];
         const int h = hs[ui], w = wsz[ui], ho = hs[ui + 1], wo = wsz[ui + 1];
         const float* xin = ui == 0 ? F(pl.pool) : F(pl.xo[ui - 1]);
+        if (h1p && ui >= ub) {
+            // ---- 16-bit tier: every tensor of this unit is an H1 tensor with a predicted scale; data gradients are H1 -> H1 launches of the
+            // cell kernels (gate and residual read as H1), weight gradients read both operands in place (wgrad_dma_h1)
+            const ConvLayer &l1 = net->layers[u.c1], &l2 = net->layers[u.c2], &l3 = net->layers[u.c3];
+            const TLayer &t1 = tr->tl[u.c1], &t2 = tr->tl[u.c2], &t3 = tr->tl[u.c3];
+            float* const GoutH = GH[cur];
+            float* const GinH = GH[cur ^ 1];
+            float* const DR2H = F((ui & 1) ? pl.sh_dr2_b : pl.sh_dr2);
+            float* const DR1H = F((ui & 1) ? pl.sh_dr1_b : pl.sh_dr1);
+            float* const DXAH = F((ui & 1) ? pl.dxa_b : pl.dxa);
+            const float* xinH = ui > ub ? xin : F(pl.sh_xo[ui - 1]);       // (unit ub reads the H1 copy of block1's fp32 output)
+            auto fmt = [&](bool gate, const void* res_key) {
+                g_h2 = H2Launch();
+                g_h2.in_fmt = 2; g_h2.out_fmt = 2; g_h2.mask_fmt = gate ? 2 : 0;
+                if (res_key) { g_h2.res_fmt = 2; g_h2.res_key = res_key; }
+            };
+            rc = layer_param_grads(tr, u.c3, F(pl.r2[ui]), B, ho, wo, GoutH, ho, wo, 1, 0, 0, dwraw, colsum, s);
+            if (rc) return rc;
+            TRY_HIP(before_write(DR2H));
+            fmt(true, nullptr);
+            TRY_HIP(conv_launch(l3, t3.d_wT, t3.nkT, t3.cinP, GoutH, B, ho, wo, l3.Cout, 0, 0, ho, wo, l3.Cin, 1, 0, nullptr, nullptr,
+                                nullptr, 0, 0, 0, F(pl.r2[ui]), false, 0, 0, DR2H, s));
+            const int pb_h = pad_before_for(h, 3, u.stride, u.rate, true), pb_w = pad_before_for(w, 3, u.stride, u.rate, true);
+            rc = layer_param_grads(tr, u.c2, F(pl.r1[ui]), B, h, w, DR2H, ho, wo, u.stride, pb_h, pb_w, dwraw, colsum, s);
+            if (rc) return rc;
+            const int keff = 2 * u.rate + 1;
+            TRY_HIP(before_write(DR1H));
+            if (u.stride > 1) {
+                // stride-2 conv2: its data gradient reads dR2 on the zero-stuffed grid; materialised (a few MB) so that it is a plain stride-1 launch
+                if (u.stride != 2) return fail(DGP_ERR_STATE, "16-bit tier: stride > 2");
+                float* const ZS = F(pl.dr1);             // (the fp32 dR1 region is free while the H1 units run)
+                const size_t zbytes = (size_t)B * 2 * ho * 2 * wo * l2.Cout * 2;
+                if (zbytes > (size_t)B * h * w * u.depth_bn * 4 + 0) { if (zbytes > (size_t)4 * ((size_t)B * h * w * u.depth_bn)) return fail(DGP_ERR_STATE, "16-bit tier: zero-stuffed gradient does not fit"); }
+                TRY_HIP(before_write(ZS));
+                TRY_HIP(hipMemsetAsync(ZS, 0, zbytes, s));
+                const long long tot = (long long)B * ho * wo * (l2.Cout / 8);
+                hipLaunchKernelGGL(h1_zero_stuff_kernel, dim3(grid_for(tot)), dim3(256), 0, s, reinterpret_cast<const uint4*>(DR2H), B, ho, wo,
+                                   l2.Cout / 8, reinterpret_cast<uint4*>(ZS));
+                fmt(true, nullptr);
+                TRY_HIP(conv_launch(l2, t2.d_wT, t2.nkT, t2.cinP, ZS, B, 2 * ho, 2 * wo, l2.Cout, keff - 1 - pb_h, keff - 1 - pb_w, h, w,
+                                    l2.Cin, 1, 0, nullptr, nullptr, nullptr, 0, 0, 0, F(pl.r1[ui]), false, 0, 0, DR1H, s, DR2H));
+            } else {
+                fmt(true, nullptr);
+                TRY_HIP(conv_launch(l2, t2.d_wT, t2.nkT, t2.cinP, DR2H, B, ho, wo, l2.Cout, keff - 1 - pb_h, keff - 1 - pb_w, h, w,
+                                    l2.Cin, 1, 0, nullptr, nullptr, nullptr, 0, 0, 0, F(pl.r1[ui]), false, 0, 0, DR1H, s));
+            }
+            const float* dxa = GoutH;
+            int dxa_mode = 1, dxa_h = ho, dxa_w = wo;
+            if (u.sc >= 0) {
+                const ConvLayer& ls = net->layers[u.sc];
+                const TLayer& ts = tr->tl[u.sc];
+                if (u.stride != 1) return fail(DGP_ERR_STATE, "16-bit tier: strided shortcut conv");
+                rc = layer_param_grads(tr, u.sc, xin, B, h, w, GoutH, ho, wo, 1, 0, 0, dwraw, colsum, s);
+                if (rc) return rc;
+                TRY_HIP(before_write(DXAH));
+                fmt(false, nullptr);
+                TRY_HIP(conv_launch(ls, ts.d_wT, ts.nkT, ts.cinP, GoutH, B, ho, wo, ls.Cout, 0, 0, h, w, ls.Cin, 1, 0, nullptr, nullptr,
+                                    nullptr, 0, 0, 0, nullptr, false, 0, 0, DXAH, s));
+                dxa = DXAH; dxa_h = h; dxa_w = w;
+            } else if (u.stride > 1) {
+                dxa_mode = -2;
+            }
+            rc = layer_param_grads(tr, u.c1, xin, B, h, w, DR1H, h, w, 1, 0, 0, dwraw, colsum, s);
+            if (rc) return rc;
+            TRY_HIP(before_write(GinH));
+            fmt(true, dxa);
+            TRY_HIP(conv_launch(l1, t1.d_wT, t1.nkT, t1.cinP, DR1H, B, h, w, l1.Cout, 0, 0, h, w, l1.Cin, 1, 0, nullptr, nullptr,
+                                dxa, dxa_mode, dxa_h, dxa_w, xinH, false, 0, 0, GinH, s));
+            if (ui == ub) {
+                // the data gradient leaves the H1 units: fp32 copy for block1's kernels (same range slot: the epilogue tracked max |G| before rounding)
+                float* Gf = G[cur ^ 1];
+                TRY_HIP(before_write(Gf));
+                const long long n8 = (long long)B * h * w * l1.Cin / 8;
+                hipLaunchKernelGGL(h1_to_f32_pred_kernel, dim3(grid_for(n8)), dim3(256), 0, s, reinterpret_cast<const uint4*>(GinH), n8,
+                                   g_ctx->shadow_prev[GinH], reinterpret_cast<float4*>(Gf), (const uint4*)nullptr);
+                range_set(Gf, range_of(GinH));
+                g_ctx->shadow_prev.erase(Gf);
+            }
+            cur ^= 1;
+            continue;
+        }
         float* Gout = G[cur];
         float* Gin = G[cur ^ 1];
         const ConvLayer &l1 = net->layers[u.c1], &l2 = net->layers[u.c2], &l3 = net->layers[u.c3];
@@ -2711,6 +2934,13 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         if (rc) return rc;
     }
     (void)nj;
+    if (h1p) {            // every H1 gradient tensor of this pass against its predicted scale (wgrad_dma_h1 raised the same flag for its operands)
+        H2CheckList cl{};
+        if (g_ctx->h2_slots.size() > sizeof(cl.idx) / sizeof(cl.idx[0])) return fail(DGP_ERR_STATE, "16-bit tier: too many H1 gradient tensors");
+        cl.n = (int)g_ctx->h2_slots.size();
+        for (int k = 0; k < cl.n; ++k) cl.idx[k] = (short)g_ctx->h2_slots[k];
+        if (cl.n) hipLaunchKernelGGL(h2_pred_check_kernel, dim3(cl.n), dim3(64), 0, s, cl, g_ctx->rng.pool, g_ctx->rng.prev, tr->d_fast_flag);
+    }
     join();                                      // every weight gradient has landed before the finalisation reads them
     if (g_ctx->defer_plan) {
         g_ctx->defer_plan = nullptr;
@@ -2757,12 +2987,20 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
 int dgp_trainer_fast_mode(dgp_trainer* tr, int32_t enable) {
     if (!tr) return fail(DGP_ERR_INVALID, "dgp_trainer_fast_mode: null");
 #ifndef DGP_TUNING
-    // measured no faster than the plain pass: an opt-in of tuning builds only
-    if (enable) return fail(DGP_ERR_INVALID, "dgp_trainer_fast_mode: the fast pass is enabled in -DDGP_TUNING builds only");
+    // (the H2 form measured no faster than the plain pass, DESIGN.md section 4: an opt-in of tuning builds only; the 16-bit tier's passes use it)
+    if (enable && tr->tier != 1) return fail(DGP_ERR_INVALID, "dgp_trainer_fast_mode: needs dgp_trainer_set_tier(tr, 1) (the H2 fast pass is enabled in -DDGP_TUNING builds only)");
 #endif
     tr->fast_next = enable != 0;
     return DGP_OK;
 }
+int dgp_trainer_set_tier(dgp_trainer* tr, int32_t tier) {
+    if (!tr || (tier != 0 && tier != 1)) return fail(DGP_ERR_INVALID, "dgp_trainer_set_tier: tier must be 0 (parity) or 1 (16-bit)");
+    tr->tier = tier;
+    if (!tier) tr->fast_next = false;
+    return DGP_OK;
+}
+int dgp_trainer_get_tier(const dgp_trainer* tr) { return tr ? tr->tier : 0; }
+
 int dgp_trainer_fast_status(dgp_trainer* tr, int32_t* was_fast, int32_t* failed) {
     if (!tr || !failed) return fail(DGP_ERR_INVALID, "dgp_trainer_fast_status: null");
     int f = 0;

@@ -15,7 +15,13 @@ from .loss import DGPHyper, LOSS_NAMES
 
 
 class Trainer:
-    def __init__(self, depth: int, num_joints: int, in_h: int, in_w: int, max_frames: int = 11, device: int = 0):
+    def __init__(self, depth: int, num_joints: int, in_h: int, in_w: int, max_frames: int = 11, device: int = 0,
+                 tier: Optional[str] = None):
+        """tier: None / "parity": fp32-class arithmetic, fp32 retained activations (the tier every parity test runs on); "f16": the 16-bit
+        tier (include/dgp_hip.h, dgp_trainer_set_tier) -- BASELINE configs[3]'s precision: blocks 2-4 keep activations and gradient
+        tensors as 2-byte H1 cells with scales predicted from the previous step, one MFMA per product, weight gradients by LDS-DMA on
+        the tensors themselves; fp32 master weights / momentum / accumulation.  The first step of a shape (and any step whose tensors
+        leave their predicted ranges) runs on the parity path, so callers never see an invalid step."""
         self.lib = _lib.load()
         self.net = engine.DGPNet(depth, num_joints, in_h, in_w, max_batch=max_frames, with_locref=True, device=device)
         self.device = self.net.device
@@ -34,6 +40,19 @@ class Trainer:
         self._ws = None
         self._ws_nt = 0
         self._shapes = {}
+        self.tier = "parity"
+        self.fast_redos = 0
+        self.fast_passes = 0
+        if tier is not None:
+            self.set_tier(tier)
+
+    def set_tier(self, tier: str):
+        t = {"parity": 0, "f16": 1}[tier]
+        _lib.check(self.lib.dgp_trainer_set_tier(self._t, t), "dgp_trainer_set_tier")
+        self.tier = tier
+        self._fast_key = None                    # the next pass is a plain one (it leaves the ranges the predicted scales come from)
+        if self.table and getattr(self, "_synced", False):
+            self.sync()                          # (the 16-bit tier's weight cells are built by the sync)
 
     def __del__(self):
         t = getattr(self, "_t", None)
@@ -75,6 +94,7 @@ class Trainer:
 
     def sync(self):
         _lib.check(self.lib.dgp_trainer_sync_weights(self._t, _stream(self.device)), "dgp_trainer_sync_weights")
+        self._synced = True
 
     # ---- one optimisation step -------------------------------------------------------------------
     def workspace(self, nt: int) -> torch.Tensor:
@@ -113,9 +133,12 @@ class Trainer:
         key = (nt, self.net.in_h, self.net.in_w)
         # (opt-in: at 11 frames the forward convs of blocks 2-4 are grids of 52-208 tiles, paced by one tile's latency rather than by
         #  operand traffic, and the fast pass measured 12.95-13.09 against 13.01-13.16 ms per step -- DESIGN.md section 6a')
-        fast = (getattr(self, "_fast_key", None) == key and os.environ.get("DGP_TRAIN_H2", "0") == "1"
-                and bool(self.lib.dgp_tuning_build()))          # (an opt-in of -DDGP_TUNING builds: include/dgp_hip.h)
+        fast = getattr(self, "_fast_key", None) == key and (
+            self.tier == "f16" or                                # the 16-bit tier: every pass after the first of a shape
+            (os.environ.get("DGP_TRAIN_H2", "0") == "1" and bool(self.lib.dgp_tuning_build())))      # (H2 fast pass: an opt-in of -DDGP_TUNING builds)
         _lib.check(self.lib.dgp_trainer_fast_mode(self._t, 1 if fast else 0), "dgp_trainer_fast_mode")
+        if fast:
+            self.fast_passes += 1
         return fast
 
     def _fast_end(self, nt: int, fast: bool) -> bool:
@@ -125,7 +148,7 @@ class Trainer:
             _lib.check(self.lib.dgp_trainer_fast_status(self._t, C.byref(was), C.byref(failed)), "dgp_trainer_fast_status")
             if failed.value:
                 self._fast_key = None
-                self.fast_redos = getattr(self, "fast_redos", 0) + 1
+                self.fast_redos += 1
                 return False
         self._fast_key = (nt, self.net.in_h, self.net.in_w)
         return True

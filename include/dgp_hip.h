@@ -223,6 +223,16 @@ int    dgp_sgd_momentum_clip(dgp_trainer* tr, float lr, float momentum, float cl
  * dgp_trainer_fast_status (synchronises the device): *failed != 0 -- a tensor left its predicted range (a jump of more than 2^5 up or
  * 2^7 down within one step); scoremaps, losses and gradients of that step are NOT valid: run it again with fast_mode(tr, 0) before
  * using any of them.  deepgraphpose_amd/train.py (Trainer.forward_backward) does exactly that. */
+/* Precision tier of the training step (BASELINE configs[3] names bf16).  0 (default): parity -- fp32-class arithmetic, fp32 retained
+ * activations.  1: the 16-bit tier -- after dgp_trainer_sync_weights, every pass requested with dgp_trainer_fast_mode(tr, 1) keeps the
+ * retained activations AND the gradient tensors of blocks 2-4 as H1 cells (2 bytes per channel, scales predicted from the previous
+ * step's ranges, no fp32 twins), runs their forward / data-gradient convs on one MFMA per product and reads both operands of their
+ * weight gradients in place by LDS-DMA; fp32 master weights, momentum, gradient accumulation and loss; block1, the root block and the
+ * heads as in tier 0.  Same protocol as the fast pass: never the first pass of a shape; dgp_trainer_fast_status reports a step whose
+ * tensors left their predicted ranges (its results are invalid: run it again with fast_mode(tr, 0)).  Call dgp_trainer_sync_weights
+ * after changing the tier.  A reported tier with measured gradient error, not the parity claim. */
+int    dgp_trainer_set_tier(dgp_trainer* tr, int32_t tier);
+int    dgp_trainer_get_tier(const dgp_trainer* tr);
 int    dgp_trainer_fast_mode(dgp_trainer* tr, int32_t enable);
 int    dgp_trainer_fast_status(dgp_trainer* tr, int32_t* was_fast, int32_t* failed);
 

@@ -737,3 +737,56 @@ def test_trainer_sync_then_net_load_weights_share_one_head_panel_width(lib_built
     sc = tr._forward(ft)[1]
     torch.cuda.synchronize()
     assert np.abs(sc.cpu().numpy() - ref["scmap"]).max() < 1e-4 * np.abs(ref["scmap"]).max()
+
+
+def _grad_agreement(g, P):
+    """global and per-tensor agreement of a gradient dict with the oracle's: cosine, relative L2 error"""
+    dots, n1, n2, per = 0.0, 0.0, 0.0, {}
+    for k, t in P.items():
+        if not t.requires_grad:
+            continue
+        ref = t.grad.numpy().astype(np.float64).ravel()
+        got = g[k].astype(np.float64).ravel()
+        dots += float(ref @ got); n1 += float(ref @ ref); n2 += float(got @ got)
+        per[k] = (float(ref @ got) / (np.linalg.norm(ref) * np.linalg.norm(got) + 1e-300), float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-300)))
+    cos = dots / np.sqrt(n1 * n2)
+    rel = np.sqrt(max(n1 + n2 - 2 * dots, 0.0) / n1)
+    return cos, rel, per
+
+
+@pytest.mark.parametrize("seed,hw,nt", [(3, (64, 96), 3), (5, (128, 160), 4)])
+def test_trainer_tier_f16_gradients_against_the_fp64_oracle(lib_built, seed, hw, nt):
+    """BASELINE configs[3] names bf16: the 16-bit tier of the training step (Trainer(tier="f16"); dgp_trainer_set_tier).  From the second pass
+    of a shape on, blocks 2-4 keep activations and gradient tensors as 2-byte H1 cells with predicted scales, their convs run one MFMA per
+    product and their weight gradients read both operands in place (wgrad_dma_h1).  Against the float64 autograd oracle: loss within
+    2e-3 relative, global gradient cosine >= 0.999 and relative L2 error <= 5 %, every tensor's cosine >= 0.98 -- a REPORTED tier, the
+    parity tier's tolerances (2e-5 / 3e-3) are for tier 0.  The first pass of a shape runs on the parity path and meets THOSE."""
+    import ctypes
+    from deepgraphpose_amd.train import Trainer
+    from deepgraphpose_amd.loss import DGPHyper
+    batch, S0, wts, frames, ws, ws_max = _train_case(seed, hw=hw, nt=nt)
+    hy = DGPHyper(gm2=1, gm3=3)
+    n_tot, n_vis = 300.0, 25.0
+    P, L = _oracle_grads(wts, frames, batch, S0, ws, ws_max, hy, n_tot, n_vis, dtype=torch.float64)
+    ref_loss = float(L["total_loss"].detach())
+    tr = Trainer(50, 3, hw[0], hw[1], max_frames=nt, tier="f16")
+    tr.load_weights(wts)
+    ft = torch.from_numpy(frames).cuda()
+    was, failed = ctypes.c_int32(), ctypes.c_int32()
+    l0 = tr.forward_backward(ft, batch, hy, S0, ws, ws_max, n_tot, n_vis)            # first pass of the shape: parity path
+    tr.lib.dgp_trainer_fast_status(tr._t, was, failed)
+    assert was.value == 0 and abs(l0["total_loss"] - ref_loss) < 1e-4 * max(1, abs(ref_loss))
+    cos0, rel0, _ = _grad_agreement(tr.get_grads(), P)
+    assert cos0 > 0.99999 and rel0 < 3e-3
+    l1 = tr.forward_backward(ft, batch, hy, S0, ws, ws_max, n_tot, n_vis)            # 16-bit pass
+    tr.lib.dgp_trainer_fast_status(tr._t, was, failed)
+    assert was.value == 1 and failed.value == 0 and tr.fast_redos == 0 and tr.fast_passes == 1
+    cos1, rel1, per = _grad_agreement(tr.get_grads(), P)
+    worst = sorted(per.items(), key=lambda kv: kv[1][0])[:3]
+    print("tier f16 %s nt %d: loss %.6f (fp64 %.6f) | gradient cosine %.6f rel L2 %.4f | worst tensors %s" % (hw, nt, l1["total_loss"], ref_loss, cos1, rel1, worst))
+    assert abs(l1["total_loss"] - ref_loss) < 2e-3 * max(1, abs(ref_loss))
+    assert cos1 >= 0.999 and rel1 <= 0.05
+    assert min(v[0] for v in per.values()) >= 0.98, worst
+    assert np.all([np.isfinite(v).all() for v in tr.get_grads().values()])
+    l2 = tr.forward_backward(ft, batch, hy, S0, ws, ws_max, n_tot, n_vis)            # deterministic up to the float atomics of dW
+    assert abs(l2["total_loss"] - l1["total_loss"]) < 1e-6 * max(1, abs(l1["total_loss"]))
