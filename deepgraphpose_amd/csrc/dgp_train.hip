@@ -1418,7 +1418,10 @@ __global__ void head_gather_kernel(const float* __restrict__ dsc, int N, int h, 
 // Training forward pool: the same maxima as maxpool3x3s2_same plus, per window and channel, the position (a * 3 + b) of its FIRST
 // maximum in row-major order -- the element TF's MaxPoolGrad (and the re-scan of maxpool_bwd_kernel below) routes the gradient to.
 __global__ __launch_bounds__(256) void maxpool_fwd_idx_kernel(const float* __restrict__ x, int N, int H, int W, int C4, int Ho, int Wo,
-                                                              int pt, int pl, float* __restrict__ y, uchar4* __restrict__ idx) {
+                                                              int pt, int pl, float* __restrict__ y, uchar4* __restrict__ idx,
+                                                              uint2* __restrict__ y_h1 = nullptr, const float* __restrict__ h1_prev = nullptr) {
+    // y_h1 (16-bit tier): an H1 copy of the pool output with the scale predicted from the previous step's range of conv1's output
+    const float sh1 = y_h1 ? shadow_scale_for(h1_prev, threadIdx.x & 63) : 0.f;
     const long long total = (long long)N * Ho * Wo * C4;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(g % C4);
@@ -1447,6 +1450,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_idx_kernel(const float* __res
         }
         *reinterpret_cast<float4*>(y + g * 4) = m;
         idx[g] = k;
+        if (sh1 > 0.f) {
+            uint2 hh_, ll_;
+            split2_f16(m, sh1, hh_, ll_);
+            y_h1[g] = hh_;
+        }
     }
 }
 
@@ -1565,6 +1573,7 @@ __global__ void momentum_kernel(float* __restrict__ w, const float* __restrict__
     }
 }
 
+bool pool_idx_on() { static const bool v = (dgp_tune("DGP_POOL_IDX", 1) != 0); return v; }
 int grid_for(long long n) {
     long long b = (n + 255) / 256;
     return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -1696,6 +1705,7 @@ struct TPlan {
     std::vector<size_t> sh_r1, sh_r2, sh_xo;
     size_t sh_g0 = 0, sh_g1 = 0, sh_dr1 = 0, sh_dr2 = 0, sh_dr1_b = 0, sh_dr2_b = 0;
     size_t feat32 = 0;           // fast pass: fp32 copy of the block4 features for the heads' backward
+    size_t sh_pool = 0;          // 16-bit tier: H1 copy of the pool output (input of the first unit)
     size_t total;
 };
 
@@ -1770,6 +1780,7 @@ TPlan make_tplan(const dgp_trainer* tr, int B) {
         p.sh_g0 = take(xmax); p.sh_g1 = take(xmax);
         p.sh_dr1 = take(r1max); p.sh_dr2 = take(r2max); p.sh_dr1_b = take(r1max); p.sh_dr2_b = take(r2max);
         p.feat32 = take((size_t)B * h * w * net->units.back().depth);
+        p.sh_pool = take((size_t)B * net->hp * net->wp * 64 / 2);
     }
     p.total = o;
     return p;
@@ -1971,7 +1982,7 @@ hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const floa
             if (e != hipSuccess) return e;
         }
     }
-    const bool big = (a.kchunks * 4 >= 128 && Cdy >= 128);
+    const bool big = h1 || (a.kchunks * 4 >= 128 && Cdy >= 128);       // (H1 operands: the LDS-DMA tile, partly filled for the 64-channel layers)
     const int BR = big ? 128 : 64;
     const int kt = (a.kchunks * 4 + BR - 1) / BR, nt = (Cdy + BR - 1) / BR;
     // workgroups per launch: ONE round of resident workgroups (2 per CU).  Every workgroup adds its whole 128 x 128 tile to dW with
@@ -2345,6 +2356,8 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     size_t ub = net->units.size();
     for (size_t ui = 1; ui < net->units.size(); ++ui)
         if (net->units[ui].depth_bn >= 128 && pl.sh_xo[ui - 1]) { ub = ui; break; }
+    // (16-bit tier: EVERY unit -- block1 included -- keeps H1 tensors; the first one reads the H1 copy of the pool output)
+    if (tr->tier == 1 && pl.sh_pool && pool_idx_on()) ub = 0;
     const bool fast = tr->fast_next && g_wgrad_dma && g_train_cells && g_ctx->rng.on && ub < net->units.size() && pl.feat32 &&
                       (tr->tier != 1 || tr->d_h1_table);
     const int FMT = tr->tier == 1 ? 2 : 1;       // cell format of this pass's H2 / H1 tensors
@@ -2405,9 +2418,18 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
             int pth = (net->hp - 1) * 2 + 3 - net->h1; if (pth < 0) pth = 0;
             int ptw = (net->wp - 1) * 2 + 3 - net->w1; if (ptw < 0) ptw = 0;
             const long long totp = (long long)nB * net->hp * net->wp * 16;
+            uint2* yh1 = nullptr;
+            const float* yprev = nullptr;
+            if (fast && FMT == 2 && ub == 0) {        // H1 copy of the pool output for the first unit (scale: conv1's range one step ago)
+                yprev = range_prev_of(range_of(F(pl.c1)));
+                if (!yprev) return fail(DGP_ERR_STATE, "16-bit tier: the root block's output has no predicted range");
+                yh1 = reinterpret_cast<uint2*>(reinterpret_cast<char*>(F(pl.sh_pool)) + (size_t)n0 * pxp * 64 * 2);
+                g_ctx->shadow_base[F(pl.pool)] = F(pl.sh_pool);
+                g_ctx->shadow_prev[F(pl.pool)] = yprev;
+            }
             hipLaunchKernelGGL(maxpool_fwd_idx_kernel, dim3(grid_for(totp)), dim3(256), 0, cs, at(pl.c1, px1 * 64), nB, net->h1, net->w1, 16,
                                net->hp, net->wp, pth / 2, ptw / 2, at(pl.pool, pxp * 64),
-                               reinterpret_cast<uchar4*>(ws + pl.pidx) + (size_t)n0 * pxp * 16);
+                               reinterpret_cast<uchar4*>(ws + pl.pidx) + (size_t)n0 * pxp * 16, yh1, yprev);
         } else {
             TRY_HIP(launch_maxpool(at(pl.c1, px1 * 64), nB, net->h1, net->w1, 64, at(pl.pool, pxp * 64), cs));
         }
@@ -2430,7 +2452,7 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
             return cells1 ? reinterpret_cast<float*>(reinterpret_cast<char*>(F(off)) + (size_t)n0 * per_frame * 2) : F(off) + (size_t)n0 * per_frame;
         };
         const bool h1u = h2u && FMT == 2;
-        const float* x = (h2u && ui == ub) ? atf(pl.sh_xo[ui - 1], pin * c.x_c, h1u) : atf(c.x_off, pin * c.x_c, h1u && ui > ub);
+        const float* x = (h2u && ui == ub) ? atf(ui == 0 ? pl.sh_pool : pl.sh_xo[ui - 1], pin * c.x_c, h1u) : atf(c.x_off, pin * c.x_c, h1u && ui > ub);
         const float* res = x;
         const void* res_key = F(c.x_off);
         int res_s = u.stride, res_H = hh, res_W = ww;
@@ -2527,7 +2549,7 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
         H2CheckList cl{};
         if (g_ctx->h2_slots.size() > sizeof(cl.idx) / sizeof(cl.idx[0])) return fail(DGP_ERR_STATE, "fast pass: too many H2 tensors");
         {   // ... and the fp16 copy of block1's output that the first H2 unit read
-            const float* pv = range_prev_of(range_of(F(pl.xo[ub - 1])));
+            const float* pv = range_prev_of(range_of(ub == 0 ? F(pl.pool) : F(pl.xo[ub - 1])));
             if (!pv) return fail(DGP_ERR_STATE, "fast pass: the first H2 unit's input has no range");
             g_ctx->h2_slots.push_back((int)((pv - g_ctx->rng.prev) / ABSMAX_SLOTS));
         }
@@ -2692,6 +2714,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
     int ub = nu;
     for (int ui = 1; ui < nu; ++ui)
         if (net->units[ui].depth_bn >= 128 && pl.sh_xo[ui - 1]) { ub = ui; break; }
+    if (h1p && pl.sh_pool && pool_idx_on()) ub = 0;      // (as dgp_train_forward decided)
     g_h2 = H2Launch();
     g_shadow_fmt = h1p ? 2 : 1;
     if (h1p) g_ctx->h2_slots.clear();                   // this pass's H1 gradient tensors, checked against their predicted scales at its end
@@ -2791,7 +2814,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
             float* const DR2H = F((ui & 1) ? pl.sh_dr2_b : pl.sh_dr2);
             float* const DR1H = F((ui & 1) ? pl.sh_dr1_b : pl.sh_dr1);
             float* const DXAH = F((ui & 1) ? pl.dxa_b : pl.dxa);
-            const float* xinH = ui > ub ? xin : F(pl.sh_xo[ui - 1]);       // (unit ub reads the H1 copy of block1's fp32 output)
+            const float* xinH = ui > ub ? xin : F(ui == 0 ? pl.sh_pool : pl.sh_xo[ui - 1]);       // (unit ub reads the H1 copy of its fp32 input)
             auto fmt = [&](bool gate, const void* res_key) {
                 g_h2 = H2Launch();
                 g_h2.in_fmt = 2; g_h2.out_fmt = 2; g_h2.mask_fmt = gate ? 2 : 0;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Training-step benchmark (BASELINE configs[3]): ResNet-50, 640x480, 4 keypoints, nt = 11 frames
-(1 labeled + 10 unlabeled), gm2=1 gm3=3, skeleton chain; fp32.  Prints one JSON line."""
+(1 labeled + 10 unlabeled), gm2=1 gm3=3, skeleton chain.  `bench_train.py [steps] [warm-up] [parity|f16]`: the parity tier (fp32-class
+arithmetic) or the 16-bit tier of the training step (Trainer(tier="f16"), include/dgp_hip.h dgp_trainer_set_tier).  One JSON line."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,6 +14,7 @@ from deepgraphpose_amd.synthetic import make_frames, make_weights
 H, W, NJ, NT = 480, 640, 4, 11
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 warm = int(sys.argv[2]) if len(sys.argv) > 2 else 2        # (the first pass has no predicted scales yet: its weight gradients run the fp32 tile)
+tier = sys.argv[3] if len(sys.argv) > 3 else "parity"
 rng = np.random.default_rng(0)
 wts = make_weights(50, NJ, True, seed=0, head_std=0.05)
 frames = torch.from_numpy(make_frames(NT, H, W, NJ, seed=0)).cuda()
@@ -24,7 +26,7 @@ lmap[5], lmask[5] = lt[0], lm[0]
 batch = dict(targets=jl, locref_map=lmap, locref_mask=lmask, visible_marker=vm, hidden_marker=hm, visible_marker_in_targets=vt)
 S0 = np.zeros((3, NJ)); [S0.__setitem__((i, i), 1) or S0.__setitem__((i, i + 1), -1) for i in range(3)]
 hy = DGPHyper(gm2=1, gm3=3)
-tr = Trainer(50, NJ, H, W, max_frames=NT)
+tr = Trainer(50, NJ, H, W, max_frames=NT, tier=tier)
 tr.load_weights(wts)
 ws, ws_max = np.full(3, 10.0), np.full(3, 200.0)
 for _ in range(warm):
@@ -40,10 +42,13 @@ fwd = 2.0 * conv_macs_per_frame(H, W, 50, NJ, True) * NT
 # gradient: -1 %), every product as 3 fp16 MFMAs -> nominal ceiling 2500 / 3 TFLOP/s of algorithmic FLOPs.  Per-kernel times of the
 # same command: profiles/r2_train_step_kernel_stats.txt (bash scripts/profile_train.sh).
 ach = 3 * fwd / dt / 1e12
+peak = 2500.0 if tier == "f16" else 833.3
 print(json.dumps({"metric": "train_step", "ms_per_step": round(dt * 1e3, 2), "frames_per_s": round(NT / dt, 1),
-                  "nt": NT, "dtype": "f32", "approx_tflops(3x fwd conv flops)": round(ach, 1),
+                  "nt": NT, "dtype": "f16" if tier == "f16" else "f32", "tier": tier, "approx_tflops(3x fwd conv flops)": round(ach, 1),
+                  "fast_passes": tr.fast_passes, "fast_redos": tr.fast_redos,
                   "roofline": {"bound": "mfma", "scope": "whole training step (forward + dgrad + wgrad convs, loss, clip, momentum)",
-                               "achieved": round(ach, 1), "peak": 833.3, "unit": "TFLOP/s", "frac": round(ach / 833.3, 4),
-                               "peak_basis": "dense f16 MFMA peak 2500 TFLOP/s / 3 partial products per fp32-class product",
+                               "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                               "peak_basis": ("dense f16 MFMA peak 2500 TFLOP/s (one MFMA per product in blocks 2-4; block1, root block and heads on the parity kernels)"
+                                              if tier == "f16" else "dense f16 MFMA peak 2500 TFLOP/s / 3 partial products per fp32-class product"),
                                "algorithmic_gflop_per_step": round(3 * fwd / 1e9, 1)},
                   "loss": {k: round(v, 5) for k, v in losses.items()}}))
