@@ -730,22 +730,35 @@ def main():
         env = dict(os.environ)
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "DGP_CONV_MODE"):
             env.pop(k, None)
-        try:
-            cp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_train.py"), str(args.train_steps), "8"], env=env, capture_output=True,
+        def _train_leg(tier):
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_train.py"), str(args.train_steps), "8", tier], env=env, capture_output=True,
                                 text=True, timeout=600)
             ln = [q for q in cp.stdout.splitlines() if q.startswith("{")]
-            if cp.returncode == 0 and ln:
-                t = json.loads(ln[-1])
-                out["train_step"] = {"ms_per_step": t["ms_per_step"], "steps": args.train_steps, "frames_per_step": t["nt"], "frames_per_s": t["frames_per_s"],
-                                     "frac": t["roofline"]["frac"], "achieved_tflops": t["roofline"]["achieved"], "peak_tflops": t["roofline"]["peak"],
-                                     "algorithmic_gflop_per_step": t["roofline"]["algorithmic_gflop_per_step"], "loss": t["loss"],
-                                     "workload": "BASELINE configs[3]: fit_dgp step, ResNet-50 640x480, 1 labeled + 10 unlabeled frames, 4 keypoints, "
-                                                 "fp32-class arithmetic (not bf16), 8 warm-up steps then `steps` timed ones",
-                                     "frac_basis": "3 x forward conv FLOPs (forward + data-gradient + weight-gradient convolutions) / step time / (2500 / 3 TFLOP/s)"}
-            else:
-                out["train_step"] = {"error": (cp.stderr or cp.stdout)[-300:]}
+            if cp.returncode != 0 or not ln:
+                return {"error": (cp.stderr or cp.stdout)[-300:]}
+            t = json.loads(ln[-1])
+            return {"ms_per_step": t["ms_per_step"], "steps": args.train_steps, "frames_per_step": t["nt"], "frames_per_s": t["frames_per_s"],
+                    "frac": t["roofline"]["frac"], "achieved_tflops": t["roofline"]["achieved"], "peak_tflops": t["roofline"]["peak"],
+                    "algorithmic_gflop_per_step": t["roofline"]["algorithmic_gflop_per_step"], "loss": t["loss"], "dtype": t["dtype"],
+                    "fast_passes": t.get("fast_passes"), "fast_redos": t.get("fast_redos")}
+        try:
+            out["train_step"] = _train_leg("parity")
+            if "error" not in out["train_step"]:
+                out["train_step"].update(
+                    workload="BASELINE configs[3]: fit_dgp step, ResNet-50 640x480, 1 labeled + 10 unlabeled frames, 4 keypoints, "
+                             "fp32-class arithmetic (the parity tier), 8 warm-up steps then `steps` timed ones",
+                    frac_basis="3 x forward conv FLOPs (forward + data-gradient + weight-gradient convolutions) / step time / (2500 / 3 TFLOP/s)")
+            # the precision configs[3] names: the 16-bit tier of the same step (H1 activations / gradient tensors, one MFMA per product, fp32
+            # master weights / momentum / accumulation); gradient agreement with the fp64 oracle: tests/test_train_gpu.py
+            out["train_step_f16"] = _train_leg("f16")
+            if "error" not in out["train_step_f16"]:
+                out["train_step_f16"].update(
+                    workload="the same step on the 16-bit tier (Trainer(tier='f16'), dgp_trainer_set_tier): 2-byte H1 activations and gradient tensors with "
+                             "predicted scales in every bottleneck unit, weight gradients by LDS-DMA on the tensors themselves; root block and heads on the "
+                             "parity kernels; the first step of a shape runs on the parity path",
+                    frac_basis="3 x forward conv FLOPs / step time / 2500 TFLOP/s (one MFMA per product)")
         except Exception as e:      # noqa: BLE001 -- the main line must still be printed
-            out["train_step"] = {"error": repr(e)[:300]}
+            out.setdefault("train_step", {"error": repr(e)[:300]})
     if world == 1 and not args.no_host_pipeline and not args.no_strict_f32:
         # the PCIe-inclusive rate of the boundary that takes HOST frames (A0 estimate_pose: decode thread -> pinned ring -> copy stream -> engines
         # -> one D2H), in a fresh child process; reported beside `value`, never as it

@@ -1990,7 +1990,9 @@ hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const floa
     // 640 -> 18.2, 512 -> 16.7, 384 -> 17.2, 256 -> 18.1 (DGP_WGRAD_WGS)
     static const int wgs_target = dgp_tune("DGP_WGRAD_WGS", 512);
     static const int wgs_small = dgp_tune("DGP_WGRAD_WGS_SMALL", 1024);      // 64 x 64 tiles: 1024 (16.7 vs 16.9 ms at 512)
-    int split = std::max(1, (big ? wgs_target : wgs_small) / (kt * nt));
+    // (wgrad_dma_h1: its loop is shorter, so the 64-KB-per-workgroup atomic epilogue weighs more: 512 -> 7.99, 384 -> 7.80, 256 -> 8.02 ms per step)
+    static const int wgs_h1 = dgp_tune("DGP_WGRAD_WGS_H1", 384);
+    int split = std::max(1, (h1 ? wgs_h1 : big ? wgs_target : wgs_small) / (kt * nt));
     int mpb = ((a.M + split - 1) / split + 63) / 64 * 64;      // (64: wgrad_dma walks 16-pixel steps unrolled by four)
     if (mpb < 256) mpb = 256;
     split = (a.M + mpb - 1) / mpb;

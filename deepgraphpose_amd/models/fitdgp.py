@@ -137,7 +137,10 @@ def _make_trainer(data_batcher, init_weights, max_frames, device=0):
     nj = data_batcher.nj
     if "pose/locref_pred/block4/weights" not in wts:
         raise KeyError("snapshot %s has no pose/locref_pred head (dgp_loss trains both heads)" % init_weights)
-    tr = Trainer(depth, nj, data_batcher.nx_in, data_batcher.ny_in, max_frames=max_frames, device=device)
+    # DGP_TRAIN_TIER=f16: the 16-bit tier of the training step (BASELINE configs[3]'s precision; include/dgp_hip.h, dgp_trainer_set_tier);
+    # default: the parity tier
+    tr = Trainer(depth, nj, data_batcher.nx_in, data_batcher.ny_in, max_frames=max_frames, device=device,
+                 tier=os.environ.get("DGP_TRAIN_TIER") or None)
     tr.load_weights(wts)
     return tr
 
