@@ -1562,8 +1562,13 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 
 __global__ void momentum_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v, long long n,
                                 float lr, float mom, float clip, const double* __restrict__ sumsq,
-                                float* __restrict__ gnorm_out) {
+                                float* __restrict__ gnorm_out, const int* __restrict__ skip) {
+    // skip: the range flag of a 16-bit / fast pass -- set: that pass's gradients are invalid, nothing is updated (the host repeats the step)
     const float gn = (float)sqrt(*sumsq);
+    if (skip && *skip) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && gnorm_out) *gnorm_out = gn;
+        return;
+    }
     const float scale = clip > 0.f ? clip / fmaxf(gn, clip) : 1.f;      // tf.clip_by_global_norm; clip <= 0: none
     if (blockIdx.x == 0 && threadIdx.x == 0 && gnorm_out) *gnorm_out = gn;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -3026,6 +3031,21 @@ int dgp_trainer_set_tier(dgp_trainer* tr, int32_t tier) {
 }
 int dgp_trainer_get_tier(const dgp_trainer* tr) { return tr ? tr->tier : 0; }
 
+/* One synchronisation for a whole step enqueued without read-backs (forward, loss, backward, dgp_sgd_momentum_clip with a NULL
+ * gnorm pointer, dgp_trainer_sync_weights): waits for the device, then *gnorm = the global gradient norm the optimiser saw and the
+ * fast / 16-bit pass status as dgp_trainer_fast_status reports it.  When *failed != 0 the optimiser skipped its update on the device
+ * (the flag is read by the momentum kernel), so the step can simply be run again on the parity path. */
+int dgp_trainer_step_status(dgp_trainer* tr, float* gnorm, int32_t* was_fast, int32_t* failed) {
+    if (!tr) return fail(DGP_ERR_INVALID, "dgp_trainer_step_status: null");
+    TRY_HIP(hipDeviceSynchronize());
+    int f = 0;
+    if (tr->fwd_fast) TRY_HIP(hipMemcpy(&f, tr->d_fast_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (gnorm) TRY_HIP(hipMemcpy(gnorm, tr->d_gnorm, sizeof(float), hipMemcpyDeviceToHost));
+    if (was_fast) *was_fast = tr->fwd_fast ? 1 : 0;
+    if (failed) *failed = f;
+    return DGP_OK;
+}
+
 int dgp_trainer_fast_status(dgp_trainer* tr, int32_t* was_fast, int32_t* failed) {
     if (!tr || !failed) return fail(DGP_ERR_INVALID, "dgp_trainer_fast_status: null");
     int f = 0;
@@ -3167,7 +3187,7 @@ int dgp_sgd_momentum_clip(dgp_trainer* tr, float lr, float momentum, float clip_
     TRY_HIP(hipMemsetAsync(tr->d_sumsq, 0, sizeof(double), s));
     hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(tr->n_train)), dim3(256), 0, s, tr->grads, tr->n_train, tr->d_sumsq);
     hipLaunchKernelGGL(momentum_kernel, dim3(grid_for(tr->n_train)), dim3(256), 0, s, tr->params, tr->grads, tr->mom, tr->n_train,
-                       lr, momentum, clip_norm, tr->d_sumsq, tr->d_gnorm);
+                       lr, momentum, clip_norm, tr->d_sumsq, tr->d_gnorm, tr->fwd_fast ? tr->d_fast_flag : nullptr);
     TRY_HIP(hipGetLastError());
     if (gnorm_host_or_null) {
         TRY_HIP(hipStreamSynchronize(s));

@@ -195,7 +195,7 @@ class Trainer:
                 return out
 
     def _forward_backward(self, frames: torch.Tensor, batch: dict, hyper: DGPHyper, S0, ws, ws_max, n_frames_total,
-                          n_visible_frames_total, labeled_only: bool = False):
+                          n_visible_frames_total, labeled_only: bool = False, readback: bool = True):
         from .loss import dgp_loss_launch, dgp_loss_prepare, losses_to_dict
         frames = frames.contiguous()
         nt = frames.shape[0]
@@ -205,18 +205,28 @@ class Trainer:
             batch = dict(batch, hidden_marker=np.empty(0, dtype=np.int32))
             S0 = np.zeros((0, nj))
             ws = ws_max = np.zeros(0)
-        # host-side order: the forward is enqueued first (it needs only the frames); while it runs the loss inputs are validated and
-        # uploaded (0.4 ms of host work); then the loss kernels and the whole backward pass are enqueued back to back, and the losses
-        # are read back (the one synchronisation) after everything is in flight
-        wsb, pred, loc = self._forward(frames)          # checks dtype / shape against the net's current input size
+        # host-side order.  Parity tier: the forward is enqueued first (it needs only the frames); while it runs (3.9 ms at 11 frames) the loss
+        # inputs are validated and uploaded (0.4 ms of host work).  16-bit tier: the forward takes 2 ms -- about what the host needs to
+        # enqueue it -- so the loss inputs go first (on their own stream, beside the tail of the previous step) and nothing stands
+        # between the forward's last launch and the loss kernels.  Then the loss kernels and the whole backward pass are enqueued back to
+        # back, and the losses are read back (the one synchronisation) after everything is in flight
         main = torch.cuda.current_stream(self.device)
         if getattr(self, "_upload_stream", None) is None:
             self._upload_stream = torch.cuda.Stream(device=self.device)
-        with torch.cuda.stream(self._upload_stream):    # the uploads run beside the forward instead of queueing behind it
-            li = dgp_loss_prepare(nt, self.net.out_h, self.net.out_w, nj, batch, hyper, S0, ws, ws_max, n_frames_total,
-                                  n_visible_frames_total, self.device)
-            uploaded = torch.cuda.Event()
-            uploaded.record(self._upload_stream)
+
+        def upload():
+            with torch.cuda.stream(self._upload_stream):    # the uploads run beside the forward instead of queueing behind it
+                li_ = dgp_loss_prepare(nt, self.net.out_h, self.net.out_w, nj, batch, hyper, S0, ws, ws_max, n_frames_total,
+                                       n_visible_frames_total, self.device)
+                ev = torch.cuda.Event()
+                ev.record(self._upload_stream)
+            return li_, ev
+        early = self.tier == "f16"
+        if early:
+            li, uploaded = upload()
+        wsb, pred, loc = self._forward(frames)          # checks dtype / shape against the net's current input size
+        if not early:
+            li, uploaded = upload()
         main.wait_event(uploaded)
         for name in li.__slots__:
             t = getattr(li, name, None)
@@ -225,7 +235,7 @@ class Trainer:
         losses, dpred, dloc, mu = dgp_loss_launch(li, pred, loc)
         _lib.check(self.lib.dgp_train_backward(self._t, nt, _ptr(wsb), wsb.numel(), _ptr(dpred), _ptr(dloc), st),
                    "dgp_train_backward")
-        return losses_to_dict(losses)
+        return losses_to_dict(losses) if readback else losses
 
     def grads_tensor(self) -> torch.Tensor:
         """The flat fp32 gradient buffer of every trainable tensor as a device tensor (no copy)."""
@@ -247,13 +257,35 @@ class Trainer:
 
     def step(self, frames, batch, hyper: DGPHyper, S0, ws, ws_max, n_frames_total, n_visible_frames_total,
              labeled_only: bool = False):
-        losses = self.forward_backward(frames, batch, hyper, S0, ws, ws_max, n_frames_total, n_visible_frames_total,
-                                       labeled_only)
+        """One optimisation step = the reference's sess.run([loss, train_op]) (DGP/models/fitdgp.py:818).  Single process: the whole step --
+        forward, loss, backward, clip + momentum, the re-packing of the weights -- is enqueued without a read-back and ONE synchronisation
+        at its end fetches losses, gradient norm and the pass status (dgp_trainer_step_status).  A 16-bit pass whose tensors left their
+        predicted ranges has skipped its update on the device and is repeated here on the parity path."""
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            self.allreduce_gradients()               # data-parallel: mean gradient over the ranks (RCCL)
-        losses["grad_norm"] = self.apply_gradients(hyper.lr, hyper.momentum, hyper.clip_norm)
-        return losses
+            losses = self.forward_backward(frames, batch, hyper, S0, ws, ws_max, n_frames_total, n_visible_frames_total, labeled_only)
+            self.allreduce_gradients()               # data-parallel: mean gradient over the ranks (RCCL) -- needs the gradients on every rank first
+            losses["grad_norm"] = self.apply_gradients(hyper.lr, hyper.momentum, hyper.clip_norm)
+            return losses
+        from .loss import losses_to_dict
+        nt = frames.shape[0]
+        while True:
+            fast = self._fast_begin(nt)
+            dev_losses = self._forward_backward(frames, batch, hyper, S0, ws, ws_max, n_frames_total, n_visible_frames_total, labeled_only,
+                                                readback=False)
+            _lib.check(self.lib.dgp_sgd_momentum_clip(self._t, hyper.lr, hyper.momentum, hyper.clip_norm, None, _stream(self.device)),
+                       "dgp_sgd_momentum_clip")
+            self.sync()                              # master -> panels / cells for the next forward (same weights again after a skipped update)
+            g, was, failed = C.c_float(), C.c_int32(), C.c_int32()
+            _lib.check(self.lib.dgp_trainer_step_status(self._t, C.byref(g), C.byref(was), C.byref(failed)), "dgp_trainer_step_status")
+            if fast and failed.value:                # the momentum kernel saw the flag and left parameters and momentum alone
+                self._fast_key = None
+                self.fast_redos += 1
+                continue
+            self._fast_key = (nt, self.net.in_h, self.net.in_w)
+            losses = losses_to_dict(dev_losses)
+            losses["grad_norm"] = g.value
+            return losses
 
 
 def _view(ptr: int, shape, device) -> torch.Tensor:

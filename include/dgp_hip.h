@@ -19,7 +19,12 @@
  *   dgp_net_load_weights                                            DGP/models/eval.py:147-214
  *
  * All functions return 0 on success or a negative dgp_status; dgp_last_error() gives a
- * thread-local message.  All launches are asynchronous on `stream`; no hidden syncs.
+ * thread-local message.  Launches are asynchronous on `stream`.  Functions that synchronise say so at their
+ * declaration; the ones on the hot path are: the FIRST dgp_forward / dgp_infer after dgp_net_load_weights,
+ * dgp_net_set_tier, dgp_net_recalibrate or a reported range overflow (the calibration pass reads every
+ * layer's tracked range: one stream sync + 1 KB copy per layer, see "H2" below), dgp_net_range_status,
+ * dgp_net_load_weights and the layer-level test entry points dgp_chain_h2 / dgp_unit_h2.  Every other
+ * forward / infer call enqueues and returns.
  * A dgp_net handle is bound to the device current at creation and is not thread-safe.
  */
 #ifndef DGP_HIP_H
@@ -212,6 +217,8 @@ int    dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, voi
                          float** scmap, float** locref, void* stream);
 int    dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t workspace_bytes, const float* dscmap,
                           const float* dlocref, void* stream);
+/* (gnorm_host_or_null != NULL synchronises the stream.  After a fast / 16-bit pass the update is conditional ON THE DEVICE: a pass
+ * that raised the range flag leaves parameters and momentum untouched -- see dgp_trainer_step_status.) */
 int    dgp_sgd_momentum_clip(dgp_trainer* tr, float lr, float momentum, float clip_norm, float* gnorm_host_or_null,
                              void* stream);
 /* Fast pass of the training step (no reference counterpart; the step's results are the same fp32-class numbers either way).
@@ -235,6 +242,12 @@ int    dgp_trainer_set_tier(dgp_trainer* tr, int32_t tier);
 int    dgp_trainer_get_tier(const dgp_trainer* tr);
 int    dgp_trainer_fast_mode(dgp_trainer* tr, int32_t enable);
 int    dgp_trainer_fast_status(dgp_trainer* tr, int32_t* was_fast, int32_t* failed);
+/* ONE synchronisation per training step: enqueue forward, loss, backward, dgp_sgd_momentum_clip(..., NULL gnorm, ...) and
+ * dgp_trainer_sync_weights without reading anything back, then call this -- it waits for the device and returns the gradient norm the
+ * optimiser saw and the pass status.  After a fast / 16-bit pass whose tensors left their predicted ranges (*failed != 0) the momentum
+ * kernel has SKIPPED its update on the device (it reads the flag), so the step can be run again on the parity path as if nothing had
+ * happened.  Replaces the two read-backs of sess.run([loss, train_op]) + a separate gnorm fetch (DGP/models/fitdgp.py:818). */
+int    dgp_trainer_step_status(dgp_trainer* tr, float* gnorm, int32_t* was_fast, int32_t* failed);
 
 /* ---- single-layer entry points (used by the parity tests and by fit_dgp later) ---- */
 

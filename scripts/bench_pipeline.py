@@ -15,7 +15,7 @@ os.makedirs(train)
 parts = ["a", "b", "c", "d"]
 yaml.safe_dump(dict(Task="Demo", date="Oct2", iteration=0, TrainingFraction=[0.95], bodyparts=parts, skeleton=[], project_path=proj), open(os.path.join(proj, "config.yaml"), "w"))
 yaml.safe_dump(dict(num_joints=4, all_joints_names=parts, net_type="resnet_50"), open(os.path.join(train, "pose_cfg.yaml"), "w"))
-snap = weights_io.save_weights(os.path.join(train, "snapshot-step2-final--0"), make_weights(50, 4, False, seed=0, head_std=0.05))[:-4]
+snap = weights_io.save_weights(os.path.join(train, "snapshot-step2-final--0"), make_weights(50, 4, False, seed=0, head_std=0.05))
 base = make_frames(16, 480, 640, 4, seed=0)
 frames = np.concatenate([base] * (T // 16))
 E.estimate_pose(os.path.join(proj, "config.yaml"), snap, frames[:64], os.path.join(tmp, "warm"), save_pose=False, batch_size=32)

@@ -24,7 +24,7 @@ for it in range(n):
     yaml.safe_dump(dict(Task="Demo", date="Oct2", iteration=0, TrainingFraction=[0.95], bodyparts=parts, skeleton=[], project_path=proj), open(os.path.join(proj, "config.yaml"), "w"))
     yaml.safe_dump(dict(num_joints=nj, all_joints_names=parts, net_type="resnet_%d" % depth), open(os.path.join(train, "pose_cfg.yaml"), "w"))
     wts = make_weights(depth, nj, False, seed=int(rng.integers(0, 1000)), head_std=0.05)
-    snap = weights_io.save_weights(os.path.join(train, "snapshot-step2-final--0"), wts)[:-4]
+    snap = weights_io.save_weights(os.path.join(train, "snapshot-step2-final--0"), wts)
     frames = make_frames(T, H, W, nj, seed=int(rng.integers(0, 1000)))
     os.environ["DGP_EVAL_CHUNK_BATCHES"] = str(chunk_batches)
     out = E.estimate_pose(os.path.join(proj, "config.yaml"), snap, frames, os.path.join(tmp, "pred"), save_pose=False, batch_size=bs)

@@ -66,14 +66,16 @@ def main():
         shutil.copyfile(f, os.path.join(dst, os.path.basename(f)))
     src = LabeledDirSource(dst)
     wts = make_weights(50, 5, True, seed=43, head_std=0.05)
-    xs, ys, ls, ix = [], [], [], []
+    xs, ys, ls, ix, xs64, ys64, ix64 = [], [], [], [], [], [], []
     for k, f in enumerate(src.files):
         r = O.infer(src._read(f)[None], wts, 50, 8.0, 1.0, 1)
         xs.append(r["x"][0]); ys.append(r["y"][0]); ls.append(r["likelihoods"][0]); ix.append(r["idx"][0])
+        r64 = O.infer(src._read(f)[None], wts, 50, 8.0, 1.0, 1, dtype=np.float64)        # the anchor: seeded weights on real frames give broad maps
+        xs64.append(r64["x"][0]); ys64.append(r64["y"][0]); ix64.append(r64["idx"][0])
         if k % 10 == 0:
             print("reaching frame", k, flush=True)
     out.update(reach_numbers=src.numbers.astype(np.int32), reach_x=np.stack(xs), reach_y=np.stack(ys), reach_lik=np.stack(ls),
-               reach_idx=np.stack(ix).astype(np.int32))
+               reach_idx=np.stack(ix).astype(np.int32), reach_x64=np.stack(xs64), reach_y64=np.stack(ys64), reach_idx64=np.stack(ix64).astype(np.int32))
     np.savez_compressed(os.path.join(HERE, "fullsize_vectors.npz"), **out)
     print("wrote", os.path.join(HERE, "fullsize_vectors.npz"))
 

@@ -127,10 +127,11 @@ def _tiny_project(tmp_path, nj=3, T=11, hw=(96, 128)):
                                                           bodyparts=parts, skeleton=[], project_path=str(proj))))
     (train / "pose_cfg.yaml").write_text(yaml.safe_dump(dict(num_joints=nj, all_joints_names=parts, net_type="resnet_50")))
     wts = make_weights(50, nj, False, seed=9, head_std=0.05)
-    snap = weights_io.save_weights(str(train / "snapshot-step2-final--0"), wts)
+    snap = weights_io.save_weights(str(train / "snapshot-step2-final--0"), wts)          # (a TF V2 bundle: returns the prefix)
+    assert snap.endswith("snapshot-step2-final--0")
     frames = make_frames(T, hw[0], hw[1], nj, seed=5)
     np.save(tmp_path / "clip.npy", frames)
-    return proj, snap[:-4], frames, wts
+    return proj, snap, frames, wts
 
 
 def test_estimate_pose_under_torchrun_env_shards_and_gathers(lib_built, tmp_path):
@@ -214,7 +215,8 @@ def test_bench_two_ranks_on_one_gpu(lib_built):
     only, n_gpus 2, every batch of both shards identical to the single-rank result."""
     procs = []
     for rank in (0, 1):
-        env = _child_env(RANK=rank, WORLD_SIZE=2, LOCAL_RANK=0, MASTER_ADDR="127.0.0.1", MASTER_PORT=29633, DGP_DIST_BACKEND="gloo")
+        env = _child_env(RANK=rank, WORLD_SIZE=2, LOCAL_RANK=0, MASTER_ADDR="127.0.0.1", MASTER_PORT=29633, DGP_DIST_BACKEND="gloo",
+                         DGP_BENCH_VISIBLE_GPUS=1)          # (two ranks on ONE device, knowingly)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
                                        "--batch", "8", "--no-cpu-baseline", "--sustain-seconds", "0.3", "--prewarm-seconds", "0.2"],
                                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))

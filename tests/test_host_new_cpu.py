@@ -185,7 +185,7 @@ def test_bench_spawner_stops_the_other_workers_when_one_dies():
     import sys
     import time
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DGP_BENCH_FAULT_RANK="1", DGP_DIST_BACKEND="gloo", PYTHONPATH=root)
+    env = dict(os.environ, DGP_BENCH_FAULT_RANK="1", DGP_DIST_BACKEND="gloo", PYTHONPATH=root, DGP_BENCH_VISIBLE_GPUS="2")      # (no device here: opt in)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     t0 = time.monotonic()
@@ -195,3 +195,18 @@ def test_bench_spawner_stops_the_other_workers_when_one_dies():
     assert "rank 1 exited with code 7" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert time.monotonic() - t0 < 200
+
+
+def test_bench_refuses_more_ranks_than_visible_devices():
+    """`python bench.py --gpus 2` where fewer than two devices are visible (none in this container) is an error unless DGP_BENCH_VISIBLE_GPUS says
+    the sharing is intended: an N-rank line measured on fewer devices is not an N-GPU line."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DGP_BENCH_VISIBLE_GPUS"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--no-cpu-baseline"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and "device(s) visible" in r.stderr

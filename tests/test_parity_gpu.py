@@ -441,7 +441,7 @@ def test_estimate_pose_end_to_end(eng, tmp_path):
     snap = weights_io.save_weights(str(train / "snapshot-step2-final--0"), wts)
     frames = make_frames(T, 96, 128, nj, seed=5)
     np.save(tmp_path / "clip.npy", frames)
-    out = E.estimate_pose(str(proj / "config.yaml"), snap[:-4], str(tmp_path / "clip.npy"), str(tmp_path / "pred"),
+    out = E.estimate_pose(str(proj / "config.yaml"), snap, str(tmp_path / "clip.npy"), str(tmp_path / "pred"),
                           shuffle=1, batch_size=2)
     ref = O.infer(frames, wts, 50, 8.0, 1.0, 1)
     assert np.abs(out["x"] - ref["x"]).max() < PX_TOL and np.abs(out["y"] - ref["y"]).max() < PX_TOL
@@ -449,19 +449,19 @@ def test_estimate_pose_end_to_end(eng, tmp_path):
     back = E.load_pose_from_dlc_to_dict(str(tmp_path / "pred" / "clip_labeled.csv"))
     np.testing.assert_allclose(back["x"], out["x"], rtol=1e-12)
     # second call: labels exist -> returns the csv path (eval.py:247-249)
-    again = E.estimate_pose(str(proj / "config.yaml"), snap[:-4], str(tmp_path / "clip.npy"), str(tmp_path / "pred"))
+    again = E.estimate_pose(str(proj / "config.yaml"), snap, str(tmp_path / "clip.npy"), str(tmp_path / "pred"))
     assert again.endswith("clip_labeled.csv")
     # sess.run drop-in
     cfg = E.yaml.safe_load(open(proj / "config.yaml"))
     from deepgraphpose_amd.config import get_train_config
     dlc_cfg = get_train_config(dict(cfg, video_path=None), shuffle=1)
-    sess, mu_n, softmax, scmap, locref, inputs = E.setup_dgp_eval_graph(dlc_cfg, snap[:-4])
+    sess, mu_n, softmax, scmap, locref, inputs = E.setup_dgp_eval_graph(dlc_cfg, snap)
     mu_b, sc_b = sess.run([mu_n, scmap], feed_dict={inputs: frames[:1].astype(np.float32)})
     assert mu_b.shape == (1, nj, 2) and sc_b.shape == (1, 12, 16, nj)
     assert np.abs(mu_b[0] - ref["mu"][0]).max() * STRIDE < PX_TOL
     dlc_cfg.net_type = "resnet_101"
     with pytest.raises(KeyError):
-        E.setup_dgp_eval_graph(dlc_cfg, snap[:-4])
+        E.setup_dgp_eval_graph(dlc_cfg, snap)
 
 
 # fp32-MFMA tiles 0-6; bf16 6-term split 7 / 9 / 10 / 12; bf16 3-term split 8 / 11 (16-bit products: looser bound);
