@@ -112,7 +112,8 @@ hipError_t launch_h2_range_check(const float* amax_slots, const int* exps, int n
 // root block fused: uint8 frames -> conv1 (7x7/2) + BN + ReLU -> 3x3/2 max-pool -> H2 cells [B, HP, WP, 64] with scale out_scale
 hipError_t launch_stem_pool_fused(const unsigned char* frames, int B, int H, int W, const void* wcells, const float* w_absmax,
                                   const float* bn_scale, const float* bn_bias, float m0, float m1, float m2, float out_scale,
-                                  float* out, float* out_absmax, hipStream_t s, int out_h1 = 0);
+                                  float* out, float* out_absmax, hipStream_t s, int out_h1 = 0, const float* out_prev = nullptr,
+                                  unsigned char* idx = nullptr);
 hipError_t launch_preprocess(const uint8_t* f, long long npix, float m0, float m1, float m2,
                              float* out, hipStream_t s);
 hipError_t launch_motion_energy(const uint8_t* frames, long long frame_bytes, int n_frames, const uint8_t* prev_frame,

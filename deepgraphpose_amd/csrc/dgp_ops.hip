@@ -458,6 +458,9 @@ struct StemPoolArgs {
     float* out;                       // H2 [B, HP, WP, 64] (out_h1: H1 cells, half the bytes)
     float* out_absmax;
     int out_h1;
+    const float* out_prev;            // training step: the output's scale is predicted on the device (shadow_scale_for) instead of out_scale
+    unsigned char* idx;               // training step: [B, HP, WP, 64] position (a * 3 + b) of each window's first maximum (maxpool_fwd_idx_kernel's
+                                      // record; windows whose maximum is 0 record position 0 -- their gradient is gated to zero anyway)
     int B, H, W, H1, W1, HP, WP, pbh, pbw, tiles_h, tiles_w, ntiles;
 };
 
@@ -477,6 +480,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
     const int l15 = lane & 15, g = lane >> 4;
     for (int i = t; i < WCELLS; i += 512) sW[i] = p.wcells[i];
     const float post = 1.f / pow2_scale_for(p.w_absmax, lane);
+    const float oscale = p.out_prev ? shadow_scale_for(p.out_prev, lane) : p.out_scale;
     const int nrb = wave < NRB - 16 ? 3 : 2;                       // row blocks wave, wave + 8, wave + 16 (23 blocks: 3 each, wave 7: 2)
     float sc4[4][1], bi4[4][1];
 #pragma unroll
@@ -586,8 +590,22 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
             const int pp = q >> 3, cg = q & 7;
             const int ph = pp / PW, pw = pp - ph * PW;
             float v[8];
+            unsigned kk[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = 0.f;
+            for (int k = 0; k < 8; ++k) { v[k] = 0.f; kk[k] = 0u; }
+            if (p.idx) {                      // (strictly greater: the first maximum stays, as in maxpool_fwd_idx_kernel; same maxima as below)
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        const float* src = sC + ((2 * ph + a) * SC + 2 * pw + b) * LDC + 8 * cg;
+                        const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+                        const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            if (x[k] > v[k]) { v[k] = x[k]; kk[k] = (unsigned)(a * 3 + b); }
+                    }
+            } else {
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -598,10 +616,14 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
                     v[0] = fmaxf(v[0], x0.x); v[1] = fmaxf(v[1], x0.y); v[2] = fmaxf(v[2], x0.z); v[3] = fmaxf(v[3], x0.w);
                     v[4] = fmaxf(v[4], x1.x); v[5] = fmaxf(v[5], x1.y); v[6] = fmaxf(v[6], x1.z); v[7] = fmaxf(v[7], x1.w);
                 }
+            }
             if (ph0 + ph < p.HP && pw0 + pw < p.WP) {
                 uint4 hi, lo;
-                h2_pack8(v, p.out_scale, hi, lo);
+                h2_pack8(v, oscale, hi, lo);
                 const size_t cell = (((size_t)n * p.HP + ph0 + ph) * p.WP + pw0 + pw) * 8 + cg;       // 8-channel group of the pool output
+                if (p.idx)
+                    *reinterpret_cast<uint2*>(p.idx + cell * 8) = make_uint2(kk[0] | (kk[1] << 8) | (kk[2] << 16) | (kk[3] << 24),
+                                                                             kk[4] | (kk[5] << 8) | (kk[6] << 16) | (kk[7] << 24));
                 uint4* dst = reinterpret_cast<uint4*>(p.out) + (p.out_h1 ? cell : 2 * cell);
                 if (!(DGP_SX & 32)) { dst[0] = hi; if (!p.out_h1) dst[1] = lo; } else amax = fmaxf(amax, __builtin_bit_cast(float, hi.x ^ lo.y));
 #pragma unroll
@@ -615,9 +637,9 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
 
 hipError_t launch_stem_pool_fused(const unsigned char* frames, int B, int H, int W, const void* wcells, const float* w_absmax,
                                   const float* bn_scale, const float* bn_bias, float m0, float m1, float m2, float out_scale,
-                                  float* out, float* out_absmax, hipStream_t s, int out_h1) {
+                                  float* out, float* out_absmax, hipStream_t s, int out_h1, const float* out_prev, unsigned char* idx) {
     StemPoolArgs a{};
-    a.out_h1 = out_h1;
+    a.out_h1 = out_h1; a.out_prev = out_prev; a.idx = idx;
     a.frames = frames; a.wcells = reinterpret_cast<const uint4*>(wcells); a.w_absmax = w_absmax; a.bn_scale = bn_scale; a.bn_bias = bn_bias;
     a.mean0 = roundf(m0); a.mean1 = roundf(m1); a.mean2 = roundf(m2); a.out_scale = out_scale; a.out = out; a.out_absmax = out_absmax;
     a.B = B; a.H = H; a.W = W; a.H1 = (H + 1) / 2; a.W1 = (W + 1) / 2;

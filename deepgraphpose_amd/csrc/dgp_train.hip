@@ -1472,7 +1472,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const float* __res
         r /= W;
         const int hi = (int)(r % H);
         const int n = (int)(r / H);
-        const float4 v = *reinterpret_cast<const float4*>(c1 + g * 4);
+        // c1 == nullptr (16-bit tier, fused root block): no conv1 map; dpool is already zero wherever the window's maximum is not positive
+        const float4 v = c1 ? *reinterpret_cast<const float4*>(c1 + g * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (v.x > 0.f || v.y > 0.f || v.z > 0.f || v.w > 0.f) {
             for (int ho = max(0, (hi + pt - 2 + 1) / 2); ho <= min(Ho - 1, (hi + pt) / 2); ++ho)
@@ -1543,6 +1544,23 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
         }
         *reinterpret_cast<float4*>(dc1 + g * 4) = acc;
     }
+}
+
+// Stem panel [49 taps][CoutP][4] -> the row panel of the fused root kernel [7 kernel rows x 8 pixels][CoutP][4]: pixel 7 is zero, and channel
+// slot 3 carries sum_c (round(mean_c) - mean_c) w_c, the weight of the kernel's constant fourth input channel (dgp_net_load_weights builds
+// the same panel on the host, dgp_net.hip).
+__global__ __launch_bounds__(256) void stem_rows_kernel(const float4* __restrict__ panel, int coutP, float d0, float d1, float d2,
+                                                        float4* __restrict__ rows) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 56 * coutP) return;
+    const int r = i / coutP, co = i - r * coutP;
+    const int kh = r >> 3, kw = r & 7;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kw < 7) {
+        v = panel[(size_t)(kh * 7 + kw) * coutP + co];
+        v.w = d0 * v.x + d1 * v.y + d2 * v.z;
+    }
+    rows[i] = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1676,6 +1694,9 @@ struct dgp_trainer {
     int tier = 0;
     int fwd_fmt = 0;                  // cell format of the last fast forward pass: 1 H2 (tuning builds' fast pass), 2 H1 (tier 1)
     void* d_h1_table = nullptr;       // PackH3Desc of every panel whose H1 cells are rebuilt per sync (tier 1)
+    float* d_stem_rows = nullptr;     // tier 1: the stem's row panel [7 x 8 pixels][64][4] and its cells for stem_pool_fused_kernel, rebuilt per sync
+    void* d_stem_cells = nullptr;
+    bool fwd_stem_fused = false;      // the last forward pass ran the fused root block (no conv1 map, no fp32 pool output)
     int n_h1 = 0;
     float* d_wrng = nullptr;          // weight-panel range slots: [2 * n_layers] (forward panels, data-gradient panels), per sync
     void* d_pack_table = nullptr;     // PackDesc of every non-head layer (pack_all_kernel), built at the first sync
@@ -1685,7 +1706,7 @@ struct dgp_trainer {
     void* d_fin_table = nullptr;      // FinDesc of every non-head layer (deferred weight-gradient finalisation), per batch size
     int n_fin = 0, fin_B = -1, fin_h = -1, fin_w = -1;
     ~dgp_trainer() {
-        for (void* q : {(void*)d_rng_pool, (void*)d_rng_prev, (void*)d_fast_flag, (void*)d_wrng, d_pack_table, d_fin_table, d_h3_table, d_h1_table}) if (q) (void)hipFree(q);
+        for (void* q : {(void*)d_rng_pool, (void*)d_rng_prev, (void*)d_fast_flag, (void*)d_wrng, d_pack_table, d_fin_table, d_h3_table, d_h1_table, (void*)d_stem_rows, d_stem_cells}) if (q) (void)hipFree(q);
         for (auto& t : tl) { if (t.d_wT) (void)hipFree(t.d_wT); if (t.d_wTh3) (void)hipFree(t.d_wTh3); if (t.d_wTh1) (void)hipFree(t.d_wTh1); }
         for (void* p : {(void*)params, (void*)grads, (void*)mom, (void*)stats, (void*)d_sumsq, (void*)d_gnorm})
             if (p) (void)hipFree(p);
@@ -2329,6 +2350,19 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
                     TRY_HIP(hipMemcpy(tr->d_h1_table, tab.data(), tab.size() * sizeof(PackH3Desc), hipMemcpyHostToDevice));
                 }
                 TRY_HIP(launch_pack_h1_all(reinterpret_cast<const PackH3Desc*>(tr->d_h1_table), tr->n_h1, s));
+                // the fused root block's weight cells (stem_pool_fused_kernel): row panel of conv1 from the panel pack_all_kernel just wrote
+                static const bool stem_fused_env = (dgp_env("DGP_TRAIN_STEM_FUSED", 1) != 0);      // A/B switch
+                ConvLayer& lc = net->layers[net->conv1];
+                if (stem_fused_env && lc.CoutP == 64 && lc.Cin == 4 && lc.KH == 7 && lc.KW == 7) {
+                    const size_t nrow = (size_t)56 * lc.CoutP * 4;
+                    if (!tr->d_stem_rows) TRY_HIP(hipMalloc(&tr->d_stem_rows, nrow * sizeof(float)));
+                    if (!tr->d_stem_cells) TRY_HIP(hipMalloc(&tr->d_stem_cells, nrow * sizeof(float)));
+                    const float* mp = net->desc.mean_pixel;
+                    hipLaunchKernelGGL(stem_rows_kernel, dim3((56 * lc.CoutP + 255) / 256), dim3(256), 0, s, reinterpret_cast<const float4*>(lc.d_w),
+                                       lc.CoutP, roundf(mp[0]) - mp[0], roundf(mp[1]) - mp[1], roundf(mp[2]) - mp[2],
+                                       reinterpret_cast<float4*>(tr->d_stem_rows));
+                    TRY_HIP(launch_pack_h3(tr->d_stem_rows, 7, lc.CoutP, tr->d_wrng + (size_t)net->conv1 * ABSMAX_SLOTS, tr->d_stem_cells, s));
+                }
             }
         }
     }
@@ -2396,6 +2430,8 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     const int n1 = two ? (B + 1) / 2 : B;
     const ConvLayer& c1 = net->layers[net->conv1];
     static const bool pool_idx = (dgp_tune("DGP_POOL_IDX", 1) != 0);       // A/B switch (0: re-scan in backward)
+    const bool stem_fused = fast && FMT == 2 && ub == 0 && pool_idx && tr->d_stem_cells && tr->d_wrng && c1.d_scale && c1.d_bias;
+    tr->fwd_stem_fused = stem_fused;
     if (two) {
         hipEvent_t ready = g_ctx->take_event();
         if (!ready) return fail(DGP_ERR_HIP, "forward chains: hipEventCreate failed");
@@ -2419,6 +2455,24 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
         const size_t px_in = (size_t)d.in_h * d.in_w, px1 = (size_t)net->h1 * net->w1, pxp = (size_t)net->hp * net->wp;
         TRY_HIP(launch_preprocess(frames + (size_t)n0 * px_in * 3, (long long)nB * d.in_h * d.in_w, d.mean_pixel[0], d.mean_pixel[1],
                                   d.mean_pixel[2], at(pl.p0, px_in * 4), cs));
+        if (stem_fused) {
+            // 16-bit tier: the root block as the inference engine's ONE kernel (uint8 frame -> conv1 + BN + ReLU -> max-pool -> H1 cells of the
+            // pool output, scale predicted from conv1's range one step ago) that also records each window's first maximum.  No conv1 map, no
+            // fp32 pool output: the first unit reads the H1 tensor, the pool's backward needs only the record.  (The centred frame above
+            // stays: the stem's weight gradient reads it.)  The launch takes conv1's range slot, in conv1's place in the order of slots.
+            float* slot = range_take();
+            const float* yprev = range_prev_of(slot);
+            if (!slot || !yprev) return fail(DGP_ERR_STATE, "16-bit tier: the root block's output has no predicted range");
+            range_set(F(pl.c1), slot);
+            range_set(F(pl.pool), slot);
+            g_ctx->shadow_base[F(pl.pool)] = F(pl.sh_pool);
+            g_ctx->shadow_prev[F(pl.pool)] = yprev;
+            TRY_HIP(launch_stem_pool_fused(frames + (size_t)n0 * px_in * 3, nB, d.in_h, d.in_w, tr->d_stem_cells,
+                                           tr->d_wrng + (size_t)net->conv1 * ABSMAX_SLOTS, c1.d_scale, c1.d_bias, d.mean_pixel[0], d.mean_pixel[1],
+                                           d.mean_pixel[2], 0.f, reinterpret_cast<float*>(reinterpret_cast<char*>(F(pl.sh_pool)) + (size_t)n0 * pxp * 64 * 2),
+                                           slot, cs, 1, yprev, reinterpret_cast<unsigned char*>(ws + pl.pidx) + (size_t)n0 * pxp * 64));
+            return DGP_OK;
+        }
         TRY_HIP(conv_launch(c1, c1.d_w, c1.nk, c1.CoutP, at(pl.p0, px_in * 4), nB, d.in_h, d.in_w, 4, 3, 3, net->h1, net->w1, 64, 2, 0,
                             c1.d_scale, c1.d_bias, nullptr, 0, 0, 0, nullptr, true, 0, 0, at(pl.c1, px1 * 64), cs, F(pl.p0), F(pl.c1)));
         if (pool_idx) {
@@ -2953,8 +3007,8 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         int ptw = (net->wp - 1) * 2 + 3 - net->w1; if (ptw < 0) ptw = 0;
         const long long tot = (long long)B * net->h1 * net->w1 * 16;
         static const bool pool_idx = (dgp_tune("DGP_POOL_IDX", 1) != 0);
-        if (pool_idx)
-            hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(grid_for(tot)), dim3(256), 0, s, F(pl.c1), G[cur],
+        if (pool_idx)          // (fused root block in the forward pass: no conv1 map -- unit 0's data gradient is already gated by pool > 0)
+            hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(grid_for(tot)), dim3(256), 0, s, (h1p && tr->fwd_stem_fused) ? (const float*)nullptr : F(pl.c1), G[cur],
                                reinterpret_cast<const uchar4*>(ws + pl.pidx), B, net->h1, net->w1, 64, net->hp, net->wp, pth / 2, ptw / 2,
                                F(pl.dc1));
         else

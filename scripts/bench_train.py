@@ -15,6 +15,7 @@ H, W, NJ, NT = 480, 640, 4, 11
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 warm = int(sys.argv[2]) if len(sys.argv) > 2 else 2        # (the first pass has no predicted scales yet: its weight gradients run the fp32 tile)
 tier = sys.argv[3] if len(sys.argv) > 3 else "parity"
+repeats = int(sys.argv[4]) if len(sys.argv) > 4 else 1     # timed blocks of `steps`; ms_per_step is the FIRST block (the contract), the others are listed
 rng = np.random.default_rng(0)
 wts = make_weights(50, NJ, True, seed=0, head_std=0.05)
 frames = torch.from_numpy(make_frames(NT, H, W, NJ, seed=0)).cuda()
@@ -31,12 +32,15 @@ tr.load_weights(wts)
 ws, ws_max = np.full(3, 10.0), np.full(3, 200.0)
 for _ in range(warm):
     losses = tr.step(frames, batch, hy, S0, ws, ws_max, 2000.0, 50.0)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(steps):
-    losses = tr.step(frames, batch, hy, S0, ws, ws_max, 2000.0, 50.0)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / steps
+blocks = []
+for _ in range(repeats):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses = tr.step(frames, batch, hy, S0, ws, ws_max, 2000.0, 50.0)
+    torch.cuda.synchronize()
+    blocks.append((time.perf_counter() - t0) / steps)
+dt = blocks[0]
 fwd = 2.0 * conv_macs_per_frame(H, W, 50, NJ, True) * NT
 # step-level roofline: forward + data-gradient + weight-gradient convolutions = 3 x the forward conv FLOPs (the stem has no data
 # gradient: -1 %), every product as 3 fp16 MFMAs -> nominal ceiling 2500 / 3 TFLOP/s of algorithmic FLOPs.  Per-kernel times of the
@@ -44,7 +48,7 @@ fwd = 2.0 * conv_macs_per_frame(H, W, 50, NJ, True) * NT
 ach = 3 * fwd / dt / 1e12
 peak = 2500.0 if tier == "f16" else 833.3
 print(json.dumps({"metric": "train_step", "ms_per_step": round(dt * 1e3, 2), "frames_per_s": round(NT / dt, 1),
-                  "nt": NT, "dtype": "f16" if tier == "f16" else "f32", "tier": tier, "approx_tflops(3x fwd conv flops)": round(ach, 1),
+                  "blocks_ms": [round(b * 1e3, 2) for b in blocks], "nt": NT, "dtype": "f16" if tier == "f16" else "f32", "tier": tier, "approx_tflops(3x fwd conv flops)": round(ach, 1),
                   "fast_passes": tr.fast_passes, "fast_redos": tr.fast_redos,
                   "roofline": {"bound": "mfma", "scope": "whole training step (forward + dgrad + wgrad convs, loss, clip, momentum)",
                                "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
