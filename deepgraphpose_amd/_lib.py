@@ -97,7 +97,8 @@ SYMBOLS = {
     "dgp_conv2d_wgrad_shadow": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgp_trainer_set_tier": (C.c_int, [_vp, C.c_int32]),
     "dgp_trainer_get_tier": (C.c_int, [_vp]),
-    "dgp_trainer_step_status": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "dgp_trainer_step_status": (C.c_int, [_vp, _vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32),
+                                               C.POINTER(C.c_int32), _vp]),
     "dgp_trainer_fast_mode": (C.c_int, [_vp, C.c_int32]),
     "dgp_trainer_fast_status": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "dgp_conv2d_dgrad_scratch_bytes": (_sz, [C.POINTER(DgpConvDesc)]),

@@ -1336,7 +1336,9 @@ struct FinDesc {
 __global__ __launch_bounds__(256) void scale_dw_dot_all_kernel(const FinDesc* __restrict__ table, const char* __restrict__ ws,
                                                                const float* __restrict__ params, float* __restrict__ grads,
                                                                int rows_per_block) {
-    __shared__ float part[4][64];
+    // a thread owns 4 adjacent output channels (16-byte accesses; every layer but the heads has Cout % 4 == 0 and 16-byte aligned
+    // offsets) of every 16th row of the block's row range
+    __shared__ float4 part[16][16];
     const FinDesc d = table[blockIdx.z];
     const int krows = d.taps * d.cin_real;
     if ((int)blockIdx.x * 64 >= d.cout || (int)blockIdx.y * rows_per_block >= krows) return;
@@ -1344,23 +1346,30 @@ __global__ __launch_bounds__(256) void scale_dw_dot_all_kernel(const FinDesc* __
     float* dot = reinterpret_cast<float*>(const_cast<char*>(ws) + d.cs_off) + d.cout;
     const float* w = params + d.w_off;
     float* dW = grads + d.w_off;
-    const int co = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int c4 = threadIdx.x & 15, co = blockIdx.x * 64 + 4 * c4, rl = threadIdx.x >> 4;
     const int k0 = blockIdx.y * rows_per_block, k1 = min(krows, k0 + rows_per_block);
-    float acc = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (co < d.cout) {
-        const float sc = d.d_scale[co];
-        for (int k = k0 + rl; k < k1; k += 4) {
+        const float4 sc = *reinterpret_cast<const float4*>(d.d_scale + co);
+#pragma unroll 4
+        for (int k = k0 + rl; k < k1; k += 16) {
             const int tp = k / d.cin_real, ci = k - tp * d.cin_real;
-            const float g = dwraw[((long long)tp * d.cin + ci) * d.cout + co];
+            const float4 g = *reinterpret_cast<const float4*>(dwraw + ((long long)tp * d.cin + ci) * d.cout + co);
             const long long o = (long long)k * d.cout + co;
-            acc += w[o] * g;
-            dW[o] = sc * g;
+            const float4 wv = *reinterpret_cast<const float4*>(w + o);
+            acc.x += wv.x * g.x; acc.y += wv.y * g.y; acc.z += wv.z * g.z; acc.w += wv.w * g.w;
+            *reinterpret_cast<float4*>(dW + o) = make_float4(sc.x * g.x, sc.y * g.y, sc.z * g.z, sc.w * g.w);
         }
     }
-    part[rl][threadIdx.x & 63] = acc;
+    part[rl][c4] = acc;
     __syncthreads();
-    if (rl == 0 && co < d.cout)
-        atomicAdd(dot + co, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < (unsigned)d.cout) {
+        const int q = threadIdx.x >> 2, e = threadIdx.x & 3;
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += reinterpret_cast<const float*>(&part[r][q])[e];
+        atomicAdd(dot + blockIdx.x * 64 + threadIdx.x, sum);
+    }
 }
 __global__ void bn_param_grads_all_kernel(const FinDesc* __restrict__ table, const char* __restrict__ ws, const float* __restrict__ stats,
                                           float eps, float* __restrict__ grads) {
@@ -1569,7 +1578,13 @@ __global__ __launch_bounds__(256) void stem_rows_kernel(const float4* __restrict
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, double* __restrict__ out) {
     __shared__ double part[4];
     double s = 0.0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    const long long n4 = n >> 2;                 // 16-byte loads (hipMalloc'ed buffer), the tail one by one
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = g4[i];
+        s += (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
+    }
+    for (long long i = 4 * n4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         s += (double)g[i] * (double)g[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -1579,10 +1594,12 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 }
 
 __global__ void momentum_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v, long long n,
-                                float lr, float mom, float clip, const double* __restrict__ sumsq,
+                                float lr, float mom, float clip, const double* __restrict__ sumsq, double* __restrict__ sumsq_next,
                                 float* __restrict__ gnorm_out, const int* __restrict__ skip) {
     // skip: the range flag of a 16-bit / fast pass -- set: that pass's gradients are invalid, nothing is updated (the host repeats the step)
+    // sumsq_next: the accumulator the NEXT step's sumsq_kernel adds into (nobody reads it now): zeroed here instead of by a fill launch
     const float gn = (float)sqrt(*sumsq);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sumsq_next = 0.0;
     if (skip && *skip) {
         if (blockIdx.x == 0 && threadIdx.x == 0 && gnorm_out) *gnorm_out = gn;
         return;
@@ -1594,6 +1611,15 @@ __global__ void momentum_kernel(float* __restrict__ w, const float* __restrict__
         v[i] = a;
         w[i] -= lr * a;                                       // var -= lr * accum
     }
+}
+
+__global__ void step_status_kernel(const float* __restrict__ losses, int n_losses, const float* __restrict__ gnorm, const int* __restrict__ flag,
+                                   float* __restrict__ host) {
+    const int t = threadIdx.x;
+    if (t < n_losses) host[t] = losses[t];
+    if (t == 8) host[8] = *gnorm;
+    if (t == 9) host[9] = (flag && *flag) ? 1.f : 0.f;
+    __threadfence_system();
 }
 
 bool pool_idx_on() { static const bool v = (dgp_tune("DGP_POOL_IDX", 1) != 0); return v; }
@@ -1678,8 +1704,10 @@ struct dgp_trainer {
     std::vector<int> is_stat;
     long long n_train = 0, n_stat = 0;
     float *params = nullptr, *grads = nullptr, *mom = nullptr, *stats = nullptr;
-    double* d_sumsq = nullptr;
+    double* d_sumsq = nullptr;        // TWO accumulators used in turn: the optimiser's kernel zeroes the other one for the next step (no fill launch)
+    int sumsq_k = 0;
     float* d_gnorm = nullptr;
+    float* h_status = nullptr;        // pinned, device-visible: dgp_trainer_step_status' kernel writes [8 losses | gnorm | flag] straight into it
     float* d_rng_pool = nullptr;      // activation / gradient range slots (RANGE_POOL arrays), zeroed per pass
     float* d_rng_prev = nullptr;      // ... as the previous step left them (copied before the zeroing)
     int* d_fast_flag = nullptr;       // != 0: an H2 tensor of the last fast pass left its predicted range (the step must be repeated)
@@ -1710,6 +1738,7 @@ struct dgp_trainer {
         for (auto& t : tl) { if (t.d_wT) (void)hipFree(t.d_wT); if (t.d_wTh3) (void)hipFree(t.d_wTh3); if (t.d_wTh1) (void)hipFree(t.d_wTh1); }
         for (void* p : {(void*)params, (void*)grads, (void*)mom, (void*)stats, (void*)d_sumsq, (void*)d_gnorm})
             if (p) (void)hipFree(p);
+        if (h_status) (void)hipHostFree(h_status);
     }
 };
 
@@ -2156,7 +2185,9 @@ int dgp_trainer_create(dgp_net* net, dgp_trainer** out) {
     const size_t nb = (size_t)tr->n_train * sizeof(float);
     if (hipMalloc(&tr->params, nb) != hipSuccess || hipMalloc(&tr->grads, nb) != hipSuccess ||
         hipMalloc(&tr->mom, nb) != hipSuccess || hipMalloc(&tr->stats, (size_t)tr->n_stat * sizeof(float)) != hipSuccess ||
-        hipMalloc(&tr->d_sumsq, sizeof(double)) != hipSuccess || hipMalloc(&tr->d_gnorm, sizeof(float)) != hipSuccess) {
+        hipMalloc(&tr->d_sumsq, 2 * sizeof(double)) != hipSuccess || hipMalloc(&tr->d_gnorm, sizeof(float)) != hipSuccess ||
+        hipMemset(tr->d_sumsq, 0, 2 * sizeof(double)) != hipSuccess || hipMemset(tr->d_gnorm, 0, sizeof(float)) != hipSuccess ||
+        hipHostMalloc(&tr->h_status, 16 * sizeof(float), hipHostMallocDefault) != hipSuccess) {
         delete tr;
         return fail(DGP_ERR_HIP, "dgp_trainer_create: hipMalloc failed");
     }
@@ -3051,7 +3082,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
             max_cout = std::max(max_cout, net->layers[li].Cout);
             max_krows = std::max(max_krows, net->layers[li].KH * net->layers[li].KW * tr->tl[li].cin_real);
         }
-        const int rpb = 64;
+        const int rpb = 128;
         const FinDesc* tab = reinterpret_cast<const FinDesc*>(tr->d_fin_table);
         hipLaunchKernelGGL(scale_dw_dot_all_kernel, dim3((max_cout + 63) / 64, (max_krows + rpb - 1) / rpb, (unsigned)tr->n_fin), dim3(256),
                            0, s, tab, (const char*)ws, tr->params, tr->grads, rpb);
@@ -3089,14 +3120,21 @@ int dgp_trainer_get_tier(const dgp_trainer* tr) { return tr ? tr->tier : 0; }
  * gnorm pointer, dgp_trainer_sync_weights): waits for the device, then *gnorm = the global gradient norm the optimiser saw and the
  * fast / 16-bit pass status as dgp_trainer_fast_status reports it.  When *failed != 0 the optimiser skipped its update on the device
  * (the flag is read by the momentum kernel), so the step can simply be run again on the parity path. */
-int dgp_trainer_step_status(dgp_trainer* tr, float* gnorm, int32_t* was_fast, int32_t* failed) {
+int dgp_trainer_step_status(dgp_trainer* tr, const float* d_losses, int32_t n_losses, float* losses, float* gnorm, int32_t* was_fast,
+                            int32_t* failed, void* stream) {
     if (!tr) return fail(DGP_ERR_INVALID, "dgp_trainer_step_status: null");
-    TRY_HIP(hipDeviceSynchronize());
-    int f = 0;
-    if (tr->fwd_fast) TRY_HIP(hipMemcpy(&f, tr->d_fast_flag, sizeof(int), hipMemcpyDeviceToHost));
-    if (gnorm) TRY_HIP(hipMemcpy(gnorm, tr->d_gnorm, sizeof(float), hipMemcpyDeviceToHost));
+    if (n_losses < 0 || n_losses > 8 || (n_losses && (!d_losses || !losses))) return fail(DGP_ERR_INVALID, "dgp_trainer_step_status: 0..8 losses");
+    hipStream_t s = (hipStream_t)stream;
+    // one tiny kernel at the end of the stream writes everything the host wants into pinned memory; one wait.  (Every launch of the step
+    // is on this stream or joined into it: the second stream's forward chain and weight gradients, the optimiser, the re-packing.)
+    hipLaunchKernelGGL(step_status_kernel, dim3(1), dim3(64), 0, s, d_losses, n_losses, tr->d_gnorm, tr->fwd_fast ? tr->d_fast_flag : (const int*)nullptr,
+                       tr->h_status);
+    TRY_HIP(hipGetLastError());
+    TRY_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < n_losses; ++i) losses[i] = tr->h_status[i];
+    if (gnorm) *gnorm = tr->h_status[8];
     if (was_fast) *was_fast = tr->fwd_fast ? 1 : 0;
-    if (failed) *failed = f;
+    if (failed) *failed = tr->h_status[9] != 0.f ? 1 : 0;
     return DGP_OK;
 }
 
@@ -3238,10 +3276,11 @@ int dgp_trainer_download(dgp_trainer* tr, int32_t which, int64_t offset, float* 
 int dgp_sgd_momentum_clip(dgp_trainer* tr, float lr, float momentum, float clip_norm, float* gnorm_host_or_null, void* stream) {
     if (!tr) return fail(DGP_ERR_INVALID, "dgp_sgd_momentum_clip: null");
     hipStream_t s = (hipStream_t)stream;
-    TRY_HIP(hipMemsetAsync(tr->d_sumsq, 0, sizeof(double), s));
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(tr->n_train)), dim3(256), 0, s, tr->grads, tr->n_train, tr->d_sumsq);
+    const int k = tr->sumsq_k;
+    tr->sumsq_k ^= 1;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(tr->n_train)), dim3(256), 0, s, tr->grads, tr->n_train, tr->d_sumsq + k);
     hipLaunchKernelGGL(momentum_kernel, dim3(grid_for(tr->n_train)), dim3(256), 0, s, tr->params, tr->grads, tr->mom, tr->n_train,
-                       lr, momentum, clip_norm, tr->d_sumsq, tr->d_gnorm, tr->fwd_fast ? tr->d_fast_flag : nullptr);
+                       lr, momentum, clip_norm, tr->d_sumsq + k, tr->d_sumsq + (k ^ 1), tr->d_gnorm, tr->fwd_fast ? tr->d_fast_flag : nullptr);
     TRY_HIP(hipGetLastError());
     if (gnorm_host_or_null) {
         TRY_HIP(hipStreamSynchronize(s));

@@ -205,11 +205,10 @@ class Trainer:
             batch = dict(batch, hidden_marker=np.empty(0, dtype=np.int32))
             S0 = np.zeros((0, nj))
             ws = ws_max = np.zeros(0)
-        # host-side order.  Parity tier: the forward is enqueued first (it needs only the frames); while it runs (3.9 ms at 11 frames) the loss
-        # inputs are validated and uploaded (0.4 ms of host work).  16-bit tier: the forward takes 2 ms -- about what the host needs to
-        # enqueue it -- so the loss inputs go first (on their own stream, beside the tail of the previous step) and nothing stands
-        # between the forward's last launch and the loss kernels.  Then the loss kernels and the whole backward pass are enqueued back to
-        # back, and the losses are read back (the one synchronisation) after everything is in flight
+        # host-side order: the forward is enqueued first (it needs only the frames: 0.5 ms of host work for 2 - 4 ms of GPU work at 11
+        # frames); while it runs the loss inputs are validated, packed into one pinned buffer and uploaded with ONE asynchronous copy on
+        # their own stream (0.2 ms of host work).  Then the loss kernels and the whole backward pass are enqueued back to back; nothing is
+        # read back here
         main = torch.cuda.current_stream(self.device)
         if getattr(self, "_upload_stream", None) is None:
             self._upload_stream = torch.cuda.Stream(device=self.device)
@@ -221,12 +220,8 @@ class Trainer:
                 ev = torch.cuda.Event()
                 ev.record(self._upload_stream)
             return li_, ev
-        early = self.tier == "f16"
-        if early:
-            li, uploaded = upload()
         wsb, pred, loc = self._forward(frames)          # checks dtype / shape against the net's current input size
-        if not early:
-            li, uploaded = upload()
+        li, uploaded = upload()
         main.wait_event(uploaded)
         for name in li.__slots__:
             t = getattr(li, name, None)
@@ -267,7 +262,7 @@ class Trainer:
             self.allreduce_gradients()               # data-parallel: mean gradient over the ranks (RCCL) -- needs the gradients on every rank first
             losses["grad_norm"] = self.apply_gradients(hyper.lr, hyper.momentum, hyper.clip_norm)
             return losses
-        from .loss import losses_to_dict
+        from .loss import LOSS_NAMES
         nt = frames.shape[0]
         while True:
             fast = self._fast_begin(nt)
@@ -277,13 +272,15 @@ class Trainer:
                        "dgp_sgd_momentum_clip")
             self.sync()                              # master -> panels / cells for the next forward (same weights again after a skipped update)
             g, was, failed = C.c_float(), C.c_int32(), C.c_int32()
-            _lib.check(self.lib.dgp_trainer_step_status(self._t, C.byref(g), C.byref(was), C.byref(failed)), "dgp_trainer_step_status")
+            lv = (C.c_float * 8)()
+            _lib.check(self.lib.dgp_trainer_step_status(self._t, _ptr(dev_losses), len(LOSS_NAMES), lv, C.byref(g), C.byref(was), C.byref(failed),
+                                                        _stream(self.device)), "dgp_trainer_step_status")
             if fast and failed.value:                # the momentum kernel saw the flag and left parameters and momentum alone
                 self._fast_key = None
                 self.fast_redos += 1
                 continue
             self._fast_key = (nt, self.net.in_h, self.net.in_w)
-            losses = losses_to_dict(dev_losses)
+            losses = {k: float(lv[i]) for i, k in enumerate(LOSS_NAMES)}
             losses["grad_norm"] = g.value
             return losses
 

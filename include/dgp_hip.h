@@ -243,11 +243,13 @@ int    dgp_trainer_get_tier(const dgp_trainer* tr);
 int    dgp_trainer_fast_mode(dgp_trainer* tr, int32_t enable);
 int    dgp_trainer_fast_status(dgp_trainer* tr, int32_t* was_fast, int32_t* failed);
 /* ONE synchronisation per training step: enqueue forward, loss, backward, dgp_sgd_momentum_clip(..., NULL gnorm, ...) and
- * dgp_trainer_sync_weights without reading anything back, then call this -- it waits for the device and returns the gradient norm the
- * optimiser saw and the pass status.  After a fast / 16-bit pass whose tensors left their predicted ranges (*failed != 0) the momentum
- * kernel has SKIPPED its update on the device (it reads the flag), so the step can be run again on the parity path as if nothing had
- * happened.  Replaces the two read-backs of sess.run([loss, train_op]) + a separate gnorm fetch (DGP/models/fitdgp.py:818). */
-int    dgp_trainer_step_status(dgp_trainer* tr, float* gnorm, int32_t* was_fast, int32_t* failed);
+ * dgp_trainer_sync_weights on `stream` without reading anything back, then call this -- a last tiny kernel writes the n_losses (<= 8)
+ * device floats at d_losses (dgp_loss_fwd_bwd's `losses`; NULL / 0: none), the gradient norm the optimiser saw and the pass status into
+ * pinned host memory, and the call waits for the stream once.  After a fast / 16-bit pass whose tensors left their predicted ranges
+ * (*failed != 0) the momentum kernel has SKIPPED its update on the device (it reads the flag), so the step can be run again on the
+ * parity path as if nothing had happened.  Replaces the read-backs of sess.run([loss, train_op]) (DGP/models/fitdgp.py:818). */
+int    dgp_trainer_step_status(dgp_trainer* tr, const float* d_losses, int32_t n_losses, float* losses, float* gnorm,
+                               int32_t* was_fast, int32_t* failed, void* stream);
 
 /* ---- single-layer entry points (used by the parity tests and by fit_dgp later) ---- */
 
