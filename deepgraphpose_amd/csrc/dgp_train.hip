@@ -235,6 +235,38 @@ __global__ void pack_head_dgrad_kernel(const float* __restrict__ w, int njt, int
     }
 }
 
+// 16-bit tier: BOTH heads' data-gradient panels side by side -- "input" channels [0, cpad0) the part head's phases, [cpad0, cpad0 +
+// cpad1) the locref head's, zero up to CT -- so that one launch over head_gather_h1_kernel's tensor gives d features of both heads
+__global__ void pack_heads_dgrad_kernel(const float* __restrict__ w0, int njt0, int cpad0, const float* __restrict__ w1, int njt1, int cpad1,
+                                        int cin, int CT, int cinP, int nchunks, float* __restrict__ packed, float* __restrict__ rng) {
+    const long long total = (long long)nchunks * cinP;
+    float mx = 0.f;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(g % cinP);
+        const int q = (int)(g / cinP);
+        const int c4 = CT >> 2;
+        const int tapp = q / c4, cob = (q - tapp * c4) << 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tapp < 4 && ci < cin) {
+            const int tap = 3 - tapp, khp = tap >> 1, kwp = tap & 1;
+            float* pv = &v.x;
+            for (int e = 0; e < 4; ++e) {
+                int co = cob + e;
+                const float* w = w0;
+                int njt = njt0;
+                if (co >= cpad0) { co -= cpad0; w = w1; njt = njt1; if (co >= cpad1) continue; }
+                if (co >= 4 * njt) continue;
+                const int ph = co / njt, c = co - ph * njt;
+                const int ka = (ph >> 1) + 2 - 2 * khp, kb = (ph & 1) + 2 - 2 * kwp;
+                if (ka <= 2 && kb <= 2) pv[e] = w[(((long long)ka * 3 + kb) * njt + c) * cin + ci];
+            }
+        }
+        *reinterpret_cast<float4*>(packed + g * 4) = v;
+        mx = amax4(mx, v);
+    }
+    pack_track(rng, mx);
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight gradient: dWraw[k][co] += sum_m A[m][k] * dY[m][co]   (k = (tap, ci), HWIO order)
 // fp32 MFMA with the output tile's rows = k, cols = co and the reduction over pixels m.  LDS images are the
@@ -942,7 +974,7 @@ __device__ __forceinline__ void wgrad_dma_t(const WgradArgs& p) {
     const float sx = shadow_scale_for(p.x_prev, lane), sy = shadow_scale_for(p.dy_prev, lane);
     if (!(shadow_usable(sx, p.x_cur, lane) && shadow_usable(sy, p.dy_cur, lane))) {
         if (!H1 && p.x && p.dy) wgrad_f32_body<2>(p);
-        else if (p.fail_flag && threadIdx.x == 0) atomicOr(p.fail_flag, 1);       // the host repeats the step on fp32 tensors
+        else if (p.fail_flag && threadIdx.x == 0) atomicOr(p.fail_flag, 2);       // the host repeats the step on fp32 tensors
         return;
     }
     const int wm = wave >> 1, wn = wave & 1;
@@ -1229,7 +1261,8 @@ __global__ __launch_bounds__(64) void h2_pred_check_kernel(const H2CheckList lis
     const int lane = threadIdx.x;
     const float* pv = prev + (size_t)list.idx[k] * ABSMAX_SLOTS;
     const float* cu = pool + (size_t)list.idx[k] * ABSMAX_SLOTS;
-    if (!shadow_usable(shadow_scale_for(pv, lane), cu, lane) && lane == 0) atomicOr(flag, 1);
+    // (bits 8..: slot + 1 of a failed tensor -- diagnostics; any non-zero value means "repeat the step")
+    if (!shadow_usable(shadow_scale_for(pv, lane), cu, lane) && lane == 0) atomicOr(flag, 1 | ((list.idx[k] + 1) << 8));
 }
 
 // H2 cells with a predicted scale -> fp32 (the heads' weight gradient and gate read the block4 features as fp32)
@@ -1384,8 +1417,9 @@ __global__ void bn_param_grads_all_kernel(const FinDesc* __restrict__ table, con
 }
 
 // head: dw[ka][kb][c][ci] = dW'raw[(khp,kwp)][ci][(a,b),c] (each w element appears once), db[c] = sum_phases colsum
+// (cpad: columns per row of dwraw; col0: first column of this head -- the 16-bit tier's merged launch holds both heads side by side)
 __global__ void finalize_head_grads(const float* __restrict__ dwraw, const float* __restrict__ colsum, int njt, int cin,
-                                    int cpad, float* __restrict__ dw, float* __restrict__ db) {
+                                    int cpad, int col0, float* __restrict__ dw, float* __restrict__ db) {
     const long long total = 9ll * njt * cin;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
         const int ci = (int)(g % cin);
@@ -1396,16 +1430,19 @@ __global__ void finalize_head_grads(const float* __restrict__ dwraw, const float
         // ka = a + 2 - 2 khp  ->  (ka=0: a=0,khp=1) (ka=1: a=1,khp=1) (ka=2: a=0,khp=0)
         const int a = ka == 1 ? 1 : 0, khp = ka == 2 ? 0 : 1;
         const int b = kb == 1 ? 1 : 0, kwp = kb == 2 ? 0 : 1;
-        dw[g] = dwraw[(((long long)(khp * 2 + kwp)) * cin + ci) * cpad + (a * 2 + b) * njt + c];
+        dw[g] = dwraw[(((long long)(khp * 2 + kwp)) * cin + ci) * cpad + col0 + (a * 2 + b) * njt + c];
     }
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < njt) db[c] = colsum[c] + colsum[njt + c] + colsum[2 * njt + c] + colsum[3 * njt + c];
+    if (c < njt) db[c] = colsum[col0 + c] + colsum[col0 + njt + c] + colsum[col0 + 2 * njt + c] + colsum[col0 + 3 * njt + c];
 }
 
 // d scoremap [N,2h,2w,njt] -> phase-major rows [N*h*w, cpad] (inverse of the forward scatter), zero padded
+// (rng: range slots that take max |value| -- one array for BOTH heads' gathers: it predicts the scale of the merged H1 tensor that
+// head_gather_h1_kernel writes in the next 16-bit pass)
 __global__ void head_gather_kernel(const float* __restrict__ dsc, int N, int h, int w, int njt, int cpad,
-                                   float* __restrict__ out) {
+                                   float* __restrict__ out, float* __restrict__ rng) {
     const long long total = (long long)N * h * w * cpad;
+    float mx = 0.f;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
         const int co = (int)(g % cpad);
         long long m = g / cpad;
@@ -1419,7 +1456,46 @@ __global__ void head_gather_kernel(const float* __restrict__ dsc, int N, int h, 
             v = dsc[(((long long)n * 2 * h + 2 * i + (ph >> 1)) * 2 * w + 2 * j + (ph & 1)) * njt + c];
         }
         out[g] = v;
+        mx = fmaxf(mx, fabsf(v));
     }
+    pack_track(rng, mx);
+}
+
+// 16-bit tier: both heads' loss gradients -> ONE phase-major H1 tensor [N*h*w, CT].  Columns [0, cpad0): the part head's phases as
+// head_gather_kernel lays them out, [cpad0, cpad0 + cpad1): the locref head's, zero up to CT (a multiple of 64: one K-step of the H1
+// kernels).  Scale: predicted from the range the same values had one step ago (prev); this step's range goes to rng.  One data-gradient
+// launch and one weight-gradient launch then serve both heads.
+__global__ __launch_bounds__(256) void head_gather_h1_kernel(const float* __restrict__ dsc0, const float* __restrict__ dsc1, int N, int h, int w,
+                                                             int njt0, int cpad0, int njt1, int cpad1, int CT, const float* __restrict__ prev,
+                                                             uint4* __restrict__ out, float* __restrict__ rng) {
+    const float scale = shadow_scale_for(prev, threadIdx.x & 63);
+    const int G = CT >> 3;
+    const long long total = (long long)N * h * w * G;
+    float mx = 0.f;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int cg = (int)(g % G);
+        long long m = g / G;
+        const int j = (int)(m % w);
+        m /= w;
+        const int i = (int)(m % h);
+        const int n = (int)(m / h);
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int co = cg * 8 + k;
+            const float* dsc = dsc0;
+            int njt = njt0;
+            if (co >= cpad0) { co -= cpad0; dsc = dsc1; njt = njt1; if (co >= cpad1) njt = 0; }
+            v[k] = 0.f;
+            if (co < 4 * njt) {
+                const int ph = co / njt, c = co - ph * njt;
+                v[k] = dsc[(((long long)n * 2 * h + 2 * i + (ph >> 1)) * 2 * w + 2 * j + (ph & 1)) * njt + c];
+            }
+            mx = fmaxf(mx, fabsf(v[k]));
+        }
+        out[g] = h1_pack8(v, scale);
+    }
+    pack_track(rng, mx);
 }
 
 // max-pool 3x3/2 SAME backward fused with the stem's ReLU gate: dC1 = (C1 > 0) * sum over windows whose first
@@ -1618,7 +1694,7 @@ __global__ void step_status_kernel(const float* __restrict__ losses, int n_losse
     const int t = threadIdx.x;
     if (t < n_losses) host[t] = losses[t];
     if (t == 8) host[8] = *gnorm;
-    if (t == 9) host[9] = (flag && *flag) ? 1.f : 0.f;
+    if (t == 9) host[9] = flag ? (float)*flag : 0.f;
     __threadfence_system();
 }
 
@@ -1725,6 +1801,12 @@ struct dgp_trainer {
     float* d_stem_rows = nullptr;     // tier 1: the stem's row panel [7 x 8 pixels][64][4] and its cells for stem_pool_fused_kernel, rebuilt per sync
     void* d_stem_cells = nullptr;
     bool fwd_stem_fused = false;      // the last forward pass ran the fused root block (no conv1 map, no fp32 pool output)
+    // tier 1: both heads' data-gradient panels merged (pack_heads_dgrad_kernel), its range slots and its H1 cells; CT input channels
+    float* d_hmT = nullptr;
+    float* d_hm_rng = nullptr;
+    void* d_hmT_h1 = nullptr;
+    int hm_ct = 0, hm_nk = 0;
+    bool fwd_feat32 = true;           // the last fast forward pass left an fp32 copy of the features (not when the heads' backward reads H1)
     int n_h1 = 0;
     float* d_wrng = nullptr;          // weight-panel range slots: [2 * n_layers] (forward panels, data-gradient panels), per sync
     void* d_pack_table = nullptr;     // PackDesc of every non-head layer (pack_all_kernel), built at the first sync
@@ -1734,7 +1816,7 @@ struct dgp_trainer {
     void* d_fin_table = nullptr;      // FinDesc of every non-head layer (deferred weight-gradient finalisation), per batch size
     int n_fin = 0, fin_B = -1, fin_h = -1, fin_w = -1;
     ~dgp_trainer() {
-        for (void* q : {(void*)d_rng_pool, (void*)d_rng_prev, (void*)d_fast_flag, (void*)d_wrng, d_pack_table, d_fin_table, d_h3_table, d_h1_table, (void*)d_stem_rows, d_stem_cells}) if (q) (void)hipFree(q);
+        for (void* q : {(void*)d_rng_pool, (void*)d_rng_prev, (void*)d_fast_flag, (void*)d_wrng, d_pack_table, d_fin_table, d_h3_table, d_h1_table, (void*)d_stem_rows, d_stem_cells, (void*)d_hmT, (void*)d_hm_rng, d_hmT_h1}) if (q) (void)hipFree(q);
         for (auto& t : tl) { if (t.d_wT) (void)hipFree(t.d_wT); if (t.d_wTh3) (void)hipFree(t.d_wTh3); if (t.d_wTh1) (void)hipFree(t.d_wTh1); }
         for (void* p : {(void*)params, (void*)grads, (void*)mom, (void*)stats, (void*)d_sumsq, (void*)d_gnorm})
             if (p) (void)hipFree(p);
@@ -1760,6 +1842,7 @@ struct TPlan {
     std::vector<size_t> sh_r1, sh_r2, sh_xo;
     size_t sh_g0 = 0, sh_g1 = 0, sh_dr1 = 0, sh_dr2 = 0, sh_dr1_b = 0, sh_dr2_b = 0;
     size_t feat32 = 0;           // fast pass: fp32 copy of the block4 features for the heads' backward
+    size_t dphh = 0;             // 16-bit tier: both heads' gathered loss gradients as one H1 tensor [B*h*w, heads_ct(nj)]
     size_t sh_pool = 0;          // 16-bit tier: H1 copy of the pool output (input of the first unit)
     size_t total;
 };
@@ -1768,6 +1851,8 @@ struct TPlan {
 static const bool g_wgrad_dma = (dgp_env("DGP_WGRAD_DMA", 1) != 0);
 
 size_t al(size_t x) { return (x + 255) / 256 * 256; }
+// channels of the merged heads tensor: both heads' padded phase columns, rounded up to the H1 kernels' K-step
+int heads_ct(int nj) { return (next_pow2(4 * nj) + next_pow2(8 * nj) + 63) / 64 * 64; }
 
 TPlan make_tplan(const dgp_trainer* tr, int B) {
     const dgp_net* net = tr->net;
@@ -1802,6 +1887,7 @@ TPlan make_tplan(const dgp_trainer* tr, int B) {
     p.dc1 = take((size_t)B * net->h1 * net->w1 * 64);
     p.dph0 = take((size_t)B * h * w * next_pow2(4 * nj));
     p.dph1 = take((size_t)B * h * w * next_pow2(8 * nj));
+    p.dphh = take((size_t)B * h * w * heads_ct(nj) / 2);
     size_t wmax = 0;
     for (size_t li = 0; li < net->layers.size(); ++li) {
         const ConvLayer& l = net->layers[li];
@@ -1907,6 +1993,7 @@ static void range_pass_begin(dgp_trainer* tr, hipStream_t s, bool backward) {
         if (tr->net->layers[li].d_w) g_ctx->rng.of[tr->net->layers[li].d_w] = tr->d_wrng + li * ABSMAX_SLOTS;
         if (tr->tl[li].d_wT) g_ctx->rng.of[tr->tl[li].d_wT] = tr->d_wrng + (nl + li) * ABSMAX_SLOTS;
     }
+    if (tr->d_hmT && tr->d_hm_rng) g_ctx->rng.of[tr->d_hmT] = tr->d_hm_rng;
 }
 
 
@@ -1974,6 +2061,7 @@ hipError_t conv_launch(const ConvLayer& l, const float* wpk, int nk, int coutP, 
         if (a.in_fmt == 2) {                       // H1 operands: the panel's high-only cells (none: launch_conv refuses)
             const auto c1 = g_ctx->cells1.find(wpk);
             a.wh3 = c1 != g_ctx->cells1.end() ? c1->second : nullptr;
+            a.wh3_bytes = a.w_bytes;               // (fp32-panel bytes: launch_conv halves both for H1 cells)
         }
     }
     if (out_mode == 0) {
@@ -2381,6 +2469,26 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
                     TRY_HIP(hipMemcpy(tr->d_h1_table, tab.data(), tab.size() * sizeof(PackH3Desc), hipMemcpyHostToDevice));
                 }
                 TRY_HIP(launch_pack_h1_all(reinterpret_cast<const PackH3Desc*>(tr->d_h1_table), tr->n_h1, s));
+                // both heads' data-gradient panels as one panel + its H1 cells (one launch gives d features of both heads)
+                static const bool heads_h1_env = (dgp_env("DGP_TRAIN_HEADS_H1", 1) != 0);      // A/B switch
+                {
+                    const ConvLayer &l0 = net->layers[net->head_part], &l1 = net->layers[net->head_locref];
+                    const TLayer &t0 = tr->tl[net->head_part], &t1 = tr->tl[net->head_locref];
+                    const int CT = heads_ct(net->desc.num_joints), nkT = nk_for(2, 2, CT);
+                    if (heads_h1_env && l0.Cin == l1.Cin && t0.cinP == t1.cinP && t0.cpad + t1.cpad <= CT && (nkT % 2) == 0 && t0.cinP % 64 == 0) {
+                        const size_t pbytes = (size_t)nkT * 8 * t0.cinP * 16;
+                        if (!tr->d_hmT) TRY_HIP(hipMalloc(&tr->d_hmT, pbytes));
+                        if (!tr->d_hmT_h1) TRY_HIP(hipMalloc(&tr->d_hmT_h1, pbytes / 2));
+                        if (!tr->d_hm_rng) TRY_HIP(hipMalloc(&tr->d_hm_rng, ABSMAX_SLOTS * sizeof(float)));
+                        tr->hm_ct = CT; tr->hm_nk = nkT;
+                        TRY_HIP(hipMemsetAsync(tr->d_hm_rng, 0, ABSMAX_SLOTS * sizeof(float), s));
+                        const long long totT = (long long)nkT * 8 * t0.cinP;
+                        hipLaunchKernelGGL(pack_heads_dgrad_kernel, dim3(grid_for(totT)), dim3(256), 0, s, tr->params + t0.w_off, l0.Cout / 4, t0.cpad,
+                                           tr->params + t1.w_off, l1.Cout / 4, t1.cpad, l0.Cin, CT, t0.cinP, nkT * 8, tr->d_hmT, tr->d_hm_rng);
+                        TRY_HIP(launch_pack_h1(tr->d_hmT, nkT, t0.cinP, tr->d_hm_rng, tr->d_hmT_h1, s));
+                        g_ctx->cells1[tr->d_hmT] = tr->d_hmT_h1;
+                    }
+                }
                 // the fused root block's weight cells (stem_pool_fused_kernel): row panel of conv1 from the panel pack_all_kernel just wrote
                 static const bool stem_fused_env = (dgp_env("DGP_TRAIN_STEM_FUSED", 1) != 0);      // A/B switch
                 ConvLayer& lc = net->layers[net->conv1];
@@ -2648,10 +2756,12 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
         cl.n = (int)g_ctx->h2_slots.size();
         for (int k = 0; k < cl.n; ++k) cl.idx[k] = (short)g_ctx->h2_slots[k];
         hipLaunchKernelGGL(h2_pred_check_kernel, dim3(cl.n), dim3(64), 0, s, cl, g_ctx->rng.pool, g_ctx->rng.prev, tr->d_fast_flag);
-        // fp32 copy of the features for the heads' backward
+        // fp32 copy of the features for the heads' backward (not when it reads the H1 features in place: merged heads of the 16-bit tier)
         const float* rfeat = range_of(xin);
         const long long n8 = (long long)B * h * w * net->units.back().depth / 8;
-        if (FMT == 2)
+        tr->fwd_feat32 = !(FMT == 2 && tr->d_hmT && tr->d_hmT_h1);
+        if (!tr->fwd_feat32) {
+        } else if (FMT == 2)
             hipLaunchKernelGGL(h1_to_f32_pred_kernel, dim3(grid_for(n8)), dim3(256), 0, s, reinterpret_cast<const uint4*>(xin), n8,
                                range_prev_of(rfeat), reinterpret_cast<float4*>(F(pl.feat32)), (const uint4*)nullptr);
         else
@@ -2825,7 +2935,51 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
     };
     // ---- heads: gather phases, parameter grads, data grad into G[cur] (gated by the last unit's ReLU)
     const float* feat = fast ? F(pl.feat32) : F(pl.xo[nu - 1]);
-    {
+    // range of the gathered loss gradients (both heads): the first slot of every backward pass -- it predicts the scale of the merged
+    // H1 tensor of the next 16-bit pass
+    float* const slot_dph = range_take();
+    const bool heads_h1 = h1p && tr->d_hmT && tr->d_hmT_h1 && slot_dph && range_prev_of(slot_dph) && !tr->fwd_feat32;
+    if (fast && !heads_h1 && !tr->fwd_feat32) return fail(DGP_ERR_STATE, "backward: the forward pass left no fp32 features for the heads");
+    if (heads_h1) {
+        // ---- 16-bit tier: both heads at once.  Their loss gradients are gathered into ONE H1 tensor (scale predicted from its range one
+        // step ago); ONE weight-gradient launch reads it and the H1 features in place (second stream), ONE H1 -> H1 data-gradient launch
+        // with the merged panel writes d features, gated by the features' ReLU, as the H1 tensor the last unit's backward reads.
+        const ConvLayer &l0 = net->layers[net->head_part], &l1 = net->layers[net->head_locref];
+        const TLayer &t0 = tr->tl[net->head_part], &t1 = tr->tl[net->head_locref];
+        const int CT = tr->hm_ct, njt0 = l0.Cout / 4, njt1 = l1.Cout / 4;
+        float* const DPH = F(pl.dphh);
+        const float* dprev = range_prev_of(slot_dph);
+        const float* featH = F(pl.xo[nu - 1]);
+        const auto fp = g_ctx->shadow_prev.find(featH);
+        if (fp == g_ctx->shadow_prev.end()) return fail(DGP_ERR_STATE, "16-bit tier: the features have no predicted range");
+        hipLaunchKernelGGL(head_gather_h1_kernel, dim3(grid_for((long long)B * fh * fw * (CT / 8))), dim3(256), 0, s, dscmap, dlocref, B, fh, fw,
+                           njt0, t0.cpad, njt1, t1.cpad, CT, dprev, reinterpret_cast<uint4*>(DPH), slot_dph);
+        range_set(DPH, slot_dph);
+        g_ctx->shadow_base[DPH] = DPH;
+        g_ctx->shadow_prev[DPH] = dprev;
+        g_ctx->h2_slots.push_back((int)((dprev - g_ctx->rng.prev) / ABSMAX_SLOTS));
+        hipStream_t hs_ = s;
+        if (ctx->overlap) {
+            hipEvent_t ready = ctx->take_event();
+            if (!ready) return fail(DGP_ERR_HIP, "weight-gradient stream: hipEventCreate failed");
+            TRY_HIP(hipEventRecord(ready, s));
+            TRY_HIP(hipStreamWaitEvent(ctx->s2, ready, 0));
+            hs_ = ctx->s2;
+        }
+        TRY_HIP(wgrad_launch(featH, B, fh, fw, l0.Cin, DPH, fh, fw, CT, 2, 2, 1, 1, 1, 1, dwraw, colsum, hs_, false, nullptr, nullptr, featH,
+                             fp->second, DPH, dprev, tr->d_fast_flag, true));
+        hipLaunchKernelGGL(finalize_head_grads, dim3(grid_for(9ll * njt0 * l0.Cin)), dim3(256), 0, hs_, dwraw, colsum, njt0, l0.Cin, CT, 0,
+                           tr->grads + t0.w_off, tr->grads + t0.b_off);
+        hipLaunchKernelGGL(finalize_head_grads, dim3(grid_for(9ll * njt1 * l1.Cin)), dim3(256), 0, hs_, dwraw, colsum, njt1, l1.Cin, CT, t0.cpad,
+                           tr->grads + t1.w_off, tr->grads + t1.b_off);
+        (void)range_take();                      // (the slot the first head's launch takes in a plain pass: every pass takes its slots in one order)
+        ConvLayer lt = l0;
+        lt.KH = lt.KW = 2; lt.rate = 1;
+        g_h2 = H2Launch();
+        g_h2.in_fmt = 2; g_h2.out_fmt = 2; g_h2.mask_fmt = 2;
+        TRY_HIP(conv_launch(lt, tr->d_hmT, tr->hm_nk, t0.cinP, DPH, B, fh, fw, CT, 0, 0, fh, fw, l0.Cin, 1, 0, nullptr, nullptr, nullptr, 0, 0, 0,
+                            featH, false, 0, 0, GH[cur], s));
+    } else {
         const size_t heads[2] = {(size_t)net->head_part, (size_t)net->head_locref};
         const float* dsrc[2] = {dscmap, dlocref};
         float* dph[2] = {F(pl.dph0), F(pl.dph1)};
@@ -2834,7 +2988,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
             const TLayer& t = tr->tl[heads[k]];
             const int njt = l.Cout / 4;
             const long long tot = (long long)B * fh * fw * t.cpad;
-            hipLaunchKernelGGL(head_gather_kernel, dim3(grid_for(tot)), dim3(256), 0, s, dsrc[k], B, fh, fw, njt, t.cpad, dph[k]);
+            hipLaunchKernelGGL(head_gather_kernel, dim3(grid_for(tot)), dim3(256), 0, s, dsrc[k], B, fh, fw, njt, t.cpad, dph[k], slot_dph);
             // the head's parameter gradients (fill + wgrad + finalise through the shared dwraw / colsum scratch, in stream order) go to the
             // second stream when the pass overlaps: the chain only needs dph[k] for the data gradient below
             hipStream_t hs_ = s;
@@ -2847,7 +3001,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
             }
             TRY_HIP(wgrad_launch(feat, B, fh, fw, l.Cin, dph[k], fh, fw, t.cpad, 2, 2, 1, 1, 1, 1, dwraw, colsum, hs_));
             hipLaunchKernelGGL(finalize_head_grads, dim3(grid_for(9ll * njt * l.Cin)), dim3(256), 0, hs_, dwraw, colsum, njt,
-                               l.Cin, t.cpad, tr->grads + t.w_off, tr->grads + t.b_off);
+                               l.Cin, t.cpad, 0, tr->grads + t.w_off, tr->grads + t.b_off);
             // dfeat (+)= convT: 2x2 taps flipped, pad' = 0; second head accumulates onto the first; gate on the last
             ConvLayer lt = l;
             lt.KH = lt.KW = 2; lt.rate = 1;
@@ -2856,7 +3010,9 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         }
     }
 
-    if (h1p) {
+    if (heads_h1) {
+        // (the merged launch wrote the H1 tensor itself)
+    } else if (h1p) {
         // the heads' data gradient (fp32, from the kernels of the parity path) enters the H1 units as an H1 tensor
         if ((rc = adopt_h1(GH[cur], G[cur]))) return rc;
         const long long n8 = (long long)B * fh * fw * net->units[nu - 1].depth / 8;
@@ -3057,6 +3213,20 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         if (cl.n) hipLaunchKernelGGL(h2_pred_check_kernel, dim3(cl.n), dim3(64), 0, s, cl, g_ctx->rng.pool, g_ctx->rng.prev, tr->d_fast_flag);
     }
     join();                                      // every weight gradient has landed before the finalisation reads them
+    if (getenv("DGP_DEBUG_FAST")) {              // diagnostics: this pass's measured ranges against the previous pass's, first backward slots
+        (void)hipStreamSynchronize(s);
+        std::vector<float> pc((size_t)12 * ABSMAX_SLOTS), pp((size_t)12 * ABSMAX_SLOTS);
+        (void)hipMemcpy(pc.data(), g_ctx->rng.pool + (size_t)2 * RANGE_FWD * ABSMAX_SLOTS, pc.size() * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(pp.data(), g_ctx->rng.prev + (size_t)2 * RANGE_FWD * ABSMAX_SLOTS, pp.size() * 4, hipMemcpyDeviceToHost);
+        int fl = 0; (void)hipMemcpy(&fl, tr->d_fast_flag, 4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[bwd h1p %d flag 0x%x]", (int)h1p, fl);
+        for (int k = 0; k < 12; ++k) {
+            float a = 0, b = 0;
+            for (int i = 0; i < ABSMAX_SLOTS; ++i) { a = std::max(a, pc[(size_t)k * ABSMAX_SLOTS + i]); b = std::max(b, pp[(size_t)k * ABSMAX_SLOTS + i]); }
+            fprintf(stderr, " %d: %.3g/%.3g", k, a, b);
+        }
+        fprintf(stderr, "\n");
+    }
     if (g_ctx->defer_plan) {
         g_ctx->defer_plan = nullptr;
         if (!tr->d_fin_table || tr->fin_B != B || tr->fin_h != d.in_h || tr->fin_w != d.in_w) {      // offsets follow the plan
@@ -3134,7 +3304,7 @@ int dgp_trainer_step_status(dgp_trainer* tr, const float* d_losses, int32_t n_lo
     for (int i = 0; i < n_losses; ++i) losses[i] = tr->h_status[i];
     if (gnorm) *gnorm = tr->h_status[8];
     if (was_fast) *was_fast = tr->fwd_fast ? 1 : 0;
-    if (failed) *failed = tr->h_status[9] != 0.f ? 1 : 0;
+    if (failed) *failed = (int32_t)tr->h_status[9];
     return DGP_OK;
 }
 

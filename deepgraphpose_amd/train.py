@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import Dict, Optional
 
 import numpy as np
@@ -276,6 +277,8 @@ class Trainer:
             _lib.check(self.lib.dgp_trainer_step_status(self._t, _ptr(dev_losses), len(LOSS_NAMES), lv, C.byref(g), C.byref(was), C.byref(failed),
                                                         _stream(self.device)), "dgp_trainer_step_status")
             if fast and failed.value:                # the momentum kernel saw the flag and left parameters and momentum alone
+                if os.environ.get("DGP_DEBUG_FAST"):
+                    print("fast pass failed: flag 0x%x" % failed.value, file=sys.stderr)
                 self._fast_key = None
                 self.fast_redos += 1
                 continue
