@@ -1807,6 +1807,9 @@ struct dgp_trainer {
     void* d_hmT_h1 = nullptr;
     int hm_ct = 0, hm_nk = 0;
     bool fwd_feat32 = true;           // the last fast forward pass left an fp32 copy of the features (not when the heads' backward reads H1)
+    // tier 1: what only a parity pass reads -- the H2 cells of every panel, the heads' 2x2-conv and data-gradient panels -- is not rebuilt by
+    // every dgp_trainer_sync_weights but when a plain pass is about to run (refresh_parity_panels)
+    bool parity_stale = false;
     int n_h1 = 0;
     float* d_wrng = nullptr;          // weight-panel range slots: [2 * n_layers] (forward panels, data-gradient panels), per sync
     void* d_pack_table = nullptr;     // PackDesc of every non-head layer (pack_all_kernel), built at the first sync
@@ -1942,6 +1945,15 @@ __global__ __launch_bounds__(256) void range_merge_kernel(float* __restrict__ a,
     if (i < n) { const float x = a[i], y = b[i]; a[i] = (y > x || y != y) ? y : x; }      // non-negative maxima; a NaN stays
 }
 
+// start of a pass: prev <- pool over [n_copy) floats (what the same kind of pass measured one step ago), pool <- 0 over [n_zero) floats,
+// optionally *flag <- 0 -- one launch instead of a copy and two fills (blit launches cost ~15 us of queue gaps each at the step's boundary)
+__global__ __launch_bounds__(256) void range_roll_kernel(float* __restrict__ pool, float* __restrict__ prev, int n_copy, int n_zero, int* __restrict__ flag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_copy) prev[i] = pool[i];
+    if (i < n_zero) pool[i] = 0.f;
+    if (i == 0 && flag) *flag = 0;
+}
+
 static float* range_take() {
     if (!g_ctx || !g_ctx->rng.on || !g_ctx->rng.pool) return nullptr;
     if (g_ctx->rng.chain2) {
@@ -1967,7 +1979,7 @@ static void range_set(const void* p, const float* slot) {
 
 // Start of a forward or a backward pass.  Forward: everything fresh (first half of the pool).  Backward: the forward tensors'
 // ranges stay (weight gradients read the retained activations), gradient tensors take slots from the second half.
-static void range_pass_begin(dgp_trainer* tr, hipStream_t s, bool backward) {
+static void range_pass_begin(dgp_trainer* tr, hipStream_t s, bool backward, int* flag_to_clear = nullptr) {
     static const bool enabled = (dgp_tune("DGP_TRAIN_F16", 1) != 0) &&
                                 !(getenv("DGP_CONV_MODE") && strcmp(getenv("DGP_CONV_MODE"), "f16x3") != 0);
     g_ctx->rng.on = enabled && tr->d_rng_pool && tr->d_wrng;
@@ -1982,11 +1994,13 @@ static void range_pass_begin(dgp_trainer* tr, hipStream_t s, bool backward) {
     if (!g_ctx->rng.on) return;
     // what this kind of pass measured one step ago predicts the scales of this pass's fp16 copies (chain 2's own slots are not needed:
     // after the merge chain 1's hold the maxima of the whole tensors)
-    if (g_wgrad_dma && tr->d_rng_prev)
-        (void)hipMemcpyAsync(reinterpret_cast<char*>(tr->d_rng_prev) + (backward ? fwd_bytes : 0),
-                             reinterpret_cast<char*>(tr->d_rng_pool) + (backward ? fwd_bytes : 0),
-                             backward ? bwd_bytes : fwd_bytes / 2, hipMemcpyDeviceToDevice, s);
-    (void)hipMemsetAsync(reinterpret_cast<char*>(tr->d_rng_pool) + (backward ? fwd_bytes : 0), 0, backward ? bwd_bytes : fwd_bytes, s);
+    {
+        const size_t off = (backward ? fwd_bytes : 0) / sizeof(float);
+        const int n_copy = (g_wgrad_dma && tr->d_rng_prev) ? (int)((backward ? bwd_bytes : fwd_bytes / 2) / sizeof(float)) : 0;
+        const int n_zero = (int)((backward ? bwd_bytes : fwd_bytes) / sizeof(float));
+        hipLaunchKernelGGL(range_roll_kernel, dim3((n_zero + 255) / 256), dim3(256), 0, s, tr->d_rng_pool + off,
+                           tr->d_rng_prev ? tr->d_rng_prev + off : nullptr, n_copy, n_zero, flag_to_clear);
+    }
     if (backward) return;
     const size_t nl = tr->net->layers.size();
     for (size_t li = 0; li < nl; ++li) {
@@ -2326,6 +2340,28 @@ int dgp_trainer_workspace_bytes(const dgp_trainer* tr, int32_t nt, size_t* out_b
     return DGP_OK;
 }
 
+}  // extern "C"
+
+// the heads' panels that only the parity path reads + the H2 cells of all panels, from the current master parameters / fp32 panels
+static int refresh_parity_panels(dgp_trainer* tr, hipStream_t s) {
+    dgp_net* net = tr->net;
+    for (int hd : {net->head_part, net->head_locref}) {
+        ConvLayer& l = net->layers[hd];
+        TLayer& t = tr->tl[hd];
+        const float* w = tr->params + t.w_off;
+        const int njt = l.Cout / 4;
+        hipLaunchKernelGGL(pack_head_fwd_kernel, dim3(grid_for((long long)l.nk * 8 * l.CoutP)), dim3(256), 0, s, w, njt, l.Cin, l.CoutP, l.nk * 8, l.d_w);
+        hipLaunchKernelGGL(pack_head_dgrad_kernel, dim3(grid_for((long long)t.nkT * 8 * t.cinP)), dim3(256), 0, s, w, njt, l.Cin, t.cpad, t.cinP,
+                           t.nkT * 8, t.d_wT);
+    }
+    if (tr->d_h3_table) TRY_HIP(launch_pack_h3_all(reinterpret_cast<const PackH3Desc*>(tr->d_h3_table), tr->n_h3, s));
+    TRY_HIP(hipGetLastError());
+    tr->parity_stale = false;
+    return DGP_OK;
+}
+
+extern "C" {
+
 // master parameters -> forward panels / folded BN / data-gradient panels of the engine
 int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
     if (tr) g_ctx = &tr->ctx;
@@ -2338,6 +2374,10 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
     // one launch for the panels / folded BN of all non-head layers (DGP_PACK_MERGED=0: one launch per layer and job, as before)
     static const bool merged_env = (dgp_tune("DGP_PACK_MERGED", 1) != 0);
     const bool merged = merged_env;
+    // tier 1, every sync after the first: the parity-only panels wait for a plain pass (A/B switch DGP_TRAIN_LAZY_PARITY=0)
+    static const bool lazy_env = (dgp_env("DGP_TRAIN_LAZY_PARITY", 1) != 0);
+    const bool lazy = lazy_env && merged && g_train_cells && tr->tier == 1 && tr->d_h3_table && tr->d_h1_table && tr->d_wrng;
+    tr->parity_stale = lazy;
     for (size_t li = 0; li < net->layers.size(); ++li) {
         ConvLayer& l = net->layers[li];
         TLayer& t = tr->tl[li];
@@ -2353,7 +2393,7 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
         if (!head && merged) continue;        // packed by pack_all_kernel below
         if (head) {
             const int njt = l.Cout / 4;
-            hipLaunchKernelGGL(pack_head_fwd_kernel, dim3(grid_for(tot)), dim3(256), 0, s, w, njt, l.Cin, l.CoutP, l.nk * 8, l.d_w);
+            if (!lazy) hipLaunchKernelGGL(pack_head_fwd_kernel, dim3(grid_for(tot)), dim3(256), 0, s, w, njt, l.Cin, l.CoutP, l.nk * 8, l.d_w);
             if (g_train_cells && merged && rng_f) {      // pointwise form of the same head for the forward pass (cells built below)
                 l.coutp_pw = head_pw_coutp(16 * njt);      // same width as dgp_net_load_weights gives the shared buffers
                 const size_t npw = (size_t)nk_for(1, 1, l.Cin) * 8 * l.coutp_pw * 4;
@@ -2364,8 +2404,8 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
             }
             hipLaunchKernelGGL(head_bias_kernel, dim3(1), dim3(256), 0, s, tr->params + t.b_off, njt, l.d_bias);
             const long long totT = (long long)t.nkT * 8 * t.cinP;
-            hipLaunchKernelGGL(pack_head_dgrad_kernel, dim3(grid_for(totT)), dim3(256), 0, s, w, njt, l.Cin, t.cpad, t.cinP,
-                               t.nkT * 8, t.d_wT);
+            if (!lazy) hipLaunchKernelGGL(pack_head_dgrad_kernel, dim3(grid_for(totT)), dim3(256), 0, s, w, njt, l.Cin, t.cpad, t.cinP,
+                                          t.nkT * 8, t.d_wT);
         } else {
             hipLaunchKernelGGL(pack_fwd_kernel, dim3(grid_for(tot)), dim3(256), 0, s, w, l.KH * l.KW, t.cin_real, l.Cin, l.Cout,
                                l.CoutP, l.nk * 8, l.d_w, rng_f);
@@ -2438,7 +2478,7 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
                 TRY_HIP(hipMalloc(&tr->d_h3_table, tab.size() * sizeof(PackH3Desc)));
                 TRY_HIP(hipMemcpy(tr->d_h3_table, tab.data(), tab.size() * sizeof(PackH3Desc), hipMemcpyHostToDevice));
             }
-            TRY_HIP(launch_pack_h3_all(reinterpret_cast<const PackH3Desc*>(tr->d_h3_table), tr->n_h3, s));
+            if (!lazy) TRY_HIP(launch_pack_h3_all(reinterpret_cast<const PackH3Desc*>(tr->d_h3_table), tr->n_h3, s));
             if (tr->tier == 1) {              // 16-bit tier: the same panels as high-only H1 cells (K-steps of 64 channels: K % 64 == 0)
                 if (!tr->d_h1_table) {
                     std::vector<PackH3Desc> tab;
@@ -2523,7 +2563,7 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     char* ws = (char*)workspace;
     auto F = [&](size_t off) { return (float*)(ws + off); };
     g_ctx->tail_slab = F(pl.tail);
-    range_pass_begin(tr, s, false);
+    range_pass_begin(tr, s, false, tr->d_fast_flag);      // (also clears the range flag of a fast pass: fast needs the ranges on)
     g_ctx->shadow_base.clear();
     g_ctx->h2_slots.clear();
     g_shadow_want = true;
@@ -2543,8 +2583,11 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     const int FMT = tr->tier == 1 ? 2 : 1;       // cell format of this pass's H2 / H1 tensors
     tr->fwd_fast = fast;
     tr->fwd_fmt = fast ? FMT : 0;
+    if (!fast && tr->parity_stale) {             // a plain pass after lazy syncs: its panels first
+        const int rcp = refresh_parity_panels(tr, s);
+        if (rcp) return rcp;
+    }
     g_shadow_fmt = (fast && FMT == 2) ? 2 : 1;   // (the one copy a tier-1 forward pass writes: block1's output, read by the first H1 unit)
-    if (fast) TRY_HIP(hipMemsetAsync(tr->d_fast_flag, 0, sizeof(int), s));
     for (size_t ui = 0; ui < net->units.size(); ++ui) {
         if (fast && ui >= ub) continue;              // (H2 tensors register themselves as they are written)
         if (pl.sh_r1[ui]) g_ctx->shadow_base[F(pl.r1[ui])] = F(pl.sh_r1[ui]);
@@ -3188,7 +3231,44 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
                             dxa, dxa_mode, dxa_h, dxa_w, xin, false, 0, 0, Gin, s));
         cur ^= 1;
     }
+    // deferred finalisation: table of every non-head layer, conv1 LAST (its weight gradient is the last launch of the pass: the other
+    // layers are finalised beside it)
+    int max_cout = 0, max_krows = 0;
+    if (g_ctx->defer_plan) {
+        if (!tr->d_fin_table || tr->fin_B != B || tr->fin_h != d.in_h || tr->fin_w != d.in_w) {      // offsets follow the plan
+            std::vector<FinDesc> tab;
+            auto entry = [&](size_t li) {
+                const ConvLayer& l = net->layers[li];
+                const TLayer& t = tr->tl[li];
+                FinDesc f{};
+                f.dw_off = (long long)pl.dw_l[li]; f.cs_off = (long long)pl.cs_l[li];
+                f.w_off = t.w_off; f.g_off = t.g_off; f.b_off = t.b_off; f.mean_off = t.mean_off; f.var_off = t.var_off;
+                f.taps = l.KH * l.KW; f.cin = l.Cin; f.cin_real = t.cin_real; f.cout = l.Cout; f.d_scale = l.d_scale;
+                tab.push_back(f);
+            };
+            for (size_t li = 0; li < net->layers.size(); ++li)
+                if ((int)li != net->head_part && (int)li != net->head_locref && (int)li != net->conv1) entry(li);
+            entry((size_t)net->conv1);
+            if (!tr->d_fin_table) TRY_HIP(hipMalloc(&tr->d_fin_table, tab.size() * sizeof(FinDesc)));
+            TRY_HIP(hipStreamSynchronize(s));        // (a previous pass may still read the old table)
+            TRY_HIP(hipMemcpy(tr->d_fin_table, tab.data(), tab.size() * sizeof(FinDesc), hipMemcpyHostToDevice));
+            tr->n_fin = (int)tab.size(); tr->fin_B = B; tr->fin_h = d.in_h; tr->fin_w = d.in_w;
+        }
+        for (size_t li = 0; li < net->layers.size(); ++li) {
+            if ((int)li == net->head_part || (int)li == net->head_locref) continue;
+            max_cout = std::max(max_cout, net->layers[li].Cout);
+            max_krows = std::max(max_krows, net->layers[li].KH * net->layers[li].KW * tr->tl[li].cin_real);
+        }
+    }
+    const int rpb = 128;
+    const FinDesc* fin_tab = reinterpret_cast<const FinDesc*>(tr->d_fin_table);
+    auto finalise = [&](int first, int count, hipStream_t st) {
+        hipLaunchKernelGGL(scale_dw_dot_all_kernel, dim3((max_cout + 63) / 64, (max_krows + rpb - 1) / rpb, (unsigned)count), dim3(256), 0, st,
+                           fin_tab + first, (const char*)ws, tr->params, tr->grads, rpb);
+    };
     // ---- root block: max-pool backward (+ stem ReLU gate), stem weight gradient
+    static const bool fin_split_env = (dgp_env("DGP_FIN_SPLIT", 1) != 0);       // A/B switch
+    const bool fin_split = fin_split_env && g_ctx->defer_plan && ctx->overlap && tr->n_fin > 1;
     {
         int pth = (net->hp - 1) * 2 + 3 - net->h1; if (pth < 0) pth = 0;
         int ptw = (net->wp - 1) * 2 + 3 - net->w1; if (ptw < 0) ptw = 0;
@@ -3201,7 +3281,17 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         else
             hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(tot)), dim3(256), 0, s, F(pl.c1), G[cur], B, net->h1, net->w1, 64,
                                net->hp, net->wp, pth / 2, ptw / 2, F(pl.dc1));
-        rc = layer_param_grads(tr, net->conv1, F(pl.p0), B, d.in_h, d.in_w, F(pl.dc1), net->h1, net->w1, 2, 3, 3, dwraw, colsum, s);
+        if (fin_split) {
+            // the stem's weight gradient (0.3 ms at 11 frames, fp32 MFMA on a 216 MB gradient) is the pass's last launch and nothing else
+            // is left to run beside it -- except the finalisation of all OTHER layers: that goes to the second stream behind the last of
+            // their weight gradients, the stem's weight gradient to this stream
+            finalise(0, tr->n_fin - 1, ctx->s2);
+            ctx->overlap = false;
+            rc = layer_param_grads(tr, net->conv1, F(pl.p0), B, d.in_h, d.in_w, F(pl.dc1), net->h1, net->w1, 2, 3, 3, dwraw, colsum, s);
+            ctx->overlap = true;
+        } else {
+            rc = layer_param_grads(tr, net->conv1, F(pl.p0), B, d.in_h, d.in_w, F(pl.dc1), net->h1, net->w1, 2, 3, 3, dwraw, colsum, s);
+        }
         if (rc) return rc;
     }
     (void)nj;
@@ -3213,50 +3303,11 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         if (cl.n) hipLaunchKernelGGL(h2_pred_check_kernel, dim3(cl.n), dim3(64), 0, s, cl, g_ctx->rng.pool, g_ctx->rng.prev, tr->d_fast_flag);
     }
     join();                                      // every weight gradient has landed before the finalisation reads them
-    if (getenv("DGP_DEBUG_FAST")) {              // diagnostics: this pass's measured ranges against the previous pass's, first backward slots
-        (void)hipStreamSynchronize(s);
-        std::vector<float> pc((size_t)12 * ABSMAX_SLOTS), pp((size_t)12 * ABSMAX_SLOTS);
-        (void)hipMemcpy(pc.data(), g_ctx->rng.pool + (size_t)2 * RANGE_FWD * ABSMAX_SLOTS, pc.size() * 4, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(pp.data(), g_ctx->rng.prev + (size_t)2 * RANGE_FWD * ABSMAX_SLOTS, pp.size() * 4, hipMemcpyDeviceToHost);
-        int fl = 0; (void)hipMemcpy(&fl, tr->d_fast_flag, 4, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[bwd h1p %d flag 0x%x]", (int)h1p, fl);
-        for (int k = 0; k < 12; ++k) {
-            float a = 0, b = 0;
-            for (int i = 0; i < ABSMAX_SLOTS; ++i) { a = std::max(a, pc[(size_t)k * ABSMAX_SLOTS + i]); b = std::max(b, pp[(size_t)k * ABSMAX_SLOTS + i]); }
-            fprintf(stderr, " %d: %.3g/%.3g", k, a, b);
-        }
-        fprintf(stderr, "\n");
-    }
     if (g_ctx->defer_plan) {
         g_ctx->defer_plan = nullptr;
-        if (!tr->d_fin_table || tr->fin_B != B || tr->fin_h != d.in_h || tr->fin_w != d.in_w) {      // offsets follow the plan
-            std::vector<FinDesc> tab;
-            for (size_t li = 0; li < net->layers.size(); ++li) {
-                if ((int)li == net->head_part || (int)li == net->head_locref) continue;
-                const ConvLayer& l = net->layers[li];
-                const TLayer& t = tr->tl[li];
-                FinDesc f{};
-                f.dw_off = (long long)pl.dw_l[li]; f.cs_off = (long long)pl.cs_l[li];
-                f.w_off = t.w_off; f.g_off = t.g_off; f.b_off = t.b_off; f.mean_off = t.mean_off; f.var_off = t.var_off;
-                f.taps = l.KH * l.KW; f.cin = l.Cin; f.cin_real = t.cin_real; f.cout = l.Cout; f.d_scale = l.d_scale;
-                tab.push_back(f);
-            }
-            if (!tr->d_fin_table) TRY_HIP(hipMalloc(&tr->d_fin_table, tab.size() * sizeof(FinDesc)));
-            TRY_HIP(hipStreamSynchronize(s));        // (a previous pass may still read the old table)
-            TRY_HIP(hipMemcpy(tr->d_fin_table, tab.data(), tab.size() * sizeof(FinDesc), hipMemcpyHostToDevice));
-            tr->n_fin = (int)tab.size(); tr->fin_B = B; tr->fin_h = d.in_h; tr->fin_w = d.in_w;
-        }
-        int max_cout = 0, max_krows = 0;
-        for (size_t li = 0; li < net->layers.size(); ++li) {
-            if ((int)li == net->head_part || (int)li == net->head_locref) continue;
-            max_cout = std::max(max_cout, net->layers[li].Cout);
-            max_krows = std::max(max_krows, net->layers[li].KH * net->layers[li].KW * tr->tl[li].cin_real);
-        }
-        const int rpb = 128;
-        const FinDesc* tab = reinterpret_cast<const FinDesc*>(tr->d_fin_table);
-        hipLaunchKernelGGL(scale_dw_dot_all_kernel, dim3((max_cout + 63) / 64, (max_krows + rpb - 1) / rpb, (unsigned)tr->n_fin), dim3(256),
-                           0, s, tab, (const char*)ws, tr->params, tr->grads, rpb);
-        hipLaunchKernelGGL(bn_param_grads_all_kernel, dim3((max_cout + 127) / 128, (unsigned)tr->n_fin), dim3(128), 0, s, tab,
+        if (fin_split) finalise(tr->n_fin - 1, 1, s);
+        else finalise(0, tr->n_fin, s);
+        hipLaunchKernelGGL(bn_param_grads_all_kernel, dim3((max_cout + 127) / 128, (unsigned)tr->n_fin), dim3(128), 0, s, fin_tab,
                            (const char*)ws, tr->stats, d.bn_eps, tr->grads);
     }
     TRY_HIP(hipGetLastError());
