@@ -588,7 +588,7 @@ __device__ __forceinline__ void ls_store_raw(floatx16 (&acc)[TM][TN], char* smem
 // Loader-specialised variant (Cin >= 32, NHWC output): the workgroup has 4 COMPUTE waves (2 x 2 over the tile)
 // that only issue ds_read_b128 + MFMA, and 4 LOADER waves that only issue buffer loads + ds_write.  A
 // buffer_load costs the issuing wave hundreds of cycles under load (the L2 -> L1 path is the co-bottleneck
-// of this kernel); with the loads on their own waves that stall no longer sits in front of
+// of this kernel, see EXPERIMENTS.md); with the loads on their own waves that stall no longer sits in front of
 // the MFMAs, and every load has a whole K-step (8k cycles) in flight before its LDS write.
 //   step ks:  compute reads buf[ks&1]      | loaders write buf[(ks+1)&1] (loaded during step ks-1),
 //                                          | then issue the loads of step ks+2;   one s_barrier per step.

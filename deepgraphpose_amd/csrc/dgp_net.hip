@@ -1333,7 +1333,7 @@ int dgp_conv2d_ranged(const dgp_conv_desc* d, const float* x, const float* packe
 }
 
 /* ---- H2 activation format at the boundary (tests, PoseNet.extract_features): converters, a single conv layer on H2 tensors, and
- * the engine's range status.  See ConvArgs::in_fmt (csrc/dgp_internal.h) and DESIGN.md section 3. */
+ * the engine's range status.  See ConvArgs::in_fmt (csrc/dgp_internal.h) and EXPERIMENTS.md section 3. */
 int dgp_f32_to_h2(const float* x, size_t n_floats, int32_t scale_exp, void* out, void* stream) {
     if (!x || !out || (n_floats & 7)) return fail(DGP_ERR_INVALID, "dgp_f32_to_h2: null argument / length not a multiple of 8");
     hipError_t e = launch_f32_to_h2(x, (long long)(n_floats / 8), ldexpf(1.f, scale_exp), out, (hipStream_t)stream);

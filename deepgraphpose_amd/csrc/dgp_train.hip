@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void wgrad_f32(const WgradArgs p) { wgrad_f32_
 
 // ------------------------------------------------------------------------------------------------
 // Weight gradient on the 16-bit matrix pipe (fp16 high/low split, 3 MFMAs per fp32-class product; the split and the range
-// scaling are those of conv_igemm_split_ls).  Same tiling as wgrad_f32<2>: 128 (k) x 128 (co) tile,
+// scaling are those of conv_igemm_split_ls, EXPERIMENTS.md section 2).  Same tiling as wgrad_f32<2>: 128 (k) x 128 (co) tile,
 // reduction over 32-pixel steps, pixel range split over grid.z, fp32 atomics.  Both MFMA operands want 8 consecutive
 // PIXELS of one channel -- a column of the natural [pixel][channel] tile -- so the LDS images stay row-major (fp16 planes,
 // 256-byte pixel rows, 16-byte chunks XOR-swizzled) and the operands come in through ds_read_b64_tr_b16, the hardware
@@ -945,7 +945,7 @@ __global__ __launch_bounds__(256) void wgrad_h3p(const WgradArgs p, const WgradR
 
 // ------------------------------------------------------------------------------------------------
 // wgrad_dma: the 128 x 128 weight-gradient tile with BOTH operands arriving as fp16 high / low cells by LDS-DMA.
-// wgrad_h3p's per-step demand was four units at 30-45 % each: 8 staging loads + their address walk, the
+// wgrad_h3p's per-step demand (EXPERIMENTS.md section 6a (4)) was four units at 30-45 % each: 8 staging loads + their address walk, the
 // fp16 split of 32 values, 16 ds_write_b64, 32 transposed reads and 24 MFMAs per thread.  Here the producers of x and dY have
 // already written the split values (ConvArgs::shadow: the H2 cell layout, [pixel][8 channels: 16 B high | 16 B low]), so a step is
 // 4 DMA instructions (no VGPR round trip, no VALU, no ds_write), the same transposed reads and the same MFMAs.
@@ -1742,7 +1742,7 @@ struct TrainCtx {
     std::unordered_map<const float*, const void*> cells1;      // ... -> its high-only H1 cells (16-bit tier, launch_pack_h1)
     const void* defer_plan = nullptr;            // TPlan of the running backward pass when weight-gradient finalisation is deferred
     char* defer_ws = nullptr;
-    // Weight gradients on a second stream: the data-gradient chain is the critical path of the backward pass
+    // Weight gradients on a second stream (EXPERIMENTS.md section 6a (8)): the data-gradient chain is the critical path of the backward pass
     // and its 11-frame grids leave CUs idle; a layer's weight gradient only needs (x, dY) and is not needed before the finalisation
     // launches, so it runs on `s2` behind an event and the chain goes on.  readers: events recorded on s2 behind the launches that
     // READ a gradient buffer -- the chain waits for them before it overwrites that buffer.
@@ -3323,7 +3323,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
 int dgp_trainer_fast_mode(dgp_trainer* tr, int32_t enable) {
     if (!tr) return fail(DGP_ERR_INVALID, "dgp_trainer_fast_mode: null");
 #ifndef DGP_TUNING
-    // (the H2 form measured no faster than the plain pass, DESIGN.md section 4: an opt-in of tuning builds only; the 16-bit tier's passes use it)
+    // (the H2 form measured no faster than the plain pass, EXPERIMENTS.md section 4: an opt-in of tuning builds only; the 16-bit tier's passes use it)
     if (enable && tr->tier != 1) return fail(DGP_ERR_INVALID, "dgp_trainer_fast_mode: needs dgp_trainer_set_tier(tr, 1) (the H2 fast pass is enabled in -DDGP_TUNING builds only)");
 #endif
     tr->fast_next = enable != 0;

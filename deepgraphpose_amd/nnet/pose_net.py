@@ -12,7 +12,7 @@ The reference functions build TF graph nodes whose variables a Saver fills later
 the calls run eagerly: `inputs` are uint8 / float frames [B,H,W,3] (numpy or device tensor), results are device tensors.
 Every contraction is a HIP kernel: the backbone through DGPNet (dgp_forward), a head applied to caller-supplied features
 through the implicit-GEMM conv kernel as the 2 x 2 convolution over the four output phases of the 3 x 3 / stride-2 SAME
-transposed convolution, the phase interleave being a view + copy.
+transposed convolution (EXPERIMENTS.md section 3), the phase interleave being a view + copy.
 """
 from __future__ import annotations
 

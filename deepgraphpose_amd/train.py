@@ -133,7 +133,7 @@ class Trainer:
     def _fast_begin(self, nt: int) -> bool:
         key = (nt, self.net.in_h, self.net.in_w)
         # (opt-in: at 11 frames the forward convs of blocks 2-4 are grids of 52-208 tiles, paced by one tile's latency rather than by
-        #  operand traffic, and the fast pass measured 12.95-13.09 against 13.01-13.16 ms per step -- DESIGN.md section 6a')
+        #  operand traffic, and the fast pass measured 12.95-13.09 against 13.01-13.16 ms per step -- EXPERIMENTS.md section 6a')
         fast = getattr(self, "_fast_key", None) == key and (
             self.tier == "f16" or                                # the 16-bit tier: every pass after the first of a shape
             (os.environ.get("DGP_TRAIN_H2", "0") == "1" and bool(self.lib.dgp_tuning_build())))      # (H2 fast pass: an opt-in of -DDGP_TUNING builds)

@@ -7,7 +7,7 @@ oracle at run time (minutes of fp32 CPU convolutions): run in the build containe
            (synthetic.make_weights(101, 20, True, seed 41), synthetic.make_frames(16, 720, 1280, 20, seed 42)): soft-argmax mu, window
            indices, likelihoods of all 16 frames, and the same coordinates / indices from the oracle's graph evaluated in float64 (the anchor every fp32
            evaluation order is measured against: with logits of standard deviation 5 on a 90 x 160 map the softmax is broad and two fp32
-           evaluations of this network differ by ~1e-3 px from each other); the scoremap and the locref map sampled at 16 384 seeded positions each + their
+           evaluations of this network differ by ~1e-3 px from each other, EXPERIMENTS.md section 2d); the scoremap and the locref map sampled at 16 384 seeded positions each + their
            maxima (the maps themselves are 18 / 37 MB)
   reach_*  BASELINE configs[1] / [0]: the 55 labeled frames of the reference's Reaching demo project (832 x 747, 15 of them 640 x 470 crops that
            frames.LabeledDirSource resizes) through ResNet-50 with seeded weights (make_weights(50, 5, True, seed 43)): x, y, likelihood,
@@ -47,7 +47,7 @@ def main():
         sc, lr = O.pose_heads(r["features"], wts, True)
         assert np.array_equal(sc, r["scmap"])
         mu.append(r["mu"]); idx.append(r["idx"]); lik.append(r["likelihoods"])
-        r64 = O.infer(frames[i:i + 2], wts, 101, 8.0, 1.0, 1, dtype=np.float64)        # the accuracy anchor
+        r64 = O.infer(frames[i:i + 2], wts, 101, 8.0, 1.0, 1, dtype=np.float64)        # the accuracy anchor (EXPERIMENTS.md section 2d)
         mu64.append(r64["mu"]); idx64.append(r64["idx"])
         for k in range(2):
             sc_s.append(sc[k].reshape(-1)[pos_sc[i + k]]); lr_s.append(lr[k].reshape(-1)[pos_lr[i + k]])

@@ -31,7 +31,7 @@ def test_resnet101_1280x720_20_keypoints_all_16_frames_both_heads(lib_built, G):
     torch.cuda.synchronize()
     assert tuple(sc.shape) == (16, 90, 160, 20) and tuple(lr.shape) == (16, 90, 160, 40)
     # logits of standard deviation ~5 over a 90 x 160 map: a BROAD softmax, the regime in which every fp32 evaluation of this network is
-    # ~1e-3 px from any other -- the gate is the fp64 anchor's: the engine may be as far from the truth as
+    # ~1e-3 px from any other (EXPERIMENTS.md section 2d) -- the gate is the fp64 anchor's: the engine may be as far from the truth as
     # max(1e-3 px, 1.5 x the fp32 CPU oracle's own distance), frame by frame; and it stays within 2.5e-3 px of the fp32 oracle
     got = mu.cpu().numpy().astype(np.float64)
     e_gpu = np.abs(got - G["r101_mu64"]).max((1, 2)) * 8.0
@@ -74,7 +74,7 @@ def test_estimate_pose_on_the_reaching_projects_labeled_frames(lib_built, G, tmp
     assert labels["x"].shape == (T, 5) and T == 246
     which = np.maximum(np.searchsorted(numbers, np.arange(T), side="right") - 1, 0)          # the labeled image frame t shows
     # seeded (untrained) weights on real frames give BROAD scoremaps -- the regime in which fp32 evaluations of this network differ by ~1e-3 px
-    # from each other: the gate is the fp64 anchor's, image by image -- the engine may be as far from the truth as
+    # from each other (EXPERIMENTS.md section 2d): the gate is the fp64 anchor's, image by image -- the engine may be as far from the truth as
     # max(1e-3 px, 1.5 x the fp32 CPU oracle's own distance) -- plus 2.5e-3 px from the fp32 oracle itself
     def dist(ax, ay, bx, by):
         return np.sqrt((ax - bx) ** 2 + (ay - by) ** 2).max(1)

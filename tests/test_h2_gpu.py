@@ -1,4 +1,4 @@
-"""The H2 activation format of the inference engine (include/dgp_hip.h, "H2"): fp16 high / low cell pairs
+"""The H2 activation format of the inference engine (include/dgp_hip.h, "H2"; EXPERIMENTS.md section 3): fp16 high / low cell pairs
 written by the producing epilogue, consumed by K loops that only issue ds_read + MFMA.
 
 Layer tests: fp32 inputs are converted to H2, the conv runs H2 -> H2 (or H2 -> fp32) through the cell kernels, the result is
