@@ -210,3 +210,11 @@ def test_bench_refuses_more_ranks_than_visible_devices():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--no-cpu-baseline"], env=env,
                        capture_output=True, text=True, timeout=240)
     assert r.returncode != 0 and "device(s) visible" in r.stderr
+
+
+def test_readme_numbers_are_generated_from_the_committed_bench_lines():
+    """README.md's table of numbers is the output of scripts/readme_numbers.py over profiles/r<latest>_bench_line*.json -- never typed."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "readme_numbers.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
