@@ -1779,15 +1779,23 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK
         int da = A_CELLS, db = B_CELLS;            // to the other buffer and back (deep ring: to the next stage, wrapping)
         int sb_c = 0; (void)sb_c;
         uint4 ra[2][2], ah[2], al[2], bq[4];
+#if defined(DGP_X) && DGP_X == 7      // timing-only: no MFMAs in the 16x16x32 loop
+        auto mma = [](const uint4& x, const uint4& y, floatx4 cc) { asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w), "v"(y.x), "v"(y.y), "v"(y.z), "v"(y.w)); return cc; };
+#else
         auto mma = [](const uint4& x, const uint4& y, floatx4 cc) {
             return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), cc, 0, 0, 0);
         };
+#endif
 #define DGP_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define DGP_RA(I) do { if constexpr (DMA) {                                                                         \
             ra[I][0] = *reinterpret_cast<const uint4*>(smem + a_cur + (I) * 2048);                                 \
             ra[I][1] = *reinterpret_cast<const uint4*>(smem + (a_cur ^ 16u) + (I) * 2048);                         \
         } else { ra[I][0] = A[16 * (I)]; ra[I][1] = A[LDAF + 16 * (I)]; } } while (0)
+#if defined(DGP_X) && DGP_X == 6      // timing-only: no B fragment reads in the 16x16x32 loop
+#define DGP_RB(F) do { asm volatile("" : "+v"(bq[(F) & 3].x), "+v"(bq[(F) & 3].y), "+v"(bq[(F) & 3].z), "+v"(bq[(F) & 3].w)); } while (0)
+#else
 #define DGP_RB(F) do { bq[(F) & 3] = B[((((F) & 1) ? 0 : 1) * KG) * LDB + 16 * (((F) % NF) >> 1)]; } while (0)
+#endif
 #if defined(DGP_X) && DGP_X == 1      // timing-only stand-in: the A operand as if it arrived pre-split (no split arithmetic)
 #define DGP_SPLIT(I) do { ah[I] = ra[I][0]; al[I] = ra[I][1]; } while (0)
 #else
