@@ -297,7 +297,7 @@ def tier_f16_child(args) -> None:
     torch.cuda.set_device(dev)
     B, K = args.batch, max(8, args.steps)
     wts = make_weights(50, NJ, False, seed=0, head_std=0.05)
-    NS = 1 if args.streams == 1 else 2              # (--streams 1: the rocprofv3 passes of scripts/profile.sh, every launch alone on the chip)
+    NS = max(1, args.streams)                       # (--streams 1: the rocprofv3 passes of scripts/profile.sh, every launch alone on the chip)
     pipe = engine.DGPPipeline(50, NJ, H, W, max_batch=B, device=0, n_streams=NS, tier="f16")
     pipe.load_weights(wts)
     net = pipe.nets[0]
