@@ -1698,6 +1698,186 @@ __global__ void step_status_kernel(const float* __restrict__ losses, int n_losse
     __threadfence_system();
 }
 
+// ------------------------------------------------------------------------------------------------
+// 16-bit tier: the stem's weight gradient with the max-pool's backward fused into its loader (round 5).
+//   dW[(kh, kw, c)][co] = sum over conv1 pixels (n, y, x) of  in[n, 2y + kh - 3, 2x + kw - 3, c] * dC1[n, y, x, co]
+//   dC1[n, y, x, co]    = sum over the <= 4 pool windows q that hold (y, x) of dPool[n, q, co] * [first maximum of (q, co) is (y, x)]
+// The layer-by-layer form wrote dC1 as fp32 (216 MB at 11 frames), read it FOUR times (one per 64-row k-tile of the 64 x 64 fp32 tile) and
+// ran on the fp32 matrix pipe: 0.30 ms, the last launch of the pass, + 0.13 ms for the pool's backward and an fp32 copy of dPool.  Here a
+// workgroup walks items of 4 conv rows x 32 columns: the centred frame patch (13 x 69 pixels) goes to LDS as fp16, dPool (H1 cells, in
+// place) and the first-maximum record of the (up to 4 x 18) pool windows that touch the item go to LDS, dC1 of the item is formed there as fp16
+// [co][pixel], and the four waves (one 16-channel column block each) run v_mfma_f32_16x16x32_f16 over all 13 k-blocks (196 rows padded to
+// 208) with the reduction over the item's 128 pixels -- dC1 never exists in memory, dPool and the record are read once.  The A operand
+// (a k row x 8 pixels of one conv row: stride-2 input columns) is gathered with eight 2-byte LDS reads; a reduction group is 4 rows x 8
+// columns so that the four k-groups of a wave read rows 2 * 74 pixels apart (8 banks: conflict-free).  Partial sums stay in registers over
+// all items of the (persistent) workgroup and are added to dW with float atomics at the end, scaled by 1 / (dPool's predicted scale).
+// ------------------------------------------------------------------------------------------------
+constexpr int STEM_SLAB_ROW = 196 * 64 + 64;
+struct StemWgradArgs {
+    const float* x;              // centred frames [B, H, W, 4] fp32 (preprocess_u8)
+    const uint4* g;              // dPool: H1 cells [B, HP, WP, 64]
+    const unsigned char* idx;    // first-maximum positions [B, HP, WP, 64]
+    const float* g_prev;         // range slots that predict dPool's scale
+    float* slab;                 // [gridDim.x][196 x 64 + 64] fp32: every workgroup's partial dW and column sums (plain stores; 512 workgroups
+                                 // adding to the SAME 50 KB with float atomics took 2.2 ms: 512 serialized updates per address)
+    float* dw;                   // stem_wgrad_reduce_kernel: [49 taps x 4][64] fp32
+    float* colsum;               // [64]
+    int B, H, W, H1, W1, HP, WP, pt, pl, bands, chunks, nitems;
+};
+
+__global__ __launch_bounds__(256) void stem_wgrad_h1_kernel(const StemWgradArgs p) {
+    constexpr int IN_R = 13, IN_C = 74, PR = 4, PC = 18, LDY = 136;      // (4 x 18 pool windows: 3 x 17 when the pool's SAME padding starts at 0, one more when it starts at 1)
+    typedef float floatx4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) uint2 sIn[IN_R * IN_C];                 // 4 halves per input pixel
+    __shared__ __attribute__((aligned(16))) uint4 sG[PR * PC * 8];                  // dPool cells of the item's pool windows
+    __shared__ __attribute__((aligned(16))) uint4 sI[PR * PC * 4];                  // their first-maximum bytes
+    __shared__ __attribute__((aligned(16))) unsigned short sDy[64 * LDY];           // dC1 of the item, [co][pixel = row * 32 + column]
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    floatx4 c[13];
+#pragma unroll
+    for (int kb = 0; kb < 13; ++kb) c[kb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    int kbase[13];                       // half index of this lane's k row inside the patch (-1: padding row)
+#pragma unroll
+    for (int kb = 0; kb < 13; ++kb) {
+        const int kk = 16 * kb + l15, tap = kk >> 2, cc = kk & 3, kh = tap / 7, kw = tap - 7 * kh;
+        kbase[kb] = kk < 196 ? (kh * IN_C + kw) * 4 + cc : -1;
+    }
+    const int o8 = t & 15, co4 = t >> 4;             // dC1 unit of this thread: pixels 8 o8 .. 8 o8 + 7 (one conv row), channels 4 co4 .. + 3
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    const unsigned short* sInH = reinterpret_cast<const unsigned short*>(sIn);
+    const unsigned short* sGH = reinterpret_cast<const unsigned short*>(sG);
+    const unsigned char* sIB = reinterpret_cast<const unsigned char*>(sI);
+    for (int item = blockIdx.x; item < p.nitems; item += gridDim.x) {
+        const int n = item / (p.bands * p.chunks), rem = item - n * (p.bands * p.chunks);
+        const int y0 = (rem / p.chunks) * 4, x0 = (rem % p.chunks) * 32;
+        const int qy0 = (y0 + p.pt) / 2 - 1, qx0 = (x0 + p.pl) / 2 - 1;            // first pool window that can hold (y0, x0)
+        // ---- centred frame patch -> fp16
+        for (int i = t; i < IN_R * IN_C; i += 256) {
+            const int r = i / IN_C, cidx = i - r * IN_C;
+            const int gr = 2 * y0 - 3 + r, gc = 2 * x0 - 3 + cidx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)gr < (unsigned)p.H && (unsigned)gc < (unsigned)p.W)
+                v = *reinterpret_cast<const float4*>(p.x + (((size_t)n * p.H + gr) * p.W + gc) * 4);
+            const half2v a = {(_Float16)v.x, (_Float16)v.y}, b = {(_Float16)v.z, (_Float16)v.w};
+            sIn[i] = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+        }
+        // ---- dPool cells and first-maximum record of the 3 x 17 windows
+        for (int i = t; i < PR * PC * 8; i += 256) {
+            const int lp = i >> 3, cell = i & 7, a = lp / PC, b = lp - a * PC;
+            const int qy = qy0 + a, qx = qx0 + b;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if ((unsigned)qy < (unsigned)p.HP && (unsigned)qx < (unsigned)p.WP) v = p.g[(((size_t)n * p.HP + qy) * p.WP + qx) * 8 + cell];
+            sG[i] = v;
+        }
+        for (int i = t; i < PR * PC * 4; i += 256) {
+            const int lp = i >> 2, part = i & 3, a = lp / PC, b = lp - a * PC;
+            const int qy = qy0 + a, qx = qx0 + b;
+            uint4 v = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+            if ((unsigned)qy < (unsigned)p.HP && (unsigned)qx < (unsigned)p.WP)
+                v = *reinterpret_cast<const uint4*>(p.idx + ((((size_t)n * p.HP + qy) * p.WP + qx) * 64 + part * 16));
+            sI[i] = v;
+        }
+        __syncthreads();
+        // ---- dC1 of the item: this thread's 8 pixels x 4 channels
+        {
+            float dy[8][4];
+            const int yy = o8 >> 2, xb = (o8 & 3) * 8;
+            const int y = y0 + yy;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int x = x0 + xb + e;
+                dy[e][0] = dy[e][1] = dy[e][2] = dy[e][3] = 0.f;
+                if (y < p.H1 && x < p.W1) {
+                    const int qya = max(0, (y + p.pt - 1) / 2), qyb = min(p.HP - 1, (y + p.pt) / 2);
+                    const int qxa = max(0, (x + p.pl - 1) / 2), qxb = min(p.WP - 1, (x + p.pl) / 2);
+                    for (int qy = qya; qy <= qyb; ++qy)
+                        for (int qx = qxa; qx <= qxb; ++qx) {
+                            const unsigned me = (unsigned)((y - (2 * qy - p.pt)) * 3 + (x - (2 * qx - p.pl)));
+                            const int lp = (qy - qy0) * PC + (qx - qx0);
+                            const unsigned k4 = *reinterpret_cast<const unsigned*>(sIB + lp * 64 + 4 * co4);
+                            const uint2 g4 = *reinterpret_cast<const uint2*>(sGH + lp * 64 + 4 * co4);
+                            const half2v g01 = __builtin_bit_cast(half2v, g4.x), g23 = __builtin_bit_cast(half2v, g4.y);
+                            if ((k4 & 0xffu) == me) dy[e][0] += (float)g01[0];
+                            if (((k4 >> 8) & 0xffu) == me) dy[e][1] += (float)g01[1];
+                            if (((k4 >> 16) & 0xffu) == me) dy[e][2] += (float)g23[0];
+                            if ((k4 >> 24) == me) dy[e][3] += (float)g23[1];
+                        }
+                }
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                unsigned w[4];
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    const half2v h = {(_Float16)dy[2 * e2][cc], (_Float16)dy[2 * e2 + 1][cc]};
+                    w[e2] = __builtin_bit_cast(unsigned, h);
+                    cs[cc] += (float)h[0] + (float)h[1];
+                }
+                *reinterpret_cast<uint4*>(sDy + (4 * co4 + cc) * LDY + 8 * o8) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        __syncthreads();
+        // ---- MFMAs: reduction groups of 4 conv rows (k-group g) x 8 columns
+#pragma unroll 1
+        for (int blk = 0; blk < 4; ++blk) {
+            const uint4 bfrag = *reinterpret_cast<const uint4*>(sDy + (16 * wave + l15) * LDY + 32 * g + 8 * blk);
+            const int pbase = ((2 * g) * IN_C + 2 * (8 * blk)) * 4;
+#pragma unroll
+            for (int kb = 0; kb < 13; ++kb) {
+                unsigned w[4] = {0u, 0u, 0u, 0u};
+                if (kbase[kb] >= 0) {
+                    const unsigned short* q = sInH + kbase[kb] + pbase;
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) w[e2] = (unsigned)q[16 * e2] | ((unsigned)q[16 * e2 + 8] << 16);
+                }
+                c[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, make_uint4(w[0], w[1], w[2], w[3])),
+                                                               __builtin_bit_cast(half8, bfrag), c[kb], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- partial sums -> this workgroup's slab row (column sums: reduced over the 16 threads of a channel quad through LDS first)
+    float* row = p.slab + (size_t)blockIdx.x * STEM_SLAB_ROW;
+#pragma unroll
+    for (int kb = 0; kb < 13; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kk = 16 * kb + 4 * g + r;
+            if (kk < 196) row[kk * 64 + 16 * wave + l15] = c[kb][r];
+        }
+    float* red = reinterpret_cast<float*>(sDy);          // (free: the last item's MFMAs are behind a barrier)
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) red[(4 * co4 + cc) * 16 + o8] = cs[cc];
+    __syncthreads();
+    if (t < 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[t * 16 + k];
+        row[196 * 64 + t] = s;
+    }
+}
+
+// sum of the workgroups' slab rows x 1 / (dPool's predicted scale) -> dW and the column sums (both zeroed by the pass): blockIdx.y sums
+// one group of 32 rows with independent loads, the groups meet with float atomics (16-32 per address)
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const StemWgradArgs p, int nrows) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float sg = shadow_scale_for(p.g_prev, threadIdx.x & 63);
+    if (i >= STEM_SLAB_ROW) return;
+    const float inv = sg > 0.f ? 1.f / sg : 0.f;
+    const int r0 = blockIdx.y * 32, r1 = min(nrows, r0 + 32);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        s0 += p.slab[(size_t)r * STEM_SLAB_ROW + i]; s1 += p.slab[(size_t)(r + 1) * STEM_SLAB_ROW + i];
+        s2 += p.slab[(size_t)(r + 2) * STEM_SLAB_ROW + i]; s3 += p.slab[(size_t)(r + 3) * STEM_SLAB_ROW + i];
+    }
+    for (; r < r1; ++r) s0 += p.slab[(size_t)r * STEM_SLAB_ROW + i];
+    const float s = ((s0 + s1) + (s2 + s3)) * inv;
+    if (i < 196 * 64) atomicAdd(p.dw + i, s);
+    else if (p.colsum) atomicAdd(p.colsum + (i - 196 * 64), s);
+}
+
 bool pool_idx_on() { static const bool v = (dgp_tune("DGP_POOL_IDX", 1) != 0); return v; }
 int grid_for(long long n) {
     long long b = (n + 255) / 256;
@@ -3077,6 +3257,13 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
 #ifdef DGP_TUNING
     if (const char* e = getenv("DGP_BWD_STOP")) stop_after = atoi(e);      // debugging aid (tuning builds): leave G of an inner unit in place
 #endif
+    // 16-bit tier with the fused root block: the stem's weight gradient reads d pool as the H1 tensor unit 0 leaves (stem_wgrad_h1_kernel:
+    // pool backward fused, no d conv1 map); A/B switch DGP_TRAIN_STEM_WGRAD_H1=0
+    static const bool stem_wgrad_env = (dgp_env("DGP_TRAIN_STEM_WGRAD_H1", 1) != 0);
+    const bool stem_wgrad_h1 = stem_wgrad_env && h1p && ub == 0 && tr->fwd_stem_fused && pool_idx_on() && g_ctx->defer_plan &&
+                               net->layers[net->conv1].Cout == 64 && net->layers[net->conv1].KH == 7 && net->layers[net->conv1].Cin == 4;
+    const float* stem_g = nullptr;
+    const float* stem_g_prev = nullptr;
     for (int ui = nu - 1; ui >= 0; --ui) {
         if (stop_after >= 0 && (nu - 1 - ui) >= stop_after) {
             if (const char* e2 = getenv("DGP_BWD_DUMP")) {
@@ -3163,7 +3350,11 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
             fmt(true, dxa);
             TRY_HIP(conv_launch(l1, t1.d_wT, t1.nkT, t1.cinP, DR1H, B, h, w, l1.Cout, 0, 0, h, w, l1.Cin, 1, 0, nullptr, nullptr,
                                 dxa, dxa_mode, dxa_h, dxa_w, xinH, false, 0, 0, GinH, s));
-            if (ui == ub) {
+            if (ui == ub && ub == 0 && stem_wgrad_h1) {
+                // (unit 0's data gradient stays H1: the fused stem weight-gradient kernel below reads it in place)
+                stem_g = GinH;
+                stem_g_prev = g_ctx->shadow_prev[GinH];
+            } else if (ui == ub) {
                 // the data gradient leaves the H1 units: fp32 copy for block1's kernels (same range slot: the epilogue tracked max |G| before rounding)
                 float* Gf = G[cur ^ 1];
                 TRY_HIP(before_write(Gf));
@@ -3274,14 +3465,31 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         int ptw = (net->wp - 1) * 2 + 3 - net->w1; if (ptw < 0) ptw = 0;
         const long long tot = (long long)B * net->h1 * net->w1 * 16;
         static const bool pool_idx = (dgp_tune("DGP_POOL_IDX", 1) != 0);
-        if (pool_idx)          // (fused root block in the forward pass: no conv1 map -- unit 0's data gradient is already gated by pool > 0)
+        if (stem_g) {
+            if (fin_split) finalise(0, tr->n_fin - 1, ctx->s2);
+            StemWgradArgs sa{};
+            sa.x = F(pl.p0); sa.g = reinterpret_cast<const uint4*>(stem_g); sa.idx = reinterpret_cast<const unsigned char*>(ws + pl.pidx);
+            sa.g_prev = stem_g_prev;
+            sa.dw = reinterpret_cast<float*>(ws + pl.dw_l[net->conv1]); sa.colsum = reinterpret_cast<float*>(ws + pl.cs_l[net->conv1]);
+            sa.B = B; sa.H = d.in_h; sa.W = d.in_w; sa.H1 = net->h1; sa.W1 = net->w1; sa.HP = net->hp; sa.WP = net->wp; sa.pt = pth / 2; sa.pl = ptw / 2;
+            sa.bands = (net->h1 + 3) / 4; sa.chunks = (net->w1 + 31) / 32; sa.nitems = B * sa.bands * sa.chunks;
+            static int n_cu_s = 0;
+            if (!n_cu_s) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu_s, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu_s <= 0) n_cu_s = 256; }
+            static const int wgs_per_cu = dgp_tune("DGP_STEM_WGRAD_WGS", 2);      // (1: 6.77, 2: 6.72, 3: 6.72, 4: 6.84 ms per step)
+            const int grid = sa.nitems < wgs_per_cu * n_cu_s ? sa.nitems : wgs_per_cu * n_cu_s;
+            sa.slab = F(pl.dc1);                  // (the d conv1 map's region: unused on this path; grid x 50 KB)
+            hipLaunchKernelGGL(stem_wgrad_h1_kernel, dim3((unsigned)grid), dim3(256), 0, s, sa);
+            hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((STEM_SLAB_ROW + 255) / 256, (grid + 31) / 32), dim3(256), 0, s, sa, grid);
+        } else if (pool_idx)          // (fused root block in the forward pass: no conv1 map -- unit 0's data gradient is already gated by pool > 0)
             hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(grid_for(tot)), dim3(256), 0, s, (h1p && tr->fwd_stem_fused) ? (const float*)nullptr : F(pl.c1), G[cur],
                                reinterpret_cast<const uchar4*>(ws + pl.pidx), B, net->h1, net->w1, 64, net->hp, net->wp, pth / 2, ptw / 2,
                                F(pl.dc1));
         else
             hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(tot)), dim3(256), 0, s, F(pl.c1), G[cur], B, net->h1, net->w1, 64,
                                net->hp, net->wp, pth / 2, ptw / 2, F(pl.dc1));
-        if (fin_split) {
+        if (stem_g) {
+            rc = DGP_OK;
+        } else if (fin_split) {
             // the stem's weight gradient (0.3 ms at 11 frames, fp32 MFMA on a 216 MB gradient) is the pass's last launch and nothing else
             // is left to run beside it -- except the finalisation of all OTHER layers: that goes to the second stream behind the last of
             // their weight gradients, the stem's weight gradient to this stream
