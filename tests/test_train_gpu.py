@@ -755,7 +755,8 @@ def _grad_agreement(g, P):
     return cos, rel, per
 
 
-@pytest.mark.parametrize("seed,hw,nt,nj", [(3, (64, 96), 3, 3), (5, (128, 160), 4, 3), (7, (64, 96), 3, 2), (9, (96, 64), 2, 1)])
+@pytest.mark.parametrize("seed,hw,nt,nj", [(3, (64, 96), 3, 3), (5, (128, 160), 4, 3), (7, (64, 96), 3, 2), (9, (96, 64), 2, 1),
+                                           (11, (102, 90), 2, 3)])      # (51 x 45 conv1 map: the pool's SAME padding starts at 1, ragged stem tiles)
 def test_trainer_tier_f16_gradients_against_the_fp64_oracle(lib_built, seed, hw, nt, nj):
     """BASELINE configs[3] names bf16: the 16-bit tier of the training step (Trainer(tier="f16"); dgp_trainer_set_tier).  From the second pass
     of a shape on, blocks 2-4 keep activations and gradient tensors as 2-byte H1 cells with predicted scales, their convs run one MFMA per
