@@ -1,5 +1,7 @@
 """Random training-step configurations (frame size, frames, bodyparts, visible frames, loss variant) against the fp64 autograd oracle.
-Usage: python scripts/fuzz_train.py [n] [seed] [--sequence]
+Usage: python scripts/fuzz_train.py [n] [seed] [--sequence] [--f16]
+--f16: the 16-bit tier (Trainer(tier="f16")): every configuration runs twice -- the first pass of a shape is a parity pass (checked with the
+parity tolerances), the second a 16-bit pass, checked with the tier's (loss 2e-3, gradient L2 5 %, heads 2 %) and for zero repeats.
 --sequence: ONE trainer per (frame size, bodyparts, skeleton) taken through four steps in a row with different frame counts, visible frames, loss
 variants and brightness -- the trainer predicts a step's tensor scales from the previous step's ranges, so nothing stale may survive a change."""
 import os, sys
@@ -13,6 +15,7 @@ from deepgraphpose_amd.synthetic import make_frames, make_weights
 from deepgraphpose_amd.train import Trainer
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 SEQ = "--sequence" in sys.argv
+F16 = "--f16" in sys.argv
 n = int(args[0]) if len(args) > 0 else 10
 rng = np.random.default_rng(int(args[1]) if len(args) > 1 else 0)
 bad = 0
@@ -44,9 +47,12 @@ for k in range(n):
     try:
         P, L = _oracle_grads(wts, frames, batch, S0, ws, ws_max, hy, 300.0, 25.0, dtype=torch.float64)
         if tr is None:
-            tr = Trainer(50, nj, hw[0], hw[1], max_frames=nt_max)
+            tr = Trainer(50, nj, hw[0], hw[1], max_frames=nt_max, tier="f16" if F16 else None)
             tr.load_weights(wts)
         losses = tr.forward_backward(torch.from_numpy(frames).cuda(), batch, hy, S0, ws, ws_max, 300.0, 25.0)
+        redo0 = tr.fast_redos
+        if F16 and not SEQ:      # (second pass of the shape: the 16-bit one)
+            losses = tr.forward_backward(torch.from_numpy(frames).cuda(), batch, hy, S0, ws, ws_max, 300.0, 25.0)
         g = tr.get_grads()
         Lt = float(L["total_loss"].detach())
         e_loss = abs(losses["total_loss"] - Lt) / max(1.0, abs(Lt))
@@ -61,6 +67,10 @@ for k in range(n):
                 head = max(head, np.linalg.norm(d.ravel()) / (np.linalg.norm(ref.ravel()) + 1e-30))
         e_g = np.sqrt(tot_err / max(tot_ref, 1e-300))
         ok = e_loss < 1e-4 and e_g < 1e-2 and head < 1e-4
+        if F16:
+            ok = e_loss < 2e-3 and e_g < 5e-2 and head < 2e-2 and np.all([np.isfinite(v).all() for v in g.values()])
+            if not SEQ:
+                ok = ok and tr.fast_passes == 1 and tr.fast_redos == redo0
     except Exception as e:      # noqa: BLE001
         ok, e_loss, e_g, head = False, -1, -1, -1
         print("   exception:", repr(e)[:300])
