@@ -911,8 +911,17 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
     const __amdgpu_buffer_rsrc_t rs_mask =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((O1 && p.mask) ? p.mask : p.in), 0, (O1 && p.mask) ? (int)p.out_bytes : 0, 0x00020000);
     float amax = 0.f;
-    unsigned ooff[2][VC];
-    uint4 rres[2][VC][2];
+    // PRE (the 16x16x32 loops: the accumulators were staged by the caller and are dead): ALL residual (and gate) cells of the wave's
+    // tile are requested up front -- NQ x VC loads in flight instead of VC, so the memory round trip is paid once per tile, not NQ times
+#ifdef DGP_EPI_NOPRE
+    constexpr bool PRE = false;
+#else
+    constexpr bool PRE = M16;
+#endif
+    constexpr int NS = PRE ? NQ : 2;               // register slots of the residual pipeline
+    unsigned ooff[NS][VC];
+    uint4 rres[NS][VC][O1 ? 1 : 2];
+    uint4 rgate[O1 ? NS : 1][VC];
     auto issue = [&](int q, int slot) {
         const int i = q / CPP, v0 = (q % CPP) * VC;
 #pragma unroll
@@ -935,18 +944,26 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
                 const unsigned roff1 = roff == OOB ? OOB : roff + 16u;
                 if (p.epi_nt & 1) { // streamed once: keep it from evicting the operand rows the other column tiles still need
                     rres[slot][u][0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)roff, 0, 2));
-                    if (!O1) rres[slot][u][1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)roff1, 0, 2));
+                    if (!O1) rres[slot][u][O1 ? 0 : 1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)roff1, 0, 2));
                 } else {
                     rres[slot][u][0] = __builtin_bit_cast(uint4, buf_load16(rs_res, roff));
-                    if (!O1) rres[slot][u][1] = __builtin_bit_cast(uint4, buf_load16(rs_res, roff1));
+                    if (!O1) rres[slot][u][O1 ? 0 : 1] = __builtin_bit_cast(uint4, buf_load16(rs_res, roff1));
                 }
+            }
+            if constexpr (O1 && PRE) {
+                if (p.mask) rgate[slot][u] = __builtin_bit_cast(uint4, buf_load16(rs_mask, ooff[slot][u]));
             }
         }
     };
-    issue(0, 0);
+    if constexpr (PRE) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) issue(q, q);
+    } else {
+        issue(0, 0);
+    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int i = q / CPP, v0 = (q % CPP) * VC, slot = q & 1;
+        const int i = q / CPP, v0 = (q % CPP) * VC, slot = PRE ? q : (q & 1);
         if (q % CPP == 0) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -957,7 +974,7 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        if (q + 1 < NQ) issue(q + 1, slot ^ 1);
+        if constexpr (!PRE) { if (q + 1 < NQ) issue(q + 1, slot ^ 1); }
 #pragma unroll
         for (int u = 0; u < VC; ++u) {
             const int row = my_r0 + (v0 + u) * RPI;
@@ -967,9 +984,9 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
             float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (p.res) {
                 if (O1) h1_unpack8(rres[slot][u][0], res_inv_scale, r);
-                else if (p.res_fmt) h2_unpack8(rres[slot][u][0], rres[slot][u][1], res_inv_scale, r);
+                else if (p.res_fmt) h2_unpack8(rres[slot][u][0], rres[slot][u][O1 ? 0 : 1], res_inv_scale, r);
                 else {
-                    const float4 r0 = __builtin_bit_cast(float4, rres[slot][u][0]), r1 = __builtin_bit_cast(float4, rres[slot][u][1]);
+                    const float4 r0 = __builtin_bit_cast(float4, rres[slot][u][0]), r1 = __builtin_bit_cast(float4, rres[slot][u][O1 ? 0 : 1]);
                     r[0] = r0.x; r[1] = r0.y; r[2] = r0.z; r[3] = r0.w; r[4] = r1.x; r[5] = r1.y; r[6] = r1.z; r[7] = r1.w;
                 }
             }
@@ -980,7 +997,9 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
             }
             if constexpr (O1) {
                 if (p.mask) {          // d/dx of ReLU: pass the gradient where the saved (H1) activation is positive
-                    const half8 g = __builtin_bit_cast(half8, __builtin_bit_cast(uint4, buf_load16(rs_mask, ooff[slot][u])));
+                    uint4 gq;
+                    if constexpr (PRE) gq = rgate[slot][u]; else gq = __builtin_bit_cast(uint4, buf_load16(rs_mask, ooff[slot][u]));
+                    const half8 g = __builtin_bit_cast(half8, gq);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) o[k] = (float)g[k] > 0.f ? o[k] : 0.f;
                 }
