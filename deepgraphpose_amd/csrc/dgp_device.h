@@ -30,6 +30,21 @@ __device__ __forceinline__ void track_absmax(float* slots, float amax, int lane,
     }
 }
 
+// The same with the slot's value already in hand (requested earlier, so that no memory round trip stands at the end of the wave: a
+// stale value costs at most one redundant atomic) and the wave maximum by DPP (quad butterfly, half-row and row mirror: 4 VALU; then one
+// v_readlane per row) instead of six ds_bpermute round trips through the LDS pipe the co-resident workgroup's K loop keeps busy.
+// amax >= 0 (a maximum of |x|): non-negative floats order like their bit patterns, so the maxima are taken on the bits.
+__device__ __forceinline__ void track_absmax_known(float* slots, float amax, int lane, int salt, unsigned known_bits) {
+    int v = (int)__float_as_uint(amax);
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false));       // quad_perm [1, 0, 3, 2]
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false));       // quad_perm [2, 3, 0, 1]
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false));      // row_half_mirror
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false));      // row_mirror
+    const int m = max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+                      max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+    if (lane == 0 && (unsigned)m > known_bits) atomicMax(reinterpret_cast<unsigned*>(slots) + (salt & (ABSMAX_SLOTS - 1)), (unsigned)m);
+}
+
 // max over the slots; every lane of the calling wave gets the value
 __device__ __forceinline__ float read_absmax(const float* slots, int lane) {
     static_assert(ABSMAX_SLOTS == 256, "one float4 per lane");

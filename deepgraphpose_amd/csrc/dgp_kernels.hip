@@ -878,7 +878,15 @@ __device__ __forceinline__ void split3_bf16(const float4 v, uint2& p1, uint2& p2
 // (the 16-bit tier; ConvArgs::out_fmt == 2).
 template <int TM, int TN, int WN, bool M16 = false, bool O1 = false>
 __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc)[TM][TN], char* smem, int wave, int lane,
-                                               int m0, int n0, int wave_m0, int wave_n0, float post) {
+                                               int m0, int n0, int wave_m0, int wave_n0, float post
+#ifdef DGP_DIAG
+                                               , unsigned long long (&eps)[4]      // diagnostic build: set-up | chunk 0 | chunks 1.. | absmax
+#endif
+                                               ) {
+#ifdef DGP_DIAG
+    unsigned long long s0_, s1_, s2_, s3_, s4_;
+    DIAG_STAMP(s0_); s2_ = s0_;
+#endif
     constexpr int OSH = O1 ? 1 : 2;                // log2 bytes per channel of the output / residual tensors
     constexpr int LDC = WN + 4;
     constexpr int C8 = WN / 8;                     // lanes per row
@@ -895,6 +903,13 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
     const int my_c8 = lane % C8, my_r0 = lane / C8;
     const int co8 = n0 + wave_n0 + 8 * my_c8;
     const bool cok = co8 < p.Cout;                 // (Cout % 8 == 0 for every H2 tensor)
+    // The wave's range slot is read NOW (one lane-uniform dword), not behind the last chunk: with the load, its compare and six
+    // ds_bpermute round trips at the END of the wave a tile carried ~1.5 k cycles (of 7-9 k of epilogue) that nothing overlapped --
+    // 16-bit tier 7 980 -> 8 490 frames/s on one stream, parity tier +1.4 % (same box; track_absmax_known)
+    unsigned slot_bits = 0u;
+    if (p.out_absmax)
+        slot_bits = __hip_atomic_load(reinterpret_cast<const unsigned*>(p.out_absmax) + ((int)(blockIdx.x * 8u + (threadIdx.x >> 6)) & (ABSMAX_SLOTS - 1)),
+                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float sc[8], bi[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { sc[k] = post; bi[k] = 0.f; }
@@ -961,8 +976,10 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
     } else {
         issue(0, 0);
     }
+    DIAG_STAMP(s1_);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
+        if (q == 1) DIAG_STAMP(s2_);
         const int i = q / CPP, v0 = (q % CPP) * VC, slot = PRE ? q : (q & 1);
         if (q % CPP == 0) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1024,7 +1041,18 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
             }
         }
     }
-    if (p.out_absmax) track_absmax(p.out_absmax, amax, lane, (int)(blockIdx.x * 8u + (threadIdx.x >> 6)));
+    DIAG_STAMP(s3_);
+    if (p.out_absmax) {
+#ifdef DGP_EPI_OLDMAX
+        track_absmax(p.out_absmax, amax, lane, (int)(blockIdx.x * 8u + (threadIdx.x >> 6)));
+#else
+        track_absmax_known(p.out_absmax, amax, lane, (int)(blockIdx.x * 8u + (threadIdx.x >> 6)), slot_bits);
+#endif
+    }
+#ifdef DGP_DIAG
+    DIAG_STAMP(s4_);
+    eps[0] = s1_ - s0_; eps[1] = s2_ - s1_; eps[2] = s3_ - s2_; eps[3] = s4_ - s3_;
+#endif
 }
 
 // BK = 32: one workgroup per CU (101 KB of LDS for 128 x 128); BK = 16: half the LDS and <= 128 registers, so TWO
@@ -2107,19 +2135,30 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK
 #endif
     }
 #ifdef DGP_DIAG
+    const unsigned long long e_loop_end = e1;        // (16x16x32 loops: the stamp behind the last barrier)
     DIAG_STAMP(e1);
 #endif
     if (part >= 0) {        // raw accumulators of this K-slice -> slab [BM][BN]; tail_fixup sums the slices and applies the epilogue
         ls_store_raw<TM, TN, WN, M16>(acc, smem, wave, lane, wave_m0, wave_n0, p.slab + (size_t)tail_slot * (BM * BN), BN);
         return;
     }
+#ifdef DGP_DIAG
+    unsigned long long eps[4] = {0, 0, 0, 0};
+    if constexpr (OH2) ls_epilogue_h2<TM, TN, WN, M16, H1>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post, eps);
+    else
+#else
     if constexpr (OH2) ls_epilogue_h2<TM, TN, WN, M16, H1>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
-    else ls_epilogue<TM, TN, WN, M16>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
+    else
+#endif
+    ls_epilogue<TM, TN, WN, M16>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
 #ifdef DGP_DIAG
     DIAG_STAMP(e2);
     if (p.dbg && threadIdx.x == 0) {
         unsigned long long* d = p.dbg + 10ull * blockIdx.x;
         d[0] = t_pro; d[1] = acc_mf + acc_ba; d[2] = e2 - e1; d[4] = acc_mf; d[7] = acc_ba;
+        d[9] = e1 - e_loop_end;                       // staging of the accumulators (16x16x32 loops) between the K loop and the epilogue
+        if constexpr (MODE != 3) { d[3] = eps[0]; d[5] = eps[1]; d[6] = eps[2]; d[8] = eps[3]; }     // (MODE 3: slots 3 / 5 / 6 hold the ring wave's stamps)
+        else d[8] = eps[3];
     }
 #endif
 }
@@ -2474,7 +2513,9 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
                "ldsread+mfma %.0f barrier-wait %.0f || loader wave: wait+split+ds_write %.0f load-issue %.0f barrier-wait %.0f\n",
                BM, BN, NT, BK, CW, nwg, nks, v[0], v[2], v[4] / nks, v[7] / nks, v[3] / nks, v[5] / nks, v[6] / nks);
         double v8 = 0; for (long long b = 0; b < nwg; ++b) v8 += (double)h[10 * b + 8];
-        printf("[diag epilogue, DMA kernels] scale/bias + staging %.0f | chunk 0 %.0f | chunks 1.. %.0f | absmax + drain %.0f (res %d)\n", v[3], v[5], v[6], v8 / nwg, a.res ? 1 : 0);
+        double v9 = 0; for (long long b = 0; b < nwg; ++b) v9 += (double)h[10 * b + 9];
+        printf("[diag epilogue, DMA kernels] last MFMAs + staging %.0f | set-up (scale / bias, residual requests) %.0f | chunk 0 %.0f | chunks 1.. %.0f | absmax %.0f (res %d)\n",
+               v9 / nwg, v[3], v[5], v[6], v8 / nwg, a.res ? 1 : 0);
     }
 #endif
     return hipGetLastError();

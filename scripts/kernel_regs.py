@@ -18,4 +18,4 @@ names = subprocess.run(["/usr/bin/c++filt"] + [r["name"] for r in rows], capture
 for r, n in zip(rows, names):
     n = n.replace("dgp::", "").split("(")[0]
     if re.search(pat, n):
-        print("%-110s vgpr %4s agpr %3s spill %3s occ %s lds %s" % (n[:110], r.get("VGPRs"), r.get("AGPRs"), r.get("VGPRs Spill"), r.get("Occupancy [waves/SIMD]"), r.get("LDS Size [bytes/block]")))
+        print("%-110s vgpr %4s agpr %3s spill %3s occ %s scratch %s" % (n[:110], r.get("VGPRs"), r.get("AGPRs"), r.get("VGPRs Spill"), r.get("Occupancy [waves/SIMD]"), r.get("ScratchSize [bytes/lane]")))
