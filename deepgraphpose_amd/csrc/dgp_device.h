@@ -16,43 +16,43 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned 
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
+// Wave-wide maximum of NON-NEGATIVE floats (maxima of |x|: they order like their bit patterns) by DPP -- quad butterfly, half-row and
+// row mirror: 4 VALU; then one v_readlane per row -- instead of six ds_bpermute round trips through the LDS pipe the co-resident
+// workgroup's K loop keeps busy.  Wave-uniform result (lives in an SGPR).
+__device__ __forceinline__ unsigned wave_max_bits(float x) {
+    int v = (int)__float_as_uint(x);
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false));       // quad_perm [1, 0, 3, 2]
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false));       // quad_perm [2, 3, 0, 1]
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false));      // row_half_mirror
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false));      // row_mirror
+    return (unsigned)max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+                         max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
 // Range tracking for the fp16-split kernels.  A tensor's max |x| lives in ABSMAX_SLOTS device floats (the maximum of
 // the slots is the value): producers spread their atomics over the slots -- tens of thousands of waves maxing into
 // ONE address serialise at the memory side (measured: a 0.3 ms layer became 0.9 ms) -- and skip the atomic when the
 // slot already holds a value at least as large.  Non-negative floats order like their bit patterns.
 __device__ __forceinline__ void track_absmax(float* slots, float amax, int lane, int salt) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const unsigned bits = wave_max_bits(amax);
     if (lane == 0) {
         unsigned* s = reinterpret_cast<unsigned*>(slots) + (salt & (ABSMAX_SLOTS - 1));
-        const unsigned bits = __float_as_uint(amax);
         if (bits > __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(s, bits);
     }
 }
 
-// The same with the slot's value already in hand (requested earlier, so that no memory round trip stands at the end of the wave: a
-// stale value costs at most one redundant atomic) and the wave maximum by DPP (quad butterfly, half-row and row mirror: 4 VALU; then one
-// v_readlane per row) instead of six ds_bpermute round trips through the LDS pipe the co-resident workgroup's K loop keeps busy.
-// amax >= 0 (a maximum of |x|): non-negative floats order like their bit patterns, so the maxima are taken on the bits.
+// track_absmax with the slot's value already in hand (requested earlier, so that no memory round trip stands at the end of the wave: a
+// stale value costs at most one redundant atomic).
 __device__ __forceinline__ void track_absmax_known(float* slots, float amax, int lane, int salt, unsigned known_bits) {
-    int v = (int)__float_as_uint(amax);
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false));       // quad_perm [1, 0, 3, 2]
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false));       // quad_perm [2, 3, 0, 1]
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false));      // row_half_mirror
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false));      // row_mirror
-    const int m = max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-                      max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-    if (lane == 0 && (unsigned)m > known_bits) atomicMax(reinterpret_cast<unsigned*>(slots) + (salt & (ABSMAX_SLOTS - 1)), (unsigned)m);
+    const unsigned m = wave_max_bits(amax);
+    if (lane == 0 && m > known_bits) atomicMax(reinterpret_cast<unsigned*>(slots) + (salt & (ABSMAX_SLOTS - 1)), m);
 }
 
 // max over the slots; every lane of the calling wave gets the value
 __device__ __forceinline__ float read_absmax(const float* slots, int lane) {
     static_assert(ABSMAX_SLOTS == 256, "one float4 per lane");
     const float4 v = reinterpret_cast<const float4*>(slots)[lane];
-    float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    return m;
+    return __uint_as_float(wave_max_bits(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w))));      // (slots hold maxima of |x|: non-negative, never NaN)
 }
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));

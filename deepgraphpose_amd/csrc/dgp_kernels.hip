@@ -878,7 +878,7 @@ __device__ __forceinline__ void split3_bf16(const float4 v, uint2& p1, uint2& p2
 // (the 16-bit tier; ConvArgs::out_fmt == 2).
 template <int TM, int TN, int WN, bool M16 = false, bool O1 = false>
 __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc)[TM][TN], char* smem, int wave, int lane,
-                                               int m0, int n0, int wave_m0, int wave_n0, float post
+                                               int m0, int n0, int wave_m0, int wave_n0, float post, float out_scale, float res_inv_scale
 #ifdef DGP_DIAG
                                                , unsigned long long (&eps)[4]      // diagnostic build: set-up | chunk 0 | chunks 1.. | absmax
 #endif
@@ -921,7 +921,8 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
         const float4 a = *reinterpret_cast<const float4*>(p.bias + co8), b = *reinterpret_cast<const float4*>(p.bias + co8 + 4);
         bi[0] = a.x; bi[1] = a.y; bi[2] = a.z; bi[3] = a.w; bi[4] = b.x; bi[5] = b.y; bi[6] = b.z; bi[7] = b.w;
     }
-    const float out_scale = h2_out_scale(p, lane), res_inv_scale = p.res_fmt ? h2_res_inv_scale(p, lane) : 1.f;
+    // (out_scale / res_inv_scale: the tensors' scales, read by the caller BEFORE its K loop -- in the trainer they are predictions from range
+    //  slots, a load and a wave reduction each, which stood in front of the first chunk of every tile)
     // O1 only (the 16-bit trainer's data-gradient convs): ReLU gate read from an H1 tensor of the output's shape (gate = stored half > 0)
     const __amdgpu_buffer_rsrc_t rs_mask =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((O1 && p.mask) ? p.mask : p.in), 0, (O1 && p.mask) ? (int)p.out_bytes : 0, 0x00020000);
@@ -1690,6 +1691,8 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK
     const float scA_c = (CS && !AH2) ? pow2_scale_for(p.in_absmax, lane, p.in2_absmax) : 1.f;       // operand scale of the compute-side split
     // exact power of two that undoes the fp16 operand scales; read now, while this wave waits for the first tile anyway
     const float post = (NT == 2 && part < 0) ? 1.f / ((AH2 ? h2_in_scale(p, lane) : pow2_scale_for(p.in_absmax, lane, p.in2_absmax)) * pow2_scale_for(p.w_absmax, lane)) : 1.f;
+    // scales of the H2 / H1 output and residual tensors (wave-uniform; host floats in the inference engine, predictions from range slots in the trainer)
+    const float epi_out_scale = OH2 ? h2_out_scale(p, lane) : 1.f, epi_res_inv_scale = (OH2 && p.res_fmt) ? h2_res_inv_scale(p, lane) : 1.f;
 #ifdef DGP_DIAG
     unsigned long long e0, e1, e2, e3, acc_mf = 0, acc_ba = 0;
     DIAG_STAMP(e0);
@@ -2144,10 +2147,10 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK
     }
 #ifdef DGP_DIAG
     unsigned long long eps[4] = {0, 0, 0, 0};
-    if constexpr (OH2) ls_epilogue_h2<TM, TN, WN, M16, H1>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post, eps);
+    if constexpr (OH2) ls_epilogue_h2<TM, TN, WN, M16, H1>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post, epi_out_scale, epi_res_inv_scale, eps);
     else
 #else
-    if constexpr (OH2) ls_epilogue_h2<TM, TN, WN, M16, H1>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
+    if constexpr (OH2) ls_epilogue_h2<TM, TN, WN, M16, H1>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post, epi_out_scale, epi_res_inv_scale);
     else
 #endif
     ls_epilogue<TM, TN, WN, M16>(p, acc, smem, wave, lane, m0, n0, wave_m0, wave_n0, post);
