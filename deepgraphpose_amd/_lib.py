@@ -90,6 +90,8 @@ SYMBOLS = {
     "dgp_conv2d_h1": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "dgp_chain_h2": (C.c_int, [_i32] * 9 + [_vp, _i32, _vp, _i32] + [_vp] * 6 + [_vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     "dgp_unit_h2": (C.c_int, [_i32] * 7 + [_vp, _i32, _vp, _i32] + [_vp] * 3 + [_i32] + [_vp] * 6 + [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "dgp_chain_h1": (C.c_int, [_i32] * 9 + [_vp, _i32, _vp, _i32] + [_vp] * 6 + [_vp, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "dgp_unit_h1": (C.c_int, [_i32] * 7 + [_vp, _i32, _vp, _i32] + [_vp] * 3 + [_i32] + [_vp] * 6 + [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "dgp_net_range_status": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), _vp]),
     "dgp_net_recalibrate": (C.c_int, [_vp]),
     "dgp_net_widen": (C.c_int, [_vp]),

@@ -79,7 +79,7 @@ __device__ unsigned long long g_unit_diag[16];
 #endif
 
 // residual cells of chunk jp (32 channels of X) for the wave's RB row blocks -> res; chain_prefetch: the first PD - 1 chunks of a tile
-template <int RES, int RB>
+template <int RES, int RB, bool H1 = false>
 __device__ __forceinline__ void chain_fetch_res(const ChainArgs& p, uint4 (&res)[RB][2], const unsigned (&roff)[RB],
                                                 const __amdgpu_buffer_rsrc_t rs_s2, int jp) {
 #if defined(DGP_UX) && (DGP_UX & 1)      // timing-only ablation (scripts/diag_unit.sh): no residual loads
@@ -89,7 +89,9 @@ __device__ __forceinline__ void chain_fetch_res(const ChainArgs& p, uint4 (&res)
     if constexpr (RES != 0) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            if (p.nt & 1) {
+            if constexpr (H1) {                    // one 16-byte cell per 8 channels: chunk jp's 32 channels are 64 bytes of the pixel row
+                res[rb][0] = (p.nt & 1) ? ld16nt(rs_s2, roff[rb], jp * 64) : ld16(rs_s2, roff[rb], jp * 64);
+            } else if (p.nt & 1) {
                 res[rb][0] = ld16nt(rs_s2, roff[rb], jp * 128);
                 res[rb][1] = ld16nt(rs_s2, roff[rb], jp * 128 + 16);
             } else {
@@ -99,17 +101,19 @@ __device__ __forceinline__ void chain_fetch_res(const ChainArgs& p, uint4 (&res)
         }
     }
 }
-template <int RES, int RB, int PD>
+template <int RES, int RB, int PD, bool H1 = false>
 __device__ __forceinline__ void chain_prefetch(const ChainArgs& p, uint4 (&res)[PD][RB][2], const unsigned (&roff)[RB],
                                                const __amdgpu_buffer_rsrc_t rs_s2) {
 #pragma unroll
-    for (int u = 0; u < PD - 1; ++u) chain_fetch_res<RES, RB>(p, res[u], roff, rs_s2, u);
+    for (int u = 0; u < PD - 1; ++u) chain_fetch_res<RES, RB, H1>(p, res[u], roff, rs_s2, u);
 }
 
 // conv3 (+ shortcut, ReLU) -> X' -> conv1 -> R1' for the RB row blocks of one wave, one weight chunk per 32 channels of X'
 // (the ring protocol is the caller's: `slot` is the chunk to read first, one barrier per chunk).  ph / pl: the B-operand fragments
 // (pixel lane & 15, k-group lane >> 4) of conv3's K-steps -- R2 first, then the K-concatenated source.
-template <int C, int C1, int CIN2, int RES, int RB, int NS, int PD, int CHUNK, int WR>
+// H1 (the 16-bit tier): every tensor is an H1 tensor (one 16-byte cell of 8 halves per 8 channels), the weight chunks are the SAME
+// chunks -- only their high fragments are read -- and a product is one MFMA: pl is not used, X' / R1' leave as single cells.
+template <int C, int C1, int CIN2, int RES, int RB, int NS, int PD, int CHUNK, int WR, bool H1 = false>
 __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring, int& slot, const uint4 (&ph)[RB][(C + CIN2) / 32],
                                            const uint4 (&pl)[RB][(C + CIN2) / 32], const unsigned (&xoff)[RB], const unsigned (&roff)[RB],
                                            const unsigned (&r1off)[RB], const __amdgpu_buffer_rsrc_t rs_s2, const __amdgpu_buffer_rsrc_t rs_xo,
@@ -119,7 +123,8 @@ __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring
     unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
 #endif
     constexpr int C4 = 4 * C, KS1 = (C + CIN2) / 32, NJP = C4 / 32, NCB = C1 / 16;
-    constexpr int F1 = KS1 * 4, F2 = NCB * 2;
+    constexpr int PL = H1 ? 1 : 2;                 // fragments per weight block: [hi][lo], or the high fragment alone (the 16-bit tier's chunks)
+    constexpr int F1 = KS1 * 2 * PL, F2 = NCB * PL;
     static_assert(WR >= 2 && WR % 2 == 0, "weight fragments in flight: pairs share the ring");
     static_assert(NJP % PD == 0 && PD >= 2, "chunk loop is unrolled PD times");
     const int g = lane >> 4;
@@ -129,7 +134,8 @@ __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) a2[rb][cb] = floatx4{0.f, 0.f, 0.f, 0.f};
     // (the caller has issued the residual loads of chunks 0 .. PD - 2 into res[0 .. PD - 2]: chain_prefetch)
-    auto fetch_res = [&](int jp, int buf) { chain_fetch_res<RES, RB>(p, res[buf], roff, rs_s2, jp); };
+    auto fetch_res = [&](int jp, int buf) { chain_fetch_res<RES, RB, H1>(p, res[buf], roff, rs_s2, jp); };
+    constexpr int CB = H1 ? 64 : 128;              // bytes of 32 channels of one pixel
     for (int jp0 = 0; jp0 < NJP; jp0 += PD) {
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
@@ -153,17 +159,19 @@ __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring
             for (int s = 0; s < KS1; ++s)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    const int f0 = (s * 2 + b) * 2;
-                    const uint4 wh = wq[f0 % WR], wl = wq[(f0 + 1) % WR];
+                    const int f0 = (s * 2 + b) * PL;
+                    const uint4 wh = wq[f0 % WR], wl = wq[(f0 + PL - 1) % WR];
+                    if constexpr (!H1) {
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb) a1[rb][b] = mma16(wl, ph[rb][s], a1[rb][b]);
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb) a1[rb][b] = mma16(wh, pl[rb][s], a1[rb][b]);
+                    }
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb) a1[rb][b] = mma16(wh, ph[rb][s], a1[rb][b]);
                     __builtin_amdgcn_sched_barrier(0);
                     if (f0 + WR < F1 + F2) wq[f0 % WR] = W[(f0 + WR) * 64];
-                    if (f0 + 1 + WR < F1 + F2) wq[(f0 + 1) % WR] = W[(f0 + 1 + WR) * 64];
+                    if (PL == 2 && f0 + 1 + WR < F1 + F2) wq[(f0 + 1) % WR] = W[(f0 + 1 + WR) * 64];
                     __builtin_amdgcn_sched_barrier(0);
                 }
             // ---- epilogue of conv3 = operand of conv1: BN affine (x the power of two that undoes the operand scales), shortcut,
@@ -178,24 +186,28 @@ __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 float o[8], r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if constexpr (RES != 0) h2_unpack8(res[u][rb][0], res[u][rb][1], p.res_inv_scale, r);
+                if constexpr (RES != 0) {
+                    if constexpr (H1) h1_unpack8(res[u][rb][0], p.res_inv_scale, r);
+                    else h2_unpack8(res[u][rb][0], res[u][rb][1], p.res_inv_scale, r);
+                }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     o[k] = a1[rb][k >> 2][k & 3] * sc[k] + bi[k] + r[k];
                     o[k] = fmaxf(o[k], 0.f);
                 }
-                h2_pack8(o, p.xout_scale, xh[rb], xl[rb]);
+                if constexpr (H1) { xh[rb] = h1_pack8(o, p.xout_scale); xl[rb] = xh[rb]; }
+                else h2_pack8(o, p.xout_scale, xh[rb], xl[rb]);
 #if defined(DGP_UX) && (DGP_UX & 2)      // timing-only ablation: no X' stores
                 if (p.nt == 77) {
 #else
                 if (p.nt & 2) {
 #endif
-                    st16nt(rs_xo, xh[rb], xoff[rb], jp * 128);
-                    st16nt(rs_xo, xl[rb], xoff[rb], jp * 128 + 16);
+                    st16nt(rs_xo, xh[rb], xoff[rb], jp * CB);
+                    if constexpr (!H1) st16nt(rs_xo, xl[rb], xoff[rb], jp * CB + 16);
                 } else {
 #if !(defined(DGP_UX) && (DGP_UX & 2))
-                    st16(rs_xo, xh[rb], xoff[rb], jp * 128);
-                    st16(rs_xo, xl[rb], xoff[rb], jp * 128 + 16);
+                    st16(rs_xo, xh[rb], xoff[rb], jp * CB);
+                    if constexpr (!H1) st16(rs_xo, xl[rb], xoff[rb], jp * CB + 16);
 #endif
                 }
                 if (xoff[rb] != OOB) {
@@ -208,17 +220,19 @@ __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
-                const int f0 = F1 + cb * 2;
-                const uint4 wh = wq[f0 % WR], wl = wq[(f0 + 1) % WR];
+                const int f0 = F1 + cb * PL;
+                const uint4 wh = wq[f0 % WR], wl = wq[(f0 + PL - 1) % WR];
+                if constexpr (!H1) {
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) a2[rb][cb] = mma16(wl, xh[rb], a2[rb][cb]);
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) a2[rb][cb] = mma16(wh, xl[rb], a2[rb][cb]);
+                }
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) a2[rb][cb] = mma16(wh, xh[rb], a2[rb][cb]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (f0 + WR < F1 + F2) wq[f0 % WR] = W[(f0 + WR) * 64];
-                if (f0 + 1 + WR < F1 + F2) wq[(f0 + 1) % WR] = W[(f0 + 1 + WR) * 64];
+                if (PL == 2 && f0 + 1 + WR < F1 + F2) wq[(f0 + 1) % WR] = W[(f0 + 1 + WR) * 64];
                 __builtin_amdgcn_sched_barrier(0);
             }
             slot = slot + 1 == NS ? 0 : slot + 1;
@@ -247,10 +261,14 @@ __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring
             float o[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = fmaxf(a2[rb][2 * q + (k >> 2)][k & 3] * sc[k] + bi[k], 0.f);
+            if constexpr (H1) {
+                st16(rs_r1, h1_pack8(o, p.r1_scale), r1off[rb], q * CB);
+            } else {
             uint4 hi, lo;
             h2_pack8(o, p.r1_scale, hi, lo);
             st16(rs_r1, hi, r1off[rb], q * 128);
             st16(rs_r1, lo, r1off[rb], q * 128 + 16);
+            }
             if (r1off[rb] != OOB) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) amax_r1 = fmaxf(amax_r1, o[k]);
@@ -269,13 +287,15 @@ __device__ __forceinline__ void chain_tail(const ChainArgs& p, const uint4* ring
 // RES   0 none (CIN2 > 0), 1 residual on the same pixel grid, 2 residual[n, 2 ho, 2 wo] (subsample of a stride-2 unit)
 // RB    16-row blocks per wave (1 or 2); NCW compute waves, NLW loader waves, NS ring slots, PD residual buffers (PD - 1 chunks ahead),
 //       WR weight fragments in flight per wave
-template <int C, int C1, int CIN2, int RES, int RB, int NCW, int NLW, int NS, int PD, int WR>
+template <int C, int C1, int CIN2, int RES, int RB, int NCW, int NLW, int NS, int PD, int WR, bool H1 = false>
 __global__ __launch_bounds__(64 * (NCW + NLW)) void chain_kernel(const ChainArgs p) {
     constexpr int C4 = 4 * C;
+    constexpr int EB = H1 ? 2 : 4;                                     // bytes per channel of the activation tensors
     constexpr int KSA = C / 32, KSB = CIN2 / 32, KS1 = KSA + KSB;      // K-steps of conv3: R2, then the second source
     constexpr int NJP = C4 / 32;                                       // chunks per tile
     constexpr int NCB = C1 / 16;                                       // 16-channel blocks of conv1's output
-    constexpr int F1 = KS1 * 4, F2 = NCB * 2, NF = F1 + F2 + 1;        // 1-KiB fragments per chunk: conv3 [s][b][plane], conv1 [cb][plane], affine
+    constexpr int PL = H1 ? 1 : 2;                                     // planes per weight block in the chunks (H1: the high fragments alone)
+    constexpr int F1 = KS1 * 2 * PL, F2 = NCB * PL, NF = F1 + F2 + 1;  // 1-KiB fragments per chunk: conv3 [s][b][plane], conv1 [cb][plane], affine
     constexpr int CHUNK = NF * 1024;
     constexpr int TILE = 16 * RB * NCW;
     static_assert(NJP % PD == 0 && PD >= 2, "chunk loop is unrolled PD times");
@@ -353,27 +373,33 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void chain_kernel(const ChainArgs
         for (int rb = 0; rb < RB; ++rb) {
             const int m = t * TILE + (wave * RB + rb) * 16 + l15;
             const bool ok = m < p.M;
-            xoff[rb] = ok ? (unsigned)m * (unsigned)(C4 * 4) + (unsigned)(g * 32) : OOB;
-            r1off[rb] = ok ? (unsigned)m * (unsigned)(C1 * 4) + (unsigned)(g * 32) : OOB;
+            xoff[rb] = ok ? (unsigned)m * (unsigned)(C4 * EB) + (unsigned)(g * 8 * EB) : OOB;
+            r1off[rb] = ok ? (unsigned)m * (unsigned)(C1 * EB) + (unsigned)(g * 8 * EB) : OOB;
             if (RES == 2) {
                 const int n = m / p.HoWo, rem = m - n * p.HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                roff[rb] = ok ? (unsigned)((n * p.res_H + 2 * ho) * p.res_W + 2 * wo) * (unsigned)(C4 * 4) + (unsigned)(g * 32) : OOB;
+                roff[rb] = ok ? (unsigned)((n * p.res_H + 2 * ho) * p.res_W + 2 * wo) * (unsigned)(C4 * EB) + (unsigned)(g * 8 * EB) : OOB;
             } else roff[rb] = xoff[rb];
-            const unsigned aoff = ok ? (unsigned)m * (unsigned)(C * 4) + (unsigned)(g * 32) : OOB;
+            const unsigned aoff = ok ? (unsigned)m * (unsigned)(C * EB) + (unsigned)(g * 8 * EB) : OOB;
 #pragma unroll
-            for (int s = 0; s < KSA; ++s) { ph[rb][s] = ld16(rs_r2, aoff, s * 128); pl[rb][s] = ld16(rs_r2, aoff, s * 128 + 16); }
+            for (int s = 0; s < KSA; ++s) {
+                ph[rb][s] = ld16(rs_r2, aoff, s * 32 * EB);
+                if constexpr (H1) pl[rb][s] = ph[rb][s]; else pl[rb][s] = ld16(rs_r2, aoff, s * 128 + 16);
+            }
             if constexpr (KSB > 0) {
-                const unsigned boff = ok ? (unsigned)m * (unsigned)(CIN2 * 4) + (unsigned)(g * 32) : OOB;
+                const unsigned boff = ok ? (unsigned)m * (unsigned)(CIN2 * EB) + (unsigned)(g * 8 * EB) : OOB;
 #pragma unroll
-                for (int s = 0; s < KSB; ++s) { ph[rb][KSA + s] = ld16(rs_s2, boff, s * 128); pl[rb][KSA + s] = ld16(rs_s2, boff, s * 128 + 16); }
+                for (int s = 0; s < KSB; ++s) {
+                    ph[rb][KSA + s] = ld16(rs_s2, boff, s * 32 * EB);
+                    if constexpr (H1) pl[rb][KSA + s] = ph[rb][KSA + s]; else pl[rb][KSA + s] = ld16(rs_s2, boff, s * 128 + 16);
+                }
             }
         }
         uint4 res[PD][RB][2];
-        chain_prefetch<RES, RB, PD>(p, res, roff, rs_s2);
+        chain_prefetch<RES, RB, PD, H1>(p, res, roff, rs_s2);
 #ifdef DGP_DIAG
         unsigned long long ud[12] = {0};
 #endif
-        chain_tail<C, C1, CIN2, RES, RB, NS, PD, CHUNK, WR>(p, ring, slot, ph, pl, xoff, roff, r1off, rs_s2, rs_xo, rs_r1, amax_x, amax_r1, lane, res UD_ARG);
+        chain_tail<C, C1, CIN2, RES, RB, NS, PD, CHUNK, WR, H1>(p, ring, slot, ph, pl, xoff, roff, r1off, rs_s2, rs_xo, rs_r1, amax_x, amax_r1, lane, res UD_ARG);
 #ifdef DGP_DIAG
         if (wave == 0 && lane == 0) {
             for (int i = 4; i < 9; ++i) atomicAdd(&g_unit_diag[i], ud[i]);
@@ -403,7 +429,10 @@ __global__ __launch_bounds__(64 * (NCW + NLW)) void chain_kernel(const ChainArgs
 // Weights: 9 chunks for conv2 (one tap each: [ks][cb][plane] fragments + conv2's BN affine) followed by the chain's chunks, through
 // the same ring; 9 + 8 barriers per tile.
 // Tiles are dealt so that workgroups on one XCD (blockIdx & 7) work on neighbouring tiles: halo rows are re-read from that L2.
-template <int C, int C1, int CIN2, int RES, int NCW, int NLW, int PD, int WR, int HWV = 1>
+// H1 (the 16-bit tier): all tensors are H1, a halo pixel is 128 B = 8 slots (cell c in slot c), two pixels per row of LDS banks, so slot s
+// of pixel hp is stored at s ^ ((hp >> 1) & 7): 16 consecutive pixels of one cell then cover the 16 bank groups once.  One DMA instruction
+// fills 8 pixels (lane L: slot L & 7 of pixel 8 i + (L >> 3)).  Weight chunks as in the parity tier, high fragments only.
+template <int C, int C1, int CIN2, int RES, int NCW, int NLW, int PD, int WR, int HWV = 1, bool H1 = false>
 __global__ __launch_bounds__(64 * (NCW + NLW + HWV)) void unit_kernel(const ChainArgs p) {
     // NLW weight-loader waves + HWV (0 / 1) halo wave.  Round 4: with the halo pieces in the weight loaders' queues (HWV = 0) the weight
     // stream waits behind them -- a wave's vector-memory operations return in order, the halo pieces come from HBM / the Infinity Cache,
@@ -411,16 +440,19 @@ __global__ __launch_bounds__(64 * (NCW + NLW + HWV)) void unit_kernel(const Chai
     // (scripts/ablate_unit.sh).  The halo wave gets a part of that back where the launch is not HBM-bound (launch_unit).
     constexpr int NS = 3;
     constexpr int TH = NCW, TW = 16, HW = TW + 2, HPIX = (TH + 2) * HW;
-    constexpr int PIXB = C * 4;
-    static_assert(C == 64, "one pixel of R1 = 16 slots of 16 bytes (the bank swizzle)");
+    constexpr int EB = H1 ? 2 : 4;
+    constexpr int PIXB = C * EB;
+    constexpr int PPI = 1024 / PIXB;                                // halo pixels per DMA instruction (4; H1: 8)
+    static_assert(C == 64, "one pixel of R1 = 16 (H1: 8) slots of 16 bytes (the bank swizzle)");
     constexpr int NHI = (HPIX * PIXB + 1023) / 1024;               // DMA instructions per halo tile (4 pixels each; the last may run past
     constexpr int HALO_BYTES = NHI * 1024;                         // the tile: those lanes are out of range and write zeros into the pad)
     static_assert(NLW == 1 || NLW == 2 || NLW == 4, "one, two or four weight-loader waves");
     static_assert(HWV == 0 || HWV == 1, "at most one halo wave");
     constexpr int NHW = HWV ? 1 : NLW;                              // waves that share a halo tile's instructions
     constexpr int C4 = 4 * C, KS1 = (C + CIN2) / 32, NJP = C4 / 32, NCB = C1 / 16;
-    constexpr int NFJ = KS1 * 4 + NCB * 2 + 1;                      // fragments of a chain chunk
-    constexpr int KS2 = C / 32, NCB2 = C / 16, NF2 = KS2 * NCB2 * 2 + 1;      // conv2: fragments per tap + the affine fragment
+    constexpr int PL = H1 ? 1 : 2;                                  // planes per weight block in the chunks (H1: the high fragments alone)
+    constexpr int NFJ = (KS1 * 2 + NCB) * PL + 1;                   // fragments of a chain chunk
+    constexpr int KS2 = C / 32, NCB2 = C / 16, NF2 = KS2 * NCB2 * PL + 1;     // conv2: fragments per tap + the affine fragment
     constexpr int NFMAX = NFJ > NF2 ? NFJ : NF2, CHUNK = NFMAX * 1024;
     constexpr int STEPS = 9 + NJP;
     // halo instructions issued per pointwise step; the halo wave is done one step before the tile ends, so that its wait at the tile's
@@ -448,11 +480,12 @@ __global__ __launch_bounds__(64 * (NCW + NLW + HWV)) void unit_kernel(const Chai
             const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.r1in), 0, (int)p.r1in_bytes, 0x00020000);
             const int f = tile / tpf, rem = tile - f * tpf, ty = rem / p.TX, tx = rem - ty * p.TX;
             for (int i = i0 + hl; i < i1; i += NHW) {
-                const int hp = 4 * i + (lane >> 4);
+                const int hp = PPI * i + (H1 ? (lane >> 3) : (lane >> 4));
                 const int hy = (hp * 57) >> 10, hx = hp - HW * hy;                 // hp / 18 (exact for hp < 400)
                 const int gy = ty * TH - 1 + hy, gx = tx * TW - 1 + hx;
                 const bool ok = hp < HPIX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-                const unsigned off = ok ? (unsigned)((f * p.H + gy) * p.W + gx) * (unsigned)PIXB + (unsigned)((((lane & 15) ^ (hp & 15))) << 4) : OOB;
+                const unsigned cell = H1 ? (unsigned)((lane & 7) ^ ((hp >> 1) & 7)) : (unsigned)((lane & 15) ^ (hp & 15));
+                const unsigned off = ok ? (unsigned)((f * p.H + gy) * p.W + gx) * (unsigned)PIXB + (cell << 4) : OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(halo + i * 1024), 16, (int)off, 0, 0, 0);
             }
         };
@@ -579,19 +612,22 @@ __global__ __launch_bounds__(64 * (NCW + NLW + HWV)) void unit_kernel(const Chai
         const bool ok = y < p.H && x < p.W;
         const int m = (f * p.H + y) * p.W + x;
         unsigned xoff[1], roff[1], r1off[1];
-        xoff[0] = ok ? (unsigned)m * (unsigned)(C4 * 4) + (unsigned)(g * 32) : OOB;
+        xoff[0] = ok ? (unsigned)m * (unsigned)(C4 * EB) + (unsigned)(g * 8 * EB) : OOB;
         roff[0] = xoff[0];
-        r1off[0] = ok ? (unsigned)m * (unsigned)(C1 * 4) + (unsigned)(g * 32) : OOB;
+        r1off[0] = ok ? (unsigned)m * (unsigned)(C1 * EB) + (unsigned)(g * 8 * EB) : OOB;
         uint4 ph[1][KS1], pl[1][KS1];
         if constexpr (CIN2 > 0) {                                      // the K-concatenated source at this wave's pixels (used after conv2)
-            const unsigned boff = ok ? (unsigned)m * (unsigned)(CIN2 * 4) + (unsigned)(g * 32) : OOB;
+            const unsigned boff = ok ? (unsigned)m * (unsigned)(CIN2 * EB) + (unsigned)(g * 8 * EB) : OOB;
 #pragma unroll
-            for (int s = 0; s < CIN2 / 32; ++s) { ph[0][KS2 + s] = ld16(rs_s2, boff, s * 128); pl[0][KS2 + s] = ld16(rs_s2, boff, s * 128 + 16); }
+            for (int s = 0; s < CIN2 / 32; ++s) {
+                ph[0][KS2 + s] = ld16(rs_s2, boff, s * 32 * EB);
+                if constexpr (H1) pl[0][KS2 + s] = ph[0][KS2 + s]; else pl[0][KS2 + s] = ld16(rs_s2, boff, s * 128 + 16);
+            }
         }
         // the residual of the first pointwise chunks is requested NOW: conv2 below touches no global memory, so HBM would sit idle
         // for nine steps and the pointwise stage would start by waiting for it
         uint4 res[PD][1][2];
-        chain_prefetch<RES, 1, PD>(p, res, roff, rs_s2);
+        chain_prefetch<RES, 1, PD, H1>(p, res, roff, rs_s2);
         // ---- conv2: 9 taps x KS2 K-steps, the pixel fragment comes from the halo tile (shifted by the tap), weights from the ring
         floatx4 acc[NCB2];
 #pragma unroll
@@ -608,16 +644,21 @@ __global__ __launch_bounds__(64 * (NCW + NLW + HWV)) void unit_kernel(const Chai
             const uint4* W = Wc + lane;
             const int hp = (wave + t / 3) * HW + l15 + t % 3;
             const char* hrow = halo + hp * PIXB;
-            const int sw = hp & 15;
+            const int sw = H1 ? ((hp >> 1) & 7) : (hp & 15);
             // pixel fragments of the tap (all K-steps) first, then the weight fragments through the ring (see chain_tail)
             uint4 ah[KS2], al[KS2];
 #pragma unroll
             for (int ks = 0; ks < KS2; ++ks) {
+                if constexpr (H1) {
+                    ah[ks] = *reinterpret_cast<const uint4*>(hrow + (((4 * ks + g) ^ sw) << 4));
+                    al[ks] = ah[ks];
+                } else {
                 const int sl = 2 * (4 * ks + g);
                 ah[ks] = *reinterpret_cast<const uint4*>(hrow + ((sl ^ sw) << 4));
                 al[ks] = *reinterpret_cast<const uint4*>(hrow + (((sl + 1) ^ sw) << 4));
+                }
             }
-            constexpr int NW2 = KS2 * NCB2 * 2;
+            constexpr int NW2 = KS2 * NCB2 * PL;
             uint4 wq[WR];
 #if defined(DGP_UX) && (DGP_UX & 8)      // timing-only ablation: the weight fragments are not read from LDS
 #define UX_W(i) make_uint4(lane, i, slot, t)
@@ -631,18 +672,20 @@ __global__ __launch_bounds__(64 * (NCW + NLW + HWV)) void unit_kernel(const Chai
             for (int ks = 0; ks < KS2; ++ks) {
 #pragma unroll
                 for (int cb = 0; cb < NCB2; ++cb) {
-                    const int f0 = (ks * NCB2 + cb) * 2;
-                    const uint4 wh = wq[f0 % WR], wl = wq[(f0 + 1) % WR];
+                    const int f0 = (ks * NCB2 + cb) * PL;
+                    const uint4 wh = wq[f0 % WR], wl = wq[(f0 + PL - 1) % WR];
 #if defined(DGP_UX) && (DGP_UX & 16)     // timing-only ablation: no MFMAs
                     acc[cb][0] += __builtin_bit_cast(float, wh.x ^ wl.y ^ ah[ks].x ^ al[ks].y);
 #else
+                    if constexpr (!H1) {
                     acc[cb] = mma16(wl, ah[ks], acc[cb]);
                     acc[cb] = mma16(wh, al[ks], acc[cb]);
+                    }
                     acc[cb] = mma16(wh, ah[ks], acc[cb]);
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                     if (f0 + WR < NW2) wq[f0 % WR] = UX_W(f0 + WR);
-                    if (f0 + 1 + WR < NW2) wq[(f0 + 1) % WR] = UX_W(f0 + 1 + WR);
+                    if (PL == 2 && f0 + 1 + WR < NW2) wq[(f0 + 1) % WR] = UX_W(f0 + 1 + WR);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -674,7 +717,8 @@ __global__ __launch_bounds__(64 * (NCW + NLW + HWV)) void unit_kernel(const Chai
             float o[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = fmaxf(acc[2 * q + (k >> 2)][k & 3] * sc[k] + bi[k], 0.f);
-            h2_pack8(o, p.r2_scale, ph[0][q], pl[0][q]);
+            if constexpr (H1) { ph[0][q] = h1_pack8(o, p.r2_scale); pl[0][q] = ph[0][q]; }
+            else h2_pack8(o, p.r2_scale, ph[0][q], pl[0][q]);
             if (ok) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) amax_r2 = fmaxf(amax_r2, o[k]);
@@ -684,7 +728,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW + HWV)) void unit_kernel(const Chai
 #ifdef DGP_DIAG
         ud[2] += u1 - u0; ud[9] += 1;
 #endif
-        chain_tail<C, C1, CIN2, RES, 1, NS, PD, CHUNK, WR>(p, ring, slot, ph, pl, xoff, roff, r1off, rs_s2, rs_xo, rs_r1, amax_x, amax_r1, lane, res UD_ARG);
+        chain_tail<C, C1, CIN2, RES, 1, NS, PD, CHUNK, WR, H1>(p, ring, slot, ph, pl, xoff, roff, r1off, rs_s2, rs_xo, rs_r1, amax_x, amax_r1, lane, res UD_ARG);
     }
 #ifdef DGP_DIAG
     UD_STAMP(uend);
@@ -701,16 +745,16 @@ __global__ __launch_bounds__(64 * (NCW + NLW + HWV)) void unit_kernel(const Chai
 // fragment [256 floats]; out per chunk: 2 pairs + 1 fragments of 1 KiB (pairs as [hi][lo], affine copied).
 // s1 / s2: the powers of two conv3's / conv1's weights are stored with.
 __global__ __launch_bounds__(256) void chain_pack_kernel(const float4* __restrict__ src, int n_chunks, int f1_pairs, int f2_pairs,
-                                                         float s1, float s2, uint4* __restrict__ out) {
+                                                         float s1, float s2, uint4* __restrict__ out, int planes) {
     const int pairs = f1_pairs + f2_pairs;
-    const int nf = 2 * pairs + 1;
+    const int nf = planes * pairs + 1;
     const long long src_chunk = (long long)pairs * 128 + 64;      // float4s
     const long long total = (long long)n_chunks * (pairs + 1) * 64;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int ln = (int)(i & 63);
         const long long fp = i >> 6;
         const int ch = (int)(fp / (pairs + 1)), pr = (int)(fp % (pairs + 1));
-        uint4* o = out + ((long long)ch * nf + 2 * pr) * 64 + ln;
+        uint4* o = out + ((long long)ch * nf + planes * pr) * 64 + ln;
         if (pr == pairs) {
             o[0] = __builtin_bit_cast(uint4, src[ch * src_chunk + (long long)pairs * 128 + ln]);
             continue;
@@ -721,27 +765,27 @@ __global__ __launch_bounds__(256) void chain_pack_kernel(const float4* __restric
         split2_f16(sp[0], sc, h0, l0);
         split2_f16(sp[1], sc, h1, l1);
         o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-        o[64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        if (planes == 2) o[64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
     }
 }
 
-hipError_t launch_chain_pack(const float* src, int n_chunks, int f1_pairs, int f2_pairs, float s1, float s2, void* out, hipStream_t s) {
+hipError_t launch_chain_pack(const float* src, int n_chunks, int f1_pairs, int f2_pairs, float s1, float s2, void* out, hipStream_t s, int planes) {
     const long long total = (long long)n_chunks * (f1_pairs + f2_pairs + 1) * 64;
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(chain_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(src), n_chunks, f1_pairs,
-                       f2_pairs, s1, s2, reinterpret_cast<uint4*>(out));
+                       f2_pairs, s1, s2, reinterpret_cast<uint4*>(out), planes);
     return hipGetLastError();
 }
 
 namespace {
 
-template <int C, int C1, int CIN2, int RES, int RB, int NCW, int NLW, int PD, int NS = 3, int WR = 4>
+template <int C, int C1, int CIN2, int RES, int RB, int NCW, int NLW, int PD, int NS = 3, int WR = 4, bool H1 = false>
 hipError_t launch_chain_t(const ChainArgs& a0, hipStream_t s) {
-    constexpr int NF = (C + CIN2) / 32 * 4 + C1 / 16 * 2 + 1;
+    constexpr int NF = ((C + CIN2) / 32 * 2 + C1 / 16) * (H1 ? 1 : 2) + 1;
     constexpr int LDS = NS * NF * 1024;
     static_assert(LDS <= 160 * 1024, "ring does not fit the LDS");
-    auto kern = chain_kernel<C, C1, CIN2, RES, RB, NCW, NLW, NS, PD, WR>;
+    auto kern = chain_kernel<C, C1, CIN2, RES, RB, NCW, NLW, NS, PD, WR, H1>;
     static bool attr_done[16] = {};
     static int wgs_per_cu[16] = {};
     const int dev = dgp_device_slot();
@@ -783,12 +827,12 @@ hipError_t launch_chain_t(const ChainArgs& a0, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int C, int C1, int CIN2, int RES, int NCW, int NLW, int PD, int WR = 4, int HWV = 1>
+template <int C, int C1, int CIN2, int RES, int NCW, int NLW, int PD, int WR = 4, int HWV = 1, bool H1 = false>
 hipError_t launch_unit_t(const ChainArgs& a0, int N, hipStream_t s) {
-    constexpr int NFJ = (C + CIN2) / 32 * 4 + C1 / 16 * 2 + 1, NF2 = (C / 32) * (C / 16) * 2 + 1, NFMAX = NFJ > NF2 ? NFJ : NF2;
-    constexpr int LDS = ((NCW + 2) * 18 * C * 4 + 1023) / 1024 * 1024 + 3 * NFMAX * 1024;
+    constexpr int NFJ = ((C + CIN2) / 32 * 2 + C1 / 16) * (H1 ? 1 : 2) + 1, NF2 = (C / 32) * (C / 16) * (H1 ? 1 : 2) + 1, NFMAX = NFJ > NF2 ? NFJ : NF2;
+    constexpr int LDS = ((NCW + 2) * 18 * C * (H1 ? 2 : 4) + 1023) / 1024 * 1024 + 3 * NFMAX * 1024;
     static_assert(LDS <= 160 * 1024, "halo tile + ring do not fit the LDS");
-    auto kern = unit_kernel<C, C1, CIN2, RES, NCW, NLW, PD, WR, HWV>;
+    auto kern = unit_kernel<C, C1, CIN2, RES, NCW, NLW, PD, WR, HWV, H1>;
     static bool attr_done[16] = {};
     static int wgs_per_cu[16] = {};
     const int dev = dgp_device_slot();
@@ -856,6 +900,9 @@ hipError_t launch_unit(const ChainArgs& a, int N, int C, int C1, int CIN2, int r
         if (cfg == 2) return launch_unit_t<64, 64, 0, 1, 10, 2, 2, 4, 0>(a, N, s);
         if (cfg == 3) return launch_unit_t<64, 64, 0, 1, 8, 2, 2, 4, 1>(a, N, s);          // with the halo wave
         // (identity units move 1.57 GB per launch at 3.6-3.7 TB/s: the halo wave measured -2 % on one box, +1 / +1.5 % on two others)
+        // (16-bit tier, ms per launch on one box: 2 loader waves 0.257, 4 loader waves 0.272 (4 residual buffers), 4 loader waves + halo wave 0.240 -- with a third of
+        //  the MFMAs the loader waves' issue rate is what a pointwise step waits for)
+        if (a.h1) return launch_unit_t<64, 64, 0, 1, 8, 4, 2, 4, 1, true>(a, N, s);
         return launch_unit_t<64, 64, 0, 1, 8, 2, 2, 4, 0>(a, N, s);
     }
     if (C == 64 && C1 == 64 && CIN2 == 64 && res == 0) {
@@ -863,12 +910,13 @@ hipError_t launch_unit(const ChainArgs& a, int N, int C, int C1, int CIN2, int r
         if (cfg == 2) return launch_unit_t<64, 64, 64, 0, 10, 2, 2, 8, 0>(a, N, s);
         if (cfg == 3) return launch_unit_t<64, 64, 64, 0, 8, 2, 2, 8, 0>(a, N, s);          // no halo wave: the halo pieces in the weight loaders' queues
         // (halo wave: 0.402 / 0.402 -> 0.367 / 0.378 ms alternating on one box, 0.406-0.417 -> 0.391-0.411 on two others)
+        if (a.h1) return launch_unit_t<64, 64, 64, 0, 8, 2, 2, 8, 1, true>(a, N, s);
         return launch_unit_t<64, 64, 64, 0, 8, 2, 2, 8, 1>(a, N, s);
     }
     return hipErrorInvalidValue;
 }
 
-int chain_frags_per_chunk(int C, int C1, int CIN2) { return (C + CIN2) / 32 * 4 + C1 / 16 * 2 + 1; }
+int chain_frags_per_chunk(int C, int C1, int CIN2, int planes) { return ((C + CIN2) / 32 * 2 + C1 / 16) * planes + 1; }
 
 const char* chain_kernel_name(int C, int C1, int CIN2, int res) {
     static thread_local char buf[64];
@@ -886,18 +934,21 @@ hipError_t launch_chain(const ChainArgs& a, int C, int C1, int CIN2, int res, hi
         if (cfg == 3) return launch_chain_t<64, 64, 0, 1, 1, 11, 1, 4>(a, s);
         if (cfg == 4) return launch_chain_t<64, 64, 0, 1, 1, 8, 2, 4>(a, s);          // more loader waves (4 / 5: two / four)
         if (cfg == 5) return launch_chain_t<64, 64, 0, 1, 1, 8, 4, 4>(a, s);
+        if (a.h1) return launch_chain_t<64, 64, 0, 1, 1, 8, 1, 4, 3, 4, true>(a, s);
         return launch_chain_t<64, 64, 0, 1, 1, 8, 1, 4>(a, s);
     }
     if (C == 64 && C1 == 64 && CIN2 == 64 && res == 0) {
         if (cfg == 1) return launch_chain_t<64, 64, 64, 0, 2, 5, 1, 2>(a, s);
         if (cfg == 4) return launch_chain_t<64, 64, 64, 0, 1, 8, 2, 2>(a, s);
         if (cfg == 5) return launch_chain_t<64, 64, 64, 0, 1, 8, 4, 2>(a, s);
+        if (a.h1) return launch_chain_t<64, 64, 64, 0, 1, 8, 1, 2, 3, 4, true>(a, s);
         return launch_chain_t<64, 64, 64, 0, 1, 8, 1, 2>(a, s);
     }
     if (C == 64 && C1 == 128 && CIN2 == 0 && res == 2) {
         if (cfg == 1) return launch_chain_t<64, 128, 0, 2, 2, 5, 1, 4>(a, s);
         if (cfg == 4) return launch_chain_t<64, 128, 0, 2, 1, 8, 2, 4>(a, s);
         if (cfg == 5) return launch_chain_t<64, 128, 0, 2, 1, 8, 4, 4>(a, s);
+        if (a.h1) return launch_chain_t<64, 128, 0, 2, 1, 8, 1, 4, 3, 4, true>(a, s);
         return launch_chain_t<64, 128, 0, 2, 1, 8, 1, 4>(a, s);
     }
     if (C == 128 && C1 == 128 && CIN2 == 0 && res == 1) {
@@ -905,15 +956,18 @@ hipError_t launch_chain(const ChainArgs& a, int C, int C1, int CIN2, int res, hi
         if (cfg == 2) return launch_chain_t<128, 128, 0, 1, 1, 8, 2, 2, 3, 8>(a, s);
         if (cfg == 3) return launch_chain_t<128, 128, 0, 1, 1, 6, 2, 2, 3, 8>(a, s);
         if (cfg == 4 || cfg == 5) return launch_chain_t<128, 128, 0, 1, 1, 8, 4, 2, 3, 4>(a, s);
+        if (a.h1) return launch_chain_t<128, 128, 0, 1, 1, 8, 2, 2, 3, 4, true>(a, s);
         return launch_chain_t<128, 128, 0, 1, 1, 8, 2, 2, 3, 4>(a, s);
     }
     if (C == 128 && C1 == 256 && CIN2 == 0 && res == 2) {
+        if (a.h1) return launch_chain_t<128, 256, 0, 2, 1, 6, 2, 4, 3, 4, true>(a, s);
         return launch_chain_t<128, 256, 0, 2, 1, 6, 2, 4>(a, s);
     }
     if (C == 256 && C1 == 256 && CIN2 == 0 && res == 1) {          // 65-KiB chunks: two ring slots, one workgroup per CU
         if (cfg == 1) return launch_chain_t<256, 256, 0, 1, 1, 4, 2, 2, 2, 8>(a, s);
         if (cfg == 2) return launch_chain_t<256, 256, 0, 1, 1, 6, 2, 2, 2, 8>(a, s);
         if (cfg == 3) return launch_chain_t<256, 256, 0, 1, 1, 5, 2, 2, 2, 4>(a, s);
+        if (a.h1) return launch_chain_t<256, 256, 0, 1, 1, 5, 2, 2, 2, 8, true>(a, s);
         return launch_chain_t<256, 256, 0, 1, 1, 5, 2, 2, 2, 8>(a, s);
     }
     return hipErrorInvalidValue;

@@ -62,6 +62,9 @@ struct ChainPlan {
     bool unit = false;                        // the fragments start with conv2's 9 tap chunks: the unit kernel runs conv2 too
     int w2_exp = 0;
     unsigned head_bytes = 0;                  // bytes of conv2's chunks in front of the chain's (0 when unit is false)
+    // the 16-bit tier's copy: the same chunks with the HIGH fragments only (half the L2 -> LDS stream; ChainArgs::h1)
+    void* d_frags_h1 = nullptr;
+    unsigned frag_bytes_h1 = 0, head_bytes_h1 = 0;
 };
 // host: build the chunked fragments (see ChainArgs) and upload them.  w3cat [(C + CIN2)][4 C], w1 [4 C][C1] row-major; sc3 may be null (= 1)
 // w2 (optional, HWIO [3][3][C][C] of a stride-1 conv2 with BN affine sc2 / bi2): build the unit kernel's fragments when an instance exists

@@ -185,9 +185,10 @@ struct ChainArgs {
     float post0, r2_scale;    // 1 / (R1 scale x conv2 weight scale); scale R2's fragments are split with
     float* r2_absmax;
     int nt;                   // bit 0: residual loads, bit 1: X' stores with the non-temporal (evict-first) policy
+    int h1;                   // 1: every tensor is an H1 tensor (the 16-bit tier): 2 bytes per channel, high weight fragments only, one MFMA per product
 };
 bool chain_supported(int C, int C1, int CIN2, int res);          // res: 0 K-concatenated shortcut, 1 identity, 2 subsample of a stride-2 unit
-int  chain_frags_per_chunk(int C, int C1, int CIN2);
+int  chain_frags_per_chunk(int C, int C1, int CIN2, int planes = 2);
 hipError_t launch_chain(const ChainArgs& a, int C, int C1, int CIN2, int res, hipStream_t s);
 const char* chain_kernel_name(int C, int C1, int CIN2, int res);
 // the unit kernel: conv2 (3x3, stride 1) in front of the chain.  Weight chunks: 9 conv2 chunks (one tap each: (C / 32) (C / 16) fragment
@@ -196,7 +197,8 @@ bool unit_supported(int C, int C1, int CIN2, int res);
 hipError_t launch_unit(const ChainArgs& a, int N, int C, int C1, int CIN2, int res, hipStream_t s);
 // fp32 fragments -> fp16 high / low fragment pairs.  src per chunk: (f1_pairs + f2_pairs) x [64 lanes][8 floats], then the affine
 // fragment [64 floats... 256 floats]; out per chunk: 2 (f1_pairs + f2_pairs) + 1 KiB-fragments
-hipError_t launch_chain_pack(const float* src, int n_chunks, int f1_pairs, int f2_pairs, float s1, float s2, void* out, hipStream_t s);
+// planes: 2 = [hi][lo] pairs; 1 = high fragments only (the 16-bit tier's chunks: f1_pairs + f2_pairs + 1 KiB-fragments per chunk)
+hipError_t launch_chain_pack(const float* src, int n_chunks, int f1_pairs, int f2_pairs, float s1, float s2, void* out, hipStream_t s, int planes = 2);
 
 // Run-time switches of the native code, two classes (README "Switches"):
 //  * dgp_env(): the shipped ones -- the precision tiers (DGP_CONV_MODE, DGP_H2) and the A/B switches between paths that all ship

@@ -57,7 +57,7 @@ static int pow2_exp_for_max(float mx) {        // e with max * 2^e in [2^14, 2^1
 }
 
 void free_chain_plan(ChainPlan& pl) {
-    for (void* q : {pl.d_frags, (void*)pl.d_sc1, (void*)pl.d_bi1}) if (q) (void)hipFree(q);
+    for (void* q : {pl.d_frags, pl.d_frags_h1, (void*)pl.d_sc1, (void*)pl.d_bi1}) if (q) (void)hipFree(q);
     pl = ChainPlan();
 }
 
@@ -127,6 +127,14 @@ int build_chain_plan(ChainPlan& pl, int C, int C1, int CIN2, int res, const floa
     if (e == hipSuccess && unit) e = hipMemcpy(d_src2, src2.data(), src2.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess && unit) e = launch_chain_pack(d_src2, 9, pairs2, 0, ldexpf(1.f, pl.w2_exp), 1.f, pl.d_frags, nullptr);
     if (e == hipSuccess) e = launch_chain_pack(d_src, NJP, KS1 * 2, NCB, ldexpf(1.f, pl.w3_exp), ldexpf(1.f, pl.w1_exp), (char*)pl.d_frags + head, nullptr);
+    // the 16-bit tier's chunks: the high fragments alone, same order
+    const int nf_h1 = chain_frags_per_chunk(C, C1, CIN2, 1), nf2_h1 = pairs2 + 1;
+    const size_t head_h1 = unit ? (size_t)9 * nf2_h1 * 1024 : 0;
+    pl.frag_bytes_h1 = (unsigned)(head_h1 + (size_t)NJP * nf_h1 * 1024);
+    pl.head_bytes_h1 = (unsigned)head_h1;
+    if (e == hipSuccess) e = hipMalloc(&pl.d_frags_h1, pl.frag_bytes_h1);
+    if (e == hipSuccess && unit) e = launch_chain_pack(d_src2, 9, pairs2, 0, ldexpf(1.f, pl.w2_exp), 1.f, pl.d_frags_h1, nullptr, 1);
+    if (e == hipSuccess) e = launch_chain_pack(d_src, NJP, KS1 * 2, NCB, ldexpf(1.f, pl.w3_exp), ldexpf(1.f, pl.w1_exp), (char*)pl.d_frags_h1 + head_h1, nullptr, 1);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipFree(d_src);
     if (d_src2) (void)hipFree(d_src2);
@@ -729,8 +737,10 @@ int run_chain(dgp_net* net, int ui, const float* r2, const float* x, int N, int 
     const Unit &u = net->units[ui], &un = net->units[ui + 1];
     const ConvLayer &l3 = net->layers[u.c3], &l1 = net->layers[un.c1];
     ChainArgs a{};
+    a.h1 = net->tier ? 1 : 0;                     // the 16-bit tier: H1 tensors, the same weight chunks (high fragments only)
+    const double EB = a.h1 ? 2.0 : 4.0;           // bytes per channel
     a.r2 = r2; a.src2 = x; a.xout = xout; a.r1out = r1out; a.sc1 = cp.d_sc1; a.bi1 = cp.d_bi1;
-    a.wfrag = (const char*)cp.d_frags + (r1in ? 0 : cp.head_bytes);
+    a.wfrag = a.h1 ? (const char*)cp.d_frags_h1 + (r1in ? 0 : cp.head_bytes_h1) : (const char*)cp.d_frags + (r1in ? 0 : cp.head_bytes);
     a.M = N * Ho * Wo; a.HoWo = Ho * Wo; a.Wo = Wo; a.res_H = H; a.res_W = W;
     if (r1in) {                                   // unit kernel: conv2 (stride 1: Ho x Wo = H x W) in front
         const ConvLayer& l2 = net->layers[u.c2];
@@ -738,7 +748,7 @@ int run_chain(dgp_net* net, int ui, const float* r2, const float* x, int N, int 
         a.post0 = ldexpf(1.f, -(net->act_exp[u.c1] + cp.w2_exp));
         a.r2_scale = ldexpf(1.f, net->act_exp[u.c2]);
         a.r2_absmax = net->amax(u.c2);
-        a.r1in_bytes = (unsigned)((size_t)N * H * W * l2.Cin * 4);
+        a.r1in_bytes = (unsigned)((double)N * H * W * l2.Cin * EB);
     }
     a.post1 = ldexpf(1.f, -(net->act_exp[u.c2] + cp.w3_exp));
     a.post2 = ldexpf(1.f, -(net->act_exp[u.c3] + cp.w1_exp));
@@ -747,17 +757,18 @@ int run_chain(dgp_net* net, int ui, const float* r2, const float* x, int N, int 
     a.r1_scale = ldexpf(1.f, net->act_exp[un.c1]);
     a.xout_absmax = net->amax(u.c3); a.r1_absmax = net->amax(un.c1);
     const double lim = 4294967000.0;
-    const double r2b = (double)a.M * cp.C * 4, xob = (double)a.M * cp.C * 16, r1b = (double)a.M * cp.C1 * 4;
-    const double s2b = cp.res == 0 ? (double)a.M * cp.CIN2 * 4 : (double)N * H * W * cp.C * 16;
+    const double r2b = (double)a.M * cp.C * EB, xob = (double)a.M * cp.C * 4 * EB, r1b = (double)a.M * cp.C1 * EB;
+    const double s2b = cp.res == 0 ? (double)a.M * cp.CIN2 * EB : (double)N * H * W * cp.C * 4 * EB;
     if (r2b > lim || xob > lim || r1b > lim || s2b > lim)
         return fail(DGP_ERR_INVALID, "activation tensor exceeds the 4 GiB buffer-descriptor range; lower the batch");
     a.r2_bytes = (unsigned)r2b; a.xout_bytes = (unsigned)xob; a.r1_bytes = (unsigned)r1b; a.src2_bytes = (unsigned)s2b;
-    a.w_bytes = cp.frag_bytes - (r1in ? 0 : cp.head_bytes);
+    a.w_bytes = a.h1 ? cp.frag_bytes_h1 - (r1in ? 0 : cp.head_bytes_h1) : cp.frag_bytes - (r1in ? 0 : cp.head_bytes);
     double flops = conv_flops_of(l3, a.M, false) + conv_flops_of(l1, a.M, false);
     if (u.sc >= 0) flops += conv_flops_of(net->layers[u.sc], a.M, false);
     if (r1in) flops += conv_flops_of(net->layers[u.c2], a.M, false);
     std::string kname = chain_kernel_name(cp.C, cp.C1, cp.CIN2, cp.res);
     if (r1in) kname = "unit" + kname.substr(5);
+    if (a.h1) kname = "h1_" + kname;
     ProfScope ps(net, s, "conv:" + (r1in ? net->layers[u.c2].scope + "+" : std::string()) + l3.scope + (u.sc >= 0 ? "+shortcut" : "") + "+" + l1.scope + "|" + kname, flops);
     hipError_t e = r1in ? launch_unit(a, N, cp.C, cp.C1, cp.CIN2, cp.res, s) : launch_chain(a, cp.C, cp.C1, cp.CIN2, cp.res, s);
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("chain launch (") + l3.scope + "): " + hipGetErrorString(e));
@@ -928,7 +939,9 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     // conv3(k) + conv1(k + 1) as one launch (DGP_CHAIN=0: layer by layer).  Calibration runs layer by layer (it needs every tensor's
     // range before the next layer runs) and is followed by a second, chained pass, so results never depend on which pass produced them
     static const bool chain_env = (dgp_env("DGP_CHAIN", 1) != 0);
-    const bool chain_on = h2 && !calib && chain_env && !tier && net->chains.size() == net->units.size();
+    static const bool chain_h1_env = (dgp_env("DGP_CHAIN_H1", 1) != 0);      // the chain / unit kernels on H1 tensors (the 16-bit tier)
+    const bool chain_tier = chain_env && (!tier || chain_h1_env);
+    const bool chain_on = h2 && !calib && chain_tier && net->chains.size() == net->units.size();
     static const bool unit_env = (dgp_env("DGP_UNIT", 1) != 0);      // conv2 inside the chain launch (block1)
     bool r1_ready = false;                            // R1 of this unit came out of the previous unit's chain launch
     float *Ra = R1, *Rb = R2;
@@ -1060,7 +1073,7 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
         e = launch_h2_range_check(net->d_amax, net->d_exps, (int)net->layers.size(), net->d_flag, s);
         if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("range check: ") + hipGetErrorString(e));
     }
-    if (calib && chain_env && !tier) return dgp_forward(net, frames, batch, workspace, workspace_bytes, scmap, locref, features, stream);   // the chained pass
+    if (calib && chain_tier) return dgp_forward(net, frames, batch, workspace, workspace_bytes, scmap, locref, features, stream);   // the chained pass
     if (net->prof_on && net->prof_used < net->prof_slots && !net->prof_in_infer) ++net->prof_used;
     return DGP_OK;
 }
@@ -1417,10 +1430,11 @@ static int conv2d_cells(int fmt, const dgp_conv_desc* d, const void* x_h2, int32
 
 /* conv3 (+ shortcut, ReLU) of a bottleneck unit and conv1 of the next unit as ONE launch on H2 tensors (the engine's chain kernel,
  * csrc/dgp_chain.hip) -- layer-level entry for tests: weights and BN affines are HOST arrays, packed per call. */
-int dgp_chain_h2(int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t C1, int32_t CIN2, int32_t res_mode, int32_t res_H, int32_t res_W,
+static int chain_layer(bool h1, int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t C1, int32_t CIN2, int32_t res_mode, int32_t res_H, int32_t res_W,
                  const void* r2_h2, int32_t r2_exp, const void* src2_h2, int32_t src2_exp,
                  const float* w3cat, const float* scale3, const float* bias3, const float* w1, const float* scale1, const float* bias1,
                  void* xout_h2, int32_t xout_exp, void* r1_h2, int32_t r1_exp, float* xout_absmax, float* r1_absmax, void* stream) {
+    const size_t EB = h1 ? 2 : 4;                  // bytes per channel: H1 cells / H2 cell pairs
     if (!r2_h2 || !src2_h2 || !w3cat || !w1 || !xout_h2 || !r1_h2) return fail(DGP_ERR_INVALID, "dgp_chain_h2: null argument");
     if (!chain_supported(C, C1, CIN2, res_mode))
         return fail(DGP_ERR_INVALID, "dgp_chain_h2: no kernel instance for this (C, C1, CIN2, res_mode)");
@@ -1429,14 +1443,15 @@ int dgp_chain_h2(int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t C1, int32
     int rc = build_chain_plan(cp, C, C1, CIN2, res_mode, w3cat, scale3, bias3, w1, scale1, bias1);
     if (rc) return rc;
     ChainArgs a{};
-    a.r2 = r2_h2; a.src2 = src2_h2; a.xout = xout_h2; a.r1out = r1_h2; a.wfrag = cp.d_frags; a.sc1 = cp.d_sc1; a.bi1 = cp.d_bi1;
+    a.h1 = h1 ? 1 : 0;
+    a.r2 = r2_h2; a.src2 = src2_h2; a.xout = xout_h2; a.r1out = r1_h2; a.wfrag = h1 ? cp.d_frags_h1 : cp.d_frags; a.sc1 = cp.d_sc1; a.bi1 = cp.d_bi1;
     a.M = N * Ho * Wo; a.HoWo = Ho * Wo; a.Wo = Wo; a.res_H = res_H; a.res_W = res_W;
     a.post1 = ldexpf(1.f, -(r2_exp + cp.w3_exp)); a.post2 = ldexpf(1.f, -(xout_exp + cp.w1_exp));
     a.res_inv_scale = ldexpf(1.f, -src2_exp); a.xout_scale = ldexpf(1.f, xout_exp); a.r1_scale = ldexpf(1.f, r1_exp);
     a.xout_absmax = xout_absmax; a.r1_absmax = r1_absmax;
-    a.r2_bytes = (unsigned)((size_t)a.M * C * 4); a.xout_bytes = (unsigned)((size_t)a.M * C * 16); a.r1_bytes = (unsigned)((size_t)a.M * C1 * 4);
-    a.src2_bytes = (unsigned)(res_mode == 0 ? (size_t)a.M * CIN2 * 4 : (size_t)N * res_H * res_W * C * 16);
-    a.w_bytes = cp.frag_bytes;
+    a.r2_bytes = (unsigned)((size_t)a.M * C * EB); a.xout_bytes = (unsigned)((size_t)a.M * C * 4 * EB); a.r1_bytes = (unsigned)((size_t)a.M * C1 * EB);
+    a.src2_bytes = (unsigned)(res_mode == 0 ? (size_t)a.M * CIN2 * EB : (size_t)N * res_H * res_W * C * 4 * EB);
+    a.w_bytes = h1 ? cp.frag_bytes_h1 : cp.frag_bytes;
     hipError_t e = launch_chain(a, C, C1, CIN2, res_mode, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);       // (the fragments are freed below)
     free_chain_plan(cp);
@@ -1446,12 +1461,13 @@ int dgp_chain_h2(int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t C1, int32
 
 /* The unit kernel at layer level (tests): conv2 (3x3, stride 1, SAME) + BN + ReLU of a bottleneck unit, its conv3 + shortcut + ReLU and
  * conv1 of the next unit in one launch; R2 never leaves the registers. */
-int dgp_unit_h2(int32_t N, int32_t H, int32_t W, int32_t C, int32_t C1, int32_t CIN2, int32_t res_mode,
+static int unit_layer(bool h1, int32_t N, int32_t H, int32_t W, int32_t C, int32_t C1, int32_t CIN2, int32_t res_mode,
                 const void* r1_h2, int32_t r1_exp, const void* src2_h2, int32_t src2_exp,
                 const float* w2, const float* scale2, const float* bias2, int32_t r2_exp,
                 const float* w3cat, const float* scale3, const float* bias3, const float* w1, const float* scale1, const float* bias1,
                 void* xout_h2, int32_t xout_exp, void* r1out_h2, int32_t r1out_exp, float* r2_absmax, float* xout_absmax, float* r1_absmax,
                 void* stream) {
+    const size_t EB = h1 ? 2 : 4;
     if (!r1_h2 || !src2_h2 || !w2 || !w3cat || !w1 || !xout_h2 || !r1out_h2) return fail(DGP_ERR_INVALID, "dgp_unit_h2: null argument");
     if (!unit_supported(C, C1, CIN2, res_mode))
         return fail(DGP_ERR_INVALID, "dgp_unit_h2: no kernel instance for this (C, C1, CIN2, res_mode)");
@@ -1461,20 +1477,54 @@ int dgp_unit_h2(int32_t N, int32_t H, int32_t W, int32_t C, int32_t C1, int32_t 
     int rc = build_chain_plan(cp, C, C1, CIN2, res_mode, w3cat, scale3, bias3, w1, scale1, bias1, w2, scale2, bias2);
     if (rc) return rc;
     ChainArgs a{};
-    a.r1in = r1_h2; a.src2 = src2_h2; a.xout = xout_h2; a.r1out = r1out_h2; a.wfrag = cp.d_frags; a.sc1 = cp.d_sc1; a.bi1 = cp.d_bi1;
+    a.h1 = h1 ? 1 : 0;
+    a.r1in = r1_h2; a.src2 = src2_h2; a.xout = xout_h2; a.r1out = r1out_h2; a.wfrag = h1 ? cp.d_frags_h1 : cp.d_frags; a.sc1 = cp.d_sc1; a.bi1 = cp.d_bi1;
     a.M = N * H * W; a.HoWo = H * W; a.Wo = W; a.res_H = H; a.res_W = W; a.H = H; a.W = W;
     a.post0 = ldexpf(1.f, -(r1_exp + cp.w2_exp)); a.r2_scale = ldexpf(1.f, r2_exp);
     a.post1 = ldexpf(1.f, -(r2_exp + cp.w3_exp)); a.post2 = ldexpf(1.f, -(xout_exp + cp.w1_exp));
     a.res_inv_scale = ldexpf(1.f, -src2_exp); a.xout_scale = ldexpf(1.f, xout_exp); a.r1_scale = ldexpf(1.f, r1out_exp);
     a.r2_absmax = r2_absmax; a.xout_absmax = xout_absmax; a.r1_absmax = r1_absmax;
-    a.r1in_bytes = (unsigned)((size_t)a.M * C * 4); a.xout_bytes = (unsigned)((size_t)a.M * C * 16); a.r1_bytes = (unsigned)((size_t)a.M * C1 * 4);
-    a.src2_bytes = (unsigned)(res_mode == 0 ? (size_t)a.M * CIN2 * 4 : (size_t)a.M * C * 16);
-    a.w_bytes = cp.frag_bytes;
+    a.r1in_bytes = (unsigned)((size_t)a.M * C * EB); a.xout_bytes = (unsigned)((size_t)a.M * C * 4 * EB); a.r1_bytes = (unsigned)((size_t)a.M * C1 * EB);
+    a.src2_bytes = (unsigned)(res_mode == 0 ? (size_t)a.M * CIN2 * 4 : (size_t)a.M * C * 4 * EB);
+    a.w_bytes = h1 ? cp.frag_bytes_h1 : cp.frag_bytes;
     hipError_t e = launch_unit(a, N, C, C1, CIN2, res_mode, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     free_chain_plan(cp);
     if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_unit_h2: ") + hipGetErrorString(e));
     return DGP_OK;
+}
+int dgp_chain_h2(int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t C1, int32_t CIN2, int32_t res_mode, int32_t res_H, int32_t res_W,
+                 const void* r2_h2, int32_t r2_exp, const void* src2_h2, int32_t src2_exp,
+                 const float* w3cat, const float* scale3, const float* bias3, const float* w1, const float* scale1, const float* bias1,
+                 void* xout_h2, int32_t xout_exp, void* r1_h2, int32_t r1_exp, float* xout_absmax, float* r1_absmax, void* stream) {
+    return chain_layer(false, N, Ho, Wo, C, C1, CIN2, res_mode, res_H, res_W, r2_h2, r2_exp, src2_h2, src2_exp, w3cat, scale3, bias3, w1, scale1, bias1,
+                       xout_h2, xout_exp, r1_h2, r1_exp, xout_absmax, r1_absmax, stream);
+}
+/* the same launches on H1 tensors (the 16-bit tier: 2 bytes per channel, high weight fragments only, one MFMA per product) */
+int dgp_chain_h1(int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t C1, int32_t CIN2, int32_t res_mode, int32_t res_H, int32_t res_W,
+                 const void* r2_h1, int32_t r2_exp, const void* src2_h1, int32_t src2_exp,
+                 const float* w3cat, const float* scale3, const float* bias3, const float* w1, const float* scale1, const float* bias1,
+                 void* xout_h1, int32_t xout_exp, void* r1_h1, int32_t r1_exp, float* xout_absmax, float* r1_absmax, void* stream) {
+    return chain_layer(true, N, Ho, Wo, C, C1, CIN2, res_mode, res_H, res_W, r2_h1, r2_exp, src2_h1, src2_exp, w3cat, scale3, bias3, w1, scale1, bias1,
+                       xout_h1, xout_exp, r1_h1, r1_exp, xout_absmax, r1_absmax, stream);
+}
+int dgp_unit_h2(int32_t N, int32_t H, int32_t W, int32_t C, int32_t C1, int32_t CIN2, int32_t res_mode,
+                const void* r1_h2, int32_t r1_exp, const void* src2_h2, int32_t src2_exp,
+                const float* w2, const float* scale2, const float* bias2, int32_t r2_exp,
+                const float* w3cat, const float* scale3, const float* bias3, const float* w1, const float* scale1, const float* bias1,
+                void* xout_h2, int32_t xout_exp, void* r1out_h2, int32_t r1out_exp, float* r2_absmax, float* xout_absmax, float* r1_absmax,
+                void* stream) {
+    return unit_layer(false, N, H, W, C, C1, CIN2, res_mode, r1_h2, r1_exp, src2_h2, src2_exp, w2, scale2, bias2, r2_exp, w3cat, scale3, bias3, w1, scale1, bias1,
+                      xout_h2, xout_exp, r1out_h2, r1out_exp, r2_absmax, xout_absmax, r1_absmax, stream);
+}
+int dgp_unit_h1(int32_t N, int32_t H, int32_t W, int32_t C, int32_t C1, int32_t CIN2, int32_t res_mode,
+                const void* r1_h1, int32_t r1_exp, const void* src2_h1, int32_t src2_exp,
+                const float* w2, const float* scale2, const float* bias2, int32_t r2_exp,
+                const float* w3cat, const float* scale3, const float* bias3, const float* w1, const float* scale1, const float* bias1,
+                void* xout_h1, int32_t xout_exp, void* r1out_h1, int32_t r1out_exp, float* r2_absmax, float* xout_absmax, float* r1_absmax,
+                void* stream) {
+    return unit_layer(true, N, H, W, C, C1, CIN2, res_mode, r1_h1, r1_exp, src2_h1, src2_exp, w2, scale2, bias2, r2_exp, w3cat, scale3, bias3, w1, scale1, bias1,
+                      xout_h1, xout_exp, r1out_h1, r1out_exp, r2_absmax, xout_absmax, r1_absmax, stream);
 }
 
 int dgp_net_range_status(dgp_net* net, int32_t* overflow, int32_t* calibrations, void* stream) {

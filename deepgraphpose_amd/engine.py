@@ -657,53 +657,55 @@ def conv2d_h1(x_h1: torch.Tensor, x_exp: int, w_hwio: np.ndarray, stride: int = 
 
 
 def chain_h2(r2_h2: torch.Tensor, r2_exp: int, src2_h2: torch.Tensor, src2_exp: int, w3cat: np.ndarray, scale3, bias3,
-             w1: np.ndarray, scale1, bias1, res_mode: int, xout_exp: int, r1_exp: int):
+             w1: np.ndarray, scale1, bias1, res_mode: int, xout_exp: int, r1_exp: int, h1: bool = False):
     """The engine's chain kernel at layer level (include/dgp_hip.h, dgp_chain_h2): conv3 (+ shortcut, ReLU) of a bottleneck unit and
     conv1 of the next unit in one launch.  r2 [N, Ho, Wo, C]; src2: X [N, Ho, Wo, 4C] (res_mode 1), X [N, H, W, 4C] read at (2 ho, 2 wo)
     (res_mode 2) or the shortcut conv's input [N, Ho, Wo, CIN2] (res_mode 0; w3cat then has C + CIN2 rows).
-    -> (x_out H2, r1 H2, x_out range slots, r1 range slots)."""
+    -> (x_out H2, r1 H2, x_out range slots, r1 range slots).  h1: every tensor is an H1 tensor (torch.float16 [N, H, W, C]; dgp_chain_h1)."""
     lib = _lib.load()
-    _need_cuda(r2_h2, torch.float32, "r2_h2")
-    _need_cuda(src2_h2, torch.float32, "src2_h2")
+    dt = torch.float16 if h1 else torch.float32
+    _need_cuda(r2_h2, dt, "r2_h2")
+    _need_cuda(src2_h2, dt, "src2_h2")
     N, Ho, Wo, Cc = r2_h2.shape
     K, C4 = w3cat.shape
     C1 = w1.shape[1]
     assert C4 == 4 * Cc and w1.shape[0] == C4
     cin2 = K - Cc
     dev = r2_h2.device
-    xo = torch.empty((N, Ho, Wo, C4), dtype=torch.float32, device=dev)
-    r1 = torch.empty((N, Ho, Wo, C1), dtype=torch.float32, device=dev)
+    xo = torch.empty((N, Ho, Wo, C4), dtype=dt, device=dev)
+    r1 = torch.empty((N, Ho, Wo, C1), dtype=dt, device=dev)
     rng = torch.zeros((2, ABSMAX_SLOTS), dtype=torch.float32, device=dev)
     f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
     w3c, s3, b3, w1c, s1, b1 = f(w3cat), f(scale3), f(bias3), f(w1), f(scale1), f(bias1)
     hp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
-    _lib.check(lib.dgp_chain_h2(N, Ho, Wo, Cc, C1, cin2, int(res_mode), src2_h2.shape[1], src2_h2.shape[2], _ptr(r2_h2), int(r2_exp),
+    _lib.check((lib.dgp_chain_h1 if h1 else lib.dgp_chain_h2)(N, Ho, Wo, Cc, C1, cin2, int(res_mode), src2_h2.shape[1], src2_h2.shape[2], _ptr(r2_h2), int(r2_exp),
                                 _ptr(src2_h2), int(src2_exp), hp(w3c), hp(s3), hp(b3), hp(w1c), hp(s1), hp(b1), _ptr(xo), int(xout_exp),
                                 _ptr(r1), int(r1_exp), _ptr(rng[0]), _ptr(rng[1]), _stream(dev)), "dgp_chain_h2")
     return xo, r1, rng[0], rng[1]
 
 
 def unit_h2(r1_h2: torch.Tensor, r1_exp: int, src2_h2: torch.Tensor, src2_exp: int, w2: np.ndarray, scale2, bias2, r2_exp: int,
-            w3cat: np.ndarray, scale3, bias3, w1: np.ndarray, scale1, bias1, res_mode: int, xout_exp: int, r1out_exp: int):
+            w3cat: np.ndarray, scale3, bias3, w1: np.ndarray, scale1, bias1, res_mode: int, xout_exp: int, r1out_exp: int, h1: bool = False):
     """The engine's unit kernel at layer level (include/dgp_hip.h, dgp_unit_h2): conv2 (3x3, stride 1) + conv3 (+ shortcut, ReLU) of a
     bottleneck unit and conv1 of the next unit in one launch.  r1 [N, H, W, C] is conv2's input; w2 HWIO [3, 3, C, C].
-    -> (x_out H2, r1_out H2, r2 range slots, x_out range slots, r1_out range slots)."""
+    -> (x_out H2, r1_out H2, r2 range slots, x_out range slots, r1_out range slots).  h1: H1 tensors (torch.float16; dgp_unit_h1)."""
     lib = _lib.load()
-    _need_cuda(r1_h2, torch.float32, "r1_h2")
-    _need_cuda(src2_h2, torch.float32, "src2_h2")
+    dt = torch.float16 if h1 else torch.float32
+    _need_cuda(r1_h2, dt, "r1_h2")
+    _need_cuda(src2_h2, dt, "src2_h2")
     N, H, W, Cc = r1_h2.shape
     K, C4 = w3cat.shape
     C1 = w1.shape[1]
     assert C4 == 4 * Cc and w1.shape[0] == C4 and w2.shape == (3, 3, Cc, Cc)
     cin2 = K - Cc
     dev = r1_h2.device
-    xo = torch.empty((N, H, W, C4), dtype=torch.float32, device=dev)
-    r1o = torch.empty((N, H, W, C1), dtype=torch.float32, device=dev)
+    xo = torch.empty((N, H, W, C4), dtype=dt, device=dev)
+    r1o = torch.empty((N, H, W, C1), dtype=dt, device=dev)
     rng = torch.zeros((3, ABSMAX_SLOTS), dtype=torch.float32, device=dev)
     f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
     arrs = [f(a) for a in (w2, scale2, bias2, w3cat, scale3, bias3, w1, scale1, bias1)]
     hp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
-    _lib.check(lib.dgp_unit_h2(N, H, W, Cc, C1, cin2, int(res_mode), _ptr(r1_h2), int(r1_exp), _ptr(src2_h2), int(src2_exp),
+    _lib.check((lib.dgp_unit_h1 if h1 else lib.dgp_unit_h2)(N, H, W, Cc, C1, cin2, int(res_mode), _ptr(r1_h2), int(r1_exp), _ptr(src2_h2), int(src2_exp),
                                hp(arrs[0]), hp(arrs[1]), hp(arrs[2]), int(r2_exp), hp(arrs[3]), hp(arrs[4]), hp(arrs[5]), hp(arrs[6]),
                                hp(arrs[7]), hp(arrs[8]), _ptr(xo), int(xout_exp), _ptr(r1o), int(r1out_exp), _ptr(rng[0]), _ptr(rng[1]),
                                _ptr(rng[2]), _stream(dev)), "dgp_unit_h2")

@@ -365,6 +365,18 @@ int  dgp_unit_h2(int32_t N, int32_t H, int32_t W, int32_t C, int32_t C1, int32_t
                  const float* w3cat, const float* scale3, const float* bias3, const float* w1, const float* scale1, const float* bias1,
                  void* xout_h2, int32_t xout_exp, void* r1out_h2, int32_t r1out_exp, float* r2_absmax, float* xout_absmax, float* r1_absmax,
                  void* stream);
+/* dgp_chain_h2 / dgp_unit_h2 on H1 tensors (the 16-bit tier's instances of the same kernels: 2 bytes per channel, the chunks' high weight
+ * fragments only, one MFMA per product; a REPORTED tier, see dgp_net_set_tier).  Same arguments, every device tensor H1. */
+int  dgp_chain_h1(int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t C1, int32_t CIN2, int32_t res_mode, int32_t res_H, int32_t res_W,
+                  const void* r2_h1, int32_t r2_exp, const void* src2_h1, int32_t src2_exp,
+                  const float* w3cat, const float* scale3, const float* bias3, const float* w1, const float* scale1, const float* bias1,
+                  void* xout_h1, int32_t xout_exp, void* r1_h1, int32_t r1_exp, float* xout_absmax, float* r1_absmax, void* stream);
+int  dgp_unit_h1(int32_t N, int32_t H, int32_t W, int32_t C, int32_t C1, int32_t CIN2, int32_t res_mode,
+                 const void* r1_h1, int32_t r1_exp, const void* src2_h1, int32_t src2_exp,
+                 const float* w2, const float* scale2, const float* bias2, int32_t r2_exp,
+                 const float* w3cat, const float* scale3, const float* bias3, const float* w1, const float* scale1, const float* bias1,
+                 void* xout_h1, int32_t xout_exp, void* r1out_h1, int32_t r1out_exp, float* r2_absmax, float* xout_absmax, float* r1_absmax,
+                 void* stream);
 /* Synchronises `stream`, then: *overflow = 1 if any forward since the last call outgrew a calibrated scale (the flag is cleared
  * and the net re-calibrates on its next forward); *calibrations = calibration passes run so far. */
 int  dgp_net_range_status(dgp_net* net, int32_t* overflow, int32_t* calibrations, void* stream);

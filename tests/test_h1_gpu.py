@@ -175,3 +175,178 @@ def test_tier_f16_overflow_is_detected_and_recovered(lib_built):
     mu, _, idx = net.infer(torch.from_numpy(frames).cuda())               # re-calibrates on this batch
     ref = O.infer(frames, wts, 50, 8.0, 1.0, 1)
     assert float(np.abs(mu.cpu().numpy() - ref["mu"]).max()) * 8.0 < 0.1
+
+
+# ---- the chain / unit kernels on H1 tensors (dgp_chain_h1 / dgp_unit_h1: the 16-bit tier's instances of csrc/dgp_chain.hip) ----------------
+# Reference: float64 on exactly the fp16 operands each stage multiplies -- activations as the cells hold them, weights rounded to fp16 on
+# their panel's power-of-two scale, and every intermediate (R2, X') rounded to the H1 cell the kernel builds its next operand from.  What
+# is left is fp32 accumulation, one fp16 rounding per stored value, and -- behind an intermediate -- the rare element whose fp16 rounding
+# falls the other way (an ulp of one operand of a 64..512-term sum): per-element bound for the first stage, a max-relative bound behind it.
+
+def _q16(t, e):
+    """float64 tensor -> the value its H1 cell holds (fp16(x 2^e) 2^-e)"""
+    return (t * 2.0 ** e).to(torch.float16).double() * 2.0 ** -e
+
+
+def _wq16(w):
+    e = _w_exp(w)
+    return (torch.from_numpy(np.asarray(w)).cuda() * 2.0 ** e).to(torch.float16).double() * 2.0 ** -e
+
+
+H1_CHAIN_CASES = [
+    # N, Ho, Wo, C, C1, CIN2, res_mode
+    (2, 17, 23, 64, 64, 0, 1),        # identity unit of block1 (ragged last tile)
+    (3, 30, 40, 64, 64, 64, 0),       # block1 unit_1: conv3 + shortcut conv K-concatenated, then unit_2's conv1
+    (2, 15, 20, 64, 128, 0, 2),       # stride-2 unit at the end of block1 -> block2 unit_1's conv1
+    (2, 15, 20, 128, 128, 0, 1),      # identity unit of block2
+    (2, 8, 10, 128, 256, 0, 2),       # end of block2 -> block3 unit_1's conv1
+    (32, 60, 80, 128, 128, 0, 1),     # batch-32 640x480 shape of block2 (1200 tiles over persistent workgroups)
+]
+
+
+@pytest.mark.parametrize("case", H1_CHAIN_CASES)
+def test_chain_on_h1_tensors(lib_built, case):
+    from deepgraphpose_amd import engine
+    N, Ho, Wo, C, C1, CIN2, res_mode = case
+    seed = abs(hash(case)) % (2 ** 31)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    C4, M = 4 * C, N * Ho * Wo
+    r2 = torch.relu(torch.randn((N, Ho, Wo, C), device="cuda", generator=g)) * 3.0
+    shp = (N, Ho, Wo, CIN2) if res_mode == 0 else ((N, Ho, Wo, C4) if res_mode == 1 else (N, 2 * Ho - 1, 2 * Wo, C4))
+    src2 = torch.relu(torch.randn(shp, device="cuda", generator=g)) * 2.0
+    w3 = (rng.standard_normal((C + CIN2, C4)) / np.sqrt(C + CIN2)).astype(np.float32)
+    w1 = (rng.standard_normal((C4, C1)) / np.sqrt(C4)).astype(np.float32)
+    s3 = None if res_mode == 0 else (1 + 0.1 * rng.standard_normal(C4)).astype(np.float32)
+    b3 = (0.1 * rng.standard_normal(C4)).astype(np.float32)
+    s1 = (1 + 0.1 * rng.standard_normal(C1)).astype(np.float32)
+    b1 = (0.1 * rng.standard_normal(C1)).astype(np.float32)
+    dd = lambda a: torch.from_numpy(np.asarray(a)).double().cuda()
+    if res_mode == 0:
+        e_r2 = e_s2 = engine.h2_exp_for(max(float(r2.max()), float(src2.max())))
+    else:
+        e_r2, e_s2 = engine.h2_exp_for(float(r2.max())), engine.h2_exp_for(float(src2.max()))
+    r2h, s2h = engine.f32_to_h1(r2, e_r2), engine.f32_to_h1(src2, e_s2)
+    r2q, s2q = engine.h1_to_f32(r2h, e_r2).double(), engine.h1_to_f32(s2h, e_s2).double()
+    if res_mode == 0:
+        acc = torch.cat([r2q.reshape(M, C), s2q.reshape(M, CIN2)], 1) @ _wq16(w3) + dd(b3)
+    else:
+        sc = s2q if res_mode == 1 else s2q[:, ::2, ::2]
+        acc = (r2q.reshape(M, C) @ _wq16(w3)) * dd(s3) + dd(b3) + sc.reshape(M, C4)
+    x_ref = torch.relu(acc)
+    e_x = engine.h2_exp_for(float(x_ref.max()))
+    r1_ref = torch.relu((_q16(x_ref, e_x) @ _wq16(w1)) * dd(s1) + dd(b1))
+    e_r1 = engine.h2_exp_for(float(r1_ref.max()))
+    xo, r1, xrng, r1rng = engine.chain_h2(r2h, e_r2, s2h, e_s2, w3, s3, b3, w1, s1, b1, res_mode, e_x, e_r1, h1=True)
+    assert xo.dtype == torch.float16 and r1.dtype == torch.float16
+    x_out = engine.h1_to_f32(xo, e_x).double().reshape(M, C4)
+    r1_out = engine.h1_to_f32(r1, e_r1).double().reshape(M, C1)
+    mx, mr = float(x_ref.max()), float(r1_ref.max())
+    tol = 2.0 ** -11 * x_ref.abs() * (1 + 1e-3) + 2.0 ** -24 * 2.0 ** -e_x + 4e-6 * mx
+    assert bool(((x_out - x_ref).abs() <= tol).all()), (case, float(((x_out - x_ref).abs() - tol).max()))
+    assert float((r1_out - r1_ref).abs().max()) < 3e-3 * mr, case                      # (an X' cell rounded the other way moves a sum by <= 2^-11 |x w|)
+    assert float((r1_out - r1_ref).abs().mean()) < 2e-4 * mr, case
+    assert abs(float(xrng.max()) - mx) <= 1e-4 * mx and abs(float(r1rng.max()) - mr) <= 2e-3 * mr
+    if M > 100000 or res_mode == 0:
+        return
+    # the layer-by-layer H1 kernels on the same cells: same operands, another accumulation order
+    y3, _ = engine.conv2d_h1(r2h, e_r2, w3.reshape(1, 1, C, C4), scale=s3, bias=b3, residual=s2h, res_stride=res_mode, res_exp=e_s2, relu=True,
+                             y_is_h1=True, y_exp=e_x, out_hw=(Ho, Wo))
+    y1, _ = engine.conv2d_h1(y3, e_x, w1.reshape(1, 1, C4, C1), scale=s1, bias=b1, relu=True, y_is_h1=True, y_exp=e_r1)
+    a = engine.h1_to_f32(y3, e_x).double().reshape(M, C4)
+    b = engine.h1_to_f32(y1, e_r1).double().reshape(M, C1)
+    assert float(((a - x_out).abs() > 0).double().mean()) < 2e-3, case                 # all but the rare tie-side flips are bit-identical
+    assert float((a - x_out).abs().max()) <= 2.0 ** -10 * mx and float((b - r1_out).abs().max()) < 3e-3 * mr, case
+
+
+H1_UNIT_CASES = [
+    # N, H, W, CIN2, res_mode            (C = C1 = 64: block1)
+    (2, 13, 21, 0, 1),        # ragged in both directions: halo zeros at every image edge, the 8-pixel DMA groups past the tile
+    (1, 4, 16, 0, 1),         # exactly one tile
+    (2, 19, 33, 64, 0),       # unit_1: conv3 + shortcut conv K-concatenated
+    (32, 120, 160, 0, 1),     # the batch-32 640x480 shape of block1/unit_2
+    (4, 120, 160, 64, 0),     # block1/unit_1 at full frame size
+]
+
+
+@pytest.mark.parametrize("case", H1_UNIT_CASES)
+def test_unit_kernel_on_h1_tensors(lib_built, case):
+    from deepgraphpose_amd import engine
+    N, H, W, CIN2, res_mode = case
+    C = C1 = 64
+    C4, M = 4 * C, N * H * W
+    seed = abs(hash(case)) % (2 ** 31)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    r1 = torch.relu(torch.randn((N, H, W, C), device="cuda", generator=g)) * 3.0
+    src2 = torch.relu(torch.randn((N, H, W, CIN2 if res_mode == 0 else C4), device="cuda", generator=g)) * 2.0
+    w2 = (rng.standard_normal((3, 3, C, C)) / np.sqrt(9 * C)).astype(np.float32)
+    s2 = (1 + 0.1 * rng.standard_normal(C)).astype(np.float32)
+    b2 = (0.1 * rng.standard_normal(C)).astype(np.float32)
+    w3 = (rng.standard_normal((C + CIN2, C4)) / np.sqrt(C + CIN2)).astype(np.float32)
+    s3 = None if res_mode == 0 else (1 + 0.1 * rng.standard_normal(C4)).astype(np.float32)
+    b3 = (0.1 * rng.standard_normal(C4)).astype(np.float32)
+    w1 = (rng.standard_normal((C4, C1)) / np.sqrt(C4)).astype(np.float32)
+    s1 = (1 + 0.1 * rng.standard_normal(C1)).astype(np.float32)
+    b1 = (0.1 * rng.standard_normal(C1)).astype(np.float32)
+    dd = lambda a: torch.from_numpy(np.asarray(a)).double().cuda()
+    e_r1 = engine.h2_exp_for(float(r1.max()))
+    r1h = engine.f32_to_h1(r1, e_r1)
+    r1q = engine.h1_to_f32(r1h, e_r1).double()
+    xp = torch.zeros((N, H + 2, W + 2, C), dtype=torch.float64, device="cuda")
+    xp[:, 1:H + 1, 1:W + 1] = r1q
+    r2_ref = torch.zeros((M, C), dtype=torch.float64, device="cuda")
+    w2q = _wq16(w2).reshape(9, C, C)
+    for t in range(9):                                    # tap by tap: the batch-32 case would need 2.8 GB of im2col columns in float64
+        r2_ref += xp[:, t // 3:t // 3 + H, t % 3:t % 3 + W].reshape(M, C) @ w2q[t]
+    r2_ref = torch.relu(r2_ref * dd(s2) + dd(b2))
+    if res_mode == 0:
+        e_r2 = e_s2 = engine.h2_exp_for(max(float(r2_ref.max()), float(src2.max())))
+    else:
+        e_r2, e_s2 = engine.h2_exp_for(float(r2_ref.max())), engine.h2_exp_for(float(src2.max()))
+    s2h = engine.f32_to_h1(src2, e_s2)
+    s2q = engine.h1_to_f32(s2h, e_s2).double()
+    r2q = _q16(r2_ref, e_r2)
+    if res_mode == 0:
+        acc = torch.cat([r2q, s2q.reshape(M, CIN2)], 1) @ _wq16(w3) + dd(b3)
+    else:
+        acc = (r2q @ _wq16(w3)) * dd(s3) + dd(b3) + s2q.reshape(M, C4)
+    x_ref = torch.relu(acc)
+    e_x = engine.h2_exp_for(float(x_ref.max()))
+    r1o_ref = torch.relu((_q16(x_ref, e_x) @ _wq16(w1)) * dd(s1) + dd(b1))
+    e_o = engine.h2_exp_for(float(r1o_ref.max()))
+    xo, r1o, r2rng, xrng, orng = engine.unit_h2(r1h, e_r1, s2h, e_s2, w2, s2, b2, e_r2, w3, s3, b3, w1, s1, b1, res_mode, e_x, e_o, h1=True)
+    x_out = engine.h1_to_f32(xo, e_x).double().reshape(M, C4)
+    r1_out = engine.h1_to_f32(r1o, e_o).double().reshape(M, C1)
+    mx, mo = float(x_ref.max()), float(r1o_ref.max())
+    # X' sits behind the rounded R2, R1' behind the rounded X': max-relative bounds (see the note above), tight mean bounds
+    assert float((x_out - x_ref).abs().max()) < 3e-3 * mx and float((x_out - x_ref).abs().mean()) < 2e-4 * mx, case
+    assert float((r1_out - r1o_ref).abs().max()) < 3e-3 * mo and float((r1_out - r1o_ref).abs().mean()) < 2e-4 * mo, case
+    for got, want in ((r2rng, r2_ref), (xrng, x_ref), (orng, r1o_ref)):
+        assert abs(float(got.max()) - float(want.max())) <= 2e-3 * float(want.max())
+
+
+def test_tier_f16_network_is_the_same_with_and_without_its_chain_kernels(lib_built, tmp_path):
+    """DGP_CHAIN_H1 is read once per process: the layer-by-layer 16-bit engine runs in a child process.  Same fp16 operands, another
+    accumulation order and intermediate cells rounded the other way -- which makes the two runs two realisations of the tier's own rounding
+    noise (measured 0.027 px apart; each is 0.02-0.035 px from the oracle): the bound is the tier's band, not a bit-identity claim."""
+    import os, subprocess, sys
+    from deepgraphpose_amd import engine
+    from deepgraphpose_amd.synthetic import make_frames, make_weights
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np, torch\n"
+            "from deepgraphpose_amd import engine\n"
+            "from deepgraphpose_amd.synthetic import make_frames, make_weights\n"
+            "net = engine.DGPNet(50, 4, 192, 256, max_batch=3, tier='f16')\n"
+            "net.load_weights(make_weights(50, 4, False, seed=5, head_std=0.05))\n"
+            "mu, conf, idx = net.infer(torch.from_numpy(make_frames(3, 192, 256, 4, seed=6)).cuda(), 1.0, 1)\n"
+            "np.savez(sys.argv[1], mu=mu.cpu().numpy(), conf=conf.cpu().numpy(), idx=idx.cpu().numpy())\n")
+    out = {}
+    for flag in ("0", "1"):
+        path = str(tmp_path / ("t%s.npz" % flag))
+        subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, DGP_CHAIN_H1=flag, PYTHONPATH=root), cwd=root)
+        out[flag] = np.load(path)
+    d = np.abs(out["0"]["mu"] - out["1"]["mu"]).max() * 8.0
+    assert d < 0.08, d
+    assert np.abs(out["0"]["conf"] - out["1"]["conf"]).max() < 0.02
+    assert (out["0"]["idx"] == out["1"]["idx"]).all(-1).mean() > 0.9
