@@ -910,17 +910,11 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
     if (p.out_absmax)
         slot_bits = __hip_atomic_load(reinterpret_cast<const unsigned*>(p.out_absmax) + ((int)(blockIdx.x * 8u + (threadIdx.x >> 6)) & (ABSMAX_SLOTS - 1)),
                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    float sc[8], bi[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { sc[k] = post; bi[k] = 0.f; }
-    if (cok && p.scale) {
-        const float4 a = *reinterpret_cast<const float4*>(p.scale + co8), b = *reinterpret_cast<const float4*>(p.scale + co8 + 4);
-        sc[0] *= a.x; sc[1] *= a.y; sc[2] *= a.z; sc[3] *= a.w; sc[4] *= b.x; sc[5] *= b.y; sc[6] *= b.z; sc[7] *= b.w;
-    }
-    if (cok && p.bias) {
-        const float4 a = *reinterpret_cast<const float4*>(p.bias + co8), b = *reinterpret_cast<const float4*>(p.bias + co8 + 4);
-        bi[0] = a.x; bi[1] = a.y; bi[2] = a.z; bi[3] = a.w; bi[4] = b.x; bi[5] = b.y; bi[6] = b.z; bi[7] = b.w;
-    }
+    // scale / bias are REQUESTED here and consumed behind the residual requests below: with `post * scale` computed on the spot the
+    // compiler waited for them (an L2 round trip) before it issued the first residual load
+    float4 sc_a = make_float4(1.f, 1.f, 1.f, 1.f), sc_b = sc_a, bi_a = make_float4(0.f, 0.f, 0.f, 0.f), bi_b = bi_a;
+    if (cok && p.scale) { sc_a = *reinterpret_cast<const float4*>(p.scale + co8); sc_b = *reinterpret_cast<const float4*>(p.scale + co8 + 4); }
+    if (cok && p.bias) { bi_a = *reinterpret_cast<const float4*>(p.bias + co8); bi_b = *reinterpret_cast<const float4*>(p.bias + co8 + 4); }
     // (out_scale / res_inv_scale: the tensors' scales, read by the caller BEFORE its K loop -- in the trainer they are predictions from range
     //  slots, a load and a wave reduction each, which stood in front of the first chunk of every tile)
     // O1 only (the 16-bit trainer's data-gradient convs): ReLU gate read from an H1 tensor of the output's shape (gate = stored half > 0)
@@ -977,6 +971,9 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
     } else {
         issue(0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);             // (keeps the requests above in front of the first use of scale / bias)
+    const float sc[8] = {post * sc_a.x, post * sc_a.y, post * sc_a.z, post * sc_a.w, post * sc_b.x, post * sc_b.y, post * sc_b.z, post * sc_b.w};
+    const float bi[8] = {bi_a.x, bi_a.y, bi_a.z, bi_a.w, bi_b.x, bi_b.y, bi_b.z, bi_b.w};
     DIAG_STAMP(s1_);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
