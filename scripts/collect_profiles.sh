@@ -16,5 +16,9 @@ cp "$S/train_step_kernel_stats.txt" "$D/${TAG}_train_step_kernel_stats.txt"
 cp "$S/train_step_f16_kernel_stats.txt" "$D/${TAG}_train_step_f16_kernel_stats.txt"
 cp "$S/train_step_f16_timeline.txt" "$D/${TAG}_train_step_f16_timeline.txt"
 cp "$S/train_step_ab_tiers.txt" "$D/${TAG}_train_step_ab_tiers.txt"
+cp "$S/traffic_per_layer_parity.txt" "$D/${TAG}_traffic_per_layer_parity.txt"
+cp "$S/traffic_per_layer_f16.txt" "$D/${TAG}_traffic_per_layer_f16.txt"
+cp "$S/f16_layer_table_hipevents.tsv" "$D/${TAG}_f16_layer_table_hipevents.tsv"
+cp "$S/f16_layer_roofs.txt" "$D/${TAG}_f16_layer_roofs.txt"
 python3 "$ROOT/scripts/readme_numbers.py"
 ls -la "$D" | grep "${TAG}"

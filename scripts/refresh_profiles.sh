@@ -23,5 +23,10 @@ cp gpurun_out/prof_${TAG}_f16/traffic.json "$OUT/f16_traffic.json"
 bash scripts/profile_train.sh > "$OUT/train_step_kernel_stats.txt" 2>&1
 bash scripts/profile_train_f16.sh > "$OUT/train_step_f16_kernel_stats.txt" 2>&1
 bash scripts/timeline_train.sh f16 15 > "$OUT/train_step_f16_timeline.txt" 2>&1
+# memory-side traffic of EVERY launch of a step beside its algorithmic bytes (separate FETCH_SIZE / WRITE_SIZE passes), both tiers
+bash scripts/traffic_per_layer.sh parity ${TAG}_parity > /dev/null 2>&1; cp gpurun_out/tpl_${TAG}_parity/per_layer.txt "$OUT/traffic_per_layer_parity.txt"
+bash scripts/traffic_per_layer.sh f16 ${TAG}_f16 > /dev/null 2>&1; cp gpurun_out/tpl_${TAG}_f16/per_layer.txt "$OUT/traffic_per_layer_f16.txt"
+python3 scripts/bench_tier.py f16 --steps 100 --table "$OUT/f16_layer_table_hipevents.tsv" > "$OUT/f16_bench_tier.txt" 2>&1
+python3 scripts/layer_roofs.py "$OUT/f16_layer_table_hipevents.tsv" 2 2500 > "$OUT/f16_layer_roofs.txt" 2>&1
 for i in 1 2; do python3 scripts/bench_train.py 50 8 f16 3 | cut -c1-140; python3 scripts/bench_train.py 50 8 parity 3 | cut -c1-140; done > "$OUT/train_step_ab_tiers.txt" 2>&1
 ls -la "$OUT"
