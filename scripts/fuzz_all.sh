@@ -14,6 +14,7 @@ run fuzz_readout $((150 * K)) $SEED            # soft-argmax, likelihood window,
 run fuzz_conv_h2 $((200 * K)) $SEED            # every loader of the cell kernels
 run fuzz_halo $((100 * K)) $SEED               # the halo walk and its fall-backs
 run fuzz_fused $((120 * K)) $SEED              # chain / unit kernels
+mv "$OUT/fuzz_fused.log" "$OUT/fuzz_fused_h2.log"; run fuzz_fused $((120 * K)) $SEED --h1        # ... their instances on H1 tensors (the 16-bit tier)
 run fuzz_conv_f32 $((200 * K)) $SEED           # fp32-activation tiles, max-pool, H2 converters
 run fuzz_backward_layers $((100 * K)) $SEED    # weight-gradient tiles, data gradient
 run fuzz_train $((14 * K)) $SEED               # whole DGP training steps vs fp64 autograd
