@@ -7,6 +7,7 @@ cd "$ROOT"; SEED=${1:-0}; K=${2:-1}; OUT=gpurun_out/fuzz_all_$SEED; mkdir -p "$O
 run() { name=$1; shift; timeout 3000 python "scripts/$name.py" "$@" > "$OUT/$name.log" 2>&1; r=$?; [ $r -ne 0 ] && rc=1
         echo "$name: rc $r, $(grep -c '^ok' "$OUT/$name.log") ok lines, $(tail -1 "$OUT/$name.log")"; grep -v '^ok\|^rej \|amdgpu' "$OUT/$name.log" | head -5 | cut -c1-220; }
 run fuzz_net $((40 * K)) $SEED                 # whole networks (size, bodyparts, batch, locref, depth) vs the oracle
+mv "$OUT/fuzz_net.log" "$OUT/fuzz_net_parity.log"; run fuzz_net $((20 * K)) $SEED --f16       # ... the 16-bit tier inside its band
 run fuzz_estimate_pose $((12 * K)) $SEED       # the A0 entry point: batch sizes, chunk rounds, ragged tails
 run fuzz_resize $((4 * K)) $SEED                # one engine through sequences of frame sizes, batch sizes and brightness
 run fuzz_pipeline $((6 * K)) $SEED              # DGPPipeline submit patterns vs one engine, bit for bit

@@ -1,12 +1,16 @@
-"""Random whole-net configurations (frame size, bodyparts, batch, locref) against the CPU oracle.  Usage: python scripts/fuzz_net.py [n] [seed]"""
+"""Random whole-net configurations (frame size, bodyparts, batch, locref) against the CPU oracle.  --f16: the 16-bit tier
+(H1 cells, its chain / unit kernels) inside ITS band (scoremap 1e-2 of the range, 0.1 px, >= 85 % of the window indices) instead of the parity gate.
+Usage: python scripts/fuzz_net.py [n] [seed] [--f16]"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepgraphpose_amd.engine import DGPNet
 from deepgraphpose_amd.synthetic import make_frames, make_weights
 from oracle import dgp_oracle as O
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+F16 = "--f16" in sys.argv
+argv = [a for a in sys.argv if a != "--f16"]
+n = int(argv[1]) if len(argv) > 1 else 20
+rng = np.random.default_rng(int(argv[2]) if len(argv) > 2 else 0)
 bad = 0
 for k in range(n):
     H, W = int(rng.integers(33, 420)), int(rng.integers(33, 420))
@@ -15,7 +19,7 @@ for k in range(n):
     wts = make_weights(depth, nj, loc, seed=int(rng.integers(1 << 20)), head_std=0.05)
     frames = make_frames(B, H, W, nj, seed=int(rng.integers(1 << 20)))
     try:
-        net = DGPNet(depth, nj, H, W, max_batch=B, with_locref=loc)
+        net = DGPNet(depth, nj, H, W, max_batch=B, with_locref=loc, tier="f16" if F16 else "parity")
         net.load_weights(wts)
         ft = torch.from_numpy(frames).cuda()
         out = net.forward(ft, want_locref=loc)
@@ -28,7 +32,11 @@ for k in range(n):
         e_sc = np.abs(sc - s_ref).max() / max(np.abs(s_ref).max(), 1e-30)
         e_lr = np.abs(lr - l_ref).max() / max(np.abs(l_ref).max(), 1e-30) if loc else 0.0
         e_mu = np.abs(mu.cpu().numpy() - ref["mu"]).max() * 8.0
-        ok = e_sc < 1e-4 and e_lr < 1e-4 and e_mu < 1e-3 and np.array_equal(idx.cpu().numpy(), ref["idx"]) and not net.range_status()[0]
+        if F16:
+            agree = float((idx.cpu().numpy() == ref["idx"]).all(-1).mean())
+            ok = e_sc < 1e-2 and e_lr < 2e-2 and e_mu < 0.1 and agree >= 0.85 and not net.range_status()[0]
+        else:
+            ok = e_sc < 1e-4 and e_lr < 1e-4 and e_mu < 1e-3 and np.array_equal(idx.cpu().numpy(), ref["idx"]) and not net.range_status()[0]
     except Exception as e:      # noqa: BLE001
         ok, e_sc, e_lr, e_mu = False, -1, -1, -1
         print("   exception:", repr(e)[:200])
