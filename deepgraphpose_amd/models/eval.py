@@ -131,7 +131,8 @@ def setup_dgp_eval_graph(dlc_cfg, dgp_model_file, loc_ref=False, gauss_len=1, ga
 
 
 # counters of the last estimate_pose call (tests, soak runs): chunks processed and chunks re-run after a range overflow
-RUN_STATS = {"chunks": 0, "chunk_reruns": 0, "strict_passes": 0, "stage_s": 0.0, "wait_frames_s": 0.0, "wait_h2d_s": 0.0, "drain_s": 0.0}
+RUN_STATS = {"chunks": 0, "chunk_reruns": 0, "strict_passes": 0, "stage_s": 0.0, "wait_frames_s": 0.0, "wait_h2d_s": 0.0, "drain_s": 0.0,
+             "setup_s": 0.0}
 
 
 def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle=1, save_pose=True, save_str="",
@@ -148,6 +149,7 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
     from ..frames import open_frame_source
     from .. import dist as ddist
     import torch.distributed as tdist
+    t_entry = time.perf_counter()
 
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not tdist.is_initialized():
         ddist.init_from_env()                      # before anything touches the GPU
@@ -384,6 +386,7 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
     # where the host side of the call spent its time: staging copies of in-memory frames (producer thread), the consumer waiting for a
     # decoded batch / for an H2D copy / for the engines at a chunk boundary
     RUN_STATS["stage_s"] = RUN_STATS["wait_frames_s"] = RUN_STATS["wait_h2d_s"] = RUN_STATS["drain_s"] = 0.0
+    RUN_STATS["setup_s"] = time.perf_counter() - t_entry      # config, snapshot -> engine (read, re-pack, upload): before the first frame moves
     for _pass in range(4):
         if not (_infer_once(video_clip) and os.environ.get("DGP_EVAL_STRICT", "0") == "1"):
             break

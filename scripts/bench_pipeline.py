@@ -26,7 +26,9 @@ out = E.estimate_pose(os.path.join(proj, "config.yaml"), snap, frames, os.path.j
 dt = time.perf_counter() - t0
 if "--json" in sys.argv:
     import json
+    setup = float(E.RUN_STATS.get("setup_s", 0.0))
     print(json.dumps({"frames_per_s": round(T / dt, 1), "frames": T, "seconds": round(dt, 3), "batch": 32,
+                      "steady_frames_per_s": round(T / max(dt - setup, 1e-9), 1),      # without the call's fixed cost (snapshot -> engine), i.e. a long video's rate
                       "host_seconds": {k: round(float(v), 3) for k, v in E.RUN_STATS.items() if k.endswith("_s")},
                       "workload": "estimate_pose on a host array of %d 640x480x3 u8 frames (ResNet-50, 4 keypoints): engine set-up, decode thread, pinned "
                                   "staging, H2D on a copy stream, two engines, one D2H of the trajectory -- PCIe-inclusive, never `value`" % T}), flush=True)
