@@ -1,11 +1,11 @@
 """Soak: N forwards of the bench workload (ResNet-50, 640x480, batch 32, both heads) on the same frames; every scoremap / locref / keypoint
-output must equal the first run bit for bit (a race in a loader protocol would show up as run-to-run differences).  Usage: python scripts/soak_determinism.py [N]"""
+output must equal the first run bit for bit (a race in a loader protocol would show up as run-to-run differences).  Usage: python scripts/soak_determinism.py [N] [parity|f16]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from deepgraphpose_amd import engine, synthetic
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-net = engine.DGPNet(50, 4, 480, 640, max_batch=32)
+net = engine.DGPNet(50, 4, 480, 640, max_batch=32, tier=(sys.argv[2] if len(sys.argv) > 2 else "parity"))
 net.load_weights(synthetic.make_weights(50, 4, True, seed=0))
 f = torch.from_numpy(synthetic.make_frames(32, 480, 640, 4, seed=1)).cuda()
 def run():
