@@ -1435,10 +1435,10 @@ static int chain_layer(bool h1, int32_t N, int32_t Ho, int32_t Wo, int32_t C, in
                  const float* w3cat, const float* scale3, const float* bias3, const float* w1, const float* scale1, const float* bias1,
                  void* xout_h2, int32_t xout_exp, void* r1_h2, int32_t r1_exp, float* xout_absmax, float* r1_absmax, void* stream) {
     const size_t EB = h1 ? 2 : 4;                  // bytes per channel: H1 cells / H2 cell pairs
-    if (!r2_h2 || !src2_h2 || !w3cat || !w1 || !xout_h2 || !r1_h2) return fail(DGP_ERR_INVALID, "dgp_chain_h2: null argument");
+    if (!r2_h2 || !src2_h2 || !w3cat || !w1 || !xout_h2 || !r1_h2) return fail(DGP_ERR_INVALID, h1 ? "dgp_chain_h1: null argument" : "dgp_chain_h2: null argument");
     if (!chain_supported(C, C1, CIN2, res_mode))
-        return fail(DGP_ERR_INVALID, "dgp_chain_h2: no kernel instance for this (C, C1, CIN2, res_mode)");
-    if (res_mode == 0 && src2_exp != r2_exp) return fail(DGP_ERR_INVALID, "dgp_chain_h2: the K-concatenated source must share R2's scale");
+        return fail(DGP_ERR_INVALID, "dgp_chain_h2 / _h1: no kernel instance for this (C, C1, CIN2, res_mode)");
+    if (res_mode == 0 && src2_exp != r2_exp) return fail(DGP_ERR_INVALID, "dgp_chain_h2 / _h1: the K-concatenated source must share R2's scale");
     ChainPlan cp;
     int rc = build_chain_plan(cp, C, C1, CIN2, res_mode, w3cat, scale3, bias3, w1, scale1, bias1);
     if (rc) return rc;
@@ -1455,7 +1455,7 @@ static int chain_layer(bool h1, int32_t N, int32_t Ho, int32_t Wo, int32_t C, in
     hipError_t e = launch_chain(a, C, C1, CIN2, res_mode, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);       // (the fragments are freed below)
     free_chain_plan(cp);
-    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_chain_h2: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string(h1 ? "dgp_chain_h1: " : "dgp_chain_h2: ") + hipGetErrorString(e));
     return DGP_OK;
 }
 
@@ -1468,11 +1468,11 @@ static int unit_layer(bool h1, int32_t N, int32_t H, int32_t W, int32_t C, int32
                 void* xout_h2, int32_t xout_exp, void* r1out_h2, int32_t r1out_exp, float* r2_absmax, float* xout_absmax, float* r1_absmax,
                 void* stream) {
     const size_t EB = h1 ? 2 : 4;
-    if (!r1_h2 || !src2_h2 || !w2 || !w3cat || !w1 || !xout_h2 || !r1out_h2) return fail(DGP_ERR_INVALID, "dgp_unit_h2: null argument");
+    if (!r1_h2 || !src2_h2 || !w2 || !w3cat || !w1 || !xout_h2 || !r1out_h2) return fail(DGP_ERR_INVALID, h1 ? "dgp_unit_h1: null argument" : "dgp_unit_h2: null argument");
     if (!unit_supported(C, C1, CIN2, res_mode))
-        return fail(DGP_ERR_INVALID, "dgp_unit_h2: no kernel instance for this (C, C1, CIN2, res_mode)");
-    if (res_mode == 0 && src2_exp != r2_exp) return fail(DGP_ERR_INVALID, "dgp_unit_h2: the K-concatenated source must share R2's scale");
-    if (r1_h2 == r1out_h2) return fail(DGP_ERR_INVALID, "dgp_unit_h2: r1out must not alias r1 (halo reads)");
+        return fail(DGP_ERR_INVALID, "dgp_unit_h2 / _h1: no kernel instance for this (C, C1, CIN2, res_mode)");
+    if (res_mode == 0 && src2_exp != r2_exp) return fail(DGP_ERR_INVALID, "dgp_unit_h2 / _h1: the K-concatenated source must share R2's scale");
+    if (r1_h2 == r1out_h2) return fail(DGP_ERR_INVALID, "dgp_unit_h2 / _h1: r1out must not alias r1 (halo reads)");
     ChainPlan cp;
     int rc = build_chain_plan(cp, C, C1, CIN2, res_mode, w3cat, scale3, bias3, w1, scale1, bias1, w2, scale2, bias2);
     if (rc) return rc;
@@ -1490,7 +1490,7 @@ static int unit_layer(bool h1, int32_t N, int32_t H, int32_t W, int32_t C, int32
     hipError_t e = launch_unit(a, N, C, C1, CIN2, res_mode, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     free_chain_plan(cp);
-    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string("dgp_unit_h2: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(DGP_ERR_HIP, std::string(h1 ? "dgp_unit_h1: " : "dgp_unit_h2: ") + hipGetErrorString(e));
     return DGP_OK;
 }
 int dgp_chain_h2(int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t C1, int32_t CIN2, int32_t res_mode, int32_t res_H, int32_t res_W,
