@@ -227,7 +227,10 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
         f0 = prep(first)
         hh, ww = f0.shape[:2]
         # two engines on two HIP streams, batches dealt in turn (engine.DGPPipeline; DGP_EVAL_STREAMS=1: one engine, A/B)
+        t_ = time.perf_counter()
         net = net_used = sess.pipe_for(hh, ww, n_streams=max(1, int(os.environ.get("DGP_EVAL_STREAMS", "2"))))
+        torch.cuda.synchronize(dev)
+        RUN_STATS["setup_s"] += time.perf_counter() - t_      # the engines of this frame size: weights re-packed and uploaded (first call of a size)
         nslots = 4                                # pinned staging: one batch being decoded, one being copied, two of slack
         pinned = [torch.empty((batch_size, hh, ww, 3), dtype=torch.uint8).pin_memory() for _ in range(nslots)]
         # The frames of a CHUNK of batches stay on the device until the chunk's range check has come back clean: a chunk whose
