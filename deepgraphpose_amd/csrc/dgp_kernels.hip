@@ -409,6 +409,11 @@ __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[T
     const int half = lane >> 5, l31 = lane & 31;
     const int HoWo = p.Ho * p.Wo;
     float* sC = reinterpret_cast<float*>(smem) + wave * (32 * LDC);
+    // the wave's range slot, read NOW (see ls_epilogue_h2: nothing may wait at the end of the wave)
+    unsigned slot_bits = 0u;
+    if (p.out_absmax)
+        slot_bits = __hip_atomic_load(reinterpret_cast<const unsigned*>(p.out_absmax) + ((int)(blockIdx.x * 8u + (threadIdx.x >> 6)) & (ABSMAX_SLOTS - 1)),
+                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     constexpr int C4 = WN / 4;
     constexpr int NV = 32 * C4 / 64;
     const __amdgpu_buffer_rsrc_t rs_res =
@@ -543,7 +548,7 @@ __device__ __forceinline__ void ls_epilogue(const ConvArgs& p, floatx16 (&acc)[T
 #ifdef DGP_DIAG
     DIAG_STAMP(g3);
 #endif
-    if (p.out_absmax) track_absmax(p.out_absmax, amax, lane, (int)(blockIdx.x * 8u + (threadIdx.x >> 6)));
+    if (p.out_absmax) track_absmax_known(p.out_absmax, amax, lane, (int)(blockIdx.x * 8u + (threadIdx.x >> 6)), slot_bits);
 #ifdef DGP_DIAG
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DIAG_STAMP(g4);
