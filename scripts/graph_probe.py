@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from deepgraphpose_amd import engine, synthetic
 B = 32
-net = engine.DGPNet(50, 4, 480, 640, max_batch=B)
+net = engine.DGPNet(50, 4, 480, 640, max_batch=B, tier=(sys.argv[1] if len(sys.argv) > 1 else "parity"))
 net.load_weights(synthetic.make_weights(50, 4, False, seed=0))
 f = torch.from_numpy(synthetic.make_frames(B, 480, 640, 4, seed=1)).cuda()
 for _ in range(3):
