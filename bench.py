@@ -428,6 +428,10 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
                          % (args.gpus, world))
+    if os.environ.get("DGP_BENCH_VISIBLE_GPUS") and n_dev > 0 and local_rank >= n_dev:
+        # ranks knowingly sharing devices under a launcher that numbers LOCAL_RANK 0..N-1 (torch.distributed.run on a box with fewer GPUs:
+        # the one-GPU test of the driver's exact command line, control plane on gloo)
+        local_rank %= n_dev
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     numa = ddist.bind_to_gpu_numa_node(local_rank)      # before any helper thread exists: they inherit the mask

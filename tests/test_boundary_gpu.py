@@ -269,6 +269,34 @@ def test_bench_through_its_own_spawner(lib_built):
     assert all(v["bound"] in ("hbm", "mfma") for v in kern.values())
 
 
+def test_bench_under_torch_distributed_run_exactly_as_the_driver_launches_it(lib_built):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 --steps K
+    --warmup W` -- the driver's command line for N > 1 -- on the one GPU of this box: the launcher numbers LOCAL_RANK 0 and 1, the explicit
+    opt-in DGP_BENCH_VISIBLE_GPUS=1 folds both onto cuda:0 (control plane on gloo: RCCL refuses two ranks on one device).  ONE JSON line,
+    from rank 0, with the collective object a reader verifies an N-rank line by."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = _child_env(DGP_DIST_BACKEND="gloo", DGP_BENCH_VISIBLE_GPUS=1)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--batch", "8", "--no-cpu-baseline",
+           "--sustain-seconds", "0.2", "--prewarm-seconds", "0.2"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    lines = [q for q in r.stdout.splitlines() if q.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["shard_check"]["indices_identical"] and d["shard_check"]["bit_identical_to_rank0"]
+    c = d["collective"]
+    assert c["backend"] == "gloo" and c["world_size"] == 2 and c["initialized"] and len(c["ranks"]) == 2
+    assert sorted(q["rank"] for q in c["ranks"]) == [0, 1] and c["distinct_devices"] == 1
+    assert "launcher" not in d and "strict_f32" not in d        # (a launcher started the workers; the child legs run at N = 1 only)
+
+
 def test_bench_strong_scaling_two_ranks_through_the_spawner(lib_built):
     """--scaling strong: ONE fixed stream (--total-batches) split over the ranks, through bench.py's own spawner; two ranks on the one
     GPU of the box (gloo control plane), result identical batch by batch to rank 0's ring."""
