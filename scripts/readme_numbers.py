@@ -67,7 +67,8 @@ def table():
         ("training step, 16-bit tier (`train_step_f16`)", "**%s ms** (%s frames/s)" % (
             span([get(d, "train_step_f16", "ms_per_step") for d in L], "%.2f"), span([get(d, "train_step_f16", "frames_per_s") for d in L]))),
         ("strict fp32 MFMA (`strict_f32`)", "%s frames/s" % span([get(d, "strict_f32", "frames_per_s") for d in L])),
-        ("ResNet-101, 1280×720, 20 keypoints, batch 16 (`r101_1280x720`)", "%s frames/s" % span([get(d, "r101_1280x720", "frames_per_s") for d in L])),
+        ("ResNet-101, 1280×720, 20 keypoints, batch 16 (`r101_1280x720`)", "%s frames/s; 16-bit tier (`r101_1280x720_f16`) %s" % (
+            span([get(d, "r101_1280x720", "frames_per_s") for d in L]), span([get(d, "r101_1280x720_f16", "frames_per_s") for d in L]))),
         ("host pipeline (`host_pipeline`: decode → pinned ring → copy stream → engine; PCIe inclusive, never `value`)",
          "%s frames/s end to end on %s frames (engine set-up inside); %s frames/s without the call's fixed cost" % (
              span([get(d, "host_pipeline", "frames_per_s") for d in L]), span([get(d, "host_pipeline", "frames") for d in L], "%d"),
