@@ -598,6 +598,12 @@ def main():
             for i, (n, fl, ms) in enumerate(launches):
                 f.write("%d\t%s\t%.3f\t%.4f\t%.2f\n" % (i, n, fl / 1e9, ms, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0))
 
+    # informative only: what a loop of NOTHING BUT MFMAs sustains on this part under its 1400 W power cap (scripts/micro/mfma_power.hip,
+    # profiles/r5_mfma_power.txt: 1.79 PFLOP/s of dense fp16 = 0.71 of the rating, at the cap) -- the ceiling of a kernel that moves no data at all
+    roofline["mfma_only_sustained_peak"] = round(1788.0 / 3.0, 1)
+    roofline["frac_of_mfma_only_sustained"] = round(roofline["achieved"] / (1788.0 / 3.0), 4)
+    roofline["mfma_only_note"] = ("a pure v_mfma_f32_16x16x32_f16 loop sustains 1788 TFLOP/s at 1350 W of the 1400 W board cap (profiles/r5_mfma_power.txt); the bench "
+                                  "workload itself runs at 1347 W with the clock throttled to ~1.96 GHz (profiles/r5_power_probe.txt): `frac` stays against the rated peak")
     if sustained and sustained.get("sclk_mhz_under_load"):
         # informative only: the chip is power-limited under this load, so the matrix pipe never sees its 2400 MHz rating
         mhz = float(sustained["sclk_mhz_under_load"])
