@@ -343,6 +343,8 @@ def tier_f16_child(args) -> None:
     assert not ov, "activation ranges outgrew the calibrated scales during the 16-bit tier's run"
     roofline, by_kernel = roofline_from_launches(launches, B, 2.0, [os.path.join(ROOT, "profiles", "traffic_r5_f16.json")])
     roofline["steps_profiled"] = n_prof
+    roofline["mfma_only_sustained_peak"] = 1788.0      # (a pure fp16 MFMA loop under the board's power cap: profiles/r5_mfma_power.txt)
+    roofline["frac_of_mfma_only_sustained"] = round(roofline["achieved"] / 1788.0, 4)
     fps2, fps1 = K * B / (t2 - t1), K * B / (t1 - t0)
     res = {"frames_per_s": round(fps2, 1), "ms_per_step": round((t2 - t1) / K * 1e3, 3), "steps": K, "streams": NS,
            "one_stream": {"frames_per_s": round(fps1, 1), "ms_per_step": round((t1 - t0) / K * 1e3, 3)},
