@@ -901,7 +901,8 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
     constexpr int CPP = NV / VC, NQ = TM * CPP;
     const int half = lane >> 5, l31 = lane & 31;
     const int HoWo = p.Ho * p.Wo;
-    float* sC = reinterpret_cast<float*>(smem) + wave * (32 * LDC);
+    // (16x16x32 loops: the caller staged the wave's WHOLE tile, TM x 32 rows; the 32x32x16 loops stage one 32-row pass at a time below)
+    float* sC = reinterpret_cast<float*>(smem) + wave * ((M16 ? TM : 1) * 32 * LDC);
     const __amdgpu_buffer_rsrc_t rs_res =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.in), 0, p.res ? (int)p.res_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
@@ -998,8 +999,9 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
 #pragma unroll
         for (int u = 0; u < VC; ++u) {
             const int row = my_r0 + (v0 + u) * RPI;
-            const float4 a0 = *reinterpret_cast<const float4*>(sC + row * LDC + 8 * my_c8);
-            const float4 a1 = *reinterpret_cast<const float4*>(sC + row * LDC + 8 * my_c8 + 4);
+            const float* srow = sC + ((M16 ? 32 * i : 0) + row) * LDC + 8 * my_c8;
+            const float4 a0 = *reinterpret_cast<const float4*>(srow);
+            const float4 a1 = *reinterpret_cast<const float4*>(srow + 4);
             float o[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
             float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (p.res) {
@@ -1088,13 +1090,19 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
 //   (high, low) cell pair of k-group g is now the pair of k-groups (2 g, 2 g + 1): the compute waves issue a_even b_even + a_odd b_odd --
 //   TWO MFMAs per 64 channels where the parity tier issues three per 32 -- on the same LDS reads.  A third of the matrix work and half the
 //   operand bytes per FLOP; 11-bit operands: NOT inside the 1e-3 px gate (bench.py reports what it measures).  O1 = H1 output.
-//   BM = 256, CW = 8 (the "tall" tile, H2 DMA kernels): eight compute waves of 32 rows x 128 columns each -- the same inner loop -- on
-//   ONE B stage: two co-resident 128-row workgroups fetch the same 16 KB of weight cells per K-step twice, a 256-row workgroup once
-//   (48 instead of 64 KB of L2 -> LDS traffic per CU and K-step).  That path, ~70 GB/s per CU (MI355X_MICROARCH.md, rows served
-//   from the XCD's L2), co-limits the deep-K layers: with a THIRD of the MFMAs (the 16-bit tier) block4's 3x3 conv only went
-//   0.39 -> 0.275 ms.  Measured (one stream, batch 32): block4 3x3 0.389 -> 0.442 ms, block4 conv1 0.195 -> 0.216 ms -- SLOWER: the eight
-//   compute waves of the one 135-KB workgroup per CU meet at one barrier per K-step, where two independent 128-row workgroups drift
-//   apart and fill each other's stalls.  Kept as an opt-in (DGP_TALL=1; DGP_TALL=2 forces it wherever it applies: the parity test).
+//   BM = 256 (round 6; the 16-bit tier only, MODE 1 / 2): FOUR compute waves of 64 rows x 128 columns each on a 256 x 128 tile, ONE
+//   workgroup per CU (256 registers per wave: 128 accumulators).  At one MFMA per product the 128 x 128 tile needs 32 KB of operands
+//   per 32 MFMAs and wave -- two co-resident workgroups pull 64 KB through the L2 -> LDS path per 1 024 matrix cycles, which is that
+//   path's rate (EXPERIMENTS.md R5 (6): the loaders need as long to ISSUE a step's LDS-DMA pieces as the MFMAs of the step take) --
+//   and every wave reads 20 fragments from LDS per 32 MFMAs.  A 64 x 128 wave tile reads 24 fragments per 64 MFMAs (-40 % LDS bytes
+//   per MFMA), the workgroup moves 48 KB per 64 MFMAs and wave (-25 % L2 -> LDS bytes per MFMA) and meets at half as many barriers.
+//   (The round-3 / round-5 "tall" tile -- 256 rows as EIGHT waves of 32 x 128 -- kept the per-wave tile and measured slower; removed.)
+//   MEASURED (round 6, profiles/r6_w64_*.txt): correct -- the network's outputs are bit-identical on either tile -- and SLOWER on every
+//   layer: 1 530-1 640 cycles per K-step where the 64 MFMAs take 1 053, with the loaders idle (barrier wait ~ 100 cycles): the tile is
+//   not operand-bound any more, it is bound by its ONE compute wave per SIMD.  scripts/micro/mfma_w64.hip / mfma_w64b.hip rebuild the
+//   loop piece by piece: MFMA stream 1 053 cycles per step, + weight-fragment reads 1 088, + A-cell reads and the ra -> ah / al copies
+//   1 220, + one workgroup barrier per step 1 375 -- every stall two co-resident 128-row workgroups hide from each other is exposed --
+//   and prologue + epilogue (12-18 k cycles per tile) have nothing to run under.  Opt-in only (DGP_H1_W64).
 //   MODE 3 (round 4; H2 DMA kernels, 3x3 / stride 1 / any dilation: the "halo walk").  With MODE 1 the A rows of a 3x3 conv cross the
 //   L2 -> LDS path NINE times, once per tap (16 KB per K-step and workgroup, as much as the weight cells).  On a stride-1 conv the tap
 //   (kh, kw) of output pixel m reads input pixel m + d ((kh - 1) W + (kw - 1)) of the FLATTENED [N H W] pixel list -- a constant
@@ -1123,15 +1131,16 @@ constexpr int HALO_TBL = HALO_ZERO + 1024;        // three stages of the address
 constexpr int HALO_B0 = HALO_TBL + 2048;          // two stages of weight cells behind it: 49 152 + 32 768 = 80 KB, two workgroups per CU
 static_assert(HALO_B0 == 49152, "80 KB per workgroup");
 template <int BM, int BN, int NT, int BK, int CW, bool PB = false, int MODE = 0, bool CS = false, bool DMA = false, bool AH2 = false, bool OH2 = false, bool DEEP = false, bool H1 = false>
-__global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK == 16 || NT == 2) ? 4 : 2)) void conv_igemm_split_ls(const ConvArgs p) {
+__global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : BM == 256 ? 2 : ((BK == 16 || NT == 2) ? 4 : 2)) void conv_igemm_split_ls(const ConvArgs p) {
     static_assert(MODE != 3 || (DMA && AH2 && OH2 && BM == 128 && BN == 128 && CW == 4 && !DEEP), "halo walk: H2 / H1 tensors, LDS-DMA, 128 x 128 tiles");
     static_assert(!DEEP || (DMA && BN == 128 && BM == 128), "deep ring: LDS-DMA kernels with 128 x 128 tiles");
-    static_assert(!H1 || (AH2 && DMA && !DEEP && BM == 128), "16-bit tier: cell input, LDS-DMA kernels");
+    static_assert(!H1 || (AH2 && DMA && !DEEP), "16-bit tier: cell input, LDS-DMA kernels");
+    static_assert(BM == 128 || (BM == 256 && H1 && CW == 4 && BN == 128 && MODE != 3), "256-row tile: the 16-bit tier's 64 x 128 wave tiles");
     static_assert(!AH2 || CS, "pre-split A operand: compute-side-split kernels only");
     static_assert(!OH2 || AH2, "H2 output: kernels with H2 input only (the stem writes fp32, the pool converts)");
     // compute waves: 2 x (CW / 2) over the tile; with the compute-side split 4 x 1 (each wave owns 32 rows and ALL columns, so no
     // two waves split the same A rows -- half the split arithmetic for 25 % more B fragment reads)
-    constexpr int WAVES_M = (CS && CW == 4) ? 4 : (CS && CW == 8 && BM == 256) ? 8 : 2;
+    constexpr int WAVES_M = (CS && CW == 4) ? 4 : 2;
     constexpr int WAVES_N = CW / WAVES_M;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -1148,8 +1157,8 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK
     constexpr int A_CELLS = DMA ? BM * CH : (CS ? CH * LDAF : NP * KG * LDA), B_CELLS = NP * KG * LDB;     // 16-byte cells per buffer
     constexpr int NSA = DEEP ? 5 : (DMA ? 3 : 2);  // A stages
     constexpr int NSB = DEEP ? 4 : 2;              // B stages
-    static_assert(!DMA || (CS && MODE != 0 && (BN == 128 || BN == 64) && ((BM == 128 && CW == 4) || (BM == 256 && CW == 8 && BN == 128))),
-                  "LDS-DMA loaders: CS kernels, plain or pointwise walk, 128 rows (4 compute waves) or 256 rows (8)");
+    static_assert(!DMA || (CS && MODE != 0 && (BN == 128 || BN == 64) && CW == 4),
+                  "LDS-DMA loaders: CS kernels, plain or pointwise walk, 4 compute waves of 32 (128-row tile) or 64 rows (256-row tile)");
     static_assert(!CS || (PB && NT == 2 && BK == 32), "compute-side split: fp16 path, pre-split weights, BK 32");
     constexpr int LDC = WN + 4;
     static_assert(NT == 2 || NT == 3 || NT == 6, "6 / 3 bf16 products, or NT = 2: fp16 high/low pair (3 products)");
@@ -1710,11 +1719,11 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK
 #if !defined(DGP_MFMA32)
     // 16x16x32 MFMAs in the pipelined loop of the 32 x 128 wave tile: the same FLOPs, LDS bytes and register reads as the 32x32x16
     // shape in twice as many, half as long matrix instructions -- +5.3 % end to end (block4 3x3: 0.499 -> 0.453 ms)
-    constexpr bool M16 = CS && TM == 1 && (TN == 4 || (TN == 2 && DMA)) && NT == 2 && BK == 32;      // (32 x 64 wave tiles: DMA images only)
+    constexpr bool M16 = CS && (TM == 1 || (TM == 2 && H1)) && (TN == 4 || (TN == 2 && DMA)) && NT == 2 && BK == 32;      // (32 x 64 wave tiles: DMA images only)
 #else
     constexpr bool M16 = false;
 #endif
-    static_assert(!DMA || (TM == 1 && (TN == 4 || TN == 2)), "DMA image is read by the pipelined loop only");
+    static_assert(!DMA || ((TM == 1 || (TM == 2 && H1)) && (TN == 4 || TN == 2)), "DMA image is read by the pipelined loops only");
     static_assert(!(DMA && AH2) || M16, "pre-split A + DMA image: 16x16x32 loop only");
     if constexpr (MODE == 3) {
         // The 16x16x32 loop of the branch below on the pixel ring: same fragment ring, same barrier placement; the A cells of the NEXT
@@ -1800,6 +1809,95 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? (BM == 256 ? 3 : 6) : ((BK
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sCw[(16 * i + 4 * g + r) * LDCW + 16 * j + l15] = c[i][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    } else if constexpr (M16 && TM == 2) {
+        // 64 x 128 wave tile of the 256-row tile (16-bit tier): four row blocks x eight column blocks of 16x16x32 MFMAs, 64 per K-step
+        // of 64 channels; a weight fragment feeds FOUR MFMAs, so a wave reads 16 + 8 cells per 64 MFMAs where the 32 x 128 tile reads
+        // 16 + 4 per 32.  ONE compute wave per SIMD: nothing hides an exposed LDS round trip (the first version -- the 32 x 128 loop's
+        // four-fragment ring, the barrier before the last two fragments -- ran 1 530 cycles per K-step for 1 024 cycles of MFMAs), so
+        // the fragment ring is EIGHT quads deep (fragment F + 8 is read behind the MFMAs of fragment F: seven fragments = 448 matrix
+        // cycles of cover) and the barrier sits before the last FOUR fragments, whose 16 MFMAs cover the next step's A cells.
+        typedef float floatx4 __attribute__((ext_vector_type(4)));
+        const int l15 = lane & 15, g = lane >> 4;
+        constexpr int NJ = 8, NF = 16;
+        floatx4 c[4][NJ];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) c[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        // DMA image: row-major, chunk ch of row r in slot ch ^ ((r >> 1) & 7) (the same for r + 16 i); this lane wants chunks 2 g, 2 g + 1
+        const unsigned a_row0 = (unsigned)((wave_m0 + l15) * 128 + (((2 * g) ^ (((wave_m0 + l15) >> 1) & 7)) << 4));
+        unsigned a_cur = a_row0;
+        int sa_c = 0;
+        const uint4* B = sB + wave_n0 + l15 + g * LDB;
+        int db = B_CELLS;
+        uint4 ra[4][2], ah[4], al[4], bq[8];
+        auto mma = [](const uint4& x, const uint4& y, floatx4 cc) {
+            return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), cc, 0, 0, 0);
+        };
+#define DGP_FENCE() __builtin_amdgcn_sched_barrier(0)
+#if defined(DGP_X) && (DGP_X == 8 || DGP_X == 9)      // timing-only: no A cell reads
+#define DGP_RA(I) do { asm volatile("" : "+v"(ra[I][0].x), "+v"(ra[I][0].y), "+v"(ra[I][0].z), "+v"(ra[I][0].w), "+v"(ra[I][1].x), "+v"(ra[I][1].y), "+v"(ra[I][1].z), "+v"(ra[I][1].w)); } while (0)
+#else
+#define DGP_RA(I) do { ra[I][0] = *reinterpret_cast<const uint4*>(smem + a_cur + (I) * 2048);                        \
+                       ra[I][1] = *reinterpret_cast<const uint4*>(smem + (a_cur ^ 16u) + (I) * 2048); } while (0)
+#endif
+#if defined(DGP_X) && (DGP_X == 6 || DGP_X == 8)      // timing-only: no B fragment reads
+#define DGP_RB(F) do { asm volatile("" : "+v"(bq[(F) & 7].x), "+v"(bq[(F) & 7].y), "+v"(bq[(F) & 7].z), "+v"(bq[(F) & 7].w)); } while (0)
+#else
+#define DGP_RB(F) do { bq[(F) & 7] = B[((((F) & 1) ? 0 : 1) * KG) * LDB + 16 * (((F) % NF) >> 1)]; } while (0)
+#endif
+        // (fragment F even = plane 1 = the odd k-groups' weights x the odd chunks `al`; F odd = plane 0 x the even chunks `ah`)
+#define DGP_MM(F) do { constexpr int j_ = (F) >> 1;                                                                 \
+        if (((F) & 1) == 0) { c[0][j_] = mma(al[0], bq[(F) & 7], c[0][j_]); c[1][j_] = mma(al[1], bq[(F) & 7], c[1][j_]);       \
+                              c[2][j_] = mma(al[2], bq[(F) & 7], c[2][j_]); c[3][j_] = mma(al[3], bq[(F) & 7], c[3][j_]); }     \
+        else { c[0][j_] = mma(ah[0], bq[(F) & 7], c[0][j_]); c[1][j_] = mma(ah[1], bq[(F) & 7], c[1][j_]);                      \
+               c[2][j_] = mma(ah[2], bq[(F) & 7], c[2][j_]); c[3][j_] = mma(ah[3], bq[(F) & 7], c[3][j_]); } } while (0)
+#define DGP_STEP(F) do { DGP_MM(F); DGP_FENCE(); DGP_RB((F) + 8); DGP_FENCE(); } while (0)
+#define DGP_TAIL(F) do { DGP_MM(F); DGP_FENCE(); if (more) DGP_RB((F) - 8); DGP_FENCE(); } while (0)
+        DGP_RA(0); DGP_RA(1); DGP_RA(2); DGP_RA(3);
+        DGP_RB(0); DGP_RB(1); DGP_RB(2); DGP_RB(3); DGP_RB(4); DGP_RB(5); DGP_RB(6); DGP_RB(7);
+        DGP_FENCE();
+        for (int ks = 0; ks < nks; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ah[i] = ra[i][0]; al[i] = ra[i][1]; }
+            DGP_FENCE();
+            DGP_STEP(0); DGP_STEP(1); DGP_STEP(2); DGP_STEP(3); DGP_STEP(4); DGP_STEP(5); DGP_STEP(6); DGP_STEP(7);
+            DGP_MM(8); DGP_FENCE();
+            DGP_MM(9); DGP_FENCE();
+            DGP_MM(10); DGP_FENCE();
+            DGP_MM(11); DGP_FENCE();
+            DIAG_STAMP(e2);
+            __syncthreads();
+            DIAG_STAMP(e3);
+#ifdef DGP_DIAG
+            acc_mf += e2 - e1; acc_ba += e3 - e2; e1 = e3;
+#endif
+            sa_c = sa_c == NSA - 1 ? 0 : sa_c + 1; a_cur = a_row0 + (unsigned)(sa_c * (A_CELLS * 16));
+            static_assert(NSB == 2, "256-row tile: two weight stages");
+            B += db; db = -db;
+            const bool more = ks + 1 < nks;
+            if (more) { DGP_RA(0); DGP_RA(1); DGP_RA(2); DGP_RA(3); DGP_RB(0); DGP_RB(1); DGP_RB(2); DGP_RB(3); }
+            DGP_FENCE();
+            DGP_TAIL(12); DGP_TAIL(13); DGP_TAIL(14); DGP_TAIL(15);
+        }
+#undef DGP_FENCE
+#undef DGP_RA
+#undef DGP_RB
+#undef DGP_MM
+#undef DGP_STEP
+#undef DGP_TAIL
+        {      // stage the wave's 64 x 128 tile (its own LDS slice: the ring is dead behind the last barrier)
+            constexpr int LDCW = WN + 4;
+            float* sCw = reinterpret_cast<float*>(smem) + wave * (64 * LDCW);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -2526,40 +2624,41 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// The 256 x 128 tile of the H2 engine (see conv_igemm_split_ls): deep-K layers only.
-static bool conv_tall_eligible(const ConvArgs& a) {
-#ifndef DGP_TUNING
-    (void)a;
-    return false;                                   // (the 256-row instances are compiled into tuning builds only)
-#else
-    static const int tall_env = dgp_tune("DGP_TALL", 0);              // opt-in (measured slower, see the kernel)
-    static const int min_nk = dgp_tune("DGP_TALL_MINK", 48);      // K-steps from which the epilogue is small change
-    if (!tall_env || a.in_fmt != 1 || a.out_fmt != 1 || !a.wh3 || a.in2 || a.up || a.stem || a.mask || a.out_mode != 0) return false;
-    if (a.CoutP % 128 != 0 || (a.Cout % 8) || (a.Cin % 32)) return false;
-    if (tall_env == 2) return true;                // (tests: every shape the kernel can take)
+// The 256 x 128 tile of the 16-bit tier (see conv_igemm_split_ls, "BM = 256"): H1 -> H1 convolutions, pointwise (incl. the K-concatenated
+// shortcut) or plain taps.  `a` holds REAL channels here (before to_h1_units): conv_kernel_name and launch_conv ask the same question.
+// DGP_H1_W64: 0 (default) never -- it measured SLOWER than the 128 x 128 tile on every layer of the bench workload (one stream: block4
+// +6..+11 % on the 3x3 layers, +6..+26 % on the pointwise ones, block3 +14..+28 %; two streams: +-1 %; EXPERIMENTS.md R6 (1) has the
+// stamps and the micro-benchmarks that say why); 1: deep-K layers with enough tiles; 2: wherever the kernel can run (the layer tests).
+static bool conv_w64_eligible(const ConvArgs& a) {
+    static const int w64_env = dgp_env("DGP_H1_W64", 0);
+    static const int min_k = dgp_tune("DGP_H1_W64_MINK", 1024);       // real K = taps x channels from which the longer K-steps pay
+    if (!w64_env || a.in_fmt != 2 || a.out_fmt != 2 || !a.wh3 || a.up || a.stem || a.out_mode != 0 || a.shadow) return false;
+    if (a.CoutP % 128 != 0 || (a.Cout % 8) || (a.Cin & 63) || (a.nk & 1)) return false;
+    const bool pointwise = a.ntaps == 1 && a.stride == 1 && a.pad_t == 0 && a.pad_l == 0 && a.H == a.Ho && a.W == a.Wo;
+    if (a.in2 && (!pointwise || (a.cin_split & 63) || ((a.Cin - a.cin_split) & 63))) return false;
+    if (pointwise && ((unsigned long long)a.M * (a.in2 ? a.cin_split : a.Cin) * 4ull != a.in_bytes ||
+                      (a.in2 && (unsigned long long)a.M * (a.Cin - a.cin_split) * 4ull != a.in2_bytes) || a.in_bytes >= 4200000000u)) return false;
+    if (w64_env >= 2) return true;
     const long long tiles = (long long)((a.M + 255) / 256) * (a.CoutP / 128);
-    return a.nk >= min_nk && tiles >= 512;         // long K loops, at least two rounds of one workgroup per CU
-#endif
+    return (long long)a.nk * 32 >= min_k && tiles >= 192;
 }
 
-static hipError_t launch_conv_tall(ConvArgs a, hipStream_t s) {
-#ifndef DGP_TUNING
-    (void)a; (void)s;
-    return hipErrorInvalidValue;
-#else
-    constexpr int BM = 256, BN = 128, NT = 2, BK = 32, CW = 8, NP = 2, KG = 4;
+static hipError_t launch_conv_w64(ConvArgs a, hipStream_t s) {       // (`a` already in H1 units)
+    constexpr int BM = 256, BN = 128, NT = 2, BK = 32, CW = 4, NP = 2, KG = 4;
     static const int tap_minor = dgp_tune("DGP_TAP_MINOR", 1);
     a.tap_minor = (tap_minor && a.ntaps > 1 && a.nk * 32 == a.ntaps * a.Cin) ? 1 : 0;
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = a.CoutP / BN;
     if (a.tap_rows == 0) a.tap_rows = a.Cin >> 2;
-    a.epi_nt = 0; a.tail_ksplit = 0; a.st_gn = 0;
+    static const int epi_nt_env = dgp_env("DGP_EPI_NT", 2);
+    a.epi_nt = epi_nt_env == 1 ? 3 : (a.ntiles >= 8 ? (epi_nt_env == 2 ? 3 : epi_nt_env == 3 ? 1 : epi_nt_env == 4 ? 2 : 0) : 0);
+    a.tail_ksplit = 0; a.st_gn = 0;
     const bool pointwise = a.ntaps == 1 && a.stride == 1 && a.pad_t == 0 && a.pad_l == 0 && a.H == a.Ho && a.W == a.Wo;
-    const int mode = (pointwise && (unsigned long long)a.M * a.Cin * 4ull == a.in_bytes && a.in_bytes < 4200000000u) ? 2 : 1;
-    auto kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, true, 2, true, true, true, true>
-                          : conv_igemm_split_ls<BM, BN, NT, BK, CW, true, 1, true, true, true, true>;
+    const int mode = pointwise ? 2 : 1;
+    auto kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, true, 2, true, true, true, true, false, true>
+                          : conv_igemm_split_ls<BM, BN, NT, BK, CW, true, 1, true, true, true, true, false, true>;
     size_t smem = (size_t)(3 * BM * 8 + 2 * NP * KG * BN) * 16;                // 3 A stages + 2 B stages = 128 KB
-    const size_t smem_epi = (size_t)CW * 32 * (BN + 4) * 4;                    // 135 KB: the eight wave tiles of the epilogue
+    const size_t smem_epi = (size_t)CW * 64 * (BN + 4) * 4;                    // 132 KB: the four 64-row wave tiles of the epilogue
     if (smem < smem_epi) smem = smem_epi;
     static bool attr_dev[16][3] = {};
     bool& attr = attr_dev[dgp_device_slot()][mode];
@@ -2569,9 +2668,26 @@ static hipError_t launch_conv_tall(ConvArgs a, hipStream_t s) {
         attr = true;
     }
     a.n_main = a.mtiles * a.ntiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(64 * (CW + 4)), smem, s, a);
-    return hipGetLastError();
+#ifdef DGP_DIAG
+    static unsigned long long* dbg_buf = nullptr;
+    if (!dbg_buf) (void)hipMalloc(&dbg_buf, 10 * 8 * 65536);
+    a.dbg = a.n_main <= 65536 ? dbg_buf : nullptr;
 #endif
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.n_main), dim3(64 * (CW + 4)), smem, s, a);
+#ifdef DGP_DIAG
+    if (a.dbg) {
+        (void)hipStreamSynchronize(s);
+        const long long nwg = a.n_main;
+        std::vector<unsigned long long> h(10 * nwg);
+        (void)hipMemcpy(h.data(), a.dbg, 80 * nwg, hipMemcpyDeviceToHost);
+        double v[10] = {0};
+        for (long long b = 0; b < nwg; ++b) for (int k = 0; k < 10; ++k) v[k] += (double)h[10 * b + k];
+        for (int k = 0; k < 10; ++k) v[k] /= (double)nwg;
+        printf("[diag w64 256x128 mode %d] tiles %lld K-steps %d | compute wave 0: first barrier %.0f cyc, staging %.0f, epilogue %.0f | per K-step: "
+               "ldsread+mfma %.0f barrier-wait %.0f\n", mode, nwg, a.nk, v[0], v[9], v[2], v[4] / a.nk, v[7] / a.nk);
+    }
+#endif
+    return hipGetLastError();
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool WIDE>
@@ -2678,7 +2794,7 @@ const char* conv_kernel_name(const ConvArgs& a, int tile_cfg) {
             case TILE_128x128_S6K16W8: return "split6_128x128_k16w8";
             case TILE_128x128_H3K16:   return "splith3_128x128_k16";
             case TILE_128x128_H3K16W8: return "splith3_128x128_k16w8";
-            case TILE_128x128_H3K32:   return a.in_fmt == 2 ? "h1_128x128_k64" : conv_tall_eligible(a) ? "splith3_256x128_k32" : "splith3_128x128_k32";
+            case TILE_128x128_H3K32:   return a.in_fmt == 2 ? (conv_w64_eligible(a) ? "h1_256x128_k64" : "h1_128x128_k64") : "splith3_128x128_k32";
             case TILE_128x64_H3:       return a.in_fmt == 2 ? "h1_128x64_k64" : "splith3_128x64_k32";
             case TILE_128x128_S6:    return "split6_128x128_k32";
             case TILE_128x64_S6:     return "split6_128x64_k32";
@@ -2731,7 +2847,7 @@ hipError_t launch_conv(const ConvArgs& a_in, int tile_cfg, hipStream_t s) {
         case TILE_128x128_H3K16:   return a.out_mode == 0 ? launch_conv_split<128, 128, 2, 16>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
         case TILE_128x128_H3K16W8: return a.out_mode == 0 ? launch_conv_split<128, 128, 2, 16, 8>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
         case TILE_128x128_H3K32:
-            if (conv_tall_eligible(a)) return launch_conv_tall(a, s);
+            if (conv_w64_eligible(a_in)) return launch_conv_w64(a, s);
             return a.out_mode == 0 ? launch_conv_split<128, 128, 2, 32>(a, s) : launch_conv_t<128, 128, 2, 4, true>(a, s);
         case TILE_128x64_H3:       return a.out_mode == 0 ? launch_conv_split<128, 64, 2, 32>(a, s) : launch_conv_t<128, 64, 2, 2, true>(a, s);
         case TILE_128x64_S6:  return a.out_mode == 0 ? launch_conv_split<128, 64, 6, 32>(a, s) : launch_conv_t<128, 64, 2, 2, true>(a, s);

@@ -114,11 +114,13 @@ def subsample(x: torch.Tensor, factor: int) -> torch.Tensor:
 # A1: backbone
 # ----------------------------------------------------------------------------
 def resnet_features(frames_u8: np.ndarray, wts: Dict[str, np.ndarray], depth: int = 50,
-                    return_endpoints: bool = False, dtype=np.float32):
+                    return_endpoints: bool = False, dtype=np.float32, output_stride: int = 16):
     """PoseNet.extract_features (PET/nnet/pose_net.py:36-54): (x - mean_pixel) ->
     slim resnet_v1_{depth}(global_pool=False, output_stride=16, is_training=False).
     dtype=np.float64: the ACCURACY ANCHOR -- the same fp32 parameters and the same graph evaluated in double precision (what every
-    fp32 evaluation order, TF's included, approximates); the reference itself runs fp32."""
+    fp32 evaluation order, TF's included, approximates); the reference itself runs fp32.
+    output_stride: 16 is what DLC / DGP build (pose_net.py:49); 32 is slim's nominal network -- only the TF-slim atrous-invariance
+    known answer uses it (tests/test_oracle_cpu.py, resnet_v1_test.testAtrousFullyConvolutionalValues)."""
     from oracle.resnet_plan import units as resnet_units   # the oracle's OWN restatement of slim's plan
     name = "resnet_v1_%d" % depth
     x = frames_u8.astype(np.float32) - np.asarray(MEAN_PIXEL, dtype=np.float32)[None, None, None, :]
@@ -130,7 +132,7 @@ def resnet_features(frames_u8: np.ndarray, wts: Dict[str, np.ndarray], depth: in
         ends["conv1"] = net
         net = max_pool_same(net, 3, 2)
         ends["pool1"] = net
-        for u in resnet_units(depth):
+        for u in resnet_units(depth, output_stride):
             if u.has_shortcut_conv:
                 sc = conv2d(net, wts[u.scope + "/shortcut/weights"], stride=u.stride, padding="SAME")
                 sc = batch_norm(sc, wts, u.scope + "/shortcut")
