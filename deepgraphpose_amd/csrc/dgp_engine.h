@@ -91,6 +91,10 @@ struct dgp_net {
     std::vector<dgp::Unit> units;
     std::vector<dgp::ChainPlan> chains;       // chains[ui]: conv3 of unit ui + conv1 of unit ui + 1 (ok = false: layer by layer)
     bool loaded = false;
+    // a trainer that owns this net (dgp_trainer_create) re-packs its panels every step and may defer the ones only the parity path reads;
+    // dgp_forward calls this first so that a forward on a trainer-owned net never reads a stale panel (dgp_train.hip, refresh_parity_panels)
+    int (*owner_sync)(void* owner, void* stream) = nullptr;
+    void* owner = nullptr;
     // precision tier (dgp_net_set_tier): 0 = parity tier (H2 cells, 22-bit operands as fp16 pairs, three MFMAs per product);
     // 1 = 16-bit tier (H1 cells: 2-byte activations end to end, fp16 operands, one MFMA per product, fp32 accumulation / epilogues /
     // heads / soft-argmax).  Scales, calibration and the range check are shared; switching tiers re-calibrates.

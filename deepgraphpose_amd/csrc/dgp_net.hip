@@ -825,6 +825,7 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     const Plan pl = make_plan(net, batch);
     if (workspace_bytes < pl.total) return fail(DGP_ERR_INVALID, "dgp_forward: workspace too small");
     if (locref && net->head_locref < 0) return fail(DGP_ERR_INVALID, "dgp_forward: net built without locref head");
+    if (net->owner_sync) { const int rco = net->owner_sync(net->owner, stream); if (rco) return rco; }
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     float* P0 = (float*)(ws + pl.off_p0);

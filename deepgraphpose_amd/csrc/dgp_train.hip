@@ -2418,6 +2418,8 @@ hipError_t wgrad_launch(const float* x, int N, int H, int W, int Cin, const floa
 
 }  // namespace
 
+static int trainer_owner_sync(void* owner, void* stream);
+
 extern "C" {
 
 int dgp_trainer_create(dgp_net* net, dgp_trainer** out) {
@@ -2425,6 +2427,7 @@ int dgp_trainer_create(dgp_net* net, dgp_trainer** out) {
     if (net->head_locref < 0) return fail(DGP_ERR_INVALID, "dgp_trainer_create: the net must be built with_locref (dgp_loss trains both heads)");
     dgp_trainer* tr = new dgp_trainer();
     tr->net = net;
+    net->owner = tr; net->owner_sync = trainer_owner_sync;
     tr->tl.resize(net->layers.size());
     auto add = [&](const std::string& name, long long size, bool stat) {
         long long& ctr = stat ? tr->n_stat : tr->n_train;
@@ -2487,7 +2490,10 @@ int dgp_trainer_create(dgp_net* net, dgp_trainer** out) {
     return DGP_OK;
 }
 
-void dgp_trainer_destroy(dgp_trainer* tr) { delete tr; }
+void dgp_trainer_destroy(dgp_trainer* tr) {
+    if (tr && tr->net && tr->net->owner == tr) { tr->net->owner = nullptr; tr->net->owner_sync = nullptr; }      // (the net outlives its trainer: train.py)
+    delete tr;
+}
 
 int dgp_trainer_num_tensors(const dgp_trainer* tr, int32_t* n_tensors, int64_t* n_trainable_floats, int64_t* n_stat_floats) {
     if (!tr) return fail(DGP_ERR_INVALID, "dgp_trainer_num_tensors: null");
@@ -2538,6 +2544,15 @@ static int refresh_parity_panels(dgp_trainer* tr, hipStream_t s) {
     TRY_HIP(hipGetLastError());
     tr->parity_stale = false;
     return DGP_OK;
+}
+
+// dgp_net::owner_sync: a forward on the trainer's net (Trainer.net.infer between steps) reads the heads' 2x2-conv panels and the H2 cells,
+// which a 16-bit trainer leaves stale between plain passes
+static int trainer_owner_sync(void* owner, void* stream) {
+    dgp_trainer* tr = static_cast<dgp_trainer*>(owner);
+    if (!tr || !tr->parity_stale) return DGP_OK;
+    g_ctx = &tr->ctx;
+    return refresh_parity_panels(tr, (hipStream_t)stream);
 }
 
 extern "C" {
@@ -3203,6 +3218,9 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         TRY_HIP(conv_launch(lt, tr->d_hmT, tr->hm_nk, t0.cinP, DPH, B, fh, fw, CT, 0, 0, fh, fw, l0.Cin, 1, 0, nullptr, nullptr, nullptr, 0, 0, 0,
                             featH, false, 0, 0, GH[cur], s));
     } else {
+        // the per-head data-gradient panels (t.d_wT) are parity-only panels: a 16-bit pass that cannot merge its heads (DGP_TRAIN_HEADS_H1=0,
+        // head widths the merged panel does not take) lands here after lazy syncs and must not read last step's weights
+        if (tr->parity_stale && (rc = refresh_parity_panels(tr, s))) return rc;
         const size_t heads[2] = {(size_t)net->head_part, (size_t)net->head_locref};
         const float* dsrc[2] = {dscmap, dlocref};
         float* dph[2] = {F(pl.dph0), F(pl.dph1)};

@@ -17,6 +17,16 @@ PINNING STATUS
     reference holds no golden vectors for it  ->  **parity unpinned** for
     A1-A3; they restate TF-1.15's published semantics and are checked by
     known-answer tests plus an independent naive restatement (oracle/dgp_naive.c).
+    What CAN be pinned to TensorFlow is (round 6, tests/test_oracle_cpu.py "TF / TF-slim's
+    OWN published known answers"): the expected matrices TF's own unit tests assert for
+    slim.conv2d / resnet_utils.conv2d_same / subsample (resnet_v1_test.py
+    testConv2DSameEven / Odd, testSubsample*), conv2d_transpose SAME stride 2
+    (conv2d_transpose_test.py testConv2DTransposeSame), the stack_blocks_dense endpoint
+    shapes, and slim's atrous invariant (output_stride 16 subsampled == nominal stride 32)
+    -- on this oracle and, across implementations, through dgp_forward
+    (tests/test_parity_gpu.py).  Padding, alignment and stride bookkeeping are therefore
+    held to numbers TF itself is held to; the fp32 accumulation order of TF's kernels is not
+    (no TF-produced tensor exists in this image).
   * The pure-numpy pieces (A6 argmax_pose_predict, B10 index helpers, locref
     targets) ARE pinned against outputs of the reference itself: see
     tests/golden/make_golden.py and tests/golden/*.npz.

@@ -235,3 +235,138 @@ def test_temporal_flow_weight_autograd_matches_finite_differences():
         Pp[t, j, k] += eps; Pm[t, j, k] -= eps
         fd = (T.temporal_flow_weights(Pp, vf, wb, 6, 8).sum() - T.temporal_flow_weights(Pm, vf, wb, 6, 8).sum()) / (2 * eps)
         assert abs(fd - g[t, j, k]) < 1e-6 * max(1.0, abs(fd)), (t, j, k, fd, g[t, j, k])
+
+
+# ------------------------------------------------------------------ TF / TF-slim's OWN published known answers
+# The conv / pool / deconv arithmetic of the reference lives in TensorFlow 1.x + tf.contrib.slim (not vendored, not importable here).
+# What IS public are the known answers TensorFlow's own unit tests assert; the tests below restate their inputs and expected outputs
+# (source file and test name in each docstring) and check the oracle against them.  They pin the padding / alignment / stride
+# bookkeeping of the restatement to numbers TF itself is held to -- the part of "TF semantics" that is not plain multiply-add.
+def _slim_create_test_input(batch, height, width, channels):
+    """tensorflow/contrib/slim/python/slim/nets/resnet_v1_test.py `create_test_input`: x[b, i, j, c] = i + j"""
+    g = (np.arange(height).reshape(height, 1) + np.arange(width).reshape(1, width)).astype(np.float32)
+    return np.tile(g.reshape(1, height, width, 1), [batch, 1, 1, channels])
+
+
+def _nchw(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).permute(0, 3, 1, 2).contiguous()
+
+
+def _hw(t):
+    return t[0, 0].numpy()
+
+
+def test_slim_subsample_known_answers():
+    """resnet_v1_test.py ResnetUtilsTest.testSubsampleThreeByThree / testSubsampleFourByFour: range(9) as 3x3 -> [0, 2, 6, 8];
+    range(16) as 4x4 -> [0, 2, 8, 10] (resnet_utils.subsample = 1x1 max-pool of stride 2: keeps the EVEN rows / columns)."""
+    x = torch.arange(9, dtype=torch.float32).reshape(1, 1, 3, 3)
+    assert O.subsample(x, 2).reshape(-1).tolist() == [0, 2, 6, 8]
+    x = torch.arange(16, dtype=torch.float32).reshape(1, 1, 4, 4)
+    assert O.subsample(x, 2).reshape(-1).tolist() == [0, 2, 8, 10]
+    assert O.subsample(x, 1) is x
+
+
+def test_slim_conv2d_same_even_known_answers():
+    """resnet_v1_test.py ResnetUtilsTest.testConv2DSameEven: x = create_test_input(1, 4, 4, 1), 3x3 kernel w[a, b] = a + b, bias 0.
+    y1 = slim.conv2d(stride 1, SAME); y2 = subsample(y1, 2); y3 = resnet_utils.conv2d_same(stride 2) == y2 (that is the POINT of
+    conv2d_same: explicit symmetric padding, so the strided conv sits on the even pixels of the dense one); y4 = slim.conv2d(stride 2,
+    SAME) -- TF's own SAME padding puts the extra pixel AFTER, so it sits on the ODD pixels and differs."""
+    x = _nchw(_slim_create_test_input(1, 4, 4, 1))
+    w = _slim_create_test_input(1, 3, 3, 1).reshape(3, 3, 1, 1)
+    y1 = O.conv2d(x, w, 1, 1, "SAME")
+    np.testing.assert_array_equal(_hw(y1), [[14, 28, 43, 26], [28, 48, 66, 37], [43, 66, 84, 46], [26, 37, 46, 22]])
+    np.testing.assert_array_equal(_hw(O.subsample(y1, 2)), [[14, 43], [43, 84]])
+    np.testing.assert_array_equal(_hw(O.conv2d_same(x, w, 2)), [[14, 43], [43, 84]])
+    np.testing.assert_array_equal(_hw(O.conv2d(x, w, 2, 1, "SAME")), [[48, 37], [37, 22]])
+
+
+def test_slim_conv2d_same_odd_known_answers():
+    """resnet_v1_test.py ResnetUtilsTest.testConv2DSameOdd: the same on a 5x5 input -- here TF's SAME and conv2d_same agree (y4 == y2)."""
+    x = _nchw(_slim_create_test_input(1, 5, 5, 1))
+    w = _slim_create_test_input(1, 3, 3, 1).reshape(3, 3, 1, 1)
+    y1 = O.conv2d(x, w, 1, 1, "SAME")
+    np.testing.assert_array_equal(_hw(y1), [[14, 28, 43, 58, 34], [28, 48, 66, 84, 46], [43, 66, 84, 102, 55],
+                                            [58, 84, 102, 120, 64], [34, 46, 55, 64, 30]])
+    y2 = [[14, 43, 34], [43, 84, 55], [34, 55, 30]]
+    np.testing.assert_array_equal(_hw(O.subsample(y1, 2)), y2)
+    np.testing.assert_array_equal(_hw(O.conv2d_same(x, w, 2)), y2)
+    np.testing.assert_array_equal(_hw(O.conv2d(x, w, 2, 1, "SAME")), y2)
+
+
+def test_tf_conv2d_transpose_same_known_answer():
+    """tensorflow/python/kernel_tests/conv2d_transpose_test.py Conv2DTransposeTest.testConv2DTransposeSame: x = ones [1, 6, 4, 3],
+    filter = ones [3, 3, 2, 3] (HW, out, in), strides 2, output [1, 12, 8, 2], padding SAME.  Expected: 3.0 everywhere, + 3.0 where ONE
+    of (h, w) is even and interior (0 < h < 11, 0 < w < 7), + 9.0 where both are -- i.e. input pixel i stamps the kernel at output rows
+    2 i .. 2 i + 2, cropped to 2 H: the alignment the part_pred / locref_pred heads rely on (pose_net.py:18-26)."""
+    x = np.ones((1, 6, 4, 3), np.float32)
+    f = np.ones((3, 3, 2, 3), np.float32)
+    y = O.conv2d_transpose_same(x, f, None, stride=2)
+    assert y.shape == (1, 12, 8, 2)
+    want = np.full((12, 8), 3.0, np.float32)
+    for h in range(12):
+        for w_ in range(8):
+            h_in = h % 2 == 0 and 0 < h < 11
+            w_in = w_ % 2 == 0 and 0 < w_ < 7
+            if h_in and w_in:
+                want[h, w_] += 9.0
+            elif h_in or w_in:
+                want[h, w_] += 3.0
+    for k in range(2):
+        np.testing.assert_array_equal(y[0, :, :, k], want)
+
+
+def test_slim_stack_blocks_dense_stride_bookkeeping():
+    """resnet_v1_test.py ResnetCompleteNetworkTest.testFullyConvolutionalEndpointShapes / testAtrousFullyConvolutionalEndpointShapes /
+    testClassificationShapes: on a 321x321 input the block endpoints of a resnet_v1 with block strides (2, 2, 2, 1) are 41 / 21 / 11 / 11
+    pixels wide at the nominal stride and 41 / 41 / 41 / 41 at output_stride = 8; on 224x224: 28 / 14 / 7 / 7.  ResNet-50 has those block
+    strides, so its plan (oracle/resnet_plan.py, the stack_blocks_dense walk) must give those widths, and 41 / 21 / 21 / 21 at the
+    output_stride = 16 that DLC builds (pose_net.py:49)."""
+    from oracle import resnet_plan
+
+    def widths(n, output_stride):
+        n = -(-n // 2)                                                    # conv1: conv2d_same 7x7 / 2 -> ceil(n / 2)
+        n = O.tf_same_pads(n, 3, 2)[0]                                    # pool1: 3x3 / 2 SAME
+        out = {}
+        for u in resnet_plan.units(50, output_stride):
+            n = -(-n // u.stride)                                         # conv2 (conv2d_same) and the shortcut (subsample / 1x1 conv) agree
+            out[u.scope.split("/")[1]] = n
+        return [out["block%d" % b] for b in (1, 2, 3, 4)]
+
+    assert widths(321, 32) == [41, 21, 11, 11]
+    assert widths(321, 8) == [41, 41, 41, 41]
+    assert widths(224, 32) == [28, 14, 7, 7]
+    assert widths(321, 16) == [41, 21, 21, 21]
+    rates = {os_: [u.rate for u in resnet_plan.units(50, os_)] for os_ in (8, 16, 32)}
+    assert rates[32] == [1] * 16
+    assert rates[16] == [1] * 13 + [2] * 3
+    assert rates[8] == [1] * 7 + [2] * 6 + [4] * 3
+    with pytest.raises(ValueError):
+        resnet_plan.units(50, 6)                                          # "The output_stride needs to be a multiple of 4."
+
+
+def _small_weights(depth, nj, seed):
+    from deepgraphpose_amd.synthetic import make_weights
+    return make_weights(depth, nj, False, seed=seed, head_std=0.05)
+
+
+def test_slim_atrous_invariant_on_the_oracle():
+    """resnet_v1_test.py ResnetCompleteNetworkTest.testAtrousFullyConvolutionalValues (and ResnetUtilsTest.testAtrousValuesBottleneck):
+    "dense feature extraction followed by subsampling gives identical results to feature extraction at the nominal network output
+    stride" -- output_stride = 16 features subsampled by 2 == output_stride = 32 features, odd AND even input sizes; TF asserts
+    atol = rtol = 1e-4 on fp32.  In float64 the oracle's two walks agree to rounding; in fp32 within TF's own tolerance (relative to
+    the feature range, which is O(1) here as in TF's test)."""
+    wts = _small_weights(50, 4, 11)
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, size=(1, 65, 97, 3), dtype=np.uint8)          # odd height, odd width
+    for shape in ((1, 65, 97, 3), (1, 64, 96, 3)):
+        fr = frames[:, :shape[1], :shape[2]]
+        d16 = O.resnet_features(fr, wts, 50, dtype=np.float64, output_stride=16)
+        d32 = O.resnet_features(fr, wts, 50, dtype=np.float64, output_stride=32)
+        assert d16.shape[1:3] == (-(-shape[1] // 16), -(-shape[2] // 16)) and d32.shape[1:3] == (-(-shape[1] // 32), -(-shape[2] // 32))
+        sub = d16[:, ::2, ::2]
+        assert sub.shape == d32.shape
+        scale = np.abs(d32).max()
+        assert np.abs(sub - d32).max() <= 1e-12 * scale
+        f16_ = O.resnet_features(fr, wts, 50, output_stride=16)
+        f32_ = O.resnet_features(fr, wts, 50, output_stride=32)
+        assert np.abs(f16_[:, ::2, ::2] - f32_).max() <= 1e-4 * scale + 1e-4

@@ -266,6 +266,27 @@ def test_network_small_matches_oracle(eng, hw, depth, nj, B):
     assert _rel_err(locref.cpu().numpy(), l_ref) < 1e-4
 
 
+@pytest.mark.parametrize("hw,depth", [((65, 97), 50), ((128, 160), 50), ((64, 96), 101)])
+def test_slim_atrous_invariant_through_dgp_forward(eng, hw, depth):
+    """TF-slim's own known answer for the atrous network (resnet_v1_test.py testAtrousFullyConvolutionalValues / testAtrousValuesBottleneck,
+    restated on the oracle in tests/test_oracle_cpu.py): the output_stride = 16 network that DLC / DGP build (pose_net.py:46-52), subsampled
+    by 2, IS slim's nominal stride-32 network.  dgp_forward only knows the stride-16 graph, so the invariant is checked ACROSS the two
+    implementations: the engine's block4 features at the even pixels against the oracle's DENSE-FREE walk (output_stride = 32: no atrous
+    conv, a strided 3x3 in block3's last unit) -- odd and even frame sizes, both backbones.  TF asserts atol = rtol = 1e-4 in fp32."""
+    from oracle import dgp_oracle as O
+    from deepgraphpose_amd.synthetic import make_weights, make_frames
+    nj, B = 4, 2
+    wts = make_weights(depth, nj, False, seed=21, head_std=0.05)
+    frames = make_frames(B, hw[0], hw[1], nj, seed=22)
+    net = eng.DGPNet(depth, nj, hw[0], hw[1], max_batch=B)
+    net.load_weights(wts)
+    _, feats = net.forward(torch.from_numpy(frames).cuda(), want_features=True)
+    nominal = O.resnet_features(frames, wts, depth, output_stride=32)
+    sub = feats.cpu().numpy()[:, ::2, ::2]
+    assert sub.shape == nominal.shape
+    assert _rel_err(sub, nominal) < 1e-4
+
+
 def test_infer_640x480_r50_matches_oracle(eng):
     """BASELINE config 2 shapes (ResNet-50, 640x480, 4 joints), batch 2 so the oracle takes seconds."""
     from oracle import dgp_oracle as O

@@ -854,3 +854,55 @@ def test_fifty_steps_of_both_trainer_tiers_stay_in_one_band(lib_built):
     assert np.isfinite(a).all() and np.isfinite(b).all()
     assert a[49] < 0.8 * a[0] and b[49] < 0.8 * b[0]
     assert (np.abs(a - b) <= 0.03 * np.abs(a) + 2e-3).all()
+
+
+_STALE_PANEL_CHILD = r"""
+import sys, ctypes, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import test_train_gpu as TT
+from deepgraphpose_amd import engine
+from deepgraphpose_amd.train import Trainer
+from deepgraphpose_amd.loss import DGPHyper
+batch, S0, wts, frames, ws, ws_max = TT._train_case(13, hw=(64, 96), nt=3, nj=3)
+hy = DGPHyper(gm2=1, gm3=3, lr=0.02)
+tr = Trainer(50, 3, 64, 96, max_frames=3, tier="f16")
+tr.load_weights(wts)
+ft = torch.from_numpy(frames).cuda()
+for _ in range(3):                                  # optimiser steps: the weights move, every sync after the first is a lazy one
+    tr.step(ft, batch, hy, S0, ws, ws_max, 300.0, 25.0)
+assert tr.fast_passes == 2 and tr.fast_redos == 0
+w_now = tr.get_weights()
+assert max(float(np.abs(w_now[k] - wts[k]).max()) for k in wts if "pose/" in k and "weights" in k) > 1e-4      # the heads DID move
+was, failed = ctypes.c_int32(), ctypes.c_int32()
+l = tr.forward_backward(ft, batch, hy, S0, ws, ws_max, 300.0, 25.0)           # a 16-bit pass on the CURRENT weights
+tr.lib.dgp_trainer_fast_status(tr._t, was, failed)
+assert was.value == 1 and failed.value == 0
+P, L = TT._oracle_grads(w_now, frames, batch, S0, ws, ws_max, hy, 300.0, 25.0, dtype=torch.float64)
+cos, rel, per = TT._grad_agreement(tr.get_grads(), P)
+worst = sorted(per.items(), key=lambda kv: kv[1][0])[:3]
+print("heads merged=%s: cosine %.6f rel %.4f worst %s" % (sys.argv[2], cos, rel, worst))
+assert abs(l["total_loss"] - float(L["total_loss"].detach())) < 2e-3 * max(1, abs(float(L["total_loss"].detach())))
+assert cos >= 0.999 and rel <= 0.05 and min(v[0] for v in per.values()) >= 0.98, (cos, rel, worst)
+# a forward on the trainer-owned net between steps reads the heads' 2x2-conv panels: they must be the CURRENT weights'
+mu_t, conf_t, idx_t = tr.net.infer(ft, 1.0, 1)
+fresh = engine.DGPNet(50, 3, 64, 96, max_batch=3, with_locref=True)
+fresh.load_weights(w_now)
+mu_f, conf_f, idx_f = fresh.infer(ft, 1.0, 1)
+d = float((mu_t - mu_f).abs().max()) * 8.0
+print("trainer-owned net vs a fresh net with the same weights: %.3g px" % d)
+assert d < 1e-3, d
+"""
+
+
+@pytest.mark.parametrize("heads_h1", ["0", "1"])
+def test_trainer_tier_f16_never_reads_stale_head_panels(lib_built, heads_h1):
+    """Round-5 advisor finding: in the 16-bit tier every weight sync after the first skips the parity-only panels (the heads' 2x2-conv and
+    per-head data-gradient panels, the H2 cells).  With the merged-heads H1 panel switched off (DGP_TRAIN_HEADS_H1=0, read once per
+    process -> child process) a 16-bit backward takes the per-head branch and read the data-gradient panels of the LAST PLAIN pass; and
+    a forward on the trainer-owned net read the stale 2x2-conv panels.  Now both refresh first: gradients after three optimiser steps
+    against the fp64 oracle ON THE CURRENT WEIGHTS, and Trainer.net.infer against a fresh net with those weights."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _STALE_PANEL_CHILD, root, heads_h1], env=dict(os.environ, DGP_TRAIN_HEADS_H1=heads_h1, PYTHONPATH=root),
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
