@@ -52,6 +52,31 @@ H, W, NJ, BATCH = 480, 640, 4, 32
 STRIDE = 8.0
 
 
+def mfma_only_sustained():
+    """(TFLOP/s, source): what a loop of NOTHING BUT v_mfma_f32_16x16x32_f16 sustains on this part under its power cap -- read from the
+    committed measurement (profiles/r*_mfma_power.txt, newest round first; one box, tagged as such in the line), 1788 when no file is there"""
+    import glob, re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_power.txt")), reverse=True):
+        try:
+            vals = [float(m.group(1)) for m in re.finditer(r"v_mfma_f32_16x16x32_f16: (\d+(?:\.\d+)?) TFLOP/s sustained", open(path).read())]
+        except OSError:
+            vals = []
+        if vals:
+            return max(vals), "profiles/%s (one MI355X box of the pool, 1400 W board cap)" % os.path.basename(path)
+    return 1788.0, "round-5 measurement (profiles file missing)"
+
+
+def newest_traffic_files(suffix=""):
+    """profiles/traffic_r<N><suffix>.json, newest round first"""
+    import glob, re
+    c = []
+    for q in glob.glob(os.path.join(ROOT, "profiles", "traffic_r*%s.json" % suffix)):
+        m = re.fullmatch(r"traffic_r(\d+)%s\.json" % re.escape(suffix), os.path.basename(q))
+        if m:
+            c.append((int(m.group(1)), q))
+    return [q for _, q in sorted(c, reverse=True)]
+
+
 def roofline_from_launches(launches, B, elem_bytes, traffic_files):
     """The `roofline` object of a bench line from the per-launch table of the instrumented steps (dgp_net_profile_launch): the dominant conv
     kernel against its matrix-pipe ceiling, every conv kernel against both roofs.  elem_bytes: 4 for the parity tier's H2 cells, 2 for the
@@ -87,7 +112,9 @@ def roofline_from_launches(launches, B, elem_bytes, traffic_files):
         "frac": round(achieved / peak, 4), "traffic": None,
         "peak_basis": ("dense %s MFMA peak %.0f TFLOP/s / %s partial products per fp32-class product; achieved counts "
                        "ALGORITHMIC conv FLOPs" % (mfma_kind, PEAK_BF16_MFMA_TFLOPS, n_mfma)) if dom.startswith("split")
-                      else "dense fp32 MFMA peak",
+                      else ("dense f16 MFMA peak %.0f TFLOP/s, ONE v_mfma_f32_16x16x32_f16 per product; achieved counts ALGORITHMIC conv FLOPs"
+                            % PEAK_BF16_MFMA_TFLOPS) if dom.startswith("h1_")
+                      else "dense fp32 MFMA peak %.1f TFLOP/s" % PEAK_F32_MFMA_TFLOPS,
         "kernel_ms_per_step": round(d_ms, 3),
         # every conv kernel against BOTH roofs: matrix pipe (algorithmic FLOPs) and HBM (algorithmic bytes of its launches: tensors
         # that enter or leave a launch once + weights; the chain / unit kernels keep X' / R2 on chip, so their bytes are fewer)
@@ -103,6 +130,9 @@ def roofline_from_launches(launches, B, elem_bytes, traffic_files):
         "conv_stack_vs_fp32_mfma_peak": round(stack_tf / PEAK_F32_MFMA_TFLOPS, 4),
         "algorithmic_gflop_per_frame": round(flop_frame / 1e9, 3),
         "conv_ms_per_step": round(conv_ms, 3), "other_kernels_ms_per_step": round(other_ms, 3),
+        "conv_ms_note": ("sum of the hipEvent-timed conv launches of the INSTRUMENTED steps, which run alone on ONE stream; the timed steps of "
+                         "`ms_per_step` are dealt to two engines on two streams (tails of one batch's launches fill with the other's), so "
+                         "ms_per_step can be smaller than this sum"),
     }
     # HBM traffic of the dominant kernel, per launch, from the committed rocprofv3 PMC passes of this same command
     # (scripts/profile.sh -> profiles/traffic_r1.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate
@@ -164,18 +194,47 @@ def _read_sclk_mhz(card_index: int = 0):
     return None
 
 
+def visible_gpu_count() -> int:
+    """GPUs this process may use, WITHOUT touching HIP: KFD topology nodes with SIMDs (CPU nodes report simd_count 0), cut down by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when one of them is set.  -1 entries end a list, as in the runtime."""
+    import glob
+    n = 0
+    for q in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(l.split(None, 1) for l in open(q).read().splitlines() if " " in l)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        except (OSError, ValueError):
+            continue
+    if n == 0:                                   # (no KFD topology in this container's sysfs: the render nodes, one per GPU)
+        n = len(glob.glob("/dev/dri/renderD*"))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = []
+            for t in v.split(","):
+                t = t.strip()
+                if t in ("", "-1"):
+                    break
+                ids.append(t)
+            n = min(n, len(ids)) if n else len(ids)
+    return n
+
+
 def spawn_workers(args) -> None:
     """`python bench.py --gpus N` without a launcher: start N worker processes (one per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
     their environment, exactly what torch.distributed.run would set), relay rank 0's JSON line and exit with the workers' worst return
-    code.  This parent never initialises the GPU (no HIP call, no torch.cuda query) and never exec()s."""
+    code.  This parent never initialises the GPU -- the visible devices are counted from the KFD topology in sysfs, not through HIP or
+    torch.cuda -- and never exec()s."""
     import socket
     import subprocess
     n = max(1, args.gpus)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    if torch.cuda.device_count() < n and not os.environ.get("DGP_BENCH_VISIBLE_GPUS"):      # (device_count() does not initialise the GPU on this image)
-        raise SystemExit("bench.py: --gpus %d but only %d device(s) visible (set DGP_BENCH_VISIBLE_GPUS to share devices knowingly)" % (n, torch.cuda.device_count()))
+    have = visible_gpu_count()
+    if 0 < have < n and not os.environ.get("DGP_BENCH_VISIBLE_GPUS"):      # (have == 0: nothing to count here -- the workers' own device binding decides)
+        raise SystemExit("bench.py: --gpus %d but only %d device(s) visible (set DGP_BENCH_VISIBLE_GPUS to share devices knowingly)" % (n, have))
     visible = int(os.environ.get("DGP_BENCH_VISIBLE_GPUS", n))      # tests: several ranks on one GPU (with DGP_DIST_BACKEND=gloo)
     procs = []
     for r in range(n):
@@ -341,11 +400,16 @@ def tier_f16_child(args) -> None:
     torch.cuda.synchronize(dev)
     ov, _ = pipe.range_status()
     assert not ov, "activation ranges outgrew the calibrated scales during the 16-bit tier's run"
-    roofline, by_kernel = roofline_from_launches(launches, B, 2.0, [os.path.join(ROOT, "profiles", "traffic_r5_f16.json")])
+    roofline, by_kernel = roofline_from_launches(launches, B, 2.0, newest_traffic_files("_f16"))
     roofline["steps_profiled"] = n_prof
-    roofline["mfma_only_sustained_peak"] = 1788.0      # (a pure fp16 MFMA loop under the board's power cap: profiles/r5_mfma_power.txt)
-    roofline["frac_of_mfma_only_sustained"] = round(roofline["achieved"] / 1788.0, 4)
+    sus, sus_src = mfma_only_sustained()               # (a pure fp16 MFMA loop under the board's power cap)
+    roofline["mfma_only_sustained_peak"] = sus
+    roofline["mfma_only_source"] = sus_src
+    roofline["frac_of_mfma_only_sustained"] = round(roofline["achieved"] / sus, 4)
     fps2, fps1 = K * B / (t2 - t1), K * B / (t1 - t0)
+    # the WHOLE step against the roof (stem, heads, soft-argmax, epilogues and launch gaps included), not only the dominant kernel
+    roofline["frac_whole_step"] = round(fps2 * roofline["algorithmic_gflop_per_frame"] / 1e3 / roofline["peak"], 4)
+    roofline["frac_whole_step_one_stream"] = round(fps1 * roofline["algorithmic_gflop_per_frame"] / 1e3 / roofline["peak"], 4)
     res = {"frames_per_s": round(fps2, 1), "ms_per_step": round((t2 - t1) / K * 1e3, 3), "steps": K, "streams": NS,
            "one_stream": {"frames_per_s": round(fps1, 1), "ms_per_step": round((t1 - t0) / K * 1e3, 3)},
            "dtype": "f16", "sclk_mhz_under_load": sclk,
@@ -591,8 +655,10 @@ def main():
         return
 
     fps = world * n_local / elapsed
-    roofline, by_kernel = roofline_from_launches(launches, B, 4.0, [os.path.join(ROOT, "profiles", "traffic_r%d.json" % r) for r in (5, 4, 3, 2, 1)])
+    roofline, by_kernel = roofline_from_launches(launches, B, 4.0, newest_traffic_files(""))
     roofline["steps_profiled"] = n_prof
+    # the WHOLE step against the roof (stem, heads, soft-argmax, epilogues and launch gaps included), not only the dominant kernel
+    roofline["frac_whole_step"] = round(fps / world * roofline["algorithmic_gflop_per_frame"] / 1e3 / roofline["peak"], 4)
     if args.layer_table:
         os.makedirs(os.path.dirname(os.path.abspath(args.layer_table)), exist_ok=True)
         with open(args.layer_table, "w") as f:
@@ -602,8 +668,10 @@ def main():
 
     # informative only: what a loop of NOTHING BUT MFMAs sustains on this part under its 1400 W power cap (scripts/micro/mfma_power.hip,
     # profiles/r5_mfma_power.txt: 1.79 PFLOP/s of dense fp16 = 0.71 of the rating, at the cap) -- the ceiling of a kernel that moves no data at all
-    roofline["mfma_only_sustained_peak"] = round(1788.0 / 3.0, 1)
-    roofline["frac_of_mfma_only_sustained"] = round(roofline["achieved"] / (1788.0 / 3.0), 4)
+    sus, sus_src = mfma_only_sustained()
+    roofline["mfma_only_sustained_peak"] = round(sus / 3.0, 1)
+    roofline["mfma_only_source"] = sus_src
+    roofline["frac_of_mfma_only_sustained"] = round(roofline["achieved"] / (sus / 3.0), 4)
     roofline["mfma_only_note"] = ("a pure v_mfma_f32_16x16x32_f16 loop sustains 1788 TFLOP/s at 1350 W of the 1400 W board cap (profiles/r5_mfma_power.txt); the bench "
                                   "workload itself runs at 1347 W with the clock throttled to ~1.96 GHz (profiles/r5_power_probe.txt): `frac` stays against the rated peak")
     if sustained and sustained.get("sclk_mhz_under_load"):
@@ -754,8 +822,10 @@ def main():
             if cp.returncode != 0 or not ln:
                 return {"error": (cp.stderr or cp.stdout)[-300:]}
             t = json.loads(ln[-1])
+            sus_ = mfma_only_sustained()[0] / (1.0 if tier == "f16" else 3.0)
             return {"ms_per_step": t["ms_per_step"], "steps": args.train_steps, "frames_per_step": t["nt"], "frames_per_s": t["frames_per_s"],
                     "frac": t["roofline"]["frac"], "achieved_tflops": t["roofline"]["achieved"], "peak_tflops": t["roofline"]["peak"],
+                    "frac_of_mfma_only_sustained": round(t["roofline"]["achieved"] / sus_, 4),
                     "algorithmic_gflop_per_step": t["roofline"]["algorithmic_gflop_per_step"], "loss": t["loss"], "dtype": t["dtype"],
                     "fast_passes": t.get("fast_passes"), "fast_redos": t.get("fast_redos")}
         try:
@@ -771,8 +841,9 @@ def main():
             if "error" not in out["train_step_f16"]:
                 out["train_step_f16"].update(
                     workload="the same step on the 16-bit tier (Trainer(tier='f16'), dgp_trainer_set_tier): 2-byte H1 activations and gradient tensors with "
-                             "predicted scales in every bottleneck unit, weight gradients by LDS-DMA on the tensors themselves; root block and heads on the "
-                             "parity kernels; the first step of a shape runs on the parity path",
+                             "predicted scales in every bottleneck unit, weight gradients by LDS-DMA on the tensors themselves; root block = the inference engine's "
+                             "fused kernel with the stem's weight gradient fused into the pool's backward, both heads' backward merged on ONE H1 panel; the "
+                             "first step of a shape runs on the parity path; `fast_passes` counts what the DEVICE reported as 16-bit passes",
                     frac_basis="3 x forward conv FLOPs / step time / 2500 TFLOP/s (one MFMA per product)")
         except Exception as e:      # noqa: BLE001 -- the main line must still be printed
             out.setdefault("train_step", {"error": repr(e)[:300]})
@@ -788,8 +859,13 @@ def main():
                                 text=True, timeout=300)
             ln = [q for q in cp.stdout.splitlines() if q.startswith("{")]
             out["host_pipeline"] = json.loads(ln[-1]) if cp.returncode == 0 and ln else {"error": (cp.stderr or cp.stdout)[-300:]}
+            # the same call on the 16-bit tier (estimate_pose(..., tier="f16")): whether the host side can feed an engine twice as fast
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_pipeline.py"), str(args.host_frames), "--json", "--tier", "f16"], env=env,
+                                capture_output=True, text=True, timeout=300)
+            ln = [q for q in cp.stdout.splitlines() if q.startswith("{")]
+            out["host_pipeline_f16"] = json.loads(ln[-1]) if cp.returncode == 0 and ln else {"error": (cp.stderr or cp.stdout)[-300:]}
         except Exception as e:      # noqa: BLE001 -- the main line must still be printed
-            out["host_pipeline"] = {"error": repr(e)[:300]}
+            out.setdefault("host_pipeline", {"error": repr(e)[:300]})
     if out["asserts_bypassed"]:
         out["value_unchecked"], out["value"] = out["value"], None
     print(json.dumps(out), flush=True)

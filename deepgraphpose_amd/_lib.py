@@ -94,6 +94,7 @@ SYMBOLS = {
     "dgp_unit_h1": (C.c_int, [_i32] * 7 + [_vp, _i32, _vp, _i32] + [_vp] * 3 + [_i32] + [_vp] * 6 + [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "dgp_net_range_status": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), _vp]),
     "dgp_net_recalibrate": (C.c_int, [_vp]),
+    "dgp_net_reset_scales": (C.c_int, [_vp]),
     "dgp_net_widen": (C.c_int, [_vp]),
     "dgp_conv2d_wgrad": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgp_conv2d_wgrad_shadow": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

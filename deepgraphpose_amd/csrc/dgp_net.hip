@@ -1558,6 +1558,13 @@ int dgp_net_widen(dgp_net* net) {
     return DGP_OK;
 }
 
+int dgp_net_reset_scales(dgp_net* net) {
+    if (!net) return fail(DGP_ERR_INVALID, "dgp_net_reset_scales: null net");
+    net->h2_calibrated = false;
+    net->h2_head = 4;                   // (dgp_net_load_weights' value)
+    return DGP_OK;
+}
+
 int dgp_maxpool_3x3s2_same(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, float* y, void* stream) {
     if (!x || !y || (C & 3)) return fail(DGP_ERR_INVALID, "dgp_maxpool_3x3s2_same: bad argument (C % 4)");
     hipError_t e = launch_maxpool(x, N, H, W, C, y, (hipStream_t)stream);

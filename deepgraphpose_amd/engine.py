@@ -222,6 +222,13 @@ class DGPNet:
         _lib.check(self.lib.dgp_net_recalibrate(self._h), "dgp_net_recalibrate")
         self.scale_epoch += 1
 
+    def reset_scales(self):
+        """Default headroom again and a calibration pass on the next forward: the state right after load_weights (an engine kept between
+        videos starts every video as a fresh one would)."""
+        _lib.check(self.lib.dgp_net_reset_scales(self._h), "dgp_net_reset_scales")
+        self.widen_count = 0
+        self.scale_epoch += 1
+
     def widen(self):
         """Re-calibrate on the next forward with 3 more bits of headroom -- what range_status() does on an overflow -- for a rank
         that follows another rank's overflow in a sharded run."""
@@ -268,8 +275,10 @@ class DGPPipeline:
         self.nets = [first] if first is not None else []
         while len(self.nets) < n_streams:
             self.nets.append(DGPNet(depth, num_joints, in_h, in_w, max_batch, with_locref, device, mean_pixel, tier=tier))
-        if tier is not None and first is not None and first.tier != self.nets[-1].tier:
-            first.set_tier(tier)
+        if tier is not None and first is not None:
+            want = "f16" if DGPNet.TIERS[tier] == 1 else "parity"      # compare with the tier that was ASKED for (with n_streams == 1 there is no second engine)
+            if first.tier != want:
+                first.set_tier(tier)
         self.device = self.nets[0].device
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
         self.nj, self.max_batch = num_joints, max_batch
@@ -354,6 +363,11 @@ class DGPPipeline:
     def recalibrate(self):
         for n in self.nets:
             n.recalibrate()
+        self._calibrated = False
+
+    def reset_scales(self):
+        for n in self.nets:
+            n.reset_scales()
         self._calibrated = False
 
     def widen(self):

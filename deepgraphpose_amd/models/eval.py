@@ -37,8 +37,9 @@ class EvalSession:
     frame size (the TF placeholder was [1, None, None, 3]); `run` accepts the same fetch list."""
 
     def __init__(self, weights: Dict[str, np.ndarray], depth: int, nj: int, loc_ref: bool, gauss_len, gamma,
-                 mean_pixel, max_batch: int = 32, device: int = 0):
+                 mean_pixel, max_batch: int = 32, device: int = 0, tier: Optional[str] = None):
         self.weights, self.depth, self.nj, self.loc_ref = weights, depth, nj, loc_ref
+        self.tier = resolve_tier(tier)
         self.gauss_len, self.gamma, self.mean_pixel = gauss_len, gamma, tuple(mean_pixel)
         self.max_batch, self.device = max_batch, device
         self._nets = {}
@@ -52,9 +53,12 @@ class EvalSession:
         keeps the uploaded, repacked weights -- the TF placeholder was [1, None, None, 3] and accepted any size too."""
         from .. import engine
         net = self._nets.get("net")
+        if net is not None and (net.max_batch < self.max_batch or net.device.index != int(self.device)):
+            self._nets = {}                        # (a kept session asked for larger batches / another GPU: new engines)
+            net = None
         if net is None:
             net = engine.DGPNet(self.depth, self.nj, h, w, max_batch=self.max_batch, with_locref=self.loc_ref,
-                                device=self.device, mean_pixel=self.mean_pixel)
+                                device=self.device, mean_pixel=self.mean_pixel, tier=self.tier)
             net.load_weights(self.weights)
             self._nets["net"] = net
         elif (net.in_h, net.in_w) != (h, w):
@@ -69,7 +73,7 @@ class EvalSession:
         pipe = self._nets.get("pipe")
         if pipe is None:
             pipe = engine.DGPPipeline(self.depth, self.nj, h, w, max_batch=self.max_batch, with_locref=self.loc_ref,
-                                      device=self.device, n_streams=n_streams, mean_pixel=self.mean_pixel, first=net)
+                                      device=self.device, n_streams=n_streams, mean_pixel=self.mean_pixel, first=net, tier=self.tier)
             for n in pipe.nets[1:]:
                 n.load_weights(self.weights)
             self._nets["pipe"] = pipe
@@ -109,11 +113,29 @@ class EvalSession:
         return res[0] if single else res
 
     def close(self):
-        self._nets = {}
+        """tf.Session.close(): drops the engines -- unless this is the session kept for the next call on the same snapshot
+        (setup_dgp_eval_graph; clear_session_cache() frees it)"""
+        if _SESSION_CACHE.get("sess") is not self:
+            self._nets = {}
 
 
-def setup_dgp_eval_graph(dlc_cfg, dgp_model_file, loc_ref=False, gauss_len=1, gamma=1):
-    """-> (sess, mu_n, softmax_tensor, scmap, locref, inputs), as eval.py:147-214.
+def resolve_tier(tier: Optional[str] = None) -> Optional[str]:
+    """The arithmetic tier of an entry point: the `tier` argument, else the environment's DGP_EVAL_TIER, else None = the library's
+    default (the parity tier: 1e-3 px / bit-exact indices).  "f16" = the 16-bit tier (2-byte activation cells, one MFMA per product,
+    ~2 x the frames/s): a REPORTED tier with measured error, never what parity claims are made on."""
+    t = tier if tier is not None else (os.environ.get("DGP_EVAL_TIER") or None)
+    if t is None:
+        return None
+    t = str(t).lower()
+    if t in ("bf16", "fp16", "half", "16", "h1"):
+        t = "f16"
+    if t not in ("parity", "f32x", "f16"):
+        raise ValueError("tier must be 'parity' or 'f16' (got %r)" % (tier if tier is not None else os.environ.get("DGP_EVAL_TIER"),))
+    return t
+
+
+def setup_dgp_eval_graph(dlc_cfg, dgp_model_file, loc_ref=False, gauss_len=1, gamma=1, tier=None):
+    """-> (sess, mu_n, softmax_tensor, scmap, locref, inputs), as eval.py:147-214.  `tier` is new (resolve_tier): None / "parity" / "f16".
 
     `dgp_model_file` is what Saver.restore takes (eval.py:194-211): the prefix of a TF V2 bundle (`<prefix>.index` +
     `.data-*`, written by the reference or by this package's fit drivers), a V1 `.ckpt` file, or an .npz / .safetensors
@@ -121,25 +143,75 @@ def setup_dgp_eval_graph(dlc_cfg, dgp_model_file, loc_ref=False, gauss_len=1, ga
     a missing file raises FileNotFoundError, a net_type that does not match the snapshot raises
     KeyError (the reference relies on exactly that failure to fall back from resnet_50 to resnet_101)."""
     from .. import weights_io
-    weights = weights_io.load_weights(str(dgp_model_file))
     depth = int(str(dlc_cfg.net_type).split("_")[-1])
+    mean_pixel = dlc_cfg.get("mean_pixel", [123.68, 116.779, 103.939])
+    # One session is kept between calls (run_dgp_demo / plot_dgp label a project's videos one after the other with ONE snapshot: the
+    # reference restored the graph for every video): same snapshot files (path, size, mtime), same graph arguments -> the engines with
+    # their uploaded, re-packed weights are reused; activation scales are calibrated again on every video's first batch.
+    key = None
+    if os.environ.get("DGP_EVAL_SESSION_CACHE", "1") != "0":
+        try:
+            f = weights_io.resolve(str(dgp_model_file))
+            stamp = tuple((q, os.path.getsize(q), os.stat(q).st_mtime_ns) for q in sorted(_snapshot_files(f)))
+            key = (stamp, depth, int(dlc_cfg.num_joints), bool(loc_ref), gauss_len, gamma, tuple(float(v) for v in mean_pixel), resolve_tier(tier))
+        except OSError:
+            key = None
+    if key is not None and _SESSION_CACHE.get("key") == key:
+        sess = _SESSION_CACHE["sess"]
+        return sess, sess.mu_n, sess.softmax_tensor, sess.scmap, sess.locref, sess.inputs
+    weights = weights_io.load_weights(str(dgp_model_file))
     if ("resnet_v1_%d/conv1/weights" % depth) not in weights:
         raise KeyError("snapshot %s holds no resnet_v1_%d variables" % (dgp_model_file, depth))
-    sess = EvalSession(weights, depth, int(dlc_cfg.num_joints), bool(loc_ref), gauss_len, gamma,
-                       dlc_cfg.get("mean_pixel", [123.68, 116.779, 103.939]))
+    sess = EvalSession(weights, depth, int(dlc_cfg.num_joints), bool(loc_ref), gauss_len, gamma, mean_pixel, tier=tier)
+    if key is not None:
+        clear_session_cache()
+        _SESSION_CACHE.update(key=key, sess=sess)
     return sess, sess.mu_n, sess.softmax_tensor, sess.scmap, sess.locref, sess.inputs
+
+
+_SESSION_CACHE: Dict[str, object] = {}
+
+
+def _snapshot_files(resolved: str):
+    """the files a snapshot consists of: a V2 bundle's .index + .data-* shards, or the single file"""
+    import glob
+    if resolved.endswith(".index"):
+        return [resolved] + glob.glob(resolved[:-len(".index")] + ".data-*")
+    return [resolved]
+
+
+def clear_session_cache():
+    """Drop the engines kept for the next call on the same snapshot (frees their device memory)."""
+    old = _SESSION_CACHE.pop("sess", None)
+    _SESSION_CACHE.pop("key", None)
+    if old is not None:
+        old._nets = {}
 
 
 # counters of the last estimate_pose call (tests, soak runs): chunks processed and chunks re-run after a range overflow
 RUN_STATS = {"chunks": 0, "chunk_reruns": 0, "strict_passes": 0, "stage_s": 0.0, "wait_frames_s": 0.0, "wait_h2d_s": 0.0, "drain_s": 0.0,
-             "setup_s": 0.0}
+             "setup_s": 0.0, "alloc_s": 0.0, "calibrate_s": 0.0, "finish_s": 0.0}
+
+# pinned staging ring, kept between calls (pinning host memory costs ~ 10 ms per 30-MB buffer; a project's videos share one frame size)
+_PINNED = {"key": None, "bufs": []}
+
+
+def _pinned_ring(nslots: int, shape):
+    import torch
+    key = (nslots, tuple(shape))
+    if _PINNED["key"] != key:
+        _PINNED["bufs"] = []                       # (drop the old ring first)
+        _PINNED["bufs"] = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(nslots)]
+        _PINNED["key"] = key
+    return _PINNED["bufs"]
 
 
 def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle=1, save_pose=True, save_str="",
-                  new_size=None, crop_size=None, batch_size: int = 32):
+                  new_size=None, crop_size=None, batch_size: int = 32, tier: Optional[str] = None):
     """Estimate pose on an arbitrary video (eval.py:217-372).  Returns {'x','y','likelihoods'} [T,nj] float64,
     or the csv path if labels already exist (:247-249).  `batch_size` is new: frames go through the GPU in
-    batches instead of one sess.run per frame.
+    batches instead of one sess.run per frame.  `tier` is new (resolve_tier): None = DGP_EVAL_TIER or the parity tier; "f16" = the
+    16-bit tier (reported error band, ~2 x the frames/s).
 
     Multi-GPU: under torchrun (one process per GPU; RANK / WORLD_SIZE / LOCAL_RANK in the environment, or an
     already initialised torch.distributed group) rank r decodes and infers only the contiguous frame block
@@ -174,10 +246,10 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
 
     try:
         dlc_cfg.net_type = "resnet_50"
-        sess, mu_n, _, scmap, _, inputs = setup_dgp_eval_graph(dlc_cfg, dgp_model_file)
+        sess, mu_n, _, scmap, _, inputs = setup_dgp_eval_graph(dlc_cfg, dgp_model_file, tier=tier)
     except KeyError:
         dlc_cfg.net_type = "resnet_101"
-        sess, mu_n, _, scmap, _, inputs = setup_dgp_eval_graph(dlc_cfg, dgp_model_file)
+        sess, mu_n, _, scmap, _, inputs = setup_dgp_eval_graph(dlc_cfg, dgp_model_file, tier=tier)
     sess.max_batch = int(batch_size)
     sess.device = local_rank
     lo, hi = ddist.shard_range(n_frames, rank, world)        # this rank's frames
@@ -202,7 +274,7 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
             im = im.crop(crop_size)
         return np.asarray(im)
 
-    def _infer_once(video_clip):
+    def _infer_once(video_clip, first_pass=True):
         nonlocal net_used
         # Host pipeline: a decode thread fills pinned staging buffers, a copy stream moves batch k+1
         # to the GPU while batch k runs through dgp_infer on the compute stream, and the keypoints of the whole video
@@ -231,8 +303,9 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
         net = net_used = sess.pipe_for(hh, ww, n_streams=max(1, int(os.environ.get("DGP_EVAL_STREAMS", "2"))))
         torch.cuda.synchronize(dev)
         RUN_STATS["setup_s"] += time.perf_counter() - t_      # the engines of this frame size: weights re-packed and uploaded (first call of a size)
-        nslots = 4                                # pinned staging: one batch being decoded, one being copied, two of slack
-        pinned = [torch.empty((batch_size, hh, ww, 3), dtype=torch.uint8).pin_memory() for _ in range(nslots)]
+        t_ = time.perf_counter()
+        nslots = max(3, int(os.environ.get("DGP_EVAL_PINNED_SLOTS", "8")))      # pinned staging ring: batches being staged / copied + slack for bursts
+        pinned = _pinned_ring(nslots, (batch_size, hh, ww, 3))
         # The frames of a CHUNK of batches stay on the device until the chunk's range check has come back clean: a chunk whose
         # activations outgrew the calibrated H2 scales is re-run from HBM, without decoding anything again (DGP_EVAL_CHUNK_BATCHES,
         # default 64 batches, capped at 4 GB of frames)
@@ -244,66 +317,133 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
         chunk_cap = int(float(os.environ.get("DGP_EVAL_CHUNK_BYTES", str(1 << 30))) // max(batch_bytes, 1)) or 1
         chunk_batches = max(1, min(int(os.environ.get("DGP_EVAL_CHUNK_BATCHES", "64")), chunk_cap, per_rank_batches))
         dchunk = torch.empty((chunk_batches, batch_size, hh, ww, 3), dtype=torch.uint8, device=dev)
+        RUN_STATS["alloc_s"] += time.perf_counter() - t_        # pinned ring (kept between calls) + the chunk's device buffer
         strict = os.environ.get("DGP_EVAL_STRICT", "0") == "1"
         stale = False                             # an earlier chunk holds results of narrower scales than the video ended with
         cal_batch = None                          # the batch every engine (and every rank) calibrates its activation scales on
+        if first_pass:
+            net.reset_scales()                    # engines kept from an earlier video: THIS video's first batch sets the scales, on the default
+                                                  # headroom -- the same bits as a fresh session (a strict re-pass keeps the widened scales)
         if world > 1 and hasattr(video_clip, "frame_at"):
             # every rank calibrates the activation scales on the video's FIRST batch (not on its own shard's), so the frozen scales --
             # and with them every output bit -- are those of a single-process run
-            net.recalibrate()
             nb0 = min(batch_size, n_frames)
             for t in range(nb0):
                 np.copyto(pinned[0][t].numpy(), prep(video_clip.frame_at(t)))
             cal_batch = pinned[0][:nb0].to(dev)
             net.calibrate(cal_batch, sess.gamma, sess.gauss_len)
             torch.cuda.synchronize(dev)
-        free_slots, ready = queue.Queue(), queue.Queue()
-        for i in range(nslots):
-            free_slots.put(i)
+        # ---- staging: N host threads fill the pinned ring (a batch is ONE GIL-free copy when the source is an in-memory stack; decoders
+        # are sequential by nature and keep one thread), the consumer below takes the batches IN ORDER.  Protocol, all under `cv`:
+        # staged[k] = (slot, frames) of batch k; a thread may stage batch k only while k < n_freed + nslots (the window of batches that can
+        # hold a slot at once: no thread can starve an earlier batch of its slot); total = number of batches once known; err = a decode error.
+        cv = threading.Condition()
+        st = {"staged": {}, "n_freed": 0, "total": None, "err": None, "free": list(range(nslots))}
+        whole_batches = new_size is None and crop_size is None and hasattr(video_clip, "iter_batches") and hasattr(video_clip, "frames")
+        n_stage = max(1, int(os.environ.get("DGP_EVAL_STAGE_THREADS", "2"))) if whole_batches else 1
 
-        whole_batches = new_size is None and crop_size is None and hasattr(video_clip, "iter_batches")
+        def take_slot(k):
+            with cv:
+                while not (k < st["n_freed"] + nslots and st["free"]) and st["err"] is None:
+                    cv.wait()
+                if st["err"] is not None:
+                    raise RuntimeError("staging stopped")
+                return st["free"].pop()
 
-        def producer():
+        def publish(k, slot, nb):
+            with cv:
+                st["staged"][k] = (slot, nb)
+                cv.notify_all()
+
+        def stage_stack(tid):                     # in-memory stack: thread tid stages batches tid, tid + n_stage, ...
             try:
-                if whole_batches:       # in-memory stack: one GIL-free copy per batch instead of one python step per frame
-                    done = 0
-                    src = video_clip.frames[lo:hi] if world > 1 else None
-                    chunks = (src[i:i + batch_size] for i in range(0, n_local, batch_size)) if world > 1 else \
-                        video_clip.iter_batches(batch_size)
-                    for chunk in chunks:
-                        nb = min(len(chunk), n_local - done)
-                        if nb <= 0:
-                            break
-                        slot = free_slots.get()
-                        t_ = time.perf_counter()
-                        np.copyto(pinned[slot][:nb].numpy(), chunk[:nb])
-                        RUN_STATS["stage_s"] += time.perf_counter() - t_
-                        ready.put((slot, nb))
-                        done += nb
-                    ready.put(None)
-                    return
-                slot, fill, count = free_slots.get(), 0, 0
+                src = video_clip.frames
+                nbat = -(-n_local // batch_size)
+                for k in range(tid, nbat, n_stage):
+                    a = lo + k * batch_size
+                    nb = min(batch_size, hi - a)
+                    slot = take_slot(k)
+                    t_ = time.perf_counter()
+                    np.copyto(pinned[slot][:nb].numpy(), src[a:a + nb])
+                    RUN_STATS["stage_s"] += time.perf_counter() - t_
+                    publish(k, slot, nb)
+            except BaseException as e:            # surface errors in the consumer
+                with cv:
+                    st["err"] = st["err"] or e
+                    cv.notify_all()
+
+        def stage_decoded():                      # frame by frame from the decoder (one thread: decoding is sequential)
+            try:
+                k, fill, count, slot = 0, 0, 0, None
                 for fr in itertools.chain([f0], (prep(x) for x in frames_it)):
                     if count >= n_local:
                         break
+                    if slot is None:
+                        slot = take_slot(k)
                     np.copyto(pinned[slot][fill].numpy(), fr)
                     fill += 1
                     count += 1
                     if fill == batch_size:
-                        ready.put((slot, fill))
-                        slot, fill = free_slots.get(), 0
+                        publish(k, slot, fill)
+                        k, fill, slot = k + 1, 0, None
                 if fill:
-                    ready.put((slot, fill))
-                ready.put(None)
-            except BaseException as e:      # surface decode errors in the consumer
-                ready.put(e)
+                    publish(k, slot, fill)
+                    k += 1
+                with cv:
+                    st["total"] = k
+                    cv.notify_all()
+            except BaseException as e:
+                with cv:
+                    st["err"] = st["err"] or e
+                    cv.notify_all()
 
-        th = threading.Thread(target=producer, daemon=True)
-        th.start()
-        copy_stream = torch.cuda.Stream(device=dev)
+        if whole_batches:
+            st["total"] = -(-n_local // batch_size)
+            threads = [threading.Thread(target=stage_stack, args=(t,), daemon=True) for t in range(n_stage)]
+        else:
+            threads = [threading.Thread(target=stage_decoded, daemon=True)]
+        for th in threads:
+            th.start()
+        copy_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, int(os.environ.get("DGP_EVAL_COPY_STREAMS", "2"))))]
         compute = torch.cuda.current_stream(dev)
         traj = torch.zeros((max(n_local, 1), nj, 5), dtype=torch.float32, device=dev)      # packed (row, col, likelihood, iy, ix)
-        start, finished = 0, False
+        pending = []                              # (H2D-complete event, pinned slot): slots go back to the ring without the host waiting for every copy
+
+        def release(block):
+            """pinned slots whose H2D copy has completed go back to the ring; block: wait for the oldest copy when none has"""
+            freed = 0
+            while pending and pending[0][0].query():
+                freed += 1
+                slot = pending.pop(0)[1]
+                with cv:
+                    st["free"].append(slot); st["n_freed"] += 1
+                    cv.notify_all()
+            if block and not freed and pending:
+                t_ = time.perf_counter()
+                pending[0][0].synchronize()
+                RUN_STATS["wait_h2d_s"] += time.perf_counter() - t_
+                release(False)
+
+        def next_batch(k):
+            """(slot, frames) of batch k, or None when the shard has no batch k"""
+            t_ = time.perf_counter()
+            try:
+                while True:
+                    with cv:
+                        if st["err"] is not None:
+                            raise st["err"]
+                        if k in st["staged"]:
+                            return st["staged"].pop(k)
+                        if st["total"] is not None and k >= st["total"]:
+                            return None
+                        if not pending:
+                            cv.wait(0.05)
+                            continue
+                    release(True)                 # the producers may be waiting for a slot this thread still holds
+            finally:
+                RUN_STATS["wait_frames_s"] += time.perf_counter() - t_
+
+        start, finished, kb = 0, False, 0
         # every rank runs the SAME number of chunk rounds (a short shard ends with empty ones): the decision to re-calibrate after a
         # range overflow is a collective
         per_rank = -(-n_frames // world)
@@ -311,31 +451,30 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
         for rnd in range(n_rounds):
             entries = []                          # (slot in dchunk, frames, offset in traj) of this chunk
             while len(entries) < chunk_batches and not finished:
-                t_ = time.perf_counter()
-                item = ready.get()
-                RUN_STATS["wait_frames_s"] += time.perf_counter() - t_
+                item = next_batch(kb)
                 if item is None:
                     finished = True
                     break
-                if isinstance(item, BaseException):
-                    raise item
+                kb += 1
                 slot, nb = item
                 k = len(entries)
-                with torch.cuda.stream(copy_stream):
+                cs = copy_streams[kb % len(copy_streams)]
+                with torch.cuda.stream(cs):
                     dchunk[k][:nb].copy_(pinned[slot][:nb], non_blocking=True)
                     copied = torch.cuda.Event()
-                    copied.record(copy_stream)
+                    copied.record(cs)
                 compute.wait_event(copied)
+                pending.append((copied, slot))
                 if cal_batch is None:
                     cal_batch = dchunk[k][:nb].clone()
+                    t_ = time.perf_counter()
+                    net.calibrate(cal_batch, sess.gamma, sess.gauss_len)      # (what the first submit would do: timed apart)
+                    RUN_STATS["calibrate_s"] += time.perf_counter() - t_
                 # written in place by the soft-argmax kernel, on the next engine's stream
                 net.submit(dchunk[k][:nb], traj[start:start + nb], sess.gamma, sess.gauss_len)
                 entries.append((k, nb, start))
                 start += nb
-                t_ = time.perf_counter()
-                copied.synchronize()              # the pinned buffer is free again once its H2D copy has completed
-                RUN_STATS["wait_h2d_s"] += time.perf_counter() - t_
-                free_slots.put(slot)
+                release(len(pending) >= nslots - 1)
             # H2 activation scales (include/dgp_hip.h): a batch that outgrew the scales calibrated on the first batch invalidates the
             # results since the last clean check, i.e. THIS chunk's.  All ranks decide together; every engine of every rank then
             # re-calibrates on the calibration batch with 3 more bits of headroom (same scales everywhere again) and the ranks whose
@@ -364,11 +503,12 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
                         net.submit(dchunk[k][:nb], traj[off:off + nb], sess.gamma, sess.gauss_len)
             RUN_STATS["chunks"] += 1 if entries else 0
         if not finished:
-            item = ready.get()                    # the producer's end marker
-            if isinstance(item, BaseException):
-                raise item
-            assert item is None, "more frames than the shard holds"
-        th.join()
+            assert next_batch(kb) is None, "more frames than the shard holds"
+        while pending:
+            release(True)
+        for th in threads:
+            th.join()
+        t_ = time.perf_counter()
         if world > 1:                                  # ONE all-gather per video: 20 bytes per (frame, joint)
             full = ddist.gather_trajectory(traj[:n_local], n_frames)
             mu_t, lik_t, _ = ddist.unpack_keypoints(full)
@@ -378,6 +518,7 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
             mu_t, lik_t, _ = ddist.unpack_keypoints(traj[:start])
             markers[:start] = mu_t.cpu().numpy()
             likelihoods[:start] = lik_t.cpu().numpy()
+        RUN_STATS["finish_s"] += time.perf_counter() - t_       # the trajectory's gather / ONE device-to-host copy
         return stale
 
     # Bit-identity of a sharded run with a single-process run holds as long as no chunk overflows (or only the first one does).  After an
@@ -389,9 +530,10 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
     # where the host side of the call spent its time: staging copies of in-memory frames (producer thread), the consumer waiting for a
     # decoded batch / for an H2D copy / for the engines at a chunk boundary
     RUN_STATS["stage_s"] = RUN_STATS["wait_frames_s"] = RUN_STATS["wait_h2d_s"] = RUN_STATS["drain_s"] = 0.0
+    RUN_STATS["alloc_s"] = RUN_STATS["calibrate_s"] = RUN_STATS["finish_s"] = 0.0
     RUN_STATS["setup_s"] = time.perf_counter() - t_entry      # config, snapshot -> engine (read, re-pack, upload): before the first frame moves
     for _pass in range(4):
-        if not (_infer_once(video_clip) and os.environ.get("DGP_EVAL_STRICT", "0") == "1"):
+        if not (_infer_once(video_clip, _pass == 0) and os.environ.get("DGP_EVAL_STRICT", "0") == "1"):
             break
         RUN_STATS["strict_passes"] += 1
         print("DGP_EVAL_STRICT: scales were widened after the first chunk; computing %s again on the final scales" % video_file, flush=True)
@@ -439,8 +581,8 @@ def load_pose_from_dlc_to_dict(filename):
 
 
 def plot_dgp(video_file, output_dir="", label_dir=None, proj_cfg_file=None, dgp_model_file=None, shuffle=1, dotsize=3,
-             colormap="jet", save_str="", mask_threshold=0.1, new_size=None):
-    """eval.py:816-874.  Exports the labels when missing, then hands (clip, x, y, mask) to the movie
+             colormap="jet", save_str="", mask_threshold=0.1, new_size=None, tier=None):
+    """eval.py:816-874 (`tier` is new: estimate_pose's).  Exports the labels when missing, then hands (clip, x, y, mask) to the movie
     renderer.  Drawing the annotated movie is moviepy / matplotlib work outside this package's scope: when
     those are absent the labels are still produced and the csv path is returned."""
     f = os.path.basename(str(video_file)).rsplit(".", 1)
@@ -453,7 +595,7 @@ def plot_dgp(video_file, output_dir="", label_dir=None, proj_cfg_file=None, dgp_
     labels = None
     if not ddist.from_rank0(os.path.exists(label_file)):
         labels = estimate_pose(proj_cfg_file, dgp_model_file, video_file, label_dir, shuffle=shuffle, save_str=save_str,
-                               new_size=new_size)
+                               new_size=new_size, tier=tier)
     if not isinstance(labels, dict):                       # labels were there already (estimate_pose returns the csv path then)
         labels = load_pose_from_dlc_to_dict(label_file)
     mask_array = labels["likelihoods"].T > mask_threshold
@@ -511,8 +653,8 @@ def soft_argmax_locref_pose(locref, softmax_map, stride, locref_stdev):
     return np.hstack((np.array(out), np.ones((nj, 1))))
 
 
-def evaluate_dgp(proj_cfg_file, dgp_model_file, shuffle=1, loc_ref=None, loc_ref_calc="dlc"):
-    """Evaluate a model by RMSE (px) on the human-labeled train/test images (eval.py:656-813).
+def evaluate_dgp(proj_cfg_file, dgp_model_file, shuffle=1, loc_ref=None, loc_ref_calc="dlc", tier=None):
+    """Evaluate a model by RMSE (px) on the human-labeled train/test images (eval.py:656-813).  `tier` is new (resolve_tier).
 
     loc_ref=True + loc_ref_calc='dlc': DLC hard arg-max + location refinement (HIP `hard_argmax` kernel);
     loc_ref=False: DGP soft-argmax (HIP `soft_argmax` kernel).  loc_ref=True + any other loc_ref_calc ('dgp'): soft-argmax
@@ -536,10 +678,10 @@ def evaluate_dgp(proj_cfg_file, dgp_model_file, shuffle=1, loc_ref=None, loc_ref
         dlc_cfg.location_refinement = False
     try:
         dlc_cfg.net_type = "resnet_50"
-        sess, mu_n, softmax_tensor, scmap_t, locref_t, inputs = setup_dgp_eval_graph(dlc_cfg, dgp_model_file, loc_ref=loc_ref)
+        sess, mu_n, softmax_tensor, scmap_t, locref_t, inputs = setup_dgp_eval_graph(dlc_cfg, dgp_model_file, loc_ref=loc_ref, tier=tier)
     except KeyError:
         dlc_cfg.net_type = "resnet_101"
-        sess, mu_n, softmax_tensor, scmap_t, locref_t, inputs = setup_dgp_eval_graph(dlc_cfg, dgp_model_file, loc_ref=loc_ref)
+        sess, mu_n, softmax_tensor, scmap_t, locref_t, inputs = setup_dgp_eval_graph(dlc_cfg, dgp_model_file, loc_ref=loc_ref, tier=tier)
 
     tsfolder = GetTrainingSetFolder(proj_config)
     scorer_dgp = "DGP"

@@ -138,15 +138,15 @@ class Trainer:
             self.tier == "f16" or                                # the 16-bit tier: every pass after the first of a shape
             (os.environ.get("DGP_TRAIN_H2", "0") == "1" and bool(self.lib.dgp_tuning_build())))      # (H2 fast pass: an opt-in of -DDGP_TUNING builds)
         _lib.check(self.lib.dgp_trainer_fast_mode(self._t, 1 if fast else 0), "dgp_trainer_fast_mode")
-        if fast:
-            self.fast_passes += 1
-        return fast
+        return fast                                  # (a REQUEST: fast_passes counts what the device reports it ran -- _fast_end / step)
 
     def _fast_end(self, nt: int, fast: bool) -> bool:
         """True: the pass is valid.  False: it was a fast pass that failed -- run it again (the next _fast_begin is a plain pass)."""
         if fast:
             was, failed = C.c_int32(), C.c_int32()
             _lib.check(self.lib.dgp_trainer_fast_status(self._t, C.byref(was), C.byref(failed)), "dgp_trainer_fast_status")
+            if was.value:                            # the library may still have run a plain pass (no LDS-DMA weight gradients, missing ranges ...)
+                self.fast_passes += 1
             if failed.value:
                 self._fast_key = None
                 self.fast_redos += 1
@@ -276,6 +276,8 @@ class Trainer:
             lv = (C.c_float * 8)()
             _lib.check(self.lib.dgp_trainer_step_status(self._t, _ptr(dev_losses), len(LOSS_NAMES), lv, C.byref(g), C.byref(was), C.byref(failed),
                                                         _stream(self.device)), "dgp_trainer_step_status")
+            if fast and was.value:
+                self.fast_passes += 1                # counted from the pass status the DEVICE wrote, not from the request
             if fast and failed.value:                # the momentum kernel saw the flag and left parameters and momentum alone
                 if os.environ.get("DGP_DEBUG_FAST"):
                     print("fast pass failed: flag 0x%x" % failed.value, file=sys.stderr)

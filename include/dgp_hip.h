@@ -384,6 +384,10 @@ int  dgp_net_recalibrate(dgp_net* net);      /* force a calibration pass on the 
 /* What dgp_net_range_status does to the engine when it reports an overflow (re-calibrate on the next forward with 3 more bits of
  * headroom), for a rank that did not overflow itself but must follow one that did (sharded runs stay bit-identical). */
 int  dgp_net_widen(dgp_net* net);
+/* Back to the state right after dgp_net_load_weights as far as the activation scales go: default headroom, calibration pass on the next
+ * forward.  For an engine that is kept between videos (models/eval.py, the session kept by setup_dgp_eval_graph): the next video's first
+ * batch then sets the same scales -- and every later frame gets the same bits -- as on a freshly built engine. */
+int  dgp_net_reset_scales(dgp_net* net);
 
 /* slots = max(slots, max |x[0..n)|) on the device (zero the DGP_ABSMAX_SLOTS floats before the first call). */
 int  dgp_tensor_absmax(const float* x, size_t n, float* absmax_dev, void* stream);

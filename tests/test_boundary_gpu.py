@@ -649,3 +649,41 @@ def test_frame_uploader_matches_plain_upload(lib_built):
     dev = up(f)
     torch.cuda.current_stream().wait_event(dev._dgp_ready)
     assert np.array_equal(dev.cpu().numpy(), np.clip(np.rint(f), 0, 255).astype(np.uint8))
+
+
+def test_estimate_pose_keeps_its_engines_between_videos_without_changing_a_bit(lib_built, tmp_path, monkeypatch):
+    """Round 6: setup_dgp_eval_graph keeps ONE session for the next call on the same snapshot (a project's videos are labelled one after the
+    other with one model; the reference restored the graph for every video).  What must not change is the result: video B through the
+    kept engines -- after video A whose flat first frames forced a re-calibration with WIDENED headroom -- equals, bit for bit, video B
+    through a fresh session (DGP_EVAL_SESSION_CACHE=0): dgp_net_reset_scales puts a kept engine back to its post-load state.  A changed
+    snapshot file (other size / mtime) or another tier is another session."""
+    from deepgraphpose_amd.models import eval as E
+    from deepgraphpose_amd import weights_io
+    from deepgraphpose_amd.synthetic import make_frames, make_weights
+    proj, snap, frames_b, wts = _tiny_project(tmp_path, T=21, hw=(64, 96))
+    flat = np.zeros((8, 64, 96, 3), np.uint8)
+    flat[..., 0], flat[..., 1], flat[..., 2] = 124, 117, 104
+    frames_a = np.concatenate([flat, make_frames(12, 64, 96, 3, seed=77)], 0)
+    cfgp = str(proj / "config.yaml")
+    E.clear_session_cache()
+    monkeypatch.setenv("DGP_EVAL_SESSION_CACHE", "0")
+    fresh = E.estimate_pose(cfgp, snap, frames_b, str(tmp_path / "o0"), save_pose=False, batch_size=4)
+    assert not E._SESSION_CACHE
+    monkeypatch.setenv("DGP_EVAL_SESSION_CACHE", "1")
+    E.estimate_pose(cfgp, snap, frames_a, str(tmp_path / "o1"), save_pose=False, batch_size=4)         # (overflows: the engines widen)
+    assert E.RUN_STATS["chunk_reruns"] >= 1
+    sess_a = E._SESSION_CACHE["sess"]
+    kept = E.estimate_pose(cfgp, snap, frames_b, str(tmp_path / "o2"), save_pose=False, batch_size=4)
+    assert E._SESSION_CACHE["sess"] is sess_a and E.RUN_STATS["chunk_reruns"] == 0
+    for k in ("x", "y", "likelihoods"):
+        assert np.array_equal(kept[k], fresh[k]), k
+    f16 = E.estimate_pose(cfgp, snap, frames_b, str(tmp_path / "o3"), save_pose=False, batch_size=4, tier="f16")
+    assert E._SESSION_CACHE["sess"] is not sess_a and not np.array_equal(f16["x"], fresh["x"])
+    sess_f = E._SESSION_CACHE["sess"]
+    w2 = dict(wts)
+    w2["pose/part_pred/block4/biases"] = wts["pose/part_pred/block4/biases"] + 0.25
+    weights_io.save_weights(snap, w2)                                                                   # same path, new contents
+    other = E.estimate_pose(cfgp, snap, frames_b, str(tmp_path / "o4"), save_pose=False, batch_size=4, tier="f16")
+    assert E._SESSION_CACHE["sess"] is not sess_f and not np.array_equal(other["likelihoods"], f16["likelihoods"])
+    E.clear_session_cache()
+    assert not E._SESSION_CACHE

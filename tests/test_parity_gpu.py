@@ -485,6 +485,47 @@ def test_estimate_pose_end_to_end(eng, tmp_path):
         E.setup_dgp_eval_graph(dlc_cfg, snap)
 
 
+def test_estimate_pose_on_the_16_bit_tier_beside_the_parity_tier(eng, tmp_path, monkeypatch):
+    """The 16-bit tier behind the reference's entry point (round 6): estimate_pose(..., tier="f16") -- or DGP_EVAL_TIER=f16 in the
+    environment -- runs the same host pipeline on H1 cells.  Same project, same frames, both tiers: the parity tier meets the north-star
+    gate against the oracle (1e-3 px, likelihood window indices through the likelihoods), the 16-bit tier stays inside ITS reported band
+    (0.08 px on ResNet-50, likelihoods within 0.05) -- and the two really are different engines."""
+    import yaml
+    from oracle import dgp_oracle as O
+    from deepgraphpose_amd import weights_io
+    from deepgraphpose_amd.models import eval as E
+    from deepgraphpose_amd.synthetic import make_weights, make_frames
+    nj, T = 4, 70
+    parts = ["a", "b", "c", "d"]
+    proj = tmp_path / "proj"
+    train = proj / "dlc-models" / "iteration-0" / "DemoOct2-trainset95shuffle1" / "train"
+    train.mkdir(parents=True)
+    (proj / "config.yaml").write_text(yaml.safe_dump(dict(Task="Demo", date="Oct2", iteration=0, TrainingFraction=[0.95],
+                                                          bodyparts=parts, skeleton=[], project_path=str(proj))))
+    (train / "pose_cfg.yaml").write_text(yaml.safe_dump(dict(num_joints=nj, all_joints_names=parts, net_type="resnet_50")))
+    wts = make_weights(50, nj, False, seed=9, head_std=0.05)
+    snap = weights_io.save_weights(str(train / "snapshot-step2-final--0"), wts)
+    frames = make_frames(T, 192, 256, nj, seed=5)
+    ref = O.infer(frames, wts, 50, 8.0, 1.0, 1)
+    monkeypatch.delenv("DGP_EVAL_TIER", raising=False)
+    par = E.estimate_pose(str(proj / "config.yaml"), snap, frames, str(tmp_path / "p0"), save_pose=False, batch_size=16)
+    f16 = E.estimate_pose(str(proj / "config.yaml"), snap, frames, str(tmp_path / "p1"), save_pose=False, batch_size=16, tier="f16")
+    monkeypatch.setenv("DGP_EVAL_TIER", "f16")
+    env = E.estimate_pose(str(proj / "config.yaml"), snap, frames, str(tmp_path / "p2"), save_pose=False, batch_size=16)
+    monkeypatch.setenv("DGP_EVAL_TIER", "fp8")
+    with pytest.raises(ValueError):
+        E.estimate_pose(str(proj / "config.yaml"), snap, frames, str(tmp_path / "p3"), save_pose=False, batch_size=16)
+
+    def px(a):
+        return float(np.sqrt((a["x"] - ref["x"]) ** 2 + (a["y"] - ref["y"]) ** 2).max())
+    print("estimate_pose vs oracle: parity %.3g px, f16 %.3g px (lik %.3g)" % (px(par), px(f16), np.abs(f16["likelihoods"] - ref["likelihoods"]).max()))
+    assert px(par) < PX_TOL and np.abs(par["likelihoods"] - ref["likelihoods"]).max() < 1e-4
+    assert px(f16) < 0.08 and np.abs(f16["likelihoods"] - ref["likelihoods"]).max() < 0.05
+    assert px(f16) > 10 * px(par)                                    # (it IS the other arithmetic)
+    for k in ("x", "y", "likelihoods"):
+        assert np.array_equal(env[k], f16[k])                        # argument and environment select the same engine, deterministically
+
+
 # fp32-MFMA tiles 0-6; bf16 6-term split 7 / 9 / 10 / 12; bf16 3-term split 8 / 11 (16-bit products: looser bound);
 # fp16 high/low split 13-16 (need operand ranges)
 _TILE_CASES = [(2, 19, 21, 64, 128, 3, 1, 1), (1, 15, 20, 128, 256, 3, 1, 2), (2, 20, 24, 256, 512, 1, 2, 1),
