@@ -835,11 +835,7 @@ static hipError_t launch_conv_ls(ConvArgs a, hipStream_t s) {
 // A compute lane (row = lane & 31, half = lane >> 5) reads k-group 2*kk + half of its row with ONE ds_read_b128 per
 // plane; 32 lanes read 512 contiguous bytes.  Plane pitch BM + 4 rows keeps the loaders' 8-byte writes conflict-free.
 // ------------------------------------------------------------------------------------
-#ifdef DGP_EXP_NO_RFL          // tuning experiment: what the waterfall loops around the walker-offset loads cost
-#define DGP_RFL(x) (x)
-#else
 #define DGP_RFL(x) __builtin_amdgcn_readfirstlane(x)
-#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <bool IS_B = false>
@@ -847,14 +843,6 @@ __device__ __forceinline__ void split3_bf16(const float4 v, uint2& p1, uint2& p2
     const unsigned M = 0xFFFF0000u;
     const float x[4] = {v.x, v.y, v.z, v.w};
     unsigned h1[4], h2[4], h3[4];
-#ifdef DGP_EXP_FAKE_SPLIT       // tuning experiment only (wrong numerics): what the split arithmetic costs (2: B operand only)
-    if (DGP_EXP_FAKE_SPLIT == 1 || IS_B) {
-    p1.x = __builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), 0x07060302);
-    p1.y = __builtin_amdgcn_perm(__float_as_uint(x[3]), __float_as_uint(x[2]), 0x07060302);
-    p2 = p1; p3 = p1;
-    return;
-    }
-#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         h1[i] = __float_as_uint(x[i]) & M;
@@ -929,11 +917,7 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
     float amax = 0.f;
     // PRE (the 16x16x32 loops: the accumulators were staged by the caller and are dead): ALL residual (and gate) cells of the wave's
     // tile are requested up front -- NQ x VC loads in flight instead of VC, so the memory round trip is paid once per tile, not NQ times
-#ifdef DGP_EPI_NOPRE
-    constexpr bool PRE = false;
-#else
     constexpr bool PRE = M16;
-#endif
     constexpr int NS = PRE ? NQ : 2;               // register slots of the residual pipeline
     unsigned ooff[NS][VC];
     uint4 rres[NS][VC][O1 ? 1 : 2];
@@ -1048,11 +1032,7 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
     }
     DIAG_STAMP(s3_);
     if (p.out_absmax) {
-#ifdef DGP_EPI_OLDMAX
-        track_absmax(p.out_absmax, amax, lane, (int)(blockIdx.x * 8u + (threadIdx.x >> 6)));
-#else
         track_absmax_known(p.out_absmax, amax, lane, (int)(blockIdx.x * 8u + (threadIdx.x >> 6)), slot_bits);
-#endif
     }
 #ifdef DGP_DIAG
     DIAG_STAMP(s4_);
@@ -1556,12 +1536,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : BM == 256 ? 2 : ((BK =
 #pragma unroll
                 for (int i = 0; i < AROWS; ++i) {
                     const int hi = hi0[i] + dh, wi = wi0[i] + dw + ((MODE == 0 && p.stem) ? c : 0);
-                    bool ok = tapok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-#ifdef DGP_EXP_SKIP_TAPS        // tuning experiments only (wrong numerics). 1: fetch the A operand of 1 tap in 3 (bound on halo
-                                // reuse); 2: no A fetch at all; 3: no A and no B fetch (what is left is issue / LDS / VALU time)
-                    if (DGP_EXP_SKIP_TAPS == 1 && p.ntaps == 9 && (w_tap % 3) != 1) ok = false;
-                    if (DGP_EXP_SKIP_TAPS >= 2) ok = false;
-#endif
+                    const bool ok = tapok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
                     ra[i] = buf_load16(rs_in, ok ? (unsigned)(rowoff[i] + doff) : OOB);
                 }
             }
@@ -1584,12 +1559,6 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : BM == 256 ? 2 : ((BK =
             }
             // the walker is wave-uniform: say so, or hipcc keeps it in VGPRs / scratch behind exec-masked updates
             w_tap = DGP_RFL(w_tap); w_kw = DGP_RFL(w_kw); w_kh = DGP_RFL(w_kh); w_ch = DGP_RFL(w_ch);
-#ifdef DGP_EXP_SKIP_TAPS
-            if (DGP_EXP_SKIP_TAPS >= 3) {
-#pragma unroll
-                for (int i = 0; i < BSLOTS; ++i) rb[i] = buf_load16(rs_w3, OOB);
-            } else
-#endif
             if (PB) {
                 const unsigned kgbase = (kbase >> 1) * 2u;          // (k-group index) * 2 planes * CoutP * 16 bytes = kbase rows / 2 * 2
 #pragma unroll
@@ -1716,13 +1685,9 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : BM == 256 ? 2 : ((BK =
     DIAG_STAMP(e1);
     const unsigned long long t_pro = e1 - e0;
 #endif
-#if !defined(DGP_MFMA32)
     // 16x16x32 MFMAs in the pipelined loop of the 32 x 128 wave tile: the same FLOPs, LDS bytes and register reads as the 32x32x16
     // shape in twice as many, half as long matrix instructions -- +5.3 % end to end (block4 3x3: 0.499 -> 0.453 ms)
     constexpr bool M16 = CS && (TM == 1 || (TM == 2 && H1)) && (TN == 4 || (TN == 2 && DMA)) && NT == 2 && BK == 32;      // (32 x 64 wave tiles: DMA images only)
-#else
-    constexpr bool M16 = false;
-#endif
     static_assert(!DMA || ((TM == 1 || (TM == 2 && H1)) && (TN == 4 || TN == 2)), "DMA image is read by the pipelined loops only");
     static_assert(!(DMA && AH2) || M16, "pre-split A + DMA image: 16x16x32 loop only");
     if constexpr (MODE == 3) {
@@ -2052,7 +2017,6 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : BM == 256 ? 2 : ((BK =
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     } else
-#if !defined(DGP_NO_PIPE)
     // (nothing but the next `if constexpr` may stand between this `else` and its statement: two static_asserts used to, which made
     //  THEM the else branch and let the generic K loop below run -- as nks extra barriers, its MFMAs being dead code -- after the
     //  16x16x32 loop as well.  Harmless while a block ran one tile; found when a persistent variant desynchronised its barriers)
@@ -2171,7 +2135,6 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : BM == 256 ? 2 : ((BK =
 #undef DGP_GH
 #undef DGP_FENCE
     } else
-#endif
     for (int ks = 0; ks < nks; ++ks) {
         const int buf = ks & 1;
         DIAG_STAMP(e1);
@@ -2415,7 +2378,7 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     // launch against 393 MB of operands on block4's conv3.  Measured (same box, ms per launch, nt 0 / 2): block3 conv3 0.105 -> 0.088,
     // the conv1 that re-reads the tensor 0.070 -> 0.076, block4 conv3 0.268 -> 0.253; everywhere (1) loses: a small output written nt
     // (R2: 39 MB) is no longer cache-resident for its consumer
-    static const int epi_nt_env = dgp_env("DGP_EPI_NT", 2);
+    static const int epi_nt_env = dgp_tune("DGP_EPI_NT", 2);
     a.epi_nt = epi_nt_env == 1 ? 3 : (a.CoutP / BN >= 8 ? (epi_nt_env == 2 ? 3 : epi_nt_env == 3 ? 1 : epi_nt_env == 4 ? 2 : 0) : 0);   // bit 0: loads, bit 1: stores
     static const int tap_minor = dgp_tune("DGP_TAP_MINOR", 1);
     a.tap_minor = (tap_minor && !a.stem && a.ntaps > 1 && a.nk * 32 == a.ntaps * a.Cin) ? 1 : 0;
@@ -2451,7 +2414,7 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
                     : mode == 1 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_PB, 1> : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_PB, 0>;
     constexpr bool CAN_CS = CAN_PB && BK == 32;
     // 2 (default): every fp16 kernel with pre-split weights; 1: 128 x 128 tiles only; 0: loaders split (A/B switch)
-    static const int cs_env = dgp_env("DGP_COMPUTE_SPLIT", 2);
+    static const int cs_env = dgp_tune("DGP_COMPUTE_SPLIT", 2);
     const bool cs = CAN_CS && a.wh3 && (cs_env >= 2 || (cs_env == 1 && BN == 128));
     if (cs) kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 2, CAN_CS>
                  : mode == 1 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 1, CAN_CS> : conv_igemm_split_ls<BM, BN, NT, BK, CW, CAN_CS, 0, CAN_CS>;
@@ -2459,7 +2422,7 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
               : mode == 1 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 1> : conv_igemm_split_ls<BM, BN, NT, BK, CW, false, 0>;
     // LDS-DMA loaders (A/B switch DGP_DMA=0): 128 x 128 CS kernels with the plain or the pointwise walk
     constexpr bool CAN_DMA = CAN_CS && BM == 128 && (BN == 128 || BN == 64);
-    static const int dma_env = dgp_env("DGP_DMA", 1);
+    static const int dma_env = dgp_tune("DGP_DMA", 1);
     const bool dma = CAN_DMA && cs && mode != 0 && dma_env;
     // deep DMA ring (see the kernel) for grids of at most one tile per CU; A/B switch DGP_DEEP_RING=0, =2: every DMA launch
     constexpr bool CAN_DEEP = CAN_DMA && BN == 128;
@@ -2650,7 +2613,7 @@ static hipError_t launch_conv_w64(ConvArgs a, hipStream_t s) {       // (`a` alr
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = a.CoutP / BN;
     if (a.tap_rows == 0) a.tap_rows = a.Cin >> 2;
-    static const int epi_nt_env = dgp_env("DGP_EPI_NT", 2);
+    static const int epi_nt_env = dgp_tune("DGP_EPI_NT", 2);
     a.epi_nt = epi_nt_env == 1 ? 3 : (a.ntiles >= 8 ? (epi_nt_env == 2 ? 3 : epi_nt_env == 3 ? 1 : epi_nt_env == 4 ? 2 : 0) : 0);
     a.tail_ksplit = 0; a.st_gn = 0;
     const bool pointwise = a.ntaps == 1 && a.stride == 1 && a.pad_t == 0 && a.pad_l == 0 && a.H == a.Ho && a.W == a.Wo;

@@ -634,13 +634,13 @@ int run_conv(dgp_net* net, const ConvLayer& l, const float* in, int N, int H, in
         a.in_bytes = (unsigned)inb; a.out_bytes = (unsigned)outb; a.res_bytes = (unsigned)resb;
         a.w_bytes = (unsigned)((size_t)l.nk * 8 * l.CoutP * 16);
     }
-    static const bool stem_rows = (dgp_env("DGP_STEM_ROWS", 1) != 0);        // A/B switch
+    static const bool stem_rows = (dgp_tune("DGP_STEM_ROWS", 1) != 0);        // A/B switch
     static const bool f32_mode = getenv("DGP_CONV_MODE") && !strcmp(getenv("DGP_CONV_MODE"), "f32");
     if (li == net->conv1 && l.d_w_rows && net->wmax_valid && stem_rows && !f32_mode && l.CoutP % 64 == 0) {
         a.stem = 1; a.tap_rows = 8; a.KH = 7; a.KW = 1; a.ntaps = 7; a.nk = 7; a.wpk = l.d_w_rows;
         a.w_bytes = (unsigned)((size_t)7 * 8 * l.CoutP * 16);
     }
-    static const bool use_cells = (dgp_env("DGP_PRESPLIT_WEIGHTS", 1) != 0);   // A/B switch
+    static const bool use_cells = (dgp_tune("DGP_PRESPLIT_WEIGHTS", 1) != 0);   // A/B switch
     if (use_cells && ranged && l.d_wh3 && (li != net->conv1 || a.stem)) { a.wh3 = l.d_wh3; a.wh3_bytes = a.w_bytes; }
     if (h2.in_fmt == 2) { a.wh3 = l.d_wh1; a.wh3_bytes = a.w_bytes; }       // (null: launch_conv refuses)
     const int tile_cfg = pick_tile(a.M, a.CoutP, a.nk * BK, ranged && a.w_absmax);
@@ -848,10 +848,10 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     static const bool h2_env = (dgp_env("DGP_H2", 1) != 0);
     static const bool f16_mode = !getenv("DGP_CONV_MODE") || !strcmp(getenv("DGP_CONV_MODE"), "f16x3") || tier16_env();
     const int tier = net->tier, FMT = tier ? 2 : 1;      // activation cells of this forward: H2 (parity tier) or H1 (16-bit tier)
-    static const bool head_pw = (dgp_env("DGP_HEAD_PW", 1) != 0);      // A/B switch
+    static const bool head_pw = (dgp_tune("DGP_HEAD_PW", 1) != 0);      // A/B switch
     static const bool fuse_env = (dgp_env("DGP_FUSE_SHORTCUT", 1) != 0);      // A/B switch
     static const bool f32_mode = getenv("DGP_CONV_MODE") && !strcmp(getenv("DGP_CONV_MODE"), "f32");
-    static const bool cells_env = (dgp_env("DGP_PRESPLIT_WEIGHTS", 1) != 0);
+    static const bool cells_env = (dgp_tune("DGP_PRESPLIT_WEIGHTS", 1) != 0);
     const bool h2 = h2_env && cells_env && f16_mode && head_pw && net->wmax_valid && net->d_exps && net->layers[net->head_part].d_wh3_pw &&
                     (net->head_locref < 0 || net->layers[net->head_locref].d_wh3_pw) && net->act_exp.size() == net->layers.size();
     if (tier) {            // the 16-bit tier has no fallback: say what is missing instead of silently running another tier
@@ -900,7 +900,7 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     };
     // ---- root block.  H2 engine: ONE kernel from the uint8 frame to the pool output's cells (stem_pool_fused_kernel);
     // otherwise preprocess -> conv1 -> max-pool as three launches
-    static const bool stem_fused_env = (dgp_env("DGP_STEM_FUSED", 1) != 0);
+    static const bool stem_fused_env = (dgp_tune("DGP_STEM_FUSED", 1) != 0);
     const ConvLayer& lstem = net->layers[net->conv1];
     const bool stem_fused = h2 && (stem_fused_env || tier) && lstem.d_wh3 && lstem.d_w_rows && lstem.CoutP == 64 && lstem.d_scale && lstem.d_bias;
     if (tier && !stem_fused) return fail(DGP_ERR_STATE, "dgp_forward: the 16-bit tier needs the fused root block");
@@ -943,7 +943,7 @@ int dgp_forward(dgp_net* net, const uint8_t* frames, int32_t batch, void* worksp
     static const bool chain_h1_env = (dgp_env("DGP_CHAIN_H1", 1) != 0);      // the chain / unit kernels on H1 tensors (the 16-bit tier)
     const bool chain_tier = chain_env && (!tier || chain_h1_env);
     const bool chain_on = h2 && !calib && chain_tier && net->chains.size() == net->units.size();
-    static const bool unit_env = (dgp_env("DGP_UNIT", 1) != 0);      // conv2 inside the chain launch (block1)
+    static const bool unit_env = (dgp_tune("DGP_UNIT", 1) != 0);      // conv2 inside the chain launch (block1)
     bool r1_ready = false;                            // R1 of this unit came out of the previous unit's chain launch
     float *Ra = R1, *Rb = R2;
     int cur = 0, h = net->hp, w = net->wp;

@@ -2031,7 +2031,7 @@ struct TPlan {
 };
 
 // A/B switch (DGP_WGRAD_DMA=0: no copies, wgrad_h3p as before)
-static const bool g_wgrad_dma = (dgp_env("DGP_WGRAD_DMA", 1) != 0);
+static const bool g_wgrad_dma = (dgp_tune("DGP_WGRAD_DMA", 1) != 0);
 
 size_t al(size_t x) { return (x + 255) / 256 * 256; }
 // channels of the merged heads tensor: both heads' padded phase columns, rounded up to the H1 kernels' K-step
@@ -2570,7 +2570,7 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
     static const bool merged_env = (dgp_tune("DGP_PACK_MERGED", 1) != 0);
     const bool merged = merged_env;
     // tier 1, every sync after the first: the parity-only panels wait for a plain pass (A/B switch DGP_TRAIN_LAZY_PARITY=0)
-    static const bool lazy_env = (dgp_env("DGP_TRAIN_LAZY_PARITY", 1) != 0);
+    static const bool lazy_env = (dgp_tune("DGP_TRAIN_LAZY_PARITY", 1) != 0);
     const bool lazy = lazy_env && merged && g_train_cells && tr->tier == 1 && tr->d_h3_table && tr->d_h1_table && tr->d_wrng;
     tr->parity_stale = lazy;
     for (size_t li = 0; li < net->layers.size(); ++li) {
@@ -2725,7 +2725,7 @@ int dgp_trainer_sync_weights(dgp_trainer* tr, void* stream) {
                     }
                 }
                 // the fused root block's weight cells (stem_pool_fused_kernel): row panel of conv1 from the panel pack_all_kernel just wrote
-                static const bool stem_fused_env = (dgp_env("DGP_TRAIN_STEM_FUSED", 1) != 0);      // A/B switch
+                static const bool stem_fused_env = (dgp_tune("DGP_TRAIN_STEM_FUSED", 1) != 0);      // A/B switch
                 ConvLayer& lc = net->layers[net->conv1];
                 if (stem_fused_env && lc.CoutP == 64 && lc.Cin == 4 && lc.KH == 7 && lc.KW == 7) {
                     const size_t nrow = (size_t)56 * lc.CoutP * 4;
@@ -2795,8 +2795,8 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     // second stream.  At 11 frames the grids of block3 / block4 cover half of the chip, and two independent chains drift apart so that
     // one chain's small or tail-heavy layers run under the other's.  Both chains write frame ranges of the SAME activation tensors
     // (the backward pass sees one batch) and max into the same range slots.
-    static const bool side_env = (dgp_env("DGP_WGRAD_OVERLAP", 1) != 0);
-    static const int chains_env = dgp_env("DGP_FWD_CHAINS", 2);
+    static const bool side_env = (dgp_tune("DGP_WGRAD_OVERLAP", 1) != 0);
+    static const int chains_env = dgp_tune("DGP_FWD_CHAINS", 2);
     if (side_env && !g_ctx->s2) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -2954,7 +2954,7 @@ int dgp_train_forward(dgp_trainer* tr, const uint8_t* frames, int32_t nt, void* 
     }
     // heads: pointwise GEMM on the cell kernels + gather of the four taps (as the inference engine) when the feature map's range
     // and the pointwise cells exist, else the 2x2-conv form on the fp32 kernel
-    static const bool head_pw = (dgp_env("DGP_HEAD_PW", 1) != 0);
+    static const bool head_pw = (dgp_tune("DGP_HEAD_PW", 1) != 0);
     auto head_forward = [&](const ConvLayer& hd, int li, int njt, float* out) -> hipError_t {
         const float* rin = range_of(xin);
         const float* rw = tr->d_wrng ? tr->d_wrng + (size_t)li * ABSMAX_SLOTS : nullptr;
@@ -3094,7 +3094,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
     g_ctx->defer_ws = ws;
     if (defer_env) TRY_HIP(hipMemsetAsync(ws + pl.dwall, 0, pl.dwall_bytes, s));
     // weight gradients on their own stream beside the data-gradient chain (DGP_WGRAD_OVERLAP=0: one stream, A/B)
-    static const bool overlap_env = (dgp_env("DGP_WGRAD_OVERLAP", 1) != 0);
+    static const bool overlap_env = (dgp_tune("DGP_WGRAD_OVERLAP", 1) != 0);
     TrainCtx* const ctx = g_ctx;
     if (defer_env && overlap_env) {
         if (!ctx->s2) {
@@ -3277,7 +3277,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
 #endif
     // 16-bit tier with the fused root block: the stem's weight gradient reads d pool as the H1 tensor unit 0 leaves (stem_wgrad_h1_kernel:
     // pool backward fused, no d conv1 map); A/B switch DGP_TRAIN_STEM_WGRAD_H1=0
-    static const bool stem_wgrad_env = (dgp_env("DGP_TRAIN_STEM_WGRAD_H1", 1) != 0);
+    static const bool stem_wgrad_env = (dgp_tune("DGP_TRAIN_STEM_WGRAD_H1", 1) != 0);
     const bool stem_wgrad_h1 = stem_wgrad_env && h1p && ub == 0 && tr->fwd_stem_fused && pool_idx_on() && g_ctx->defer_plan &&
                                net->layers[net->conv1].Cout == 64 && net->layers[net->conv1].KH == 7 && net->layers[net->conv1].Cin == 4;
     const float* stem_g = nullptr;
@@ -3476,7 +3476,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
                            fin_tab + first, (const char*)ws, tr->params, tr->grads, rpb);
     };
     // ---- root block: max-pool backward (+ stem ReLU gate), stem weight gradient
-    static const bool fin_split_env = (dgp_env("DGP_FIN_SPLIT", 1) != 0);       // A/B switch
+    static const bool fin_split_env = (dgp_tune("DGP_FIN_SPLIT", 1) != 0);       // A/B switch
     const bool fin_split = fin_split_env && g_ctx->defer_plan && ctx->overlap && tr->n_fin > 1;
     {
         int pth = (net->hp - 1) * 2 + 3 - net->h1; if (pth < 0) pth = 0;

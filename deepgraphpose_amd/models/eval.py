@@ -192,6 +192,11 @@ def clear_session_cache():
 RUN_STATS = {"chunks": 0, "chunk_reruns": 0, "strict_passes": 0, "stage_s": 0.0, "wait_frames_s": 0.0, "wait_h2d_s": 0.0, "drain_s": 0.0,
              "setup_s": 0.0, "alloc_s": 0.0, "calibrate_s": 0.0, "finish_s": 0.0}
 
+# The host pipeline's geometry (measured settings, not run-time switches; tests patch the module attributes): engines / HIP streams the
+# batches are dealt to, pinned staging slots, host threads staging an in-memory stack, copy streams the uploads alternate on, bytes of
+# frames a chunk keeps resident for a re-run after a range overflow.
+EVAL_STREAMS, PINNED_SLOTS, STAGE_THREADS, COPY_STREAMS, CHUNK_BYTES = 2, 8, 2, 2, 1 << 30
+
 # pinned staging ring, kept between calls (pinning host memory costs ~ 10 ms per 30-MB buffer; a project's videos share one frame size)
 _PINNED = {"key": None, "bufs": []}
 
@@ -298,23 +303,23 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
             raise ValueError("no frames in %s" % video_file)
         f0 = prep(first)
         hh, ww = f0.shape[:2]
-        # two engines on two HIP streams, batches dealt in turn (engine.DGPPipeline; DGP_EVAL_STREAMS=1: one engine, A/B)
+        # two engines on two HIP streams, batches dealt in turn (engine.DGPPipeline)
         t_ = time.perf_counter()
-        net = net_used = sess.pipe_for(hh, ww, n_streams=max(1, int(os.environ.get("DGP_EVAL_STREAMS", "2"))))
+        net = net_used = sess.pipe_for(hh, ww, n_streams=EVAL_STREAMS)
         torch.cuda.synchronize(dev)
         RUN_STATS["setup_s"] += time.perf_counter() - t_      # the engines of this frame size: weights re-packed and uploaded (first call of a size)
         t_ = time.perf_counter()
-        nslots = max(3, int(os.environ.get("DGP_EVAL_PINNED_SLOTS", "8")))      # pinned staging ring: batches being staged / copied + slack for bursts
+        nslots = PINNED_SLOTS                     # pinned staging ring: batches being staged / copied + slack for bursts
         pinned = _pinned_ring(nslots, (batch_size, hh, ww, 3))
         # The frames of a CHUNK of batches stay on the device until the chunk's range check has come back clean: a chunk whose
         # activations outgrew the calibrated H2 scales is re-run from HBM, without decoding anything again (DGP_EVAL_CHUNK_BATCHES,
         # default 64 batches, capped at 4 GB of frames)
-        # -- never more batches than the shard holds, and at most DGP_EVAL_CHUNK_BYTES (default 1 GiB) of frames: 34 batches of 32 at
+        # -- never more batches than the shard holds, and at most CHUNK_BYTES (1 GiB) of frames: 34 batches of 32 at
         # 640 x 480, 24 batches of 16 at 1280 x 720, next to the engines' workspaces.  Every term is the same on every rank (the chunk
         # rounds below are collective), so nothing here may depend on a rank's free memory.
         batch_bytes = batch_size * hh * ww * 3
         per_rank_batches = max(1, -(-(-(-n_frames // world)) // batch_size))
-        chunk_cap = int(float(os.environ.get("DGP_EVAL_CHUNK_BYTES", str(1 << 30))) // max(batch_bytes, 1)) or 1
+        chunk_cap = int(CHUNK_BYTES // max(batch_bytes, 1)) or 1
         chunk_batches = max(1, min(int(os.environ.get("DGP_EVAL_CHUNK_BATCHES", "64")), chunk_cap, per_rank_batches))
         dchunk = torch.empty((chunk_batches, batch_size, hh, ww, 3), dtype=torch.uint8, device=dev)
         RUN_STATS["alloc_s"] += time.perf_counter() - t_        # pinned ring (kept between calls) + the chunk's device buffer
@@ -340,7 +345,7 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
         cv = threading.Condition()
         st = {"staged": {}, "n_freed": 0, "total": None, "err": None, "free": list(range(nslots))}
         whole_batches = new_size is None and crop_size is None and hasattr(video_clip, "iter_batches") and hasattr(video_clip, "frames")
-        n_stage = max(1, int(os.environ.get("DGP_EVAL_STAGE_THREADS", "2"))) if whole_batches else 1
+        n_stage = STAGE_THREADS if whole_batches else 1
 
         def take_slot(k):
             with cv:
@@ -404,7 +409,7 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
             threads = [threading.Thread(target=stage_decoded, daemon=True)]
         for th in threads:
             th.start()
-        copy_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, int(os.environ.get("DGP_EVAL_COPY_STREAMS", "2"))))]
+        copy_streams = [torch.cuda.Stream(device=dev) for _ in range(COPY_STREAMS)]
         compute = torch.cuda.current_stream(dev)
         traj = torch.zeros((max(n_local, 1), nj, 5), dtype=torch.float32, device=dev)      # packed (row, col, likelihood, iy, ix)
         pending = []                              # (H2D-complete event, pinned slot): slots go back to the ring without the host waiting for every copy

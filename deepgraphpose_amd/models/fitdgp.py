@@ -30,6 +30,8 @@ from ..dataset import MultiDataset, coord2map
 from ..loss import DGPHyper
 from .fitdgp_util import gen_batch
 
+PREFETCH_DEPTH = 2          # iterations of host batches built ahead on a background thread (0: inline); a measured setting, not a switch
+
 _VIDEO_EXT = ("avi", "mp4", "mov", "mkv")
 
 
@@ -260,11 +262,11 @@ def _dp_setup():
 def _prefetched(make_item, n_items: int, depth=None):
     """make_item(0), make_item(1), ... in order, built by ONE background thread up to `depth` items ahead of the consumer: the host
     work of iteration it + 1 (frame reads, augmentation, target maps) runs while the GPU trains on iteration it.  A single producer
-    keeps the order of every random draw, so a run is the same with or without prefetching (DGP_FIT_PREFETCH=0: inline)."""
+    keeps the order of every random draw, so a run is the same with or without prefetching (PREFETCH_DEPTH = 0: inline)."""
     import queue
     import threading
     if depth is None:
-        depth = int(os.environ.get("DGP_FIT_PREFETCH", "2"))
+        depth = PREFETCH_DEPTH
     if depth <= 0 or n_items <= 1:
         for i in range(n_items):
             yield make_item(i)
@@ -479,7 +481,7 @@ def fit_dgp_labeledonly(snapshot, dlcpath, shuffle=1, step=1, saveiters=1000, di
     train_op = loss.graph.minimize(total_loss_visible, learning_rate)          # fitdgp.py:412-418
     sess = TrainSession(trainer, loss.graph)
     saver = weights_io.Saver(max_to_keep=dgp_cfg.max_to_keep)     # fitdgp.py:401, 696
-    uploader = _FrameUploader(trainer.device) if int(os.environ.get("DGP_FIT_PREFETCH", "2")) > 0 else None
+    uploader = _FrameUploader(trainer.device) if PREFETCH_DEPTH > 0 else None
     nepoch = int(np.min([int(data_batcher.n_visible_frames_total * dgp_cfg.n_times_all_frames), maxiters]))
     table = np.array([(i, vv) for i, v in enumerate(visible_frame_total) for vv in v]).reshape(-1, 2)
     batch_ind_all = np.random.randint(0, table.shape[0], size=nepoch)
@@ -552,7 +554,7 @@ def fit_dgp(snapshot, dlcpath, batch_size=10, shuffle=1, step=2, saveiters=1000,
     train_op = loss.graph.minimize(total_loss, learning_rate)                  # fitdgp.py:708-713
     sess = TrainSession(trainer, loss.graph)
     saver = weights_io.Saver(max_to_keep=dgp_cfg.max_to_keep)     # fitdgp.py:401, 696
-    uploader = _FrameUploader(trainer.device) if int(os.environ.get("DGP_FIT_PREFETCH", "2")) > 0 else None
+    uploader = _FrameUploader(trainer.device) if PREFETCH_DEPTH > 0 else None
     batch_ind_all = gen_batch(visible_frame_total, hidden_frame_total, all_frame_total, dgp_cfg, maxiters)
     save_iters = max(int(saveiters / dgp_cfg.batch_size), 1)
     n_sched = len(batch_ind_all)

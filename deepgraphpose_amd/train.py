@@ -136,7 +136,7 @@ class Trainer:
         #  operand traffic, and the fast pass measured 12.95-13.09 against 13.01-13.16 ms per step -- EXPERIMENTS.md section 6a')
         fast = getattr(self, "_fast_key", None) == key and (
             self.tier == "f16" or                                # the 16-bit tier: every pass after the first of a shape
-            (os.environ.get("DGP_TRAIN_H2", "0") == "1" and bool(self.lib.dgp_tuning_build())))      # (H2 fast pass: an opt-in of -DDGP_TUNING builds)
+            (bool(self.lib.dgp_tuning_build()) and os.environ.get("DGP_TRAIN_H2", "0") == "1"))      # (H2 fast pass: an opt-in of -DDGP_TUNING builds, the only ones that read the variable)
         _lib.check(self.lib.dgp_trainer_fast_mode(self._t, 1 if fast else 0), "dgp_trainer_fast_mode")
         return fast                                  # (a REQUEST: fast_passes counts what the device reports it ran -- _fast_end / step)
 
@@ -279,8 +279,6 @@ class Trainer:
             if fast and was.value:
                 self.fast_passes += 1                # counted from the pass status the DEVICE wrote, not from the request
             if fast and failed.value:                # the momentum kernel saw the flag and left parameters and momentum alone
-                if os.environ.get("DGP_DEBUG_FAST"):
-                    print("fast pass failed: flag 0x%x" % failed.value, file=sys.stderr)
                 self._fast_key = None
                 self.fast_redos += 1
                 continue

@@ -414,3 +414,55 @@ def test_dgrad_rejects_an_h2_gate_on_fewer_than_64_channels(lib_built):
     dx = engine.conv2d_dgrad(dy, w, (7, 9), mask=mask, ranged=True, mask_h2=False)
     ref = torch.where(mask > 0, _dgrad_ref(dy.double(), w.double(), 7, 9, 1, 1, 0, 0), torch.zeros((2, 7, 9, 32), dtype=torch.float64, device="cuda"))
     assert float((dx.double() - ref).abs().max() / ref.abs().max()) < REL_TOL
+
+
+@pytest.mark.parametrize("depth,nj", [(50, 4), (101, 20)])
+def test_full_size_config4_step_on_the_16_bit_tier(lib_built, depth, nj):
+    """BASELINE configs[3] at FULL size on the tier it names (16-bit): 640 x 480, 11 frames (1 labeled + 10 unlabeled), gm2 = 1, gm3 = 3 --
+    ResNet-50 with 4 keypoints on a chain skeleton, and ResNet-101 with 20 keypoints (configs[4]'s network) -- against the autograd oracle
+    evaluated on the host cores at run time (fp32: its own distance from float64 is ~1e-3 of the 16-bit tier's band).  The SAME bounds as
+    the small-shape gradient tests of tests/test_train_gpu.py: loss within 2e-3 relative, global gradient cosine >= 0.999, relative L2
+    error <= 5 %, every tensor's cosine >= 0.98 -- at the real grid sizes (104-208-tile H1 launches, 384-workgroup weight-gradient
+    grids, the fused stem kernels on 120 x 160 maps).  Pass 1 is the shape's parity pass and meets the parity bounds."""
+    import ctypes
+    from test_train_gpu import _make_loss_case, _oracle_grads, _grad_agreement
+    from deepgraphpose_amd.synthetic import make_weights, make_frames
+    from deepgraphpose_amd.train import Trainer
+    from deepgraphpose_amd.loss import DGPHyper
+    torch.set_num_threads(min(32, torch.get_num_threads() * 2 if torch.get_num_threads() < 16 else 32))
+    nt, hw = 11, (480, 640)
+    nl = 3 if nj == 4 else 19
+    rng = np.random.default_rng(44 + depth)
+    batch, _ = _make_loss_case(rng, nt, 60, 80, nj, 1, 0.0, 2)
+    S0 = np.zeros((nl, nj))
+    for l in range(nl):
+        S0[l, l], S0[l, l + 1] = 1, -1
+    wts = make_weights(depth, nj, True, seed=4, head_std=0.05)
+    frames = make_frames(nt, hw[0], hw[1], nj, seed=4)
+    ws, ws_max = rng.uniform(5, 20, nl), rng.uniform(10, 40, nl)
+    hy = DGPHyper(gm2=1, gm3=3)
+    n_tot, n_vis = 1000.0, 50.0
+    tr = Trainer(depth, nj, hw[0], hw[1], max_frames=nt, tier="f16")
+    tr.load_weights(wts)
+    ft = torch.from_numpy(frames).cuda()
+    was, failed = ctypes.c_int32(), ctypes.c_int32()
+    l0 = tr.forward_backward(ft, batch, hy, S0, ws, ws_max, n_tot, n_vis)            # first pass of the shape: parity path
+    tr.lib.dgp_trainer_fast_status(tr._t, was, failed)
+    assert was.value == 0
+    g0 = tr.get_grads()
+    l1 = tr.forward_backward(ft, batch, hy, S0, ws, ws_max, n_tot, n_vis)            # the 16-bit pass
+    tr.lib.dgp_trainer_fast_status(tr._t, was, failed)
+    assert was.value == 1 and failed.value == 0 and tr.fast_passes == 1 and tr.fast_redos == 0
+    g1 = tr.get_grads()
+    P, L = _oracle_grads(wts, frames, batch, S0, ws, ws_max, hy, n_tot, n_vis, depth=depth, dtype=torch.float32)
+    ref_loss = float(L["total_loss"].detach())
+    cos0, rel0, _ = _grad_agreement(g0, P)
+    cos1, rel1, per = _grad_agreement(g1, P)
+    worst = sorted(per.items(), key=lambda kv: kv[1][0])[:3]
+    print("full size, ResNet-%d nj %d: loss parity %.6f / f16 %.6f (oracle %.6f) | parity pass cosine %.6f rel %.2e | 16-bit pass cosine %.6f rel %.4f | worst %s"
+          % (depth, nj, l0["total_loss"], l1["total_loss"], ref_loss, cos0, rel0, cos1, rel1, worst))
+    assert abs(l0["total_loss"] - ref_loss) < 2e-4 * max(1, abs(ref_loss)) and cos0 > 0.99999 and rel0 < 3e-3
+    assert abs(l1["total_loss"] - ref_loss) < 2e-3 * max(1, abs(ref_loss))
+    assert cos1 >= 0.999 and rel1 <= 0.05
+    assert min(v[0] for v in per.values()) >= 0.98, worst
+    assert all(np.isfinite(v).all() for v in g1.values())

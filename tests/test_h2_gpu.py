@@ -266,18 +266,6 @@ def test_per_tap_loaders_of_the_3x3_layers_in_a_child_process(lib_built):
     assert r.returncode == 0 and "5 passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
 
 
-def test_tall_tile_on_every_shape_it_can_take_in_a_child_process(lib_built, tuning_build):
-    """The 256 x 128 tile (eight compute waves on one B stage) is an opt-in (DGP_TALL=1: deep-K layers with >= 512 tiles); DGP_TALL=2 forces it
-    wherever the kernel applies: pointwise and 3x3 loaders, dilation, stride 2, H2 / fp32 / strided residuals, ragged last row tile."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DGP_TALL="2", PYTHONPATH=root)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_h2_gpu.py"), "-q", "-m", "gpu", "-k",
-                        "test_conv_on_h2_tensors_matches_float64 and (case0 or case4 or case5 or case6 or case7 or case9 or case10)"],
-                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "7 passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
-
-
 def test_extreme_frames_keep_parity(lib_built):
     """Frames far from the synthetic blobs the other tests use -- all black, all white, uniform noise, one saturated channel -- through
     the H2 engine (calibration on this very batch): finite outputs, no range overflow, coordinates within 1e-3 px of the oracle and
