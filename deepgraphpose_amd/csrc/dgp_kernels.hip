@@ -1082,7 +1082,8 @@ __device__ __forceinline__ void ls_epilogue_h2(const ConvArgs& p, floatx16 (&acc
 //   not operand-bound any more, it is bound by its ONE compute wave per SIMD.  scripts/micro/mfma_w64.hip / mfma_w64b.hip rebuild the
 //   loop piece by piece: MFMA stream 1 053 cycles per step, + weight-fragment reads 1 088, + A-cell reads and the ra -> ah / al copies
 //   1 220, + one workgroup barrier per step 1 375 -- every stall two co-resident 128-row workgroups hide from each other is exposed --
-//   and prologue + epilogue (12-18 k cycles per tile) have nothing to run under.  Opt-in only (DGP_H1_W64).
+//   and prologue + epilogue (12-18 k cycles per tile) have nothing to run under.  Instantiated for the parity tier's H2 cells too (three
+//   MFMAs per product: 96 per K-step, so the fixed per-step cost weighs a third as much): still +8..+34 % slower per layer.  Opt-in only (DGP_W64).
 //   MODE 3 (round 4; H2 DMA kernels, 3x3 / stride 1 / any dilation: the "halo walk").  With MODE 1 the A rows of a 3x3 conv cross the
 //   L2 -> LDS path NINE times, once per tap (16 KB per K-step and workgroup, as much as the weight cells).  On a stride-1 conv the tap
 //   (kh, kw) of output pixel m reads input pixel m + d ((kh - 1) W + (kw - 1)) of the FLATTENED [N H W] pixel list -- a constant
@@ -1115,7 +1116,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : BM == 256 ? 2 : ((BK =
     static_assert(MODE != 3 || (DMA && AH2 && OH2 && BM == 128 && BN == 128 && CW == 4 && !DEEP), "halo walk: H2 / H1 tensors, LDS-DMA, 128 x 128 tiles");
     static_assert(!DEEP || (DMA && BN == 128 && BM == 128), "deep ring: LDS-DMA kernels with 128 x 128 tiles");
     static_assert(!H1 || (AH2 && DMA && !DEEP), "16-bit tier: cell input, LDS-DMA kernels");
-    static_assert(BM == 128 || (BM == 256 && H1 && CW == 4 && BN == 128 && MODE != 3), "256-row tile: the 16-bit tier's 64 x 128 wave tiles");
+    static_assert(BM == 128 || (BM == 256 && AH2 && OH2 && DMA && CW == 4 && BN == 128 && MODE != 3), "256-row tile: cell tensors, 64 x 128 wave tiles");
     static_assert(!AH2 || CS, "pre-split A operand: compute-side-split kernels only");
     static_assert(!OH2 || AH2, "H2 output: kernels with H2 input only (the stem writes fp32, the pool converts)");
     // compute waves: 2 x (CW / 2) over the tile; with the compute-side split 4 x 1 (each wave owns 32 rows and ALL columns, so no
@@ -1687,8 +1688,8 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : BM == 256 ? 2 : ((BK =
 #endif
     // 16x16x32 MFMAs in the pipelined loop of the 32 x 128 wave tile: the same FLOPs, LDS bytes and register reads as the 32x32x16
     // shape in twice as many, half as long matrix instructions -- +5.3 % end to end (block4 3x3: 0.499 -> 0.453 ms)
-    constexpr bool M16 = CS && (TM == 1 || (TM == 2 && H1)) && (TN == 4 || (TN == 2 && DMA)) && NT == 2 && BK == 32;      // (32 x 64 wave tiles: DMA images only)
-    static_assert(!DMA || ((TM == 1 || (TM == 2 && H1)) && (TN == 4 || TN == 2)), "DMA image is read by the pipelined loops only");
+    constexpr bool M16 = CS && (TM == 1 || (TM == 2 && AH2 && DMA)) && (TN == 4 || (TN == 2 && DMA)) && NT == 2 && BK == 32;      // (32 x 64 wave tiles: DMA images only)
+    static_assert(!DMA || ((TM == 1 || (TM == 2 && AH2)) && (TN == 4 || TN == 2)), "DMA image is read by the pipelined loops only");
     static_assert(!(DMA && AH2) || M16, "pre-split A + DMA image: 16x16x32 loop only");
     if constexpr (MODE == 3) {
         // The 16x16x32 loop of the branch below on the pixel ring: same fragment ring, same barrier placement; the A cells of the NEXT
@@ -1817,12 +1818,15 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : BM == 256 ? 2 : ((BK =
 #else
 #define DGP_RB(F) do { bq[(F) & 7] = B[((((F) & 1) ? 0 : 1) * KG) * LDB + 16 * (((F) % NF) >> 1)]; } while (0)
 #endif
-        // (fragment F even = plane 1 = the odd k-groups' weights x the odd chunks `al`; F odd = plane 0 x the even chunks `ah`)
+        // H1: fragment F even = plane 1 = the odd k-groups' weights x the odd chunks `al`; F odd = plane 0 x the even chunks `ah`.
+        // H2 (parity tier): chunk 2 g = the HIGH cell `ah` of k-group g, chunk 2 g + 1 its LOW cell `al`; F even = the low weight plane x ah,
+        // F odd = the high plane x al, then x ah -- per accumulator the same order as the 32 x 128 loop (a_hi b_lo, a_lo b_hi, a_hi b_hi).
+#define DGP_MM4(X, F, J) do { c[0][J] = mma(X[0], bq[(F) & 7], c[0][J]); c[1][J] = mma(X[1], bq[(F) & 7], c[1][J]);                     \
+                              c[2][J] = mma(X[2], bq[(F) & 7], c[2][J]); c[3][J] = mma(X[3], bq[(F) & 7], c[3][J]); } while (0)
 #define DGP_MM(F) do { constexpr int j_ = (F) >> 1;                                                                 \
-        if (((F) & 1) == 0) { c[0][j_] = mma(al[0], bq[(F) & 7], c[0][j_]); c[1][j_] = mma(al[1], bq[(F) & 7], c[1][j_]);       \
-                              c[2][j_] = mma(al[2], bq[(F) & 7], c[2][j_]); c[3][j_] = mma(al[3], bq[(F) & 7], c[3][j_]); }     \
-        else { c[0][j_] = mma(ah[0], bq[(F) & 7], c[0][j_]); c[1][j_] = mma(ah[1], bq[(F) & 7], c[1][j_]);                      \
-               c[2][j_] = mma(ah[2], bq[(F) & 7], c[2][j_]); c[3][j_] = mma(ah[3], bq[(F) & 7], c[3][j_]); } } while (0)
+        if constexpr (H1) { if (((F) & 1) == 0) DGP_MM4(al, F, j_); else DGP_MM4(ah, F, j_); }                      \
+        else if (((F) & 1) == 0) DGP_MM4(ah, F, j_);                                                                \
+        else { DGP_MM4(al, F, j_); DGP_MM4(ah, F, j_); } } while (0)
 #define DGP_STEP(F) do { DGP_MM(F); DGP_FENCE(); DGP_RB((F) + 8); DGP_FENCE(); } while (0)
 #define DGP_TAIL(F) do { DGP_MM(F); DGP_FENCE(); if (more) DGP_RB((F) - 8); DGP_FENCE(); } while (0)
         DGP_RA(0); DGP_RA(1); DGP_RA(2); DGP_RA(3);
@@ -1855,6 +1859,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : BM == 256 ? 2 : ((BK =
 #undef DGP_RA
 #undef DGP_RB
 #undef DGP_MM
+#undef DGP_MM4
 #undef DGP_STEP
 #undef DGP_TAIL
         {      // stage the wave's 64 x 128 tile (its own LDS slice: the ring is dead behind the last barrier)
@@ -2587,26 +2592,30 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// The 256 x 128 tile of the 16-bit tier (see conv_igemm_split_ls, "BM = 256"): H1 -> H1 convolutions, pointwise (incl. the K-concatenated
-// shortcut) or plain taps.  `a` holds REAL channels here (before to_h1_units): conv_kernel_name and launch_conv ask the same question.
-// DGP_H1_W64: 0 (default) never -- it measured SLOWER than the 128 x 128 tile on every layer of the bench workload (one stream: block4
-// +6..+11 % on the 3x3 layers, +6..+26 % on the pointwise ones, block3 +14..+28 %; two streams: +-1 %; EXPERIMENTS.md R6 (1) has the
-// stamps and the micro-benchmarks that say why); 1: deep-K layers with enough tiles; 2: wherever the kernel can run (the layer tests).
+// The 256 x 128 tile (see conv_igemm_split_ls, "BM = 256"): cell -> cell convolutions of either tier (H1 -> H1, H2 -> H2), pointwise (incl. the
+// K-concatenated shortcut) or plain taps.  `a` holds REAL channels here (before to_h1_units): conv_kernel_name and launch_conv ask the same
+// question.  DGP_W64: 0 (default) never -- it measured SLOWER than the 128 x 128 tile on every layer of the bench workload in BOTH tiers
+// (one stream, profiles/r6_w64_ab_layers.txt / r6_w64_h2_ab_layers.txt: 16-bit tier block4 +6..+26 %, block3 +14..+28 %; parity tier
+// block4 +8..+19 %, block3 +12..+34 %; EXPERIMENTS.md R6 (1) has the stamps and the micro-benchmarks that say why); any other value:
+// wherever the kernel can run (the layer tests, the bit-identity tests of both tiers).
+static int w64_env() { static const int v = dgp_env("DGP_W64", 0); return v; }
 static bool conv_w64_eligible(const ConvArgs& a) {
-    static const int w64_env = dgp_env("DGP_H1_W64", 0);
-    static const int min_k = dgp_tune("DGP_H1_W64_MINK", 1024);       // real K = taps x channels from which the longer K-steps pay
-    if (!w64_env || a.in_fmt != 2 || a.out_fmt != 2 || !a.wh3 || a.up || a.stem || a.out_mode != 0 || a.shadow) return false;
-    if (a.CoutP % 128 != 0 || (a.Cout % 8) || (a.Cin & 63) || (a.nk & 1)) return false;
+    const int fmt = a.in_fmt;
+    if (!w64_env() || (fmt != 1 && fmt != 2) || a.out_fmt != fmt || !a.wh3 || a.up || a.stem || a.out_mode != 0 || a.shadow) return false;
+    if (a.res && a.res_fmt != fmt && !(fmt == 1 && a.res_fmt == 0)) return false;
+    if (a.in_scale_dev || a.out_scale_dev || a.res_scale_dev) { if (fmt == 1) return false; }      // (the parity trainer's predicted scales: 128-row kernels)
+    if (a.mask && !(fmt == 2 && a.mask_fmt == 2)) return false;
+    const int cq = fmt == 2 ? 63 : 31;                                 // channels per K-step - 1
+    if (a.CoutP % 128 != 0 || (a.Cout % 8) || (a.Cin & cq) || (fmt == 2 && (a.nk & 1))) return false;
     const bool pointwise = a.ntaps == 1 && a.stride == 1 && a.pad_t == 0 && a.pad_l == 0 && a.H == a.Ho && a.W == a.Wo;
-    if (a.in2 && (!pointwise || (a.cin_split & 63) || ((a.Cin - a.cin_split) & 63))) return false;
+    if (a.in2 && (!pointwise || (a.cin_split & cq) || ((a.Cin - a.cin_split) & cq))) return false;
     if (pointwise && ((unsigned long long)a.M * (a.in2 ? a.cin_split : a.Cin) * 4ull != a.in_bytes ||
                       (a.in2 && (unsigned long long)a.M * (a.Cin - a.cin_split) * 4ull != a.in2_bytes) || a.in_bytes >= 4200000000u)) return false;
-    if (w64_env >= 2) return true;
-    const long long tiles = (long long)((a.M + 255) / 256) * (a.CoutP / 128);
-    return (long long)a.nk * 32 >= min_k && tiles >= 192;
+    if (!pointwise && a.nk * 32 != a.ntaps * a.Cin) return false;      // (plain taps: whole channel chunks per tap)
+    return true;
 }
 
-static hipError_t launch_conv_w64(ConvArgs a, hipStream_t s) {       // (`a` already in H1 units)
+static hipError_t launch_conv_w64(ConvArgs a, hipStream_t s) {       // (`a` already in H1 units where the tensors are H1)
     constexpr int BM = 256, BN = 128, NT = 2, BK = 32, CW = 4, NP = 2, KG = 4;
     static const int tap_minor = dgp_tune("DGP_TAP_MINOR", 1);
     a.tap_minor = (tap_minor && a.ntaps > 1 && a.nk * 32 == a.ntaps * a.Cin) ? 1 : 0;
@@ -2618,13 +2627,16 @@ static hipError_t launch_conv_w64(ConvArgs a, hipStream_t s) {       // (`a` alr
     a.tail_ksplit = 0; a.st_gn = 0;
     const bool pointwise = a.ntaps == 1 && a.stride == 1 && a.pad_t == 0 && a.pad_l == 0 && a.H == a.Ho && a.W == a.Wo;
     const int mode = pointwise ? 2 : 1;
-    auto kern = mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, true, 2, true, true, true, true, false, true>
-                          : conv_igemm_split_ls<BM, BN, NT, BK, CW, true, 1, true, true, true, true, false, true>;
+    const bool h1 = a.in_fmt == 2;
+    auto kern = h1 ? (mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, true, 2, true, true, true, true, false, true>
+                                : conv_igemm_split_ls<BM, BN, NT, BK, CW, true, 1, true, true, true, true, false, true>)
+                   : (mode == 2 ? conv_igemm_split_ls<BM, BN, NT, BK, CW, true, 2, true, true, true, true, false, false>
+                                : conv_igemm_split_ls<BM, BN, NT, BK, CW, true, 1, true, true, true, true, false, false>);
     size_t smem = (size_t)(3 * BM * 8 + 2 * NP * KG * BN) * 16;                // 3 A stages + 2 B stages = 128 KB
     const size_t smem_epi = (size_t)CW * 64 * (BN + 4) * 4;                    // 132 KB: the four 64-row wave tiles of the epilogue
     if (smem < smem_epi) smem = smem_epi;
-    static bool attr_dev[16][3] = {};
-    bool& attr = attr_dev[dgp_device_slot()][mode];
+    static bool attr_dev[16][2][3] = {};
+    bool& attr = attr_dev[dgp_device_slot()][h1 ? 1 : 0][mode];
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -2757,7 +2769,8 @@ const char* conv_kernel_name(const ConvArgs& a, int tile_cfg) {
             case TILE_128x128_S6K16W8: return "split6_128x128_k16w8";
             case TILE_128x128_H3K16:   return "splith3_128x128_k16";
             case TILE_128x128_H3K16W8: return "splith3_128x128_k16w8";
-            case TILE_128x128_H3K32:   return a.in_fmt == 2 ? (conv_w64_eligible(a) ? "h1_256x128_k64" : "h1_128x128_k64") : "splith3_128x128_k32";
+            case TILE_128x128_H3K32:   return a.in_fmt == 2 ? (conv_w64_eligible(a) ? "h1_256x128_k64" : "h1_128x128_k64")
+                                              : (conv_w64_eligible(a) ? "splith3_256x128_k32" : "splith3_128x128_k32");
             case TILE_128x64_H3:       return a.in_fmt == 2 ? "h1_128x64_k64" : "splith3_128x64_k32";
             case TILE_128x128_S6:    return "split6_128x128_k32";
             case TILE_128x64_S6:     return "split6_128x64_k32";

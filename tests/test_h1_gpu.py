@@ -353,13 +353,13 @@ def test_tier_f16_network_is_the_same_with_and_without_its_chain_kernels(lib_bui
 
 
 def test_conv_cases_on_the_256_row_tile(lib_built):
-    """Round 6: the 256 x 128 tile (four compute waves of 64 x 128).  DGP_H1_W64 is read once per process, so the layer cases above run
-    again in a child process with DGP_H1_W64=2, which routes every H1 -> H1 convolution the tile can take to it (pointwise, strided,
+    """Round 6: the 256 x 128 tile (four compute waves of 64 x 128).  DGP_W64 is read once per process, so the layer cases above run
+    again in a child process with DGP_W64=2, which routes every H1 -> H1 convolution the tile can take to it (pointwise, strided,
     dilated, with same-grid and subsampled residuals, ragged last tiles)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k",
-                        "conv_on_h1_tensors_matches_float64"], env=dict(os.environ, DGP_H1_W64="2", PYTHONPATH=root), cwd=root,
+                        "conv_on_h1_tensors_matches_float64"], env=dict(os.environ, DGP_W64="2", PYTHONPATH=root), cwd=root,
                        capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
 
@@ -379,12 +379,12 @@ def test_tier_f16_network_is_bit_identical_on_the_256_row_tile(lib_built, tmp_pa
             "mu, conf, idx = net.infer(fr, 1.0, 1)\n"
             "net.profile_begin(1); net.infer(fr, 1.0, 1); torch.cuda.synchronize(); ns, table = net.profile_end()\n"
             "n256 = sum('h1_256x128_k64' in n for n, _, _ in table)\n"
-            "assert (n256 > 0) == (os.environ['DGP_H1_W64'] == '2'), (n256, [n for n, _, _ in table])\n"
+            "assert (n256 > 0) == (os.environ['DGP_W64'] == '2'), (n256, [n for n, _, _ in table])\n"
             "np.savez(sys.argv[1], mu=mu.cpu().numpy(), conf=conf.cpu().numpy(), idx=idx.cpu().numpy())\n")
     out = {}
     for flag in ("0", "2"):
         path = str(tmp_path / ("w%s.npz" % flag))
-        subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, DGP_H1_W64=flag, PYTHONPATH=root), cwd=root)
+        subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, DGP_W64=flag, PYTHONPATH=root), cwd=root)
         out[flag] = np.load(path)
     for k in ("mu", "conf", "idx"):
         assert np.array_equal(out["0"][k], out["2"][k]), k

@@ -435,3 +435,39 @@ def test_h2_residual_with_an_fp32_output_is_rejected(lib_built):
     y, _ = engine.conv2d_h2(xh, xe, w, residual=res, res_stride=1, res_is_h2=False, y_is_h2=False)
     ref = torch.einsum("nhwc,co->nhwo", engine.h2_to_f32(xh, xe).double(), torch.from_numpy(w[0, 0]).double().cuda()) + res.double()
     assert float((y.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
+def test_h2_conv_cases_on_the_256_row_tile(lib_built):
+    """Round 6: the 256 x 128 tile (four compute waves of 64 x 128) on the parity tier's H2 cells.  DGP_W64 is read once per process: the
+    layer cases above run again in a child with DGP_W64=2, which routes every H2 -> H2 convolution the tile can take to it."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k",
+                        "test_conv_on_h2_tensors_matches_float64"], env=dict(os.environ, DGP_W64="2", PYTHONPATH=root), cwd=root,
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+
+
+def test_parity_network_is_bit_identical_on_the_256_row_tile(lib_built, tmp_path):
+    """Same cells, same order of products per accumulator (a_hi b_lo, a_lo b_hi, a_hi b_hi; K-steps in order): the parity tier's outputs do
+    not change by a bit whichever tile a layer runs on -- and the child checks that the 256-row kernel really ran."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, os, numpy as np, torch\n"
+            "from deepgraphpose_amd import engine\n"
+            "from deepgraphpose_amd.synthetic import make_frames, make_weights\n"
+            "net = engine.DGPNet(50, 4, 256, 320, max_batch=4)\n"
+            "net.load_weights(make_weights(50, 4, False, seed=5, head_std=0.05))\n"
+            "fr = torch.from_numpy(make_frames(4, 256, 320, 4, seed=6)).cuda()\n"
+            "mu, conf, idx = net.infer(fr, 1.0, 1)\n"
+            "net.profile_begin(1); net.infer(fr, 1.0, 1); torch.cuda.synchronize(); ns, table = net.profile_end()\n"
+            "n256 = sum('splith3_256x128_k32' in n for n, _, _ in table)\n"
+            "assert (n256 > 0) == (os.environ['DGP_W64'] == '2'), (n256, [n for n, _, _ in table])\n"
+            "np.savez(sys.argv[1], mu=mu.cpu().numpy(), conf=conf.cpu().numpy(), idx=idx.cpu().numpy())\n")
+    out = {}
+    for flag in ("0", "2"):
+        path = str(tmp_path / ("w%s.npz" % flag))
+        subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, DGP_W64=flag, PYTHONPATH=root), cwd=root)
+        out[flag] = np.load(path)
+    for k in ("mu", "conf", "idx"):
+        assert np.array_equal(out["0"][k], out["2"][k]), k
