@@ -100,6 +100,8 @@ SYMBOLS = {
     "dgp_conv2d_wgrad_shadow": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgp_trainer_set_tier": (C.c_int, [_vp, C.c_int32]),
     "dgp_trainer_get_tier": (C.c_int, [_vp]),
+    "dgp_trainer_grad_groups": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "dgp_trainer_grad_group_wait": (C.c_int, [_vp, C.c_int32, _vp]),
     "dgp_trainer_step_status": (C.c_int, [_vp, _vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32),
                                                C.POINTER(C.c_int32), _vp]),
     "dgp_trainer_fast_mode": (C.c_int, [_vp, C.c_int32]),

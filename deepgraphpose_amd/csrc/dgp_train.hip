@@ -1998,8 +1998,17 @@ struct dgp_trainer {
     int n_h3 = 0;
     void* d_fin_table = nullptr;      // FinDesc of every non-head layer (deferred weight-gradient finalisation), per batch size
     int n_fin = 0, fin_B = -1, fin_h = -1, fin_w = -1;
+    // Gradient groups (data-parallel training: the all-reduce of a group starts while the backward pass is still running).  The flat
+    // gradient buffer is laid out in layer order and the pass finishes the layers back to front, so a group is a run of bottleneck
+    // units: group 0 = the heads + the last units, ..., the LAST group = whatever is left + the stem.  Per group: the unit after whose
+    // backward it is complete (-1: the end of the pass), its rows of the finalisation table, its float range in the flat buffer and
+    // the event recorded behind its finalisation.
+    struct GradGroup { int cut_ui = -1, fin_first = 0, fin_count = 0; long long lo = 0, hi = 0; hipEvent_t ev = nullptr; };
+    std::vector<GradGroup> groups;
+    std::vector<int> fin_of_layer;
     ~dgp_trainer() {
         for (void* q : {(void*)d_rng_pool, (void*)d_rng_prev, (void*)d_fast_flag, (void*)d_wrng, d_pack_table, d_fin_table, d_h3_table, d_h1_table, (void*)d_stem_rows, d_stem_cells, (void*)d_hmT, (void*)d_hm_rng, d_hmT_h1}) if (q) (void)hipFree(q);
+        for (auto& g : groups) if (g.ev) (void)hipEventDestroy(g.ev);
         for (auto& t : tl) { if (t.d_wT) (void)hipFree(t.d_wT); if (t.d_wTh3) (void)hipFree(t.d_wTh3); if (t.d_wTh1) (void)hipFree(t.d_wTh1); }
         for (void* p : {(void*)params, (void*)grads, (void*)mom, (void*)stats, (void*)d_sumsq, (void*)d_gnorm})
             if (p) (void)hipFree(p);
@@ -2516,7 +2525,10 @@ int dgp_trainer_tensor_info(const dgp_trainer* tr, int32_t i, char* name, int32_
 /* which: 0 params, 1 grads, 2 momentum, 3 frozen statistics */
 float* dgp_trainer_buffer(dgp_trainer* tr, int32_t which) {
     if (!tr) return nullptr;
-    switch (which) { case 0: return tr->params; case 1: return tr->grads; case 2: return tr->mom; case 3: return tr->stats; }
+    switch (which) {
+        case 0: return tr->params; case 1: return tr->grads; case 2: return tr->mom; case 3: return tr->stats;
+        case 4: return reinterpret_cast<float*>(tr->d_fast_flag);      // ONE int32: != 0 when a 16-bit pass left its predicted ranges (data-parallel: all-reduce MAX)
+    }
     return nullptr;
 }
 
@@ -3282,6 +3294,119 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
                                net->layers[net->conv1].Cout == 64 && net->layers[net->conv1].KH == 7 && net->layers[net->conv1].Cin == 4;
     const float* stem_g = nullptr;
     const float* stem_g_prev = nullptr;
+    // deferred finalisation: table of every non-head layer, conv1 LAST (its weight gradient is the last launch of the pass: the other
+    // layers are finalised beside it)
+    int max_cout = 0, max_krows = 0;
+    if (g_ctx->defer_plan) {
+        if (!tr->d_fin_table || tr->fin_B != B || tr->fin_h != d.in_h || tr->fin_w != d.in_w) {      // offsets follow the plan
+            std::vector<FinDesc> tab;
+            tr->fin_of_layer.assign(net->layers.size(), -1);
+            auto entry = [&](size_t li) {
+                tr->fin_of_layer[li] = (int)tab.size();
+                const ConvLayer& l = net->layers[li];
+                const TLayer& t = tr->tl[li];
+                FinDesc f{};
+                f.dw_off = (long long)pl.dw_l[li]; f.cs_off = (long long)pl.cs_l[li];
+                f.w_off = t.w_off; f.g_off = t.g_off; f.b_off = t.b_off; f.mean_off = t.mean_off; f.var_off = t.var_off;
+                f.taps = l.KH * l.KW; f.cin = l.Cin; f.cin_real = t.cin_real; f.cout = l.Cout; f.d_scale = l.d_scale;
+                tab.push_back(f);
+            };
+            for (size_t li = 0; li < net->layers.size(); ++li)
+                if ((int)li != net->head_part && (int)li != net->head_locref && (int)li != net->conv1) entry(li);
+            entry((size_t)net->conv1);
+            if (!tr->d_fin_table) TRY_HIP(hipMalloc(&tr->d_fin_table, tab.size() * sizeof(FinDesc)));
+            TRY_HIP(hipStreamSynchronize(s));        // (a previous pass may still read the old table)
+            TRY_HIP(hipMemcpy(tr->d_fin_table, tab.data(), tab.size() * sizeof(FinDesc), hipMemcpyHostToDevice));
+            tr->n_fin = (int)tab.size(); tr->fin_B = B; tr->fin_h = d.in_h; tr->fin_w = d.in_w;
+        }
+        for (size_t li = 0; li < net->layers.size(); ++li) {
+            if ((int)li == net->head_part || (int)li == net->head_locref) continue;
+            max_cout = std::max(max_cout, net->layers[li].Cout);
+            max_krows = std::max(max_krows, net->layers[li].KH * net->layers[li].KW * tr->tl[li].cin_real);
+        }
+    }
+    const int rpb = 128;
+    const FinDesc* fin_tab = reinterpret_cast<const FinDesc*>(tr->d_fin_table);
+    auto finalise = [&](int first, int count, hipStream_t st) {
+        if (count <= 0) return;
+        hipLaunchKernelGGL(scale_dw_dot_all_kernel, dim3((max_cout + 63) / 64, (max_krows + rpb - 1) / rpb, (unsigned)count), dim3(256), 0, st,
+                           fin_tab + first, (const char*)ws, tr->params, tr->grads, rpb);
+    };
+    auto bn_grads = [&](int first, int count, hipStream_t st) {
+        if (count <= 0) return;
+        hipLaunchKernelGGL(bn_param_grads_all_kernel, dim3((max_cout + 127) / 128, (unsigned)count), dim3(128), 0, st, fin_tab + first,
+                           (const char*)ws, tr->stats, d.bn_eps, tr->grads);
+    };
+    // ---- gradient groups (see dgp_trainer::GradGroup): cut the units, back to front, into runs of >= a quarter of the parameters each
+    if (tr->groups.empty()) {
+        auto layer_range = [&](int li, long long& lo, long long& hi) {
+            if (li < 0) return;
+            const ConvLayer& l = net->layers[li];
+            const TLayer& t = tr->tl[li];
+            const bool head = (li == net->head_part || li == net->head_locref);
+            const long long wsz_ = head ? 9ll * (l.Cout / 4) * l.Cin : (long long)l.KH * l.KW * t.cin_real * l.Cout;
+            const long long bsz_ = head ? l.Cout / 4 : l.Cout;
+            auto acc = [&](long long off, long long n) { lo = std::min(lo, off); hi = std::max(hi, off + (n + 3) / 4 * 4); };
+            acc(t.w_off, wsz_);
+            if (!head) acc(t.g_off, bsz_);
+            acc(t.b_off, bsz_);
+        };
+        std::vector<dgp_trainer::GradGroup> gs;
+        const bool can = g_ctx->defer_plan != nullptr && !tr->fin_of_layer.empty();
+        if (can) {
+            dgp_trainer::GradGroup cur_g;
+            long long lo = tr->n_train, hi = 0;
+            int f_lo = tr->n_fin, f_n = 0;
+            layer_range(net->head_part, lo, hi);
+            layer_range(net->head_locref, lo, hi);
+            for (int ui = nu - 1; ui >= 1; --ui) {
+                const Unit& u = net->units[ui];
+                for (int li : {u.sc, u.c1, u.c2, u.c3}) {
+                    if (li < 0) continue;
+                    layer_range(li, lo, hi);
+                    f_lo = std::min(f_lo, tr->fin_of_layer[li]); ++f_n;
+                }
+                if (hi - lo >= tr->n_train / 4 && gs.size() < 6) {
+                    cur_g.cut_ui = ui; cur_g.fin_first = f_lo; cur_g.fin_count = f_n; cur_g.lo = lo; cur_g.hi = hi;
+                    gs.push_back(cur_g);
+                    lo = tr->n_train; hi = 0; f_lo = tr->n_fin; f_n = 0;
+                }
+            }
+            // the last group: everything in front of the last cut (its table rows are [0, first cut row) + the stem's row, finalised at the end)
+            dgp_trainer::GradGroup last;
+            last.cut_ui = -1; last.lo = 0; last.hi = gs.empty() ? tr->n_train : gs.back().lo;
+            last.fin_first = 0; last.fin_count = gs.empty() ? tr->n_fin - 1 : gs.back().fin_first;
+            bool ok = true;                              // the groups must tile the flat buffer and the table, back to front
+            long long expect_hi = tr->n_train;
+            int expect_f = tr->n_fin - 1;
+            for (const auto& g : gs) {
+                ok = ok && g.hi == expect_hi && g.fin_first + g.fin_count == expect_f && g.lo < g.hi;
+                expect_hi = g.lo; expect_f = g.fin_first;
+            }
+            if (!ok) gs.clear(), last.hi = tr->n_train, last.fin_count = tr->n_fin - 1;
+            gs.push_back(last);
+        } else {
+            dgp_trainer::GradGroup all;
+            all.cut_ui = -1; all.lo = 0; all.hi = tr->n_train;
+            gs.push_back(all);
+        }
+        for (auto& g : gs)
+            if (hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) != hipSuccess) return fail(DGP_ERR_HIP, "gradient groups: hipEventCreate failed");
+        tr->groups = gs;
+    }
+    size_t grp_next = 0;                                 // next group to complete
+    // a group is complete behind the weight gradients of its layers: finalise it on their stream and record its event
+    auto close_groups_at = [&](int ui) -> hipError_t {
+        while (grp_next + 1 < tr->groups.size() && tr->groups[grp_next].cut_ui == ui) {
+            auto& g = tr->groups[grp_next++];
+            hipStream_t st = ctx->overlap ? ctx->s2 : s;
+            finalise(g.fin_first, g.fin_count, st);
+            bn_grads(g.fin_first, g.fin_count, st);
+            hipError_t e2 = hipEventRecord(g.ev, st);
+            if (e2 != hipSuccess) return e2;
+        }
+        return hipSuccess;
+    };
     for (int ui = nu - 1; ui >= 0; --ui) {
         if (stop_after >= 0 && (nu - 1 - ui) >= stop_after) {
             if (const char* e2 = getenv("DGP_BWD_DUMP")) {
@@ -3383,6 +3508,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
                 g_ctx->shadow_prev.erase(Gf);
             }
             cur ^= 1;
+            TRY_HIP(close_groups_at(ui));
             continue;
         }
         float* Gout = G[cur];
@@ -3439,42 +3565,8 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         TRY_HIP(conv_launch(l1, t1.d_wT, t1.nkT, t1.cinP, DR1, B, h, w, l1.Cout, 0, 0, h, w, l1.Cin, 1, 0, nullptr, nullptr,
                             dxa, dxa_mode, dxa_h, dxa_w, xin, false, 0, 0, Gin, s));
         cur ^= 1;
+        TRY_HIP(close_groups_at(ui));
     }
-    // deferred finalisation: table of every non-head layer, conv1 LAST (its weight gradient is the last launch of the pass: the other
-    // layers are finalised beside it)
-    int max_cout = 0, max_krows = 0;
-    if (g_ctx->defer_plan) {
-        if (!tr->d_fin_table || tr->fin_B != B || tr->fin_h != d.in_h || tr->fin_w != d.in_w) {      // offsets follow the plan
-            std::vector<FinDesc> tab;
-            auto entry = [&](size_t li) {
-                const ConvLayer& l = net->layers[li];
-                const TLayer& t = tr->tl[li];
-                FinDesc f{};
-                f.dw_off = (long long)pl.dw_l[li]; f.cs_off = (long long)pl.cs_l[li];
-                f.w_off = t.w_off; f.g_off = t.g_off; f.b_off = t.b_off; f.mean_off = t.mean_off; f.var_off = t.var_off;
-                f.taps = l.KH * l.KW; f.cin = l.Cin; f.cin_real = t.cin_real; f.cout = l.Cout; f.d_scale = l.d_scale;
-                tab.push_back(f);
-            };
-            for (size_t li = 0; li < net->layers.size(); ++li)
-                if ((int)li != net->head_part && (int)li != net->head_locref && (int)li != net->conv1) entry(li);
-            entry((size_t)net->conv1);
-            if (!tr->d_fin_table) TRY_HIP(hipMalloc(&tr->d_fin_table, tab.size() * sizeof(FinDesc)));
-            TRY_HIP(hipStreamSynchronize(s));        // (a previous pass may still read the old table)
-            TRY_HIP(hipMemcpy(tr->d_fin_table, tab.data(), tab.size() * sizeof(FinDesc), hipMemcpyHostToDevice));
-            tr->n_fin = (int)tab.size(); tr->fin_B = B; tr->fin_h = d.in_h; tr->fin_w = d.in_w;
-        }
-        for (size_t li = 0; li < net->layers.size(); ++li) {
-            if ((int)li == net->head_part || (int)li == net->head_locref) continue;
-            max_cout = std::max(max_cout, net->layers[li].Cout);
-            max_krows = std::max(max_krows, net->layers[li].KH * net->layers[li].KW * tr->tl[li].cin_real);
-        }
-    }
-    const int rpb = 128;
-    const FinDesc* fin_tab = reinterpret_cast<const FinDesc*>(tr->d_fin_table);
-    auto finalise = [&](int first, int count, hipStream_t st) {
-        hipLaunchKernelGGL(scale_dw_dot_all_kernel, dim3((max_cout + 63) / 64, (max_krows + rpb - 1) / rpb, (unsigned)count), dim3(256), 0, st,
-                           fin_tab + first, (const char*)ws, tr->params, tr->grads, rpb);
-    };
     // ---- root block: max-pool backward (+ stem ReLU gate), stem weight gradient
     static const bool fin_split_env = (dgp_tune("DGP_FIN_SPLIT", 1) != 0);       // A/B switch
     const bool fin_split = fin_split_env && g_ctx->defer_plan && ctx->overlap && tr->n_fin > 1;
@@ -3484,7 +3576,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
         const long long tot = (long long)B * net->h1 * net->w1 * 16;
         static const bool pool_idx = (dgp_tune("DGP_POOL_IDX", 1) != 0);
         if (stem_g) {
-            if (fin_split) finalise(0, tr->n_fin - 1, ctx->s2);
+            if (fin_split) finalise(0, tr->groups.back().fin_count, ctx->s2);      // (what the gradient groups have not finalised yet)
             StemWgradArgs sa{};
             sa.x = F(pl.p0); sa.g = reinterpret_cast<const uint4*>(stem_g); sa.idx = reinterpret_cast<const unsigned char*>(ws + pl.pidx);
             sa.g_prev = stem_g_prev;
@@ -3511,7 +3603,7 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
             // the stem's weight gradient (0.3 ms at 11 frames, fp32 MFMA on a 216 MB gradient) is the pass's last launch and nothing else
             // is left to run beside it -- except the finalisation of all OTHER layers: that goes to the second stream behind the last of
             // their weight gradients, the stem's weight gradient to this stream
-            finalise(0, tr->n_fin - 1, ctx->s2);
+            finalise(0, tr->groups.back().fin_count, ctx->s2);
             ctx->overlap = false;
             rc = layer_param_grads(tr, net->conv1, F(pl.p0), B, d.in_h, d.in_w, F(pl.dc1), net->h1, net->w1, 2, 3, 3, dwraw, colsum, s);
             ctx->overlap = true;
@@ -3531,11 +3623,14 @@ int dgp_train_backward(dgp_trainer* tr, int32_t nt, void* workspace, size_t work
     join();                                      // every weight gradient has landed before the finalisation reads them
     if (g_ctx->defer_plan) {
         g_ctx->defer_plan = nullptr;
-        if (fin_split) finalise(tr->n_fin - 1, 1, s);
-        else finalise(0, tr->n_fin, s);
-        hipLaunchKernelGGL(bn_param_grads_all_kernel, dim3((max_cout + 127) / 128, (unsigned)tr->n_fin), dim3(128), 0, s, fin_tab,
-                           (const char*)ws, tr->stats, d.bn_eps, tr->grads);
+        const int rest = tr->groups.back().fin_count;      // rows [0, rest) + the stem's row: the last gradient group
+        if (!fin_split) finalise(0, rest, s);
+        finalise(tr->n_fin - 1, 1, s);
+        bn_grads(0, rest, s);
+        bn_grads(tr->n_fin - 1, 1, s);
     }
+    if (grp_next + 1 != tr->groups.size()) return fail(DGP_ERR_STATE, "backward: a gradient group was not closed");
+    TRY_HIP(hipEventRecord(tr->groups.back().ev, s));
     TRY_HIP(hipGetLastError());
     return DGP_OK;
 }
@@ -3553,6 +3648,27 @@ int dgp_trainer_fast_mode(dgp_trainer* tr, int32_t enable) {
     if (enable && tr->tier != 1) return fail(DGP_ERR_INVALID, "dgp_trainer_fast_mode: needs dgp_trainer_set_tier(tr, 1) (the H2 fast pass is enabled in -DDGP_TUNING builds only)");
 #endif
     tr->fast_next = enable != 0;
+    return DGP_OK;
+}
+/* Gradient groups of the LAST dgp_train_backward (data-parallel training): group k = floats [lo[k], hi[k]) of the flat gradient buffer
+ * (dgp_trainer_buffer(tr, 1)), in the order the pass completes them -- the heads and the last bottleneck units first, the stem last; the
+ * groups tile the buffer.  *n_groups = 0 before the first backward pass. */
+int dgp_trainer_grad_groups(dgp_trainer* tr, int32_t max_groups, int32_t* n_groups, int64_t* lo, int64_t* hi) {
+    if (!tr || !n_groups) return fail(DGP_ERR_INVALID, "dgp_trainer_grad_groups: null");
+    *n_groups = (int32_t)tr->groups.size();
+    if ((int)tr->groups.size() > max_groups) return fail(DGP_ERR_INVALID, "dgp_trainer_grad_groups: more groups than max_groups");
+    for (size_t k = 0; k < tr->groups.size(); ++k) {
+        if (lo) lo[k] = tr->groups[k].lo;
+        if (hi) hi[k] = tr->groups[k].hi;
+    }
+    return DGP_OK;
+}
+/* Makes `stream` wait until group k of the last dgp_train_backward is final in the gradient buffer (hipStreamWaitEvent: nothing blocks
+ * on the host).  A communication stream that waits for group k can all-reduce it while the pass is still computing the later groups. */
+int dgp_trainer_grad_group_wait(dgp_trainer* tr, int32_t k, void* stream) {
+    if (!tr || k < 0 || k >= (int)tr->groups.size() || !tr->groups[k].ev) return fail(DGP_ERR_INVALID, "dgp_trainer_grad_group_wait: no such group");
+    g_ctx = &tr->ctx;
+    TRY_HIP(hipStreamWaitEvent((hipStream_t)stream, tr->groups[k].ev, 0));
     return DGP_OK;
 }
 int dgp_trainer_set_tier(dgp_trainer* tr, int32_t tier) {

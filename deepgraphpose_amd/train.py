@@ -44,6 +44,7 @@ class Trainer:
         self.tier = "parity"
         self.fast_redos = 0
         self.fast_passes = 0
+        self._comm_stream = None
         if tier is not None:
             self.set_tier(tier)
 
@@ -238,11 +239,48 @@ class Trainer:
         ptr = self.lib.dgp_trainer_buffer(self._t, 1)
         return _view(ptr, (self.n_trainable,), self.device)
 
-    def allreduce_gradients(self, group=None):
-        """Data-parallel step: average the gradients over the ranks (RCCL) before apply_gradients."""
+    def grad_groups(self):
+        """[(lo, hi)] float ranges of the flat gradient buffer in the order the last backward pass completed them (dgp_trainer_grad_groups)"""
+        n = C.c_int32()
+        lo, hi = (C.c_int64 * 8)(), (C.c_int64 * 8)()
+        _lib.check(self.lib.dgp_trainer_grad_groups(self._t, 8, C.byref(n), lo, hi), "dgp_trainer_grad_groups")
+        return [(int(lo[k]), int(hi[k])) for k in range(n.value)]
+
+    def allreduce_gradients(self, group=None, overlap: bool = True):
+        """Data-parallel step: average the gradients over the ranks (RCCL) before apply_gradients.
+
+        overlap (default): NO host synchronisation and one all-reduce per gradient GROUP, issued on a communication stream that waits for
+        the event the backward pass recorded behind that group's finalisation -- the heads and block4 (60 % of the parameters) are on the
+        wire while the pass is still computing blocks 3 .. 1; the caller's stream then waits for the collectives.  The result is the same
+        sum (one all-reduce per contiguous range of the same buffer); overlap=False: one synchronisation, then 64-MB buckets (round 5)."""
         from .dist import average_gradients
-        torch.cuda.current_stream(self.device).synchronize()       # backward kernels ran on this stream via the C-ABI
-        average_gradients(self.grads_tensor(), group)
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        groups = self.grad_groups() if overlap else []
+        if not groups:
+            torch.cuda.current_stream(self.device).synchronize()       # backward kernels ran on this stream via the C-ABI
+            average_gradients(self.grads_tensor(), group)
+            return
+        flat = self.grads_tensor()
+        world = dist.get_world_size(group)
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=self.device)
+        cs = self._comm_stream
+        handles = []
+        with torch.cuda.stream(cs):
+            for k, (lo, hi) in enumerate(groups):
+                _lib.check(self.lib.dgp_trainer_grad_group_wait(self._t, k, C.c_void_p(cs.cuda_stream)), "dgp_trainer_grad_group_wait")
+                handles.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
+            if self.tier == "f16":
+                # a 16-bit pass that left its predicted ranges on ONE rank poisons the sum on every rank: all ranks must skip the update
+                # (the optimiser's kernel reads the flag) and repeat the step on the parity path together
+                flag = _view(self.lib.dgp_trainer_buffer(self._t, 4), (1,), self.device, "<i4")
+                handles.append(dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group, async_op=True))
+            for h in handles:
+                h.wait()                                               # (the communication stream waits for the collective)
+            flat.mul_(1.0 / world)
+        torch.cuda.current_stream(self.device).wait_stream(cs)         # the optimiser's kernels run behind the averaged gradients
 
     def apply_gradients(self, lr: float, momentum: float = 0.9, clip_norm: float = 10.0) -> float:
         g = C.c_float()
@@ -258,17 +296,17 @@ class Trainer:
         at its end fetches losses, gradient norm and the pass status (dgp_trainer_step_status).  A 16-bit pass whose tensors left their
         predicted ranges has skipped its update on the device and is repeated here on the parity path."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            losses = self.forward_backward(frames, batch, hyper, S0, ws, ws_max, n_frames_total, n_visible_frames_total, labeled_only)
-            self.allreduce_gradients()               # data-parallel: mean gradient over the ranks (RCCL) -- needs the gradients on every rank first
-            losses["grad_norm"] = self.apply_gradients(hyper.lr, hyper.momentum, hyper.clip_norm)
-            return losses
+        dp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         from .loss import LOSS_NAMES
         nt = frames.shape[0]
         while True:
             fast = self._fast_begin(nt)
             dev_losses = self._forward_backward(frames, batch, hyper, S0, ws, ws_max, n_frames_total, n_visible_frames_total, labeled_only,
                                                 readback=False)
+            if dp:
+                # data-parallel: the mean gradient over the ranks (RCCL), group by group while the backward pass is still running; the
+                # optimiser's kernels are enqueued behind it -- still ONE host synchronisation per step
+                self.allreduce_gradients()
             _lib.check(self.lib.dgp_sgd_momentum_clip(self._t, hyper.lr, hyper.momentum, hyper.clip_norm, None, _stream(self.device)),
                        "dgp_sgd_momentum_clip")
             self.sync()                              # master -> panels / cells for the next forward (same weights again after a skipped update)
@@ -288,13 +326,11 @@ class Trainer:
             return losses
 
 
-def _view(ptr: int, shape, device) -> torch.Tensor:
-    """torch view of a device pointer inside the (torch-owned) workspace."""
-    n = int(np.prod(shape))
-    arr = (C.c_float * n).from_address(ptr) if False else None      # not addressable from the host
-    # build a tensor over foreign device memory through the __cuda_array_interface__ protocol
+def _view(ptr: int, shape, device, typestr: str = "<f4") -> torch.Tensor:
+    """torch view of a device pointer inside the (torch-owned) workspace / the library's flat buffers (fp32, or int32 with typestr "<i4")."""
+    # a tensor over foreign device memory through the __cuda_array_interface__ protocol
     class _Holder:
         pass
     h = _Holder()
-    h.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (ptr, False), "version": 2}
+    h.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 2}
     return torch.as_tensor(h, device=device)

@@ -208,7 +208,8 @@ int    dgp_trainer_num_tensors(const dgp_trainer* tr, int32_t* n_tensors, int64_
                                int64_t* n_stat_floats);
 int    dgp_trainer_tensor_info(const dgp_trainer* tr, int32_t i, char* name, int32_t cap, int64_t* offset,
                                int64_t* size, int32_t* is_stat);
-float* dgp_trainer_buffer(dgp_trainer* tr, int32_t which);  /* 0 params, 1 grads, 2 momentum, 3 BN statistics */
+float* dgp_trainer_buffer(dgp_trainer* tr, int32_t which);  /* 0 params, 1 grads, 2 momentum, 3 BN statistics; 4: the 16-bit pass's failure flag
+                                                              * (ONE int32 on the device; data-parallel runs all-reduce it with MAX before the update) */
 int    dgp_trainer_upload(dgp_trainer* tr, int32_t which, int64_t offset, const float* host, int64_t n);
 int    dgp_trainer_download(dgp_trainer* tr, int32_t which, int64_t offset, float* host, int64_t n);
 int    dgp_trainer_workspace_bytes(const dgp_trainer* tr, int32_t nt, size_t* out_bytes);
@@ -240,6 +241,13 @@ int    dgp_sgd_momentum_clip(dgp_trainer* tr, float lr, float momentum, float cl
  * after changing the tier.  A reported tier with measured gradient error, not the parity claim. */
 int    dgp_trainer_set_tier(dgp_trainer* tr, int32_t tier);
 int    dgp_trainer_get_tier(const dgp_trainer* tr);
+/* Data-parallel training (the reference trains on one GPU; DGP/models/fitdgp.py:708-713 is the update every replica applies): the
+ * gradient all-reduce of a GROUP of layers can start while dgp_train_backward is still computing the earlier layers.  Group k = floats
+ * [lo[k], hi[k]) of the flat gradient buffer (dgp_trainer_buffer(tr, 1)), in the order the LAST backward pass completes them (heads and
+ * last bottleneck units first, stem last; the groups tile the buffer; *n_groups = 0 before the first pass).
+ * dgp_trainer_grad_group_wait makes `stream` wait for group k (hipStreamWaitEvent: nothing blocks on the host). */
+int    dgp_trainer_grad_groups(dgp_trainer* tr, int32_t max_groups, int32_t* n_groups, int64_t* lo, int64_t* hi);
+int    dgp_trainer_grad_group_wait(dgp_trainer* tr, int32_t k, void* stream);
 int    dgp_trainer_fast_mode(dgp_trainer* tr, int32_t enable);
 int    dgp_trainer_fast_status(dgp_trainer* tr, int32_t* was_fast, int32_t* failed);
 /* ONE synchronisation per training step: enqueue forward, loss, backward, dgp_sgd_momentum_clip(..., NULL gnorm, ...) and

@@ -560,10 +560,14 @@ def test_fit_dlc_driver(lib_built, tmp_path):
     fit_dgp_labeledonly("snapshot-step0-final--0", proj, shuffle=1, step=1, maxiters=2, displayiters=1, aug=False)
 
 
-def test_data_parallel_two_ranks_on_one_gpu(lib_built, tmp_path):
+@pytest.mark.parametrize("tier", ["parity", "f16"])
+def test_data_parallel_two_ranks_on_one_gpu(lib_built, tmp_path, tier):
     """N4 on hardware with W = 2: two processes on cuda:0 (control plane on gloo via DGP_DIST_BACKEND; RCCL refuses two ranks per
     device) run Trainer.step on DIFFERENT windows from the same weights.  The gradient both apply is the mean of the two
-    single-process gradients, and the replicas stay bit-identical after two steps."""
+    single-process gradients, and the replicas stay bit-identical after the steps.  Round 6: the all-reduce runs GROUP BY GROUP behind the
+    events the backward pass records (dgp_trainer_grad_groups / _grad_group_wait: heads + block4 first, stem last, no host
+    synchronisation before the optimiser) -- the groups tile the flat buffer, the first one holds >= a quarter of the parameters; on
+    the 16-bit tier the failure flag is all-reduced too (a failed prediction on one rank must skip the update on every rank)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = r'''
@@ -578,13 +582,21 @@ import torch.distributed as dist
 assert world == 2 and dist.get_backend() == "gloo"
 wts = TT._train_case(7)[2]
 batch, S0, _, frames, ws, ws_max = TT._train_case(20 + rank)
-tr = Trainer(50, 3, 64, 96, max_frames=3)
+tr = Trainer(50, 3, 64, 96, max_frames=3, tier=sys.argv[3])
 tr.load_weights(wts)
 hy = DGPHyper(gm2=1, gm3=3, lr=0.005)
 ft = torch.from_numpy(frames).cuda()
+assert tr.grad_groups() == []                       # (no backward pass yet)
 tr.step(ft, batch, hy, S0, ws, ws_max, 300.0, 25.0)
 g = tr.get_grads()
-tr.step(ft, batch, hy, S0, ws, ws_max, 300.0, 25.0)
+groups = tr.grad_groups()
+assert len(groups) >= 2 and groups[0][1] == tr.n_trainable and groups[-1][0] == 0, groups
+assert all(groups[k][0] == groups[k + 1][1] for k in range(len(groups) - 1)), groups       # back to front, no gap, no overlap
+assert groups[0][1] - groups[0][0] >= tr.n_trainable // 4, groups
+for _ in range(2):
+    tr.step(ft, batch, hy, S0, ws, ws_max, 300.0, 25.0)
+if sys.argv[3] == "f16":
+    assert tr.fast_passes >= 2 and tr.fast_redos == 0, (tr.fast_passes, tr.fast_redos)
 w = tr.get_weights()
 np.savez(sys.argv[2] + "_g%d.npz" % rank, **g)
 np.savez(sys.argv[2] + "_w%d.npz" % rank, **w)
@@ -596,7 +608,7 @@ dist.destroy_process_group()
         env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), RANK=str(rank), WORLD_SIZE="2",
                    LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", DGP_DIST_BACKEND="gloo")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, "-c", code, os.path.join(root, "tests"), str(tmp_path / "dp")], env=env, cwd=root,
+        procs.append(subprocess.Popen([sys.executable, "-c", code, os.path.join(root, "tests"), str(tmp_path / "dp"), tier], env=env, cwd=root,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for pr in procs:
