@@ -82,7 +82,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             f.write(want)
         return obj
 
-    jobs = max(1, min(len(SOURCES), int(os.environ.get("DGP_BUILD_JOBS", "6"))))
+    jobs = max(1, min(len(SOURCES), os.cpu_count() or 1))
     with ThreadPoolExecutor(jobs) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs

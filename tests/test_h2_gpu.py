@@ -226,7 +226,15 @@ def test_reported_16_bit_tier_is_an_11_bit_version_of_the_same_network(lib_built
     assert 2e-5 < rel < 2e-2, rel                               # the mode is active, and it is the same network
     # (window indices: an arg-max over 1-4 scoremap cells that may be nearly equal -- the tier's measured agreement is 99.6 % over 256 frames,
     #  one of the 24 pairs of this batch flips with the chain kernels on H1 tensors; the band of tests/test_h1_gpu.py)
-    assert (idx_a.cpu().numpy() == t["idx"]).all(-1).mean() >= 0.9
+    ia, it = idx_a.cpu().numpy(), t["idx"]
+    same = (ia == it).all(-1)
+    assert same.mean() >= 0.9
+    # ... and a pair may flip ONLY at a near-tie: the parity scoremap's values at the two cells differ by no more than twice the distance
+    # between the two tiers' scoremaps (everything with a clearer winner agrees exactly)
+    noise = float(np.abs(a - t["sc"]).max())
+    for b, j in zip(*np.nonzero(~same)):
+        gap = abs(float(a[b, ia[b, j, 0], ia[b, j, 1], j]) - float(a[b, it[b, j, 0], it[b, j, 1], j]))
+        assert gap <= 2.0 * noise, (int(b), int(j), gap, noise)
     assert np.abs(mu_a.cpu().numpy() - t["mu"]).max() * 8.0 < 0.25
 
 
