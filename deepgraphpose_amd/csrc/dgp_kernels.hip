@@ -1180,8 +1180,19 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : BM == 256 ? 2 : ((BK =
         const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, loc = b >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int mt = tile / p.ntiles;
-    const int nt = tile - mt * p.ntiles;
+    // Pointwise launches with TWO column tiles (block3's conv1: K 1024 -> 256): groups of 32 row tiles, column-major inside a group, so that
+    // workgroups `loc` and `loc + 32` of an XCD -- the two a CU holds when the dispatcher fills the CUs once and then again -- are the two
+    // column tiles of ONE row tile: the A rows, which come from the memory-side cache, are requested by both from the same CU at about the
+    // same time (one L2 miss path instead of two), where the plain order pairs two row tiles of one column (sharing the L2-resident weight
+    // cells).  Bit-identical; measured (profiles/r6_tile_order_ab.txt): 16-bit tier 44-46 -> 39-41 us per launch (-10 %), parity tier -2..-5 %.
+    // With four or more column tiles the same pairing is a wash (+-2 %: it gives up the shared weight cells), the 3x3 layers lose 2-4 %.
+    int mt, nt;
+    if (MODE == 2 && p.ntiles == 2 && p.st_gn == 0 && !(p.tail_ksplit > 1)) {
+        const int G = tile >> 6, lg = tile & 63;
+        const int left = p.mtiles - 32 * G, hh = left < 32 ? left : 32;       // (the last group may be shorter)
+        nt = lg / hh;
+        mt = 32 * G + (lg - nt * hh);
+    } else { mt = tile / p.ntiles; nt = tile - mt * p.ntiles; }
     const int m0 = mt * BM;
     const int n0 = nt * BN;
     const int HoWo = p.Ho * p.Wo;
