@@ -69,10 +69,14 @@ def table():
         ("strict fp32 MFMA (`strict_f32`)", "%s frames/s" % span([get(d, "strict_f32", "frames_per_s") for d in L])),
         ("ResNet-101, 1280×720, 20 keypoints, batch 16 (`r101_1280x720`)", "%s frames/s; 16-bit tier (`r101_1280x720_f16`) %s" % (
             span([get(d, "r101_1280x720", "frames_per_s") for d in L]), span([get(d, "r101_1280x720_f16", "frames_per_s") for d in L]))),
-        ("host pipeline (`host_pipeline`: decode → pinned ring → copy stream → engine; PCIe inclusive, never `value`)",
-         "%s frames/s end to end on %s frames (engine set-up inside); %s frames/s without the call's fixed cost" % (
-             span([get(d, "host_pipeline", "frames_per_s") for d in L]), span([get(d, "host_pipeline", "frames") for d in L], "%d"),
-             span([get(d, "host_pipeline", "steady_frames_per_s") for d in L]))),
+        ("host pipeline (`host_pipeline` / `host_pipeline_f16`: `estimate_pose` on host frames -- staging threads → pinned ring → two copy streams → two engines; "
+         "PCIe inclusive, never `value`)",
+         "parity tier **%s frames/s**, 16-bit tier **%s frames/s** end to end on %s frames (second call on a snapshot: the session is kept)" % (
+             span([get(d, "host_pipeline", "frames_per_s") for d in L]), span([get(d, "host_pipeline_f16", "frames_per_s") for d in L]),
+             span([get(d, "host_pipeline", "frames") for d in L], "%d"))),
+        ("whole step against the roof (`roofline.frac_whole_step`: stem, heads, soft-argmax, epilogues, launch gaps included)",
+         "parity tier %s of 833 TFLOP/s, 16-bit tier %s of 2500" % (span([get(d, "roofline", "frac_whole_step") for d in L], "%.3f"),
+                                                                 span([get(d, "tier_f16", "roofline", "frac_whole_step") for d in L], "%.3f"))),
         ("CPU baseline (`cpu_baseline`: the oracle on the box's host cores, bounded sample)", "%s frames/s on %s cores (`kind: %s`)" % (
             span([get(d, "cpu_baseline", "value") for d in L], "%.1f"), span([get(d, "cpu_baseline", "cores") for d in L], "%d"),
             get(L[0], "cpu_baseline", "kind"))),
