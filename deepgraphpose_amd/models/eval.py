@@ -448,71 +448,77 @@ def estimate_pose(proj_cfg_file, dgp_model_file, video_file, output_dir, shuffle
             finally:
                 RUN_STATS["wait_frames_s"] += time.perf_counter() - t_
 
-        start, finished, kb = 0, False, 0
-        # every rank runs the SAME number of chunk rounds (a short shard ends with empty ones): the decision to re-calibrate after a
-        # range overflow is a collective
-        per_rank = -(-n_frames // world)
-        n_rounds = max(1, -(-(-(-per_rank // batch_size)) // chunk_batches))
-        for rnd in range(n_rounds):
-            entries = []                          # (slot in dchunk, frames, offset in traj) of this chunk
-            while len(entries) < chunk_batches and not finished:
-                item = next_batch(kb)
-                if item is None:
-                    finished = True
-                    break
-                kb += 1
-                slot, nb = item
-                k = len(entries)
-                cs = copy_streams[kb % len(copy_streams)]
-                with torch.cuda.stream(cs):
-                    dchunk[k][:nb].copy_(pinned[slot][:nb], non_blocking=True)
-                    copied = torch.cuda.Event()
-                    copied.record(cs)
-                compute.wait_event(copied)
-                pending.append((copied, slot))
-                if cal_batch is None:
-                    cal_batch = dchunk[k][:nb].clone()
+        try:
+            start, finished, kb = 0, False, 0
+            # every rank runs the SAME number of chunk rounds (a short shard ends with empty ones): the decision to re-calibrate after a
+            # range overflow is a collective
+            per_rank = -(-n_frames // world)
+            n_rounds = max(1, -(-(-(-per_rank // batch_size)) // chunk_batches))
+            for rnd in range(n_rounds):
+                entries = []                          # (slot in dchunk, frames, offset in traj) of this chunk
+                while len(entries) < chunk_batches and not finished:
+                    item = next_batch(kb)
+                    if item is None:
+                        finished = True
+                        break
+                    kb += 1
+                    slot, nb = item
+                    k = len(entries)
+                    cs = copy_streams[kb % len(copy_streams)]
+                    with torch.cuda.stream(cs):
+                        dchunk[k][:nb].copy_(pinned[slot][:nb], non_blocking=True)
+                        copied = torch.cuda.Event()
+                        copied.record(cs)
+                    compute.wait_event(copied)
+                    pending.append((copied, slot))
+                    if cal_batch is None:
+                        cal_batch = dchunk[k][:nb].clone()
+                        t_ = time.perf_counter()
+                        net.calibrate(cal_batch, sess.gamma, sess.gauss_len)      # (what the first submit would do: timed apart)
+                        RUN_STATS["calibrate_s"] += time.perf_counter() - t_
+                    # written in place by the soft-argmax kernel, on the next engine's stream
+                    net.submit(dchunk[k][:nb], traj[start:start + nb], sess.gamma, sess.gauss_len)
+                    entries.append((k, nb, start))
+                    start += nb
+                    release(len(pending) >= nslots - 1)
+                # H2 activation scales (include/dgp_hip.h): a batch that outgrew the scales calibrated on the first batch invalidates the
+                # results since the last clean check, i.e. THIS chunk's.  All ranks decide together; every engine of every rank then
+                # re-calibrates on the calibration batch with 3 more bits of headroom (same scales everywhere again) and the ranks whose
+                # chunk overflowed re-run it from the frames still resident in HBM.
+                for attempt in range(5):
                     t_ = time.perf_counter()
-                    net.calibrate(cal_batch, sess.gamma, sess.gauss_len)      # (what the first submit would do: timed apart)
-                    RUN_STATS["calibrate_s"] += time.perf_counter() - t_
-                # written in place by the soft-argmax kernel, on the next engine's stream
-                net.submit(dchunk[k][:nb], traj[start:start + nb], sess.gamma, sess.gauss_len)
-                entries.append((k, nb, start))
-                start += nb
-                release(len(pending) >= nslots - 1)
-            # H2 activation scales (include/dgp_hip.h): a batch that outgrew the scales calibrated on the first batch invalidates the
-            # results since the last clean check, i.e. THIS chunk's.  All ranks decide together; every engine of every rank then
-            # re-calibrates on the calibration batch with 3 more bits of headroom (same scales everywhere again) and the ranks whose
-            # chunk overflowed re-run it from the frames still resident in HBM.
-            for attempt in range(5):
-                t_ = time.perf_counter()
-                net.join()
-                torch.cuda.synchronize(dev)
-                RUN_STATS["drain_s"] += time.perf_counter() - t_
-                overflow = bool(net.range_status()[0])
-                anywhere = ddist.any_rank(overflow, device="cuda:%d" % sess.device)
-                if not anywhere:
-                    break
-                if attempt == 4:
-                    raise RuntimeError("activation scales did not settle after 4 re-calibrations in %s" % video_file)
-                if not overflow:
-                    net.widen()                   # follow the rank that overflowed: same headroom everywhere
-                net.calibrate(cal_batch, sess.gamma, sess.gauss_len)
-                if rnd > 0:
-                    stale = True                  # chunks [0, rnd) were computed with the narrower scales (valid, but other bits)
-                if overflow or strict:            # strict: every rank re-runs this chunk on the new scales, not only the one that overflowed
-                    print("activation ranges outgrew the calibrated scales: re-calibrated, re-running frames %d-%d of %s"
-                          % (lo + entries[0][2] if entries else lo, lo + start, video_file), flush=True)
-                    RUN_STATS["chunk_reruns"] += 1
-                    for k, nb, off in entries:
-                        net.submit(dchunk[k][:nb], traj[off:off + nb], sess.gamma, sess.gauss_len)
-            RUN_STATS["chunks"] += 1 if entries else 0
-        if not finished:
-            assert next_batch(kb) is None, "more frames than the shard holds"
-        while pending:
-            release(True)
-        for th in threads:
-            th.join()
+                    net.join()
+                    torch.cuda.synchronize(dev)
+                    RUN_STATS["drain_s"] += time.perf_counter() - t_
+                    overflow = bool(net.range_status()[0])
+                    anywhere = ddist.any_rank(overflow, device="cuda:%d" % sess.device)
+                    if not anywhere:
+                        break
+                    if attempt == 4:
+                        raise RuntimeError("activation scales did not settle after 4 re-calibrations in %s" % video_file)
+                    if not overflow:
+                        net.widen()                   # follow the rank that overflowed: same headroom everywhere
+                    net.calibrate(cal_batch, sess.gamma, sess.gauss_len)
+                    if rnd > 0:
+                        stale = True                  # chunks [0, rnd) were computed with the narrower scales (valid, but other bits)
+                    if overflow or strict:            # strict: every rank re-runs this chunk on the new scales, not only the one that overflowed
+                        print("activation ranges outgrew the calibrated scales: re-calibrated, re-running frames %d-%d of %s"
+                              % (lo + entries[0][2] if entries else lo, lo + start, video_file), flush=True)
+                        RUN_STATS["chunk_reruns"] += 1
+                        for k, nb, off in entries:
+                            net.submit(dchunk[k][:nb], traj[off:off + nb], sess.gamma, sess.gauss_len)
+                RUN_STATS["chunks"] += 1 if entries else 0
+            if not finished:
+                assert next_batch(kb) is None, "more frames than the shard holds"
+            while pending:
+                release(True)
+            for th in threads:
+                th.join()
+        except BaseException as e:               # a failure on this side must not leave the staging threads waiting for a slot for ever
+            with cv:
+                st["err"] = st["err"] or e
+                cv.notify_all()
+            raise
         t_ = time.perf_counter()
         if world > 1:                                  # ONE all-gather per video: 20 bytes per (frame, joint)
             full = ddist.gather_trajectory(traj[:n_local], n_frames)
