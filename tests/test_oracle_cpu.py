@@ -370,3 +370,18 @@ def test_slim_atrous_invariant_on_the_oracle():
         f16_ = O.resnet_features(fr, wts, 50, output_stride=16)
         f32_ = O.resnet_features(fr, wts, 50, output_stride=32)
         assert np.abs(f16_[:, ::2, ::2] - f32_).max() <= 1e-4 * scale + 1e-4
+
+
+def test_tf_max_pool_same_known_answer():
+    """tensorflow/python/kernel_tests/pooling_ops_test.py PoolingTest._testMaxPoolSamePadding: input 1 .. 18 as [1, 2, 3, 3] (NHWC), 2 x 2 window,
+    stride 2, SAME -> [13, 14, 15, 16, 17, 18]: the odd width is padded AFTER (the second window holds column 2 alone) and padding never wins.
+    The root block's pool (slim.max_pool2d([3, 3], stride 2, 'SAME')) is the same operator with another window."""
+    x = np.arange(1, 19, dtype=np.float32).reshape(1, 2, 3, 3)
+    y = O.max_pool_same(_nchw(x), 2, 2)
+    assert tuple(y.shape) == (1, 3, 1, 2)
+    assert y.permute(0, 2, 3, 1).reshape(-1).tolist() == [13.0, 14.0, 15.0, 16.0, 17.0, 18.0]
+    # 3 x 3 / 2 SAME by hand on an even and an odd size (out = ceil(n / 2)): n = 4 pads 0 before / 1 after -> windows {0, 1, 2}, {2, 3};
+    # n = 5 pads 1 / 1 -> windows {0, 1}, {1, 2, 3}, {3, 4}
+    for n, want in ((4, [[10, 11], [14, 15]]), (5, [[6, 8, 9], [16, 18, 19], [21, 23, 24]])):
+        z = np.arange(n * n, dtype=np.float32).reshape(1, n, n, 1)
+        np.testing.assert_array_equal(O.max_pool_same(_nchw(z), 3, 2)[0, 0].numpy(), want)
