@@ -21,7 +21,8 @@ PINNING STATUS
     OWN published known answers"): the expected matrices TF's own unit tests assert for
     slim.conv2d / resnet_utils.conv2d_same / subsample (resnet_v1_test.py
     testConv2DSameEven / Odd, testSubsample*), conv2d_transpose SAME stride 2
-    (conv2d_transpose_test.py testConv2DTransposeSame), the stack_blocks_dense endpoint
+    (conv2d_transpose_test.py testConv2DTransposeSame), max-pool SAME (pooling_ops_test.py
+    _testMaxPoolSamePadding), the stack_blocks_dense endpoint
     shapes, and slim's atrous invariant (output_stride 16 subsampled == nominal stride 32)
     -- on this oracle and, across implementations, through dgp_forward
     (tests/test_parity_gpu.py).  Padding, alignment and stride bookkeeping are therefore
