@@ -218,3 +218,77 @@ def test_readme_numbers_are_generated_from_the_committed_bench_lines():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "readme_numbers.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_resolve_tier_argument_environment_and_rejects(monkeypatch):
+    """The one argument the entry points add to the reference's signatures (round 6): None -> DGP_EVAL_TIER -> the library default."""
+    from deepgraphpose_amd.models import eval as E
+    monkeypatch.delenv("DGP_EVAL_TIER", raising=False)
+    assert E.resolve_tier(None) is None and E.resolve_tier("parity") == "parity" and E.resolve_tier("f16") == "f16"
+    assert E.resolve_tier("BF16") == "f16" and E.resolve_tier("fp16") == "f16"        # (what configs[3] calls the tier)
+    monkeypatch.setenv("DGP_EVAL_TIER", "f16")
+    assert E.resolve_tier(None) == "f16" and E.resolve_tier("parity") == "parity"     # the argument wins
+    monkeypatch.setenv("DGP_EVAL_TIER", "int8")
+    with pytest.raises(ValueError):
+        E.resolve_tier(None)
+    import inspect
+    for fn in (E.estimate_pose, E.setup_dgp_eval_graph, E.evaluate_dgp, E.plot_dgp):
+        assert inspect.signature(fn).parameters["tier"].default is None
+    # the reference's own parameters are untouched, in order (eval.py:147, :217-218, :656-657, :816-818)
+    assert list(inspect.signature(E.estimate_pose).parameters)[:9] == ["proj_cfg_file", "dgp_model_file", "video_file", "output_dir", "shuffle",
+                                                                          "save_pose", "save_str", "new_size", "crop_size"]
+    assert list(inspect.signature(E.setup_dgp_eval_graph).parameters)[:5] == ["dlc_cfg", "dgp_model_file", "loc_ref", "gauss_len", "gamma"]
+
+
+def test_setup_dgp_eval_graph_keeps_one_session_per_snapshot(tmp_path, monkeypatch):
+    """The session kept between calls (no GPU needed: engines are built on first use): same snapshot files + same arguments -> the same
+    session object; another tier, changed file contents or DGP_EVAL_SESSION_CACHE=0 -> another one; clear_session_cache() drops it."""
+    from deepgraphpose_amd import weights_io
+    from deepgraphpose_amd.models import eval as E
+    from deepgraphpose_amd.synthetic import make_weights
+
+    class Cfg(dict):
+        __getattr__ = dict.get
+    cfg = Cfg(net_type="resnet_50", num_joints=3)
+    wts = make_weights(50, 3, False, seed=1)
+    snap = weights_io.save_weights(str(tmp_path / "snapshot-step2-final--0"), wts)
+    monkeypatch.delenv("DGP_EVAL_TIER", raising=False)
+    monkeypatch.delenv("DGP_EVAL_SESSION_CACHE", raising=False)
+    E.clear_session_cache()
+    s1 = E.setup_dgp_eval_graph(cfg, snap)[0]
+    assert E.setup_dgp_eval_graph(cfg, snap)[0] is s1
+    s1.close()                                               # tf.Session.close(): the kept session survives it
+    assert E.setup_dgp_eval_graph(cfg, snap)[0] is s1
+    assert E.setup_dgp_eval_graph(cfg, snap, gamma=2)[0] is not s1                       # another graph argument
+    s2 = E.setup_dgp_eval_graph(cfg, snap, tier="f16")[0]
+    assert s2.tier == "f16" and E.setup_dgp_eval_graph(cfg, snap, tier="f16")[0] is s2
+    w2 = dict(wts)
+    w2["pose/part_pred/block4/biases"] = wts["pose/part_pred/block4/biases"] + 1.0
+    weights_io.save_weights(snap, w2)                                                    # same path, other bytes
+    s3 = E.setup_dgp_eval_graph(cfg, snap, tier="f16")[0]
+    assert s3 is not s2 and float(s3.weights["pose/part_pred/block4/biases"][0]) == float(w2["pose/part_pred/block4/biases"][0])
+    monkeypatch.setenv("DGP_EVAL_SESSION_CACHE", "0")
+    assert E.setup_dgp_eval_graph(cfg, snap, tier="f16")[0] is not s3
+    cfg101 = Cfg(net_type="resnet_101", num_joints=3)
+    with pytest.raises(KeyError):
+        E.setup_dgp_eval_graph(cfg101, snap)                                             # (the reference's resnet_50 -> 101 fallback relies on it)
+    with pytest.raises(FileNotFoundError):
+        E.setup_dgp_eval_graph(cfg, str(tmp_path / "nope"))
+    E.clear_session_cache()
+    assert not E._SESSION_CACHE
+
+
+def test_bench_counts_visible_gpus_without_touching_hip(monkeypatch):
+    """bench.py's spawner decides whether `--gpus N` fits from sysfs and the *_VISIBLE_DEVICES variables alone (the parent process must
+    never initialise the GPU): list parsing as in the runtime (-1 ends a list), the smallest of the lists wins."""
+    import bench
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    base = bench.visible_gpu_count()
+    assert base >= 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2,3")
+    assert bench.visible_gpu_count() == (min(base, 4) if base else 4)
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0,1,-1,3")
+    assert bench.visible_gpu_count() == (min(base, 2) if base else 2)
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count() == 0
