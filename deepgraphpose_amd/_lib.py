@@ -95,6 +95,7 @@ SYMBOLS = {
     "dgp_net_range_status": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), _vp]),
     "dgp_net_recalibrate": (C.c_int, [_vp]),
     "dgp_net_reset_scales": (C.c_int, [_vp]),
+    "dgp_net_copy_scales": (C.c_int, [_vp, _vp, _vp]),
     "dgp_net_widen": (C.c_int, [_vp]),
     "dgp_conv2d_wgrad": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgp_conv2d_wgrad_shadow": (C.c_int, [C.POINTER(DgpConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -1558,6 +1558,29 @@ int dgp_net_widen(dgp_net* net) {
     return DGP_OK;
 }
 
+int dgp_net_copy_scales(dgp_net* dst, const dgp_net* src, void* stream) {
+    if (!dst || !src) return fail(DGP_ERR_INVALID, "dgp_net_copy_scales: null net");
+    if (!src->h2_calibrated) return fail(DGP_ERR_STATE, "dgp_net_copy_scales: the source engine is not calibrated");
+    if (!dst->loaded || !dst->d_exps || dst->layers.size() != src->layers.size() || dst->units.size() != src->units.size() || dst->tier != src->tier ||
+        dst->desc.in_h != src->desc.in_h || dst->desc.in_w != src->desc.in_w)
+        return fail(DGP_ERR_INVALID, "dgp_net_copy_scales: the engines differ (layers, tier or frame size)");
+    dst->act_exp = src->act_exp;
+    dst->unit_fuse_ok = src->unit_fuse_ok;
+    dst->h2_head = src->h2_head;
+    std::vector<int> ex(dst->layers.size(), dgp_net::H2_NONE);          // (what the calibration pass uploads for the per-forward range check)
+    ex[dst->conv1] = dst->act_exp[dst->conv1];
+    for (const Unit& u : dst->units) {
+        ex[u.c1] = dst->act_exp[u.c1]; ex[u.c2] = dst->act_exp[u.c2]; ex[u.c3] = dst->act_exp[u.c3];
+        if (u.sc >= 0) ex[u.sc] = dst->act_exp[u.sc];
+    }
+    hipError_t e;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));                  // (a forward of `dst` still in flight reads the old exponents)
+    HIP_TRY(hipMemcpy(dst->d_exps, ex.data(), ex.size() * sizeof(int), hipMemcpyHostToDevice));
+    dst->h2_calibrated = true;
+    ++dst->h2_calibrations;
+    return DGP_OK;
+}
+
 int dgp_net_reset_scales(dgp_net* net) {
     if (!net) return fail(DGP_ERR_INVALID, "dgp_net_reset_scales: null net");
     net->h2_calibrated = false;

@@ -229,6 +229,13 @@ class DGPNet:
         self.widen_count = 0
         self.scale_epoch += 1
 
+    def copy_scales_from(self, other: "DGPNet"):
+        """Take `other`'s calibrated activation scales (same network, weights, tier, frame size): what this engine would find by calibrating
+        on the same batch itself, without the layer-by-layer pass (dgp_net_copy_scales)."""
+        _lib.check(self.lib.dgp_net_copy_scales(self._h, other._h, _stream(self.device)), "dgp_net_copy_scales")
+        self.widen_count = other.widen_count
+        self.scale_epoch += 1
+
     def widen(self):
         """Re-calibrate on the next forward with 3 more bits of headroom -- what range_status() does on an overflow -- for a rank
         that follows another rank's overflow in a sharded run."""
@@ -300,14 +307,19 @@ class DGPPipeline:
         self.in_h, self.in_w, self.out_h, self.out_w = n0.in_h, n0.in_w, n0.out_h, n0.out_w
 
     def calibrate(self, frames: torch.Tensor, gamma: float = 1.0, gauss_len: int = 1):
-        """Run `frames` through every engine (each calibrates on it after load_weights / recalibrate / an overflow); synchronises."""
+        """Engine 0 runs `frames` (it calibrates on them after load_weights / recalibrate / an overflow) and the other engines take its
+        scales (dgp_net_copy_scales: the calibration is deterministic, so that is what each would have found on the same batch -- round 6,
+        one layer-by-layer pass per video instead of one per engine); synchronises."""
         scratch = torch.empty((frames.shape[0], self.nj, 5), dtype=torch.float32, device=self.device)
         cur = torch.cuda.current_stream(self.device)
-        for n, st in zip(self.nets, self.streams):
-            st.wait_stream(cur)
+        n0, st0 = self.nets[0], self.streams[0]
+        st0.wait_stream(cur)
+        with torch.cuda.stream(st0):
+            n0.infer_packed(frames, scratch, gamma, gauss_len)
+        st0.synchronize()
+        for n, st in zip(self.nets[1:], self.streams[1:]):
             with torch.cuda.stream(st):
-                n.infer_packed(frames, scratch, gamma, gauss_len)
-            st.synchronize()
+                n.copy_scales_from(n0)
         self._calibrated = True
         self._epochs = [n.scale_epoch for n in self.nets]
 

@@ -396,6 +396,11 @@ int  dgp_net_widen(dgp_net* net);
  * forward.  For an engine that is kept between videos (models/eval.py, the session kept by setup_dgp_eval_graph): the next video's first
  * batch then sets the same scales -- and every later frame gets the same bits -- as on a freshly built engine. */
 int  dgp_net_reset_scales(dgp_net* net);
+/* The calibrated activation scales of `src` (same network, weights, tier and frame size) become `dst`'s: what `dst` would have found by
+ * calibrating on the same batch itself -- the calibration is deterministic -- without its layer-by-layer pass.  For callers that keep
+ * several engines in step (two batches in flight: one engine calibrates on the video's first batch, the others copy).  Synchronises
+ * `stream` (the stream `dst` runs on). */
+int  dgp_net_copy_scales(dgp_net* dst, const dgp_net* src, void* stream);
 
 /* slots = max(slots, max |x[0..n)|) on the device (zero the DGP_ABSMAX_SLOTS floats before the first call). */
 int  dgp_tensor_absmax(const float* x, size_t n, float* absmax_dev, void* stream);
