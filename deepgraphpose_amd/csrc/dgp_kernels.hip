@@ -15,6 +15,7 @@
 #include <cstring>
 #include <cstdio>
 #include <vector>
+#include <algorithm>
 #include <type_traits>
 
 namespace dgp {
@@ -1155,6 +1156,10 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : BM == 256 ? 2 : ((BK =
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef DGP_DIAG
+    unsigned long long rt0;                          // 100-MHz wall clock at the workgroup's first instruction (the per-CU timeline of the launch)
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
+#endif
     int tile;
     int part = -1, tail_slot = 0;                    // part >= 0: this block computes one K-slice of a tail tile into a slab
     if (p.tail_ksplit > 1 && (int)blockIdx.x >= p.n_main) {
@@ -1319,7 +1324,11 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : BM == 256 ? 2 : ((BK =
                 for (int it = -1; it < nks; ++it) {
                     if (it + 1 < nks) issue_cells();                     // step it + 1
                     if (lw < 2 && it >= 0 && ws < nks) write_table();    // step it + 2: read by the compute waves behind barrier it + 1
+#if defined(DGP_X) && DGP_X == 10      // timing only: this step's weight cells are not waited for (what a second step of lookahead would buy)
+                    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+#else
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
                     __builtin_amdgcn_s_barrier();
                 }
                 return;
@@ -1348,7 +1357,9 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : BM == 256 ? 2 : ((BK =
 #endif
             for (int it = -2; it < nks; ++it) {
                 DIAG_STAMP(h0);
+#if !(defined(DGP_X) && DGP_X == 10)
                 if (it + 1 >= 0 && it + 1 < nks) issue_cells();          // weight cells of step it + 1 first
+#endif
                 if (it > -2) {                                           // ring bookkeeping
                     if (ws + 1 < nks) {
                         wl += wt == 8 ? d_ch : ((wt == 2 || wt == 5) ? d_kh : d);
@@ -1369,6 +1380,9 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : BM == 256 ? 2 : ((BK =
                 int n_far = end_g - G;
                 n_far = n_far < 0 ? 0 : n_far;
                 while (G < end_g) issue_group();
+#if defined(DGP_X) && DGP_X == 10
+                if (it + 1 >= 0 && it + 1 < nks) { issue_cells(); n_far += 4; }
+#endif
                 DIAG_STAMP(h1);
                 if (it >= -1) {
                     switch (n_far) {                                     // everything but this iteration's lookahead pieces has landed
@@ -1380,7 +1394,15 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : BM == 256 ? 2 : ((BK =
                         case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
                         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
                         case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+#if defined(DGP_X) && DGP_X == 10
+                        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+                        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+                        default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+#else
                         default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+#endif
                     }
                     DIAG_STAMP(h2);
                     __builtin_amdgcn_s_barrier();
@@ -1486,8 +1508,13 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : BM == 256 ? 2 : ((BK =
                 }
                 if (it >= -1) {
                     if constexpr (!DEEP) {
+#if defined(DGP_X) && DGP_X == 10
+                        if (moreA) { if constexpr (AROWS == 8) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+                        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#else
                         if (moreA) { if constexpr (AROWS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                     } else {
                         // step it + 1 must have landed; what may stay in flight was issued after its cells: the A rows of steps
                         // it + 2 .. min(it + LA, nks - 1) and the cells of steps it + 2 .. min(it + LB, nks - 1), 4 instructions each
@@ -2241,6 +2268,13 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 6 : BM == 256 ? 2 : ((BK =
         d[9] = e1 - e_loop_end;                       // staging of the accumulators (16x16x32 loops) between the K loop and the epilogue
         if constexpr (MODE != 3) { d[3] = eps[0]; d[5] = eps[1]; d[6] = eps[2]; d[8] = eps[3]; }     // (MODE 3: slots 3 / 5 / 6 hold the ring wave's stamps)
         else d[8] = eps[3];
+        unsigned long long rt1;
+        unsigned hwid, xcc;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* tl = p.dbg + 10ull * 65536 + 3ull * blockIdx.x;
+        tl[0] = rt0; tl[1] = rt1; tl[2] = ((unsigned long long)(xcc & 15u) << 16) | (hwid & 0x7F00u);
     }
 #endif
 }
@@ -2553,7 +2587,7 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
     }
 #ifdef DGP_DIAG
     static unsigned long long* dbg_buf = nullptr;
-    if (!dbg_buf) (void)hipMalloc(&dbg_buf, 10 * 8 * 65536);
+    if (!dbg_buf) (void)hipMalloc(&dbg_buf, 13 * 8 * 65536);
     a.dbg = nwg <= 65536 ? dbg_buf : nullptr;
 #endif
     // supertile order (see the kernel): H2 engine, 128-wide tiles, >= 8 column tiles and a weight panel that cannot stay in an XCD's L2
@@ -2596,6 +2630,43 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
                BM, BN, NT, BK, CW, nwg, nks, v[0], v[2], v[4] / nks, v[7] / nks, v[3] / nks, v[5] / nks, v[6] / nks);
         double v8 = 0; for (long long b = 0; b < nwg; ++b) v8 += (double)h[10 * b + 8];
         double v9 = 0; for (long long b = 0; b < nwg; ++b) v9 += (double)h[10 * b + 9];
+        {   // per-CU timeline of the launch: how many workgroups a CU holds over the launch's span, and how long a freed slot stays empty
+            std::vector<unsigned long long> tl(3 * nwg);
+            (void)hipMemcpy(tl.data(), a.dbg + 10ull * 65536, 24 * nwg, hipMemcpyDeviceToHost);
+            unsigned long long t_lo = ~0ull, t_hi = 0;
+            std::vector<std::pair<unsigned long long, std::pair<unsigned long long, int>>> ev;      // (cu key, (time, +1 / -1))
+            double dur = 0; long long nz = 0;
+            for (long long b = 0; b < nwg; ++b) {
+                const unsigned long long s0 = tl[3 * b], s1 = tl[3 * b + 1], k = tl[3 * b + 2];
+                if (!s1 || s1 < s0) continue;
+                ++nz; dur += (double)(s1 - s0);
+                if (s0 < t_lo) t_lo = s0;
+                if (s1 > t_hi) t_hi = s1;
+                ev.push_back({k, {s0, +1}}); ev.push_back({k, {s1, -1}});
+            }
+            std::sort(ev.begin(), ev.end(), [](const auto& x, const auto& y) {
+                return x.first != y.first ? x.first < y.first : x.second.first != y.second.first ? x.second.first < y.second.first : x.second.second < y.second.second; });
+            double res_t[4] = {0, 0, 0, 0}, gap_sum = 0; long long gaps = 0; int ncu = 0;
+            for (size_t i = 0; i < ev.size();) {
+                size_t j = i; while (j < ev.size() && ev[j].first == ev[i].first) ++j;
+                ++ncu;
+                int cnt = 0; unsigned long long tprev = t_lo, last_end = 0; bool pending = false;
+                for (size_t e = i; e < j; ++e) {
+                    const unsigned long long tt = ev[e].second.first;
+                    res_t[cnt > 3 ? 3 : cnt] += (double)(tt - tprev); tprev = tt;
+                    if (ev[e].second.second > 0) { if (pending) { gap_sum += (double)(tt - last_end); ++gaps; pending = false; } ++cnt; }
+                    else { --cnt; last_end = tt; pending = true; }
+                }
+                res_t[0] += (double)(t_hi - tprev);
+                i = j;
+            }
+            const double span = (double)(t_hi - t_lo), tot = span * ncu;
+            if (nz && span > 0)
+                printf("[diag timeline] span %.2f us on %d CUs | workgroup life %.2f us (%.0f shader cycles -> %.2f GHz) | CU time holding 0 / 1 / 2 / 3+ workgroups: %.3f %.3f %.3f %.3f | "
+                       "a freed slot waits %.2f us for its next workgroup (%lld hand-overs)\n",
+                       span / 100.0, ncu, dur / nz / 100.0, v[0] + v[1] + v[2] + v9 / nwg, (v[0] + v[1] + v[2] + v9 / nwg) / (dur / nz * 10.0),
+                       res_t[0] / tot, res_t[1] / tot, res_t[2] / tot, res_t[3] / tot, gaps ? gap_sum / gaps / 100.0 : 0.0, gaps);
+        }
         printf("[diag epilogue, DMA kernels] last MFMAs + staging %.0f | set-up (scale / bias, residual requests) %.0f | chunk 0 %.0f | chunks 1.. %.0f | absmax %.0f (res %d)\n",
                v9 / nwg, v[3], v[5], v[6], v8 / nwg, a.res ? 1 : 0);
     }

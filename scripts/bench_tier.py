@@ -21,6 +21,7 @@ ap.add_argument("--hw", type=int, nargs=2, default=[480, 640])
 ap.add_argument("--depth", type=int, default=50)
 ap.add_argument("--nj", type=int, default=4)
 ap.add_argument("--table", type=str, default="")
+ap.add_argument("--timing-only", action="store_true", help="timing-only ablation builds: the results are garbage, skip the range check")
 args = ap.parse_args()
 H, W = args.hw
 B, NJ = args.batch, args.nj
@@ -32,7 +33,7 @@ out = torch.zeros((B, NJ, 5), device="cuda")
 for _ in range(5):
     net.infer_packed(frames, out)
 torch.cuda.synchronize()
-assert not net.range_status()[0]
+assert args.timing_only or not net.range_status()[0]
 t0 = time.perf_counter()
 for _ in range(args.steps):
     net.infer_packed(frames, out)
