@@ -448,9 +448,16 @@ __device__ __forceinline__ double wave_sum(double v) {
 //             tile to LDS as fp32 (aliases the phase-1 planes)
 //   phase 4   3 x 3 / 2 max over the LDS tile, H2 split with the pool output's scale, two 16-byte stores per 8 channels, range tracking
 // One persistent workgroup per CU (156 KB of LDS) walks the tiles.
+// H1T (round 6; the 16-bit tier's inference pass): TWO workgroups per CU, so that one's GEMM runs under the other's fetch / convert / pool
+// phases.  72 KB each: ONE weight plane (the tier's layers all multiply by the weights' high cells), a 4 x 16 pool tile (9 x 33 conv1
+// pixels, 19 row blocks), and the conv1 tile in LDS as fp16(x * out_scale) -- rounding is monotone, so the maximum of the rounded values
+// is the rounded maximum: the cells are bit-identical to rounding after the pool.  GEMM column 16 j + l15 holds channel 4 l15 + j, so a
+// lane's four accumulators of a pixel are four consecutive channels = one 8-byte LDS write, and a pool thread reads a cell in one 16-byte
+// read.  The range is tracked on the fp32 values in phase 3 (every conv1 pixel of the map lies in some valid window: the same maximum).
 // ------------------------------------------------------------------------------------
 struct StemPoolArgs {
-    const unsigned char* frames;      // [B, H, W, 3]
+    const unsigned char* frames;      // [B, H, W, 3] starts fr_delta bytes behind this (4-byte aligned) address
+    int fr_delta, fr_bytes;           // fr_bytes = fr_delta + B H W 3
     const uint4* wcells;              // [7 kernel rows][4 k-groups][2 planes][64][8 halves]  (launch_pack_h3 of the stem row panel)
     const float* w_absmax;            // its range slots
     const float* bn_scale; const float* bn_bias;
@@ -464,69 +471,100 @@ struct StemPoolArgs {
     int B, H, W, H1, W1, HP, WP, pbh, pbw, tiles_h, tiles_w, ntiles;
 };
 
+template <bool H1T>
 __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolArgs p) {
-    constexpr int PH = 5, PW = 16, SR = 2 * PH + 1, SC = 2 * PW + 1, MS = SR * SC, NRB = (MS + 15) / 16;     // 11, 33, 363, 23
-    constexpr int IR = 2 * SR + 5, IC = 72;                                                                   // 27 x 72 input pixels
-    static_assert(NRB <= 24, "three row blocks per wave");
-    constexpr int WCELLS = 7 * 4 * 2 * 64;
+    constexpr int PH = H1T ? 4 : 5, PW = 16, SR = 2 * PH + 1, SC = 2 * PW + 1, MS = SR * SC, NRB = (MS + 15) / 16;     // 11, 33, 363, 23 (H1T: 9, 33, 297, 19)
+    constexpr int IR = 2 * SR + 5, IC = 72;                                                                   // 27 x 72 input pixels (H1T: 23 x 72)
+    static_assert(NRB <= 24 && NRB > 16, "two or three row blocks per wave");
+    constexpr int NPL = H1T ? 1 : 2;                                                                          // weight planes in LDS
+    constexpr int WCELLS = 7 * 4 * NPL * 64;
     constexpr int LDC = 68;                                                                                   // floats per conv1 pixel in LDS
+    constexpr int LDH = 72;                                                                                   // H1T: halves per conv1 pixel
     typedef float floatx4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* sW = reinterpret_cast<uint4*>(smem);
     char* sU = smem + WCELLS * 16;
     uint2* sHi = reinterpret_cast<uint2*>(sU);                     // [IR][IC]
     float* sC = reinterpret_cast<float*>(sU);                      // [NRB * 16][LDC]   (aliases the planes)
+    _Float16* sCh = reinterpret_cast<_Float16*>(sU);               // H1T: [NRB * 16][LDH]
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, g = lane >> 4;
-    for (int i = t; i < WCELLS; i += 512) sW[i] = p.wcells[i];
+    for (int i = t; i < WCELLS; i += 512) {
+        if constexpr (H1T) sW[i] = p.wcells[((i >> 6) * 2) * 64 + 4 * (i & 15) + ((i >> 4) & 3)];      // high plane; slot 16 j + l15 <- channel 4 l15 + j
+        else sW[i] = p.wcells[i];
+    }
     const float post = 1.f / pow2_scale_for(p.w_absmax, lane);
     const float oscale = p.out_prev ? shadow_scale_for(p.out_prev, lane) : p.out_scale;
     const int nrb = wave < NRB - 16 ? 3 : 2;                       // row blocks wave, wave + 8, wave + 16 (23 blocks: 3 each, wave 7: 2)
     float sc4[4][1], bi4[4][1];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { sc4[j][0] = p.bn_scale[16 * j + l15] * post; bi4[j][0] = p.bn_bias[16 * j + l15]; }
+    for (int j = 0; j < 4; ++j) {
+        const int ch = H1T ? 4 * l15 + j : 16 * j + l15;
+        sc4[j][0] = p.bn_scale[ch] * post; bi4[j][0] = p.bn_bias[ch];
+    }
     float amax = 0.f;
-    // the next tile's input pixels travel in registers: their global loads are issued before the GEMM and land under it
-    constexpr int NPX = (IR * IC + 511) / 512;
-    unsigned pix[NPX][3];
+    // the next tile's input pixels travel in registers: their global loads are issued before the GEMM and land under it.  A thread owns FOUR
+    // consecutive pixels of one input row (12 bytes): ONE aligned 16-byte buffer load + three v_alignbyte (round 6; 12 byte loads before).
+    // Bytes of rows / columns outside the frame are whatever the batch holds there (or zeros past its ends): phase 1 masks those pixels.
+    constexpr int NG = IC / 4;                                      // four-pixel groups per input row
+    static_assert(IC % 4 == 0 && IR * NG <= 512, "one group per thread");
+    const int fr_r = t / NG, fr_c = 4 * (t - fr_r * NG);           // this thread's row and first column inside the tile's input window
+    const bool fr_on = t < IR * NG;
+    const __amdgpu_buffer_rsrc_t rs_fr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.frames), 0, p.fr_bytes & ~3, 0x00020000);
+    // (a second register set = two tiles of lookahead measured no gain: phase 1 does not wait for the frame bytes)
+    unsigned pix[3] = {0u, 0u, 0u};                                 // byte 3 k + c = channel c of pixel k
     auto fetch = [&](int tile) {
         const int n = tile / (p.tiles_h * p.tiles_w), rem = tile - n * (p.tiles_h * p.tiles_w);
         const int ir0 = 2 * (2 * (rem / p.tiles_w) * PH - p.pbh) - 3, ic0 = 2 * (2 * (rem % p.tiles_w) * PW - p.pbw) - 3;
-        const unsigned char* fr = p.frames + (size_t)n * p.H * p.W * 3;
+        const int gr = ir0 + fr_r, gc = ic0 + fr_c;
+        if (!fr_on || (unsigned)gr >= (unsigned)p.H) return;       // (masked in phase 1)
+        const int start = ((n * p.H + gr) * p.W + gc) * 3 + p.fr_delta;
+        if (gc >= 0 && (start & ~3) + 16 <= (p.fr_bytes & ~3)) {
+            const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs_fr, start & ~3, 0, 0);
+            const unsigned sh = (unsigned)start & 3u;
+            pix[0] = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
+            pix[1] = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
+            pix[2] = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
+        } else {                                                    // the group straddles the frame's left edge or the batch's last bytes: byte loads of the pixels inside
+            unsigned b[12];
 #pragma unroll
-        for (int u = 0; u < NPX; ++u) {
-            const int q = t + 512 * u;
-            const int r = q / IC, c = q - r * IC;
-            const int gr = ir0 + r, gc = ic0 + c;
-            const bool ok = q < IR * IC && (unsigned)gr < (unsigned)p.H && (unsigned)gc < (unsigned)p.W;
-            const unsigned char* px = fr + ((size_t)(ok ? gr : 0) * p.W + (ok ? gc : 0)) * 3;
-            pix[u][0] = px[0]; pix[u][1] = px[1]; pix[u][2] = px[2];
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) b[3 * k + c] = (gc + k >= 0 && start + 3 * k + c < p.fr_bytes) ? (unsigned)p.frames[start + 3 * k + c] : 0u;
+#pragma unroll
+            for (int w = 0; w < 3; ++w) pix[w] = b[4 * w] | (b[4 * w + 1] << 8) | (b[4 * w + 2] << 16) | (b[4 * w + 3] << 24);
         }
     };
 #ifndef DGP_SX
 #define DGP_SX 0      // timing-only ablations of the phases (scripts/ablate_stem.sh; results are garbage): 1 no input fetch, 2 no phase 1,
 #endif                // 4 no MFMAs, 8 no phase-3 tile store, 16 no pooling reads, 32 no global stores
     if (!(DGP_SX & 1) && (int)blockIdx.x < p.ntiles) fetch(blockIdx.x);
-    if (DGP_SX & 1) for (int u = 0; u < NPX; ++u) { pix[u][0] = t; pix[u][1] = u; pix[u][2] = lane; }
+    if (DGP_SX & 1) { pix[0] = t; pix[1] = wave; pix[2] = lane; }
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int n = tile / (p.tiles_h * p.tiles_w), rem = tile - n * (p.tiles_h * p.tiles_w);
         const int ph0 = (rem / p.tiles_w) * PH, pw0 = (rem % p.tiles_w) * PW;
         const int r0 = 2 * ph0 - p.pbh, c0 = 2 * pw0 - p.pbw;      // first conv1 pixel of the tile
         const int ir0 = 2 * r0 - 3, ic0 = 2 * c0 - 3;              // first input pixel
         // ---- phase 1: input pixels (already in registers) -> fp16 high / low planes
+        if (!(DGP_SX & 2) && fr_on) {
+            const int gr = ir0 + fr_r, gc = ic0 + fr_c;
+            const bool rok = (unsigned)gr < (unsigned)p.H;
+            unsigned w[8];
 #pragma unroll
-        for (int u = 0; u < NPX; ++u) {
-            const int q = t + 512 * u;
-            if (!(DGP_SX & 2) && q < IR * IC) {
-                const int r = q / IC, c = q - r * IC;
-                const int gr = ir0 + r, gc = ic0 + c;
+            for (int k = 0; k < 4; ++k) {
+                // bytes 3 k .. 3 k + 2 of the 12
+                const unsigned b0 = (pix[(3 * k) >> 2] >> (8 * ((3 * k) & 3))) & 255u, b1 = (pix[(3 * k + 1) >> 2] >> (8 * ((3 * k + 1) & 3))) & 255u,
+                               b2 = (pix[(3 * k + 2) >> 2] >> (8 * ((3 * k + 2) & 3))) & 255u;
                 half2v x01 = {(_Float16)0.f, (_Float16)0.f}, x23 = x01;
-                if ((unsigned)gr < (unsigned)p.H && (unsigned)gc < (unsigned)p.W) {
-                    x01 = half2v{(_Float16)((float)pix[u][0] - p.mean0), (_Float16)((float)pix[u][1] - p.mean1)};
-                    x23 = half2v{(_Float16)((float)pix[u][2] - p.mean2), (_Float16)1.f};
+                if (rok && (unsigned)(gc + k) < (unsigned)p.W) {
+                    x01 = half2v{(_Float16)((float)b0 - p.mean0), (_Float16)((float)b1 - p.mean1)};
+                    x23 = half2v{(_Float16)((float)b2 - p.mean2), (_Float16)1.f};
                 }
-                sHi[q] = make_uint2(__builtin_bit_cast(unsigned, x01), __builtin_bit_cast(unsigned, x23));
+                w[2 * k] = __builtin_bit_cast(unsigned, x01); w[2 * k + 1] = __builtin_bit_cast(unsigned, x23);
             }
+            uint4* dst = reinterpret_cast<uint4*>(sHi + fr_r * IC + fr_c);          // 4 pixels x 8 bytes, 32-byte aligned
+            dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
         }
         __syncthreads();
         if (!(DGP_SX & 1) && tile + (int)gridDim.x < p.ntiles) fetch(tile + gridDim.x);
@@ -549,8 +587,8 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
             uint4 bh[4], bl[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                bh[j] = sW[((kh * 4 + g) * 2 + 0) * 64 + 16 * j + l15];
-                bl[j] = sW[((kh * 4 + g) * 2 + 1) * 64 + 16 * j + l15];
+                bh[j] = sW[((kh * 4 + g) * NPL + 0) * 64 + 16 * j + l15];
+                if constexpr (!H1T) bl[j] = sW[((kh * 4 + g) * NPL + 1) * 64 + 16 * j + l15];
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -558,8 +596,9 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
                     const uint4 ah = *reinterpret_cast<const uint4*>(sHi + abase[i] + kh * IC);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if (DGP_SX & 4) { acc[i][j][0] += __builtin_bit_cast(float, ah.x ^ bl[j].y ^ bh[j].z); continue; }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah), __builtin_bit_cast(half8, bl[j]), acc[i][j], 0, 0, 0);
+                        if (DGP_SX & 4) { acc[i][j][0] += __builtin_bit_cast(float, ah.x ^ bh[j].y ^ bh[j].z); continue; }
+                        if constexpr (!H1T)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah), __builtin_bit_cast(half8, bl[j]), acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
                     }
                 }
@@ -575,6 +614,21 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
                     const int m = 16 * (wave + 8 * i) + 4 * g + r;
                     const int rl = m / SC, cl = m - rl * SC;
                     const bool ok = m < MS && (unsigned)(r0 + rl) < (unsigned)p.H1 && (unsigned)(c0 + cl) < (unsigned)p.W1;
+                    if constexpr (H1T) {
+                        float v4[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v4[j] = ok ? fmaxf(acc[i][j][r] * sc4[j][0] + bi4[j][0], 0.f) : 0.f;
+                            amax = fmaxf(amax, v4[j]);
+                        }
+                        unsigned h01, h23;                         // h1_pack8's rounding: fp16(scale * v)
+                        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h01) : "v"(oscale), "v"(v4[0]));
+                        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(oscale), "v"(v4[1]));
+                        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h23) : "v"(oscale), "v"(v4[2]));
+                        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h23) : "v"(oscale), "v"(v4[3]));
+                        if (!(DGP_SX & 8)) *reinterpret_cast<uint2*>(sCh + m * LDH + 4 * l15) = make_uint2(h01, h23);
+                        continue;
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float v = fmaxf(acc[i][j][r] * sc4[j][0] + bi4[j][0], 0.f);
@@ -589,6 +643,22 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
         for (int q = t; q < PH * PW * 8; q += 512) {
             const int pp = q >> 3, cg = q & 7;
             const int ph = pp / PW, pw = pp - ph * PW;
+            if constexpr (H1T) {
+                half8 mx = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        if (DGP_SX & 16) { mx[0] = (_Float16)(float)(a + b + q); continue; }
+                        mx = __builtin_elementwise_max(mx, *reinterpret_cast<const half8*>(sCh + ((2 * ph + a) * SC + 2 * pw + b) * LDH + 8 * cg));
+                    }
+                if (ph0 + ph < p.HP && pw0 + pw < p.WP) {
+                    const size_t cell = (((size_t)n * p.HP + ph0 + ph) * p.WP + pw0 + pw) * 8 + cg;
+                    if (!(DGP_SX & 32)) reinterpret_cast<uint4*>(p.out)[cell] = __builtin_bit_cast(uint4, mx);
+                    else amax = fmaxf(amax, (float)mx[0]);
+                }
+                continue;
+            }
             float v[8];
             unsigned kk[8];
 #pragma unroll
@@ -638,28 +708,40 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
 hipError_t launch_stem_pool_fused(const unsigned char* frames, int B, int H, int W, const void* wcells, const float* w_absmax,
                                   const float* bn_scale, const float* bn_bias, float m0, float m1, float m2, float out_scale,
                                   float* out, float* out_absmax, hipStream_t s, int out_h1, const float* out_prev, unsigned char* idx) {
+    if ((long long)B * H * W * 3 >= (1LL << 31)) return hipErrorInvalidValue;      // (the frame batch is one buffer resource: 32-bit byte offsets)
     StemPoolArgs a{};
     a.out_h1 = out_h1; a.out_prev = out_prev; a.idx = idx;
-    a.frames = frames; a.wcells = reinterpret_cast<const uint4*>(wcells); a.w_absmax = w_absmax; a.bn_scale = bn_scale; a.bn_bias = bn_bias;
+    a.fr_delta = (int)(reinterpret_cast<uintptr_t>(frames) & 3u); a.frames = frames - a.fr_delta; a.fr_bytes = a.fr_delta + B * H * W * 3;
+    a.wcells = reinterpret_cast<const uint4*>(wcells); a.w_absmax = w_absmax; a.bn_scale = bn_scale; a.bn_bias = bn_bias;
     a.mean0 = roundf(m0); a.mean1 = roundf(m1); a.mean2 = roundf(m2); a.out_scale = out_scale; a.out = out; a.out_absmax = out_absmax;
     a.B = B; a.H = H; a.W = W; a.H1 = (H + 1) / 2; a.W1 = (W + 1) / 2;
     a.HP = (a.H1 + 1) / 2; a.WP = (a.W1 + 1) / 2;
     const int pth = ((a.HP - 1) * 2 + 3 - a.H1) > 0 ? ((a.HP - 1) * 2 + 3 - a.H1) : 0;
     const int ptw = ((a.WP - 1) * 2 + 3 - a.W1) > 0 ? ((a.WP - 1) * 2 + 3 - a.W1) : 0;
     a.pbh = pth / 2; a.pbw = ptw / 2;
-    a.tiles_h = (a.HP + 4) / 5; a.tiles_w = (a.WP + 15) / 16; a.ntiles = B * a.tiles_h * a.tiles_w;
-    constexpr size_t smem = (size_t)7 * 4 * 2 * 64 * 16 + (size_t)23 * 16 * 68 * 4;
-    static bool attr_dev[16] = {};
-    bool& attr = attr_dev[dgp_device_slot()];
+    // the two-workgroup variant: the 16-bit tier's inference pass (the trainer's pool records the first maximum of the fp32 values)
+    static const int h1t_env = dgp_tune("DGP_STEM_H1T", 1);
+    const bool h1t = h1t_env && out_h1 && !idx;
+    const int ph = h1t ? 4 : 5;
+    a.tiles_h = (a.HP + ph - 1) / ph; a.tiles_w = (a.WP + 15) / 16; a.ntiles = B * a.tiles_h * a.tiles_w;
+    const size_t smem = h1t ? (size_t)7 * 4 * 64 * 16 + (size_t)19 * 16 * 72 * 2 : (size_t)7 * 4 * 2 * 64 * 16 + (size_t)23 * 16 * 68 * 4;
+    static bool attr_dev[16][2] = {};
+    bool& attr = attr_dev[dgp_device_slot()][h1t ? 1 : 0];
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(h1t ? reinterpret_cast<const void*>(stem_pool_fused_kernel<true>) : reinterpret_cast<const void*>(stem_pool_fused_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr = true;
     }
     static int n_cu = 0;
     if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
-    const int grid = a.ntiles < n_cu ? a.ntiles : n_cu;
-    hipLaunchKernelGGL(stem_pool_fused_kernel, dim3((unsigned)grid), dim3(512), smem, s, a);
+    if (h1t) {
+        const int grid = a.ntiles < 2 * n_cu ? a.ntiles : 2 * n_cu;
+        hipLaunchKernelGGL(stem_pool_fused_kernel<true>, dim3((unsigned)grid), dim3(512), smem, s, a);
+    } else {
+        const int grid = a.ntiles < n_cu ? a.ntiles : n_cu;
+        hipLaunchKernelGGL(stem_pool_fused_kernel<false>, dim3((unsigned)grid), dim3(512), smem, s, a);
+    }
     return hipGetLastError();
 }
 

@@ -650,6 +650,30 @@ def test_inference_net_changes_frame_size(eng):
         assert np.array_equal(idx.cpu().numpy(), ref["idx"])
 
 
+@pytest.mark.parametrize("tier", ["parity", "f16"])
+@pytest.mark.parametrize("hw", [(75, 83), (64, 97), (61, 130)])
+def test_root_block_reads_frames_at_any_byte_alignment(eng, hw, tier):
+    """The root block fetches four pixels (12 bytes) per thread with one aligned 16-byte load: a frame batch that starts at any byte
+    offset, rows of any length (W * 3 not a multiple of 4) and the batch's last bytes must give the bits of an aligned copy."""
+    from deepgraphpose_amd.synthetic import make_frames, make_weights
+    h, w = hw
+    wts = make_weights(50, 2, False, seed=12, head_std=0.05)
+    fr = make_frames(3, h, w, 2, seed=13)
+    net = eng.DGPNet(50, 2, h, w, max_batch=3, tier=tier)
+    net.load_weights(wts)
+    base = torch.from_numpy(fr).cuda()
+    ref = [x.clone() for x in net.infer(base, 1.0, 1)]
+    n = fr.size
+    for delta in (1, 2, 3):
+        buf = torch.zeros(n + 8, dtype=torch.uint8, device="cuda")
+        buf[delta:delta + n] = base.reshape(-1)
+        view = buf[delta:delta + n].view(3, h, w, 3)
+        assert view.data_ptr() % 4 == (base.data_ptr() + delta) % 4
+        got = net.infer(view, 1.0, 1)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b), (hw, tier, delta)
+
+
 # ---------------------------------------------------------------------------- motion energy (8(f) N4)
 @pytest.mark.parametrize("shape", [(1, 8, 8, 3), (5, 17, 23, 3), (40, 48, 64, 3), (19, 31, 37, 3), (33, 480, 640, 3)])
 def test_motion_energy_is_bit_exact(eng, shape):
