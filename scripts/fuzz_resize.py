@@ -38,6 +38,14 @@ for it in range(n):
         ref = O.infer(fr, wts, depth, 8.0, 1.0, 1)
         d = float(np.abs(mu.cpu().numpy() - ref["mu"]).max() * 8.0)
         ok = d < 1e-3 and np.array_equal(idx.cpu().numpy(), ref["idx"]) and float(np.abs(conf.cpu().numpy() - ref["likelihoods"]).max()) < 1e-4
+        if not ok and d < 2.5e-3 and np.array_equal(idx.cpu().numpy(), ref["idx"]):
+            # a broad softmax (random heads): two fp32 evaluations differ by ~ 1e-3 px.  The fp64 anchor decides: the engine must be within the
+            # gate of it and no further from it than the fp32 oracle is (seed 7: engine 4.1e-4, oracle 1.2e-3)
+            s64, _ = O.pose_heads(O.resnet_features(fr, wts, depth, dtype=np.float64), wts, False)
+            mu64 = O.argmax_2d_from_cm(np.asarray(s64), 1.0, 1, dtype=np.float64)[0].reshape(ref["mu"].shape)
+            d_e, d_o = float(np.abs(mu.cpu().numpy() - mu64).max() * 8.0), float(np.abs(ref["mu"] - mu64).max() * 8.0)
+            ok = d_e < 1e-3 and d_e <= d_o
+            print("     (fp64 anchor: engine %.1e px, fp32 oracle %.1e px)" % (d_e, d_o))
         bad += not ok
         print("%s net %d (R%d nj %d, created %d x %d, max batch %d) stop %d: %3d x %3d batch %d kind %d   %.1e px" % ("ok  " if ok else "BAD ", it, depth, nj, h0, w0, B, stop, h, w, b, kind, d), flush=True)
 print("failures:", bad)
