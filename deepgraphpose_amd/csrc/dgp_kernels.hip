@@ -2633,6 +2633,13 @@ static hipError_t launch_conv_split(ConvArgs a, hipStream_t s) {
         {   // per-CU timeline of the launch: how many workgroups a CU holds over the launch's span, and how long a freed slot stays empty
             std::vector<unsigned long long> tl(3 * nwg);
             (void)hipMemcpy(tl.data(), a.dbg + 10ull * 65536, 24 * nwg, hipMemcpyDeviceToHost);
+            if (const char* dump = getenv("DGP_DIAG_DUMP")) {      // raw (start, end, CU) of every workgroup of every launch, for scripts/cu_phase.py
+                if (FILE* f = fopen(dump, "a")) {
+                    fprintf(f, "# launch %dx%d tiles %lld K-steps %d\n", BM, BN, nwg, nks);
+                    for (long long b = 0; b < nwg; ++b) fprintf(f, "%llu %llu %llu\n", tl[3 * b], tl[3 * b + 1], tl[3 * b + 2]);
+                    fclose(f);
+                }
+            }
             unsigned long long t_lo = ~0ull, t_hi = 0;
             std::vector<std::pair<unsigned long long, std::pair<unsigned long long, int>>> ev;      // (cu key, (time, +1 / -1))
             double dur = 0; long long nz = 0;
