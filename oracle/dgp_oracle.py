@@ -20,7 +20,10 @@ PINNING STATUS
     What CAN be pinned to TensorFlow is (round 6, tests/test_oracle_cpu.py "TF / TF-slim's
     OWN published known answers"): the expected matrices TF's own unit tests assert for
     slim.conv2d / resnet_utils.conv2d_same / subsample (resnet_v1_test.py
-    testConv2DSameEven / Odd, testSubsample*), conv2d_transpose SAME stride 2
+    testConv2DSameEven / Odd, testSubsample*), tf.nn.conv2d itself (conv_ops_test.py
+    Conv2DTest: 1x1 / 2x2 / 1x2 filters, stride 2 VALID and SAME, kernel smaller than
+    the stride, kernel = input size; tests/_tf_kat.py -- each vector is first re-derived
+    from the definition in float64 loops), conv2d_transpose SAME stride 2
     (conv2d_transpose_test.py testConv2DTransposeSame), max-pool SAME (pooling_ops_test.py
     _testMaxPoolSamePadding), the stack_blocks_dense endpoint
     shapes, and slim's atrous invariant (output_stride 16 subsampled == nominal stride 32)

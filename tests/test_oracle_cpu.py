@@ -372,6 +372,18 @@ def test_slim_atrous_invariant_on_the_oracle():
         assert np.abs(f16_[:, ::2, ::2] - f32_).max() <= 1e-4 * scale + 1e-4
 
 
+@pytest.mark.parametrize("case", __import__("_tf_kat").TF_CONV2D_KNOWN_ANSWERS, ids=lambda c: c[0])
+def test_tf_conv2d_known_answers(case):
+    """tensorflow/python/kernel_tests/conv_ops_test.py Conv2DTest (tests/_tf_kat.py holds the vectors): the published expected outputs agree
+    with the definition evaluated in float64 loops (so a mis-remembered vector cannot pin anything), and the oracle's conv2d -- HWIO
+    filters, no kernel flip, VALID / SAME with the extra pixel AFTER -- reproduces them exactly."""
+    import _tf_kat as K
+    name, in_shape, f_shape, stride, padding, expected = case
+    np.testing.assert_array_equal(K.brute_force(in_shape, f_shape, stride, padding).reshape(-1), np.asarray(expected, np.float64))
+    y = O.conv2d(_nchw(K.tf_test_values(in_shape)), K.tf_test_values(f_shape), stride, 1, padding)
+    np.testing.assert_array_equal(y.permute(0, 2, 3, 1).reshape(-1).numpy(), np.asarray(expected, np.float32))
+
+
 def test_tf_max_pool_same_known_answer():
     """tensorflow/python/kernel_tests/pooling_ops_test.py PoolingTest._testMaxPoolSamePadding: input 1 .. 18 as [1, 2, 3, 3] (NHWC), 2 x 2 window,
     stride 2, SAME -> [13, 14, 15, 16, 17, 18]: the odd width is padded AFTER (the second window holds column 2 alone) and padding never wins.

@@ -650,6 +650,49 @@ def test_inference_net_changes_frame_size(eng):
         assert np.array_equal(idx.cpu().numpy(), ref["idx"])
 
 
+def _pad_cin(x, w):
+    """the conv kernel takes Cin = 4 * 2^k and Cout % 4 == 0: zero input channels / filter rows and zero filter columns up to that (the
+    sums do not change; the callers read the first Cout columns back)"""
+    c, co = x.shape[3], w.shape[3]
+    cp = 4
+    while cp < c:
+        cp *= 2
+    cop = (co + 3) // 4 * 4
+    xp = np.zeros(x.shape[:3] + (cp,), np.float32); xp[..., :c] = x
+    wp = np.zeros(w.shape[:2] + (cp, cop), np.float32); wp[:, :, :c, :co] = w
+    return xp, wp
+
+
+def test_tf_conv2d_known_answers_through_the_c_abi(eng):
+    """TensorFlow's own conv2d known answers (conv_ops_test.py Conv2DTest, tests/_tf_kat.py) and TF-slim's conv2d_same ones
+    (resnet_v1_test.py testConv2DSameEven / Odd) through the PRODUCT's conv kernel (dgp_conv2d over the C-ABI): HWIO filters, no kernel
+    flip, VALID, TF's SAME (extra pixel after) and slim's explicit symmetric padding -- exact, the values are small integers."""
+    import _tf_kat as K
+    for name, in_shape, f_shape, stride, padding, expected in K.TF_CONV2D_KNOWN_ANSWERS:
+        oh, pt, _ = K.tf_out_and_pads(in_shape[1], f_shape[0], stride, padding)
+        ow, pl, _ = K.tf_out_and_pads(in_shape[2], f_shape[1], stride, padding)
+        x, w = _pad_cin(K.tf_test_values(in_shape), K.tf_test_values(f_shape))
+        y = eng.conv2d(torch.from_numpy(x).cuda(), w, stride, 1, pt, pl, out_hw=(oh, ow))
+        assert y.shape[:3] == (in_shape[0], oh, ow), name
+        np.testing.assert_array_equal(y.cpu().numpy()[..., :f_shape[3]].reshape(-1), np.asarray(expected, np.float32), err_msg=name)
+        assert not y.cpu().numpy()[..., f_shape[3]:].any(), name
+    for n, dense, strided_same, strided_tf in (
+            (4, [[14, 28, 43, 26], [28, 48, 66, 37], [43, 66, 84, 46], [26, 37, 46, 22]], [[14, 43], [43, 84]], [[48, 37], [37, 22]]),
+            (5, [[14, 28, 43, 58, 34], [28, 48, 66, 84, 46], [43, 66, 84, 102, 55], [58, 84, 102, 120, 64], [34, 46, 55, 64, 30]],
+             [[14, 43, 34], [43, 84, 55], [34, 55, 30]], [[14, 43, 34], [43, 84, 55], [34, 55, 30]])):
+        g = (np.arange(n).reshape(n, 1) + np.arange(n).reshape(1, n)).astype(np.float32)           # create_test_input: x[i, j] = i + j
+        x, w = _pad_cin(g.reshape(1, n, n, 1), (np.arange(3).reshape(3, 1) + np.arange(3).reshape(1, 3)).astype(np.float32).reshape(3, 3, 1, 1))
+        x = torch.from_numpy(x).cuda()
+        y1 = eng.conv2d(x, w, 1, 1, 1, 1, out_hw=(n, n))                                           # slim.conv2d(stride 1, SAME)
+        np.testing.assert_array_equal(y1.cpu().numpy()[0, :, :, 0], np.asarray(dense, np.float32))
+        o = (n + 1) // 2
+        y3 = eng.conv2d(x, w, 2, 1, 1, 1, out_hw=(o, o))                                           # resnet_utils.conv2d_same(stride 2): pad 1 before
+        np.testing.assert_array_equal(y3.cpu().numpy()[0, :, :, 0], np.asarray(strided_same, np.float32))
+        _, pt, _ = K.tf_out_and_pads(n, 3, 2, "SAME")
+        y4 = eng.conv2d(x, w, 2, 1, pt, pt, out_hw=(o, o))                                         # slim.conv2d(stride 2, SAME): TF's own padding
+        np.testing.assert_array_equal(y4.cpu().numpy()[0, :, :, 0], np.asarray(strided_tf, np.float32))
+
+
 @pytest.mark.parametrize("tier", ["parity", "f16"])
 @pytest.mark.parametrize("hw", [(75, 83), (64, 97), (61, 130)])
 def test_root_block_reads_frames_at_any_byte_alignment(eng, hw, tier):
