@@ -37,7 +37,22 @@ for k in range(n):
             agree = float((idx.cpu().numpy() == ref["idx"]).all(-1).mean())
             ok = e_sc < 1e-2 and e_lr < 2e-2 and e_mu < (0.5 if depth == 101 else 0.25) and agree >= 0.85 and not net.range_status()[0]
         else:
-            ok = e_sc < 1e-4 and e_lr < 1e-4 and e_mu < 1e-3 and np.array_equal(idx.cpu().numpy(), ref["idx"]) and not net.range_status()[0]
+            # Index differences that are accepted, and only these: (a) the window is [floor(mu), ceil(mu) + 1): where a coordinate lies within the
+            # coordinate gate (1e-3 px = 1.25e-4 cells) of an integer two evaluations may floor / ceil differently; (b) the reference takes the FIRST
+            # maximum of the fp32 value e^x / (e^x + 1) (eval.py:335-340), which is 1 - 2^-24 k for logits above ~ 15: cells whose values are within two
+            # units in the last place of each other tie or not by the last bit of expf (seed 8: logits 16.0 / 16.9 in one window, R101, random heads)
+            idx_e, mu_ref = idx.cpu().numpy(), ref["mu"]
+            differ = (idx_e != ref["idx"]).any(-1)
+            on_edge = (np.abs(mu_ref - np.round(mu_ref)) < 1.5e-4).any(-1)
+            sat_tie = np.zeros_like(differ)
+            for b, j in np.argwhere(differ):
+                xe, xo = np.float32(s_ref[b, idx_e[b, j, 0], idx_e[b, j, 1], j]), np.float32(s_ref[b, ref["idx"][b, j, 0], ref["idx"][b, j, 1], j])
+                se, so = np.exp(xe) / (np.exp(xe) + np.float32(1)), np.exp(xo) / (np.exp(xo) + np.float32(1))
+                sat_tie[b, j] = abs(float(se) - float(so)) <= 2.0 ** -23
+            if differ.any():
+                print("   %d window indices differ: %d where mu is within 1.5e-4 cells of an integer, %d saturated ties of the fp32 sigmoid" % (
+                    int(differ.sum()), int((differ & on_edge).sum()), int((differ & sat_tie).sum())))
+            ok = e_sc < 1e-4 and e_lr < 1e-4 and e_mu < 1e-3 and not (differ & ~on_edge & ~sat_tie).any() and not net.range_status()[0]
     except Exception as e:      # noqa: BLE001
         ok, e_sc, e_lr, e_mu = False, -1, -1, -1
         print("   exception:", repr(e)[:200])
