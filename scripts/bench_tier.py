@@ -21,6 +21,7 @@ ap.add_argument("--hw", type=int, nargs=2, default=[480, 640])
 ap.add_argument("--depth", type=int, default=50)
 ap.add_argument("--nj", type=int, default=4)
 ap.add_argument("--table", type=str, default="")
+ap.add_argument("--offset-ms", type=float, default=0.0, help="two streams: hold the second engine's stream back once by this long (do the two batches in flight run the same layers at the same time?)")
 ap.add_argument("--timing-only", action="store_true", help="timing-only ablation builds: the results are garbage, skip the range check")
 args = ap.parse_args()
 H, W = args.hw
@@ -49,12 +50,15 @@ for i in range(6):
 pipe.join()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
+if args.offset_ms > 0:
+    with torch.cuda.stream(pipe.streams[1]):
+        torch.cuda._sleep(int(args.offset_ms * 1e-3 * 100e6))      # (ROCm: wall-clock ticks of 100 MHz)
 for i in range(args.steps):
     pipe.submit(frames, outs[i & 1])
 pipe.join()
 torch.cuda.synchronize()
 t1 = time.perf_counter()
-ms2 = (t1 - t0) / args.steps * 1e3
+ms2 = ((t1 - t0) * 1e3 - args.offset_ms) / args.steps
 print("tier %s two streams: %.3f ms per step, %.0f frames/s" % (args.tier, ms2, B / ms2 * 1e3))
 net.profile_begin(3)
 for _ in range(3):
