@@ -1,7 +1,8 @@
 """Random whole-net configurations (frame size, bodyparts, batch, locref) against the CPU oracle.  --f16: the 16-bit tier
 (H1 cells, its chain / unit kernels) inside ITS band (scoremap 1e-2 of the range -- measured 1.2-1.9e-3 --, 0.25 px -- small maps with a broad softmax amplify:
 0.15-0.36 px on 12 x 36 / 16 x 44 maps of ResNet-101 (with and without the fused kernels), bound 0.5 there --, >= 85 % of the window indices) instead of the parity gate.
-Usage: python scripts/fuzz_net.py [n] [seed] [--f16]"""
+Round 6: the 16-bit tier's criteria are tied to what produces them (see the code): scoremap inside the band, the read-out exact on the engine's own scoremap,
+index flips only between cells the oracle itself holds within twice the scoremap error.   Usage: python scripts/fuzz_net.py [n] [seed] [--f16]"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -34,8 +35,30 @@ for k in range(n):
         e_lr = np.abs(lr - l_ref).max() / max(np.abs(l_ref).max(), 1e-30) if loc else 0.0
         e_mu = np.abs(mu.cpu().numpy() - ref["mu"]).max() * 8.0
         if F16:
-            agree = float((idx.cpu().numpy() == ref["idx"]).all(-1).mean())
-            ok = e_sc < 1e-2 and e_lr < 2e-2 and e_mu < (0.5 if depth == 101 else 0.25) and agree >= 0.85 and not net.range_status()[0]
+            # the tier's band is a band on the SCOREMAP (2-byte operands); coordinates and indices follow from it through a read-out that is exact:
+            # (a) the oracle's read-out of the ENGINE's scoremap must give the engine's coordinates (two fp32 evaluations of the same input);
+            # (b) a window index may differ from the oracle's only where the oracle's own logits at the two cells lie within twice the
+            #     scoremap error of each other (or tie at the saturated fp32 sigmoid); (c) a loose sanity bound on the coordinates themselves
+            #     (small broad maps amplify: seed 9, ResNet-101 178 x 101 -> a 23 x 13 map, 0.58 px from a scoremap error of 1.7e-3 of the range)
+            idx_e, mu_e = idx.cpu().numpy(), mu.cpu().numpy()
+            mu_ro = O.argmax_2d_from_cm(sc, 1.0, 1)[0].reshape(mu_e.shape)
+            e_ro = float(np.abs(mu_e - mu_ro).max() * 8.0)
+            abs_err = float(np.abs(sc - s_ref).max())
+            flips_ok = True
+            edge_tol = max(1.5e-4, 1.5 * e_mu / 8.0)                              # (the window's floor / ceil flips where a coordinate is this close to an integer)
+            for b, j in np.argwhere((idx_e != ref["idx"]).any(-1)):
+                xe, xo = np.float32(s_ref[b, idx_e[b, j, 0], idx_e[b, j, 1], j]), np.float32(s_ref[b, ref["idx"][b, j, 0], ref["idx"][b, j, 1], j])
+                se, so = np.exp(xe) / (np.exp(xe) + np.float32(1)), np.exp(xo) / (np.exp(xo) + np.float32(1))
+                near = abs(float(xe) - float(xo)) <= 2.0 * abs_err or abs(float(se) - float(so)) <= 2.0 ** -23
+                edge = bool((np.abs(ref["mu"][b, j] - np.round(ref["mu"][b, j])) < edge_tol).any())
+                inside = (np.abs(idx_e[b, j] - ref["idx"][b, j]) <= 2).all()      # both windows hang on coordinates that differ by < 1 cell
+                if not ((near or edge) and inside):
+                    flips_ok = False
+                    print("   index (%d, %d): engine %s oracle %s, oracle logits %.6g / %.6g (scoremap error %.2g), mu %s" % (
+                        b, j, idx_e[b, j], ref["idx"][b, j], xe, xo, abs_err, ref["mu"][b, j]))
+            ok = e_sc < 1e-2 and e_lr < 2e-2 and e_ro < 2.5e-3 and flips_ok and e_mu < 1.0 and not net.range_status()[0]
+            if e_mu >= (0.5 if depth == 101 else 0.25):
+                print("   coordinates %.2g px from the oracle; the oracle's read-out of the engine's scoremap is %.1e px from the engine's" % (e_mu, e_ro))
         else:
             # Index differences that are accepted, and only these: (a) the window is [floor(mu), ceil(mu) + 1): where a coordinate lies within the
             # coordinate gate (1e-3 px = 1.25e-4 cells) of an integer two evaluations may floor / ceil differently; (b) the reference takes the FIRST
@@ -52,7 +75,16 @@ for k in range(n):
             if differ.any():
                 print("   %d window indices differ: %d where mu is within 1.5e-4 cells of an integer, %d saturated ties of the fp32 sigmoid" % (
                     int(differ.sum()), int((differ & on_edge).sum()), int((differ & sat_tie).sum())))
-            ok = e_sc < 1e-4 and e_lr < 1e-4 and e_mu < 1e-3 and not (differ & ~on_edge & ~sat_tie).any() and not net.range_status()[0]
+            mu_ok = e_mu < 1e-3
+            if not mu_ok and e_mu < 2.5e-3:
+                # a broad softmax on a small map (random heads): two fp32 evaluations differ by ~ 1e-3 px.  The fp64 anchor decides, as in fuzz_resize:
+                # the engine must be inside the gate of IT (seed 9, 23 x 13 and 39 x 6 maps of ResNet-101: engine 8.7e-4 / 3.0e-4, fp32 oracle 3.5e-4 / 8.5e-4)
+                s64, _ = O.pose_heads(O.resnet_features(frames, wts, depth, dtype=np.float64), wts, False)
+                mu64 = O.argmax_2d_from_cm(np.asarray(s64), 1.0, 1, dtype=np.float64)[0].reshape(mu_ref.shape)
+                d_e, d_o = float(np.abs(mu.cpu().numpy() - mu64).max() * 8.0), float(np.abs(mu_ref - mu64).max() * 8.0)
+                mu_ok = d_e < 1e-3
+                print("   fp64 anchor: engine %.1e px, fp32 oracle %.1e px" % (d_e, d_o))
+            ok = e_sc < 1e-4 and e_lr < 1e-4 and mu_ok and not (differ & ~on_edge & ~sat_tie).any() and not net.range_status()[0]
     except Exception as e:      # noqa: BLE001
         ok, e_sc, e_lr, e_mu = False, -1, -1, -1
         print("   exception:", repr(e)[:200])
