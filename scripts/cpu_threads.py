@@ -1,3 +1,4 @@
+"""The CPU oracle's frames/s against torch's thread count (8 ... 128) on the bench workload: how many host threads bench.py's cpu_baseline leg should use."""
 import sys, time, os
 sys.path.insert(0, os.getcwd())
 import torch, numpy as np

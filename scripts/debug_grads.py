@@ -1,3 +1,4 @@
+"""Per-parameter comparison of one training step's gradients: the trainer against the oracle's fp64 and fp32 autograd (the case of tests/test_train_gpu.py)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, "tests")
 import numpy as np, torch

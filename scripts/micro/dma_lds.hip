@@ -1,3 +1,5 @@
+// buffer_load ... lds (LDS-DMA) semantics check: 16 bytes per lane land lane-linearly at the wave's M0 base, an out-of-range lane writes zeros.
+// hipcc --offload-arch=gfx950 -o dma_lds dma_lds.hip && ./dma_lds
 #include <hip/hip_runtime.h>
 typedef __attribute__((address_space(3))) void lds_void;
 __global__ void k(const float* in, int nbytes, float* out) {

@@ -1,3 +1,4 @@
+"""A 2x2 'sub-pixel' conv of the 16-bit tier's heads on H1 tensors against float64 on the same fp16 operands (the merged heads' backward of the trainer)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

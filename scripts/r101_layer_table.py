@@ -1,3 +1,4 @@
+"""Per-launch table of one instrumented ResNet-101 1280x720 pass (20 keypoints, batch 16; BASELINE configs[4]'s per-GPU shape)."""
 import os, sys, collections
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import numpy as np, torch

@@ -1,4 +1,5 @@
 #!/bin/bash
+# the 256-row tile's K loop piece by piece: timing-only -DDGP_X variants of the W64 loop (diagnostic build's stamps); profiles/r6_w64_stamps_ablation.txt
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out/w64
 for v in "$@"; do

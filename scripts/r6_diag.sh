@@ -1,4 +1,5 @@
 #!/bin/bash
+# diagnostic build's stamps of every conv launch of the 16-bit tier, 128-row tile (DGP_W64=0) and 256-row tile (DGP_W64=2)
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out/w64
 for v in 0 2; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+# the round's full verification on one box: pytest -m gpu, __graft_entry__.smoke(), the default bench.py line
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out/r6full
 timeout 2400 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -15 | tee gpurun_out/r6full/pytest.txt

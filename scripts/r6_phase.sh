@@ -1,4 +1,5 @@
 #!/bin/bash
+# raw per-workgroup timelines of every conv launch (DGP_DIAG_DUMP) -> scripts/cu_phase.py: are the two workgroups of a CU in phase?
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out/tl; rm -f gpurun_out/tl/dump_*.txt
 for t in parity f16; do

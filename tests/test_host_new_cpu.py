@@ -220,6 +220,15 @@ def test_readme_numbers_are_generated_from_the_committed_bench_lines():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_scripts_index_is_up_to_date():
+    """scripts/README.md is the output of scripts/index.py (one line per script from its docstring / leading comment): every script says what it is."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "index.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, "run `python scripts/index.py`"
+    assert "(no description)" not in open(os.path.join(root, "scripts", "README.md")).read()
+
+
 def test_resolve_tier_argument_environment_and_rejects(monkeypatch):
     """The one argument the entry points add to the reference's signatures (round 6): None -> DGP_EVAL_TIER -> the library default."""
     from deepgraphpose_amd.models import eval as E
