@@ -449,8 +449,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 //   phase 4   3 x 3 / 2 max over the LDS tile, H2 split with the pool output's scale, two 16-byte stores per 8 channels, range tracking
 // One persistent workgroup per CU (156 KB of LDS) walks the tiles.
 // H1T (round 6; the 16-bit tier's inference pass): TWO workgroups per CU, so that one's GEMM runs under the other's fetch / convert / pool
-// phases.  72 KB each: ONE weight plane (the tier's layers all multiply by the weights' high cells), a 4 x 16 pool tile (9 x 33 conv1
-// pixels, 19 row blocks), and the conv1 tile in LDS as fp16(x * out_scale) -- rounding is monotone, so the maximum of the rounded values
+// phases.  74 KB each: ONE weight plane (the tier's layers all multiply by the weights' high cells), a 3 x 16 pool tile (7 x 33 conv1
+// pixels, 15 row blocks), the input planes in their OWN 11 KB (so a tile needs two barriers -- planes ready, conv1 tile ready -- instead of
+// four) and the conv1 tile in LDS as fp16(x * out_scale) -- rounding is monotone, so the maximum of the rounded values
 // is the rounded maximum: the cells are bit-identical to rounding after the pool.  GEMM column 16 j + l15 holds channel 4 l15 + j, so a
 // lane's four accumulators of a pixel are four consecutive channels = one 8-byte LDS write, and a pool thread reads a cell in one 16-byte
 // read.  The range is tracked on the fp32 values in phase 3 (every conv1 pixel of the map lies in some valid window: the same maximum).
@@ -471,11 +472,16 @@ struct StemPoolArgs {
     int B, H, W, H1, W1, HP, WP, pbh, pbw, tiles_h, tiles_w, ntiles;
 };
 
+#ifndef DGP_STEM_PH
+#define DGP_STEM_PH 5      // pool rows per tile of the parity tier's kernel.  5: the conv1 tile aliases the input planes, four barriers per tile; 4 / 3: own
+                           // buffers, two barriers -- same-box A/B (scripts/r6_stem_ph.sh): 255-261 us at 4 against 256-259 at 5, 297-301 at 3: with ONE workgroup per
+                           // CU the phases are serial either way
+#endif
 template <bool H1T>
 __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolArgs p) {
-    constexpr int PH = H1T ? 4 : 5, PW = 16, SR = 2 * PH + 1, SC = 2 * PW + 1, MS = SR * SC, NRB = (MS + 15) / 16;     // 11, 33, 363, 23 (H1T: 9, 33, 297, 19)
-    constexpr int IR = 2 * SR + 5, IC = 72;                                                                   // 27 x 72 input pixels (H1T: 23 x 72)
-    static_assert(NRB <= 24 && NRB > 16, "two or three row blocks per wave");
+    constexpr int PH = H1T ? 3 : DGP_STEM_PH, PW = 16, SR = 2 * PH + 1, SC = 2 * PW + 1, MS = SR * SC, NRB = (MS + 15) / 16;     // 11, 33, 363, 23 (H1T: 7, 33, 231, 15)
+    constexpr int IR = 2 * SR + 5, IC = 72;                                                                   // 27 x 72 input pixels (H1T: 19 x 72)
+    static_assert(NRB <= 24 && NRB > 8, "one to three row blocks per wave");
     constexpr int NPL = H1T ? 1 : 2;                                                                          // weight planes in LDS
     constexpr int WCELLS = 7 * 4 * NPL * 64;
     constexpr int LDC = 68;                                                                                   // floats per conv1 pixel in LDS
@@ -485,8 +491,9 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
     uint4* sW = reinterpret_cast<uint4*>(smem);
     char* sU = smem + WCELLS * 16;
     uint2* sHi = reinterpret_cast<uint2*>(sU);                     // [IR][IC]
-    float* sC = reinterpret_cast<float*>(sU);                      // [NRB * 16][LDC]   (aliases the planes)
-    _Float16* sCh = reinterpret_cast<_Float16*>(sU);               // H1T: [NRB * 16][LDH]
+    constexpr bool ALIAS = !H1T && PH >= 5;                         // the conv1 tile aliases the planes where both do not fit (5 x 16 tiles of the parity tier)
+    float* sC = reinterpret_cast<float*>(sU + (ALIAS ? 0 : IR * IC * 8));      // [NRB * 16][LDC]
+    _Float16* sCh = reinterpret_cast<_Float16*>(sU + IR * IC * 8); // H1T: [NRB * 16][LDH], BEHIND the planes (not aliased: two barriers per tile instead of four)
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, g = lane >> 4;
     for (int i = t; i < WCELLS; i += 512) {
@@ -495,7 +502,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
     }
     const float post = 1.f / pow2_scale_for(p.w_absmax, lane);
     const float oscale = p.out_prev ? shadow_scale_for(p.out_prev, lane) : p.out_scale;
-    const int nrb = wave < NRB - 16 ? 3 : 2;                       // row blocks wave, wave + 8, wave + 16 (23 blocks: 3 each, wave 7: 2)
+    const int nrb = (NRB - wave + 7) / 8;                          // row blocks wave, wave + 8, wave + 16 below NRB (23 blocks: 3 each, wave 7: 2; H1T, 15: 2 each, wave 7: 1)
     float sc4[4][1], bi4[4][1];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -604,7 +611,8 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
                 }
             }
         }
-        __syncthreads();                                          // every wave is done with the planes: the conv1 tile overwrites them
+        if constexpr (ALIAS) __syncthreads();                     // every wave is done with the planes: the conv1 tile overwrites them (else: its own buffer; the
+                                                                  // barrier behind phase 1 already says that every wave has left the previous tile's pool phase)
         // ---- phase 3: BN + ReLU -> LDS tile
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -700,7 +708,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
                 for (int k = 0; k < 8; ++k) amax = fmaxf(amax, v[k]);
             }
         }
-        __syncthreads();                                          // the next tile's planes overwrite the conv1 tile
+        if constexpr (ALIAS) __syncthreads();                     // the next tile's planes overwrite the conv1 tile
     }
     if (p.out_absmax) track_absmax(p.out_absmax, amax, lane, (int)(blockIdx.x * 8u + (threadIdx.x >> 6)));
 }
@@ -722,9 +730,9 @@ hipError_t launch_stem_pool_fused(const unsigned char* frames, int B, int H, int
     // the two-workgroup variant: the 16-bit tier's inference pass (the trainer's pool records the first maximum of the fp32 values)
     static const int h1t_env = dgp_tune("DGP_STEM_H1T", 1);
     const bool h1t = h1t_env && out_h1 && !idx;
-    const int ph = h1t ? 4 : 5;
+    const int ph = h1t ? 3 : DGP_STEM_PH;
     a.tiles_h = (a.HP + ph - 1) / ph; a.tiles_w = (a.WP + 15) / 16; a.ntiles = B * a.tiles_h * a.tiles_w;
-    const size_t smem = h1t ? (size_t)7 * 4 * 64 * 16 + (size_t)19 * 16 * 72 * 2 : (size_t)7 * 4 * 2 * 64 * 16 + (size_t)23 * 16 * 68 * 4;
+    const size_t smem = h1t ? (size_t)7 * 4 * 64 * 16 + (size_t)19 * 72 * 8 + (size_t)15 * 16 * 72 * 2 : (size_t)7 * 4 * 2 * 64 * 16 + (DGP_STEM_PH >= 5 ? (size_t)23 * 16 * 68 * 4 : (size_t)(4 * DGP_STEM_PH + 7) * 72 * 8 + (size_t)(((2 * DGP_STEM_PH + 1) * 33 + 15) / 16) * 16 * 68 * 4);
     static bool attr_dev[16][2] = {};
     bool& attr = attr_dev[dgp_device_slot()][h1t ? 1 : 0];
     if (!attr) {
