@@ -50,6 +50,53 @@ __device__ __forceinline__ float block_max(float v, double* red) {
     return fmaxf(fmaxf((float)red[0], (float)red[1]), fmaxf((float)red[2], (float)red[3]));
 }
 
+// the same for NW waves (loss_ce_backward runs 16: a marker map is ONE workgroup on the critical path between the forward and the backward pass);
+// `red` is NW doubles, summed in wave order
+template <int NW>
+__device__ __forceinline__ double block_sum_n(double v, double* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wsum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double t = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += red[w];
+    return t;
+}
+// K sums with ONE pair of barriers (red: K x NW doubles); each sum is formed exactly as block_sum_n forms it
+template <int NW, int K>
+__device__ __forceinline__ void block_sums_n(double (&v)[K], double* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = wsum(v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) red[k * NW + wave] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double t = red[k * NW];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) t += red[k * NW + w];
+        v[k] = t;
+    }
+}
+template <int NW>
+__device__ __forceinline__ float block_max_n(float v, double* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wmaxf(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = (double)v;
+    __syncthreads();
+    float t = (float)red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t = fmaxf(t, (float)red[w]);
+    return t;
+}
+
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float ce_logits(float z, float x) {      // tf.nn.sigmoid_cross_entropy_with_logits
     return fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
@@ -267,7 +314,7 @@ __global__ __launch_bounds__(256) void loss_normalisers(LossArgs a) {
         a.norm[1] = a.n_h > 0 ? (float)(a.hidden_scale / (a.n_h * HW)) : 0.f;             // hidden, gm3 = 0
         a.norm[2] = cnt > 0 ? (float)(a.hidden_scale / (cnt * HW)) : 0.f;                 // hidden, gm3 = 3
         a.losses[0] = 0.f; a.losses[1] = 0.f; a.losses[2] = 0.f;
-        a.norm[3] = 0.f;   // locref nonzero count (filled by loss_locref_count)
+        a.norm[3] = 0.f;   // locref nonzero count (published by loss_locref_backward)
     }
 }
 
@@ -281,12 +328,14 @@ __global__ __launch_bounds__(256) void loss_normalisers(LossArgs a) {
 // of and the equality tests stay exact; every output equals what the LDS variant gives (tests force both on one map).  A fallback for
 // frames beyond ~960 x 1280, not a fast path: (2 gauss_len + 1)^2 exps per cell in the blur.
 // ------------------------------------------------------------------------------------------------
+constexpr int LOSS_CE_THREADS = 1024;      // (256 until round 6: 107 us per step for 44 maps of 60 x 80, every pass 19 iterations per thread)
 template <bool LARGE>
-__global__ __launch_bounds__(256) void loss_ce_backward(LossArgs a) {
+__global__ __launch_bounds__(LOSS_CE_THREADS) void loss_ce_backward(LossArgs a) {
+    constexpr int NT = LOSS_CE_THREADS, NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sG = reinterpret_cast<float*>(smem);      // H*W Gaussian bump (later: softmax probabilities)
     float* sq = sG + (LARGE ? 0 : a.H * a.W);        // H*W sigmoid(x)
-    __shared__ double red[8];
+    __shared__ double red[3 * NW];
     __shared__ float gk[16];
     const int m = blockIdx.x, n = m / a.nj, cj = m - n * a.nj;
     const int kind = a.kind[m];
@@ -295,7 +344,7 @@ __global__ __launch_bounds__(256) void loss_ce_backward(LossArgs a) {
     const float* x = a.pred + base;
     float* dx = a.dpred + base;
     if (kind < 0) {       // marker in neither list: no loss term
-        for (int i = threadIdx.x; i < HW; i += 256) dx[(long long)i * a.nj] = 0.f;
+        for (int i = threadIdx.x; i < HW; i += NT) dx[(long long)i * a.nj] = 0.f;
         return;
     }
     const float t0 = a.t_all[2 * m], t1 = a.t_all[2 * m + 1];
@@ -309,25 +358,26 @@ __global__ __launch_bounds__(256) void loss_ce_backward(LossArgs a) {
     auto Gat = [&](int i) -> float { if (!LARGE) return sG[i]; const int h = i / a.W; return loss_gauss_cell((float)h, (float)(i - h * a.W), t0, t1, inv2l2); };
     auto Qat = [&](int i) -> float { return LARGE ? loss_sigmoid_cell(x[(long long)i * a.nj]) : sq[i]; };
     float gmax = -1.f, c = -1.f;
-    for (int i = threadIdx.x; i < HW; i += 256) {
+    for (int i = threadIdx.x; i < HW; i += NT) {
         const int h = i / a.W, w = i - h * a.W;
         const float G = loss_gauss_cell((float)h, (float)w, t0, t1, inv2l2);
         const float q = loss_sigmoid_cell(x[(long long)i * a.nj]);
         if (!LARGE) { sG[i] = G; sq[i] = q; }
         gmax = fmaxf(gmax, G); c = fmaxf(c, q);
     }
-    gmax = block_max(gmax, red);
-    c = block_max(c, red);
-    double ngd = 0, nqd = 0;
-    for (int i = threadIdx.x; i < HW; i += 256) { if (Gat(i) == gmax) ngd += 1; if (Qat(i) == c) nqd += 1; }
-    const float ng = (float)block_sum(ngd, red), nq = (float)block_sum(nqd, red);
+    gmax = block_max_n<NW>(gmax, red);
+    c = block_max_n<NW>(c, red);
+    double ngq[2] = {0, 0};
+    for (int i = threadIdx.x; i < HW; i += NT) { if (Gat(i) == gmax) ngq[0] += 1; if (Qat(i) == c) ngq[1] += 1; }
+    block_sums_n<NW>(ngq, red);
+    const float ng = (float)ngq[0], nq = (float)ngq[1];
     const float gden = gmax + 1e-5f;
     const float A = !hidden ? a.norm[0] : (scaled_logit ? a.norm[2] * (1.f - c) : a.norm[1]);
     const float Araw = !hidden ? a.norm[0] : (scaled_logit ? a.norm[2] : a.norm[1]);
 
     // pass 1: loss value, dL/dc, dL/dGmax accumulators
     double ce_sum = 0, dLdc = 0, dLdgmax = 0;
-    for (int i = threadIdx.x; i < HW; i += 256) {
+    for (int i = threadIdx.x; i < HW; i += NT) {
         const float G = Gat(i), g = G / gden, q = Qat(i);
         const float xi = x[(long long)i * a.nj];
         const float z = scale_target ? g * c : g;
@@ -347,15 +397,17 @@ __global__ __launch_bounds__(256) void loss_ce_backward(LossArgs a) {
         const float dLdg = scale_target ? dLdz * c : dLdz;
         dLdgmax += (double)(-dLdg * G / (gden * gden));
     }
-    ce_sum = block_sum(ce_sum, red);
-    dLdc = block_sum(dLdc, red);
-    dLdgmax = block_sum(dLdgmax, red);
+    {
+        double v3[3] = {ce_sum, dLdc, dLdgmax};
+        block_sums_n<NW>(v3, red);
+        ce_sum = v3[0]; dLdc = v3[1]; dLdgmax = v3[2];
+    }
     if (scaled_logit) dLdc += -(double)Araw * ce_sum;      // d/dc of the (1 - c) weight
     if (threadIdx.x == 0) atomicAdd(&a.losses[hidden ? 1 : 0], (float)((double)A * ce_sum));
 
     // pass 2: dL/dx (direct) and dL/dt
     double gt0 = 0, gt1 = 0;
-    for (int i = threadIdx.x; i < HW; i += 256) {
+    for (int i = threadIdx.x; i < HW; i += NT) {
         const int h = i / a.W, w = i - h * a.W;
         const float dh = (float)h - t0, dw = (float)w - t1;
         const float G = Gat(i), g = G / gden, q = Qat(i);
@@ -389,8 +441,11 @@ __global__ __launch_bounds__(256) void loss_ce_backward(LossArgs a) {
         }
     }
     if (!hidden) return;
-    gt0 = block_sum(gt0, red);
-    gt1 = block_sum(gt1, red);
+    {
+        double v2[2] = {gt0, gt1};
+        block_sums_n<NW>(v2, red);
+        gt0 = v2[0]; gt1 = v2[1];
+    }
     const float g_h = (float)gt0 + a.dLdt[2 * m], g_w = (float)gt1 + a.dLdt[2 * m + 1];
 
     // ---- back through mu = soft-argmax(x): p = softmax(gamma x), b = blur(p), mu = sum b (h,w) / sum b
@@ -402,17 +457,17 @@ __global__ __launch_bounds__(256) void loss_ce_backward(LossArgs a) {
         for (int i = 0; i <= 2 * r; ++i) gk[i] /= sacc;
     }
     float mx = -INFINITY;
-    for (int i = threadIdx.x; i < HW; i += 256) { float v = x[(long long)i * a.nj] * a.gamma; asm volatile("" : "+v"(v)); mx = fmaxf(mx, v); }
-    mx = block_max(mx, red);
+    for (int i = threadIdx.x; i < HW; i += NT) { float v = x[(long long)i * a.nj] * a.gamma; asm volatile("" : "+v"(v)); mx = fmaxf(mx, v); }
+    mx = block_max_n<NW>(mx, red);
     double se = 0;
-    for (int i = threadIdx.x; i < HW; i += 256) { const float e = loss_softmax_cell(x[(long long)i * a.nj], a.gamma, mx); if (!LARGE) sp[i] = e; se += (double)e; }
-    se = block_sum(se, red);
+    for (int i = threadIdx.x; i < HW; i += NT) { const float e = loss_softmax_cell(x[(long long)i * a.nj], a.gamma, mx); if (!LARGE) sp[i] = e; se += (double)e; }
+    se = block_sum_n<NW>(se, red);
     const float den = (float)se;
-    if (!LARGE) for (int i = threadIdx.x; i < HW; i += 256) sp[i] /= den;
+    if (!LARGE) for (int i = threadIdx.x; i < HW; i += NT) sp[i] /= den;
     __syncthreads();
     auto Pat = [&](int i) -> float { return LARGE ? loss_softmax_cell(x[(long long)i * a.nj], a.gamma, mx) / den : sp[i]; };
     double B = 0, Bh = 0, Bw = 0;
-    for (int i = threadIdx.x; i < HW; i += 256) {
+    for (int i = threadIdx.x; i < HW; i += NT) {
         const int h = i / a.W, w = i - h * a.W;
         float bsum = 0.f;
         for (int aa = -r; aa <= r; ++aa) {
@@ -426,7 +481,11 @@ __global__ __launch_bounds__(256) void loss_ce_backward(LossArgs a) {
         }
         B += (double)bsum; Bh += (double)bsum * h; Bw += (double)bsum * w;
     }
-    B = block_sum(B, red); Bh = block_sum(Bh, red); Bw = block_sum(Bw, red);
+    {
+        double v3[3] = {B, Bh, Bw};
+        block_sums_n<NW>(v3, red);
+        B = v3[0]; Bh = v3[1]; Bw = v3[2];
+    }
     const float mu_h = (float)(Bh / B), mu_w = (float)(Bw / B), invB = (float)(1.0 / B);
     // dL/db_i = r_i = (g_h (h - mu_h) + g_w (w - mu_w)) / B inside the map, 0 outside; dL/dp = blur(r)
     auto dLdp = [&](int h, int w) {
@@ -443,9 +502,9 @@ __global__ __launch_bounds__(256) void loss_ce_backward(LossArgs a) {
         return sacc;
     };
     double inner = 0;
-    for (int i = threadIdx.x; i < HW; i += 256) { const int h = i / a.W, w = i - h * a.W; inner += (double)(Pat(i) * dLdp(h, w)); }
-    inner = block_sum(inner, red);
-    for (int i = threadIdx.x; i < HW; i += 256) {
+    for (int i = threadIdx.x; i < HW; i += NT) { const int h = i / a.W, w = i - h * a.W; inner += (double)(Pat(i) * dLdp(h, w)); }
+    inner = block_sum_n<NW>(inner, red);
+    for (int i = threadIdx.x; i < HW; i += NT) {
         const int h = i / a.W, w = i - h * a.W;
         dx[(long long)i * a.nj] += a.gamma * Pat(i) * (dLdp(h, w) - (float)inner);
     }
@@ -455,29 +514,29 @@ __global__ __launch_bounds__(256) void loss_ce_backward(LossArgs a) {
 // locref Huber (k = 1) on visible markers: count of non-zero mask entries, then loss + gradient.
 // One workgroup per visible marker; channel pair (2j, 2j+1) of frame n.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void loss_locref_count(LossArgs a) {
-    __shared__ double red[8];
-    const int m = a.visible_marker[blockIdx.x], n = m / a.nj, cj = m - n * a.nj;
+constexpr int LOSS_LOCREF_THREADS = 1024;
+// (round 6: ONE launch.  The count of non-zero mask entries over all visible markers -- small integers, exact in any order -- is formed by every workgroup
+//  itself instead of by a launch of its own in front; 1024 threads: a marker is one workgroup on the critical path between forward and backward pass)
+__global__ __launch_bounds__(LOSS_LOCREF_THREADS) void loss_locref_backward(LossArgs a) {
+    constexpr int NT = LOSS_LOCREF_THREADS, NW = NT / 64;
+    __shared__ double red[NW];
     const int HW = a.H * a.W;
-    const float* mk = a.locref_mask + (long long)n * HW * 2 * a.nj + 2 * cj;
     double cnt = 0;
-    for (int i = threadIdx.x; i < 2 * HW; i += 256) {
-        const int px = i >> 1, k = i & 1;
-        if (mk[(long long)px * 2 * a.nj + k] != 0.f) cnt += 1;
+    for (int v = 0; v < a.n_v; ++v) {
+        const int mv = a.visible_marker[v], nv = mv / a.nj, cv = mv - nv * a.nj;
+        const float* mk = a.locref_mask + (long long)nv * HW * 2 * a.nj + 2 * cv;
+        for (int i = threadIdx.x; i < 2 * HW; i += NT) {
+            const int px = i >> 1, k = i & 1;
+            if (mk[(long long)px * 2 * a.nj + k] != 0.f) cnt += 1;
+        }
     }
-    cnt = block_sum(cnt, red);
-    if (threadIdx.x == 0) atomicAdd(&a.norm[3], (float)cnt);
-}
-
-__global__ __launch_bounds__(256) void loss_locref_backward(LossArgs a) {
-    __shared__ double red[8];
+    const float nz = (float)block_sum_n<NW>(cnt, red);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.norm[3] = nz;
     const int m = a.visible_marker[blockIdx.x], n = m / a.nj, cj = m - n * a.nj;
-    const int HW = a.H * a.W;
     const long long base = (long long)n * HW * 2 * a.nj + 2 * cj;
-    const float nz = a.norm[3];
     const float wgt = nz > 0.f ? a.locref_weight / nz : 0.f;
     double ls = 0;
-    for (int i = threadIdx.x; i < 2 * HW; i += 256) {
+    for (int i = threadIdx.x; i < 2 * HW; i += NT) {
         const int px = i >> 1, k = i & 1;
         const long long o = base + (long long)px * 2 * a.nj + k;
         const float d = a.locref_pred[o] - a.locref_map[o], mk = a.locref_mask[o];
@@ -488,7 +547,7 @@ __global__ __launch_bounds__(256) void loss_locref_backward(LossArgs a) {
         ls += (double)(el * mk);
         a.dlocref[o] = wgt * mk * de;
     }
-    ls = block_sum(ls, red);
+    ls = block_sum_n<NW>(ls, red);
     if (threadIdx.x == 0) atomicAdd(&a.losses[2], (float)(ls * wgt));
 }
 
@@ -581,7 +640,7 @@ hipError_t launch_loss(const LossArgs& a, hipStream_t s) {
     const size_t smem = (size_t)2 * a.H * a.W * sizeof(float);
     const char* force = getenv("DGP_LOSS_STREAM");            // tests: the streaming variant on a map the LDS variant also takes (read per call)
     if (smem > LOSS_LDS_LIMIT || (force && atoi(force) != 0)) {
-        hipLaunchKernelGGL(loss_ce_backward<true>, dim3(nm), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(loss_ce_backward<true>, dim3(nm), dim3(LOSS_CE_THREADS), 0, s, a);
     } else {
         static bool attr_dev[16] = {};
         bool& attr = attr_dev[dgp_device_slot()];
@@ -591,11 +650,10 @@ hipError_t launch_loss(const LossArgs& a, hipStream_t s) {
             if (e != hipSuccess) return e;
             attr = true;
         }
-        hipLaunchKernelGGL(loss_ce_backward<false>, dim3(nm), dim3(256), smem, s, a);
+        hipLaunchKernelGGL(loss_ce_backward<false>, dim3(nm), dim3(LOSS_CE_THREADS), smem, s, a);
     }
     if (a.n_v > 0) {
-        hipLaunchKernelGGL(loss_locref_count, dim3(a.n_v), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(loss_locref_backward, dim3(a.n_v), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(loss_locref_backward, dim3(a.n_v), dim3(LOSS_LOCREF_THREADS), 0, s, a);
     }
     hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(64), 0, s, a);
     return hipGetLastError();

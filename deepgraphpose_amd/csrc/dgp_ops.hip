@@ -766,8 +766,9 @@ hipError_t launch_stem_pool_fused(const unsigned char* frames, int B, int H, int
 // any size).  The softmax values are then not cached but RECOMPUTED from global memory wherever the blur reads them -- the same
 // expressions on the same inputs, so every output is bit-identical to what the LDS variant would give; (2 r + 1)^2 exps per cell
 // instead of one, a fallback for frames beyond ~1920 x 1280, not a fast path.
+constexpr int SOFT_ARGMAX_THREADS = 1024;      // (256 until round 6: one workgroup per map is a latency chain -- 19 iterations per thread and pass on a 60 x 80 map)
 template <bool LARGE>
-__global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restrict__ scmap, int H, int W, int C,
+__global__ __launch_bounds__(SOFT_ARGMAX_THREADS) void soft_argmax_kernel(const float* __restrict__ scmap, int H, int W, int C,
                                                           float gamma, int glen, float* __restrict__ mu,
                                                           float* __restrict__ conf, int* __restrict__ idx,
                                                           float* __restrict__ pmap, int rs) {
@@ -775,8 +776,9 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
     // into ONE packed [.,5] record (row, col, conf, iy, ix) -- the trajectory layout the RCCL all-gather moves
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sp = reinterpret_cast<float*>(smem);       // H*W
-    __shared__ double red[3][4];
-    __shared__ float redf[4];
+    constexpr int NT = SOFT_ARGMAX_THREADS, NW = NT / 64;
+    __shared__ double red[3][NW];
+    __shared__ float redf[NW];
     __shared__ float gk[16];
 
     const int b = blockIdx.x / C;
@@ -802,7 +804,7 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
     // The empty asm makes the product opaque to the optimiser; it costs no instruction.
     auto scaled = [&](int i) -> float { float v = src[(long long)i * C] * gamma; asm volatile("" : "+v"(v)); return v; };
     float mx = -INFINITY;
-    for (int i = t; i < HW; i += 256) {
+    for (int i = t; i < HW; i += NT) {
         const float v = scaled(i);
         if (!LARGE) sp[i] = v;
         mx = fmaxf(mx, v);
@@ -810,10 +812,12 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
     mx = wave_max(mx);
     if (lane == 0) redf[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    mx = redf[0];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) mx = fmaxf(mx, redf[k]);
 
     double se = 0.0;
-    for (int i = t; i < HW; i += 256) {
+    for (int i = t; i < HW; i += NT) {
         const float e = expf((LARGE ? scaled(i) : sp[i]) - mx);
         if (!LARGE) sp[i] = e;
         se += (double)e;
@@ -821,17 +825,20 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
     se = wave_sum(se);
     if (lane == 0) red[0][wave] = se;
     __syncthreads();
-    const float denom = (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    double dsum = red[0][0];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) dsum += red[0][k];
+    const float denom = (float)dsum;
     __syncthreads();
     if (!LARGE) {
-        for (int i = t; i < HW; i += 256) sp[i] = sp[i] / denom;    // tf.nn.softmax output
+        for (int i = t; i < HW; i += NT) sp[i] = sp[i] / denom;    // tf.nn.softmax output
     }
     __syncthreads();
     auto P = [&](int i) -> float { return LARGE ? expf(scaled(i) - mx) / denom : sp[i]; };
 
     // blur (zero padded) + moments
     double s0 = 0.0, sh = 0.0, sw = 0.0;
-    for (int i = t; i < HW; i += 256) {
+    for (int i = t; i < HW; i += NT) {
         const int h = i / W, w = i - h * W;
         float acc = 0.f;
         for (int a = -r; a <= r; ++a) {
@@ -852,12 +859,12 @@ __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restric
     s0 = wave_sum(s0); sh = wave_sum(sh); sw = wave_sum(sw);
     if (lane == 0) { red[0][wave] = s0; red[1][wave] = sh; red[2][wave] = sw; }
     __syncthreads();
-    const double t0 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    const double th = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    const double tw = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    double t0 = red[0][0], th = red[1][0], tw = red[2][0];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) { t0 += red[0][k]; th += red[1][k]; tw += red[2][k]; }
     if (pmap) {
         const float inv_src = (float)t0;
-        for (int i = t; i < HW; i += 256) {
+        for (int i = t; i < HW; i += NT) {
             const long long o = ((long long)b * HW + i) * C + cj;
             pmap[o] = pmap[o] / inv_src;
         }
@@ -897,7 +904,7 @@ hipError_t launch_soft_argmax(const float* scmap, int B, int H, int W, int C, fl
     const size_t smem = (size_t)H * W * sizeof(float);
     const char* force = getenv("DGP_SOFTARGMAX_STREAM");      // tests: the streaming variant on a map the LDS variant also takes (read per call)
     if (smem > SOFT_ARGMAX_LDS_LIMIT || (force && atoi(force) != 0)) {      // the map does not fit the LDS: streaming variant (same arithmetic, bit-identical)
-        hipLaunchKernelGGL(soft_argmax_kernel<true>, dim3((unsigned)(B * C)), dim3(256), 0, s, scmap, H, W, C, gamma, gauss_len, mu, conf, idx,
+        hipLaunchKernelGGL(soft_argmax_kernel<true>, dim3((unsigned)(B * C)), dim3(SOFT_ARGMAX_THREADS), 0, s, scmap, H, W, C, gamma, gauss_len, mu, conf, idx,
                            pmap, record_stride);
         return hipGetLastError();
     }
@@ -909,7 +916,7 @@ hipError_t launch_soft_argmax(const float* scmap, int B, int H, int W, int C, fl
         if (e != hipSuccess) return e;
         attr_set = smem;
     }
-    hipLaunchKernelGGL(soft_argmax_kernel<false>, dim3((unsigned)(B * C)), dim3(256), smem, s, scmap, H, W, C, gamma,
+    hipLaunchKernelGGL(soft_argmax_kernel<false>, dim3((unsigned)(B * C)), dim3(SOFT_ARGMAX_THREADS), smem, s, scmap, H, W, C, gamma,
                        gauss_len, mu, conf, idx, pmap, record_stride);
     return hipGetLastError();
 }
