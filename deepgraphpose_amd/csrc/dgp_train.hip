@@ -3841,7 +3841,9 @@ int dgp_sgd_momentum_clip(dgp_trainer* tr, float lr, float momentum, float clip_
     hipStream_t s = (hipStream_t)stream;
     const int k = tr->sumsq_k;
     tr->sumsq_k ^= 1;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(tr->n_train)), dim3(256), 0, s, tr->grads, tr->n_train, tr->d_sumsq + k);
+    // (768 workgroups, three per CU: every workgroup ends in ONE fp64 atomic on the same address, and 4 096 of them in a row cost more than the 102 MB read)
+    const int sumsq_grid = grid_for(tr->n_train) < 768 ? grid_for(tr->n_train) : 768;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(sumsq_grid), dim3(256), 0, s, tr->grads, tr->n_train, tr->d_sumsq + k);
     hipLaunchKernelGGL(momentum_kernel, dim3(grid_for(tr->n_train)), dim3(256), 0, s, tr->params, tr->grads, tr->mom, tr->n_train,
                        lr, momentum, clip_norm, tr->d_sumsq + k, tr->d_sumsq + (k ^ 1), tr->d_gnorm, tr->fwd_fast ? tr->d_fast_flag : nullptr);
     TRY_HIP(hipGetLastError());
