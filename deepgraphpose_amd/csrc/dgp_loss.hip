@@ -621,7 +621,8 @@ hipError_t launch_dlc_loss(const DlcLossArgs& a, hipStream_t s) {
     int grid = (int)((n + 255) / 256);
     if (grid > 1024) grid = 1024;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(dlc_loss_reduce, dim3(grid), dim3(256), 0, s, a);
+    // (every workgroup of the reduction ends in four fp64 atomics on four fixed addresses: one workgroup per CU keeps that queue short -- see sumsq_kernel)
+    hipLaunchKernelGGL(dlc_loss_reduce, dim3(grid > 256 ? 256 : grid), dim3(256), 0, s, a);
     hipLaunchKernelGGL(dlc_loss_backward, dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
