@@ -455,6 +455,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // is the rounded maximum: the cells are bit-identical to rounding after the pool.  GEMM column 16 j + l15 holds channel 4 l15 + j, so a
 // lane's four accumulators of a pixel are four consecutive channels = one 8-byte LDS write, and a pool thread reads a cell in one 16-byte
 // read.  The range is tracked on the fp32 values in phase 3 (every conv1 pixel of the map lies in some valid window: the same maximum).
+// The training step's record of each window's first maximum is taken on these fp16 values (two fp32 values that round to one fp16 value tie).
 // ------------------------------------------------------------------------------------
 struct StemPoolArgs {
     const unsigned char* frames;      // [B, H, W, 3] starts fr_delta bytes behind this (4-byte aligned) address
@@ -653,6 +654,18 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
             const int ph = pp / PW, pw = pp - ph * PW;
             if constexpr (H1T) {
                 half8 mx = {0, 0, 0, 0, 0, 0, 0, 0};
+                unsigned kk[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+                if (p.idx) {                  // training step: the first maximum of the tier's OWN (fp16) values, strictly greater as in the fp32 kernel
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) {
+                            const half8 x = *reinterpret_cast<const half8*>(sCh + ((2 * ph + a) * SC + 2 * pw + b) * LDH + 8 * cg);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k)
+                                if (x[k] > mx[k]) { mx[k] = x[k]; kk[k] = (unsigned)(a * 3 + b); }
+                        }
+                } else {
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -660,8 +673,12 @@ __global__ __launch_bounds__(512, 2) void stem_pool_fused_kernel(const StemPoolA
                         if (DGP_SX & 16) { mx[0] = (_Float16)(float)(a + b + q); continue; }
                         mx = __builtin_elementwise_max(mx, *reinterpret_cast<const half8*>(sCh + ((2 * ph + a) * SC + 2 * pw + b) * LDH + 8 * cg));
                     }
+                }
                 if (ph0 + ph < p.HP && pw0 + pw < p.WP) {
                     const size_t cell = (((size_t)n * p.HP + ph0 + ph) * p.WP + pw0 + pw) * 8 + cg;
+                    if (p.idx)
+                        *reinterpret_cast<uint2*>(p.idx + cell * 8) = make_uint2(kk[0] | (kk[1] << 8) | (kk[2] << 16) | (kk[3] << 24),
+                                                                                 kk[4] | (kk[5] << 8) | (kk[6] << 16) | (kk[7] << 24));
                     if (!(DGP_SX & 32)) reinterpret_cast<uint4*>(p.out)[cell] = __builtin_bit_cast(uint4, mx);
                     else amax = fmaxf(amax, (float)mx[0]);
                 }
@@ -729,7 +746,8 @@ hipError_t launch_stem_pool_fused(const unsigned char* frames, int B, int H, int
     a.pbh = pth / 2; a.pbw = ptw / 2;
     // the two-workgroup variant: the 16-bit tier's inference pass (the trainer's pool records the first maximum of the fp32 values)
     static const int h1t_env = dgp_tune("DGP_STEM_H1T", 1);
-    const bool h1t = h1t_env && out_h1 && !idx;
+    static const int h1t_train_env = dgp_tune("DGP_STEM_H1T_TRAIN", 1);
+    const bool h1t = h1t_env && out_h1 && (!idx || h1t_train_env);      // (training: the pool's first-maximum record is taken on the tier's own fp16 values)
     const int ph = h1t ? 3 : DGP_STEM_PH;
     a.tiles_h = (a.HP + ph - 1) / ph; a.tiles_w = (a.WP + 15) / 16; a.ntiles = B * a.tiles_h * a.tiles_w;
     const size_t smem = h1t ? (size_t)7 * 4 * 64 * 16 + (size_t)19 * 72 * 8 + (size_t)15 * 16 * 72 * 2 : (size_t)7 * 4 * 2 * 64 * 16 + (DGP_STEM_PH >= 5 ? (size_t)23 * 16 * 68 * 4 : (size_t)(4 * DGP_STEM_PH + 7) * 72 * 8 + (size_t)(((2 * DGP_STEM_PH + 1) * 33 + 15) / 16) * 16 * 68 * 4);
