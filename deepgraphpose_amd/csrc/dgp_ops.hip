@@ -448,7 +448,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 //             tile to LDS as fp32 (aliases the phase-1 planes)
 //   phase 4   3 x 3 / 2 max over the LDS tile, H2 split with the pool output's scale, two 16-byte stores per 8 channels, range tracking
 // One persistent workgroup per CU (156 KB of LDS) walks the tiles.
-// H1T (round 6; the 16-bit tier's inference pass): TWO workgroups per CU, so that one's GEMM runs under the other's fetch / convert / pool
+// H1T (round 6; the 16-bit tier): TWO workgroups per CU, so that one's GEMM runs under the other's fetch / convert / pool
 // phases.  74 KB each: ONE weight plane (the tier's layers all multiply by the weights' high cells), a 3 x 16 pool tile (7 x 33 conv1
 // pixels, 15 row blocks), the input planes in their OWN 11 KB (so a tile needs two barriers -- planes ready, conv1 tile ready -- instead of
 // four) and the conv1 tile in LDS as fp16(x * out_scale) -- rounding is monotone, so the maximum of the rounded values
